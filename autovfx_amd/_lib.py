@@ -1,0 +1,110 @@
+"""ctypes loader for libgsr_hip.so, the C-ABI rasterizer declared in include/gsr.h.
+
+There is deliberately no fallback: if the shared library is missing or does not export the full
+ABI, importing this module raises, and so does every package that depends on it
+(``diff_gaussian_rasterization``).  Build the library with ``python -m autovfx_amd.build``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("GSR_LIB", os.path.join(_HERE, "lib", "libgsr_hip.so"))
+
+ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+
+# enum mirrors of include/gsr.h
+GEOM_SLOTS = ("depths", "means2D", "conic_opacity", "rgb", "tiles_touched", "internal_radii", "depth_order",
+              "point_offsets")
+BIN_SLOTS = ("point_list", "tile_keys")
+IMG_SLOTS = ("ranges", "n_contrib")
+STAGES = ("preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "ranges", "blend")
+ABI_VERSION = 1
+
+# every symbol include/gsr.h declares
+SYMBOLS = ("gsr_forward", "gsr_mark_visible", "gsr_backward", "gsr_last_geom_offsets", "gsr_last_binning_offsets",
+           "gsr_last_image_offsets", "gsr_set_stage_timing", "gsr_get_stage_times", "gsr_last_error",
+           "gsr_abi_version", "gsr_target_arch")
+
+
+class GsrLibraryError(ImportError):
+    pass
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise GsrLibraryError(
+            f"{LIB_PATH} not found: the HIP rasterizer is not built. Run `python -m autovfx_amd.build` "
+            "(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU fallback.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64.so missing
+        raise GsrLibraryError(f"could not load {LIB_PATH}: {e}") from e
+    missing = [s for s in SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise GsrLibraryError(f"{LIB_PATH} does not export {missing}; rebuild it")
+
+    c_f = ctypes.c_void_p  # device float* / int* travel as integers (tensor.data_ptr())
+    lib.gsr_forward.restype = ctypes.c_int
+    lib.gsr_forward.argtypes = [
+        ALLOC_FN, ctypes.c_void_p, ALLOC_FN, ctypes.c_void_p, ALLOC_FN, ctypes.c_void_p,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int,            # P D M
+        c_f, ctypes.c_int, ctypes.c_int,                     # background width height
+        c_f, c_f, c_f, c_f, c_f, ctypes.c_float, c_f, c_f,   # means3D shs colors opacities scales mod rotations cov3D
+        c_f, c_f, c_f, ctypes.c_float, ctypes.c_float, ctypes.c_int,  # view proj campos tanx tany prefiltered
+        c_f, c_f, c_f, c_f, ctypes.c_int, ctypes.c_void_p]   # out_color out_depth out_alpha radii debug stream
+    lib.gsr_mark_visible.restype = ctypes.c_int
+    lib.gsr_mark_visible.argtypes = [ctypes.c_int, c_f, c_f, c_f, c_f, ctypes.c_void_p]
+    lib.gsr_backward.restype = ctypes.c_int
+    lib.gsr_backward.argtypes = []
+    for name, n in (("gsr_last_geom_offsets", len(GEOM_SLOTS)), ("gsr_last_binning_offsets", len(BIN_SLOTS)),
+                    ("gsr_last_image_offsets", len(IMG_SLOTS))):
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.POINTER(ctypes.c_size_t * n)]
+    lib.gsr_set_stage_timing.restype = None
+    lib.gsr_set_stage_timing.argtypes = [ctypes.c_int]
+    lib.gsr_get_stage_times.restype = ctypes.c_int
+    lib.gsr_get_stage_times.argtypes = [ctypes.POINTER(ctypes.c_float * len(STAGES))]
+    lib.gsr_last_error.restype = ctypes.c_char_p
+    lib.gsr_last_error.argtypes = []
+    lib.gsr_abi_version.restype = ctypes.c_int
+    lib.gsr_abi_version.argtypes = []
+    lib.gsr_target_arch.restype = ctypes.c_char_p
+    lib.gsr_target_arch.argtypes = []
+    if lib.gsr_abi_version() != ABI_VERSION:
+        raise GsrLibraryError(f"{LIB_PATH} has ABI {lib.gsr_abi_version()}, this binding expects {ABI_VERSION}")
+    return lib
+
+
+lib = _load()
+
+
+def last_error() -> str:
+    return lib.gsr_last_error().decode("utf-8", "replace")
+
+
+def offsets(kind: str) -> dict:
+    names, fn = {"geom": (GEOM_SLOTS, lib.gsr_last_geom_offsets), "binning": (BIN_SLOTS, lib.gsr_last_binning_offsets),
+                 "image": (IMG_SLOTS, lib.gsr_last_image_offsets)}[kind]
+    arr = (ctypes.c_size_t * len(names))()
+    if fn(ctypes.byref(arr)) != 0:
+        raise RuntimeError(last_error())
+    return dict(zip(names, (int(v) for v in arr)))
+
+
+def set_stage_timing(enable: bool) -> None:
+    lib.gsr_set_stage_timing(1 if enable else 0)
+
+
+def stage_times_ms() -> dict:
+    """Mean per-stage milliseconds over the calls since ``set_stage_timing(True)``; key ``calls``
+    holds how many calls were averaged."""
+    arr = (ctypes.c_float * len(STAGES))()
+    n = lib.gsr_get_stage_times(ctypes.byref(arr))
+    if n < 0:
+        raise RuntimeError(last_error())
+    out = dict(zip(STAGES, (float(v) for v in arr)))
+    out["calls"] = int(n)
+    return out

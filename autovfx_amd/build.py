@@ -1,0 +1,65 @@
+"""Builds libgsr_hip.so (the C-ABI rasterizer, include/gsr.h) for gfx950 with hipcc.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so is
+git-ignored but travels to the GPU box with the repo snapshot.  Usage: ``python -m autovfx_amd.build``.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "lib")
+LIB = os.path.join(OUT_DIR, "libgsr_hip.so")
+SOURCES = ["gsr_kernels.hip", "gsr_sort.hip", "gsr_api.hip"]
+HEADERS = [os.path.join(CSRC, "gsr_internal.h"), os.path.join(HERE, "..", "include", "gsr.h")]
+# -ffp-contract=off: the parity contract is fp32 in the reference's operation order;
+# no -ffast-math: IEEE divide / sqrt, accurate expf.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
+         "-Wno-unused-result", "-fvisibility=hidden", "-DNDEBUG"]
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OUT_DIR, exist_ok=True)
+    cc = hipcc()
+    objs, jobs = [], []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(OUT_DIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [sp] + HEADERS + [__file__]):
+            jobs.append([cc, "-x", "hip", *FLAGS, "-c", sp, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or _stale(LIB, objs):
+        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs,
+             "-Wl,--exclude-libs,ALL"])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

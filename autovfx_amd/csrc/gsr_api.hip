@@ -1,0 +1,324 @@
+// gsr_api.hip -- the C ABI (include/gsr.h) and the host orchestration of one forward call.
+//
+// Mirrors what CudaRasterizer::Rasterizer::forward does on the host
+// (DGR/cuda_rasterizer/rasterizer_impl.cu:197-339): carve scratch out of caller-provided arenas
+// (rasterizer_impl.h:22-27,66-72), run the stages, read num_rendered back once to size the binning
+// arena (:282), return it.  The stage list itself is this library's own (see gsr_sort.hip).
+#include "../../include/gsr.h"
+#include "gsr_internal.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace {
+
+thread_local char g_error[512] = "";
+thread_local size_t g_geom_off[GSR_GEOM_NUM_SLOTS];
+thread_local size_t g_bin_off[GSR_BIN_NUM_SLOTS];
+thread_local size_t g_img_off[GSR_IMG_NUM_SLOTS];
+thread_local bool g_have_offsets = false;
+
+// Stage timing: a ring of event sets so a whole timed region can be averaged afterwards without
+// synchronising between calls.
+constexpr int kTimingRing = 256;
+constexpr int kEventsPerCall = GSR_STAGE_NUM + 1;
+bool g_timing = false;
+thread_local hipEvent_t g_ev[kTimingRing][kEventsPerCall];
+thread_local bool g_ev_made = false;
+thread_local long g_timed_calls = 0;   // completed timed calls since timing was (re)enabled
+thread_local int g_slot = 0;           // ring slot of the call in progress
+
+int fail(gsr_status code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+    return (int)code;
+}
+
+#define GSR_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(GSR_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+// After each stage in debug mode: the CHECK_CUDA of auxiliary.h:166-173.
+#define GSR_STAGE_CHECK(name)                                                                  \
+    do {                                                                                       \
+        if (debug) {                                                                           \
+            hipError_t e_ = hipStreamSynchronize(stream);                                      \
+            if (e_ != hipSuccess)                                                              \
+                return fail(GSR_ERR_HIP, "stage %s failed: %s", name, hipGetErrorString(e_)); \
+        }                                                                                      \
+    } while (0)
+
+// Bump carver over a caller arena; every sub-array starts on a 256-byte boundary *relative to the
+// arena base* so layouts are reproducible, and the arena is requested with 256 bytes of slack so
+// the base itself can be rounded up.
+struct Carver {
+    size_t off = 0;
+    template <typename T>
+    size_t take(size_t count) {
+        off = (off + 255) & ~size_t(255);
+        const size_t at = off;
+        off += count * sizeof(T);
+        return at;
+    }
+    size_t total() const { return ((off + 255) & ~size_t(255)) + 256; }
+};
+
+char* align_base(char* p) {
+    return reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 255) & ~uintptr_t(255));
+}
+
+// Bits of tile id to sort on: position of the highest set bit of T, plus one
+// (rasterizer_impl.cu:35-50 getHigherMsb restated as a plain loop).
+int tile_key_bits(uint32_t num_tiles) {
+    int b = 0;
+    while (b < 32 && (num_tiles >> b) != 0) ++b;
+    return b;  // bit_length(T) >= bit_length(T - 1): every tile id fits
+}
+
+struct Pinned {
+    uint32_t* host = nullptr;  // 64 pinned bytes per calling thread, deliberately never freed:
+};                             // freeing at thread exit can race HIP runtime teardown
+thread_local Pinned g_pinned;
+
+void stamp(int idx, hipStream_t s) {
+    if (!g_timing) return;
+    (void)hipEventRecord(g_ev[g_slot][idx], s);
+}
+
+} // namespace
+
+extern "C" {
+
+const char* gsr_last_error(void) { return g_error; }
+int gsr_abi_version(void) { return GSR_ABI_VERSION; }
+const char* gsr_target_arch(void) { return "gfx950"; }
+int gsr_backward(void) { return fail(GSR_ERR_UNSUPPORTED, "gsr_backward is not built yet (SURVEY.md 8f-1)"); }
+
+void gsr_set_stage_timing(int enable) {
+    g_timing = enable != 0;
+    g_timed_calls = 0;
+}
+
+int gsr_get_stage_times(float ms[GSR_STAGE_NUM]) {
+    for (int i = 0; i < GSR_STAGE_NUM; ++i) ms[i] = 0.f;
+    if (g_timed_calls <= 0) return fail(GSR_ERR_INVALID_ARG, "no timed gsr_forward call on this thread");
+    const int ncalls = (int)(g_timed_calls < kTimingRing ? g_timed_calls : kTimingRing);
+    double sum[GSR_STAGE_NUM] = {0};
+    for (int c = 0; c < ncalls; ++c) {
+        const int slot = (int)((g_timed_calls - 1 - c) % kTimingRing);
+        GSR_HIP(hipEventSynchronize(g_ev[slot][kEventsPerCall - 1]));
+        for (int i = 0; i < GSR_STAGE_NUM; ++i) {
+            float t = 0.f;
+            GSR_HIP(hipEventElapsedTime(&t, g_ev[slot][i], g_ev[slot][i + 1]));
+            sum[i] += t;
+        }
+    }
+    for (int i = 0; i < GSR_STAGE_NUM; ++i) ms[i] = (float)(sum[i] / ncalls);
+    return ncalls;
+}
+
+int gsr_last_geom_offsets(size_t o[GSR_GEOM_NUM_SLOTS]) {
+    if (!g_have_offsets) return fail(GSR_ERR_INVALID_ARG, "no gsr_forward call on this thread");
+    memcpy(o, g_geom_off, sizeof g_geom_off);
+    return GSR_OK;
+}
+int gsr_last_binning_offsets(size_t o[GSR_BIN_NUM_SLOTS]) {
+    if (!g_have_offsets) return fail(GSR_ERR_INVALID_ARG, "no gsr_forward call on this thread");
+    memcpy(o, g_bin_off, sizeof g_bin_off);
+    return GSR_OK;
+}
+int gsr_last_image_offsets(size_t o[GSR_IMG_NUM_SLOTS]) {
+    if (!g_have_offsets) return fail(GSR_ERR_INVALID_ARG, "no gsr_forward call on this thread");
+    memcpy(o, g_img_off, sizeof g_img_off);
+    return GSR_OK;
+}
+
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, void* stream_) {
+    (void)projmatrix;  // the reference passes it but only the view-space depth test is live (auxiliary.h:154)
+    if (P < 0) return fail(GSR_ERR_INVALID_ARG, "P < 0");
+    if (P == 0) return GSR_OK;
+    if (!means3D || !viewmatrix || !present) return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    GSR_HIP(gsr::launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream_));
+    return GSR_OK;
+}
+
+int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_alloc, void* binning_user,
+                gsr_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background,
+                int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
+                const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                float* out_depth, float* out_alpha, int* radii, int debug, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P < 0 || width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARG, "bad sizes P=%d W=%d H=%d", P, width, height);
+    if (P == 0) return 0;  // rasterize_points.cu:83: outputs stay as the binding zero-filled them
+    if (!geom_alloc || !binning_alloc || !image_alloc) return fail(GSR_ERR_INVALID_ARG, "null scratch callback");
+    if (!means3D || !opacities || !background || !viewmatrix || !projmatrix || !cam_pos || !out_color ||
+        !out_depth || !out_alpha)
+        return fail(GSR_ERR_INVALID_ARG, "null required pointer");
+    if ((shs == nullptr) == (colors_precomp == nullptr))
+        return fail(GSR_ERR_INVALID_ARG, "provide exactly one of shs / colors_precomp");
+    const bool have_sr = scales != nullptr && rotations != nullptr;
+    if ((scales != nullptr) != (rotations != nullptr) || have_sr == (cov3D_precomp != nullptr))
+        return fail(GSR_ERR_INVALID_ARG, "provide exactly one of (scales, rotations) / cov3D_precomp");
+    if (shs != nullptr && M <= 0) return fail(GSR_ERR_INVALID_ARG, "shs given with M=%d", M);
+
+    gsr::Camera cam;
+    cam.viewmatrix = viewmatrix;
+    cam.projmatrix = projmatrix;
+    cam.cam_pos = cam_pos;
+    cam.tan_fovx = tan_fovx;
+    cam.tan_fovy = tan_fovy;
+    cam.focal_y = height / (2.0f * tan_fovy);  // rasterizer_impl.cu:223-224
+    cam.focal_x = width / (2.0f * tan_fovx);
+    cam.width = width;
+    cam.height = height;
+    cam.grid_x = (width + gsr::kTile - 1) / gsr::kTile;
+    cam.grid_y = (height + gsr::kTile - 1) / gsr::kTile;
+    if (cam.grid_x > 65535 || cam.grid_y > 65535) return fail(GSR_ERR_INVALID_ARG, "image too large");
+    const int T = cam.grid_x * cam.grid_y;
+    const size_t n = (size_t)P;
+
+    if (g_timing && !g_ev_made) {
+        for (auto& set : g_ev)
+            for (auto& e : set) GSR_HIP(hipEventCreate(&e));
+        g_ev_made = true;
+    }
+    g_slot = (int)(g_timed_calls % kTimingRing);
+    if (!g_pinned.host) GSR_HIP(hipHostMalloc((void**)&g_pinned.host, 64, hipHostMallocPortable));
+
+    // ---- geometry arena ----
+    size_t sort_tmp = 0, scan_tmp = 0;
+    GSR_HIP(gsr::depth_sort_temp_bytes(P, &sort_tmp));
+    GSR_HIP(gsr::scan_temp_bytes(P, &scan_tmp));
+    Carver gc;
+    g_geom_off[GSR_GEOM_DEPTHS] = gc.take<float>(n);
+    g_geom_off[GSR_GEOM_MEANS2D] = gc.take<float2>(n);
+    g_geom_off[GSR_GEOM_CONIC_OPACITY] = gc.take<float4>(n);
+    g_geom_off[GSR_GEOM_RGB] = gc.take<float>(3 * n);
+    g_geom_off[GSR_GEOM_TILES_TOUCHED] = gc.take<uint32_t>(n);
+    g_geom_off[GSR_GEOM_INTERNAL_RADII] = gc.take<int>(n);
+    const size_t off_keys_a = gc.take<uint32_t>(n), off_keys_b = gc.take<uint32_t>(n);
+    const size_t off_ids_a = gc.take<uint32_t>(n), off_ids_b = gc.take<uint32_t>(n);
+    g_geom_off[GSR_GEOM_POINT_OFFSETS] = gc.take<uint32_t>(n);
+    const size_t off_flag = gc.take<uint32_t>(16);
+    const size_t off_tmp = gc.take<char>(sort_tmp > scan_tmp ? sort_tmp : scan_tmp);
+    char* graw = geom_alloc(gc.total(), geom_user);
+    if (!graw) return fail(GSR_ERR_ALLOC, "geometry scratch callback returned NULL for %zu bytes", gc.total());
+    char* gbase = align_base(graw);
+    const size_t gshift = (size_t)(gbase - graw);
+
+    // ---- image arena ----
+    Carver ic;
+    g_img_off[GSR_IMG_RANGES] = ic.take<uint2>((size_t)T);
+    g_img_off[GSR_IMG_N_CONTRIB] = ic.take<uint32_t>((size_t)width * height);
+    char* iraw = image_alloc(ic.total(), image_user);
+    if (!iraw) return fail(GSR_ERR_ALLOC, "image scratch callback returned NULL for %zu bytes", ic.total());
+    char* ibase = align_base(iraw);
+    for (auto& o : g_img_off) o += (size_t)(ibase - iraw);
+
+    gsr::GaussianInputs in;
+    in.P = P; in.sh_degree = D; in.M = M;
+    in.means3D = means3D; in.scales = scales; in.rotations = rotations; in.cov3D_precomp = cov3D_precomp;
+    in.opacities = opacities; in.shs = shs; in.colors_precomp = colors_precomp;
+    in.scale_modifier = scale_modifier; in.prefiltered = prefiltered;
+
+    gsr::GeometryArrays ga;
+    ga.depths = (float*)(gbase + g_geom_off[GSR_GEOM_DEPTHS]);
+    ga.means2D = (float2*)(gbase + g_geom_off[GSR_GEOM_MEANS2D]);
+    ga.conic_opacity = (float4*)(gbase + g_geom_off[GSR_GEOM_CONIC_OPACITY]);
+    ga.rgb = (float*)(gbase + g_geom_off[GSR_GEOM_RGB]);
+    ga.tiles_touched = (uint32_t*)(gbase + g_geom_off[GSR_GEOM_TILES_TOUCHED]);
+    ga.radii = radii ? radii : (int*)(gbase + g_geom_off[GSR_GEOM_INTERNAL_RADII]);
+    ga.depth_keys = (uint32_t*)(gbase + off_keys_a);
+    ga.ids = (uint32_t*)(gbase + off_ids_a);
+    ga.error_flag = (uint32_t*)(gbase + off_flag);
+    uint32_t* point_offsets = (uint32_t*)(gbase + g_geom_off[GSR_GEOM_POINT_OFFSETS]);
+    void* tmp = gbase + off_tmp;
+    const size_t tmp_bytes = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
+
+    if (prefiltered) GSR_HIP(hipMemsetAsync(ga.error_flag, 0, sizeof(uint32_t), stream));
+    stamp(0, stream);
+    GSR_HIP(gsr::launch_preprocess(in, cam, ga, stream));
+    GSR_STAGE_CHECK("preprocess");
+    stamp(1, stream);
+
+    uint32_t *keys_sorted = nullptr, *order = nullptr;
+    GSR_HIP(gsr::depth_sort(tmp, tmp_bytes, P, ga.depth_keys, (uint32_t*)(gbase + off_keys_b), ga.ids,
+                            (uint32_t*)(gbase + off_ids_b), &keys_sorted, &order, stream));
+    GSR_STAGE_CHECK("depth_sort");
+    stamp(2, stream);
+    g_geom_off[GSR_GEOM_DEPTH_ORDER] = (size_t)((char*)order - gbase);
+
+    GSR_HIP(gsr::scan_tiles_in_order(tmp, tmp_bytes, P, ga.tiles_touched, order, point_offsets, stream));
+    // The one host round trip of the call (rasterizer_impl.cu:282): num_rendered sizes the binning arena.
+    GSR_HIP(hipMemcpyAsync(g_pinned.host, point_offsets + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    g_pinned.host[1] = 0;
+    if (prefiltered)
+        GSR_HIP(hipMemcpyAsync(g_pinned.host + 1, ga.error_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GSR_HIP(hipStreamSynchronize(stream));
+    const uint32_t num_rendered = g_pinned.host[0];
+    if (debug && prefiltered && (g_pinned.host[1] & 1u))
+        return fail(GSR_ERR_PREFILTERED, "a Gaussian was culled although prefiltered is set (auxiliary.h:156-160)");
+    if (num_rendered > 0x7FFFFFFFu) return fail(GSR_ERR_INVALID_ARG, "num_rendered %u overflows int", num_rendered);
+    stamp(3, stream);
+    for (auto& o : g_geom_off) o += gshift;
+
+    // ---- binning arena ----
+    const size_t nr = num_rendered ? num_rendered : 1;
+    size_t tsort_tmp = 0;
+    GSR_HIP(gsr::tile_sort_temp_bytes((uint32_t)nr, &tsort_tmp));
+    Carver bc;
+    const size_t off_tk_a = bc.take<uint32_t>(nr), off_tk_b = bc.take<uint32_t>(nr);
+    const size_t off_pl_a = bc.take<uint32_t>(nr), off_pl_b = bc.take<uint32_t>(nr);
+    const size_t off_btmp = bc.take<char>(tsort_tmp);
+    char* braw = binning_alloc(bc.total(), binning_user);
+    if (!braw) return fail(GSR_ERR_ALLOC, "binning scratch callback returned NULL for %zu bytes", bc.total());
+    char* bbase = align_base(braw);
+    uint32_t *tile_keys = (uint32_t*)(bbase + off_tk_a), *point_list = (uint32_t*)(bbase + off_pl_a);
+
+    uint2* ranges = (uint2*)(iraw + g_img_off[GSR_IMG_RANGES]);
+    uint32_t* n_contrib = (uint32_t*)(iraw + g_img_off[GSR_IMG_N_CONTRIB]);
+
+    if (num_rendered > 0) {
+        GSR_HIP(gsr::launch_duplicate(P, cam, order, point_offsets, ga.means2D, ga.radii, tile_keys, point_list, stream));
+        GSR_STAGE_CHECK("duplicate");
+        stamp(4, stream);
+        uint32_t *tk_sorted = nullptr, *pl_sorted = nullptr;
+        GSR_HIP(gsr::tile_sort(bbase + off_btmp, tsort_tmp, num_rendered, tile_key_bits((uint32_t)T), tile_keys,
+                               (uint32_t*)(bbase + off_tk_b), point_list, (uint32_t*)(bbase + off_pl_b),
+                               &tk_sorted, &pl_sorted, stream));
+        GSR_STAGE_CHECK("tile_sort");
+        stamp(5, stream);
+        tile_keys = tk_sorted;
+        point_list = pl_sorted;
+        GSR_HIP(gsr::launch_tile_ranges(num_rendered, T, tile_keys, ranges, stream));
+    } else {
+        stamp(4, stream);
+        stamp(5, stream);
+        GSR_HIP(hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), stream));  // rasterizer_impl.cu:311
+    }
+    GSR_STAGE_CHECK("tile_ranges");
+    stamp(6, stream);
+    g_bin_off[GSR_BIN_POINT_LIST] = (size_t)((char*)point_list - braw);
+    g_bin_off[GSR_BIN_TILE_KEYS] = (size_t)((char*)tile_keys - braw);
+
+    const float* features = colors_precomp != nullptr ? colors_precomp : ga.rgb;
+    GSR_HIP(gsr::launch_blend(cam, ranges, point_list, ga.means2D, features, ga.depths, ga.conic_opacity, background,
+                              out_color, out_depth, out_alpha, n_contrib, stream));
+    GSR_STAGE_CHECK("blend");
+    stamp(7, stream);
+    if (g_timing) ++g_timed_calls;
+    g_have_offsets = true;
+    return (int)num_rendered;
+}
+
+} // extern "C"

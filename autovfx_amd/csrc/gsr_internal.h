@@ -1,0 +1,78 @@
+// gsr_internal.h -- declarations shared by the translation units of libgsr_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace gsr {
+
+constexpr int kTile = 16;                    // tile edge in pixels; part of the result
+constexpr uint32_t kCulledKey = 0xFFFFFFFFu; // depth key of a Gaussian that produces no pairs
+
+struct Camera {
+    const float* viewmatrix;  // 16 floats, transposed w2c
+    const float* projmatrix;  // 16 floats, transposed full projection
+    const float* cam_pos;     // 3 floats
+    float tan_fovx, tan_fovy, focal_x, focal_y;
+    int width, height, grid_x, grid_y;
+};
+
+struct GaussianInputs {
+    int P, sh_degree, M;
+    const float* means3D;
+    const float* scales;         // nullable
+    const float* rotations;      // nullable
+    const float* cov3D_precomp;  // nullable
+    const float* opacities;
+    const float* shs;            // nullable
+    const float* colors_precomp; // nullable
+    float scale_modifier;
+    int prefiltered;
+};
+
+struct GeometryArrays {
+    float* depths;
+    float2* means2D;
+    float4* conic_opacity;
+    float* rgb;
+    uint32_t* tiles_touched;
+    int* radii;           // caller's radii or the internal array
+    uint32_t* depth_keys; // sort keys (float bits of depth, kCulledKey if culled)
+    uint32_t* ids;        // 0..P-1, the sort payload
+    uint32_t* error_flag; // device word: bit 0 = prefiltered violation
+};
+
+// ---- kernels (gsr_kernels.hip) ----
+hipError_t launch_preprocess(const GaussianInputs& in, const Camera& cam, const GeometryArrays& out,
+                             hipStream_t stream);
+hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
+                               hipStream_t stream);
+hipError_t launch_duplicate(int P, const Camera& cam, const uint32_t* depth_order, const uint32_t* point_offsets,
+                            const float2* means2D, const int* radii, uint32_t* tile_keys, uint32_t* point_list,
+                            hipStream_t stream);
+hipError_t launch_tile_ranges(uint32_t num_rendered, int num_tiles, const uint32_t* sorted_tile_keys,
+                              uint2* ranges, hipStream_t stream);
+hipError_t launch_blend(const Camera& cam, const uint2* ranges, const uint32_t* point_list, const float2* means2D,
+                        const float* features, const float* depths, const float4* conic_opacity,
+                        const float* background, float* out_color, float* out_depth, float* out_alpha,
+                        uint32_t* n_contrib, hipStream_t stream);
+
+// ---- device-wide primitives (gsr_sort.hip) ----
+// All three follow the two-call protocol: with temp == nullptr they only report temp_bytes.
+hipError_t depth_sort_temp_bytes(int P, size_t* temp_bytes);
+// Stable ascending sort of (depth_keys, ids) over all 32 key bits.  Buffers *_alt are the ping-pong
+// partners; on return *keys_sorted / *ids_sorted point at whichever buffer holds the result.
+hipError_t depth_sort(void* temp, size_t temp_bytes, int P, uint32_t* keys, uint32_t* keys_alt, uint32_t* ids,
+                      uint32_t* ids_alt, uint32_t** keys_sorted, uint32_t** ids_sorted, hipStream_t stream);
+hipError_t scan_temp_bytes(int P, size_t* temp_bytes);
+// offsets[k] = sum_{j<=k} tiles_touched[order[j]]
+hipError_t scan_tiles_in_order(void* temp, size_t temp_bytes, int P, const uint32_t* tiles_touched,
+                               const uint32_t* order, uint32_t* offsets, hipStream_t stream);
+hipError_t tile_sort_temp_bytes(uint32_t n, size_t* temp_bytes);
+// Stable ascending sort of (tile_keys, point_list) on the low `bits` key bits.
+hipError_t tile_sort(void* temp, size_t temp_bytes, uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt,
+                     uint32_t* vals, uint32_t* vals_alt, uint32_t** keys_sorted, uint32_t** vals_sorted,
+                     hipStream_t stream);
+
+} // namespace gsr

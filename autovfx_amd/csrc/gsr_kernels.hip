@@ -1,0 +1,525 @@
+// gsr_kernels.hip -- hand-written CDNA4 (gfx950, wave64) kernels of the forward rasterizer.
+//
+// What each kernel replaces in the reference (DGR = sugar/gaussian_splatting/submodules/
+// diff-gaussian-rasterization, under /root/reference):
+//   preprocess_kernel   <- preprocessCUDA       DGR/cuda_rasterizer/forward.cu:155-256
+//                          (+ in_frustum auxiliary.h:139-164, computeCov3D forward.cu:118-152,
+//                           computeCov2D forward.cu:74-113, getRect auxiliary.h:46-56,
+//                           ndc2Pix auxiliary.h:41-44, computeColorFromSH forward.cu:20-71)
+//   mark_visible_kernel <- checkFrustum         DGR/cuda_rasterizer/rasterizer_impl.cu:54-66
+//   duplicate_kernel    <- duplicateWithKeys    DGR/cuda_rasterizer/rasterizer_impl.cu:70-111
+//   tile_ranges_kernel  <- identifyTileRanges   DGR/cuda_rasterizer/rasterizer_impl.cu:116-138
+//   blend_kernel        <- renderCUDA           DGR/cuda_rasterizer/forward.cu:261-378
+//
+// Results are the reference's: fp32 in the reference's operation order,
+// built with -ffp-contract=off so nothing is fused behind our back.  The *structure* is not the
+// reference's:
+//   * the (tile, depth) order is produced by a 32-bit depth sort of Gaussians followed by a
+//     stable tile-id sort of the expanded pairs, so the duplicate kernel walks Gaussians in depth
+//     order and emits 32-bit tile keys (the reference sorts 64-bit keys once);
+//   * pair expansion is wave-cooperative: 64 lanes share the flattened pair range of their 64
+//     Gaussians (prefix sums + lane binary search through ds_bpermute), so writes are coalesced
+//     and a screen-filling splat does not serialise one lane;
+//   * tile ranges come from two binary searches per tile over the sorted tile keys (no memset,
+//     no pass over all pairs);
+//   * one wave64 blends one 16x16 tile, each lane owning a 2x2 pixel quad: no workgroup barriers,
+//     wave-exact early exit, per-entry LDS broadcast reads amortised over 4 pixels, and an exact
+//     pre-test that skips expf for pairs that cannot reach alpha >= 1/255.
+#include "gsr_internal.h"
+
+namespace gsr {
+namespace {
+
+// 4-byte aligned aggregates: the compiler may still fuse them into dwordx3/x4 accesses, but no
+// 16-byte alignment is assumed of caller tensors.
+struct __attribute__((aligned(4))) F3 { float x, y, z; };
+struct __attribute__((aligned(4))) F4 { float x, y, z, w; };
+
+struct Mat3 { float m[3][3]; };  // m[row][col]
+
+// k = 0,1,2 summed left to right: glm's mat3 * mat3 (type_mat3x3.inl:486-518) in math notation.
+__device__ __forceinline__ Mat3 mul3(const Mat3& a, const Mat3& b) {
+    Mat3 r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            r.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j];
+    return r;
+}
+__device__ __forceinline__ Mat3 transpose3(const Mat3& a) {
+    Mat3 r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r.m[i][j] = a.m[j][i];
+    return r;
+}
+
+// float -> int, round toward zero, saturating, NaN -> 0 (what the GPU conversion does; spelled
+// out so host oracle and device agree by construction).
+__device__ __forceinline__ int f2i_sat(float v) {
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)v;
+}
+
+__device__ __forceinline__ float ndc_to_pix(float v, int S) {
+    return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5);  // auxiliary.h:41-44 is double math
+}
+
+struct TileRect { int x0, y0, x1, y1; };
+
+__device__ __forceinline__ TileRect tile_rect(float px, float py, int radius, int gx, int gy) {
+    TileRect r;
+    r.x0 = min(gx, max(0, f2i_sat((px - radius) / kTile)));
+    r.y0 = min(gy, max(0, f2i_sat((py - radius) / kTile)));
+    r.x1 = min(gx, max(0, f2i_sat((px + radius + kTile - 1) / kTile)));
+    r.y1 = min(gy, max(0, f2i_sat((py + radius + kTile - 1) / kTile)));
+    return r;
+}
+
+// SH basis constants (auxiliary.h:22-39).
+constexpr float kSH0 = 0.28209479177387814f;
+constexpr float kSH1 = 0.4886025119029199f;
+constexpr float kSH2_0 = 1.0925484305920792f, kSH2_1 = -1.0925484305920792f, kSH2_2 = 0.31539156525252005f,
+                kSH2_3 = -1.0925484305920792f, kSH2_4 = 0.5462742152960396f;
+constexpr float kSH3_0 = -0.5900435899266435f, kSH3_1 = 2.890611442640554f, kSH3_2 = -0.4570457994644658f,
+                kSH3_3 = 0.3731763325901154f, kSH3_4 = -0.4570457994644658f, kSH3_5 = 1.445305721320277f,
+                kSH3_6 = -0.5900435899266435f;
+
+__device__ __forceinline__ F3 ld3(const float* p) { return *reinterpret_cast<const F3*>(p); }
+__device__ __forceinline__ F3 axpy(F3 acc, float s, F3 v) {  // acc + s * v, unfused
+    return F3{acc.x + s * v.x, acc.y + s * v.y, acc.z + s * v.z};
+}
+__device__ __forceinline__ F3 axmy(F3 acc, float s, F3 v) {  // acc - s * v, unfused
+    return F3{acc.x - s * v.x, acc.y - s * v.y, acc.z - s * v.z};
+}
+
+// forward.cu:20-71.  `sh` points at this Gaussian's [M,3] block; deg already clamped to what M holds.
+__device__ __forceinline__ F3 sh_to_rgb(int deg, F3 pos, F3 cam, const float* sh) {
+    float dx = pos.x - cam.x, dy = pos.y - cam.y, dz = pos.z - cam.z;
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float x = dx / len, y = dy / len, z = dz / len;
+    F3 c = ld3(sh);
+    F3 v = F3{kSH0 * c.x, kSH0 * c.y, kSH0 * c.z};
+    if (deg > 0) {
+        v = axmy(v, kSH1 * y, ld3(sh + 3));
+        v = axpy(v, kSH1 * z, ld3(sh + 6));
+        v = axmy(v, kSH1 * x, ld3(sh + 9));
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            v = axpy(v, kSH2_0 * xy, ld3(sh + 12));
+            v = axpy(v, kSH2_1 * yz, ld3(sh + 15));
+            v = axpy(v, kSH2_2 * (2.0f * zz - xx - yy), ld3(sh + 18));
+            v = axpy(v, kSH2_3 * xz, ld3(sh + 21));
+            v = axpy(v, kSH2_4 * (xx - yy), ld3(sh + 24));
+            if (deg > 2) {
+                v = axpy(v, kSH3_0 * y * (3.0f * xx - yy), ld3(sh + 27));
+                v = axpy(v, kSH3_1 * xy * z, ld3(sh + 30));
+                v = axpy(v, kSH3_2 * y * (4.0f * zz - xx - yy), ld3(sh + 33));
+                v = axpy(v, kSH3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), ld3(sh + 36));
+                v = axpy(v, kSH3_4 * x * (4.0f * zz - xx - yy), ld3(sh + 39));
+                v = axpy(v, kSH3_5 * z * (xx - yy), ld3(sh + 42));
+                v = axpy(v, kSH3_6 * x * (xx - 3.0f * yy), ld3(sh + 45));
+            }
+        }
+    }
+    v.x += 0.5f; v.y += 0.5f; v.z += 0.5f;
+    return F3{fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f)};
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: one lane per Gaussian.  Streaming, HBM-bound: 236 B in (M = 16) and 52 B out per visible
+// Gaussian, 12 B in / 12 B out per culled one.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Camera cam, GeometryArrays out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= in.P) return;
+
+    const float* __restrict__ vm = cam.viewmatrix;
+    const float* __restrict__ pm = cam.projmatrix;
+
+    out.ids[i] = (uint32_t)i;
+    const F3 p = ld3(in.means3D + 3 * (size_t)i);
+
+    // auxiliary.h:58-77 (sums left to right)
+    const float hx = pm[0] * p.x + pm[4] * p.y + pm[8] * p.z + pm[12];
+    const float hy = pm[1] * p.x + pm[5] * p.y + pm[9] * p.z + pm[13];
+    const float hw = pm[3] * p.x + pm[7] * p.y + pm[11] * p.z + pm[15];
+    const float vx = vm[0] * p.x + vm[4] * p.y + vm[8] * p.z + vm[12];
+    const float vy = vm[1] * p.x + vm[5] * p.y + vm[9] * p.z + vm[13];
+    const float vz = vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14];
+
+    int radius_out = 0;
+    uint32_t tiles = 0;
+    uint32_t key = kCulledKey;
+
+    if (vz <= 0.2f) {
+        // The reference printf+traps here when prefiltered is set (auxiliary.h:156-160); we record
+        // the violation and keep the context alive.
+        if (in.prefiltered) atomicOr(out.error_flag, 1u);
+    } else {
+        const float pw = 1.0f / (hw + 0.0000001f);
+        const float ndc_x = hx * pw, ndc_y = hy * pw;
+
+        // ---- 3D covariance (forward.cu:118-152) ----
+        float c3[6];
+        if (in.cov3D_precomp != nullptr) {
+            const float* c = in.cov3D_precomp + 6 * (size_t)i;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) c3[k] = c[k];
+        } else {
+            const F3 s = ld3(in.scales + 3 * (size_t)i);
+            const F4 q = *reinterpret_cast<const F4*>(in.rotations + 4 * (size_t)i);
+            const float r = q.x, x = q.y, y = q.z, z = q.w;
+            Mat3 S = {{{in.scale_modifier * s.x, 0.f, 0.f}, {0.f, in.scale_modifier * s.y, 0.f},
+                       {0.f, 0.f, in.scale_modifier * s.z}}};
+            Mat3 R;  // glm column-major constructor: (a,b,c) is column 0
+            R.m[0][0] = 1.f - 2.f * (y * y + z * z); R.m[1][0] = 2.f * (x * y - r * z);       R.m[2][0] = 2.f * (x * z + r * y);
+            R.m[0][1] = 2.f * (x * y + r * z);       R.m[1][1] = 1.f - 2.f * (x * x + z * z); R.m[2][1] = 2.f * (y * z - r * x);
+            R.m[0][2] = 2.f * (x * z - r * y);       R.m[1][2] = 2.f * (y * z + r * x);       R.m[2][2] = 1.f - 2.f * (x * x + y * y);
+            const Mat3 Mm = mul3(S, R);
+            const Mat3 Sg = mul3(transpose3(Mm), Mm);
+            c3[0] = Sg.m[0][0]; c3[1] = Sg.m[1][0]; c3[2] = Sg.m[2][0];
+            c3[3] = Sg.m[1][1]; c3[4] = Sg.m[2][1]; c3[5] = Sg.m[2][2];
+        }
+
+        // ---- EWA 2D covariance (forward.cu:74-113) ----
+        const float limx = 1.3f * cam.tan_fovx, limy = 1.3f * cam.tan_fovy;
+        const float txtz = vx / vz, tytz = vy / vz;
+        const float tx = fminf(limx, fmaxf(-limx, txtz)) * vz;
+        const float ty = fminf(limy, fmaxf(-limy, tytz)) * vz;
+        Mat3 J = {{{cam.focal_x / vz, 0.f, 0.f}, {0.f, cam.focal_y / vz, 0.f},
+                   {-(cam.focal_x * tx) / (vz * vz), -(cam.focal_y * ty) / (vz * vz), 0.f}}};
+        Mat3 Wm;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) Wm.m[a][b] = vm[4 * a + b];
+        const Mat3 T = mul3(Wm, J);
+        Mat3 V = {{{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}}};
+        const Mat3 cov = mul3(mul3(transpose3(T), transpose3(V)), T);
+        const float ca = cov.m[0][0] + 0.3f, cb = cov.m[1][0], cc = cov.m[1][1] + 0.3f;
+
+        const float det = ca * cc - cb * cb;
+        if (det != 0.0f) {
+            const float det_inv = 1.f / det;
+            const float mid = 0.5f * (ca + cc);
+            const float lam1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float lam2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float rad = ceilf(3.f * sqrtf(fmaxf(lam1, lam2)));
+            const float px = ndc_to_pix(ndc_x, cam.width), py = ndc_to_pix(ndc_y, cam.height);
+            const int irad = f2i_sat(rad);
+            const TileRect rc = tile_rect(px, py, irad, cam.grid_x, cam.grid_y);
+            const uint32_t area = (uint32_t)(rc.x1 - rc.x0) * (uint32_t)(rc.y1 - rc.y0);
+            if (area != 0) {
+                if (in.colors_precomp == nullptr) {
+                    int deg = in.sh_degree;  // never read past M coefficients (D may be 4 with M = 16)
+                    if (deg > 2 && in.M < 16) deg = 2;
+                    if (deg > 1 && in.M < 9) deg = 1;
+                    if (deg > 0 && in.M < 4) deg = 0;
+                    const F3 cp = ld3(cam.cam_pos);
+                    const F3 col = sh_to_rgb(deg, p, cp, in.shs + 3 * (size_t)in.M * i);
+                    *reinterpret_cast<F3*>(out.rgb + 3 * (size_t)i) = col;
+                }
+                out.depths[i] = vz;
+                out.means2D[i] = make_float2(px, py);
+                out.conic_opacity[i] = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, in.opacities[i]);
+                radius_out = irad;
+                tiles = area;
+                key = __float_as_uint(vz);
+            }
+        }
+    }
+    out.radii[i] = radius_out;
+    out.tiles_touched[i] = tiles;
+    out.depth_keys[i] = key;
+}
+
+__global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means3D,
+                                                           const float* __restrict__ vm,
+                                                           uint8_t* __restrict__ present) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const F3 p = ld3(means3D + 3 * (size_t)i);
+    const float vz = vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14];
+    present[i] = (uint8_t)(vz > 0.2f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: wave-cooperative pair expansion in depth order.  Lane L of a wave owns sorted position
+// k = wave_base + L; the wave's pairs occupy [offsets[k0-1], offsets[k0+63]) contiguously, and all
+// 64 lanes stride over that flat range, locating the owning Gaussian by binary search on the
+// lanes' inclusive counts (6 ds_bpermute steps).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) duplicate_kernel(int P, int grid_x, int grid_y,
+                                                        const uint32_t* __restrict__ depth_order,
+                                                        const uint32_t* __restrict__ point_offsets,
+                                                        const float2* __restrict__ means2D,
+                                                        const int* __restrict__ radii,
+                                                        uint32_t* __restrict__ tile_keys,
+                                                        uint32_t* __restrict__ point_list) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t incl = 0, excl = 0;
+    if (k < P) {
+        incl = point_offsets[k];
+        excl = k > 0 ? point_offsets[k - 1] : 0u;
+    } else if (P > 0) {
+        incl = excl = point_offsets[P - 1];
+    }
+    const uint32_t base = __shfl(excl, 0);
+    const uint32_t total = __shfl(incl, 63) - base;  // wave-uniform
+    if (total == 0) return;
+
+    uint32_t gid = 0, xy0 = 0, w = 1;
+    if (incl != excl) {
+        gid = depth_order[k];
+        const float2 c = means2D[gid];
+        const TileRect rc = tile_rect(c.x, c.y, radii[gid], grid_x, grid_y);
+        xy0 = (uint32_t)rc.x0 | ((uint32_t)rc.y0 << 16);
+        w = (uint32_t)(rc.x1 - rc.x0);
+    }
+    const uint32_t incl_rel = incl - base, excl_rel = excl - base;
+
+    for (uint32_t t0 = 0; t0 < total; t0 += 64) {  // wave-uniform trip count: every lane shuffles
+        const uint32_t t = t0 + lane;
+        int lo = 0, hi = 63;  // smallest lane whose inclusive count exceeds t
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const int mid = (lo + hi) >> 1;
+            const uint32_t v = __shfl(incl_rel, mid);
+            if (v > t) hi = mid; else lo = mid + 1;
+        }
+        const uint32_t o_excl = __shfl(excl_rel, lo);
+        const uint32_t o_xy0 = __shfl(xy0, lo);
+        const uint32_t o_w = __shfl(w, lo);
+        const uint32_t o_gid = __shfl(gid, lo);
+        if (t < total) {
+            const uint32_t local = t - o_excl;
+            const uint32_t row = local / o_w, col = local - row * o_w;
+            const uint32_t tile = ((o_xy0 >> 16) + row) * (uint32_t)grid_x + (o_xy0 & 0xFFFFu) + col;
+            tile_keys[base + t] = tile;
+            point_list[base + t] = o_gid;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: ranges[t] = [lower_bound(t), lower_bound(t+1)) over the sorted tile keys; (0,0) when empty,
+// which is what the reference's memset + boundary scan leaves behind.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__ a, uint32_t n, uint32_t v) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256) tile_ranges_kernel(uint32_t n, int num_tiles,
+                                                          const uint32_t* __restrict__ keys,
+                                                          uint2* __restrict__ ranges) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= num_tiles) return;
+    const uint32_t b = lower_bound_u32(keys, n, (uint32_t)t);
+    const uint32_t e = lower_bound_u32(keys, n, (uint32_t)t + 1u);
+    ranges[t] = (e > b) ? make_uint2(b, e) : make_uint2(0u, 0u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: one wave64 per 16x16 tile, lane = 2x2 pixel quad (lane & 7, lane >> 3).
+//
+// Per batch of 64 list entries every lane gathers one entry (id -> xy, conic+opacity, rgb, depth)
+// and parks it in LDS; the wave then walks the batch reading each entry as a broadcast (all lanes
+// the same address: conflict-free) and updating its 4 pixels.  The next batch's gathers are issued
+// before the walk so their latency hides behind it.
+//
+// Exactness: per (pixel, entry) the arithmetic is the reference's (forward.cu:331-364).  The only
+// shortcut is `power < skip_below`, with skip_below = -ln(255*o) - 1e-4: below it o*exp(power) is
+// < 1/255 by a margin ~100x the combined rounding error of logf/expf/the products, so the
+// reference's `alpha < 1/255` test would have skipped the pair too; pairs inside the margin take
+// the exact path.
+// ------------------------------------------------------------------------------------------------
+struct BlendEntryA { float x, y, cxx, cxy; };       // ds_read_b128
+struct BlendEntryB { float cyy, skip_below; };      // ds_read_b64
+struct BlendEntryC { float opacity, r, g, b; };     // ds_read_b128, contributing pairs only
+
+__device__ __forceinline__ int xcd_band_tile(int b, int T) {
+    // Blocks are dealt round-robin to the 8 XCDs (block b -> XCD b % 8).  Give each XCD a contiguous
+    // band of tile rows so neighbouring tiles, which share splats, hit the same L2.  Bijective for
+    // any T.  Placement is a speed hint only; results do not depend on it.
+    const int q = T >> 3, r = T & 7;
+    const int xcd = b & 7, local = b >> 3;
+    return xcd * q + min(xcd, r) + local;
+}
+
+__global__ void __launch_bounds__(64) blend_kernel(int W, int H, int grid_x, int num_tiles,
+                                                   const uint2* __restrict__ ranges,
+                                                   const uint32_t* __restrict__ point_list,
+                                                   const float2* __restrict__ means2D,
+                                                   const float* __restrict__ features,
+                                                   const float* __restrict__ depths,
+                                                   const float4* __restrict__ conic_opacity,
+                                                   const float* __restrict__ background,
+                                                   float* __restrict__ out_color, float* __restrict__ out_depth,
+                                                   float* __restrict__ out_alpha,
+                                                   uint32_t* __restrict__ n_contrib) {
+    __shared__ BlendEntryA sA[64];  // 2.75 KiB per wave: 32 single-wave workgroups fit a CU's 160 KiB
+    __shared__ BlendEntryB sB[64];
+    __shared__ BlendEntryC sC[64];
+    __shared__ float sD[64];
+
+    const int tile = xcd_band_tile(blockIdx.x, num_tiles);
+    const int lane = threadIdx.x;
+    const int tile_x = tile % grid_x, tile_y = tile / grid_x;
+    const int px0 = tile_x * kTile + 2 * (lane & 7);
+    const int py0 = tile_y * kTile + 2 * (lane >> 3);
+    const float fx0 = (float)px0, fx1 = (float)(px0 + 1);
+    const float fy0 = (float)py0, fy1 = (float)(py0 + 1);
+
+    // pixel q = 2*row + col of the quad
+    bool inside[4] = {px0 < W && py0 < H, px0 + 1 < W && py0 < H, px0 < W && py0 + 1 < H, px0 + 1 < W && py0 + 1 < H};
+    bool done[4] = {!inside[0], !inside[1], !inside[2], !inside[3]};
+    float T[4] = {1.f, 1.f, 1.f, 1.f};
+    float Cr[4] = {0.f, 0.f, 0.f, 0.f}, Cg[4] = {0.f, 0.f, 0.f, 0.f}, Cb[4] = {0.f, 0.f, 0.f, 0.f};
+    float Dz[4] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t last[4] = {0u, 0u, 0u, 0u};
+
+    const uint2 range = ranges[tile];
+    const uint32_t count = range.y - range.x;
+
+    // registers holding the batch in flight
+    float2 g_xy = make_float2(0.f, 0.f);
+    float4 g_co = make_float4(0.f, 0.f, 0.f, 0.f);
+    F3 g_rgb = {0.f, 0.f, 0.f};
+    float g_z = 0.f;
+    auto gather = [&](uint32_t first) {
+        const uint32_t e = first + (uint32_t)lane;
+        if (e < count) {
+            const uint32_t id = point_list[range.x + e];
+            g_xy = means2D[id];
+            g_co = conic_opacity[id];
+            g_rgb = ld3(features + 3 * (size_t)id);
+            g_z = depths[id];
+        }
+    };
+    if (count > 0) gather(0);
+
+    for (uint32_t first = 0; first < count; first += 64) {
+        // park the gathered batch (single-wave workgroup: the barriers only order this wave's own
+        // LDS reads of the previous batch / writes of this one / broadcast reads below)
+        __syncthreads();
+        sA[lane] = BlendEntryA{g_xy.x, g_xy.y, g_co.x, g_co.y};
+        sB[lane] = BlendEntryB{g_co.z, -logf(255.0f * g_co.w) - 1.0e-4f};
+        sC[lane] = BlendEntryC{g_co.w, g_rgb.x, g_rgb.y, g_rgb.z};
+        sD[lane] = g_z;
+        __syncthreads();
+        if (first + 64 < count) gather(first + 64);
+
+        const int n = (int)min(64u, count - first);
+        for (int j = 0; j < n; ++j) {
+            const BlendEntryA a = sA[j];
+            const BlendEntryB b = sB[j];
+            const float dx0 = a.x - fx0, dx1 = a.x - fx1;
+            const float dy0 = a.y - fy0, dy1 = a.y - fy1;
+            const float ax0 = a.cxx * dx0 * dx0, ax1 = a.cxx * dx1 * dx1;
+            const float by0 = b.cyy * dy0 * dy0, by1 = b.cyy * dy1 * dy1;
+            const float m0 = a.cxy * dx0, m1 = a.cxy * dx1;
+            float power[4];
+            power[0] = -0.5f * (ax0 + by0) - m0 * dy0;
+            power[1] = -0.5f * (ax1 + by0) - m1 * dy0;
+            power[2] = -0.5f * (ax0 + by1) - m0 * dy1;
+            power[3] = -0.5f * (ax1 + by1) - m1 * dy1;
+            bool live[4];
+            bool any_live = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                live[q] = !done[q] && !(power[q] > 0.0f) && !(power[q] < b.skip_below);
+                any_live |= live[q];
+            }
+            if (!__any(any_live)) continue;  // wave-uniform: nobody needs expf or the colour
+            const BlendEntryC c = sC[j];
+            const float z = sD[j];
+            const uint32_t position = first + (uint32_t)j + 1u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!live[q]) continue;
+                const float alpha = fminf(0.99f, c.opacity * expf(power[q]));
+                if (alpha < 1.0f / 255.0f) continue;
+                const float test_T = T[q] * (1.f - alpha);
+                if (test_T < 0.0001f) { done[q] = true; continue; }
+                Cr[q] += c.r * alpha * T[q];
+                Cg[q] += c.g * alpha * T[q];
+                Cb[q] += c.b * alpha * T[q];
+                Dz[q] += z * alpha * T[q];
+                T[q] = test_T;
+                last[q] = position;
+            }
+            if (__all(done[0] && done[1] && done[2] && done[3])) break;
+        }
+        if (__all(done[0] && done[1] && done[2] && done[3])) break;
+    }
+
+    const float bg0 = background[0], bg1 = background[1], bg2 = background[2];
+    const size_t plane = (size_t)W * (size_t)H;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (!inside[q]) continue;
+        const size_t pid = (size_t)W * (size_t)(py0 + (q >> 1)) + (size_t)(px0 + (q & 1));
+        out_alpha[pid] = 1.f - T[q];
+        if (n_contrib != nullptr) n_contrib[pid] = last[q];
+        out_color[pid] = Cr[q] + T[q] * bg0;
+        out_color[plane + pid] = Cg[q] + T[q] * bg1;
+        out_color[2 * plane + pid] = Cb[q] + T[q] * bg2;
+        out_depth[pid] = Dz[q];
+    }
+}
+
+inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+} // namespace
+
+hipError_t launch_preprocess(const GaussianInputs& in, const Camera& cam, const GeometryArrays& out,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL(preprocess_kernel, dim3(div_up(in.P, 256)), dim3(256), 0, stream, in, cam, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
+                               hipStream_t stream) {
+    hipLaunchKernelGGL(mark_visible_kernel, dim3(div_up(P, 256)), dim3(256), 0, stream, P, means3D, viewmatrix,
+                       present);
+    return hipGetLastError();
+}
+
+hipError_t launch_duplicate(int P, const Camera& cam, const uint32_t* depth_order, const uint32_t* point_offsets,
+                            const float2* means2D, const int* radii, uint32_t* tile_keys, uint32_t* point_list,
+                            hipStream_t stream) {
+    hipLaunchKernelGGL(duplicate_kernel, dim3(div_up(P, 256)), dim3(256), 0, stream, P, cam.grid_x, cam.grid_y,
+                       depth_order, point_offsets, means2D, radii, tile_keys, point_list);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_ranges(uint32_t num_rendered, int num_tiles, const uint32_t* sorted_tile_keys,
+                              uint2* ranges, hipStream_t stream) {
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(div_up(num_tiles, 256)), dim3(256), 0, stream, num_rendered,
+                       num_tiles, sorted_tile_keys, ranges);
+    return hipGetLastError();
+}
+
+hipError_t launch_blend(const Camera& cam, const uint2* ranges, const uint32_t* point_list, const float2* means2D,
+                        const float* features, const float* depths, const float4* conic_opacity,
+                        const float* background, float* out_color, float* out_depth, float* out_alpha,
+                        uint32_t* n_contrib, hipStream_t stream) {
+    const int T = cam.grid_x * cam.grid_y;
+    hipLaunchKernelGGL(blend_kernel, dim3(T), dim3(64), 0, stream, cam.width, cam.height, cam.grid_x, T, ranges,
+                       point_list, means2D, features, depths, conic_opacity, background, out_color, out_depth,
+                       out_alpha, n_contrib);
+    return hipGetLastError();
+}
+
+} // namespace gsr

@@ -1,0 +1,128 @@
+"""Frame-parallel rendering of a camera trajectory: one process per GPU, frames dealt round-robin,
+one gather of the finished frames to rank 0 at the end (RCCL over xGMI when the backend is "nccl").
+
+The reference renders a trajectory serially on one GPU (``scene_representation.py:355-356``: a
+``tqdm`` loop over ``camera_views``); frames are independent when the Gaussian set is static, so
+the only multi-GPU strategy that fits is data parallelism over frames.  Every
+rank holds a full replica of the Gaussians (3 M Gaussians = 0.7 GB; HBM is 288 GB), rank ``r`` of
+``N`` renders frames ``r, r+N, r+2N, ...`` (round-robin balances an orbit's slowly varying load
+better than contiguous blocks) and nothing is exchanged until the final gather.  No collective sits
+on the per-frame path.
+
+Frame payload: RGBA8, quantised like ``torchvision.utils.save_image`` does for the PNGs the
+reference writes (``scene_representation.py:427``), i.e. ``clamp(x*255+0.5, 0, 255)``
+truncated to uint8; optionally the fp32 depth map (what ``depth/*.npy`` holds).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from .cameras import Camera
+from .scenes import GaussianCloud
+
+
+def shard_frames(num_frames: int, rank: int, world_size: int) -> List[int]:
+    """Frame indices owned by ``rank``: round-robin."""
+    if not (0 <= rank < world_size):
+        raise ValueError(f"rank {rank} outside world of {world_size}")
+    return list(range(rank, num_frames, world_size))
+
+
+def pack_rgba8(color: torch.Tensor, alpha: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[3,H,W] + [1,H,W] float -> [4,H,W] uint8 with save_image's rounding."""
+    rgba = torch.cat((color, alpha), dim=0)
+    q = rgba.mul(255.0).add_(0.5).clamp_(0.0, 255.0).to(torch.uint8)
+    if out is not None:
+        out.copy_(q)
+        return out
+    return q
+
+
+def settings_for_camera(cam: Camera, bg: torch.Tensor, sh_degree: int, scale_modifier: float = 1.0,
+                        debug: bool = False):
+    """The ``GaussianRasterizationSettings`` that ``gaussian_renderer.render`` builds
+    (``gaussian_renderer/__init__.py:98-114``)."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    return GaussianRasterizationSettings(
+        image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=cam.tanfovx,
+        tanfovy=cam.tanfovy, bg=bg, scale_modifier=scale_modifier, viewmatrix=cam.world_view_transform,
+        projmatrix=cam.full_proj_transform, sh_degree=sh_degree, campos=cam.camera_center, prefiltered=False,
+        debug=debug)
+
+
+def rasterize(cloud: GaussianCloud, cam: Camera, bg: torch.Tensor):
+    """One forward call through the drop-in API; ``cloud``/``cam``/``bg`` already on the GPU."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    rast = GaussianRasterizer(raster_settings=settings_for_camera(cam, bg, cloud.sh_degree))
+    if cloud.colors_precomp is not None:
+        return rast(means3D=cloud.means3D, means2D=None, opacities=cloud.opacities, colors_precomp=cloud.colors_precomp,
+                    scales=cloud.scales, rotations=cloud.rotations)
+    return rast(means3D=cloud.means3D, means2D=None, opacities=cloud.opacities, shs=cloud.shs, scales=cloud.scales,
+                rotations=cloud.rotations)
+
+
+RenderFn = Callable[[GaussianCloud, Camera, torch.Tensor], Sequence[torch.Tensor]]
+
+
+def render_shard(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids: Sequence[int], bg: torch.Tensor,
+                 keep_depth: bool = False, render_fn: RenderFn = rasterize) -> Dict[str, torch.Tensor]:
+    """Render this rank's frames; returns stacked ``rgba8 [n,4,H,W]`` (and ``depth [n,H,W]``)."""
+    device = cloud.means3D.device
+    n = len(frame_ids)
+    H, W = (cameras[0].image_height, cameras[0].image_width) if len(cameras) else (0, 0)
+    rgba = torch.empty((n, 4, H, W), dtype=torch.uint8, device=device)
+    depth = torch.empty((n, H, W), dtype=torch.float32, device=device) if keep_depth else None
+    with torch.no_grad():
+        for slot, f in enumerate(frame_ids):
+            color, d, alpha, _radii = render_fn(cloud, cameras[f], bg)
+            pack_rgba8(color, alpha, out=rgba[slot])
+            if keep_depth:
+                depth[slot].copy_(d[0])
+    out = {"rgba8": rgba}
+    if keep_depth:
+        out["depth"] = depth
+    return out
+
+
+def gather_frames(local: torch.Tensor, num_frames: int, dst: int = 0, group=None) -> Optional[torch.Tensor]:
+    """Final gather of a round-robin-sharded stack ``[n_local, ...]`` to ``dst`` in frame order.
+
+    Shards differ in length by at most one frame; every rank pads to the common maximum so a single
+    ``gather`` (RCCL: all seven xGMI links into the root active at once) moves everything.  Returns
+    ``[num_frames, ...]`` on ``dst`` and ``None`` elsewhere.  With no process group it is the identity.
+    """
+    if not (dist.is_available() and dist.is_initialized()):
+        return local[:num_frames]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    per = (num_frames + world - 1) // world
+    padded = local
+    if local.shape[0] < per:
+        pad = torch.zeros((per - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        padded = torch.cat((local, pad), dim=0)
+    padded = padded.contiguous()
+    bufs = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
+    dist.gather(padded, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    out = torch.empty((num_frames,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        ids = shard_frames(num_frames, r, world)
+        if ids:
+            out[ids] = bufs[r][:len(ids)]
+    return out
+
+
+def render_trajectory(cloud: GaussianCloud, cameras: Sequence[Camera], bg: torch.Tensor, keep_depth: bool = False,
+                      dst: int = 0, render_fn: RenderFn = rasterize) -> Optional[Dict[str, torch.Tensor]]:
+    """Shard -> render -> gather.  Works with or without an initialised process group."""
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(), dist.get_world_size()
+    else:
+        rank, world = 0, 1
+    ids = shard_frames(len(cameras), rank, world)
+    local = render_shard(cloud, cameras, ids, bg, keep_depth, render_fn)
+    gathered = {k: gather_frames(v, len(cameras), dst) for k, v in local.items()}
+    return gathered if rank == dst else None

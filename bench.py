@@ -1,0 +1,245 @@
+#!/usr/bin/env python
+"""bench.py -- frames/s of the 3DGS forward render path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A *step* is one ``GaussianRasterizer.forward`` call (SH colour path) on one frame of the workload's
+orbit trajectory, plus the RGBA8 pack of that frame; with N > 1 ranks the frames are dealt
+round-robin (frame-parallel, weak scaling: every rank renders K frames) and the packed frames are
+gathered to rank 0 with one RCCL gather inside the timed region.  Inputs (Gaussians, camera
+matrices) are resident in HBM before the clock starts.  Rank 0 prints ONE JSON line.
+
+Workload (default ``c3``) = BASELINE.json configs[2] shape on one GPU: 3 M synthetic Gaussians,
+1920x1080, 800-frame orbit, SH degree 3 (M = 16), bg = 0.  ``--workload c2`` is the 1 M / 960x540
+stand-in.  Weights are random by construction (there are no checkpoints offline): data = synthetic.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel of the frame, measured live with HIP events recorded by the library
+                on the launch stream during the timed region; ``frame`` holds the whole-frame figure
+                against SURVEY.md section 8d's B_alg.
+  cpu_baseline  the CPU oracle (C + OpenMP restatement of the reference kernels, oracle/) timed on
+                this box's host cores on a bounded sample (rank 0, N = 1 only), with the parity of
+                the GPU frame against it.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    "c3": dict(name="C3: 3M synthetic Gaussians, 1920x1080, 800-frame orbit (BASELINE configs[2], per-GPU shard)",
+               cfg="config_c3", width=1920, height=1080, frames=800),
+    "c2": dict(name="C2 stand-in: 1M synthetic Gaussians, 960x540, 200-frame orbit (BASELINE configs[1])",
+               cfg="config_c2", width=960, height=540, frames=200),
+}
+
+
+def algorithmic_bytes(P, V, D, T, W, H, M=16):
+    """SURVEY.md section 8d, per stage (bytes per frame)."""
+    bit = max(1, int(T).bit_length())
+    n_pass = -(-(32 + bit) // 8)
+    st = {
+        "preprocess": 20 * P + (32 + 12 * M + 40) * V,
+        "scan": 8 * P,
+        "duplicate": 20 * V + 12 * D,
+        "sort": 24 * D * n_pass,
+        "ranges": 8 * D + 8 * T,
+        "blend": 44 * D + 24 * W * H,
+    }
+    st["frame"] = sum(st.values())
+    st["n_pass"] = n_pass
+    return st
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--gaussians", type=int, default=0, help="override P (parity/debug only; invalidates the metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the final RCCL gather (N > 1)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+
+    from autovfx_amd import _lib, scenes
+    from autovfx_amd.cameras import orbit_cameras
+    from autovfx_amd.frame_parallel import gather_frames, pack_rgba8, rasterize
+    from diff_gaussian_rasterization import _C
+
+    wl = WORKLOADS[args.workload]
+    W, H, F = wl["width"], wl["height"], wl["frames"]
+    cfg = getattr(scenes, wl["cfg"])
+    cloud_cpu = cfg(P=args.gaussians) if args.gaussians else cfg()
+    cloud = cloud_cpu.to(device)
+    cams_cpu = orbit_cameras(F, W, H)
+    K, Wm = args.steps, args.warmup
+    # rank r renders frames r, r+N, ... ; warm-up frames precede the timed ones on the same orbit
+    frame_of = lambda i: (i * world + rank) % F
+    need = sorted({frame_of(i) for i in range(Wm + K)})
+    cams = {f: cams_cpu[f].to(device) for f in need}
+    bg = torch.zeros(3, dtype=torch.float32, device=device)
+    rgba = torch.empty((K, 4, H, W), dtype=torch.uint8, device=device)
+    P, M = cloud.P, int(cloud.shs.shape[1])
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+
+    def step(i, slot):
+        color, _depth, alpha, _radii = rasterize(cloud, cams[frame_of(i)], bg)
+        pack_rgba8(color, alpha, out=rgba[slot % K])
+
+    with torch.no_grad():
+        for i in range(Wm):
+            step(i, i)
+        _lib.set_stage_timing(True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(K):
+            step(Wm + i, i)
+        gathered = None
+        if world > 1 and not args.no_gather:
+            gathered = gather_frames(rgba, K * world, dst=0)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        stage_ms = _lib.stage_times_ms()
+        _lib.set_stage_timing(False)
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- per-frame workload statistics (untimed): V and D of this rank's timed frames ----
+    Vs, Ds = [], []
+    sample = list(range(0, K, max(1, K // 8)))
+    with torch.no_grad():
+        e = torch.Tensor([])
+        for i in sample:
+            cam = cams[frame_of(Wm + i)]
+            n, _c, _d, _a, radii, *_ = _C.rasterize_gaussians(
+                bg, cloud.means3D, e, cloud.opacities, cloud.scales, cloud.rotations, 1.0, e,
+                cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy, H, W, cloud.shs,
+                cloud.sh_degree, cam.camera_center, False, False)
+            Ds.append(int(n))
+            Vs.append(int((radii > 0).sum().item()))
+    V, D = float(np.mean(Vs)), float(np.mean(Ds))
+    alg = algorithmic_bytes(P, V, D, T, W, H, M)
+
+    fps = K * world / elapsed
+    ms_per_step = elapsed / K * 1e3
+
+    calls = stage_ms.pop("calls")
+    stage_alg = {"preprocess": alg["preprocess"], "depth_sort": 0, "scan": alg["scan"], "duplicate": alg["duplicate"],
+                 "tile_sort": alg["sort"], "ranges": alg["ranges"], "blend": alg["blend"]}
+    stages = {k: {"ms": round(v, 4), "alg_bytes": int(stage_alg[k]),
+                  "alg_GBps": round(stage_alg[k] / (v * 1e-3) / 1e9, 1) if v > 0 else None}
+              for k, v in stage_ms.items()}
+    dom = max(stage_ms, key=stage_ms.get)
+    dom_gbps = stage_alg[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+    frame_gbps = alg["frame"] / (ms_per_step * 1e-3) / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": {"blend": "blend_kernel", "preprocess": "preprocess_kernel",
+                                   "duplicate": "duplicate_kernel", "ranges": "tile_ranges_kernel"}.get(dom, dom),
+        "achieved": round(dom_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": round(dom_gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+        "avg_launch_ms": round(stage_ms[dom], 4), "alg_bytes_per_launch": int(stage_alg[dom]),
+        "timed_calls": calls,
+        "frame": {"alg_bytes": int(alg["frame"]), "achieved": round(frame_gbps, 1),
+                  "frac": round(frame_gbps / HBM_PEAK_GBPS, 4), "n_pass_ref_sort": alg["n_pass"]},
+        "stages": stages,
+    }
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(cloud_cpu, cams_cpu, frame_of(Wm), cloud, cams, bg, W, H)
+
+    if rank == 0:
+        line = {
+            "metric": "rendered frames/sec at 1920x1080, 3M Gaussians" if args.workload == "c3" and not args.gaussians
+                      else f"rendered frames/sec at {W}x{H}, {P} Gaussians",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["name"], "P": P, "sh_coeffs": M, "width": W, "height": H, "tiles": T,
+                       "visible_mean": round(V, 1), "num_rendered_mean": round(D, 1),
+                       "boundary": "GaussianRasterizer.forward (SH) + RGBA8 pack per frame"
+                                   + ("; final RCCL gather of RGBA8 frames to rank 0" if world > 1 and not args.no_gather else ""),
+                       "parallelism": f"frame-parallel x{world}"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        if gathered is not None:
+            line["config"]["gathered_frames"] = int(gathered.shape[0])
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(cloud_cpu, cams_cpu, frame, cloud, cams, bg, W, H):
+    """Time the CPU oracle on ONE frame of the same workload and report the GPU frame's parity."""
+    from oracle import cpu_oracle
+    from autovfx_amd.frame_parallel import rasterize
+    cam = cams_cpu[frame]
+    kw = dict(means3D=cloud_cpu.means3D, opacities=cloud_cpu.opacities, bg=np.zeros(3, np.float32), width=W, height=H,
+              viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, campos=cam.camera_center,
+              tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, sh_degree=cloud_cpu.sh_degree, shs=cloud_cpu.shs,
+              scales=cloud_cpu.scales, rotations=cloud_cpu.rotations)
+    cpu_oracle.lib()
+    t0 = time.perf_counter()
+    ref = cpu_oracle.forward(**kw)
+    sec = time.perf_counter() - t0
+    with torch.no_grad():
+        color, depth, alpha, radii = rasterize(cloud, cams[frame], bg)
+    torch.cuda.synchronize()
+    err = np.abs(color.cpu().numpy() - ref["color"]).max(axis=0)
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+    except OSError:
+        pass
+    return {"value": round(1.0 / sec, 4), "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"1 frame (orbit index {frame}) of the same workload, full size, C+OpenMP oracle, {sec:.2f} s",
+            "cpu_model": model,
+            "parity": {"rgb_maxabs": float(err.max()), "rgb_px_over_1e-4": int((err > 1e-4).sum()),
+                       "alpha_maxabs": float(np.abs(alpha.cpu().numpy() - ref["alpha"]).max()),
+                       "depth_maxabs": float(np.abs(depth.cpu().numpy() - ref["depth"]).max()),
+                       "radii_equal": bool((radii.cpu().numpy() == ref["radii"]).all()),
+                       "pixels": int(W * H)}}
+
+
+if __name__ == "__main__":
+    main()

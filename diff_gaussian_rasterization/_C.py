@@ -1,0 +1,155 @@
+"""``diff_gaussian_rasterization._C`` -- the extension-module surface of the reference, backed by
+libgsr_hip.so through its C ABI (include/gsr.h).
+
+The reference builds ``_C`` as a pybind11/CUDA torch extension exposing three functions
+(``DGR/ext.cpp:16-18``, DGR = sugar/gaussian_splatting/submodules/diff-gaussian-rasterization):
+
+* ``rasterize_gaussians``          -> ``RasterizeGaussiansCUDA``         ``DGR/rasterize_points.cu:36-119``
+* ``rasterize_gaussians_backward`` -> ``RasterizeGaussiansBackwardCUDA`` ``DGR/rasterize_points.cu:121-209``
+* ``mark_visible``                 -> ``markVisible``                    ``DGR/rasterize_points.cu:211-230``
+
+This module keeps those names, argument orders, return tuples and error behaviour; what changes
+is everything underneath (HIP kernels for gfx950, called with raw device pointers on torch's
+current HIP stream).  Tensors must live on a GPU: there is no CPU path, by design.
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+from typing import Optional, Tuple
+
+import torch
+
+from autovfx_amd import _lib
+
+_tls = threading.local()
+
+
+def _alloc_geom(nbytes, _user):
+    return _tls.call.alloc("geom", nbytes)
+
+
+def _alloc_binning(nbytes, _user):
+    return _tls.call.alloc("binning", nbytes)
+
+
+def _alloc_image(nbytes, _user):
+    return _tls.call.alloc("image", nbytes)
+
+
+# ctypes trampolines are created once; the per-call state lives in thread-local storage.
+_GEOM_CB = _lib.ALLOC_FN(_alloc_geom)
+_BINNING_CB = _lib.ALLOC_FN(_alloc_binning)
+_IMAGE_CB = _lib.ALLOC_FN(_alloc_image)
+
+
+class _CallScratch:
+    """The three growable byte tensors of ``rasterize_points.cu:73-80`` (resizeFunctional)."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.buffers = {k: torch.empty(0, dtype=torch.uint8, device=device) for k in ("geom", "binning", "image")}
+
+    def alloc(self, which: str, nbytes: int) -> int:
+        t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        self.buffers[which] = t
+        return t.data_ptr()
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer of a tensor, or NULL for the reference's "empty tensor means absent"."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def _f32c(name: str, t: torch.Tensor, device: torch.device) -> torch.Tensor:
+    if t.numel() == 0:
+        return t
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected a float32 tensor, got {t.dtype}")
+    if t.device != device:
+        raise RuntimeError(f"{name}: expected a tensor on {device}, got {t.device}")
+    return t.contiguous()
+
+
+def _require_gpu(t: torch.Tensor, what: str) -> torch.device:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what} is on {t.device}: the MI355X rasterizer only runs on a HIP device (there is no CPU fallback)")
+    return t.device
+
+
+_last_layout = {}
+
+
+def last_layout() -> dict:
+    """Byte offsets of every scratch sub-array of this thread's most recent forward call
+    (introspection for the parity tests; not part of the reference surface)."""
+    return dict(_last_layout)
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug) -> Tuple[int, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor,
+                                                     torch.Tensor, torch.Tensor, torch.Tensor]:
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    device = _require_gpu(means3D, "means3D")
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+
+    out_color = torch.zeros((3, H, W), dtype=torch.float32, device=device)
+    out_depth = torch.zeros((1, H, W), dtype=torch.float32, device=device)
+    out_alpha = torch.zeros((1, H, W), dtype=torch.float32, device=device)
+    radii = torch.zeros((P,), dtype=torch.int32, device=device)
+    scratch = _CallScratch(device)
+    rendered = 0
+    if P != 0:
+        M = int(sh.size(1)) if sh.numel() != 0 else 0
+        tensors = [_f32c(n, t, device) for n, t in (
+            ("background", background), ("means3D", means3D), ("sh", sh), ("colors", colors), ("opacity", opacity),
+            ("scales", scales), ("rotations", rotations), ("cov3D_precomp", cov3D_precomp),
+            ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("campos", campos))]
+        bg_, m3_, sh_, col_, op_, sc_, rot_, cov_, vm_, pm_, cp_ = tensors
+        _tls.call = scratch
+        try:
+            with torch.cuda.device(device):
+                stream = torch.cuda.current_stream(device).cuda_stream
+                rendered = _lib.lib.gsr_forward(
+                    _GEOM_CB, None, _BINNING_CB, None, _IMAGE_CB, None, P, int(degree), M, _ptr(bg_), W, H,
+                    _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_),
+                    _ptr(cov_), _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx), float(tan_fovy),
+                    1 if prefiltered else 0, out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(),
+                    radii.data_ptr(), 1 if debug else 0, ctypes.c_void_p(stream))
+        finally:
+            _tls.call = None
+        if rendered < 0:
+            raise RuntimeError(f"gsr_forward failed ({rendered}): {_lib.last_error()}")
+        _last_layout.clear()
+        _last_layout.update({"geom": _lib.offsets("geom"), "binning": _lib.offsets("binning"),
+                             "image": _lib.offsets("image")})
+    return (rendered, out_color, out_depth, out_alpha, radii, scratch.buffers["geom"], scratch.buffers["binning"],
+            scratch.buffers["image"])
+
+
+def rasterize_gaussians_backward(*args):
+    """24-argument backward of the reference (``rasterize_points.h:40-65``).  Not built yet: the
+    backward pass is the first "next" row of the scope table."""
+    _lib.lib.gsr_backward()
+    raise NotImplementedError("rasterize_gaussians_backward: " + _lib.last_error())
+
+
+def mark_visible(means3D, viewmatrix, projmatrix) -> torch.Tensor:
+    device = _require_gpu(means3D, "means3D")
+    P = int(means3D.size(0))
+    present = torch.zeros((P,), dtype=torch.bool, device=device)
+    if P != 0:
+        m3_ = _f32c("means3D", means3D, device)
+        vm_ = _f32c("viewmatrix", viewmatrix, device)
+        pm_ = _f32c("projmatrix", projmatrix, device)
+        with torch.cuda.device(device):
+            rc = _lib.lib.gsr_mark_visible(P, _ptr(m3_), _ptr(vm_), _ptr(pm_), present.data_ptr(),
+                                           ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"gsr_mark_visible failed ({rc}): {_lib.last_error()}")
+    return present

@@ -1,0 +1,155 @@
+/*
+ * gsr.h -- C ABI of the MI355X-native 3D-Gaussian-splatting forward rasterizer (libgsr_hip.so).
+ *
+ * This is the drop-in boundary for the reference's device library.  Each entry point replaces
+ * one member of the reference interface (paths under /root/reference, DGR = sugar/
+ * gaussian_splatting/submodules/diff-gaussian-rasterization):
+ *
+ *   gsr_forward        <- CudaRasterizer::Rasterizer::forward   DGR/cuda_rasterizer/rasterizer.h:31-55
+ *                         (impl DGR/cuda_rasterizer/rasterizer_impl.cu:197-339), as called by
+ *                         RasterizeGaussiansCUDA               DGR/rasterize_points.cu:36-119
+ *   gsr_mark_visible   <- CudaRasterizer::Rasterizer::markVisible DGR/cuda_rasterizer/rasterizer.h:24-29
+ *                         (impl rasterizer_impl.cu:141-153), as called by markVisible
+ *                         DGR/rasterize_points.cu:211-230
+ *   gsr_backward       <- CudaRasterizer::Rasterizer::backward  DGR/cuda_rasterizer/rasterizer.h:57-90
+ *                         NOT BUILT YET; returns GSR_ERR_UNSUPPORTED.
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only, no torch / C++ types cross this boundary;
+ *   - every data pointer is a DEVICE pointer (HIP, gfx950) unless the name says host;
+ *   - the std::function<char*(size_t)> scratch callbacks of the reference become a C function
+ *     pointer plus a user cookie; each is called exactly once per gsr_forward, like the reference;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it.  gsr_forward blocks
+ *     the host once (to learn num_rendered before sizing the binning scratch), exactly where the
+ *     reference does (rasterizer_impl.cu:282);
+ *   - errors never propagate as C++ exceptions: functions return a negative gsr_status and
+ *     gsr_last_error() describes the failure (thread-local string).
+ *
+ * Tensor layouts are the reference's: means3D[P,3], shs[P,M,3],
+ * colors_precomp[P,3], opacities[P], scales[P,3], rotations[P,4] (w,x,y,z), cov3D_precomp[P,6],
+ * viewmatrix / projmatrix = 16 floats of the transposed matrices, out_color[3,H,W] planar,
+ * out_depth[H,W], out_alpha[H,W], radii[P] int32.  "nullable" pointers select the alternative
+ * input exactly as the reference's nullptr tests do (forward.cu:205,241).
+ */
+#ifndef GSR_H_INCLUDED
+#define GSR_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define GSR_API __attribute__((visibility("default")))
+#else
+#define GSR_API
+#endif
+
+typedef enum gsr_status {
+    GSR_OK = 0,
+    GSR_ERR_INVALID_ARG = -1,  /* bad sizes / missing required pointer / both alternatives given   */
+    GSR_ERR_ALLOC = -2,        /* a scratch callback returned NULL                                  */
+    GSR_ERR_HIP = -3,          /* a HIP runtime call or kernel failed (message has the HIP string) */
+    GSR_ERR_UNSUPPORTED = -4,  /* entry point declared but not built yet                            */
+    GSR_ERR_PREFILTERED = -5   /* prefiltered=1 but a Gaussian failed the near-plane test (debug)   */
+} gsr_status;
+
+/* Scratch provider: must return a device pointer to at least `nbytes` bytes that stays valid until
+ * the work enqueued by the current call has finished (rasterize_points.cu:27-33). */
+typedef char* (*gsr_alloc_fn)(size_t nbytes, void* user);
+
+/*
+ * Forward rasterization.  Returns num_rendered (>= 0: number of (tile, Gaussian) pairs, the
+ * reference's return value) or a negative gsr_status.
+ *
+ *   P  number of Gaussians;  D  active SH degree;  M  SH coefficients per Gaussian (0 if no shs)
+ *   exactly one of {shs, colors_precomp} and exactly one of {scales+rotations, cov3D_precomp}
+ *   radii may be NULL (then an internal array is used), every other output is required.
+ *   P == 0 is legal and returns 0 without touching any output (rasterize_points.cu:83).
+ */
+GSR_API int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user,
+                gsr_alloc_fn binning_alloc, void* binning_user,
+                gsr_alloc_fn image_alloc, void* image_user,
+                int P, int D, int M,
+                const float* background, int width, int height,
+                const float* means3D, const float* shs /*nullable*/,
+                const float* colors_precomp /*nullable*/, const float* opacities,
+                const float* scales /*nullable*/, float scale_modifier,
+                const float* rotations /*nullable*/, const float* cov3D_precomp /*nullable*/,
+                const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                float tan_fovx, float tan_fovy, int prefiltered,
+                float* out_color, float* out_depth, float* out_alpha, int* radii /*nullable*/,
+                int debug, void* stream);
+
+/* present[i] = (view-space z of means3D[i]) > 0.2 ; present is a device array of P bytes (bool). */
+GSR_API int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, void* stream);
+
+/* Declared so the binding surface is complete; returns GSR_ERR_UNSUPPORTED (backward is the
+ * first "next" row). */
+GSR_API int gsr_backward(void);
+
+/* ---- introspection (used by the parity tests and bench.py; not part of the reference API) ---- */
+
+/* Sub-arrays of the geometry / binning / image scratch, as byte offsets from the pointer the
+ * callback returned.  Offsets depend only on the sizes given. */
+typedef enum gsr_geom_slot {
+    GSR_GEOM_DEPTHS = 0,        /* f32[P]   view-space z (valid where radii > 0)                  */
+    GSR_GEOM_MEANS2D,           /* f32[2P]  pixel centre                                           */
+    GSR_GEOM_CONIC_OPACITY,     /* f32[4P]  inverse 2D covariance (xx,xy,yy) + opacity             */
+    GSR_GEOM_RGB,               /* f32[3P]  SH-evaluated colour (unused with colors_precomp)       */
+    GSR_GEOM_TILES_TOUCHED,     /* u32[P]   tiles in the splat's rectangle (0 = culled)            */
+    GSR_GEOM_INTERNAL_RADII,    /* i32[P]   used when the caller passes radii == NULL              */
+    GSR_GEOM_DEPTH_ORDER,       /* u32[P]   Gaussian ids, ascending (depth bits, id); culled last  */
+    GSR_GEOM_POINT_OFFSETS,     /* u32[P]   inclusive scan of tiles_touched in DEPTH_ORDER order   */
+    GSR_GEOM_NUM_SLOTS
+} gsr_geom_slot;
+
+typedef enum gsr_binning_slot {
+    GSR_BIN_POINT_LIST = 0,     /* u32[num_rendered] Gaussian ids sorted by (tile, depth bits, id) */
+    GSR_BIN_TILE_KEYS,          /* u32[num_rendered] tile id of each entry of POINT_LIST           */
+    GSR_BIN_NUM_SLOTS
+} gsr_binning_slot;
+
+typedef enum gsr_image_slot {
+    GSR_IMG_RANGES = 0,         /* u32[2T] [begin,end) into POINT_LIST per 16x16 tile; (0,0) if empty */
+    GSR_IMG_N_CONTRIB,          /* u32[W*H] 1-based list position of the last blended entry          */
+    GSR_IMG_NUM_SLOTS
+} gsr_image_slot;
+
+/* Valid after a gsr_forward call on this thread: where that call put each slot. */
+GSR_API int gsr_last_geom_offsets(size_t offsets[GSR_GEOM_NUM_SLOTS]);
+GSR_API int gsr_last_binning_offsets(size_t offsets[GSR_BIN_NUM_SLOTS]);
+GSR_API int gsr_last_image_offsets(size_t offsets[GSR_IMG_NUM_SLOTS]);
+
+/* Per-stage device timing of gsr_forward via hipEvents on `stream` (off by default). */
+typedef enum gsr_stage {
+    GSR_STAGE_PREPROCESS = 0,   /* per-Gaussian projection, covariance, SH                         */
+    GSR_STAGE_DEPTH_SORT,       /* radix sort of P depth keys                                       */
+    GSR_STAGE_SCAN,             /* inclusive scan of tile counts (+ the host read of num_rendered) */
+    GSR_STAGE_DUPLICATE,        /* (tile, id) pair expansion                                        */
+    GSR_STAGE_TILE_SORT,        /* stable radix sort of pairs by tile id                            */
+    GSR_STAGE_RANGES,           /* per-tile [begin,end)                                             */
+    GSR_STAGE_BLEND,            /* per-tile front-to-back compositing                               */
+    GSR_STAGE_NUM
+} gsr_stage;
+/* Enabling (or re-enabling) resets the per-thread record of timed calls. */
+GSR_API void gsr_set_stage_timing(int enable);
+/* Mean milliseconds per stage over the gsr_forward calls made on this thread since timing was
+ * enabled (at most the last 256; synchronises on their events).  Returns the number of calls
+ * averaged, or a negative gsr_status.  Early exits (P == 0, errors) are not recorded. */
+GSR_API int gsr_get_stage_times(float ms[GSR_STAGE_NUM]);
+
+GSR_API const char* gsr_last_error(void);
+GSR_API int gsr_abi_version(void);
+/* Name of the compiled code-object target ("gfx950"). */
+GSR_API const char* gsr_target_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H_INCLUDED */

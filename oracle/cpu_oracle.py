@@ -1,0 +1,137 @@
+"""ctypes front-end of the CPU oracle (oracle/gsr_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by ``__graft_entry__.smoke()`` and by the
+``cpu_baseline`` leg of bench.py.  The product (autovfx_amd/, diff_gaussian_rasterization/) never
+imports it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Dict, Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libgsr_oracle.so")
+_lib = None
+
+_F = ctypes.POINTER(ctypes.c_float)
+_U8 = ctypes.POINTER(ctypes.c_uint8)
+_U32 = ctypes.POINTER(ctypes.c_uint32)
+_U64 = ctypes.POINTER(ctypes.c_uint64)
+_I32 = ctypes.POINTER(ctypes.c_int32)
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "gsr_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libgsr_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.gsro_key_bits.restype = ctypes.c_uint32
+        L.gsro_key_bits.argtypes = [ctypes.c_uint32]
+        L.gsro_mark_visible.restype = None
+        L.gsro_mark_visible.argtypes = [ctypes.c_int, _F, _F, _F, _U8]
+        L.gsro_forward.restype = ctypes.c_int64
+        L.gsro_forward.argtypes = [
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, _F, ctypes.c_int, ctypes.c_int,  # P deg M bg W H
+            _F, _F, _F, _F, _F, ctypes.c_float, _F, _F,                                # means3D shs colors opac scales mod rots cov3D
+            _F, _F, _F, ctypes.c_float, ctypes.c_float,                                # view proj cam tanx tany
+            _F, _F, _F, _I32,                                                          # out_color out_depth out_alpha radii
+            _F, _F, _F, _F, _U32, _U32, _U32,                                          # means2D depths conop rgb tiles offsets ncontrib
+            ctypes.c_size_t, _U64, _U32, _U32]                                         # cap keys list ranges
+        _lib = L
+    return _lib
+
+
+def _f32(a) -> Optional[np.ndarray]:
+    if a is None:
+        return None
+    if hasattr(a, "detach"):
+        a = a.detach().cpu().numpy()
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a if a.size else None
+
+
+def _ptr(a, ty):
+    return ctypes.cast(None, ty) if a is None else a.ctypes.data_as(ty)
+
+
+def key_bits(num_tiles: int) -> int:
+    return int(lib().gsro_key_bits(num_tiles))
+
+
+def mark_visible(means3D, viewmatrix, projmatrix) -> np.ndarray:
+    m, v, p = _f32(means3D), _f32(viewmatrix), _f32(projmatrix)
+    P = 0 if m is None else m.shape[0]
+    out = np.zeros(P, dtype=np.uint8)
+    if P:
+        lib().gsro_mark_visible(P, _ptr(m, _F), _ptr(v, _F), _ptr(p, _F), _ptr(out, _U8))
+    return out.astype(bool)
+
+
+def forward(*, means3D, opacities, bg, width: int, height: int, viewmatrix, projmatrix, campos,
+            tanfovx: float, tanfovy: float, sh_degree: int = 0, scale_modifier: float = 1.0, shs=None,
+            colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
+            intermediates: bool = False) -> Dict[str, np.ndarray]:
+    """Run the restated forward pass; returns color[3,H,W], depth[1,H,W], alpha[1,H,W], radii[P],
+    num_rendered and (optionally) every intermediate of the pipeline."""
+    m = _f32(means3D)
+    P = 0 if m is None else int(m.shape[0])
+    H, W = int(height), int(width)
+    out = {
+        "color": np.zeros((3, H, W), np.float32), "depth": np.zeros((1, H, W), np.float32),
+        "alpha": np.zeros((1, H, W), np.float32), "radii": np.zeros(P, np.int32), "num_rendered": 0,
+    }
+    if P == 0:
+        return out
+    sh, col, sc, rot, cov = _f32(shs), _f32(colors_precomp), _f32(scales), _f32(rotations), _f32(cov3D_precomp)
+    if (sh is None) == (col is None):
+        raise ValueError("exactly one of shs / colors_precomp")
+    if ((sc is None or rot is None) and cov is None) or ((sc is not None or rot is not None) and cov is not None):
+        raise ValueError("exactly one of (scales, rotations) / cov3D_precomp")
+    M = 0 if sh is None else int(sh.shape[1])
+    op, bgv = _f32(opacities), _f32(bg)
+    vm, pm, cp = _f32(viewmatrix), _f32(projmatrix), _f32(campos)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    inter = {}
+    cap = 0
+    keys = lst = None
+    if intermediates:
+        inter = {"means2D": np.zeros((P, 2), np.float32), "depths": np.zeros(P, np.float32),
+                 "conic_opacity": np.zeros((P, 4), np.float32), "rgb": np.zeros((P, 3), np.float32),
+                 "tiles_touched": np.zeros(P, np.uint32), "point_offsets": np.zeros(P, np.uint32),
+                 "n_contrib": np.zeros((H, W), np.uint32), "ranges": np.zeros((T, 2), np.uint32)}
+    L = lib()
+
+    def call(cap, keys, lst):
+        return int(L.gsro_forward(
+            P, int(sh_degree), M, _ptr(bgv, _F), W, H, _ptr(m, _F), _ptr(sh, _F), _ptr(col, _F), _ptr(op, _F),
+            _ptr(sc, _F), float(scale_modifier), _ptr(rot, _F), _ptr(cov, _F), _ptr(vm, _F), _ptr(pm, _F),
+            _ptr(cp, _F), float(tanfovx), float(tanfovy), _ptr(out["color"], _F), _ptr(out["depth"], _F),
+            _ptr(out["alpha"], _F), _ptr(out["radii"], _I32), _ptr(inter.get("means2D"), _F),
+            _ptr(inter.get("depths"), _F), _ptr(inter.get("conic_opacity"), _F), _ptr(inter.get("rgb"), _F),
+            _ptr(inter.get("tiles_touched"), _U32), _ptr(inter.get("point_offsets"), _U32),
+            _ptr(inter.get("n_contrib"), _U32), cap, _ptr(keys, _U64), _ptr(lst, _U32),
+            _ptr(inter.get("ranges"), _U32)))
+
+    D = call(0, None, None)
+    if intermediates:
+        keys = np.zeros(max(D, 1), np.uint64)
+        lst = np.zeros(max(D, 1), np.uint32)
+        for k in ("color", "depth", "alpha"):
+            out[k].fill(0)
+        D = call(max(D, 1), keys, lst)
+        inter["point_list_keys"] = keys[:D]
+        inter["point_list"] = lst[:D]
+    out["num_rendered"] = D
+    out.update(inter)
+    return out

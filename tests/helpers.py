@@ -1,0 +1,104 @@
+"""Shared plumbing for the tests: run the same scene through the CPU oracle and the HIP library."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from autovfx_amd.cameras import Camera
+from autovfx_amd.scenes import GaussianCloud
+
+
+def oracle_kwargs(cloud: GaussianCloud, cam: Camera, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, sh_degree=None,
+                  cov3D_precomp=None):
+    kw = dict(means3D=cloud.means3D, opacities=cloud.opacities, bg=np.asarray(bg, np.float32),
+              width=cam.image_width, height=cam.image_height, viewmatrix=cam.world_view_transform,
+              projmatrix=cam.full_proj_transform, campos=cam.camera_center, tanfovx=cam.tanfovx,
+              tanfovy=cam.tanfovy, sh_degree=cloud.sh_degree if sh_degree is None else sh_degree,
+              scale_modifier=scale_modifier)
+    if cloud.colors_precomp is not None:
+        kw["colors_precomp"] = cloud.colors_precomp
+    else:
+        kw["shs"] = cloud.shs
+    if cov3D_precomp is not None:
+        kw["cov3D_precomp"] = cov3D_precomp
+    else:
+        kw["scales"] = cloud.scales
+        kw["rotations"] = cloud.rotations
+    return kw
+
+
+def settings_for(cam: Camera, device, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, sh_degree=3, prefiltered=False,
+                 debug=False):
+    from diff_gaussian_rasterization import GaussianRasterizationSettings
+    return GaussianRasterizationSettings(
+        image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=cam.tanfovx,
+        tanfovy=cam.tanfovy, bg=torch.tensor(bg, dtype=torch.float32, device=device),
+        scale_modifier=scale_modifier, viewmatrix=cam.world_view_transform.to(device),
+        projmatrix=cam.full_proj_transform.to(device), sh_degree=sh_degree,
+        campos=cam.camera_center.to(device), prefiltered=prefiltered, debug=debug)
+
+
+def run_hip(cloud: GaussianCloud, cam: Camera, device="cuda:0", bg=(0.0, 0.0, 0.0), scale_modifier=1.0,
+            sh_degree=None, cov3D_precomp=None, debug=False):
+    """Call the product exactly the way gaussian_renderer.render() does (reference
+    gaussian_renderer/__init__.py:101-159) and return numpy outputs."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    c = cloud.to(device)
+    st = settings_for(cam, device, bg, scale_modifier, cloud.sh_degree if sh_degree is None else sh_degree,
+                      debug=debug)
+    rast = GaussianRasterizer(st)
+    means2D = torch.zeros_like(c.means3D)
+    kw = {}
+    if cov3D_precomp is not None:
+        kw["cov3D_precomp"] = torch.as_tensor(cov3D_precomp, dtype=torch.float32, device=device)
+    else:
+        kw["scales"], kw["rotations"] = c.scales, c.rotations
+    with torch.no_grad():
+        color, depth, alpha, radii = rast(means3D=c.means3D, means2D=means2D, opacities=c.opacities, shs=c.shs,
+                                          colors_precomp=c.colors_precomp, **kw)
+    torch.cuda.synchronize()
+    return {"color": color.cpu().numpy(), "depth": depth.cpu().numpy(), "alpha": alpha.cpu().numpy(),
+            "radii": radii.cpu().numpy()}
+
+
+def hip_forward_raw(cloud: GaussianCloud, cam: Camera, device="cuda:0", bg=(0.0, 0.0, 0.0), scale_modifier=1.0,
+                    sh_degree=None, cov3D_precomp=None, debug=True):
+    """Call ``_C.rasterize_gaussians`` directly and decode every scratch sub-array."""
+    from diff_gaussian_rasterization import _C
+    c = cloud.to(device)
+    st = settings_for(cam, device, bg, scale_modifier, cloud.sh_degree if sh_degree is None else sh_degree)
+    e = torch.Tensor([])
+    cov = e if cov3D_precomp is None else torch.as_tensor(cov3D_precomp, dtype=torch.float32, device=device)
+    (n, color, depth, alpha, radii, geom, binning, img) = _C.rasterize_gaussians(
+        st.bg, c.means3D, e if c.colors_precomp is None else c.colors_precomp, c.opacities,
+        e if cov3D_precomp is not None else c.scales, e if cov3D_precomp is not None else c.rotations,
+        scale_modifier, cov, st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, st.image_height,
+        st.image_width, e if c.shs is None else c.shs, st.sh_degree, st.campos, False, debug)
+    torch.cuda.synchronize()
+    lay = _C.last_layout()
+    P, W, H = cloud.P, cam.image_width, cam.image_height
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+
+    def view(buf, off, dtype, count, shape=None):
+        nbytes = count * torch.tensor([], dtype=dtype).element_size()
+        t = buf[off:off + nbytes].view(dtype)
+        return (t.reshape(shape) if shape else t).cpu().numpy()
+
+    out = {"num_rendered": n, "color": color.cpu().numpy(), "depth": depth.cpu().numpy(),
+           "alpha": alpha.cpu().numpy(), "radii": radii.cpu().numpy()}
+    if P:
+        g = lay["geom"]
+        out["depths"] = view(geom, g["depths"], torch.float32, P)
+        out["means2D"] = view(geom, g["means2D"], torch.float32, 2 * P, (P, 2))
+        out["conic_opacity"] = view(geom, g["conic_opacity"], torch.float32, 4 * P, (P, 4))
+        out["rgb"] = view(geom, g["rgb"], torch.float32, 3 * P, (P, 3))
+        out["tiles_touched"] = view(geom, g["tiles_touched"], torch.int32, P).astype(np.uint32)
+        out["depth_order"] = view(geom, g["depth_order"], torch.int32, P).astype(np.uint32)
+        out["point_offsets"] = view(geom, g["point_offsets"], torch.int32, P).astype(np.uint32)
+        b = lay["binning"]
+        out["point_list"] = view(binning, b["point_list"], torch.int32, n).astype(np.uint32)
+        out["tile_keys"] = view(binning, b["tile_keys"], torch.int32, n).astype(np.uint32)
+        i = lay["image"]
+        out["ranges"] = view(img, i["ranges"], torch.int32, 2 * T, (T, 2)).astype(np.uint32)
+        out["n_contrib"] = view(img, i["n_contrib"], torch.int32, W * H, (H, W)).astype(np.uint32)
+    return out
