@@ -1,0 +1,69 @@
+"""Generate tests/golden/*.npz from the REFERENCE's own sources compiled for the host
+(oracle/_ref, see oracle/build_ref.py).  Run in the build container (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+Each fixture stores the *inputs* (so nothing about scene generation can drift) and every output
+and intermediate the reference produced for them.  tests/test_golden.py checks the C oracle
+bit-for-bit against these on CPU, and tests/test_parity_gpu.py checks the HIP path against them on
+the GPU box, where /root/reference does not exist.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from autovfx_amd import scenes  # noqa: E402
+from autovfx_amd.cameras import orbit_cameras  # noqa: E402
+from oracle import ref_oracle  # noqa: E402
+from helpers import oracle_kwargs  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def cases():
+    c = scenes.config_c1(P=1500, seed=101)
+    yield "sh3_c1mini_96x64", oracle_kwargs(c, scenes.c1_camera(96, 64), bg=(0.1, 0.2, 0.3))
+    for deg in (0, 1, 2, 4):
+        c = scenes.config_c1(P=600, seed=110 + deg)
+        yield f"sh{deg}_48x48", oracle_kwargs(c, scenes.c1_camera(48, 48), sh_degree=deg)
+    c = scenes.config_c4(P=3000, seed=120)
+    yield "precomp_flat_orbit_80x45", oracle_kwargs(c, orbit_cameras(8, 80, 45)[2], bg=(1.0, 1.0, 1.0))
+    c = scenes.config_c1(P=800, seed=130)
+    r, x, y, z = c.rotations.unbind(1)
+    R = torch.stack((1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                     2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                     2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)), 1).view(-1, 3, 3)
+    L = R @ torch.diag_embed(c.scales)
+    S = L @ L.transpose(1, 2)
+    cov = torch.stack((S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]), 1).contiguous()
+    yield "cov3d_precomp_50x70", oracle_kwargs(c, scenes.c1_camera(50, 70), cov3D_precomp=cov, scale_modifier=1.0)
+    c = scenes.config_c1(P=900, seed=140)
+    yield "scale_mod_ragged_33x17", oracle_kwargs(c, scenes.c1_camera(33, 17), scale_modifier=1.6, bg=(0.9, 0.1, 0.5))
+    c = scenes.config_c2(P=2500, seed=150)
+    c.scales *= 6.0
+    yield "orbit_normal_cloud_112x63", oracle_kwargs(c, orbit_cameras(20, 112, 63)[7])
+    c = scenes.config_c1(P=400, seed=160)
+    c.means3D[:, 2] = 0.0      # one depth plane: order decided by the tie rule
+    c.scales[:30] *= 25.0      # some screen-filling splats
+    yield "ties_and_big_splats_64x64", oracle_kwargs(c, scenes.c1_camera(64, 64))
+
+
+def main():
+    for name, kw in cases():
+        out = ref_oracle.forward(intermediates=True, **kw)
+        inputs = {"in_" + k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v))
+                  for k, v in kw.items() if v is not None}
+        outputs = {"out_" + k: np.asarray(v) for k, v in out.items()}
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **inputs, **outputs)
+        print(f"{name}: P={kw['means3D'].shape[0]} D={out['num_rendered']} -> {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,100 @@
+"""The C-ABI shared library: loads without a GPU, exports every symbol include/gsr.h declares,
+agrees with the Python mirrors of its enums, and rejects bad calls without touching a device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(ROOT, "include", "gsr.h")).read()
+
+
+def declared_functions():
+    return re.findall(r"GSR_API\s+[\w\s\*]+?\b(gsr_\w+)\s*\(", HEADER)
+
+
+def enum_members(name):
+    body = re.search(r"typedef enum " + name + r"\s*\{(.*?)\}", HEADER, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    return [m for m in re.findall(r"\b(GSR_\w+)\b", body)]
+
+
+def test_header_declares_the_reference_entry_points():
+    fns = declared_functions()
+    for must in ("gsr_forward", "gsr_mark_visible", "gsr_backward", "gsr_last_error"):
+        assert must in fns
+    # every entry point cites the reference interface it replaces
+    for cite in ("rasterizer.h:31-55", "rasterizer.h:24-29", "rasterizer.h:57-90", "rasterize_points.cu:36-119"):
+        assert cite in HEADER
+
+
+def test_library_exports_every_declared_symbol():
+    from autovfx_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    fns = declared_functions()
+    assert sorted(fns) == sorted(_lib.SYMBOLS)
+    for f in fns:
+        assert hasattr(lib, f), f"{f} not exported"
+    assert _lib.lib.gsr_abi_version() == int(re.search(r"#define GSR_ABI_VERSION (\d+)", HEADER).group(1))
+    assert _lib.lib.gsr_target_arch() == b"gfx950"
+
+
+def test_enum_mirrors_match_header():
+    from autovfx_amd import _lib
+    to_name = lambda members, prefix: tuple(m[len(prefix):].lower() for m in members if not m.endswith("NUM_SLOTS") and m != "GSR_STAGE_NUM")
+    assert to_name(enum_members("gsr_geom_slot"), "GSR_GEOM_") == tuple(s.lower() for s in _lib.GEOM_SLOTS)
+    assert to_name(enum_members("gsr_binning_slot"), "GSR_BIN_") == _lib.BIN_SLOTS
+    assert to_name(enum_members("gsr_image_slot"), "GSR_IMG_") == _lib.IMG_SLOTS
+    assert to_name(enum_members("gsr_stage"), "GSR_STAGE_") == _lib.STAGES
+
+
+def test_argument_errors_do_not_need_a_device():
+    from autovfx_amd import _lib
+    L = _lib.lib
+    assert L.gsr_backward() == -4 and "not built" in _lib.last_error()
+    assert L.gsr_mark_visible(-1, None, None, None, None, None) == -1
+    assert L.gsr_mark_visible(0, None, None, None, None, None) == 0
+    null_cb = ctypes.cast(None, _lib.ALLOC_FN)
+    args = [null_cb, None, null_cb, None, null_cb, None]
+    tail = [None] * 4 + [0, None]
+    # P == 0 returns 0 before anything else is looked at (rasterize_points.cu:83)
+    assert L.gsr_forward(*args, 0, 3, 16, None, 64, 64, None, None, None, None, None, 1.0, None, None, None, None,
+                         None, 0.5, 0.5, 0, *tail) == 0
+    assert L.gsr_forward(*args, 5, 3, 16, None, 0, 64, None, None, None, None, None, 1.0, None, None, None, None,
+                         None, 0.5, 0.5, 0, *tail) == -1
+    assert L.gsr_forward(*args, 5, 3, 16, None, 64, 64, None, None, None, None, None, 1.0, None, None, None, None,
+                         None, 0.5, 0.5, 0, *tail) == -1
+    assert "null" in _lib.last_error()
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    import importlib
+    import sys
+    monkeypatch.setenv("GSR_LIB", str(tmp_path / "nope.so"))
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k.startswith(("autovfx_amd._lib", "diff_gaussian_rasterization"))}
+    import autovfx_amd
+    monkeypatch.delattr(autovfx_amd, "_lib", raising=False)   # `from autovfx_amd import _lib` must re-import
+    try:
+        with pytest.raises(ImportError, match="no CPU fallback"):
+            importlib.import_module("autovfx_amd._lib")
+        with pytest.raises(ImportError):
+            importlib.import_module("diff_gaussian_rasterization")
+    finally:
+        for k in list(sys.modules):
+            if k.startswith(("autovfx_amd._lib", "diff_gaussian_rasterization")):
+                sys.modules.pop(k)
+        sys.modules.update(saved)
+
+
+def test_cpu_tensors_are_rejected_not_silently_handled():
+    import torch
+    from autovfx_amd import scenes
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from helpers import settings_for
+    c = scenes.config_c1(P=4)
+    rast = GaussianRasterizer(settings_for(scenes.c1_camera(16, 16), "cpu"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        rast(c.means3D, torch.zeros_like(c.means3D), c.opacities, shs=c.shs, scales=c.scales, rotations=c.rotations)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        rast.markVisible(c.means3D)

@@ -1,0 +1,76 @@
+"""The N > 1 path on CPU: two ``gloo`` ranks shard a trajectory round-robin, render their frames with
+a stand-in renderer (the CPU oracle -- tests may use it, the product path never does) and gather to
+rank 0; the result must equal the single-process run frame for frame."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from autovfx_amd import frame_parallel as fp
+from autovfx_amd import scenes
+from autovfx_amd.cameras import orbit_cameras
+
+
+def oracle_render(cloud, cam, bg):
+    from oracle import cpu_oracle
+    r = cpu_oracle.forward(means3D=cloud.means3D, opacities=cloud.opacities, bg=bg.numpy(), width=cam.image_width,
+                           height=cam.image_height, viewmatrix=cam.world_view_transform,
+                           projmatrix=cam.full_proj_transform, campos=cam.camera_center, tanfovx=cam.tanfovx,
+                           tanfovy=cam.tanfovy, sh_degree=cloud.sh_degree, shs=cloud.shs, scales=cloud.scales,
+                           rotations=cloud.rotations)
+    return (torch.from_numpy(r["color"]), torch.from_numpy(r["depth"]), torch.from_numpy(r["alpha"]),
+            torch.from_numpy(r["radii"]))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, num_frames, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cloud = scenes.config_c1(P=300, seed=2)
+        cams = orbit_cameras(num_frames, 40, 24)
+        res = fp.render_trajectory(cloud, cams, torch.zeros(3), keep_depth=True, render_fn=oracle_render)
+        if rank == 0:
+            torch.save(res, out_path)
+        else:
+            assert res is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_frames_round_robin():
+    assert fp.shard_frames(10, 0, 4) == [0, 4, 8]
+    assert fp.shard_frames(10, 3, 4) == [3, 7]
+    assert fp.shard_frames(2, 3, 4) == []
+    got = sorted(sum((fp.shard_frames(801, r, 8) for r in range(8)), []))
+    assert got == list(range(801))
+    with pytest.raises(ValueError):
+        fp.shard_frames(4, 4, 4)
+
+
+def test_pack_rgba8_is_save_image_rounding():
+    x = torch.tensor([0.0, 0.5 / 255, 1.49 / 255, 0.999, 1.0, 1.7, -0.2]).view(1, 1, -1)
+    q = fp.pack_rgba8(x.repeat(3, 1, 1), x)
+    np.testing.assert_array_equal(q[0, 0].numpy(), [0, 1, 1, 255, 255, 255, 0])
+
+
+@pytest.mark.parametrize("num_frames", [5, 4])
+def test_two_rank_gloo_matches_single_process(tmp_path, num_frames):
+    out = str(tmp_path / "gathered.pt")
+    mp.spawn(_worker, args=(2, _free_port(), num_frames, out), nprocs=2, join=True)
+    got = torch.load(out)
+    cloud = scenes.config_c1(P=300, seed=2)
+    cams = orbit_cameras(num_frames, 40, 24)
+    ref = fp.render_trajectory(cloud, cams, torch.zeros(3), keep_depth=True, render_fn=oracle_render)
+    assert got["rgba8"].shape == (num_frames, 4, 24, 40) and got["rgba8"].dtype == torch.uint8
+    assert torch.equal(got["rgba8"], ref["rgba8"]) and torch.equal(got["depth"], ref["depth"])
+    assert len({bytes(f.numpy().tobytes()) for f in got["rgba8"]}) == num_frames   # frames differ: order is checked

@@ -1,0 +1,63 @@
+"""Host-side logic that needs no GPU: camera conventions, trajectory schema, the launch-syntax
+rewriter of oracle/build_ref.py, and bench.py's algorithmic-bytes formula."""
+import json
+import math
+
+import numpy as np
+import torch
+
+from autovfx_amd import cameras as cams
+
+
+def test_projection_matrix_layout():
+    """graphics_utils.py:52-72: P[0,0]=2n/(r-l), P[1,1]=2n/(t-b), P[3,2]=1, P[2,2]=f/(f-n), P[2,3]=-fn/(f-n)."""
+    fx, fy = math.radians(60), math.radians(40)
+    P = cams.projection_matrix(0.01, 100.0, fx, fy)
+    assert abs(P[0, 0] - 1 / math.tan(fx / 2)) < 1e-6 and abs(P[1, 1] - 1 / math.tan(fy / 2)) < 1e-6
+    assert P[3, 2] == 1 and abs(P[2, 2] - 100 / 99.99) < 1e-6 and abs(P[2, 3] + 1 / 99.99) < 1e-6
+    assert P[0, 2] == 0 and P[1, 2] == 0
+
+
+def test_camera_matrices_are_transposed_and_consistent():
+    c2w = cams.orbit_c2w(4.0, 12, 30.0)[5]
+    cam = cams.Camera.from_c2w(c2w, 500.0, 500.0, 640, 360)
+    w2c = np.linalg.inv(c2w).astype(np.float32)
+    np.testing.assert_allclose(cam.world_view_transform.numpy(), w2c.T, atol=1e-6)
+    np.testing.assert_allclose(cam.camera_center.numpy(), c2w[:3, 3], atol=1e-5)
+    full = (cam.projection_matrix.numpy().T @ w2c).T
+    np.testing.assert_allclose(cam.full_proj_transform.numpy(), full, atol=1e-5)
+    assert abs(cams.fov2focal(cam.FoVx, 640) - 500.0) < 1e-3
+    # the orbit looks at the origin: it projects to the image centre, in front of the camera
+    o = np.array([0, 0, 0, 1], np.float32) @ cam.full_proj_transform.numpy()
+    assert abs(o[0] / o[3]) < 1e-5 and abs(o[1] / o[3]) < 1e-5 and o[3] > 0.2
+    assert abs(np.linalg.norm(cam.camera_center.numpy()) - 4.0) < 1e-4
+
+
+def test_trajectory_json_roundtrip(tmp_path):
+    poses = cams.orbit_c2w(4.0, 7)
+    d = cams.trajectory_dict("orbit", poses[::-1], 400.0, 410.0, 320.0, 180.0, 640, 360)
+    assert [f["filename"] for f in d["frames"]][:2] == ["00000.png", "00001.png"] and d["camera_model"] == "OPENCV"
+    p = tmp_path / "t.json"
+    p.write_text(json.dumps(d))
+    got = cams.cameras_from_trajectory(str(p), downscale_factor=2.0)
+    assert len(got) == 7 and got[0].image_width == 320 and got[0].image_height == 180
+    np.testing.assert_allclose(got[0].camera_center.numpy(), poses[-1][:3, 3], atol=1e-5)
+    assert abs(cams.fov2focal(got[0].FoVx, 320) - 200.0) < 1e-3
+
+
+def test_launch_rewriter():
+    from oracle.build_ref import rewrite_launches
+    src = "a();\nfoo<3> << <(P + 255) / 256, 256 >> > (\n  x, f(y, z));\nbar << <grid, block >> > (q)\nCHECK(, d)"
+    out = rewrite_launches(src)
+    assert "<<" not in out
+    assert "gsr_shim::launch(dim3((P + 255) / 256), dim3(256), [&]() { foo<3>(\n  x, f(y, z)); })" in out
+    assert "gsr_shim::launch(dim3(grid), dim3(block), [&]() { bar(q); })\nCHECK(, d)" in out
+
+
+def test_algorithmic_bytes_worked_example():
+    """C3 with V = 2.4 M, D = 15 M -> about 3.94 GB per frame, 6 sort passes."""
+    import bench
+    b = bench.algorithmic_bytes(3_000_000, 2_400_000, 15_000_000, 8160, 1920, 1080, 16)
+    assert b["n_pass"] == 6
+    assert abs(b["frame"] / 1e9 - 3.94) < 0.02
+    assert b["blend"] == 44 * 15_000_000 + 24 * 1920 * 1080
