@@ -25,7 +25,9 @@ ABI_VERSION = 1
 # every symbol include/gsr.h declares
 SYMBOLS = ("gsr_forward", "gsr_mark_visible", "gsr_backward", "gsr_last_geom_offsets", "gsr_last_binning_offsets",
            "gsr_last_image_offsets", "gsr_set_stage_timing", "gsr_get_stage_times", "gsr_last_error",
-           "gsr_abi_version", "gsr_target_arch")
+           "gsr_abi_version", "gsr_target_arch", "gsr_set_option", "gsr_get_option")
+OPT_TILE_CULL = 0
+OPT_BLEND_VARIANT = 1
 
 
 class GsrLibraryError(ImportError):
@@ -63,6 +65,10 @@ def _load() -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.POINTER(ctypes.c_size_t * n)]
+    lib.gsr_set_option.restype = ctypes.c_int
+    lib.gsr_set_option.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.gsr_get_option.restype = ctypes.c_int
+    lib.gsr_get_option.argtypes = [ctypes.c_int]
     lib.gsr_set_stage_timing.restype = None
     lib.gsr_set_stage_timing.argtypes = [ctypes.c_int]
     lib.gsr_get_stage_times.restype = ctypes.c_int
@@ -92,6 +98,15 @@ def offsets(kind: str) -> dict:
     if fn(ctypes.byref(arr)) != 0:
         raise RuntimeError(last_error())
     return dict(zip(names, (int(v) for v in arr)))
+
+
+def set_option(option: int, value: int) -> None:
+    if lib.gsr_set_option(int(option), int(value)) != 0:
+        raise RuntimeError(last_error())
+
+
+def get_option(option: int) -> int:
+    return int(lib.gsr_get_option(int(option)))
 
 
 def set_stage_timing(enable: bool) -> None:

@@ -23,6 +23,7 @@ thread_local bool g_have_offsets = false;
 // synchronising between calls.
 constexpr int kTimingRing = 256;
 constexpr int kEventsPerCall = GSR_STAGE_NUM + 1;
+int g_options[GSR_OPT_NUM] = {/*GSR_OPT_TILE_CULL*/ 1, /*GSR_OPT_BLEND_VARIANT*/ 1};
 bool g_timing = false;
 thread_local hipEvent_t g_ev[kTimingRing][kEventsPerCall];
 thread_local bool g_ev_made = false;
@@ -100,6 +101,16 @@ const char* gsr_last_error(void) { return g_error; }
 int gsr_abi_version(void) { return GSR_ABI_VERSION; }
 const char* gsr_target_arch(void) { return "gfx950"; }
 int gsr_backward(void) { return fail(GSR_ERR_UNSUPPORTED, "gsr_backward is not built yet (SURVEY.md 8f-1)"); }
+
+int gsr_set_option(int option, int value) {
+    if (option < 0 || option >= GSR_OPT_NUM) return fail(GSR_ERR_INVALID_ARG, "unknown option %d", option);
+    g_options[option] = value;
+    return GSR_OK;
+}
+int gsr_get_option(int option) {
+    if (option < 0 || option >= GSR_OPT_NUM) return fail(GSR_ERR_INVALID_ARG, "unknown option %d", option);
+    return g_options[option];
+}
 
 void gsr_set_stage_timing(int enable) {
     g_timing = enable != 0;
@@ -289,7 +300,8 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     uint32_t* n_contrib = (uint32_t*)(iraw + g_img_off[GSR_IMG_N_CONTRIB]);
 
     if (num_rendered > 0) {
-        GSR_HIP(gsr::launch_duplicate(P, cam, order, point_offsets, ga.means2D, ga.radii, tile_keys, point_list, stream));
+        GSR_HIP(gsr::launch_duplicate(P, cam, g_options[GSR_OPT_TILE_CULL] != 0, order, point_offsets, ga.means2D,
+                                      ga.conic_opacity, ga.radii, tile_keys, point_list, stream));
         GSR_STAGE_CHECK("duplicate");
         stamp(4, stream);
         uint32_t *tk_sorted = nullptr, *pl_sorted = nullptr;
@@ -312,7 +324,7 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     g_bin_off[GSR_BIN_TILE_KEYS] = (size_t)((char*)tile_keys - braw);
 
     const float* features = colors_precomp != nullptr ? colors_precomp : ga.rgb;
-    GSR_HIP(gsr::launch_blend(cam, ranges, point_list, ga.means2D, features, ga.depths, ga.conic_opacity, background,
+    GSR_HIP(gsr::launch_blend(cam, g_options[GSR_OPT_BLEND_VARIANT], ranges, point_list, ga.means2D, features, ga.depths, ga.conic_opacity, background,
                               out_color, out_depth, out_alpha, n_contrib, stream));
     GSR_STAGE_CHECK("blend");
     stamp(7, stream);

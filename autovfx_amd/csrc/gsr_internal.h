@@ -48,15 +48,16 @@ hipError_t launch_preprocess(const GaussianInputs& in, const Camera& cam, const 
                              hipStream_t stream);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
                                hipStream_t stream);
-hipError_t launch_duplicate(int P, const Camera& cam, const uint32_t* depth_order, const uint32_t* point_offsets,
-                            const float2* means2D, const int* radii, uint32_t* tile_keys, uint32_t* point_list,
-                            hipStream_t stream);
+hipError_t launch_duplicate(int P, const Camera& cam, bool cull, const uint32_t* depth_order,
+                            const uint32_t* point_offsets, const float2* means2D, const float4* conic_opacity,
+                            const int* radii, uint32_t* tile_keys, uint32_t* point_list, hipStream_t stream);
 hipError_t launch_tile_ranges(uint32_t num_rendered, int num_tiles, const uint32_t* sorted_tile_keys,
                               uint2* ranges, hipStream_t stream);
-hipError_t launch_blend(const Camera& cam, const uint2* ranges, const uint32_t* point_list, const float2* means2D,
-                        const float* features, const float* depths, const float4* conic_opacity,
-                        const float* background, float* out_color, float* out_depth, float* out_alpha,
-                        uint32_t* n_contrib, hipStream_t stream);
+// variant 0: one wave per tile, 4 pixels per lane; variant 1: one wave per 8x8 quadrant
+hipError_t launch_blend(const Camera& cam, int variant, const uint2* ranges, const uint32_t* point_list,
+                        const float2* means2D, const float* features, const float* depths,
+                        const float4* conic_opacity, const float* background, float* out_color, float* out_depth,
+                        float* out_alpha, uint32_t* n_contrib, hipStream_t stream);
 
 // ---- device-wide primitives (gsr_sort.hip) ----
 // All three follow the two-call protocol: with temp == nullptr they only report temp_bytes.

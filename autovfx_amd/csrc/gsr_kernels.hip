@@ -22,9 +22,9 @@
 //     and a screen-filling splat does not serialise one lane;
 //   * tile ranges come from two binary searches per tile over the sorted tile keys (no memset,
 //     no pass over all pairs);
-//   * one wave64 blends one 16x16 tile, each lane owning a 2x2 pixel quad: no workgroup barriers,
-//     wave-exact early exit, per-entry LDS broadcast reads amortised over 4 pixels, and an exact
-//     pre-test that skips expf for pairs that cannot reach alpha >= 1/255.
+//   * one wave64 blends one 16x16 tile, each lane owning one pixel per 8x8 quadrant: no workgroup
+//     barriers, wave-exact early exit, per-entry LDS broadcast reads amortised over 4 pixels, and
+//     an exact pre-test that skips expf for pairs that cannot reach alpha >= 1/255.
 #include "gsr_internal.h"
 
 namespace gsr {
@@ -249,15 +249,51 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* _
 }
 
 // ------------------------------------------------------------------------------------------------
+// Exact-image tile culling.  The reference pairs a splat with every tile of the bounding square of
+// its 3-sigma circle; for many of those tiles no pixel can reach alpha >= 1/255, so the blend
+// would skip the pair at every pixel.  This predicate returns false only when that is provable:
+// with q(d) = 0.5 (A dx^2 + C dy^2) + B dx dy  (power = -q, forward.cu:338), alpha >= 1/255 needs
+// q <= ln(255 o); q is convex, so its minimum over the tile's pixel rectangle is 0 if the centre is
+// inside and otherwise lies on one of the four edges, where it has a closed form.  The comparison
+// keeps a 0.2 % + 1e-3 margin, ~10x the worst-case fp32 rounding of q for |rho| < 0.995
+// (error <= 4e-7 (1+|rho|)/(1-|rho|) q); anything less regular is never culled.  Dropping such a
+// pair cannot change any pixel, bit for bit (tests compare culled and unculled renders exactly).
+// The same predicate on an 8x8 quadrant lets the quadrant blend skip list entries wholesale.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float edge_q(float A, float B, float C, float dx, float dy) {
+    return 0.5f * (A * dx * dx + C * dy * dy) + B * dx * dy;
+}
+
+// Pixel rectangle [px_first, px_first + w - 1] x [py_first, py_first + h - 1].
+__device__ __forceinline__ bool splat_reaches_rect(float4 co, float2 c, int px_first, int py_first, int w, int h) {
+    const float A = co.x, B = co.y, C = co.z;
+    if (!(A > 0.f) || !(C > 0.f) || !((B * B) < 0.99f * (A * C))) return true;
+    const float budget = logf(255.0f * co.w);  // o <= 0 gives -inf (nothing visible), NaN keeps the pair
+    const float x_lo = c.x - (float)(px_first + w - 1), x_hi = c.x - (float)px_first;
+    const float y_lo = c.y - (float)(py_first + h - 1), y_hi = c.y - (float)py_first;
+    if (x_lo <= 0.f && x_hi >= 0.f && y_lo <= 0.f && y_hi >= 0.f) return true;  // centre inside the rectangle
+    float qmin = edge_q(A, B, C, x_lo, fminf(y_hi, fmaxf(y_lo, -(B * x_lo) / C)));
+    qmin = fminf(qmin, edge_q(A, B, C, x_hi, fminf(y_hi, fmaxf(y_lo, -(B * x_hi) / C))));
+    qmin = fminf(qmin, edge_q(A, B, C, fminf(x_hi, fmaxf(x_lo, -(B * y_lo) / A)), y_lo));
+    qmin = fminf(qmin, edge_q(A, B, C, fminf(x_hi, fmaxf(x_lo, -(B * y_hi) / A)), y_hi));
+    return !(qmin * 0.998f - 1.0e-3f > budget);
+}
+
+__device__ __forceinline__ bool splat_reaches_tile(float4 co, float2 c, int tile_x, int tile_y) {
+    return splat_reaches_rect(co, c, tile_x * kTile, tile_y * kTile, kTile, kTile);
+}
+
+// ------------------------------------------------------------------------------------------------
 // K3: wave-cooperative pair expansion in depth order.  Lane L of a wave owns sorted position
 // k = wave_base + L; the wave's pairs occupy [offsets[k0-1], offsets[k0+63]) contiguously, and all
 // 64 lanes stride over that flat range, locating the owning Gaussian by binary search on the
 // lanes' inclusive counts (6 ds_bpermute steps).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) duplicate_kernel(int P, int grid_x, int grid_y,
+__global__ void __launch_bounds__(256) duplicate_kernel(int P, int grid_x, int grid_y, int cull,
                                                         const uint32_t* __restrict__ depth_order,
                                                         const uint32_t* __restrict__ point_offsets,
                                                         const float2* __restrict__ means2D,
+                                                        const float4* __restrict__ conic_opacity,
                                                         const int* __restrict__ radii,
                                                         uint32_t* __restrict__ tile_keys,
                                                         uint32_t* __restrict__ point_list) {
@@ -300,7 +336,12 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, int grid_x, int g
         if (t < total) {
             const uint32_t local = t - o_excl;
             const uint32_t row = local / o_w, col = local - row * o_w;
-            const uint32_t tile = ((o_xy0 >> 16) + row) * (uint32_t)grid_x + (o_xy0 & 0xFFFFu) + col;
+            const uint32_t tx = (o_xy0 & 0xFFFFu) + col, ty = (o_xy0 >> 16) + row;
+            uint32_t tile = ty * (uint32_t)grid_x + tx;
+            // a culled pair keeps its slot but gets the key one past the last tile: the stable tile
+            // sort parks it behind every live pair and no range ever covers it
+            if (cull && !splat_reaches_tile(conic_opacity[o_gid], means2D[o_gid], (int)tx, (int)ty))
+                tile = (uint32_t)(grid_x * grid_y);
             tile_keys[base + t] = tile;
             point_list[base + t] = o_gid;
         }
@@ -331,7 +372,10 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(uint32_t n, int num_ti
 }
 
 // ------------------------------------------------------------------------------------------------
-// K6: one wave64 per 16x16 tile, lane = 2x2 pixel quad (lane & 7, lane >> 3).
+// K6: one wave64 per 16x16 tile.  Lane (lane & 7, lane >> 3) owns the pixel at that position in
+// each of the tile's four 8x8 quadrants (pixel q sits in quadrant q).  The test part of the inner
+// loop shares dx/dy between the four pixels; the exact part runs once per quadrant and is skipped
+// wave-uniformly for quadrants the splat does not reach, which is most of them for small splats.
 //
 // Per batch of 64 list entries every lane gathers one entry (id -> xy, conic+opacity, rgb, depth)
 // and parks it in LDS; the wave then walks the batch reading each entry as a broadcast (all lanes
@@ -357,7 +401,7 @@ __device__ __forceinline__ int xcd_band_tile(int b, int T) {
     return xcd * q + min(xcd, r) + local;
 }
 
-__global__ void __launch_bounds__(64) blend_kernel(int W, int H, int grid_x, int num_tiles,
+__global__ void __launch_bounds__(64, 8) blend_kernel(int W, int H, int grid_x, int num_tiles,
                                                    const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ point_list,
                                                    const float2* __restrict__ means2D,
@@ -376,13 +420,15 @@ __global__ void __launch_bounds__(64) blend_kernel(int W, int H, int grid_x, int
     const int tile = xcd_band_tile(blockIdx.x, num_tiles);
     const int lane = threadIdx.x;
     const int tile_x = tile % grid_x, tile_y = tile / grid_x;
-    const int px0 = tile_x * kTile + 2 * (lane & 7);
-    const int py0 = tile_y * kTile + 2 * (lane >> 3);
-    const float fx0 = (float)px0, fx1 = (float)(px0 + 1);
-    const float fy0 = (float)py0, fy1 = (float)(py0 + 1);
+    constexpr int kQ = kTile / 2;  // quadrant edge
+    const int px0 = tile_x * kTile + (lane & 7);
+    const int py0 = tile_y * kTile + (lane >> 3);
+    const float fx0 = (float)px0, fx1 = (float)(px0 + kQ);
+    const float fy0 = (float)py0, fy1 = (float)(py0 + kQ);
 
-    // pixel q = 2*row + col of the quad
-    bool inside[4] = {px0 < W && py0 < H, px0 + 1 < W && py0 < H, px0 < W && py0 + 1 < H, px0 + 1 < W && py0 + 1 < H};
+    // pixel q lives in quadrant q = 2*row + col
+    bool inside[4] = {px0 < W && py0 < H, px0 + kQ < W && py0 < H, px0 < W && py0 + kQ < H,
+                      px0 + kQ < W && py0 + kQ < H};
     bool done[4] = {!inside[0], !inside[1], !inside[2], !inside[3]};
     float T[4] = {1.f, 1.f, 1.f, 1.f};
     float Cr[4] = {0.f, 0.f, 0.f, 0.f}, Cg[4] = {0.f, 0.f, 0.f, 0.f}, Cb[4] = {0.f, 0.f, 0.f, 0.f};
@@ -469,13 +515,132 @@ __global__ void __launch_bounds__(64) blend_kernel(int W, int H, int grid_x, int
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (!inside[q]) continue;
-        const size_t pid = (size_t)W * (size_t)(py0 + (q >> 1)) + (size_t)(px0 + (q & 1));
+        const size_t pid = (size_t)W * (size_t)(py0 + kQ * (q >> 1)) + (size_t)(px0 + kQ * (q & 1));
         out_alpha[pid] = 1.f - T[q];
         if (n_contrib != nullptr) n_contrib[pid] = last[q];
         out_color[pid] = Cr[q] + T[q] * bg0;
         out_color[plane + pid] = Cg[q] + T[q] * bg1;
         out_color[2 * plane + pid] = Cb[q] + T[q] * bg2;
         out_depth[pid] = Dz[q];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6q: one wave64 per 8x8 QUADRANT of a 16x16 tile (4 single-wave workgroups per tile), one pixel
+// per lane.  Same list, same per-pixel arithmetic as blend_kernel; what changes is the shape of
+// the work:
+//   * four times as many, four times smaller work items: a tile whose list is long or never
+//     saturates no longer pins one wave for the whole launch, and a quadrant stops as soon as ITS
+//     64 pixels are done;
+//   * while staging a batch of 64 entries each lane also runs the conservative reach test of its
+//     entry against this quadrant; the wave then walks only the set bits of the ballot, so entries
+//     that cannot touch the quadrant cost no LDS read and no per-pixel work at all.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int grid_x, int num_tiles,
+                                                            const uint2* __restrict__ ranges,
+                                                            const uint32_t* __restrict__ point_list,
+                                                            const float2* __restrict__ means2D,
+                                                            const float* __restrict__ features,
+                                                            const float* __restrict__ depths,
+                                                            const float4* __restrict__ conic_opacity,
+                                                            const float* __restrict__ background,
+                                                            float* __restrict__ out_color,
+                                                            float* __restrict__ out_depth,
+                                                            float* __restrict__ out_alpha,
+                                                            uint32_t* __restrict__ n_contrib) {
+    __shared__ BlendEntryA sA[64];
+    __shared__ BlendEntryB sB[64];
+    __shared__ BlendEntryC sC[64];
+    __shared__ float sD[64];
+
+    constexpr int kQ = kTile / 2;
+    const int item = xcd_band_tile(blockIdx.x, 4 * num_tiles);  // the 4 quadrants of a tile share an XCD
+    const int tile = item >> 2, quad = item & 3;
+    const int lane = threadIdx.x;
+    const int qx0 = (tile % grid_x) * kTile + kQ * (quad & 1);
+    const int qy0 = (tile / grid_x) * kTile + kQ * (quad >> 1);
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const float fx = (float)px, fy = (float)py;
+    const bool inside = px < W && py < H;
+    bool done = !inside;
+    if (__all(done)) return;  // quadrant entirely outside the image: nothing to write
+
+    float T = 1.f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dz = 0.f;
+    uint32_t last = 0u;
+
+    const uint2 range = ranges[tile];
+    const uint32_t count = range.y - range.x;
+
+    float2 g_xy = make_float2(0.f, 0.f);
+    float4 g_co = make_float4(0.f, 0.f, 0.f, 0.f);
+    F3 g_rgb = {0.f, 0.f, 0.f};
+    float g_z = 0.f;
+    auto gather = [&](uint32_t first) {
+        const uint32_t e = first + (uint32_t)lane;
+        if (e < count) {
+            const uint32_t id = point_list[range.x + e];
+            g_xy = means2D[id];
+            g_co = conic_opacity[id];
+            g_rgb = ld3(features + 3 * (size_t)id);
+            g_z = depths[id];
+        }
+    };
+    if (count > 0) gather(0);
+
+    for (uint32_t first = 0; first < count; first += 64) {
+        const bool mine = first + (uint32_t)lane < count;
+        unsigned long long todo = __ballot(mine && splat_reaches_rect(g_co, g_xy, qx0, qy0, kQ, kQ));
+        if (todo != 0ull) {
+            __syncthreads();  // single-wave workgroup: orders this wave's LDS reads / writes only
+            sA[lane] = BlendEntryA{g_xy.x, g_xy.y, g_co.x, g_co.y};
+            sB[lane] = BlendEntryB{g_co.z, -logf(255.0f * g_co.w) - 1.0e-4f};
+            sC[lane] = BlendEntryC{g_co.w, g_rgb.x, g_rgb.y, g_rgb.z};
+            sD[lane] = g_z;
+            __syncthreads();
+        }
+        if (first + 64 < count) gather(first + 64);
+
+        while (todo != 0ull) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const BlendEntryA a = sA[j];
+            const BlendEntryB b = sB[j];
+            const float dx = a.x - fx, dy = a.y - fy;
+            const float power = -0.5f * (a.cxx * dx * dx + b.cyy * dy * dy) - a.cxy * dx * dy;
+            const bool live = !done && !(power > 0.0f) && !(power < b.skip_below);
+            if (!__any(live)) continue;
+            if (live) {
+                const BlendEntryC c = sC[j];
+                const float alpha = fminf(0.99f, c.opacity * expf(power));
+                if (!(alpha < 1.0f / 255.0f)) {
+                    const float test_T = T * (1.f - alpha);
+                    if (test_T < 0.0001f) {
+                        done = true;
+                    } else {
+                        const float z = sD[j];
+                        Cr += c.r * alpha * T;
+                        Cg += c.g * alpha * T;
+                        Cb += c.b * alpha * T;
+                        Dz += z * alpha * T;
+                        T = test_T;
+                        last = first + (uint32_t)j + 1u;
+                    }
+                }
+            }
+            if (__all(done)) break;
+        }
+        if (__all(done)) break;
+    }
+
+    if (inside) {
+        const size_t plane = (size_t)W * (size_t)H;
+        const size_t pid = (size_t)W * (size_t)py + (size_t)px;
+        out_alpha[pid] = 1.f - T;
+        if (n_contrib != nullptr) n_contrib[pid] = last;
+        out_color[pid] = Cr + T * background[0];
+        out_color[plane + pid] = Cg + T * background[1];
+        out_color[2 * plane + pid] = Cb + T * background[2];
+        out_depth[pid] = Dz;
     }
 }
 
@@ -496,11 +661,11 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmat
     return hipGetLastError();
 }
 
-hipError_t launch_duplicate(int P, const Camera& cam, const uint32_t* depth_order, const uint32_t* point_offsets,
-                            const float2* means2D, const int* radii, uint32_t* tile_keys, uint32_t* point_list,
-                            hipStream_t stream) {
+hipError_t launch_duplicate(int P, const Camera& cam, bool cull, const uint32_t* depth_order,
+                            const uint32_t* point_offsets, const float2* means2D, const float4* conic_opacity,
+                            const int* radii, uint32_t* tile_keys, uint32_t* point_list, hipStream_t stream) {
     hipLaunchKernelGGL(duplicate_kernel, dim3(div_up(P, 256)), dim3(256), 0, stream, P, cam.grid_x, cam.grid_y,
-                       depth_order, point_offsets, means2D, radii, tile_keys, point_list);
+                       cull ? 1 : 0, depth_order, point_offsets, means2D, conic_opacity, radii, tile_keys, point_list);
     return hipGetLastError();
 }
 
@@ -511,11 +676,17 @@ hipError_t launch_tile_ranges(uint32_t num_rendered, int num_tiles, const uint32
     return hipGetLastError();
 }
 
-hipError_t launch_blend(const Camera& cam, const uint2* ranges, const uint32_t* point_list, const float2* means2D,
-                        const float* features, const float* depths, const float4* conic_opacity,
-                        const float* background, float* out_color, float* out_depth, float* out_alpha,
-                        uint32_t* n_contrib, hipStream_t stream) {
+hipError_t launch_blend(const Camera& cam, int variant, const uint2* ranges, const uint32_t* point_list,
+                        const float2* means2D, const float* features, const float* depths,
+                        const float4* conic_opacity, const float* background, float* out_color, float* out_depth,
+                        float* out_alpha, uint32_t* n_contrib, hipStream_t stream) {
     const int T = cam.grid_x * cam.grid_y;
+    if (variant == 1) {
+        hipLaunchKernelGGL(blend_quadrant_kernel, dim3(4 * T), dim3(64), 0, stream, cam.width, cam.height, cam.grid_x,
+                           T, ranges, point_list, means2D, features, depths, conic_opacity, background, out_color,
+                           out_depth, out_alpha, n_contrib);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(blend_kernel, dim3(T), dim3(64), 0, stream, cam.width, cam.height, cam.grid_x, T, ranges,
                        point_list, means2D, features, depths, conic_opacity, background, out_color, out_depth,
                        out_alpha, n_contrib);

@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--gaussians", type=int, default=0, help="override P (parity/debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the final RCCL gather (N > 1)")
+    ap.add_argument("--blend-variant", type=int, default=None, help="A/B knob: GSR_OPT_BLEND_VARIANT")
+    ap.add_argument("--no-cull", action="store_true", help="A/B knob: GSR_OPT_TILE_CULL = 0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,6 +100,10 @@ def main():
     from autovfx_amd.frame_parallel import gather_frames, pack_rgba8, rasterize
     from diff_gaussian_rasterization import _C
 
+    if args.blend_variant is not None:
+        _lib.set_option(_lib.OPT_BLEND_VARIANT, args.blend_variant)
+    if args.no_cull:
+        _lib.set_option(_lib.OPT_TILE_CULL, 0)
     wl = WORKLOADS[args.workload]
     W, H, F = wl["width"], wl["height"], wl["frames"]
     cfg = getattr(scenes, wl["cfg"])
@@ -198,7 +204,9 @@ def main():
                        "visible_mean": round(V, 1), "num_rendered_mean": round(D, 1),
                        "boundary": "GaussianRasterizer.forward (SH) + RGBA8 pack per frame"
                                    + ("; final RCCL gather of RGBA8 frames to rank 0" if world > 1 and not args.no_gather else ""),
-                       "parallelism": f"frame-parallel x{world}"},
+                       "parallelism": f"frame-parallel x{world}",
+                       "options": {"tile_cull": _lib.get_option(_lib.OPT_TILE_CULL),
+                                   "blend_variant": _lib.get_option(_lib.OPT_BLEND_VARIANT)}},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         if gathered is not None:

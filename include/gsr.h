@@ -110,8 +110,8 @@ typedef enum gsr_geom_slot {
 } gsr_geom_slot;
 
 typedef enum gsr_binning_slot {
-    GSR_BIN_POINT_LIST = 0,     /* u32[num_rendered] Gaussian ids sorted by (tile, depth bits, id) */
-    GSR_BIN_TILE_KEYS,          /* u32[num_rendered] tile id of each entry of POINT_LIST           */
+    GSR_BIN_POINT_LIST = 0,     /* u32[num_rendered] Gaussian ids sorted by (tile, depth bits, id); see GSR_OPT_TILE_CULL */
+    GSR_BIN_TILE_KEYS,          /* u32[num_rendered] tile id of each entry of POINT_LIST (T = parked) */
     GSR_BIN_NUM_SLOTS
 } gsr_binning_slot;
 
@@ -125,6 +125,23 @@ typedef enum gsr_image_slot {
 GSR_API int gsr_last_geom_offsets(size_t offsets[GSR_GEOM_NUM_SLOTS]);
 GSR_API int gsr_last_binning_offsets(size_t offsets[GSR_BIN_NUM_SLOTS]);
 GSR_API int gsr_last_image_offsets(size_t offsets[GSR_IMG_NUM_SLOTS]);
+
+/* ---- options (process-wide; defaults in brackets) ---- */
+typedef enum gsr_option {
+    /* [1] Exact-image tile culling: a (tile, Gaussian) pair of the reference's rectangle for which
+     * no pixel of the tile can reach alpha >= 1/255 is parked behind all live pairs (tile key T)
+     * instead of being blended.  color / depth / alpha / radii / num_rendered are bit-identical
+     * with the option on or off; POINT_LIST then holds the live pairs in the reference's order
+     * followed by the parked ones, and RANGES / N_CONTRIB index the live prefix.  0 reproduces
+     * the reference's lists exactly. */
+    GSR_OPT_TILE_CULL = 0,
+    /* [1] Blend kernel shape: 0 = one wave64 per 16x16 tile (4 pixels per lane), 1 = one wave64 per
+     * 8x8 quadrant with per-quadrant entry skipping.  Same results; a tuning / A-B knob. */
+    GSR_OPT_BLEND_VARIANT = 1,
+    GSR_OPT_NUM
+} gsr_option;
+GSR_API int gsr_set_option(int option, int value);
+GSR_API int gsr_get_option(int option);
 
 /* Per-stage device timing of gsr_forward via hipEvents on `stream` (off by default). */
 typedef enum gsr_stage {

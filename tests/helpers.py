@@ -62,9 +62,19 @@ def run_hip(cloud: GaussianCloud, cam: Camera, device="cuda:0", bg=(0.0, 0.0, 0.
 
 
 def hip_forward_raw(cloud: GaussianCloud, cam: Camera, device="cuda:0", bg=(0.0, 0.0, 0.0), scale_modifier=1.0,
-                    sh_degree=None, cov3D_precomp=None, debug=True):
-    """Call ``_C.rasterize_gaussians`` directly and decode every scratch sub-array."""
+                    sh_degree=None, cov3D_precomp=None, debug=True, cull=False):
+    """Call ``_C.rasterize_gaussians`` directly and decode every scratch sub-array.
+    ``cull=False`` switches exact-image tile culling off so the lists are the reference's."""
+    from autovfx_amd import _lib
     from diff_gaussian_rasterization import _C
+    _lib.set_option(_lib.OPT_TILE_CULL, 1 if cull else 0)
+    try:
+        return _hip_forward_raw(_C, cloud, cam, device, bg, scale_modifier, sh_degree, cov3D_precomp, debug)
+    finally:
+        _lib.set_option(_lib.OPT_TILE_CULL, 1)
+
+
+def _hip_forward_raw(_C, cloud, cam, device, bg, scale_modifier, sh_degree, cov3D_precomp, debug):
     c = cloud.to(device)
     st = settings_for(cam, device, bg, scale_modifier, cloud.sh_degree if sh_degree is None else sh_degree)
     e = torch.Tensor([])

@@ -94,11 +94,47 @@ def assert_stage_parity(name, hip, ref):
     np.testing.assert_array_equal(hip["ranges"], ref["ranges"], err_msg=f"{name}: ranges")
 
 
+def pair_is_dead(ref, gid, tile, W, H):
+    """Exact per-pixel restatement of forward.cu:331-349 for one (tile, Gaussian) pair: True when every
+    pixel of the tile would skip the pair (power > 0 or alpha < 1/255), with a 0.1 % safety band."""
+    gx = (W + 15) // 16
+    ty, tx = divmod(int(tile), gx)
+    ys, xs = np.mgrid[ty * 16:min(H, ty * 16 + 16), tx * 16:min(W, tx * 16 + 16)]
+    cx, cy = ref["means2D"][gid]
+    A, B, C, o = ref["conic_opacity"][gid].astype(np.float64)
+    dx, dy = cx - xs, cy - ys
+    power = -0.5 * (A * dx * dx + C * dy * dy) - B * dx * dy
+    alpha = np.where(power > 0, 0.0, o * np.exp(np.minimum(power, 0)))
+    return bool(alpha.max() < (1.0 / 255.0) * (1 - 1e-3))
+
+
+def assert_culled_lists(name, on, ref, W, H):
+    """With GSR_OPT_TILE_CULL on: per tile the list is the reference's list minus pairs that are dead at
+    every pixel, in the reference's order."""
+    kept = dropped = 0
+    for t in range(ref["ranges"].shape[0]):
+        lref = ref["point_list"][ref["ranges"][t, 0]:ref["ranges"][t, 1]]
+        lhip = on["point_list"][on["ranges"][t, 0]:on["ranges"][t, 1]]
+        i = 0
+        for g in lref:
+            if i < len(lhip) and lhip[i] == g:
+                i += 1
+            else:
+                dropped += 1
+                assert pair_is_dead(ref, int(g), t, W, H), f"{name}: live pair (tile {t}, gaussian {g}) was culled"
+        assert i == len(lhip), f"{name}: tile {t} list is not a subsequence of the reference list"
+        kept += len(lhip)
+    live = int(on["ranges"][:, 1].max()) if on["ranges"].size else 0
+    assert (on["tile_keys"][live:] == ref["ranges"].shape[0]).all() and kept == live
+    report(name + ":cull", kept=kept, dropped=dropped, kept_frac=kept / max(1, kept + dropped))
+    return kept, dropped
+
+
 def run_both(name, cloud, cam, stage=True, **kw):
     ref = cpu_oracle.forward(intermediates=True, **oracle_kwargs(cloud, cam, **kw))
     if cloud.colors_precomp is None:
         ref["rgb_used"] = True
-    hip = hip_forward_raw(cloud, cam, **kw)
+    hip = hip_forward_raw(cloud, cam, cull=False, **kw)        # the reference's lists, exactly
     if stage:
         assert_stage_parity(name, hip, ref)
     st = assert_images(name, hip, ref)
@@ -106,6 +142,13 @@ def run_both(name, cloud, cam, stage=True, **kw):
     nc_bad = int((hip["n_contrib"] != ref["n_contrib"]).sum())
     report(name + ":n_contrib", mismatched=nc_bad)
     assert nc_bad <= int(np.ceil(FLIP_PPM * 1e-6 * ref["n_contrib"].size)) + st["color_bad_px"]
+    # default mode (exact-image tile culling): same images bit for bit, same public outputs, thinner lists
+    on = hip_forward_raw(cloud, cam, cull=True, **kw)
+    for k in ("color", "depth", "alpha", "radii"):
+        np.testing.assert_array_equal(on[k], hip[k], err_msg=f"{name}: {k} changed by tile culling")
+    assert on["num_rendered"] == hip["num_rendered"]
+    if stage and ref["num_rendered"] <= 400_000:
+        assert_culled_lists(name, on, ref, cam.image_width, cam.image_height)
     return hip, ref
 
 
@@ -315,6 +358,31 @@ def test_argument_validation_matches_reference():
         out.sum().backward()
 
 
+@pytest.mark.parametrize("case", ["c1", "c2_mid", "big", "ragged"])
+def test_blend_variants_agree_bit_for_bit(case):
+    """GSR_OPT_BLEND_VARIANT 0 (wave per tile) and 1 (wave per quadrant) are two schedules of the same
+    per-pixel arithmetic: every output, n_contrib included, must be identical."""
+    from autovfx_amd import _lib
+    if case == "c1":
+        cloud, cam = scenes.config_c1(), scenes.c1_camera()
+    elif case == "c2_mid":
+        cloud, cam = scenes.config_c2(P=300_000, seed=4), orbit_cameras(200, 960, 540)[120]
+    elif case == "big":
+        cloud, cam = scenes.config_c1(P=400, seed=7), scenes.c1_camera(512, 384)
+        cloud.scales[:60] *= 30.0
+    else:
+        cloud, cam = scenes.config_c1(P=3000, seed=11), scenes.c1_camera(251, 131)
+    outs = []
+    for variant in (0, 1):
+        _lib.set_option(_lib.OPT_BLEND_VARIANT, variant)
+        try:
+            outs.append(hip_forward_raw(cloud, cam, bg=(0.3, 0.2, 0.1), cull=True))
+        finally:
+            _lib.set_option(_lib.OPT_BLEND_VARIANT, 1)
+    for k in ("color", "depth", "alpha", "n_contrib", "radii", "point_list", "ranges"):
+        np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=f"{case}: {k} differs between blend variants")
+
+
 # ---- golden vectors produced by the reference's own sources (tests/golden/make_golden.py) --------------------
 
 from test_golden import GOLDEN, load_case  # noqa: E402
@@ -338,7 +406,7 @@ def test_hip_matches_reference_golden_vectors(path):
     # settings_for() takes tan(fov/2) from the camera; make it return the stored float exactly
     cam = _ExactTanCamera(cam, kw["tanfovx"], kw["tanfovy"])
     hip = hip_forward_raw(cloud, cam, bg=tuple(float(v) for v in kw["bg"]), scale_modifier=kw["scale_modifier"],
-                          **extra)
+                          cull=False, **extra)
     name = "golden:" + os.path.basename(path)[:-4]
     if cloud.colors_precomp is None:
         ref["rgb_used"] = True
@@ -369,7 +437,12 @@ def test_full_size_properties(c3_frame):
     (c) a permutation of the Gaussians (depths are distinct) leaves the image unchanged bit for bit;
     (d) radii > 0 <=> the Gaussian produced pairs, and num_rendered == sum of tiles_touched."""
     cloud, cam = c3_frame
-    a = hip_forward_raw(cloud, cam, bg=(0.0, 0.0, 0.0), debug=False)
+    a = hip_forward_raw(cloud, cam, bg=(0.0, 0.0, 0.0), debug=False, cull=False)
+    on = hip_forward_raw(cloud, cam, bg=(0.0, 0.0, 0.0), debug=False, cull=True)
+    for k in ("color", "depth", "alpha", "radii"):
+        np.testing.assert_array_equal(on[k], a[k], err_msg=f"c3: {k} changed by tile culling")
+    live = int(on["ranges"][:, 1].max())
+    report("c3_cull", num_rendered=int(a["num_rendered"]), live_pairs=live, kept_frac=live / a["num_rendered"])
     assert a["alpha"].min() >= 0.0 and a["alpha"].max() < 1.0 and a["depth"].min() >= 0.0
     assert a["num_rendered"] == int(a["tiles_touched"].astype(np.int64).sum())
     np.testing.assert_array_equal(a["radii"] > 0, a["tiles_touched"] > 0)
