@@ -16,7 +16,7 @@ ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 
 # enum mirrors of include/gsr.h
 GEOM_SLOTS = ("depths", "means2D", "conic_opacity", "rgb", "tiles_touched", "internal_radii", "depth_order",
-              "point_offsets")
+              "point_offsets", "live_mask")
 BIN_SLOTS = ("point_list", "tile_keys")
 IMG_SLOTS = ("ranges", "n_contrib")
 STAGES = ("preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "ranges", "blend")
@@ -25,7 +25,7 @@ ABI_VERSION = 1
 # every symbol include/gsr.h declares
 SYMBOLS = ("gsr_forward", "gsr_mark_visible", "gsr_backward", "gsr_last_geom_offsets", "gsr_last_binning_offsets",
            "gsr_last_image_offsets", "gsr_set_stage_timing", "gsr_get_stage_times", "gsr_last_error",
-           "gsr_abi_version", "gsr_target_arch", "gsr_set_option", "gsr_get_option")
+           "gsr_abi_version", "gsr_target_arch", "gsr_set_option", "gsr_get_option", "gsr_pack_rgba8", "gsr_last_pair_counts")
 OPT_TILE_CULL = 0
 OPT_BLEND_VARIANT = 1
 
@@ -58,6 +58,10 @@ def _load() -> ctypes.CDLL:
         c_f, c_f, c_f, c_f, ctypes.c_int, ctypes.c_void_p]   # out_color out_depth out_alpha radii debug stream
     lib.gsr_mark_visible.restype = ctypes.c_int
     lib.gsr_mark_visible.argtypes = [ctypes.c_int, c_f, c_f, c_f, c_f, ctypes.c_void_p]
+    lib.gsr_last_pair_counts.restype = ctypes.c_int
+    lib.gsr_last_pair_counts.argtypes = [ctypes.POINTER(ctypes.c_uint32 * 2)]
+    lib.gsr_pack_rgba8.restype = ctypes.c_int
+    lib.gsr_pack_rgba8.argtypes = [c_f, c_f, c_f, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.gsr_backward.restype = ctypes.c_int
     lib.gsr_backward.argtypes = []
     for name, n in (("gsr_last_geom_offsets", len(GEOM_SLOTS)), ("gsr_last_binning_offsets", len(BIN_SLOTS)),
@@ -98,6 +102,13 @@ def offsets(kind: str) -> dict:
     if fn(ctypes.byref(arr)) != 0:
         raise RuntimeError(last_error())
     return dict(zip(names, (int(v) for v in arr)))
+
+
+def pair_counts() -> dict:
+    arr = (ctypes.c_uint32 * 2)()
+    if lib.gsr_last_pair_counts(ctypes.byref(arr)) != 0:
+        raise RuntimeError(last_error())
+    return {"num_rendered": int(arr[0]), "live_pairs": int(arr[1])}
 
 
 def set_option(option: int, value: int) -> None:

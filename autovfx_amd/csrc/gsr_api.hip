@@ -18,6 +18,7 @@ thread_local size_t g_geom_off[GSR_GEOM_NUM_SLOTS];
 thread_local size_t g_bin_off[GSR_BIN_NUM_SLOTS];
 thread_local size_t g_img_off[GSR_IMG_NUM_SLOTS];
 thread_local bool g_have_offsets = false;
+thread_local uint32_t g_counts[2] = {0, 0};  // last call: {num_rendered (reference), live pairs}
 
 // Stage timing: a ring of event sets so a whole timed region can be averaged afterwards without
 // synchronising between calls.
@@ -83,8 +84,9 @@ int tile_key_bits(uint32_t num_tiles) {
     return b;  // bit_length(T) >= bit_length(T - 1): every tile id fits
 }
 
+constexpr size_t kCounterBytes = (gsr::kRectPartials + 1) * sizeof(unsigned long long);
 struct Pinned {
-    uint32_t* host = nullptr;  // 64 pinned bytes per calling thread, deliberately never freed:
+    uint32_t* host = nullptr;  // a few KB of pinned memory per calling thread, deliberately never freed:
 };                             // freeing at thread exit can race HIP runtime teardown
 thread_local Pinned g_pinned;
 
@@ -145,6 +147,12 @@ int gsr_last_binning_offsets(size_t o[GSR_BIN_NUM_SLOTS]) {
     memcpy(o, g_bin_off, sizeof g_bin_off);
     return GSR_OK;
 }
+int gsr_last_pair_counts(uint32_t counts[2]) {
+    if (!g_have_offsets) return fail(GSR_ERR_INVALID_ARG, "no gsr_forward call on this thread");
+    counts[0] = g_counts[0];
+    counts[1] = g_counts[1];
+    return GSR_OK;
+}
 int gsr_last_image_offsets(size_t o[GSR_IMG_NUM_SLOTS]) {
     if (!g_have_offsets) return fail(GSR_ERR_INVALID_ARG, "no gsr_forward call on this thread");
     memcpy(o, g_img_off, sizeof g_img_off);
@@ -158,6 +166,13 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
     if (P == 0) return GSR_OK;
     if (!means3D || !viewmatrix || !present) return fail(GSR_ERR_INVALID_ARG, "null pointer");
     GSR_HIP(gsr::launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream_));
+    return GSR_OK;
+}
+
+int gsr_pack_rgba8(const float* color, const float* alpha, uint8_t* rgba8, int width, int height, void* stream_) {
+    if (width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARG, "bad image size %dx%d", width, height);
+    if (!color || !alpha || !rgba8) return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    GSR_HIP(gsr::launch_pack_rgba8(color, alpha, rgba8, (size_t)width * height, (hipStream_t)stream_));
     return GSR_OK;
 }
 
@@ -204,7 +219,7 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
         g_ev_made = true;
     }
     g_slot = (int)(g_timed_calls % kTimingRing);
-    if (!g_pinned.host) GSR_HIP(hipHostMalloc((void**)&g_pinned.host, 64, hipHostMallocPortable));
+    if (!g_pinned.host) GSR_HIP(hipHostMalloc((void**)&g_pinned.host, kCounterBytes + 64, hipHostMallocPortable));
 
     // ---- geometry arena ----
     size_t sort_tmp = 0, scan_tmp = 0;
@@ -220,7 +235,9 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     const size_t off_keys_a = gc.take<uint32_t>(n), off_keys_b = gc.take<uint32_t>(n);
     const size_t off_ids_a = gc.take<uint32_t>(n), off_ids_b = gc.take<uint32_t>(n);
     g_geom_off[GSR_GEOM_POINT_OFFSETS] = gc.take<uint32_t>(n);
-    const size_t off_flag = gc.take<uint32_t>(16);
+    g_geom_off[GSR_GEOM_LIVE_MASK] = gc.take<uint32_t>(n);
+    // kRectPartials u64 partial sums of rectangle areas, then one u32 error flag
+    const size_t off_flag = gc.take<unsigned long long>(gsr::kRectPartials + 1);
     const size_t off_tmp = gc.take<char>(sort_tmp > scan_tmp ? sort_tmp : scan_tmp);
     char* graw = geom_alloc(gc.total(), geom_user);
     if (!graw) return fail(GSR_ERR_ALLOC, "geometry scratch callback returned NULL for %zu bytes", gc.total());
@@ -241,6 +258,7 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     in.means3D = means3D; in.scales = scales; in.rotations = rotations; in.cov3D_precomp = cov3D_precomp;
     in.opacities = opacities; in.shs = shs; in.colors_precomp = colors_precomp;
     in.scale_modifier = scale_modifier; in.prefiltered = prefiltered;
+    in.tile_cull = g_options[GSR_OPT_TILE_CULL] != 0;
 
     gsr::GeometryArrays ga;
     ga.depths = (float*)(gbase + g_geom_off[GSR_GEOM_DEPTHS]);
@@ -251,12 +269,14 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     ga.radii = radii ? radii : (int*)(gbase + g_geom_off[GSR_GEOM_INTERNAL_RADII]);
     ga.depth_keys = (uint32_t*)(gbase + off_keys_a);
     ga.ids = (uint32_t*)(gbase + off_ids_a);
-    ga.error_flag = (uint32_t*)(gbase + off_flag);
+    ga.rect_total = (unsigned long long*)(gbase + off_flag);
+    ga.error_flag = (uint32_t*)(ga.rect_total + gsr::kRectPartials);
+    ga.live_mask = (uint32_t*)(gbase + g_geom_off[GSR_GEOM_LIVE_MASK]);
     uint32_t* point_offsets = (uint32_t*)(gbase + g_geom_off[GSR_GEOM_POINT_OFFSETS]);
     void* tmp = gbase + off_tmp;
     const size_t tmp_bytes = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
 
-    if (prefiltered) GSR_HIP(hipMemsetAsync(ga.error_flag, 0, sizeof(uint32_t), stream));
+    GSR_HIP(hipMemsetAsync(gbase + off_flag, 0, kCounterBytes, stream));
     stamp(0, stream);
     GSR_HIP(gsr::launch_preprocess(in, cam, ga, stream));
     GSR_STAGE_CHECK("preprocess");
@@ -271,20 +291,31 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
 
     GSR_HIP(gsr::scan_tiles_in_order(tmp, tmp_bytes, P, ga.tiles_touched, order, point_offsets, stream));
     // The one host round trip of the call (rasterizer_impl.cu:282): num_rendered sizes the binning arena.
-    GSR_HIP(hipMemcpyAsync(g_pinned.host, point_offsets + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    g_pinned.host[1] = 0;
-    if (prefiltered)
-        GSR_HIP(hipMemcpyAsync(g_pinned.host + 1, ga.error_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    // host: [counters: kRectPartials x u64, flag u32 (+pad)] [live pairs u32]
+    char* hostb = reinterpret_cast<char*>(g_pinned.host);
+    GSR_HIP(hipMemcpyAsync(hostb, gbase + off_flag, kCounterBytes, hipMemcpyDeviceToHost, stream));
+    GSR_HIP(hipMemcpyAsync(hostb + kCounterBytes, point_offsets + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     GSR_HIP(hipStreamSynchronize(stream));
-    const uint32_t num_rendered = g_pinned.host[0];
-    if (debug && prefiltered && (g_pinned.host[1] & 1u))
+    uint32_t num_live = 0, flag = 0;
+    memcpy(&num_live, hostb + kCounterBytes, sizeof num_live);
+    memcpy(&flag, hostb + gsr::kRectPartials * sizeof(unsigned long long), sizeof flag);
+    unsigned long long rect_total = 0;
+    for (int i = 0; i < gsr::kRectPartials; ++i) {
+        unsigned long long v;
+        memcpy(&v, hostb + i * sizeof v, sizeof v);
+        rect_total += v;
+    }
+    if (debug && prefiltered && (flag & 1u))
         return fail(GSR_ERR_PREFILTERED, "a Gaussian was culled although prefiltered is set (auxiliary.h:156-160)");
-    if (num_rendered > 0x7FFFFFFFu) return fail(GSR_ERR_INVALID_ARG, "num_rendered %u overflows int", num_rendered);
+    if (rect_total > 0x7FFFFFFFull) return fail(GSR_ERR_INVALID_ARG, "num_rendered %llu overflows int", rect_total);
+    const uint32_t num_rendered = (uint32_t)rect_total;  // the reference's count; == num_live when culling is off
+    g_counts[0] = num_rendered;
+    g_counts[1] = num_live;
     stamp(3, stream);
     for (auto& o : g_geom_off) o += gshift;
 
     // ---- binning arena ----
-    const size_t nr = num_rendered ? num_rendered : 1;
+    const size_t nr = num_live ? num_live : 1;
     size_t tsort_tmp = 0;
     GSR_HIP(gsr::tile_sort_temp_bytes((uint32_t)nr, &tsort_tmp));
     Carver bc;
@@ -299,20 +330,20 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     uint2* ranges = (uint2*)(iraw + g_img_off[GSR_IMG_RANGES]);
     uint32_t* n_contrib = (uint32_t*)(iraw + g_img_off[GSR_IMG_N_CONTRIB]);
 
-    if (num_rendered > 0) {
-        GSR_HIP(gsr::launch_duplicate(P, cam, g_options[GSR_OPT_TILE_CULL] != 0, order, point_offsets, ga.means2D,
-                                      ga.conic_opacity, ga.radii, tile_keys, point_list, stream));
+    if (num_live > 0) {
+        GSR_HIP(gsr::launch_duplicate(P, cam, order, point_offsets, ga.means2D, ga.radii, ga.live_mask, tile_keys,
+                                      point_list, stream));
         GSR_STAGE_CHECK("duplicate");
         stamp(4, stream);
         uint32_t *tk_sorted = nullptr, *pl_sorted = nullptr;
-        GSR_HIP(gsr::tile_sort(bbase + off_btmp, tsort_tmp, num_rendered, tile_key_bits((uint32_t)T), tile_keys,
+        GSR_HIP(gsr::tile_sort(bbase + off_btmp, tsort_tmp, num_live, tile_key_bits((uint32_t)T), tile_keys,
                                (uint32_t*)(bbase + off_tk_b), point_list, (uint32_t*)(bbase + off_pl_b),
                                &tk_sorted, &pl_sorted, stream));
         GSR_STAGE_CHECK("tile_sort");
         stamp(5, stream);
         tile_keys = tk_sorted;
         point_list = pl_sorted;
-        GSR_HIP(gsr::launch_tile_ranges(num_rendered, T, tile_keys, ranges, stream));
+        GSR_HIP(gsr::launch_tile_ranges(num_live, T, tile_keys, ranges, stream));
     } else {
         stamp(4, stream);
         stamp(5, stream);

@@ -9,6 +9,7 @@ namespace gsr {
 
 constexpr int kTile = 16;                    // tile edge in pixels; part of the result
 constexpr uint32_t kCulledKey = 0xFFFFFFFFu; // depth key of a Gaussian that produces no pairs
+constexpr int kRectPartials = 256;           // partial sums of rectangle areas (power of two)
 
 struct Camera {
     const float* viewmatrix;  // 16 floats, transposed w2c
@@ -29,6 +30,7 @@ struct GaussianInputs {
     const float* colors_precomp; // nullable
     float scale_modifier;
     int prefiltered;
+    int tile_cull;  // GSR_OPT_TILE_CULL
 };
 
 struct GeometryArrays {
@@ -36,7 +38,9 @@ struct GeometryArrays {
     float2* means2D;
     float4* conic_opacity;
     float* rgb;
-    uint32_t* tiles_touched;
+    uint32_t* tiles_touched; // live tiles of the splat's rectangle (== its area when culling is off)
+    uint32_t* live_mask;     // bit i = i-th tile of the rectangle (row-major) is live; all ones = whole rectangle
+    unsigned long long* rect_total;  // kRectPartials device counters; their sum = the reference's num_rendered
     int* radii;           // caller's radii or the internal array
     uint32_t* depth_keys; // sort keys (float bits of depth, kCulledKey if culled)
     uint32_t* ids;        // 0..P-1, the sort payload
@@ -48,9 +52,9 @@ hipError_t launch_preprocess(const GaussianInputs& in, const Camera& cam, const 
                              hipStream_t stream);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
                                hipStream_t stream);
-hipError_t launch_duplicate(int P, const Camera& cam, bool cull, const uint32_t* depth_order,
-                            const uint32_t* point_offsets, const float2* means2D, const float4* conic_opacity,
-                            const int* radii, uint32_t* tile_keys, uint32_t* point_list, hipStream_t stream);
+hipError_t launch_duplicate(int P, const Camera& cam, const uint32_t* depth_order, const uint32_t* point_offsets,
+                            const float2* means2D, const int* radii, const uint32_t* live_mask, uint32_t* tile_keys,
+                            uint32_t* point_list, hipStream_t stream);
 hipError_t launch_tile_ranges(uint32_t num_rendered, int num_tiles, const uint32_t* sorted_tile_keys,
                               uint2* ranges, hipStream_t stream);
 // variant 0: one wave per tile, 4 pixels per lane; variant 1: one wave per 8x8 quadrant
@@ -58,6 +62,9 @@ hipError_t launch_blend(const Camera& cam, int variant, const uint2* ranges, con
                         const float2* means2D, const float* features, const float* depths,
                         const float4* conic_opacity, const float* background, float* out_color, float* out_depth,
                         float* out_alpha, uint32_t* n_contrib, hipStream_t stream);
+
+hipError_t launch_pack_rgba8(const float* color, const float* alpha, uint8_t* out, size_t n_pixels,
+                             hipStream_t stream);
 
 // ---- device-wide primitives (gsr_sort.hip) ----
 // All three follow the two-call protocol: with temp == nullptr they only report temp_bytes.

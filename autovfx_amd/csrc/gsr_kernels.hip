@@ -131,6 +131,50 @@ __device__ __forceinline__ F3 sh_to_rgb(int deg, F3 pos, F3 cam, const float* sh
 }
 
 // ------------------------------------------------------------------------------------------------
+// Exact-image tile culling.  The reference pairs a splat with every tile of the bounding square of
+// its 3-sigma circle; for many of those tiles no pixel can reach alpha >= 1/255, so the blend
+// would skip the pair at every pixel.  This predicate returns false only when that is provable:
+// with q(d) = 0.5 (A dx^2 + C dy^2) + B dx dy  (power = -q, forward.cu:338), alpha >= 1/255 needs
+// q <= ln(255 o); q is convex, so its minimum over the tile's pixel rectangle is 0 if the centre is
+// inside and otherwise lies on one of the four edges, where it has a closed form.  The comparison
+// keeps a 0.2 % + 1e-3 margin, ~10x the worst-case fp32 rounding of q for |rho| < 0.995
+// (error <= 4e-7 (1+|rho|)/(1-|rho|) q); anything less regular is never culled.  Dropping such a
+// pair cannot change any pixel, bit for bit (tests compare culled and unculled renders exactly).
+// The test runs in the preprocess kernel, where the splat's conic is in registers and the ALU is
+// idle behind HBM: a splat whose rectangle has <= 32 tiles gets a 32-bit mask of live tiles and its
+// pair count becomes popcount(mask), so dead pairs are never written, sorted or ranged.  Larger
+// splats keep their full rectangle (their dead corners are a small fraction and a per-lane loop
+// over hundreds of tiles would serialise the wave).
+// The same predicate on an 8x8 quadrant lets the quadrant blend skip list entries wholesale.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float edge_q(float A, float B, float C, float dx, float dy) {
+    return 0.5f * (A * dx * dx + C * dy * dy) + B * dx * dy;
+}
+
+// Pixel rectangle [px_first, px_first + w - 1] x [py_first, py_first + h - 1].
+// The hardware reciprocal / log2 (1 ulp) are enough here: a slightly misplaced edge minimiser
+// changes q only to second order, and the log error (~1e-6) is far inside the 1e-3 margin.
+__device__ __forceinline__ bool splat_reaches_rect(float4 co, float2 c, int px_first, int py_first, int w, int h) {
+    const float A = co.x, B = co.y, C = co.z;
+    if (!(A > 0.f) || !(C > 0.f) || !((B * B) < 0.99f * (A * C))) return true;
+    // ln(255 o); o <= 0 gives -inf (nothing visible), NaN keeps the pair
+    const float budget = 0.69314718f * __builtin_amdgcn_logf(255.0f * co.w);
+    const float x_lo = c.x - (float)(px_first + w - 1), x_hi = c.x - (float)px_first;
+    const float y_lo = c.y - (float)(py_first + h - 1), y_hi = c.y - (float)py_first;
+    if (x_lo <= 0.f && x_hi >= 0.f && y_lo <= 0.f && y_hi >= 0.f) return true;  // centre inside the rectangle
+    const float nb_c = -B * __builtin_amdgcn_rcpf(C), nb_a = -B * __builtin_amdgcn_rcpf(A);
+    float qmin = edge_q(A, B, C, x_lo, fminf(y_hi, fmaxf(y_lo, nb_c * x_lo)));
+    qmin = fminf(qmin, edge_q(A, B, C, x_hi, fminf(y_hi, fmaxf(y_lo, nb_c * x_hi))));
+    qmin = fminf(qmin, edge_q(A, B, C, fminf(x_hi, fmaxf(x_lo, nb_a * y_lo)), y_lo));
+    qmin = fminf(qmin, edge_q(A, B, C, fminf(x_hi, fmaxf(x_lo, nb_a * y_hi)), y_hi));
+    return !(qmin * 0.998f - 1.0e-3f > budget);
+}
+
+__device__ __forceinline__ bool splat_reaches_tile(float4 co, float2 c, int tile_x, int tile_y) {
+    return splat_reaches_rect(co, c, tile_x * kTile, tile_y * kTile, kTile, kTile);
+}
+
+// ------------------------------------------------------------------------------------------------
 // K1: one lane per Gaussian.  Streaming, HBM-bound: 236 B in (M = 16) and 52 B out per visible
 // Gaussian, 12 B in / 12 B out per culled one.
 // ------------------------------------------------------------------------------------------------
@@ -153,7 +197,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
     const float vz = vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14];
 
     int radius_out = 0;
-    uint32_t tiles = 0;
+    uint32_t tiles = 0, rect_area = 0, mask = 0xFFFFFFFFu;
     uint32_t key = kCulledKey;
 
     if (vz <= 0.2f) {
@@ -224,18 +268,36 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
                     const F3 col = sh_to_rgb(deg, p, cp, in.shs + 3 * (size_t)in.M * i);
                     *reinterpret_cast<F3*>(out.rgb + 3 * (size_t)i) = col;
                 }
+                const float4 conic_o = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, in.opacities[i]);
                 out.depths[i] = vz;
                 out.means2D[i] = make_float2(px, py);
-                out.conic_opacity[i] = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, in.opacities[i]);
+                out.conic_opacity[i] = conic_o;
                 radius_out = irad;
+                rect_area = area;
                 tiles = area;
+                if (in.tile_cull && area <= 32u) {  // exact-image tile culling, see above
+                    mask = 0u;
+                    uint32_t bit = 0;
+                    for (int ty = rc.y0; ty < rc.y1; ++ty)
+                        for (int tx = rc.x0; tx < rc.x1; ++tx, ++bit)
+                            if (splat_reaches_tile(conic_o, make_float2(px, py), tx, ty)) mask |= 1u << bit;
+                    tiles = (uint32_t)__popc(mask);
+                }
                 key = __float_as_uint(vz);
             }
         }
     }
     out.radii[i] = radius_out;
     out.tiles_touched[i] = tiles;
+    out.live_mask[i] = mask;
     out.depth_keys[i] = key;
+    // The reference's num_rendered (sum of rectangle areas) is part of its return value: keep it.
+    // One atomic per wave, spread over kRectPartials words (same-word atomics serialise at ~12 ns).
+    unsigned long long wave_rect = rect_area;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wave_rect += __shfl_xor(wave_rect, d);
+    if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) && wave_rect != 0)
+        atomicAdd(out.rect_total + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kRectPartials - 1)), wave_rect);
 }
 
 __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means3D,
@@ -249,52 +311,29 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// Exact-image tile culling.  The reference pairs a splat with every tile of the bounding square of
-// its 3-sigma circle; for many of those tiles no pixel can reach alpha >= 1/255, so the blend
-// would skip the pair at every pixel.  This predicate returns false only when that is provable:
-// with q(d) = 0.5 (A dx^2 + C dy^2) + B dx dy  (power = -q, forward.cu:338), alpha >= 1/255 needs
-// q <= ln(255 o); q is convex, so its minimum over the tile's pixel rectangle is 0 if the centre is
-// inside and otherwise lies on one of the four edges, where it has a closed form.  The comparison
-// keeps a 0.2 % + 1e-3 margin, ~10x the worst-case fp32 rounding of q for |rho| < 0.995
-// (error <= 4e-7 (1+|rho|)/(1-|rho|) q); anything less regular is never culled.  Dropping such a
-// pair cannot change any pixel, bit for bit (tests compare culled and unculled renders exactly).
-// The same predicate on an 8x8 quadrant lets the quadrant blend skip list entries wholesale.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float edge_q(float A, float B, float C, float dx, float dy) {
-    return 0.5f * (A * dx * dx + C * dy * dy) + B * dx * dy;
-}
-
-// Pixel rectangle [px_first, px_first + w - 1] x [py_first, py_first + h - 1].
-__device__ __forceinline__ bool splat_reaches_rect(float4 co, float2 c, int px_first, int py_first, int w, int h) {
-    const float A = co.x, B = co.y, C = co.z;
-    if (!(A > 0.f) || !(C > 0.f) || !((B * B) < 0.99f * (A * C))) return true;
-    const float budget = logf(255.0f * co.w);  // o <= 0 gives -inf (nothing visible), NaN keeps the pair
-    const float x_lo = c.x - (float)(px_first + w - 1), x_hi = c.x - (float)px_first;
-    const float y_lo = c.y - (float)(py_first + h - 1), y_hi = c.y - (float)py_first;
-    if (x_lo <= 0.f && x_hi >= 0.f && y_lo <= 0.f && y_hi >= 0.f) return true;  // centre inside the rectangle
-    float qmin = edge_q(A, B, C, x_lo, fminf(y_hi, fmaxf(y_lo, -(B * x_lo) / C)));
-    qmin = fminf(qmin, edge_q(A, B, C, x_hi, fminf(y_hi, fmaxf(y_lo, -(B * x_hi) / C))));
-    qmin = fminf(qmin, edge_q(A, B, C, fminf(x_hi, fmaxf(x_lo, -(B * y_lo) / A)), y_lo));
-    qmin = fminf(qmin, edge_q(A, B, C, fminf(x_hi, fmaxf(x_lo, -(B * y_hi) / A)), y_hi));
-    return !(qmin * 0.998f - 1.0e-3f > budget);
-}
-
-__device__ __forceinline__ bool splat_reaches_tile(float4 co, float2 c, int tile_x, int tile_y) {
-    return splat_reaches_rect(co, c, tile_x * kTile, tile_y * kTile, kTile, kTile);
-}
-
-// ------------------------------------------------------------------------------------------------
 // K3: wave-cooperative pair expansion in depth order.  Lane L of a wave owns sorted position
-// k = wave_base + L; the wave's pairs occupy [offsets[k0-1], offsets[k0+63]) contiguously, and all
-// 64 lanes stride over that flat range, locating the owning Gaussian by binary search on the
-// lanes' inclusive counts (6 ds_bpermute steps).
+// k = wave_base + L; the wave's LIVE pairs occupy [offsets[k0-1], offsets[k0+63]) contiguously, and
+// all 64 lanes stride over that flat range, locating the owning Gaussian by binary search on the
+// lanes' inclusive counts (6 ds_bpermute steps) and the tile by selecting the r-th set bit of the
+// owner's live mask.  Writes are coalesced and exactly num_live long; a screen-filling splat does
+// not serialise one lane.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) duplicate_kernel(int P, int grid_x, int grid_y, int cull,
+__device__ __forceinline__ uint32_t select_set_bit(uint32_t m, uint32_t r) {  // position of the r-th (0-based) set bit
+    uint32_t pos = 0, c;
+    c = (uint32_t)__popc(m & 0xFFFFu); if (r >= c) { r -= c; pos += 16; m >>= 16; }
+    c = (uint32_t)__popc(m & 0xFFu);   if (r >= c) { r -= c; pos += 8;  m >>= 8; }
+    c = (uint32_t)__popc(m & 0xFu);    if (r >= c) { r -= c; pos += 4;  m >>= 4; }
+    c = (uint32_t)__popc(m & 0x3u);    if (r >= c) { r -= c; pos += 2;  m >>= 2; }
+    if (r >= (m & 1u)) pos += 1;
+    return pos;
+}
+
+__global__ void __launch_bounds__(256) duplicate_kernel(int P, int grid_x, int grid_y,
                                                         const uint32_t* __restrict__ depth_order,
                                                         const uint32_t* __restrict__ point_offsets,
                                                         const float2* __restrict__ means2D,
-                                                        const float4* __restrict__ conic_opacity,
                                                         const int* __restrict__ radii,
+                                                        const uint32_t* __restrict__ live_mask,
                                                         uint32_t* __restrict__ tile_keys,
                                                         uint32_t* __restrict__ point_list) {
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -310,13 +349,14 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, int grid_x, int g
     const uint32_t total = __shfl(incl, 63) - base;  // wave-uniform
     if (total == 0) return;
 
-    uint32_t gid = 0, xy0 = 0, w = 1;
+    uint32_t gid = 0, xy0 = 0, w = 1, mask = 0xFFFFFFFFu;
     if (incl != excl) {
         gid = depth_order[k];
         const float2 c = means2D[gid];
         const TileRect rc = tile_rect(c.x, c.y, radii[gid], grid_x, grid_y);
         xy0 = (uint32_t)rc.x0 | ((uint32_t)rc.y0 << 16);
         w = (uint32_t)(rc.x1 - rc.x0);
+        mask = live_mask[gid];  // all ones: every tile of the rectangle is live (or culling is off)
     }
     const uint32_t incl_rel = incl - base, excl_rel = excl - base;
 
@@ -333,16 +373,12 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, int grid_x, int g
         const uint32_t o_xy0 = __shfl(xy0, lo);
         const uint32_t o_w = __shfl(w, lo);
         const uint32_t o_gid = __shfl(gid, lo);
+        const uint32_t o_mask = __shfl(mask, lo);
         if (t < total) {
-            const uint32_t local = t - o_excl;
+            const uint32_t r = t - o_excl;                              // rank among the owner's live tiles
+            const uint32_t local = o_mask == 0xFFFFFFFFu ? r : select_set_bit(o_mask, r);
             const uint32_t row = local / o_w, col = local - row * o_w;
-            const uint32_t tx = (o_xy0 & 0xFFFFu) + col, ty = (o_xy0 >> 16) + row;
-            uint32_t tile = ty * (uint32_t)grid_x + tx;
-            // a culled pair keeps its slot but gets the key one past the last tile: the stable tile
-            // sort parks it behind every live pair and no range ever covers it
-            if (cull && !splat_reaches_tile(conic_opacity[o_gid], means2D[o_gid], (int)tx, (int)ty))
-                tile = (uint32_t)(grid_x * grid_y);
-            tile_keys[base + t] = tile;
+            tile_keys[base + t] = ((o_xy0 >> 16) + row) * (uint32_t)grid_x + (o_xy0 & 0xFFFFu) + col;
             point_list[base + t] = o_gid;
         }
     }
@@ -644,6 +680,34 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Frame hand-off: planar fp32 RGB + alpha -> planar RGBA8 with the rounding torchvision's
+// save_image applies to the PNGs the reference writes (scene_representation.py:427):
+// clamp(x * 255 + 0.5, 0, 255) truncated.  Pure streaming: 16 B in, 4 B out per pixel.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t quantize8(float v) {
+    const float q = fminf(255.0f, fmaxf(0.0f, v * 255.0f + 0.5f));
+    return (uint32_t)(int)q;
+}
+
+__global__ void __launch_bounds__(256) pack_rgba8_kernel(const float* __restrict__ color,
+                                                         const float* __restrict__ alpha,
+                                                         uint8_t* __restrict__ out, size_t n_pixels, int vec_ok) {
+    // grid.y = plane (0..2 colour, 3 alpha); each thread owns 4 consecutive pixels of its plane
+    const int plane = blockIdx.y;
+    const float* __restrict__ src = plane < 3 ? color + (size_t)plane * n_pixels : alpha;
+    uint8_t* __restrict__ dst = out + (size_t)plane * n_pixels;
+    const size_t base = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (base >= n_pixels) return;
+    if (vec_ok && base + 3 < n_pixels) {
+        const float4 v = *reinterpret_cast<const float4*>(src + base);
+        const uint32_t packed = quantize8(v.x) | (quantize8(v.y) << 8) | (quantize8(v.z) << 16) | (quantize8(v.w) << 24);
+        *reinterpret_cast<uint32_t*>(dst + base) = packed;
+    } else {
+        for (size_t i = base; i < n_pixels && i < base + 4; ++i) dst[i] = (uint8_t)quantize8(src[i]);
+    }
+}
+
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
 } // namespace
@@ -661,11 +725,11 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmat
     return hipGetLastError();
 }
 
-hipError_t launch_duplicate(int P, const Camera& cam, bool cull, const uint32_t* depth_order,
-                            const uint32_t* point_offsets, const float2* means2D, const float4* conic_opacity,
-                            const int* radii, uint32_t* tile_keys, uint32_t* point_list, hipStream_t stream) {
+hipError_t launch_duplicate(int P, const Camera& cam, const uint32_t* depth_order, const uint32_t* point_offsets,
+                            const float2* means2D, const int* radii, const uint32_t* live_mask, uint32_t* tile_keys,
+                            uint32_t* point_list, hipStream_t stream) {
     hipLaunchKernelGGL(duplicate_kernel, dim3(div_up(P, 256)), dim3(256), 0, stream, P, cam.grid_x, cam.grid_y,
-                       cull ? 1 : 0, depth_order, point_offsets, means2D, conic_opacity, radii, tile_keys, point_list);
+                       depth_order, point_offsets, means2D, radii, live_mask, tile_keys, point_list);
     return hipGetLastError();
 }
 
@@ -673,6 +737,16 @@ hipError_t launch_tile_ranges(uint32_t num_rendered, int num_tiles, const uint32
                               uint2* ranges, hipStream_t stream) {
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(div_up(num_tiles, 256)), dim3(256), 0, stream, num_rendered,
                        num_tiles, sorted_tile_keys, ranges);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_rgba8(const float* color, const float* alpha, uint8_t* out, size_t n_pixels,
+                             hipStream_t stream) {
+    const bool vec_ok = n_pixels % 4 == 0 && ((uintptr_t)color % 16 == 0) && ((uintptr_t)alpha % 16 == 0) &&
+                        ((uintptr_t)out % 4 == 0);
+    const size_t threads = (n_pixels + 3) / 4;
+    hipLaunchKernelGGL(pack_rgba8_kernel, dim3((unsigned)((threads + 255) / 256), 4), dim3(256), 0, stream, color,
+                       alpha, out, n_pixels, vec_ok ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -98,10 +98,13 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     device = _require_gpu(means3D, "means3D")
     P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
 
-    out_color = torch.zeros((3, H, W), dtype=torch.float32, device=device)
-    out_depth = torch.zeros((1, H, W), dtype=torch.float32, device=device)
-    out_alpha = torch.zeros((1, H, W), dtype=torch.float32, device=device)
-    radii = torch.zeros((P,), dtype=torch.int32, device=device)
+    # The reference zero-fills its outputs (rasterize_points.cu:68-71), which only matters for P == 0:
+    # with P > 0 every pixel and every radius is written by the kernels, so the fills are skipped.
+    make = torch.zeros if P == 0 else torch.empty
+    out_color = make((3, H, W), dtype=torch.float32, device=device)
+    out_depth = make((1, H, W), dtype=torch.float32, device=device)
+    out_alpha = make((1, H, W), dtype=torch.float32, device=device)
+    radii = make((P,), dtype=torch.int32, device=device)
     scratch = _CallScratch(device)
     rendered = 0
     if P != 0:
@@ -127,7 +130,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             raise RuntimeError(f"gsr_forward failed ({rendered}): {_lib.last_error()}")
         _last_layout.clear()
         _last_layout.update({"geom": _lib.offsets("geom"), "binning": _lib.offsets("binning"),
-                             "image": _lib.offsets("image")})
+                             "image": _lib.offsets("image"), "counts": _lib.pair_counts()})
     return (rendered, out_color, out_depth, out_alpha, radii, scratch.buffers["geom"], scratch.buffers["binning"],
             scratch.buffers["image"])
 

@@ -89,6 +89,12 @@ GSR_API int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user,
 GSR_API int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream);
 
+/* Frame hand-off used by the trajectory driver: planar fp32 color[3,H,W] + alpha[H,W] -> planar
+ * uint8 rgba8[4,H,W], quantised as torchvision.utils.save_image does for the RGBA PNGs the reference
+ * writes (scene_representation.py:427): clamp(x * 255 + 0.5, 0, 255), truncated. */
+GSR_API int gsr_pack_rgba8(const float* color, const float* alpha, uint8_t* rgba8, int width, int height,
+                           void* stream);
+
 /* Declared so the binding surface is complete; returns GSR_ERR_UNSUPPORTED (backward is the
  * first "next" row). */
 GSR_API int gsr_backward(void);
@@ -102,16 +108,17 @@ typedef enum gsr_geom_slot {
     GSR_GEOM_MEANS2D,           /* f32[2P]  pixel centre                                           */
     GSR_GEOM_CONIC_OPACITY,     /* f32[4P]  inverse 2D covariance (xx,xy,yy) + opacity             */
     GSR_GEOM_RGB,               /* f32[3P]  SH-evaluated colour (unused with colors_precomp)       */
-    GSR_GEOM_TILES_TOUCHED,     /* u32[P]   tiles in the splat's rectangle (0 = culled)            */
+    GSR_GEOM_TILES_TOUCHED,     /* u32[P]   live tiles of the splat's rectangle (0 = culled); see GSR_OPT_TILE_CULL */
     GSR_GEOM_INTERNAL_RADII,    /* i32[P]   used when the caller passes radii == NULL              */
     GSR_GEOM_DEPTH_ORDER,       /* u32[P]   Gaussian ids, ascending (depth bits, id); culled last  */
     GSR_GEOM_POINT_OFFSETS,     /* u32[P]   inclusive scan of tiles_touched in DEPTH_ORDER order   */
+    GSR_GEOM_LIVE_MASK,         /* u32[P]   bit i = i-th tile (row-major) of the rectangle is live; ~0 = all */
     GSR_GEOM_NUM_SLOTS
 } gsr_geom_slot;
 
 typedef enum gsr_binning_slot {
-    GSR_BIN_POINT_LIST = 0,     /* u32[num_rendered] Gaussian ids sorted by (tile, depth bits, id); see GSR_OPT_TILE_CULL */
-    GSR_BIN_TILE_KEYS,          /* u32[num_rendered] tile id of each entry of POINT_LIST (T = parked) */
+    GSR_BIN_POINT_LIST = 0,     /* u32[live pairs] Gaussian ids sorted by (tile, depth bits, id); see GSR_OPT_TILE_CULL */
+    GSR_BIN_TILE_KEYS,          /* u32[live pairs] tile id of each entry of POINT_LIST                */
     GSR_BIN_NUM_SLOTS
 } gsr_binning_slot;
 
@@ -125,15 +132,18 @@ typedef enum gsr_image_slot {
 GSR_API int gsr_last_geom_offsets(size_t offsets[GSR_GEOM_NUM_SLOTS]);
 GSR_API int gsr_last_binning_offsets(size_t offsets[GSR_BIN_NUM_SLOTS]);
 GSR_API int gsr_last_image_offsets(size_t offsets[GSR_IMG_NUM_SLOTS]);
+/* counts[0] = num_rendered as the reference defines it (sum of rectangle areas, the return value of
+ * gsr_forward); counts[1] = live pairs = length of POINT_LIST / TILE_KEYS. */
+GSR_API int gsr_last_pair_counts(uint32_t counts[2]);
 
 /* ---- options (process-wide; defaults in brackets) ---- */
 typedef enum gsr_option {
     /* [1] Exact-image tile culling: a (tile, Gaussian) pair of the reference's rectangle for which
-     * no pixel of the tile can reach alpha >= 1/255 is parked behind all live pairs (tile key T)
-     * instead of being blended.  color / depth / alpha / radii / num_rendered are bit-identical
-     * with the option on or off; POINT_LIST then holds the live pairs in the reference's order
-     * followed by the parked ones, and RANGES / N_CONTRIB index the live prefix.  0 reproduces
-     * the reference's lists exactly. */
+     * no pixel of the tile can reach alpha >= 1/255 is never expanded, sorted or blended.
+     * color / depth / alpha / radii and the returned num_rendered are bit-identical with the option
+     * on or off; POINT_LIST then holds only the live pairs (a subsequence of the reference's list,
+     * same order), and TILES_TOUCHED / POINT_OFFSETS / RANGES / N_CONTRIB count live pairs.
+     * 0 reproduces the reference's lists exactly. */
     GSR_OPT_TILE_CULL = 0,
     /* [1] Blend kernel shape: 0 = one wave64 per 16x16 tile (4 pixels per lane), 1 = one wave64 per
      * 8x8 quadrant with per-quadrant entry skipping.  Same results; a tuning / A-B knob. */

@@ -106,8 +106,12 @@ def _hip_forward_raw(_C, cloud, cam, device, bg, scale_modifier, sh_degree, cov3
         out["depth_order"] = view(geom, g["depth_order"], torch.int32, P).astype(np.uint32)
         out["point_offsets"] = view(geom, g["point_offsets"], torch.int32, P).astype(np.uint32)
         b = lay["binning"]
-        out["point_list"] = view(binning, b["point_list"], torch.int32, n).astype(np.uint32)
-        out["tile_keys"] = view(binning, b["tile_keys"], torch.int32, n).astype(np.uint32)
+        live = lay["counts"]["live_pairs"]
+        assert lay["counts"]["num_rendered"] == n
+        out["live_pairs"] = live
+        out["live_mask"] = view(geom, g["live_mask"], torch.int32, P).astype(np.uint32)
+        out["point_list"] = view(binning, b["point_list"], torch.int32, live).astype(np.uint32)
+        out["tile_keys"] = view(binning, b["tile_keys"], torch.int32, live).astype(np.uint32)
         i = lay["image"]
         out["ranges"] = view(img, i["ranges"], torch.int32, 2 * T, (T, 2)).astype(np.uint32)
         out["n_contrib"] = view(img, i["n_contrib"], torch.int32, W * H, (H, W)).astype(np.uint32)

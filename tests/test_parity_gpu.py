@@ -124,8 +124,10 @@ def assert_culled_lists(name, on, ref, W, H):
                 assert pair_is_dead(ref, int(g), t, W, H), f"{name}: live pair (tile {t}, gaussian {g}) was culled"
         assert i == len(lhip), f"{name}: tile {t} list is not a subsequence of the reference list"
         kept += len(lhip)
-    live = int(on["ranges"][:, 1].max()) if on["ranges"].size else 0
-    assert (on["tile_keys"][live:] == ref["ranges"].shape[0]).all() and kept == live
+    assert kept == on["live_pairs"] == on["point_list"].size and kept == int(on["tiles_touched"].sum())
+    small = ref["tiles_touched"] <= 32
+    assert (on["live_mask"][~small] == 0xFFFFFFFF).all(), "large rectangles must not be culled"
+    assert (on["tiles_touched"] <= ref["tiles_touched"]).all()
     report(name + ":cull", kept=kept, dropped=dropped, kept_frac=kept / max(1, kept + dropped))
     return kept, dropped
 
@@ -383,6 +385,24 @@ def test_blend_variants_agree_bit_for_bit(case):
         np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=f"{case}: {k} differs between blend variants")
 
 
+@pytest.mark.parametrize("hw", [(1080, 1920), (33, 17), (7, 5)])
+def test_pack_rgba8_matches_save_image_rounding(hw):
+    """The fused hand-off kernel against the plain torch expression of torchvision's save_image rounding."""
+    from autovfx_amd.frame_parallel import pack_rgba8
+    H, W = hw
+    g = torch.Generator().manual_seed(H)
+    color = (torch.rand(3, H, W, generator=g) * 1.4 - 0.2).cuda()
+    alpha = torch.rand(1, H, W, generator=g).cuda()
+    color[0, 0, :4] = torch.tensor([0.0, 1.0, 0.5 / 255, 254.5 / 255])[: min(4, W)].cuda()
+    got = pack_rgba8(color, alpha)
+    ref = torch.cat((color, alpha), 0).mul(255.0).add_(0.5).clamp_(0.0, 255.0).to(torch.uint8)
+    assert got.dtype == torch.uint8 and got.shape == (4, H, W)
+    assert torch.equal(got, ref)
+    out = torch.empty(2, 4, H, W, dtype=torch.uint8, device="cuda")
+    pack_rgba8(color, alpha, out=out[1])
+    assert torch.equal(out[1], ref)
+
+
 # ---- golden vectors produced by the reference's own sources (tests/golden/make_golden.py) --------------------
 
 from test_golden import GOLDEN, load_case  # noqa: E402
@@ -441,7 +461,8 @@ def test_full_size_properties(c3_frame):
     on = hip_forward_raw(cloud, cam, bg=(0.0, 0.0, 0.0), debug=False, cull=True)
     for k in ("color", "depth", "alpha", "radii"):
         np.testing.assert_array_equal(on[k], a[k], err_msg=f"c3: {k} changed by tile culling")
-    live = int(on["ranges"][:, 1].max())
+    live = on["live_pairs"]
+    assert a["live_pairs"] == a["num_rendered"] == on["num_rendered"]
     report("c3_cull", num_rendered=int(a["num_rendered"]), live_pairs=live, kept_frac=live / a["num_rendered"])
     assert a["alpha"].min() >= 0.0 and a["alpha"].max() < 1.0 and a["depth"].min() >= 0.0
     assert a["num_rendered"] == int(a["tiles_touched"].astype(np.int64).sum())
