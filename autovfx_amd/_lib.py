@@ -15,8 +15,8 @@ LIB_PATH = os.environ.get("GSR_LIB", os.path.join(_HERE, "lib", "libgsr_hip.so")
 ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 
 # enum mirrors of include/gsr.h
-GEOM_SLOTS = ("depths", "means2D", "conic_opacity", "rgb", "tiles_touched", "internal_radii", "depth_order",
-              "point_offsets", "live_mask")
+GEOM_SLOTS = ("depths", "means2D", "conic_opacity", "rgb", "splat_bins", "internal_radii", "depth_order",
+              "point_offsets")
 BIN_SLOTS = ("point_list", "tile_keys")
 IMG_SLOTS = ("ranges", "n_contrib")
 STAGES = ("preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "ranges", "blend")

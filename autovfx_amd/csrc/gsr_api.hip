@@ -230,12 +230,11 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     g_geom_off[GSR_GEOM_MEANS2D] = gc.take<float2>(n);
     g_geom_off[GSR_GEOM_CONIC_OPACITY] = gc.take<float4>(n);
     g_geom_off[GSR_GEOM_RGB] = gc.take<float>(3 * n);
-    g_geom_off[GSR_GEOM_TILES_TOUCHED] = gc.take<uint32_t>(n);
+    g_geom_off[GSR_GEOM_SPLAT_BINS] = gc.take<gsr::SplatBin>(n);
     g_geom_off[GSR_GEOM_INTERNAL_RADII] = gc.take<int>(n);
     const size_t off_keys_a = gc.take<uint32_t>(n), off_keys_b = gc.take<uint32_t>(n);
     const size_t off_ids_a = gc.take<uint32_t>(n), off_ids_b = gc.take<uint32_t>(n);
     g_geom_off[GSR_GEOM_POINT_OFFSETS] = gc.take<uint32_t>(n);
-    g_geom_off[GSR_GEOM_LIVE_MASK] = gc.take<uint32_t>(n);
     // kRectPartials u64 partial sums of rectangle areas, then one u32 error flag
     const size_t off_flag = gc.take<unsigned long long>(gsr::kRectPartials + 1);
     const size_t off_tmp = gc.take<char>(sort_tmp > scan_tmp ? sort_tmp : scan_tmp);
@@ -265,13 +264,12 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     ga.means2D = (float2*)(gbase + g_geom_off[GSR_GEOM_MEANS2D]);
     ga.conic_opacity = (float4*)(gbase + g_geom_off[GSR_GEOM_CONIC_OPACITY]);
     ga.rgb = (float*)(gbase + g_geom_off[GSR_GEOM_RGB]);
-    ga.tiles_touched = (uint32_t*)(gbase + g_geom_off[GSR_GEOM_TILES_TOUCHED]);
+    ga.bins = (gsr::SplatBin*)(gbase + g_geom_off[GSR_GEOM_SPLAT_BINS]);
     ga.radii = radii ? radii : (int*)(gbase + g_geom_off[GSR_GEOM_INTERNAL_RADII]);
     ga.depth_keys = (uint32_t*)(gbase + off_keys_a);
     ga.ids = (uint32_t*)(gbase + off_ids_a);
     ga.rect_total = (unsigned long long*)(gbase + off_flag);
     ga.error_flag = (uint32_t*)(ga.rect_total + gsr::kRectPartials);
-    ga.live_mask = (uint32_t*)(gbase + g_geom_off[GSR_GEOM_LIVE_MASK]);
     uint32_t* point_offsets = (uint32_t*)(gbase + g_geom_off[GSR_GEOM_POINT_OFFSETS]);
     void* tmp = gbase + off_tmp;
     const size_t tmp_bytes = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
@@ -289,7 +287,7 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     stamp(2, stream);
     g_geom_off[GSR_GEOM_DEPTH_ORDER] = (size_t)((char*)order - gbase);
 
-    GSR_HIP(gsr::scan_tiles_in_order(tmp, tmp_bytes, P, ga.tiles_touched, order, point_offsets, stream));
+    GSR_HIP(gsr::scan_tiles_in_order(tmp, tmp_bytes, P, ga.bins, order, point_offsets, stream));
     // The one host round trip of the call (rasterizer_impl.cu:282): num_rendered sizes the binning arena.
     // host: [counters: kRectPartials x u64, flag u32 (+pad)] [live pairs u32]
     char* hostb = reinterpret_cast<char*>(g_pinned.host);
@@ -331,8 +329,7 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     uint32_t* n_contrib = (uint32_t*)(iraw + g_img_off[GSR_IMG_N_CONTRIB]);
 
     if (num_live > 0) {
-        GSR_HIP(gsr::launch_duplicate(P, cam, order, point_offsets, ga.means2D, ga.radii, ga.live_mask, tile_keys,
-                                      point_list, stream));
+        GSR_HIP(gsr::launch_duplicate(P, cam, order, point_offsets, ga.bins, tile_keys, point_list, stream));
         GSR_STAGE_CHECK("duplicate");
         stamp(4, stream);
         uint32_t *tk_sorted = nullptr, *pl_sorted = nullptr;

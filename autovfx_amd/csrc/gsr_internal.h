@@ -33,13 +33,21 @@ struct GaussianInputs {
     int tile_cull;  // GSR_OPT_TILE_CULL
 };
 
+// Everything the pair expansion needs about one splat, in one 16-byte record so that walking the
+// splats in depth order costs one gather per splat instead of three.
+struct SplatBin {
+    uint32_t xy0;    // first tile of the rectangle: x | y << 16
+    uint32_t width;  // rectangle width in tiles
+    uint32_t mask;   // bit i = i-th tile (row-major) is live; all ones = the whole rectangle
+    uint32_t count;  // live tiles = pairs this splat emits (0 = culled)
+};
+
 struct GeometryArrays {
     float* depths;
     float2* means2D;
     float4* conic_opacity;
     float* rgb;
-    uint32_t* tiles_touched; // live tiles of the splat's rectangle (== its area when culling is off)
-    uint32_t* live_mask;     // bit i = i-th tile of the rectangle (row-major) is live; all ones = whole rectangle
+    SplatBin* bins;
     unsigned long long* rect_total;  // kRectPartials device counters; their sum = the reference's num_rendered
     int* radii;           // caller's radii or the internal array
     uint32_t* depth_keys; // sort keys (float bits of depth, kCulledKey if culled)
@@ -53,8 +61,7 @@ hipError_t launch_preprocess(const GaussianInputs& in, const Camera& cam, const 
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
                                hipStream_t stream);
 hipError_t launch_duplicate(int P, const Camera& cam, const uint32_t* depth_order, const uint32_t* point_offsets,
-                            const float2* means2D, const int* radii, const uint32_t* live_mask, uint32_t* tile_keys,
-                            uint32_t* point_list, hipStream_t stream);
+                            const SplatBin* bins, uint32_t* tile_keys, uint32_t* point_list, hipStream_t stream);
 hipError_t launch_tile_ranges(uint32_t num_rendered, int num_tiles, const uint32_t* sorted_tile_keys,
                               uint2* ranges, hipStream_t stream);
 // variant 0: one wave per tile, 4 pixels per lane; variant 1: one wave per 8x8 quadrant
@@ -74,9 +81,9 @@ hipError_t depth_sort_temp_bytes(int P, size_t* temp_bytes);
 hipError_t depth_sort(void* temp, size_t temp_bytes, int P, uint32_t* keys, uint32_t* keys_alt, uint32_t* ids,
                       uint32_t* ids_alt, uint32_t** keys_sorted, uint32_t** ids_sorted, hipStream_t stream);
 hipError_t scan_temp_bytes(int P, size_t* temp_bytes);
-// offsets[k] = sum_{j<=k} tiles_touched[order[j]]
-hipError_t scan_tiles_in_order(void* temp, size_t temp_bytes, int P, const uint32_t* tiles_touched,
-                               const uint32_t* order, uint32_t* offsets, hipStream_t stream);
+// offsets[k] = sum_{j<=k} bins[order[j]].count
+hipError_t scan_tiles_in_order(void* temp, size_t temp_bytes, int P, const SplatBin* bins, const uint32_t* order,
+                               uint32_t* offsets, hipStream_t stream);
 hipError_t tile_sort_temp_bytes(uint32_t n, size_t* temp_bytes);
 // Stable ascending sort of (tile_keys, point_list) on the low `bits` key bits.
 hipError_t tile_sort(void* temp, size_t temp_bytes, uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt,

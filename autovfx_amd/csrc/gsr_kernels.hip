@@ -197,7 +197,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
     const float vz = vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14];
 
     int radius_out = 0;
-    uint32_t tiles = 0, rect_area = 0, mask = 0xFFFFFFFFu;
+    uint32_t rect_area = 0;
+    SplatBin bin = {0u, 1u, 0xFFFFFFFFu, 0u};
     uint32_t key = kCulledKey;
 
     if (vz <= 0.2f) {
@@ -274,22 +275,23 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
                 out.conic_opacity[i] = conic_o;
                 radius_out = irad;
                 rect_area = area;
-                tiles = area;
+                bin.xy0 = (uint32_t)rc.x0 | ((uint32_t)rc.y0 << 16);
+                bin.width = (uint32_t)(rc.x1 - rc.x0);
+                bin.count = area;
                 if (in.tile_cull && area <= 32u) {  // exact-image tile culling, see above
-                    mask = 0u;
-                    uint32_t bit = 0;
+                    uint32_t mask = 0u, bit = 0;
                     for (int ty = rc.y0; ty < rc.y1; ++ty)
                         for (int tx = rc.x0; tx < rc.x1; ++tx, ++bit)
                             if (splat_reaches_tile(conic_o, make_float2(px, py), tx, ty)) mask |= 1u << bit;
-                    tiles = (uint32_t)__popc(mask);
+                    bin.mask = mask;
+                    bin.count = (uint32_t)__popc(mask);
                 }
                 key = __float_as_uint(vz);
             }
         }
     }
     out.radii[i] = radius_out;
-    out.tiles_touched[i] = tiles;
-    out.live_mask[i] = mask;
+    *reinterpret_cast<uint4*>(out.bins + i) = make_uint4(bin.xy0, bin.width, bin.mask, bin.count);
     out.depth_keys[i] = key;
     // The reference's num_rendered (sum of rectangle areas) is part of its return value: keep it.
     // One atomic per wave, spread over kRectPartials words (same-word atomics serialise at ~12 ns).
@@ -331,9 +333,7 @@ __device__ __forceinline__ uint32_t select_set_bit(uint32_t m, uint32_t r) {  //
 __global__ void __launch_bounds__(256) duplicate_kernel(int P, int grid_x, int grid_y,
                                                         const uint32_t* __restrict__ depth_order,
                                                         const uint32_t* __restrict__ point_offsets,
-                                                        const float2* __restrict__ means2D,
-                                                        const int* __restrict__ radii,
-                                                        const uint32_t* __restrict__ live_mask,
+                                                        const SplatBin* __restrict__ bins,
                                                         uint32_t* __restrict__ tile_keys,
                                                         uint32_t* __restrict__ point_list) {
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -352,11 +352,10 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, int grid_x, int g
     uint32_t gid = 0, xy0 = 0, w = 1, mask = 0xFFFFFFFFu;
     if (incl != excl) {
         gid = depth_order[k];
-        const float2 c = means2D[gid];
-        const TileRect rc = tile_rect(c.x, c.y, radii[gid], grid_x, grid_y);
-        xy0 = (uint32_t)rc.x0 | ((uint32_t)rc.y0 << 16);
-        w = (uint32_t)(rc.x1 - rc.x0);
-        mask = live_mask[gid];  // all ones: every tile of the rectangle is live (or culling is off)
+        const uint4 b = *reinterpret_cast<const uint4*>(bins + gid);  // one 16-byte gather per splat
+        xy0 = b.x;
+        w = b.y;
+        mask = b.z;  // all ones: every tile of the rectangle is live (or culling is off)
     }
     const uint32_t incl_rel = incl - base, excl_rel = excl - base;
 
@@ -726,10 +725,9 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmat
 }
 
 hipError_t launch_duplicate(int P, const Camera& cam, const uint32_t* depth_order, const uint32_t* point_offsets,
-                            const float2* means2D, const int* radii, const uint32_t* live_mask, uint32_t* tile_keys,
-                            uint32_t* point_list, hipStream_t stream) {
+                            const SplatBin* bins, uint32_t* tile_keys, uint32_t* point_list, hipStream_t stream) {
     hipLaunchKernelGGL(duplicate_kernel, dim3(div_up(P, 256)), dim3(256), 0, stream, P, cam.grid_x, cam.grid_y,
-                       depth_order, point_offsets, means2D, radii, live_mask, tile_keys, point_list);
+                       depth_order, point_offsets, bins, tile_keys, point_list);
     return hipGetLastError();
 }
 

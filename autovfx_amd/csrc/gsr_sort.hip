@@ -21,9 +21,9 @@ namespace gsr {
 
 namespace {
 struct TilesInOrder {
-    const uint32_t* tiles;
+    const SplatBin* bins;
     const uint32_t* order;
-    __device__ __forceinline__ uint32_t operator()(uint32_t k) const { return tiles[order[k]]; }
+    __device__ __forceinline__ uint32_t operator()(uint32_t k) const { return bins[order[k]].count; }
 };
 } // namespace
 
@@ -50,10 +50,10 @@ hipError_t scan_temp_bytes(int P, size_t* temp_bytes) {
                                    rocprim::plus<uint32_t>());
 }
 
-hipError_t scan_tiles_in_order(void* temp, size_t temp_bytes, int P, const uint32_t* tiles_touched,
-                               const uint32_t* order, uint32_t* offsets, hipStream_t stream) {
+hipError_t scan_tiles_in_order(void* temp, size_t temp_bytes, int P, const SplatBin* bins, const uint32_t* order,
+                               uint32_t* offsets, hipStream_t stream) {
     auto in = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint32_t>(0u),
-                                               TilesInOrder{tiles_touched, order});
+                                               TilesInOrder{bins, order});
     return rocprim::inclusive_scan(temp, temp_bytes, in, offsets, (size_t)P, rocprim::plus<uint32_t>(), stream);
 }
 

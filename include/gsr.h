@@ -108,11 +108,11 @@ typedef enum gsr_geom_slot {
     GSR_GEOM_MEANS2D,           /* f32[2P]  pixel centre                                           */
     GSR_GEOM_CONIC_OPACITY,     /* f32[4P]  inverse 2D covariance (xx,xy,yy) + opacity             */
     GSR_GEOM_RGB,               /* f32[3P]  SH-evaluated colour (unused with colors_precomp)       */
-    GSR_GEOM_TILES_TOUCHED,     /* u32[P]   live tiles of the splat's rectangle (0 = culled); see GSR_OPT_TILE_CULL */
+    GSR_GEOM_SPLAT_BINS,        /* u32[4P]  per splat: first tile x | y << 16, rectangle width, live-tile mask
+                                   (~0 = all), live tiles = pairs emitted (0 = culled); GSR_OPT_TILE_CULL */
     GSR_GEOM_INTERNAL_RADII,    /* i32[P]   used when the caller passes radii == NULL              */
     GSR_GEOM_DEPTH_ORDER,       /* u32[P]   Gaussian ids, ascending (depth bits, id); culled last  */
-    GSR_GEOM_POINT_OFFSETS,     /* u32[P]   inclusive scan of tiles_touched in DEPTH_ORDER order   */
-    GSR_GEOM_LIVE_MASK,         /* u32[P]   bit i = i-th tile (row-major) of the rectangle is live; ~0 = all */
+    GSR_GEOM_POINT_OFFSETS,     /* u32[P]   inclusive scan of the pair counts in DEPTH_ORDER order     */
     GSR_GEOM_NUM_SLOTS
 } gsr_geom_slot;
 
@@ -142,7 +142,7 @@ typedef enum gsr_option {
      * no pixel of the tile can reach alpha >= 1/255 is never expanded, sorted or blended.
      * color / depth / alpha / radii and the returned num_rendered are bit-identical with the option
      * on or off; POINT_LIST then holds only the live pairs (a subsequence of the reference's list,
-     * same order), and TILES_TOUCHED / POINT_OFFSETS / RANGES / N_CONTRIB count live pairs.
+     * same order), and SPLAT_BINS / POINT_OFFSETS / RANGES / N_CONTRIB count live pairs.
      * 0 reproduces the reference's lists exactly. */
     GSR_OPT_TILE_CULL = 0,
     /* [1] Blend kernel shape: 0 = one wave64 per 16x16 tile (4 pixels per lane), 1 = one wave64 per

@@ -102,14 +102,15 @@ def _hip_forward_raw(_C, cloud, cam, device, bg, scale_modifier, sh_degree, cov3
         out["means2D"] = view(geom, g["means2D"], torch.float32, 2 * P, (P, 2))
         out["conic_opacity"] = view(geom, g["conic_opacity"], torch.float32, 4 * P, (P, 4))
         out["rgb"] = view(geom, g["rgb"], torch.float32, 3 * P, (P, 3))
-        out["tiles_touched"] = view(geom, g["tiles_touched"], torch.int32, P).astype(np.uint32)
+        bins = view(geom, g["splat_bins"], torch.int32, 4 * P, (P, 4)).astype(np.uint32)
+        out["tiles_touched"] = bins[:, 3].copy()    # live tiles = pairs the splat emits
+        out["live_mask"] = bins[:, 2].copy()
         out["depth_order"] = view(geom, g["depth_order"], torch.int32, P).astype(np.uint32)
         out["point_offsets"] = view(geom, g["point_offsets"], torch.int32, P).astype(np.uint32)
         b = lay["binning"]
         live = lay["counts"]["live_pairs"]
         assert lay["counts"]["num_rendered"] == n
         out["live_pairs"] = live
-        out["live_mask"] = view(geom, g["live_mask"], torch.int32, P).astype(np.uint32)
         out["point_list"] = view(binning, b["point_list"], torch.int32, live).astype(np.uint32)
         out["tile_keys"] = view(binning, b["tile_keys"], torch.int32, live).astype(np.uint32)
         i = lay["image"]
