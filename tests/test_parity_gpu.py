@@ -491,3 +491,18 @@ def test_full_size_properties(c3_frame):
     report("c3_permutation", depth_ties=int(ties), differing_px=diff_px)
     assert diff_px <= 4 * ties, f"{diff_px} pixels changed under permutation with {ties} depth ties"
     np.testing.assert_array_equal(c["radii"], a["radii"][perm.numpy()])
+
+
+def test_multi_stream_shard_matches_serial():
+    """render_shard(streams=2) (two host threads, two HIP streams) returns exactly the serial result."""
+    from autovfx_amd import frame_parallel as fp
+    dev = torch.device("cuda", 0)
+    cloud = scenes.config_c2(P=100_000, seed=2).to(dev)
+    cams = [c.to(dev) for c in orbit_cameras(9, 320, 180)]
+    bg = torch.zeros(3, device=dev)
+    ids = list(range(9))
+    a = fp.render_shard(cloud, cams, ids, bg, keep_depth=True, streams=1)
+    b = fp.render_shard(cloud, cams, ids, bg, keep_depth=True, streams=2)
+    torch.cuda.synchronize()
+    assert torch.equal(a["rgba8"], b["rgba8"]) and torch.equal(a["depth"], b["depth"])
+    assert len({bytes(f.cpu().numpy().tobytes()) for f in a["rgba8"]}) == 9
