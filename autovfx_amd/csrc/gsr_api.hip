@@ -86,8 +86,9 @@ int tile_key_bits(uint32_t num_tiles) {
 
 constexpr size_t kCounterBytes = (gsr::kRectPartials + 1) * sizeof(unsigned long long);
 struct Pinned {
-    uint32_t* host = nullptr;  // a few KB of pinned memory per calling thread, deliberately never freed:
-};                             // freeing at thread exit can race HIP runtime teardown
+    uint32_t* host = nullptr;    // a few KB of pinned memory per calling thread, deliberately never freed:
+    hipEvent_t copied = nullptr; // freeing at thread exit can race HIP runtime teardown
+};
 thread_local Pinned g_pinned;
 
 void stamp(int idx, hipStream_t s) {
@@ -219,7 +220,10 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
         g_ev_made = true;
     }
     g_slot = (int)(g_timed_calls % kTimingRing);
-    if (!g_pinned.host) GSR_HIP(hipHostMalloc((void**)&g_pinned.host, kCounterBytes + 64, hipHostMallocPortable));
+    if (!g_pinned.host) {
+        GSR_HIP(hipHostMalloc((void**)&g_pinned.host, kCounterBytes + 64, hipHostMallocPortable));
+        GSR_HIP(hipEventCreateWithFlags(&g_pinned.copied, hipEventDisableTiming));
+    }
 
     // ---- geometry arena ----
     size_t sort_tmp = 0, scan_tmp = 0;
@@ -268,8 +272,8 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     ga.radii = radii ? radii : (int*)(gbase + g_geom_off[GSR_GEOM_INTERNAL_RADII]);
     ga.depth_keys = (uint32_t*)(gbase + off_keys_a);
     ga.ids = (uint32_t*)(gbase + off_ids_a);
-    ga.rect_total = (unsigned long long*)(gbase + off_flag);
-    ga.error_flag = (uint32_t*)(ga.rect_total + gsr::kRectPartials);
+    ga.pair_totals = (unsigned long long*)(gbase + off_flag);
+    ga.error_flag = (uint32_t*)(ga.pair_totals + gsr::kRectPartials);
     uint32_t* point_offsets = (uint32_t*)(gbase + g_geom_off[GSR_GEOM_POINT_OFFSETS]);
     void* tmp = gbase + off_tmp;
     const size_t tmp_bytes = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
@@ -280,6 +284,13 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     GSR_STAGE_CHECK("preprocess");
     stamp(1, stream);
 
+    // The one host round trip of the call (rasterizer_impl.cu:282 reads num_rendered back to size the
+    // binning arena).  Here the totals come out of the preprocess kernel, so the copy is queued right
+    // behind it and the host waits on an event while the GPU is already running the depth sort.
+    char* hostb = reinterpret_cast<char*>(g_pinned.host);
+    GSR_HIP(hipMemcpyAsync(hostb, gbase + off_flag, kCounterBytes, hipMemcpyDeviceToHost, stream));
+    GSR_HIP(hipEventRecord(g_pinned.copied, stream));
+
     uint32_t *keys_sorted = nullptr, *order = nullptr;
     GSR_HIP(gsr::depth_sort(tmp, tmp_bytes, P, ga.depth_keys, (uint32_t*)(gbase + off_keys_b), ga.ids,
                             (uint32_t*)(gbase + off_ids_b), &keys_sorted, &order, stream));
@@ -288,24 +299,21 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     g_geom_off[GSR_GEOM_DEPTH_ORDER] = (size_t)((char*)order - gbase);
 
     GSR_HIP(gsr::scan_tiles_in_order(tmp, tmp_bytes, P, ga.bins, order, point_offsets, stream));
-    // The one host round trip of the call (rasterizer_impl.cu:282): num_rendered sizes the binning arena.
-    // host: [counters: kRectPartials x u64, flag u32 (+pad)] [live pairs u32]
-    char* hostb = reinterpret_cast<char*>(g_pinned.host);
-    GSR_HIP(hipMemcpyAsync(hostb, gbase + off_flag, kCounterBytes, hipMemcpyDeviceToHost, stream));
-    GSR_HIP(hipMemcpyAsync(hostb + kCounterBytes, point_offsets + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    GSR_HIP(hipStreamSynchronize(stream));
-    uint32_t num_live = 0, flag = 0;
-    memcpy(&num_live, hostb + kCounterBytes, sizeof num_live);
+
+    GSR_HIP(hipEventSynchronize(g_pinned.copied));
+    uint32_t flag = 0;
     memcpy(&flag, hostb + gsr::kRectPartials * sizeof(unsigned long long), sizeof flag);
-    unsigned long long rect_total = 0;
+    unsigned long long rect_total = 0, live_total = 0;
     for (int i = 0; i < gsr::kRectPartials; ++i) {
         unsigned long long v;
         memcpy(&v, hostb + i * sizeof v, sizeof v);
-        rect_total += v;
+        rect_total += v >> 32;
+        live_total += v & 0xFFFFFFFFull;
     }
     if (debug && prefiltered && (flag & 1u))
         return fail(GSR_ERR_PREFILTERED, "a Gaussian was culled although prefiltered is set (auxiliary.h:156-160)");
     if (rect_total > 0x7FFFFFFFull) return fail(GSR_ERR_INVALID_ARG, "num_rendered %llu overflows int", rect_total);
+    const uint32_t num_live = (uint32_t)live_total;
     const uint32_t num_rendered = (uint32_t)rect_total;  // the reference's count; == num_live when culling is off
     g_counts[0] = num_rendered;
     g_counts[1] = num_live;

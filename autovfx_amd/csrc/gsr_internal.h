@@ -48,7 +48,7 @@ struct GeometryArrays {
     float4* conic_opacity;
     float* rgb;
     SplatBin* bins;
-    unsigned long long* rect_total;  // kRectPartials device counters; their sum = the reference's num_rendered
+    unsigned long long* pair_totals; // kRectPartials partial sums: (sum of rectangle areas) << 32 | live pairs
     int* radii;           // caller's radii or the internal array
     uint32_t* depth_keys; // sort keys (float bits of depth, kCulledKey if culled)
     uint32_t* ids;        // 0..P-1, the sort payload

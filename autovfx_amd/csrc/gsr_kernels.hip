@@ -293,13 +293,15 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
     out.radii[i] = radius_out;
     *reinterpret_cast<uint4*>(out.bins + i) = make_uint4(bin.xy0, bin.width, bin.mask, bin.count);
     out.depth_keys[i] = key;
-    // The reference's num_rendered (sum of rectangle areas) is part of its return value: keep it.
-    // One atomic per wave, spread over kRectPartials words (same-word atomics serialise at ~12 ns).
-    unsigned long long wave_rect = rect_area;
+    // Pair totals, needed on the host before the binning arena can be sized: the live pairs (what
+    // gets expanded and sorted) in the low word and the reference's num_rendered (sum of rectangle
+    // areas, part of its return value) in the high word of one 64-bit add.  One atomic per wave,
+    // spread over kRectPartials words (same-word atomics serialise at ~12 ns each).
+    unsigned long long wave_tot = ((unsigned long long)rect_area << 32) | (unsigned long long)bin.count;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) wave_rect += __shfl_xor(wave_rect, d);
-    if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) && wave_rect != 0)
-        atomicAdd(out.rect_total + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kRectPartials - 1)), wave_rect);
+    for (int d = 32; d >= 1; d >>= 1) wave_tot += __shfl_xor(wave_tot, d);
+    if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) && wave_tot != 0)
+        atomicAdd(out.pair_totals + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kRectPartials - 1)), wave_tot);
 }
 
 __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means3D,
