@@ -20,7 +20,7 @@ GEOM_SLOTS = ("depths", "means2D", "conic_opacity", "rgb", "splat_bins", "intern
 BIN_SLOTS = ("point_list", "tile_keys")
 IMG_SLOTS = ("ranges", "n_contrib")
 STAGES = ("preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "ranges", "blend")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/gsr.h declares
 SYMBOLS = ("gsr_forward", "gsr_mark_visible", "gsr_backward", "gsr_last_geom_offsets", "gsr_last_binning_offsets",
@@ -63,7 +63,14 @@ def _load() -> ctypes.CDLL:
     lib.gsr_pack_rgba8.restype = ctypes.c_int
     lib.gsr_pack_rgba8.argtypes = [c_f, c_f, c_f, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.gsr_backward.restype = ctypes.c_int
-    lib.gsr_backward.argtypes = []
+    lib.gsr_backward.argtypes = [
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f, ctypes.c_int, ctypes.c_int,  # P D M R bg W H
+        c_f, c_f, c_f, c_f, ctypes.c_float, c_f, c_f,          # means3D shs colors scales mod rotations cov3D
+        c_f, c_f, c_f, ctypes.c_float, ctypes.c_float,         # view proj campos tanx tany
+        c_f, c_f, c_f, c_f,                                    # radii geom binning image
+        c_f, c_f, c_f, c_f,                                    # accum_alphas dL_dpix dL_dpix_depth dL_dpix_alpha
+        c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f,      # dL_dmean2D conic opacity color depth mean3D cov3D sh scale rot
+        ctypes.c_int, ctypes.c_void_p]                         # debug stream
     for name, n in (("gsr_last_geom_offsets", len(GEOM_SLOTS)), ("gsr_last_binning_offsets", len(BIN_SLOTS)),
                     ("gsr_last_image_offsets", len(IMG_SLOTS))):
         fn = getattr(lib, name)

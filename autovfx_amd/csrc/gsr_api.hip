@@ -103,7 +103,6 @@ extern "C" {
 const char* gsr_last_error(void) { return g_error; }
 int gsr_abi_version(void) { return GSR_ABI_VERSION; }
 const char* gsr_target_arch(void) { return "gfx950"; }
-int gsr_backward(void) { return fail(GSR_ERR_UNSUPPORTED, "gsr_backward is not built yet (SURVEY.md 8f-1)"); }
 
 int gsr_set_option(int option, int value) {
     if (option < 0 || option >= GSR_OPT_NUM) return fail(GSR_ERR_INVALID_ARG, "unknown option %d", option);
@@ -170,6 +169,72 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
     return GSR_OK;
 }
 
+int gsr_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii, const char* geom_buffer,
+                 const char* binning_buffer, const char* image_buffer, const float* accum_alphas, const float* dL_dpix,
+                 const float* dL_dpix_depth, const float* dL_dpix_alpha, float* dL_dmean2D, float* dL_dconic,
+                 float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D,
+                 float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (P < 0 || width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARG, "bad sizes P=%d W=%d H=%d", P, width, height);
+    if (P == 0) return GSR_OK;  // rasterize_points.cu:169: gradients stay as the binding zero-filled them
+    if (!geom_buffer || !binning_buffer || !image_buffer) return fail(GSR_ERR_INVALID_ARG, "null scratch buffer");
+    if (!means3D || !background || !viewmatrix || !projmatrix || !cam_pos || !accum_alphas || !dL_dpix ||
+        !dL_dpix_depth || !dL_dpix_alpha || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_ddepth ||
+        !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)
+        return fail(GSR_ERR_INVALID_ARG, "null required pointer");
+    if (shs != nullptr && (M <= 0 || !dL_dsh)) return fail(GSR_ERR_INVALID_ARG, "shs given with M=%d or no dL_dsh", M);
+    if ((scales != nullptr) != (rotations != nullptr) || (scales != nullptr) == (cov3D_precomp != nullptr))
+        return fail(GSR_ERR_INVALID_ARG, "provide exactly one of (scales, rotations) / cov3D_precomp");
+
+    const char* bases[3] = {align_base(const_cast<char*>(geom_buffer)), align_base(const_cast<char*>(binning_buffer)),
+                            align_base(const_cast<char*>(image_buffer))};
+    gsr::ArenaHeader h[3];
+    for (int i = 0; i < 3; ++i) GSR_HIP(hipMemcpyAsync(&h[i], bases[i], sizeof h[i], hipMemcpyDeviceToHost, stream));
+    GSR_HIP(hipStreamSynchronize(stream));
+    for (int i = 0; i < 3; ++i)
+        if (h[i].magic != gsr::kArenaMagic || h[i].kind != (uint32_t)i)
+            return fail(GSR_ERR_INVALID_ARG, "scratch buffer %d was not produced by gsr_forward", i);
+    if (h[0].count[0] != (uint32_t)P || h[0].count[1] != (uint32_t)R || h[2].count[0] != (uint32_t)width ||
+        h[2].count[1] != (uint32_t)height)
+        return fail(GSR_ERR_INVALID_ARG, "scratch buffers belong to a different call (P %u/%d, R %u/%d, %ux%u/%dx%d)",
+                    h[0].count[0], P, h[0].count[1], R, h[2].count[0], h[2].count[1], width, height);
+
+    gsr::Camera cam;
+    cam.viewmatrix = viewmatrix; cam.projmatrix = projmatrix; cam.cam_pos = cam_pos;
+    cam.tan_fovx = tan_fovx; cam.tan_fovy = tan_fovy;
+    cam.focal_y = height / (2.0f * tan_fovy);  // rasterizer_impl.cu:390-391
+    cam.focal_x = width / (2.0f * tan_fovx);
+    cam.width = width; cam.height = height;
+    cam.grid_x = (width + gsr::kTile - 1) / gsr::kTile;
+    cam.grid_y = (height + gsr::kTile - 1) / gsr::kTile;
+
+    const float* depths = (const float*)(bases[0] + h[0].off[0]);
+    const float2* means2D = (const float2*)(bases[0] + h[0].off[1]);
+    const float4* conic_opacity = (const float4*)(bases[0] + h[0].off[2]);
+    const float* rgb = (const float*)(bases[0] + h[0].off[3]);
+    if (radii == nullptr) radii = (const int*)(bases[0] + h[0].off[4]);
+    const uint32_t* point_list = (const uint32_t*)(bases[1] + h[1].off[0]);
+    const uint2* ranges = (const uint2*)(bases[2] + h[2].off[0]);
+    const uint32_t* n_contrib = (const uint32_t*)(bases[2] + h[2].off[1]);
+    const float* colors = colors_precomp != nullptr ? colors_precomp : rgb;  // rasterizer_impl.cu:399
+
+    GSR_HIP(gsr::launch_render_backward(cam, ranges, point_list, background, means2D, conic_opacity, colors, depths,
+                                        accum_alphas, n_contrib, dL_dpix, dL_dpix_depth, dL_dpix_alpha, dL_dmean2D,
+                                        dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, stream));
+    GSR_STAGE_CHECK("render_backward");
+    gsr::BackwardInputs b;
+    b.P = P; b.sh_degree = D; b.M = M; b.means3D = means3D; b.radii = radii; b.shs = shs; b.scales = scales;
+    b.rotations = rotations; b.cov3D_precomp = cov3D_precomp; b.scale_modifier = scale_modifier;
+    b.dL_dmean2D = dL_dmean2D; b.dL_dconic = dL_dconic; b.dL_dcolor = dL_dcolor; b.dL_ddepth = dL_ddepth;
+    b.dL_dmean3D = dL_dmean3D; b.dL_dcov3D = dL_dcov3D; b.dL_dsh = dL_dsh; b.dL_dscale = dL_dscale; b.dL_drot = dL_drot;
+    GSR_HIP(gsr::launch_preprocess_backward(b, cam, stream));
+    GSR_STAGE_CHECK("preprocess_backward");
+    return GSR_OK;
+}
+
 int gsr_pack_rgba8(const float* color, const float* alpha, uint8_t* rgba8, int width, int height, void* stream_) {
     if (width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARG, "bad image size %dx%d", width, height);
     if (!color || !alpha || !rgba8) return fail(GSR_ERR_INVALID_ARG, "null pointer");
@@ -230,6 +295,7 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     GSR_HIP(gsr::depth_sort_temp_bytes(P, &sort_tmp));
     GSR_HIP(gsr::scan_temp_bytes(P, &scan_tmp));
     Carver gc;
+    gc.take<gsr::ArenaHeader>(1);  // header at the arena's aligned base
     g_geom_off[GSR_GEOM_DEPTHS] = gc.take<float>(n);
     g_geom_off[GSR_GEOM_MEANS2D] = gc.take<float2>(n);
     g_geom_off[GSR_GEOM_CONIC_OPACITY] = gc.take<float4>(n);
@@ -249,6 +315,7 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
 
     // ---- image arena ----
     Carver ic;
+    ic.take<gsr::ArenaHeader>(1);
     g_img_off[GSR_IMG_RANGES] = ic.take<uint2>((size_t)T);
     g_img_off[GSR_IMG_N_CONTRIB] = ic.take<uint32_t>((size_t)width * height);
     char* iraw = image_alloc(ic.total(), image_user);
@@ -325,6 +392,7 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     size_t tsort_tmp = 0;
     GSR_HIP(gsr::tile_sort_temp_bytes((uint32_t)nr, &tsort_tmp));
     Carver bc;
+    bc.take<gsr::ArenaHeader>(1);
     const size_t off_tk_a = bc.take<uint32_t>(nr), off_tk_b = bc.take<uint32_t>(nr);
     const size_t off_pl_a = bc.take<uint32_t>(nr), off_pl_b = bc.take<uint32_t>(nr);
     const size_t off_btmp = bc.take<char>(tsort_tmp);
@@ -358,6 +426,26 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     stamp(6, stream);
     g_bin_off[GSR_BIN_POINT_LIST] = (size_t)((char*)point_list - braw);
     g_bin_off[GSR_BIN_TILE_KEYS] = (size_t)((char*)tile_keys - braw);
+
+    {   // self-describing arenas for gsr_backward
+        gsr::ArenaHeader hg = {}, hb = {}, hi = {};
+        hg.magic = hb.magic = hi.magic = gsr::kArenaMagic;
+        hg.kind = 0; hb.kind = 1; hi.kind = 2;
+        hg.count[0] = (uint32_t)P; hg.count[1] = num_rendered; hg.count[2] = num_live;
+        hg.off[0] = (uint64_t)((char*)ga.depths - gbase);
+        hg.off[1] = (uint64_t)((char*)ga.means2D - gbase);
+        hg.off[2] = (uint64_t)((char*)ga.conic_opacity - gbase);
+        hg.off[3] = (uint64_t)((char*)ga.rgb - gbase);
+        hg.off[4] = (uint64_t)(g_geom_off[GSR_GEOM_INTERNAL_RADII] - gshift);
+        hb.count[0] = num_live;
+        hb.off[0] = (uint64_t)((char*)point_list - bbase);
+        hi.count[0] = (uint32_t)width; hi.count[1] = (uint32_t)height; hi.count[2] = (uint32_t)T;
+        hi.off[0] = (uint64_t)((char*)ranges - ibase);
+        hi.off[1] = (uint64_t)((char*)n_contrib - ibase);
+        GSR_HIP(gsr::launch_write_header(gbase, hg, stream));
+        GSR_HIP(gsr::launch_write_header(bbase, hb, stream));
+        GSR_HIP(gsr::launch_write_header(ibase, hi, stream));
+    }
 
     const float* features = colors_precomp != nullptr ? colors_precomp : ga.rgb;
     GSR_HIP(gsr::launch_blend(cam, g_options[GSR_OPT_BLEND_VARIANT], ranges, point_list, ga.means2D, features, ga.depths, ga.conic_opacity, background,

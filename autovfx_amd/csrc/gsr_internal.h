@@ -70,6 +70,45 @@ hipError_t launch_blend(const Camera& cam, int variant, const uint2* ranges, con
                         const float4* conic_opacity, const float* background, float* out_color, float* out_depth,
                         float* out_alpha, uint32_t* n_contrib, hipStream_t stream);
 
+// First 256 bytes of each scratch arena: what the backward pass needs to find the forward's arrays
+// again.  The reference re-derives its layout from sizes (rasterizer_impl.cu:381-383 fromChunk);
+// ours also depends on which radix ping-pong buffer ended up holding the sorted list, so it is recorded.
+constexpr uint32_t kArenaMagic = 0x47535231u;  // "GSR1"
+struct ArenaHeader {
+    uint32_t magic;
+    uint32_t kind;      // 0 geometry, 1 binning, 2 image
+    uint32_t count[4];  // geometry: P, num_rendered (reference), live pairs; binning: live pairs; image: W, H, T
+    uint32_t pad[2];
+    uint64_t off[8];    // byte offsets from the header's own address
+};
+hipError_t launch_write_header(void* dst, const ArenaHeader& h, hipStream_t stream);
+
+struct BackwardInputs {
+    int P, sh_degree, M;
+    const float* means3D;
+    const int* radii;
+    const float* shs;            // nullable
+    const float* scales;         // nullable
+    const float* rotations;      // nullable
+    const float* cov3D_precomp;  // nullable
+    float scale_modifier;
+    const float* dL_dmean2D;
+    const float* dL_dconic;
+    const float* dL_dcolor;
+    const float* dL_ddepth;
+    float* dL_dmean3D;
+    float* dL_dcov3D;
+    float* dL_dsh;
+    float* dL_dscale;
+    float* dL_drot;
+};
+hipError_t launch_render_backward(const Camera& cam, const uint2* ranges, const uint32_t* point_list,
+                                  const float* background, const float2* means2D, const float4* conic_opacity,
+                                  const float* colors, const float* depths, const float* accum_alphas,
+                                  const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
+                                  const float* dL_dpix_alpha, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                                  float* dL_dcolors, float* dL_ddepths, hipStream_t stream);
+hipError_t launch_preprocess_backward(const BackwardInputs& b, const Camera& cam, hipStream_t stream);
 hipError_t launch_pack_rgba8(const float* color, const float* alpha, uint8_t* out, size_t n_pixels,
                              hipStream_t stream);
 

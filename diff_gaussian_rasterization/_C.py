@@ -135,11 +135,43 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             scratch.buffers["image"])
 
 
-def rasterize_gaussians_backward(*args):
-    """24-argument backward of the reference (``rasterize_points.h:40-65``).  Not built yet: the
-    backward pass is the first "next" row of the scope table."""
-    _lib.lib.gsr_backward()
-    raise NotImplementedError("rasterize_gaussians_backward: " + _lib.last_error())
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
+                                 dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, out_alpha,
+                                 debug):
+    """Gradients of one forward call: the 24-argument backward of the reference
+    (``DGR/rasterize_points.h:40-65``, ``DGR/rasterize_points.cu:121-209``), same order in, same 8-tuple out
+    ``(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)``."""
+    device = _require_gpu(means3D, "means3D")
+    P = int(means3D.size(0))
+    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    M = int(sh.size(1)) if sh.numel() != 0 else 0
+    z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=device)
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors = z(P, 3), z(P, 3), z(P, 3)
+    dL_ddepths, dL_dconic, dL_dopacity = z(P, 1), z(P, 2, 2), z(P, 1)   # the first two are intermediates
+    dL_dcov3D, dL_dsh, dL_dscales, dL_drotations = z(P, 6), z(P, M, 3), z(P, 3), z(P, 4)
+    if P != 0:
+        f = lambda n, t: _f32c(n, t, device)
+        bg_, m3_, sh_, col_, sc_, rot_, cov_, vm_, pm_, cp_, oa_, gc_, gd_, ga_ = (
+            f("background", background), f("means3D", means3D), f("sh", sh), f("colors", colors), f("scales", scales),
+            f("rotations", rotations), f("cov3D_precomp", cov3D_precomp), f("viewmatrix", viewmatrix),
+            f("projmatrix", projmatrix), f("campos", campos), f("out_alpha", out_alpha),
+            f("dL_dout_color", dL_dout_color), f("dL_dout_depth", dL_dout_depth), f("dL_dout_alpha", dL_dout_alpha))
+        radii_ = radii.contiguous()
+        if radii_.dtype != torch.int32:
+            raise RuntimeError(f"radii: expected an int32 tensor, got {radii_.dtype}")
+        with torch.cuda.device(device):
+            rc = _lib.lib.gsr_backward(
+                P, int(degree), M, int(R), _ptr(bg_), W, H, _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(sc_),
+                float(scale_modifier), _ptr(rot_), _ptr(cov_), _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx),
+                float(tan_fovy), _ptr(radii_), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(oa_),
+                _ptr(gc_), _ptr(gd_), _ptr(ga_), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(),
+                dL_dcolors.data_ptr(), dL_ddepths.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
+                dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(), dL_drotations.data_ptr(), 1 if debug else 0,
+                ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"gsr_backward failed ({rc}): {_lib.last_error()}")
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
 
 def mark_visible(means3D, viewmatrix, projmatrix) -> torch.Tensor:

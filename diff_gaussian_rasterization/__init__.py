@@ -9,9 +9,8 @@ unchanged.  Same names, same argument meaning, same 4-tuple ``(color, depth, alp
 return, same exceptions for bad argument combinations.  The device side is libgsr_hip.so
 (hand-written gfx950 kernels behind the C ABI in include/gsr.h), reached through ``_C``.
 
-The forward pass is complete; the backward pass is the next row of the scope table
-(SURVEY.md section 8f-1): calling ``.backward()`` through this function raises
-``NotImplementedError`` instead of returning wrong gradients.
+Forward and backward are both native (``gsr_forward`` / ``gsr_backward``), so the training-time callers
+(``sugar/gaussian_splatting/train.py:84,134``, ``scene_representation.py:495,520`` inpaint re-training) work too.
 """
 from __future__ import annotations
 

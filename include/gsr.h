@@ -12,7 +12,8 @@
  *                         (impl rasterizer_impl.cu:141-153), as called by markVisible
  *                         DGR/rasterize_points.cu:211-230
  *   gsr_backward       <- CudaRasterizer::Rasterizer::backward  DGR/cuda_rasterizer/rasterizer.h:57-90
- *                         NOT BUILT YET; returns GSR_ERR_UNSUPPORTED.
+ *                         (impl rasterizer_impl.cu:343-446), as called by RasterizeGaussiansBackwardCUDA
+ *                         DGR/rasterize_points.cu:121-209
  *
  * Conventions
  *   - plain C: pointers and sizes only, no torch / C++ types cross this boundary;
@@ -41,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 1
+#define GSR_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define GSR_API __attribute__((visibility("default")))
@@ -95,9 +96,33 @@ GSR_API int gsr_mark_visible(int P, const float* means3D, const float* viewmatri
 GSR_API int gsr_pack_rgba8(const float* color, const float* alpha, uint8_t* rgba8, int width, int height,
                            void* stream);
 
-/* Declared so the binding surface is complete; returns GSR_ERR_UNSUPPORTED (backward is the
- * first "next" row). */
-GSR_API int gsr_backward(void);
+/*
+ * Backward rasterization: gradients of a gsr_forward call.  Mirrors Rasterizer::backward
+ * (rasterizer.h:57-90, rasterizer_impl.cu:343-446) as called by RasterizeGaussiansBackwardCUDA
+ * (DGR/rasterize_points.cu:121-209).
+ *   R                 the num_rendered that gsr_forward returned for this call
+ *   geom/binning/image_buffer   the three scratch arenas of that call, untouched since (the pointers the
+ *                     scratch callbacks returned); they are self-describing and are validated
+ *   accum_alphas      the forward's out_alpha;  dL_dpix[3,H,W], dL_dpix_depth[H,W], dL_dpix_alpha[H,W]
+ *   outputs must arrive zero-filled (the binding does torch::zeros, :158-168): dL_dmean2D[P,3],
+ *   dL_dconic[P,4] (xx, xy, unused, yy), dL_dopacity[P], dL_dcolor[P,3], dL_ddepth[P], dL_dmean3D[P,3],
+ *   dL_dcov3D[P,6], dL_dsh[P,M,3] (NULL allowed without shs), dL_dscale[P,3], dL_drot[P,4]
+ * Per-Gaussian sums are formed with one wave-level reduction and one atomic per 8x8 pixel block instead
+ * of one atomic per pixel, so their last bits are order-dependent like the reference's.
+ * Returns GSR_OK or a negative gsr_status.  Blocks the host once (reads the three arena headers).
+ */
+GSR_API int gsr_backward(int P, int D, int M, int R, const float* background, int width, int height,
+                         const float* means3D, const float* shs /*nullable*/,
+                         const float* colors_precomp /*nullable*/, const float* scales /*nullable*/,
+                         float scale_modifier, const float* rotations /*nullable*/,
+                         const float* cov3D_precomp /*nullable*/, const float* viewmatrix,
+                         const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                         const int* radii /*nullable*/, const char* geom_buffer, const char* binning_buffer,
+                         const char* image_buffer, const float* accum_alphas, const float* dL_dpix,
+                         const float* dL_dpix_depth, const float* dL_dpix_alpha, float* dL_dmean2D,
+                         float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepth,
+                         float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh /*nullable*/, float* dL_dscale,
+                         float* dL_drot, int debug, void* stream);
 
 /* ---- introspection (used by the parity tests and bench.py; not part of the reference API) ---- */
 

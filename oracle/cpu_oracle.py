@@ -135,3 +135,57 @@ def forward(*, means3D, opacities, bg, width: int, height: int, viewmatrix, proj
     out["num_rendered"] = D
     out.update(inter)
     return out
+
+
+_BACKWARD_ARGTYPES = None
+
+
+def _backward_argtypes():
+    return [ctypes.c_int, ctypes.c_int, ctypes.c_int, _F, ctypes.c_int, ctypes.c_int,   # P deg M bg W H
+            _F, _F, _F, _F, _F, ctypes.c_float, _F, _F,                                  # means3D shs colors opac scales mod rots cov3D
+            _F, _F, _F, ctypes.c_float, ctypes.c_float,                                  # view proj cam tanx tany
+            _F, _F, _F,                                                                  # dL_dout color depth alpha
+            _F, _F, _F, _I32,                                                            # out_color out_depth out_alpha radii
+            _F, _F, _F, _F, _F, _F, _F, _F, _F, _F]                                      # grads
+
+
+def run_backward(fn, *, means3D, opacities, bg, width, height, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
+                 dL_dcolor, dL_ddepth, dL_dalpha, sh_degree=0, scale_modifier=1.0, shs=None, colors_precomp=None,
+                 scales=None, rotations=None, cov3D_precomp=None) -> Dict[str, np.ndarray]:
+    """Forward + backward through a ``*_forward_backward`` C entry point (this oracle's or oracle/_ref's).
+    Returns the forward outputs and every gradient the reference's backward produces."""
+    m = _f32(means3D)
+    P = 0 if m is None else int(m.shape[0])
+    H, W = int(height), int(width)
+    sh, col, sc, rot, cov = _f32(shs), _f32(colors_precomp), _f32(scales), _f32(rotations), _f32(cov3D_precomp)
+    M = 0 if sh is None else int(sh.shape[1])
+    out = {"color": np.zeros((3, H, W), np.float32), "depth": np.zeros((1, H, W), np.float32),
+           "alpha": np.zeros((1, H, W), np.float32), "radii": np.zeros(P, np.int32),
+           "dL_dmeans2D": np.zeros((P, 3), np.float32), "dL_dcolors": np.zeros((P, 3), np.float32),
+           "dL_dopacity": np.zeros((P, 1), np.float32), "dL_dmeans3D": np.zeros((P, 3), np.float32),
+           "dL_dcov3D": np.zeros((P, 6), np.float32), "dL_dsh": np.zeros((P, M, 3), np.float32),
+           "dL_dscales": np.zeros((P, 3), np.float32), "dL_drotations": np.zeros((P, 4), np.float32),
+           "dL_dconic": np.zeros((P, 4), np.float32), "dL_ddepths": np.zeros((P, 1), np.float32)}
+    if P == 0:
+        out["num_rendered"] = 0
+        return out
+    op, bgv, vm, pm, cp = _f32(opacities), _f32(bg), _f32(viewmatrix), _f32(projmatrix), _f32(campos)
+    gc, gd, ga = _f32(dL_dcolor), _f32(dL_ddepth), _f32(dL_dalpha)
+    n = fn(P, int(sh_degree), M, _ptr(bgv, _F), W, H, _ptr(m, _F), _ptr(sh, _F), _ptr(col, _F), _ptr(op, _F),
+           _ptr(sc, _F), float(scale_modifier), _ptr(rot, _F), _ptr(cov, _F), _ptr(vm, _F), _ptr(pm, _F), _ptr(cp, _F),
+           float(tanfovx), float(tanfovy), _ptr(gc, _F), _ptr(gd, _F), _ptr(ga, _F), _ptr(out["color"], _F),
+           _ptr(out["depth"], _F), _ptr(out["alpha"], _F), _ptr(out["radii"], _I32), _ptr(out["dL_dmeans2D"], _F),
+           _ptr(out["dL_dcolors"], _F), _ptr(out["dL_dopacity"], _F), _ptr(out["dL_dmeans3D"], _F),
+           _ptr(out["dL_dcov3D"], _F), _ptr(out["dL_dsh"], _F), _ptr(out["dL_dscales"], _F),
+           _ptr(out["dL_drotations"], _F), _ptr(out["dL_dconic"], _F), _ptr(out["dL_ddepths"], _F))
+    out["num_rendered"] = int(n)
+    return out
+
+
+def backward(**kw) -> Dict[str, np.ndarray]:
+    L = lib()
+    if not getattr(L, "_bw_ready", False):
+        L.gsro_forward_backward.restype = ctypes.c_int64
+        L.gsro_forward_backward.argtypes = _backward_argtypes()
+        L._bw_ready = True
+    return run_backward(L.gsro_forward_backward, **kw)

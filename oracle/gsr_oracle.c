@@ -436,3 +436,353 @@ int64_t gsro_forward(int P, int deg, int M, const float* bg, int W, int H, const
     free(keys); free(vals); free(ranges);
     return (int64_t)D;
 }
+
+/* =====================================================================================================
+ * BACKWARD PASS (restatement of DGR/cuda_rasterizer/backward.cu and rasterizer_impl.cu:343-446).
+ * Same rules as above: fp32, the reference's operation order.  Per-Gaussian gradients that the
+ * reference accumulates with atomicAdd are accumulated here in the order the reference's own
+ * sources produce when run one CUDA thread at a time (tile, batch of 256, pixel thread, entry), which
+ * is the order oracle/_ref executes them in, so the two agree bit for bit.
+ * ===================================================================================================== */
+
+/* backward.cu:415-599.  Lists/ranges/n_contrib/out_alpha are the forward pass's. */
+void gsro_render_backward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* bg,
+                          const float* means2D, const float* conic_opacity, const float* colors,
+                          const float* depths, const float* out_alpha, const uint32_t* n_contrib,
+                          const float* dL_dpix /*[3,H,W]*/, const float* dL_dpix_depth, const float* dL_dpix_alpha,
+                          float* dL_dmean2D /*[P,3]*/, float* dL_dconic /*[P,4]*/, float* dL_dopacity,
+                          float* dL_dcolors /*[P,3]*/, float* dL_ddepths) {
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const int BS = TILE * TILE;
+    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
+    typedef struct { float T, rec[3], red, rea, last_alpha, last_color[3], last_depth; uint32_t contributor; } PixState;
+    PixState* st = (PixState*)malloc(sizeof(PixState) * BS);
+    for (int ty = 0; ty < gy; ++ty)
+        for (int tx = 0; tx < gx; ++tx) {
+            const uint32_t lo = ranges[2 * (ty * gx + tx)], hi = ranges[2 * (ty * gx + tx) + 1];
+            const int total = (int)(hi - lo);
+            const int rounds = (total + BS - 1) / BS;
+            for (int t = 0; t < BS; ++t) {
+                const int px = tx * TILE + t % TILE, py = ty * TILE + t / TILE;
+                const int inside = px < W && py < H;
+                memset(&st[t], 0, sizeof(PixState));
+                st[t].T = inside ? (1 - out_alpha[(size_t)W * py + px]) : 0;
+                st[t].contributor = (uint32_t)total;
+            }
+            int toDo = total;
+            for (int i = 0; i < rounds; ++i, toDo -= BS) {
+                const int nbatch = toDo < BS ? toDo : BS;
+                for (int t = 0; t < BS; ++t) {
+                    const int px = tx * TILE + t % TILE, py = ty * TILE + t / TILE;
+                    if (!(px < W && py < H)) continue;
+                    const size_t pid = (size_t)W * py + px;
+                    PixState* s = &st[t];
+                    const float T_final = 1 - out_alpha[pid];
+                    const int last_contributor = (int)n_contrib[pid];
+                    const float pxf = (float)px, pyf = (float)py;
+                    const float dLp[3] = {dL_dpix[pid], dL_dpix[(size_t)H * W + pid], dL_dpix[2 * (size_t)H * W + pid]};
+                    const float dLd = dL_dpix_depth[pid], dLa = dL_dpix_alpha[pid];
+                    for (int j = 0; j < nbatch; ++j) {
+                        s->contributor--;
+                        if (s->contributor >= (uint32_t)last_contributor) continue;
+                        const uint32_t g = point_list[hi - (uint32_t)(i * BS + j) - 1];
+                        const float dx = means2D[2 * (size_t)g] - pxf, dy = means2D[2 * (size_t)g + 1] - pyf;
+                        const float* co = conic_opacity + 4 * (size_t)g;
+                        const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                        if (power > 0.0f) continue;
+                        const float G = expf(power);
+                        const float alpha = fminf(0.99f, co[3] * G);
+                        if (alpha < 1.0f / 255.0f) continue;
+                        s->T = s->T / (1.f - alpha);
+                        const float dchannel_dcolor = alpha * s->T;
+                        float dL_dalpha = 0.0f;
+                        for (int ch = 0; ch < 3; ++ch) {
+                            const float c = colors[3 * (size_t)g + ch];
+                            s->rec[ch] = s->last_alpha * s->last_color[ch] + (1.f - s->last_alpha) * s->rec[ch];
+                            s->last_color[ch] = c;
+                            dL_dalpha += (c - s->rec[ch]) * dLp[ch];
+                            dL_dcolors[3 * (size_t)g + ch] += dchannel_dcolor * dLp[ch];
+                        }
+                        const float dep = depths[g];
+                        s->red = s->last_alpha * s->last_depth + (1.f - s->last_alpha) * s->red;
+                        s->last_depth = dep;
+                        dL_dalpha += (dep - s->red) * dLd;
+                        dL_ddepths[g] += dchannel_dcolor * dLd;
+                        s->rea = s->last_alpha + (1.f - s->last_alpha) * s->rea;
+                        dL_dalpha += (1 - s->rea) * dLa;
+                        dL_dalpha *= s->T;
+                        s->last_alpha = alpha;
+                        float bg_dot = 0;
+                        for (int ch = 0; ch < 3; ++ch) bg_dot += bg[ch] * dLp[ch];
+                        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                        const float dL_dG = co[3] * dL_dalpha;
+                        const float gdx = G * dx, gdy = G * dy;
+                        const float dG_ddelx = -gdx * co[0] - gdy * co[1];
+                        const float dG_ddely = -gdy * co[2] - gdx * co[1];
+                        dL_dmean2D[3 * (size_t)g + 0] += dL_dG * dG_ddelx * ddelx_dx;
+                        dL_dmean2D[3 * (size_t)g + 1] += dL_dG * dG_ddely * ddely_dy;
+                        dL_dconic[4 * (size_t)g + 0] += -0.5f * gdx * dx * dL_dG;
+                        dL_dconic[4 * (size_t)g + 1] += -0.5f * gdx * dy * dL_dG;
+                        dL_dconic[4 * (size_t)g + 3] += -0.5f * gdy * dy * dL_dG;
+                        dL_dopacity[g] += G * dL_dalpha;
+                    }
+                }
+            }
+        }
+    free(st);
+}
+
+/* auxiliary.h:103-114 */
+static void dnormvdv3(const float v[3], const float dv[3], float out[3]) {
+    const float sum2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    out[0] = ((+sum2 - v[0] * v[0]) * dv[0] - v[1] * v[0] * dv[1] - v[2] * v[0] * dv[2]) * invsum32;
+    out[1] = (-v[0] * v[1] * dv[0] + (sum2 - v[1] * v[1]) * dv[1] - v[2] * v[1] * dv[2]) * invsum32;
+    out[2] = (-v[0] * v[2] * dv[0] - v[1] * v[2] * dv[1] + (sum2 - v[2] * v[2]) * dv[2]) * invsum32;
+}
+
+/* backward.cu:20-138.  dL_dcolor is this Gaussian's [3]; adds into dL_dmean, writes dL_dsh[M*3]. */
+static void sh_backward(int deg, int M, const float p[3], const float cam[3], const float* sh, const float dL_dcolor[3],
+                        float dL_dmean[3], float* dL_dsh) {
+    (void)M;
+    float rgbf[3]; uint8_t clamped[3];
+    sh_to_rgb(deg, p, cam, sh, rgbf, clamped); /* the forward's clamp decision, recomputed (same arithmetic) */
+    const float o[3] = {p[0] - cam[0], p[1] - cam[1], p[2] - cam[2]};
+    const float len = sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+    const float x = o[0] / len, y = o[1] / len, z = o[2] / len;
+    float dL[3];
+    for (int c = 0; c < 3; ++c) dL[c] = dL_dcolor[c] * (clamped[c] ? 0 : 1);
+    float ddir[3] = {0, 0, 0};
+    for (int c = 0; c < 3; ++c) {
+#define SH(k) sh[3 * (k) + c]
+#define DSH(k) dL_dsh[3 * (k) + c]
+        float dx = 0, dy = 0, dz = 0;
+        DSH(0) = kC0 * dL[c];
+        if (deg > 0) {
+            DSH(1) = (-kC1 * y) * dL[c];
+            DSH(2) = (kC1 * z) * dL[c];
+            DSH(3) = (-kC1 * x) * dL[c];
+            dx = -kC1 * SH(3);
+            dy = -kC1 * SH(1);
+            dz = kC1 * SH(2);
+            if (deg > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                DSH(4) = (kC2[0] * xy) * dL[c];
+                DSH(5) = (kC2[1] * yz) * dL[c];
+                DSH(6) = (kC2[2] * (2.f * zz - xx - yy)) * dL[c];
+                DSH(7) = (kC2[3] * xz) * dL[c];
+                DSH(8) = (kC2[4] * (xx - yy)) * dL[c];
+                dx += kC2[0] * y * SH(4) + kC2[2] * 2.f * -x * SH(6) + kC2[3] * z * SH(7) + kC2[4] * 2.f * x * SH(8);
+                dy += kC2[0] * x * SH(4) + kC2[1] * z * SH(5) + kC2[2] * 2.f * -y * SH(6) + kC2[4] * 2.f * -y * SH(8);
+                dz += kC2[1] * y * SH(5) + kC2[2] * 2.f * 2.f * z * SH(6) + kC2[3] * x * SH(7);
+                if (deg > 2) {
+                    DSH(9) = (kC3[0] * y * (3.f * xx - yy)) * dL[c];
+                    DSH(10) = (kC3[1] * xy * z) * dL[c];
+                    DSH(11) = (kC3[2] * y * (4.f * zz - xx - yy)) * dL[c];
+                    DSH(12) = (kC3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * dL[c];
+                    DSH(13) = (kC3[4] * x * (4.f * zz - xx - yy)) * dL[c];
+                    DSH(14) = (kC3[5] * z * (xx - yy)) * dL[c];
+                    DSH(15) = (kC3[6] * x * (xx - 3.f * yy)) * dL[c];
+                    dx += (kC3[0] * SH(9) * 3.f * 2.f * xy + kC3[1] * SH(10) * yz + kC3[2] * SH(11) * -2.f * xy +
+                           kC3[3] * SH(12) * -3.f * 2.f * xz + kC3[4] * SH(13) * (-3.f * xx + 4.f * zz - yy) +
+                           kC3[5] * SH(14) * 2.f * xz + kC3[6] * SH(15) * 3.f * (xx - yy));
+                    dy += (kC3[0] * SH(9) * 3.f * (xx - yy) + kC3[1] * SH(10) * xz +
+                           kC3[2] * SH(11) * (-3.f * yy + 4.f * zz - xx) + kC3[3] * SH(12) * -3.f * 2.f * yz +
+                           kC3[4] * SH(13) * -2.f * xy + kC3[5] * SH(14) * -2.f * yz + kC3[6] * SH(15) * -3.f * 2.f * xy);
+                    dz += (kC3[1] * SH(10) * xy + kC3[2] * SH(11) * 4.f * 2.f * yz +
+                           kC3[3] * SH(12) * 3.f * (2.f * zz - xx - yy) + kC3[4] * SH(13) * 4.f * 2.f * xz +
+                           kC3[5] * SH(14) * (xx - yy));
+                }
+            }
+        }
+#undef SH
+#undef DSH
+        /* glm::dot(dRGBd*, dL_dRGB) sums the three channels left to right: accumulate per channel in order */
+        if (c == 0) { ddir[0] = dx * dL[0]; ddir[1] = dy * dL[0]; ddir[2] = dz * dL[0]; }
+        else { ddir[0] += dx * dL[c]; ddir[1] += dy * dL[c]; ddir[2] += dz * dL[c]; }
+    }
+    float dm[3];
+    dnormvdv3(o, ddir, dm);
+    dL_dmean[0] += dm[0]; dL_dmean[1] += dm[1]; dL_dmean[2] += dm[2];
+}
+
+/* backward.cu:144-276 (cov2D) + 278-342 (cov3D) + 346-413 (preprocess), one Gaussian at a time. */
+void gsro_preprocess_backward(int P, int deg, int M, const float* means3D, const int* radii, const float* shs,
+                              const float* scales, const float* rots, float mod, const float* cov3D_pre,
+                              const float* view, const float* proj, const float* cam, int W, int H, float tanx,
+                              float tany, const float* dL_dmean2D, const float* dL_dconic, const float* dL_dcolor,
+                              const float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                              float* dL_dscale, float* dL_drot) {
+    const float h_y = H / (2.0f * tany), h_x = W / (2.0f * tanx);
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < P; ++idx) {
+        if (!(radii[idx] > 0)) continue;
+        const float* mean = means3D + 3 * (size_t)idx;
+        float c3tmp[6];
+        const float* cov3D;
+        if (cov3D_pre) cov3D = cov3D_pre + 6 * (size_t)idx;
+        else { cov3d_from_scale_rot(scales + 3 * (size_t)idx, mod, rots + 4 * (size_t)idx, c3tmp); cov3D = c3tmp; }
+        /* ---- computeCov2DCUDA ---- */
+        const float dLc[3] = {dL_dconic[4 * (size_t)idx], dL_dconic[4 * (size_t)idx + 1], dL_dconic[4 * (size_t)idx + 3]};
+        float t[3];
+        xform43(view, mean, t);
+        const float limx = 1.3f * tanx, limy = 1.3f * tany;
+        const float txtz = t[0] / t[2], tytz = t[1] / t[2];
+        t[0] = fminf(limx, fmaxf(-limx, txtz)) * t[2];
+        t[1] = fminf(limy, fmaxf(-limy, tytz)) * t[2];
+        const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0 : 1;
+        const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0 : 1;
+        m3 J = {{{0}}}, Wm, T, V, Tt, Vt, A, C;
+        J.m[0][0] = h_x / t[2]; J.m[2][0] = -(h_x * t[0]) / (t[2] * t[2]);
+        J.m[1][1] = h_y / t[2]; J.m[2][1] = -(h_y * t[1]) / (t[2] * t[2]);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Wm.m[r][c] = view[4 * r + c];
+        V.m[0][0] = cov3D[0]; V.m[1][0] = cov3D[1]; V.m[2][0] = cov3D[2];
+        V.m[0][1] = cov3D[1]; V.m[1][1] = cov3D[3]; V.m[2][1] = cov3D[4];
+        V.m[0][2] = cov3D[2]; V.m[1][2] = cov3D[4]; V.m[2][2] = cov3D[5];
+        T = m3_mul(&Wm, &J);
+        Tt = m3_t(&T); Vt = m3_t(&V);
+        A = m3_mul(&Tt, &Vt);
+        C = m3_mul(&A, &T);
+        /* glm X[c][r] == (row r, col c) here */
+#define TG(c, r) T.m[r][c]
+#define VG(c, r) V.m[r][c]
+#define WG(c, r) Wm.m[r][c]
+        const float a = C.m[0][0] + 0.3f, b = C.m[1][0], c_ = C.m[1][1] + 0.3f;
+        const float denom = a * c_ - b * b;
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        float* dcov = dL_dcov3D + 6 * (size_t)idx;
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-c_ * c_ * dLc[0] + 2 * b * c_ * dLc[1] + (denom - a * c_) * dLc[2]);
+            dL_dc = denom2inv * (-a * a * dLc[2] + 2 * a * b * dLc[1] + (denom - a * c_) * dLc[0]);
+            dL_db = denom2inv * 2 * (b * c_ * dLc[0] - (denom + 2 * b * b) * dLc[1] + a * b * dLc[2]);
+            dcov[0] = (TG(0, 0) * TG(0, 0) * dL_da + TG(0, 0) * TG(1, 0) * dL_db + TG(1, 0) * TG(1, 0) * dL_dc);
+            dcov[3] = (TG(0, 1) * TG(0, 1) * dL_da + TG(0, 1) * TG(1, 1) * dL_db + TG(1, 1) * TG(1, 1) * dL_dc);
+            dcov[5] = (TG(0, 2) * TG(0, 2) * dL_da + TG(0, 2) * TG(1, 2) * dL_db + TG(1, 2) * TG(1, 2) * dL_dc);
+            dcov[1] = 2 * TG(0, 0) * TG(0, 1) * dL_da + (TG(0, 0) * TG(1, 1) + TG(0, 1) * TG(1, 0)) * dL_db + 2 * TG(1, 0) * TG(1, 1) * dL_dc;
+            dcov[2] = 2 * TG(0, 0) * TG(0, 2) * dL_da + (TG(0, 0) * TG(1, 2) + TG(0, 2) * TG(1, 0)) * dL_db + 2 * TG(1, 0) * TG(1, 2) * dL_dc;
+            dcov[4] = 2 * TG(0, 2) * TG(0, 1) * dL_da + (TG(0, 1) * TG(1, 2) + TG(0, 2) * TG(1, 1)) * dL_db + 2 * TG(1, 1) * TG(1, 2) * dL_dc;
+        } else {
+            for (int i = 0; i < 6; ++i) dcov[i] = 0;
+        }
+        const float dL_dT00 = 2 * (TG(0, 0) * VG(0, 0) + TG(0, 1) * VG(0, 1) + TG(0, 2) * VG(0, 2)) * dL_da + (TG(1, 0) * VG(0, 0) + TG(1, 1) * VG(0, 1) + TG(1, 2) * VG(0, 2)) * dL_db;
+        const float dL_dT01 = 2 * (TG(0, 0) * VG(1, 0) + TG(0, 1) * VG(1, 1) + TG(0, 2) * VG(1, 2)) * dL_da + (TG(1, 0) * VG(1, 0) + TG(1, 1) * VG(1, 1) + TG(1, 2) * VG(1, 2)) * dL_db;
+        const float dL_dT02 = 2 * (TG(0, 0) * VG(2, 0) + TG(0, 1) * VG(2, 1) + TG(0, 2) * VG(2, 2)) * dL_da + (TG(1, 0) * VG(2, 0) + TG(1, 1) * VG(2, 1) + TG(1, 2) * VG(2, 2)) * dL_db;
+        const float dL_dT10 = 2 * (TG(1, 0) * VG(0, 0) + TG(1, 1) * VG(0, 1) + TG(1, 2) * VG(0, 2)) * dL_dc + (TG(0, 0) * VG(0, 0) + TG(0, 1) * VG(0, 1) + TG(0, 2) * VG(0, 2)) * dL_db;
+        const float dL_dT11 = 2 * (TG(1, 0) * VG(1, 0) + TG(1, 1) * VG(1, 1) + TG(1, 2) * VG(1, 2)) * dL_dc + (TG(0, 0) * VG(1, 0) + TG(0, 1) * VG(1, 1) + TG(0, 2) * VG(1, 2)) * dL_db;
+        const float dL_dT12 = 2 * (TG(1, 0) * VG(2, 0) + TG(1, 1) * VG(2, 1) + TG(1, 2) * VG(2, 2)) * dL_dc + (TG(0, 0) * VG(2, 0) + TG(0, 1) * VG(2, 1) + TG(0, 2) * VG(2, 2)) * dL_db;
+        const float dL_dJ00 = WG(0, 0) * dL_dT00 + WG(0, 1) * dL_dT01 + WG(0, 2) * dL_dT02;
+        const float dL_dJ02 = WG(2, 0) * dL_dT00 + WG(2, 1) * dL_dT01 + WG(2, 2) * dL_dT02;
+        const float dL_dJ11 = WG(1, 0) * dL_dT10 + WG(1, 1) * dL_dT11 + WG(1, 2) * dL_dT12;
+        const float dL_dJ12 = WG(2, 0) * dL_dT10 + WG(2, 1) * dL_dT11 + WG(2, 2) * dL_dT12;
+#undef TG
+#undef VG
+#undef WG
+        const float tz = 1.f / t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+        const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+        const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+        const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t[0]) * tz3 * dL_dJ02 + (2 * h_y * t[1]) * tz3 * dL_dJ12;
+        /* transformVec4x3Transpose (auxiliary.h:89-97) */
+        float dmean[3] = {view[0] * dL_dtx + view[1] * dL_dty + view[2] * dL_dtz,
+                          view[4] * dL_dtx + view[5] * dL_dty + view[6] * dL_dtz,
+                          view[8] * dL_dtx + view[9] * dL_dty + view[10] * dL_dtz};
+        /* ---- preprocessCUDA (backward) ---- */
+        float mh[4];
+        xform44(proj, mean, mh);
+        const float m_w = 1.0f / (mh[3] + 0.0000001f);
+        const float mul1 = (proj[0] * mean[0] + proj[4] * mean[1] + proj[8] * mean[2] + proj[12]) * m_w * m_w;
+        const float mul2 = (proj[1] * mean[0] + proj[5] * mean[1] + proj[9] * mean[2] + proj[13]) * m_w * m_w;
+        const float* g2 = dL_dmean2D + 3 * (size_t)idx;
+        const float d1[3] = {(proj[0] * m_w - proj[3] * mul1) * g2[0] + (proj[1] * m_w - proj[3] * mul2) * g2[1],
+                             (proj[4] * m_w - proj[7] * mul1) * g2[0] + (proj[5] * m_w - proj[7] * mul2) * g2[1],
+                             (proj[8] * m_w - proj[11] * mul1) * g2[0] + (proj[9] * m_w - proj[11] * mul2) * g2[1]};
+        for (int k = 0; k < 3; ++k) dmean[k] += d1[k];
+        const float mul3 = view[2] * mean[0] + view[6] * mean[1] + view[10] * mean[2] + view[14];
+        const float d2[3] = {(view[2] - view[3] * mul3) * dL_ddepth[idx], (view[6] - view[7] * mul3) * dL_ddepth[idx],
+                             (view[10] - view[11] * mul3) * dL_ddepth[idx]};
+        for (int k = 0; k < 3; ++k) dmean[k] += d2[k];
+        if (shs) sh_backward(deg, M, mean, cam, shs + 3 * (size_t)M * idx, dL_dcolor + 3 * (size_t)idx, dmean, dL_dsh + 3 * (size_t)M * idx);
+        for (int k = 0; k < 3; ++k) dL_dmean3D[3 * (size_t)idx + k] = dmean[k];
+        if (scales) {
+            /* computeCov3D backward (backward.cu:278-342) */
+            const float* q = rots + 4 * (size_t)idx;
+            const float r = q[0], x = q[1], y = q[2], z = q[3];
+            m3 R, S = {{{0}}}, M3, dSig, dM, Rt, dMt;
+            R.m[0][0] = 1.f - 2.f * (y * y + z * z); R.m[1][0] = 2.f * (x * y - r * z);       R.m[2][0] = 2.f * (x * z + r * y);
+            R.m[0][1] = 2.f * (x * y + r * z);       R.m[1][1] = 1.f - 2.f * (x * x + z * z); R.m[2][1] = 2.f * (y * z - r * x);
+            R.m[0][2] = 2.f * (x * z - r * y);       R.m[1][2] = 2.f * (y * z + r * x);       R.m[2][2] = 1.f - 2.f * (x * x + y * y);
+            const float s[3] = {mod * scales[3 * (size_t)idx], mod * scales[3 * (size_t)idx + 1], mod * scales[3 * (size_t)idx + 2]};
+            S.m[0][0] = s[0]; S.m[1][1] = s[1]; S.m[2][2] = s[2];
+            M3 = m3_mul(&S, &R);
+            dSig.m[0][0] = dcov[0];        dSig.m[1][0] = 0.5f * dcov[1]; dSig.m[2][0] = 0.5f * dcov[2];
+            dSig.m[0][1] = 0.5f * dcov[1]; dSig.m[1][1] = dcov[3];        dSig.m[2][1] = 0.5f * dcov[4];
+            dSig.m[0][2] = 0.5f * dcov[2]; dSig.m[1][2] = 0.5f * dcov[4]; dSig.m[2][2] = dcov[5];
+            m3 M2 = M3;  /* 2.0f * M : scalar * matrix scales every entry */
+            for (int a2 = 0; a2 < 3; ++a2) for (int b2 = 0; b2 < 3; ++b2) M2.m[a2][b2] = 2.0f * M3.m[a2][b2];
+            dM = m3_mul(&M2, &dSig);
+            Rt = m3_t(&R);
+            dMt = m3_t(&dM);
+            /* glm::dot(Rt[c], dMt[c]): columns c, summed x,y,z */
+#define COL(Mx, c, r) Mx.m[r][c]
+            float* ds = dL_dscale + 3 * (size_t)idx;
+            for (int c = 0; c < 3; ++c)
+                ds[c] = COL(Rt, c, 0) * COL(dMt, c, 0) + COL(Rt, c, 1) * COL(dMt, c, 1) + COL(Rt, c, 2) * COL(dMt, c, 2);
+            for (int c = 0; c < 3; ++c) for (int rr = 0; rr < 3; ++rr) COL(dMt, c, rr) *= s[c];
+#define D(c, rr) COL(dMt, c, rr)
+            float* dq = dL_drot + 4 * (size_t)idx;
+            dq[0] = 2 * z * (D(0, 1) - D(1, 0)) + 2 * y * (D(2, 0) - D(0, 2)) + 2 * x * (D(1, 2) - D(2, 1));
+            dq[1] = 2 * y * (D(1, 0) + D(0, 1)) + 2 * z * (D(2, 0) + D(0, 2)) + 2 * r * (D(1, 2) - D(2, 1)) - 4 * x * (D(2, 2) + D(1, 1));
+            dq[2] = 2 * x * (D(1, 0) + D(0, 1)) + 2 * r * (D(2, 0) - D(0, 2)) + 2 * z * (D(1, 2) + D(2, 1)) - 4 * y * (D(2, 2) + D(0, 0));
+            dq[3] = 2 * r * (D(0, 1) - D(1, 0)) + 2 * x * (D(2, 0) + D(0, 2)) + 2 * y * (D(1, 2) + D(2, 1)) - 4 * z * (D(1, 1) + D(0, 0));
+#undef D
+#undef COL
+        }
+    }
+}
+
+/*
+ * Forward + backward in one call (the state the reference keeps in its three scratch buffers between
+ * RasterizeGaussiansCUDA and RasterizeGaussiansBackwardCUDA stays inside this function).
+ * Gradient outputs must arrive zero-filled (rasterize_points.cu:158-168); dL_dmeans2D is [P,3],
+ * dL_dconic is [P,4] (x, y, unused, w), dL_dcov3D [P,6], dL_dsh [P,M,3].
+ */
+int64_t gsro_forward_backward(int P, int deg, int M, const float* bg, int W, int H, const float* means3D,
+                              const float* shs, const float* colors_pre, const float* opac, const float* scales,
+                              float mod, const float* rots, const float* cov3D_pre, const float* view,
+                              const float* proj, const float* cam, float tanx, float tany,
+                              const float* dL_dout_color, const float* dL_dout_depth, const float* dL_dout_alpha,
+                              float* out_color, float* out_depth, float* out_alpha, int* radii,
+                              float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D,
+                              float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots,
+                              float* dL_dconic, float* dL_ddepths) {
+    if (P == 0) return 0;
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, T = gx * gy;
+    const size_t n = (size_t)P;
+    float* means2D = (float*)calloc(2 * n, 4);
+    float* depths = (float*)calloc(n, 4);
+    float* conop = (float*)calloc(4 * n, 4);
+    float* rgb = (float*)calloc(3 * n, 4);
+    uint32_t* tiles = (uint32_t*)calloc(n, 4);
+    uint32_t* offs = (uint32_t*)calloc(n, 4);
+    uint32_t* ncontrib = (uint32_t*)calloc((size_t)W * H, 4);
+    gsro_preprocess(P, deg, M, means3D, scales, mod, rots, opac, shs, cov3D_pre, colors_pre, view, proj, cam, W, H,
+                    tanx, tany, radii, means2D, depths, NULL, rgb, conop, tiles, NULL);
+    const uint32_t D = gsro_inclusive_sum(P, tiles, offs);
+    uint64_t* keys = (uint64_t*)malloc((D ? D : 1) * sizeof(uint64_t));
+    uint32_t* vals = (uint32_t*)malloc((D ? D : 1) * sizeof(uint32_t));
+    uint32_t* ranges = (uint32_t*)malloc((size_t)T * 2 * sizeof(uint32_t));
+    gsro_duplicate(P, W, H, means2D, depths, offs, radii, keys, vals);
+    gsro_sort_pairs(D, keys, vals, 32 + gsro_key_bits((uint32_t)T));
+    gsro_tile_ranges(D, keys, T, ranges);
+    const float* feat = colors_pre ? colors_pre : rgb;
+    gsro_blend(W, H, ranges, vals, means2D, feat, depths, conop, bg, out_color, out_depth, out_alpha, ncontrib);
+    gsro_render_backward(W, H, ranges, vals, bg, means2D, conop, feat, depths, out_alpha,
+                         ncontrib, dL_dout_color, dL_dout_depth, dL_dout_alpha, dL_dmeans2D, dL_dconic, dL_dopacity,
+                         dL_dcolors, dL_ddepths);
+    gsro_preprocess_backward(P, deg, M, means3D, radii, shs, scales, rots, mod, cov3D_pre, view, proj, cam, W, H, tanx,
+                             tany, dL_dmeans2D, dL_dconic, dL_dcolors, dL_ddepths, dL_dmeans3D, dL_dcov3D, dL_dsh,
+                             dL_dscales, dL_drots);
+    free(means2D); free(depths); free(conop); free(rgb); free(tiles); free(offs); free(ncontrib);
+    free(keys); free(vals); free(ranges);
+    return (int64_t)D;
+}

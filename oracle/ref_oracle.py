@@ -92,3 +92,14 @@ def forward(*, means3D, opacities, bg, width: int, height: int, viewmatrix, proj
     out["num_rendered"] = D
     out.update(inter)
     return out
+
+
+def backward(**kw) -> Dict[str, np.ndarray]:
+    """Forward + backward through the reference's own sources (same interface as cpu_oracle.backward)."""
+    from .cpu_oracle import _backward_argtypes, run_backward
+    L = lib()
+    if not getattr(L, "_bw_ready", False):
+        L.gsr_ref_forward_backward.restype = ctypes.c_longlong
+        L.gsr_ref_forward_backward.argtypes = _backward_argtypes()
+        L._bw_ready = True
+    return run_backward(L.gsr_ref_forward_backward, **kw)

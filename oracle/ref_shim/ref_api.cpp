@@ -70,3 +70,28 @@ void gsr_ref_mark_visible(int P, const float* means3D, const float* viewmatrix, 
 }
 
 } // extern "C"
+
+// Forward then backward through the reference's own host code (rasterizer_impl.cu:197-339, 343-446),
+// keeping its three scratch arenas alive in between, the way RasterizeGaussiansCUDA /
+// RasterizeGaussiansBackwardCUDA (rasterize_points.cu:36-119, 121-209) do through ctx.saved_tensors.
+extern "C" long long gsr_ref_forward_backward(
+    int P, int D, int M, const float* background, int width, int height, const float* means3D, const float* shs,
+    const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+    const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+    const float* cam_pos, float tan_fovx, float tan_fovy, const float* dL_dout_color, const float* dL_dout_depth,
+    const float* dL_dout_alpha, float* out_color, float* out_depth, float* out_alpha, int* radii, float* dL_dmeans2D,
+    float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscales,
+    float* dL_drots, float* dL_dconic, float* dL_ddepths) {
+    if (P == 0) return 0;
+    std::vector<char> geom, binning, img;
+    const int R = Rasterizer::forward(arena(geom), arena(binning), arena(img), P, D, M, background, width, height,
+                                      means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                                      cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, false,
+                                      out_color, out_depth, out_alpha, radii, false);
+    Rasterizer::backward(P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier,
+                         rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, radii,
+                         geom.data(), binning.data(), img.data(), out_alpha, dL_dout_color, dL_dout_depth,
+                         dL_dout_alpha, dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors, dL_ddepths, dL_dmeans3D,
+                         dL_dcov3D, dL_dsh, dL_dscales, dL_drots, false);
+    return R;
+}

@@ -54,7 +54,37 @@ def cases():
     yield "ties_and_big_splats_64x64", oracle_kwargs(c, scenes.c1_camera(64, 64))
 
 
+def backward_cases():
+    """Small forward+backward cases through the reference's backward.cu (bw_*.npz)."""
+    import numpy as np
+    def grads(cam, seed):
+        g = np.random.default_rng(seed)
+        H, W = cam.image_height, cam.image_width
+        return dict(dL_dcolor=g.standard_normal((3, H, W)).astype(np.float32),
+                    dL_ddepth=(0.1 * g.standard_normal((1, H, W))).astype(np.float32),
+                    dL_dalpha=g.standard_normal((1, H, W)).astype(np.float32))
+    cam = scenes.c1_camera(48, 32)
+    kw = oracle_kwargs(scenes.config_c1(P=500, seed=201), cam, bg=(0.1, 0.2, 0.3)); kw.update(grads(cam, 1))
+    yield "bw_sh3_48x32", kw
+    cam = orbit_cameras(8, 40, 30)[3]
+    kw = oracle_kwargs(scenes.config_c4(P=800, seed=202), cam, bg=(1.0, 1.0, 1.0)); kw.update(grads(cam, 2))
+    yield "bw_precomp_flat_40x30", kw
+    cam = scenes.c1_camera(33, 17)
+    c = scenes.config_c1(P=300, seed=203)
+    c.scales[:20] *= 20.0
+    kw = oracle_kwargs(c, cam, scale_modifier=1.3, sh_degree=1, bg=(0.5, 0.5, 0.5)); kw.update(grads(cam, 3))
+    yield "bw_sh1_big_splats_33x17", kw
+
+
 def main():
+    for name, kw in backward_cases():
+        out = ref_oracle.backward(**kw)
+        inputs = {"in_" + k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v))
+                  for k, v in kw.items() if v is not None}
+        outputs = {"out_" + k: np.asarray(v) for k, v in out.items()}
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **inputs, **outputs)
+        print(f"{name}: P={kw['means3D'].shape[0]} D={out['num_rendered']} -> {os.path.getsize(path) / 1024:.0f} KiB")
     for name, kw in cases():
         out = ref_oracle.forward(intermediates=True, **kw)
         inputs = {"in_" + k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v))

@@ -77,7 +77,10 @@ def test_native_module_surface():
         "viewmatrix", "projmatrix", "tan_fovx", "tan_fovy", "image_height", "image_width", "sh", "degree", "campos",
         "prefiltered", "debug"]
     assert list(inspect.signature(_C.mark_visible).parameters) == ["means3D", "viewmatrix", "projmatrix"]
-    assert callable(_C.rasterize_gaussians_backward)
+    assert list(inspect.signature(_C.rasterize_gaussians_backward).parameters) == [
+        "background", "means3D", "radii", "colors", "scales", "rotations", "scale_modifier", "cov3D_precomp",
+        "viewmatrix", "projmatrix", "tan_fovx", "tan_fovy", "dL_dout_color", "dL_dout_depth", "dL_dout_alpha", "sh",
+        "degree", "campos", "geomBuffer", "R", "binningBuffer", "imageBuffer", "out_alpha", "debug"]
     assert GaussianRasterizationSettings._fields == (
         "image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix",
         "sh_degree", "campos", "prefiltered", "debug")

@@ -1,0 +1,163 @@
+"""GPU parity of the backward pass: ``loss.backward()`` through the drop-in API (-> gsr_backward -> gfx950
+kernels) against the CPU oracle's backward and against golden vectors from the reference's backward.cu.
+
+Bar: per gradient array, max |hip - ref| <= 2e-4 * max|ref| + 1e-6.  Exact bit equality is not attainable
+for sums formed with atomics (neither here nor in the reference); the forward images feeding the backward
+already agree to ~1e-6 and the per-Gaussian arithmetic is the reference's op for op.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from autovfx_amd import scenes
+from autovfx_amd.cameras import orbit_cameras
+from autovfx_amd.scenes import GaussianCloud
+from oracle import cpu_oracle
+
+from helpers import oracle_kwargs, settings_for
+from test_oracle_backward import GOLDEN_BW, cpu_cov3d, load_bw_case, pixel_grads
+from test_parity_gpu import report
+
+pytestmark = pytest.mark.gpu
+REL, ABS = 2e-4, 1e-6
+
+
+def hip_backward(cloud, cam, pg, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, sh_degree=None, cov3D_precomp=None,
+                 device="cuda:0", cull=True, tanfov=None):
+    from autovfx_amd import _lib
+    from diff_gaussian_rasterization import GaussianRasterizer
+    c = cloud.to(device)
+    st = settings_for(cam, device, bg, scale_modifier, cloud.sh_degree if sh_degree is None else sh_degree)
+    if tanfov is not None:
+        st = st._replace(tanfovx=tanfov[0], tanfovy=tanfov[1])
+    leaf = lambda t: None if t is None else t.clone().requires_grad_(True)
+    means3D, opac = leaf(c.means3D), leaf(c.opacities)
+    shs, colors = leaf(c.shs), leaf(c.colors_precomp)
+    means2D = torch.zeros_like(c.means3D, requires_grad=True)
+    kw, cov = {}, None
+    if cov3D_precomp is not None:
+        cov = torch.as_tensor(cov3D_precomp, dtype=torch.float32, device=device).clone().requires_grad_(True)
+        kw["cov3D_precomp"] = cov
+        scales = rots = None
+    else:
+        scales, rots = leaf(c.scales), leaf(c.rotations)
+        kw["scales"], kw["rotations"] = scales, rots
+    _lib.set_option(_lib.OPT_TILE_CULL, 1 if cull else 0)
+    try:
+        color, depth, alpha, radii = GaussianRasterizer(st)(means3D=means3D, means2D=means2D, opacities=opac, shs=shs,
+                                                            colors_precomp=colors, **kw)
+        t = lambda a: torch.from_numpy(a).to(device)
+        loss = (color * t(pg["dL_dcolor"])).sum() + (depth * t(pg["dL_ddepth"])).sum() + (alpha * t(pg["dL_dalpha"])).sum()
+        loss.backward()
+    finally:
+        _lib.set_option(_lib.OPT_TILE_CULL, 1)
+    torch.cuda.synchronize()
+    g = lambda x: None if x is None or x.grad is None else x.grad.cpu().numpy()
+    return {"color": color.detach().cpu().numpy(), "dL_dmeans3D": g(means3D), "dL_dmeans2D": g(means2D),
+            "dL_dopacity": g(opac), "dL_dsh": g(shs), "dL_dcolors": g(colors), "dL_dscales": g(scales),
+            "dL_drotations": g(rots), "dL_dcov3D": g(cov), "radii": radii.cpu().numpy()}
+
+
+def compare(name, hip, ref, keys):
+    worst = {}
+    for k in keys:
+        if hip.get(k) is None:
+            continue
+        a, b = hip[k].astype(np.float64).reshape(-1), ref[k].astype(np.float64).reshape(-1)
+        scale = float(np.abs(b).max()) if b.size else 0.0
+        err = float(np.abs(a - b).max()) if b.size else 0.0
+        worst[k] = err / max(scale, 1e-30)
+        assert err <= REL * scale + ABS, f"{name}: {k} max abs err {err:.3e} vs scale {scale:.3e}"
+    report("bw:" + name, **{k: float(v) for k, v in worst.items()})
+
+
+KEYS_SH = ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations")
+KEYS_PRE = ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dscales", "dL_drotations")
+
+
+@pytest.mark.parametrize("cull", [True, False])
+def test_backward_sh_scene(cull):
+    cloud, cam = scenes.config_c1(P=6000, seed=31), scenes.c1_camera(192, 128)
+    pg = pixel_grads(cam, 5)
+    kw = oracle_kwargs(cloud, cam, bg=(0.1, 0.2, 0.3))
+    kw.update(pg)
+    ref = cpu_oracle.backward(**kw)
+    hip = hip_backward(cloud, cam, pg, bg=(0.1, 0.2, 0.3), cull=cull)
+    np.testing.assert_array_equal(hip["radii"], ref["radii"])
+    compare(f"sh_cull{int(cull)}", hip, ref, KEYS_SH)
+
+
+def test_backward_precomputed_colours_and_orbit_camera():
+    cloud, cam = scenes.config_c4(P=15000, seed=32), orbit_cameras(8, 240, 135)[3]
+    pg = pixel_grads(cam, 6)
+    kw = oracle_kwargs(cloud, cam, bg=(1.0, 1.0, 1.0))
+    kw.update(pg)
+    compare("precomp", hip_backward(cloud, cam, pg, bg=(1.0, 1.0, 1.0)), cpu_oracle.backward(**kw), KEYS_PRE)
+
+
+def test_backward_cov3d_precomp_scale_modifier_low_degree():
+    cloud, cam = scenes.config_c1(P=2500, seed=33), scenes.c1_camera(100, 70)
+    pg = pixel_grads(cam, 7)
+    cov = cpu_cov3d(cloud)
+    kw = oracle_kwargs(cloud, cam, cov3D_precomp=cov, sh_degree=1, bg=(0.5, 0.5, 0.5))
+    kw.update(pg)
+    hip = hip_backward(cloud, cam, pg, bg=(0.5, 0.5, 0.5), cov3D_precomp=cov, sh_degree=1)
+    compare("cov3d_deg1", hip, cpu_oracle.backward(**kw), ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dcov3D"))
+    cloud2 = scenes.config_c1(P=2500, seed=34)
+    kw = oracle_kwargs(cloud2, cam, scale_modifier=1.7)
+    kw.update(pg)
+    compare("scale_mod", hip_backward(cloud2, cam, pg, scale_modifier=1.7), cpu_oracle.backward(**kw), KEYS_SH)
+
+
+def test_backward_big_splats_and_ragged_image():
+    cloud, cam = scenes.config_c1(P=500, seed=35), scenes.c1_camera(131, 77)
+    cloud.scales[:40] *= 20.0
+    pg = pixel_grads(cam, 8)
+    kw = oracle_kwargs(cloud, cam)
+    kw.update(pg)
+    compare("big_ragged", hip_backward(cloud, cam, pg), cpu_oracle.backward(**kw), KEYS_SH)
+
+
+@pytest.mark.parametrize("path", GOLDEN_BW, ids=[os.path.basename(p)[:-4] for p in GOLDEN_BW])
+def test_backward_matches_reference_golden_vectors(path):
+    from autovfx_amd.cameras import Camera
+    kw, ref = load_bw_case(path)
+    t = lambda k: None if k not in kw else torch.from_numpy(np.asarray(kw[k]))
+    cloud = GaussianCloud(t("means3D"), t("opacities"), t("scales"), t("rotations"), t("shs"), t("colors_precomp"),
+                          kw["sh_degree"])
+    cam = Camera(kw["width"], kw["height"], 2 * np.arctan(kw["tanfovx"]), 2 * np.arctan(kw["tanfovy"]),
+                 t("viewmatrix"), t("projmatrix"), t("projmatrix"), t("campos"))
+    pg = {k: kw[k] for k in ("dL_dcolor", "dL_ddepth", "dL_dalpha")}
+    hip = hip_backward(cloud, cam, pg, bg=tuple(float(v) for v in kw["bg"]), scale_modifier=kw["scale_modifier"],
+                       tanfov=(kw["tanfovx"], kw["tanfovy"]))
+    compare("golden:" + os.path.basename(path)[:-4], hip, ref, KEYS_SH if cloud.shs is not None else KEYS_PRE)
+
+
+def test_training_step_reduces_loss():
+    """The call shape of the reference's training loops (train.py:84-134, scene_representation.py:495-520):
+    render, L1 to a target, backward, Adam step -- the loss must go down."""
+    dev = "cuda:0"
+    from diff_gaussian_rasterization import GaussianRasterizer
+    cam = scenes.c1_camera(96, 96)
+    target_cloud = scenes.config_c1(P=3000, seed=40).to(dev)
+    st = settings_for(cam, dev, sh_degree=3)
+    with torch.no_grad():
+        target = GaussianRasterizer(st)(target_cloud.means3D, None, target_cloud.opacities, shs=target_cloud.shs,
+                                        scales=target_cloud.scales, rotations=target_cloud.rotations)[0]
+    shs = (target_cloud.shs + 0.3 * torch.randn_like(target_cloud.shs)).requires_grad_(True)
+    logit_o = torch.logit(target_cloud.opacities.clamp(0.02, 0.98)).add(0.5).requires_grad_(True)
+    opt = torch.optim.Adam([shs, logit_o], lr=0.02)
+    losses = []
+    for _ in range(12):
+        screen = torch.zeros_like(target_cloud.means3D, requires_grad=True)
+        img = GaussianRasterizer(st)(target_cloud.means3D, screen, torch.sigmoid(logit_o), shs=shs,
+                                     scales=target_cloud.scales, rotations=target_cloud.rotations)[0]
+        loss = (img - target).abs().mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    report("bw:train", first=losses[0], last=losses[-1])
+    assert losses[-1] < 0.7 * losses[0], losses

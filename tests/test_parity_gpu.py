@@ -354,10 +354,10 @@ def test_argument_validation_matches_reference():
         rast(c.means3D[:, :2], m2, c.opacities, shs=c.shs, scales=c.scales, rotations=c.rotations)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         rast(c.means3D.cpu(), m2, c.opacities, shs=c.shs, scales=c.scales, rotations=c.rotations)
-    with pytest.raises(NotImplementedError):
-        x = c.means3D.clone().requires_grad_(True)
-        out = rast(x, m2, c.opacities, shs=c.shs, scales=c.scales, rotations=c.rotations)[0]
-        out.sum().backward()
+    x = c.means3D.clone().requires_grad_(True)
+    out = rast(x, m2, c.opacities, shs=c.shs, scales=c.scales, rotations=c.rotations)[0]
+    out.sum().backward()
+    assert x.grad is not None and x.grad.shape == (10, 3) and torch.isfinite(x.grad).all()
 
 
 @pytest.mark.parametrize("case", ["c1", "c2_mid", "big", "ragged"])
