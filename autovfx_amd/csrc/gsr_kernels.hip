@@ -700,9 +700,21 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
 // so the number of global atomics drops 64x and their order (hence the last bits of the sums) is
 // this library's, not the reference's -- parity for gradients is stated with a tolerance.
 // ================================================================================================
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+// Sum over the wave with DPP moves (no LDS traffic); the total is valid in lane 63 only.
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_ror:4, row_ror:8, row_bcast:15, row_bcast:31 -- the
+// classic GCN wave64 reduction; lanes without a source (row 0 for the broadcasts) add 0.
+template <int kCtrl>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), kCtrl, 0xF, 0xF, false);
+    return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum_in_last_lane(float v) {
+    v = dpp_add<0xB1>(v);
+    v = dpp_add<0x4E>(v);
+    v = dpp_add<0x124>(v);
+    v = dpp_add<0x128>(v);
+    v = dpp_add<0x142>(v);
+    v = dpp_add<0x143>(v);
     return v;
 }
 
@@ -841,10 +853,12 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
                 g_op = G * dL_dalpha;
             }
             if (!__any(contrib)) continue;
-            g_cr = wave_sum(g_cr); g_cg = wave_sum(g_cg); g_cb = wave_sum(g_cb); g_dep = wave_sum(g_dep);
-            g_mx = wave_sum(g_mx); g_my = wave_sum(g_my);
-            g_kx = wave_sum(g_kx); g_ky = wave_sum(g_ky); g_kw = wave_sum(g_kw); g_op = wave_sum(g_op);
-            if (lane == 0) {
+            g_cr = wave_sum_in_last_lane(g_cr); g_cg = wave_sum_in_last_lane(g_cg);
+            g_cb = wave_sum_in_last_lane(g_cb); g_dep = wave_sum_in_last_lane(g_dep);
+            g_mx = wave_sum_in_last_lane(g_mx); g_my = wave_sum_in_last_lane(g_my);
+            g_kx = wave_sum_in_last_lane(g_kx); g_ky = wave_sum_in_last_lane(g_ky);
+            g_kw = wave_sum_in_last_lane(g_kw); g_op = wave_sum_in_last_lane(g_op);
+            if (lane == 63) {
                 const size_t id = sId[j];
                 atomicAdd(dL_dcolors + 3 * id + 0, g_cr);
                 atomicAdd(dL_dcolors + 3 * id + 1, g_cg);
@@ -872,38 +886,47 @@ __device__ __forceinline__ F3 dnormvdv3(F3 v, F3 dv) {
     return o;
 }
 
-// backward.cu:20-138 for one colour channel c: writes dL_dsh[3k + c], returns d(channel)/d(dir).
-__device__ __forceinline__ F3 sh_backward_channel(int deg, float x, float y, float z, const float* __restrict__ sh,
-                                                  int c, float dL, float* __restrict__ dL_dsh) {
-#define SHC(k) sh[3 * (k) + c]
-#define DSH(k) dL_dsh[3 * (k) + c]
-    float dx = 0.f, dy = 0.f, dz = 0.f;
-    DSH(0) = kSH0 * dL;
+// backward.cu:20-138, split in two: d(colour)/d(sh_k) is a scalar per coefficient shared by the
+// three channels (written as one 12-byte store per coefficient), d(colour)/d(dir) is per channel.
+__device__ __forceinline__ void sh_coefficient_grads(int deg, float x, float y, float z, float k[16]) {
+    k[0] = kSH0;
     if (deg > 0) {
-        DSH(1) = (-kSH1 * y) * dL;
-        DSH(2) = (kSH1 * z) * dL;
-        DSH(3) = (-kSH1 * x) * dL;
+        k[1] = -kSH1 * y;
+        k[2] = kSH1 * z;
+        k[3] = -kSH1 * x;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            k[4] = kSH2_0 * xy;
+            k[5] = kSH2_1 * yz;
+            k[6] = kSH2_2 * (2.f * zz - xx - yy);
+            k[7] = kSH2_3 * xz;
+            k[8] = kSH2_4 * (xx - yy);
+            if (deg > 2) {
+                k[9] = kSH3_0 * y * (3.f * xx - yy);
+                k[10] = kSH3_1 * xy * z;
+                k[11] = kSH3_2 * y * (4.f * zz - xx - yy);
+                k[12] = kSH3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                k[13] = kSH3_4 * x * (4.f * zz - xx - yy);
+                k[14] = kSH3_5 * z * (xx - yy);
+                k[15] = kSH3_6 * x * (xx - 3.f * yy);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ F3 sh_dir_grads_channel(int deg, float x, float y, float z, const float* __restrict__ sh, int c) {
+#define SHC(k) sh[3 * (k) + c]
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (deg > 0) {
         dx = -kSH1 * SHC(3);
         dy = -kSH1 * SHC(1);
         dz = kSH1 * SHC(2);
         if (deg > 1) {
             const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-            DSH(4) = (kSH2_0 * xy) * dL;
-            DSH(5) = (kSH2_1 * yz) * dL;
-            DSH(6) = (kSH2_2 * (2.f * zz - xx - yy)) * dL;
-            DSH(7) = (kSH2_3 * xz) * dL;
-            DSH(8) = (kSH2_4 * (xx - yy)) * dL;
             dx += kSH2_0 * y * SHC(4) + kSH2_2 * 2.f * -x * SHC(6) + kSH2_3 * z * SHC(7) + kSH2_4 * 2.f * x * SHC(8);
             dy += kSH2_0 * x * SHC(4) + kSH2_1 * z * SHC(5) + kSH2_2 * 2.f * -y * SHC(6) + kSH2_4 * 2.f * -y * SHC(8);
             dz += kSH2_1 * y * SHC(5) + kSH2_2 * 2.f * 2.f * z * SHC(6) + kSH2_3 * x * SHC(7);
             if (deg > 2) {
-                DSH(9) = (kSH3_0 * y * (3.f * xx - yy)) * dL;
-                DSH(10) = (kSH3_1 * xy * z) * dL;
-                DSH(11) = (kSH3_2 * y * (4.f * zz - xx - yy)) * dL;
-                DSH(12) = (kSH3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy)) * dL;
-                DSH(13) = (kSH3_4 * x * (4.f * zz - xx - yy)) * dL;
-                DSH(14) = (kSH3_5 * z * (xx - yy)) * dL;
-                DSH(15) = (kSH3_6 * x * (xx - 3.f * yy)) * dL;
                 dx += (kSH3_0 * SHC(9) * 3.f * 2.f * xy + kSH3_1 * SHC(10) * yz + kSH3_2 * SHC(11) * -2.f * xy +
                        kSH3_3 * SHC(12) * -3.f * 2.f * xz + kSH3_4 * SHC(13) * (-3.f * xx + 4.f * zz - yy) +
                        kSH3_5 * SHC(14) * 2.f * xz + kSH3_6 * SHC(15) * 3.f * (xx - yy));
@@ -917,7 +940,6 @@ __device__ __forceinline__ F3 sh_backward_channel(int deg, float x, float y, flo
         }
     }
 #undef SHC
-#undef DSH
     return F3{dx, dy, dz};
 }
 
@@ -1069,9 +1091,15 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(BackwardArgs g
         F3 pre = sh_unclamped(deg, x, y, z, sh);
         const float dL0 = dLc[0] * (pre.x < 0 ? 0.f : 1.f), dL1 = dLc[1] * (pre.y < 0 ? 0.f : 1.f),
                     dL2 = dLc[2] * (pre.z < 0 ? 0.f : 1.f);
-        const F3 d0 = sh_backward_channel(deg, x, y, z, sh, 0, dL0, dsh);
-        const F3 d1 = sh_backward_channel(deg, x, y, z, sh, 1, dL1, dsh);
-        const F3 d2 = sh_backward_channel(deg, x, y, z, sh, 2, dL2, dsh);
+        float kk[16];
+        sh_coefficient_grads(deg, x, y, z, kk);
+        const int ncoef = (deg + 1) * (deg + 1);
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (k < ncoef) *reinterpret_cast<F3*>(dsh + 3 * k) = F3{kk[k] * dL0, kk[k] * dL1, kk[k] * dL2};
+        const F3 d0 = sh_dir_grads_channel(deg, x, y, z, sh, 0);
+        const F3 d1 = sh_dir_grads_channel(deg, x, y, z, sh, 1);
+        const F3 d2 = sh_dir_grads_channel(deg, x, y, z, sh, 2);
         const F3 ddir = F3{d0.x * dL0 + d1.x * dL1 + d2.x * dL2, d0.y * dL0 + d1.y * dL1 + d2.y * dL2,
                            d0.z * dL0 + d1.z * dL1 + d2.z * dL2};
         const F3 dm = dnormvdv3(o, ddir);
