@@ -235,6 +235,23 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     return GSR_OK;
 }
 
+int gsr_blend(int width, int height, const uint32_t* ranges, const uint32_t* point_list, const float* means2D,
+              const float* conic_opacity, const float* depths, const float* features, const float* background,
+              float* out_color, float* out_depth, float* out_alpha, uint32_t* n_contrib, void* stream_) {
+    if (width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARG, "bad image size %dx%d", width, height);
+    if (!ranges || !point_list || !means2D || !conic_opacity || !depths || !features || !background || !out_color ||
+        !out_depth || !out_alpha)
+        return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    gsr::Camera cam = {};
+    cam.width = width; cam.height = height;
+    cam.grid_x = (width + gsr::kTile - 1) / gsr::kTile;
+    cam.grid_y = (height + gsr::kTile - 1) / gsr::kTile;
+    GSR_HIP(gsr::launch_blend(cam, g_options[GSR_OPT_BLEND_VARIANT], (const uint2*)ranges, point_list,
+                              (const float2*)means2D, features, depths, (const float4*)conic_opacity, background,
+                              out_color, out_depth, out_alpha, n_contrib, (hipStream_t)stream_));
+    return GSR_OK;
+}
+
 int gsr_pack_rgba8(const float* color, const float* alpha, uint8_t* rgba8, int width, int height, void* stream_) {
     if (width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARG, "bad image size %dx%d", width, height);
     if (!color || !alpha || !rgba8) return fail(GSR_ERR_INVALID_ARG, "null pointer");

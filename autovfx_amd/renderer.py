@@ -1,0 +1,112 @@
+"""``render()``: the per-frame function AutoVFX calls, mirrored for the MI355X rasterizer.
+
+Same signature, same result dictionary and the same arithmetic as
+``sugar/gaussian_splatting/gaussian_renderer/__init__.py:83-218``:
+
+1. activations and SH / normal preparation in PyTorch (``:118-146,169-171``),
+2. rasterizer pass 1, SH colours (``:151-159``) -> RGBA (``:162``) and depth,
+3. rasterizer pass 2, per-Gaussian normals as precomputed colours (``:176-184``) -> normal map,
+   normalised per pixel (``:189-194``),
+4. pseudo-normals from the depth map by local differences (``:197-208`` with ``depth_pcd2normal`` ``:22-38`` and
+   ``get_ray_directions`` ``:41-80``; ``kornia.create_meshgrid`` is replaced by the two ``arange``s it amounts to).
+
+It exists for two reasons: the reference's own ``render`` cannot be imported where ``kornia``,
+``plyfile`` and ``simple_knn`` are missing, and it is the boundary at which the second of the two
+measurements of SURVEY.md section 8d is taken (``bench.py --boundary render``).  The second rasterizer pass
+hits the geometry cache of ``diff_gaussian_rasterization._C`` (same tensors, new colours), so it costs
+one blend launch instead of a full pipeline; results are bit-identical either way.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from .cameras import fov2focal
+
+
+class PipelineParams:
+    """``arguments.PipelineParams`` defaults (``sugar/sugar_scene/gs_model.py:34-37``)."""
+    convert_SHs_python = False
+    compute_cov3D_python = False
+    debug = False
+
+
+def depth_pcd2normal(xyz: torch.Tensor) -> torch.Tensor:
+    """Un-projected points [H,W,3] -> pseudo normal map by central differences (``:22-38``)."""
+    hd, wd, _ = xyz.shape
+    bottom, top = xyz[2:hd, 1:wd - 1, :], xyz[0:hd - 2, 1:wd - 1, :]
+    right, left = xyz[1:hd - 1, 2:wd, :], xyz[1:hd - 1, 0:wd - 2, :]
+    n = torch.cross(right - left, top - bottom, dim=-1)
+    n = torch.nn.functional.normalize(n, p=2, dim=-1)
+    return torch.nn.functional.pad(n.permute(2, 0, 1), (1, 1, 1, 1), mode="constant").permute(1, 2, 0)
+
+
+def get_ray_directions(H: int, W: int, fx: float, fy: float, cx: float, cy: float, device) -> torch.Tensor:
+    """Camera-space ray through each pixel centre, [H,W,3] (``:41-80`` with ``random=False``)."""
+    v, u = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=device),
+                          torch.arange(W, dtype=torch.float32, device=device), indexing="ij")
+    return torch.stack(((u - cx + 0.5) / fx, (v - cy + 0.5) / fy, torch.ones_like(u)), -1)
+
+
+def render(viewpoint_camera, pc, pipe=PipelineParams, bg_color: Optional[torch.Tensor] = None,
+           scaling_modifier: float = 1.0, override_color: Optional[torch.Tensor] = None):
+    """Render one view.  ``pc`` is anything with the ``GaussianModel`` getters; ``bg_color`` lives on the GPU."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+    xyz = pc.get_xyz
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
+        bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
+    rasterizer = GaussianRasterizer(raster_settings=settings)
+
+    means3D, means2D, opacity = xyz, screenspace_points, pc.get_opacity
+    scales = rotations = cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales, rotations = pc.get_scaling, pc.get_rotation
+
+    dir_pp = xyz - viewpoint_camera.camera_center.repeat(xyz.shape[0], 1)
+    dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+
+    shs = colors_precomp = None
+    if override_color is None:
+        if pipe.convert_SHs_python:
+            raise NotImplementedError("convert_SHs_python: the SH evaluation lives in the rasterizer")
+        shs = pc.get_features
+    else:
+        colors_precomp = override_color
+
+    rendered_image, depth_image, alpha_image, radii = rasterizer(
+        means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity, scales=scales,
+        rotations=rotations, cov3D_precomp=cov3D_precomp)
+    rendered_image = torch.cat((rendered_image, alpha_image), dim=0)
+    depth_image = depth_image.squeeze(0)
+
+    normal_normed = pc.get_normal(dir_pp_normalized=dir_pp_normalized) * 0.5 + 0.5
+    normal_image = rasterizer(means3D=means3D, means2D=means2D, shs=None, colors_precomp=normal_normed,
+                              opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)[0]
+    normal_image = (normal_image - 0.5) * 2.0
+    normal_image = torch.nn.functional.normalize(normal_image.permute(1, 2, 0), p=2, dim=-1)
+
+    h, w = int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)
+    fx, fy = fov2focal(viewpoint_camera.FoVx, w), fov2focal(viewpoint_camera.FoVy, h)
+    c2w = viewpoint_camera.world_view_transform.inverse()
+    directions = get_ray_directions(h, w, fx, fy, w / 2, h / 2, depth_image.device)
+    rays_d = directions @ c2w[:3, :3].T
+    rays_o = c2w[:3, 3].expand_as(rays_d)
+    points3D = rays_o + rays_d * depth_image.unsqueeze(-1)
+    pseudo_normal = depth_pcd2normal(points3D)
+
+    return {"render": rendered_image, "depth": depth_image, "normal": normal_image, "pseudo_normal": pseudo_normal,
+            "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}

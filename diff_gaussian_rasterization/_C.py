@@ -82,6 +82,31 @@ def _require_gpu(t: torch.Tensor, what: str) -> torch.device:
 
 _last_layout = {}
 
+# ---- geometry reuse between consecutive calls -------------------------------------------------------------------
+# gaussian_renderer.render() calls the rasterizer twice per frame with the very same tensor objects for the
+# geometry (means3D, opacity, scales, rotations / cov3D, camera) and only the colour source changed
+# (gaussian_renderer/__init__.py:151-159 then :176-184).  When a call arrives whose geometry inputs are the SAME
+# tensor objects at the SAME autograd version as the previous call on this thread and stream, and it brings
+# precomputed colours, everything up to the per-tile lists is reused and only the blend kernel runs.  The
+# previous call's inputs and scratch are kept alive by the cache, so object identity cannot be recycled.
+# Disable with GSR_GEOMETRY_CACHE=0.
+import os as _os
+
+_GEOMETRY_CACHE = _os.environ.get("GSR_GEOMETRY_CACHE", "1") != "0"
+cache_stats = {"hits": 0, "misses": 0}
+
+
+def set_geometry_cache(enabled: bool) -> None:
+    global _GEOMETRY_CACHE
+    _GEOMETRY_CACHE = bool(enabled)
+    _tls.cache = None
+
+
+def _geometry_key(tensors, scalars):
+    # "absent" inputs arrive as fresh empty tensors on every call (reference __init__.py:200-210)
+    return tuple(("absent",) if t.numel() == 0 else (id(t), t._version, t.data_ptr(), tuple(t.shape))
+                 for t in tensors) + tuple(scalars)
+
 
 def last_layout() -> dict:
     """Byte offsets of every scratch sub-array of this thread's most recent forward call
@@ -107,6 +132,17 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     radii = make((P,), dtype=torch.int32, device=device)
     scratch = _CallScratch(device)
     rendered = 0
+    geometry_inputs = (means3D, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos)
+    key = None
+    if P != 0 and _GEOMETRY_CACHE:
+        key = _geometry_key(geometry_inputs, (float(scale_modifier), float(tan_fovx), float(tan_fovy), H, W,
+                                              bool(prefiltered), _lib.get_option(_lib.OPT_TILE_CULL),
+                                              torch.cuda.current_stream(device).cuda_stream))
+        hit = getattr(_tls, "cache", None)
+        if hit is not None and hit["key"] == key and colors.numel() != 0 and sh.numel() == 0:
+            cache_stats["hits"] += 1
+            return _blend_cached(hit, background, colors, device, H, W, out_color, out_depth, out_alpha)
+        cache_stats["misses"] += 1
     if P != 0:
         M = int(sh.size(1)) if sh.numel() != 0 else 0
         tensors = [_f32c(n, t, device) for n, t in (
@@ -131,8 +167,30 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         _last_layout.clear()
         _last_layout.update({"geom": _lib.offsets("geom"), "binning": _lib.offsets("binning"),
                              "image": _lib.offsets("image"), "counts": _lib.pair_counts()})
+        if key is not None:
+            _tls.cache = {"key": key, "inputs": geometry_inputs, "layout": {k: dict(v) for k, v in _last_layout.items()},
+                          "rendered": rendered, "radii": radii, "geom": scratch.buffers["geom"],
+                          "binning": scratch.buffers["binning"], "image": scratch.buffers["image"]}
     return (rendered, out_color, out_depth, out_alpha, radii, scratch.buffers["geom"], scratch.buffers["binning"],
             scratch.buffers["image"])
+
+
+def _blend_cached(hit, background, colors, device, H, W, out_color, out_depth, out_alpha):
+    """Second pass over cached geometry: one blend launch (gsr_blend)."""
+    lay, geom, binning, image = hit["layout"], hit["geom"], hit["binning"], hit["image"]
+    bg_, col_ = _f32c("background", background, device), _f32c("colors", colors, device)
+    g, b, i = lay["geom"], lay["binning"], lay["image"]
+    with torch.cuda.device(device):
+        rc = _lib.lib.gsr_blend(
+            W, H, image.data_ptr() + i["ranges"], binning.data_ptr() + b["point_list"],
+            geom.data_ptr() + g["means2D"], geom.data_ptr() + g["conic_opacity"], geom.data_ptr() + g["depths"],
+            col_.data_ptr(), bg_.data_ptr(), out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(),
+            image.data_ptr() + i["n_contrib"], ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"gsr_blend failed ({rc}): {_lib.last_error()}")
+    _last_layout.clear()
+    _last_layout.update({k: dict(v) for k, v in lay.items()})
+    return hit["rendered"], out_color, out_depth, out_alpha, hit["radii"].clone(), geom, binning, image
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,

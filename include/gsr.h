@@ -90,6 +90,19 @@ GSR_API int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user,
 GSR_API int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream);
 
+/*
+ * The blend stage on its own (renderCUDA, DGR/cuda_rasterizer/forward.cu:261-378): composite `features`
+ * [P,3] over the per-tile lists of an earlier gsr_forward call.  gaussian_renderer.render() rasterizes every
+ * frame twice over identical geometry -- SH colours, then normals as colors_precomp
+ * (gaussian_renderer/__init__.py:151-159,176-184) -- and the reference recomputes projection, keys and the
+ * sort for the second pass; with this entry point the second pass costs one kernel.  All pointers are
+ * sub-arrays of that call's scratch arenas (gsr_last_*_offsets) or caller tensors; n_contrib may be NULL.
+ */
+GSR_API int gsr_blend(int width, int height, const uint32_t* ranges, const uint32_t* point_list,
+                      const float* means2D, const float* conic_opacity, const float* depths,
+                      const float* features, const float* background, float* out_color, float* out_depth,
+                      float* out_alpha, uint32_t* n_contrib /*nullable*/, void* stream);
+
 /* Frame hand-off used by the trajectory driver: planar fp32 color[3,H,W] + alpha[H,W] -> planar
  * uint8 rgba8[4,H,W], quantised as torchvision.utils.save_image does for the RGBA PNGs the reference
  * writes (scene_representation.py:427): clamp(x * 255 + 0.5, 0, 255), truncated. */

@@ -25,7 +25,7 @@ from autovfx_amd.cameras import Camera, orbit_cameras
 from autovfx_amd.scenes import GaussianCloud
 from oracle import cpu_oracle
 
-from helpers import hip_forward_raw, oracle_kwargs, run_hip
+from helpers import hip_forward_raw, oracle_kwargs, run_hip, settings_for
 
 pytestmark = pytest.mark.gpu
 
@@ -506,3 +506,49 @@ def test_multi_stream_shard_matches_serial():
     torch.cuda.synchronize()
     assert torch.equal(a["rgba8"], b["rgba8"]) and torch.equal(a["depth"], b["depth"])
     assert len({bytes(f.cpu().numpy().tobytes()) for f in a["rgba8"]}) == 9
+
+
+def test_second_pass_reuses_geometry_bit_for_bit():
+    """gaussian_renderer.render() rasterizes twice over identical geometry tensors (SH pass, then normals as
+    colors_precomp).  The second pass reuses the first's projection / lists (only the blend runs); the result
+    must be bit-identical to a full recomputation, and any in-place change of a geometry tensor must miss."""
+    from diff_gaussian_rasterization import GaussianRasterizer, _C
+    dev = "cuda:0"
+    cam = orbit_cameras(12, 400, 240)[5]
+    c = scenes.config_c2(P=80_000, seed=13).to(dev)
+    st = settings_for(cam, dev, sh_degree=3, bg=(0.2, 0.3, 0.4))
+    normals = torch.nn.functional.normalize(c.means3D, dim=1) * 0.5 + 0.5
+    m2 = torch.zeros_like(c.means3D)
+
+    def two_passes():
+        rast = GaussianRasterizer(st)
+        with torch.no_grad():
+            a = rast(means3D=c.means3D, means2D=m2, opacities=c.opacities, shs=c.shs, scales=c.scales, rotations=c.rotations)
+            b = rast(means3D=c.means3D, means2D=m2, opacities=c.opacities, colors_precomp=normals, scales=c.scales,
+                     rotations=c.rotations)
+        torch.cuda.synchronize()
+        return [t.clone() for t in a], [t.clone() for t in b]
+
+    _C.set_geometry_cache(False)
+    ref_a, ref_b = two_passes()
+    _C.set_geometry_cache(True)
+    h0 = _C.cache_stats["hits"]
+    got_a, got_b = two_passes()
+    assert _C.cache_stats["hits"] == h0 + 1, "second pass did not hit the geometry cache"
+    for x, y in zip(ref_a + ref_b, got_a + got_b):
+        assert torch.equal(x, y)
+    # in-place edit bumps the tensor version: next colour pass must recompute (and differ)
+    rast = GaussianRasterizer(st)
+    with torch.no_grad():
+        rast(means3D=c.means3D, means2D=m2, opacities=c.opacities, shs=c.shs, scales=c.scales, rotations=c.rotations)
+        c.means3D[:, 0] += 0.05
+        h1 = _C.cache_stats["hits"]
+        moved = rast(means3D=c.means3D, means2D=m2, opacities=c.opacities, colors_precomp=normals, scales=c.scales,
+                     rotations=c.rotations)[0]
+    assert _C.cache_stats["hits"] == h1 and not torch.equal(moved, ref_b[0])
+    # gradients flow through a cached second pass too
+    x = normals.clone().requires_grad_(True)
+    rast(means3D=c.means3D, means2D=m2, opacities=c.opacities, shs=c.shs, scales=c.scales, rotations=c.rotations)
+    img = rast(means3D=c.means3D, means2D=m2, opacities=c.opacities, colors_precomp=x, scales=c.scales, rotations=c.rotations)[0]
+    img.sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all() and float(x.grad.abs().sum()) > 0
