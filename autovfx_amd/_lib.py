@@ -28,6 +28,7 @@ SYMBOLS = ("gsr_forward", "gsr_mark_visible", "gsr_backward", "gsr_last_geom_off
            "gsr_abi_version", "gsr_target_arch", "gsr_set_option", "gsr_get_option", "gsr_pack_rgba8", "gsr_last_pair_counts", "gsr_blend")
 OPT_TILE_CULL = 0
 OPT_BLEND_VARIANT = 1
+OPT_BLEND_LDS_PAD = 2
 
 
 class GsrLibraryError(ImportError):

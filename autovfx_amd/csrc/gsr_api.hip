@@ -24,7 +24,7 @@ thread_local uint32_t g_counts[2] = {0, 0};  // last call: {num_rendered (refere
 // synchronising between calls.
 constexpr int kTimingRing = 256;
 constexpr int kEventsPerCall = GSR_STAGE_NUM + 1;
-int g_options[GSR_OPT_NUM] = {/*GSR_OPT_TILE_CULL*/ 1, /*GSR_OPT_BLEND_VARIANT*/ 1};
+int g_options[GSR_OPT_NUM] = {/*GSR_OPT_TILE_CULL*/ 1, /*GSR_OPT_BLEND_VARIANT*/ 1, /*GSR_OPT_BLEND_LDS_PAD*/ 0};
 bool g_timing = false;
 thread_local hipEvent_t g_ev[kTimingRing][kEventsPerCall];
 thread_local bool g_ev_made = false;
@@ -246,7 +246,7 @@ int gsr_blend(int width, int height, const uint32_t* ranges, const uint32_t* poi
     cam.width = width; cam.height = height;
     cam.grid_x = (width + gsr::kTile - 1) / gsr::kTile;
     cam.grid_y = (height + gsr::kTile - 1) / gsr::kTile;
-    GSR_HIP(gsr::launch_blend(cam, g_options[GSR_OPT_BLEND_VARIANT], (const uint2*)ranges, point_list,
+    GSR_HIP(gsr::launch_blend(cam, g_options[GSR_OPT_BLEND_VARIANT], g_options[GSR_OPT_BLEND_LDS_PAD], (const uint2*)ranges, point_list,
                               (const float2*)means2D, features, depths, (const float4*)conic_opacity, background,
                               out_color, out_depth, out_alpha, n_contrib, (hipStream_t)stream_));
     return GSR_OK;
@@ -465,7 +465,7 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     }
 
     const float* features = colors_precomp != nullptr ? colors_precomp : ga.rgb;
-    GSR_HIP(gsr::launch_blend(cam, g_options[GSR_OPT_BLEND_VARIANT], ranges, point_list, ga.means2D, features, ga.depths, ga.conic_opacity, background,
+    GSR_HIP(gsr::launch_blend(cam, g_options[GSR_OPT_BLEND_VARIANT], g_options[GSR_OPT_BLEND_LDS_PAD], ranges, point_list, ga.means2D, features, ga.depths, ga.conic_opacity, background,
                               out_color, out_depth, out_alpha, n_contrib, stream));
     GSR_STAGE_CHECK("blend");
     stamp(7, stream);

@@ -65,7 +65,7 @@ hipError_t launch_duplicate(int P, const Camera& cam, const uint32_t* depth_orde
 hipError_t launch_tile_ranges(uint32_t num_rendered, int num_tiles, const uint32_t* sorted_tile_keys,
                               uint2* ranges, hipStream_t stream);
 // variant 0: one wave per tile, 4 pixels per lane; variant 1: one wave per 8x8 quadrant
-hipError_t launch_blend(const Camera& cam, int variant, const uint2* ranges, const uint32_t* point_list,
+hipError_t launch_blend(const Camera& cam, int variant, int lds_pad_bytes, const uint2* ranges, const uint32_t* point_list,
                         const float2* means2D, const float* features, const float* depths,
                         const float4* conic_opacity, const float* background, float* out_color, float* out_depth,
                         float* out_alpha, uint32_t* n_contrib, hipStream_t stream);

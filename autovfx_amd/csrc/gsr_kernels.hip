@@ -642,15 +642,8 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
         }
         if (first + 64 < count) gather(first + 64);
 
-        while (todo != 0ull) {
-            const int j = __builtin_ctzll(todo);
-            todo &= todo - 1ull;
-            const BlendEntryA a = sA[j];
-            const BlendEntryB b = sB[j];
-            const float dx = a.x - fx, dy = a.y - fy;
-            const float power = -0.5f * (a.cxx * dx * dx + b.cyy * dy * dy) - a.cxy * dx * dy;
-            const bool live = !done && !(power > 0.0f) && !(power < b.skip_below);
-            if (!__any(live)) continue;
+        // One list entry against this lane's pixel: forward.cu:331-364, unchanged arithmetic.
+        auto apply = [&](int j, float power, bool live) {
             if (live) {
                 const BlendEntryC c = sC[j];
                 const float alpha = fminf(0.99f, c.opacity * expf(power));
@@ -669,6 +662,17 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
                     }
                 }
             }
+        };
+        while (todo != 0ull) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const BlendEntryA a = sA[j];
+            const BlendEntryB b = sB[j];
+            const float dx = a.x - fx, dy = a.y - fy;
+            const float power = -0.5f * (a.cxx * dx * dx + b.cyy * dy * dy) - a.cxy * dx * dy;
+            const bool live = !done && !(power > 0.0f) && !(power < b.skip_below);
+            if (!__any(live)) continue;
+            apply(j, power, live);
             if (__all(done)) break;
         }
         if (__all(done)) break;
@@ -1245,13 +1249,15 @@ hipError_t launch_pack_rgba8(const float* color, const float* alpha, uint8_t* ou
     return hipGetLastError();
 }
 
-hipError_t launch_blend(const Camera& cam, int variant, const uint2* ranges, const uint32_t* point_list,
-                        const float2* means2D, const float* features, const float* depths,
+hipError_t launch_blend(const Camera& cam, int variant, int lds_pad_bytes, const uint2* ranges,
+                        const uint32_t* point_list, const float2* means2D, const float* features, const float* depths,
                         const float4* conic_opacity, const float* background, float* out_color, float* out_depth,
                         float* out_alpha, uint32_t* n_contrib, hipStream_t stream) {
     const int T = cam.grid_x * cam.grid_y;
     if (variant == 1) {
-        hipLaunchKernelGGL(blend_quadrant_kernel, dim3(4 * T), dim3(64), 0, stream, cam.width, cam.height, cam.grid_x,
+        // lds_pad_bytes of unused dynamic LDS cap how many single-wave workgroups share a CU, which leaves
+        // wave slots free for the memory-bound kernels of another frame running on a second stream
+        hipLaunchKernelGGL(blend_quadrant_kernel, dim3(4 * T), dim3(64), (size_t)lds_pad_bytes, stream, cam.width, cam.height, cam.grid_x,
                            T, ranges, point_list, means2D, features, depths, conic_opacity, background, out_color,
                            out_depth, out_alpha, n_contrib);
         return hipGetLastError();

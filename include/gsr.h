@@ -186,6 +186,9 @@ typedef enum gsr_option {
     /* [1] Blend kernel shape: 0 = one wave64 per 16x16 tile (4 pixels per lane), 1 = one wave64 per
      * 8x8 quadrant with per-quadrant entry skipping.  Same results; a tuning / A-B knob. */
     GSR_OPT_BLEND_VARIANT = 1,
+    /* [0] Bytes of unused dynamic LDS added to every blend workgroup (variant 1) to cap its occupancy and
+     * leave wave slots for the memory-bound stages of another frame on a second stream.  A tuning knob. */
+    GSR_OPT_BLEND_LDS_PAD = 2,
     GSR_OPT_NUM
 } gsr_option;
 GSR_API int gsr_set_option(int option, int value);

@@ -381,8 +381,9 @@ def test_blend_variants_agree_bit_for_bit(case):
             outs.append(hip_forward_raw(cloud, cam, bg=(0.3, 0.2, 0.1), cull=True))
         finally:
             _lib.set_option(_lib.OPT_BLEND_VARIANT, 1)
-    for k in ("color", "depth", "alpha", "n_contrib", "radii", "point_list", "ranges"):
-        np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=f"{case}: {k} differs between blend variants")
+    for other in outs[1:]:
+        for k in ("color", "depth", "alpha", "n_contrib", "radii", "point_list", "ranges"):
+            np.testing.assert_array_equal(outs[0][k], other[k], err_msg=f"{case}: {k} differs between blend variants")
 
 
 @pytest.mark.parametrize("hw", [(1080, 1920), (33, 17), (7, 5)])
