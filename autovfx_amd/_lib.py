@@ -15,8 +15,7 @@ LIB_PATH = os.environ.get("GSR_LIB", os.path.join(_HERE, "lib", "libgsr_hip.so")
 ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 
 # enum mirrors of include/gsr.h
-GEOM_SLOTS = ("depths", "means2D", "conic_opacity", "rgb", "splat_bins", "internal_radii", "depth_order",
-              "point_offsets")
+GEOM_SLOTS = ("raster", "rgb", "splat_bins", "internal_radii", "depth_order", "point_offsets")
 BIN_SLOTS = ("point_list", "tile_keys")
 IMG_SLOTS = ("ranges", "n_contrib")
 STAGES = ("preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "ranges", "blend")
@@ -60,7 +59,7 @@ def _load() -> ctypes.CDLL:
     lib.gsr_mark_visible.restype = ctypes.c_int
     lib.gsr_mark_visible.argtypes = [ctypes.c_int, c_f, c_f, c_f, c_f, ctypes.c_void_p]
     lib.gsr_blend.restype = ctypes.c_int
-    lib.gsr_blend.argtypes = [ctypes.c_int, ctypes.c_int] + [c_f] * 11 + [ctypes.c_void_p]
+    lib.gsr_blend.argtypes = [ctypes.c_int, ctypes.c_int] + [c_f] * 9 + [ctypes.c_void_p]
     lib.gsr_last_pair_counts.restype = ctypes.c_int
     lib.gsr_last_pair_counts.argtypes = [ctypes.POINTER(ctypes.c_uint32 * 2)]
     lib.gsr_pack_rgba8.restype = ctypes.c_int

@@ -211,9 +211,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     cam.grid_x = (width + gsr::kTile - 1) / gsr::kTile;
     cam.grid_y = (height + gsr::kTile - 1) / gsr::kTile;
 
-    const float* depths = (const float*)(bases[0] + h[0].off[0]);
-    const float2* means2D = (const float2*)(bases[0] + h[0].off[1]);
-    const float4* conic_opacity = (const float4*)(bases[0] + h[0].off[2]);
+    const gsr::SplatRaster* raster = (const gsr::SplatRaster*)(bases[0] + h[0].off[0]);
     const float* rgb = (const float*)(bases[0] + h[0].off[3]);
     if (radii == nullptr) radii = (const int*)(bases[0] + h[0].off[4]);
     const uint32_t* point_list = (const uint32_t*)(bases[1] + h[1].off[0]);
@@ -221,7 +219,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     const uint32_t* n_contrib = (const uint32_t*)(bases[2] + h[2].off[1]);
     const float* colors = colors_precomp != nullptr ? colors_precomp : rgb;  // rasterizer_impl.cu:399
 
-    GSR_HIP(gsr::launch_render_backward(cam, ranges, point_list, background, means2D, conic_opacity, colors, depths,
+    GSR_HIP(gsr::launch_render_backward(cam, ranges, point_list, background, raster, colors,
                                         accum_alphas, n_contrib, dL_dpix, dL_dpix_depth, dL_dpix_alpha, dL_dmean2D,
                                         dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, stream));
     GSR_STAGE_CHECK("render_backward");
@@ -235,11 +233,11 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     return GSR_OK;
 }
 
-int gsr_blend(int width, int height, const uint32_t* ranges, const uint32_t* point_list, const float* means2D,
-              const float* conic_opacity, const float* depths, const float* features, const float* background,
+int gsr_blend(int width, int height, const uint32_t* ranges, const uint32_t* point_list, const float* raster,
+              const float* features, const float* background,
               float* out_color, float* out_depth, float* out_alpha, uint32_t* n_contrib, void* stream_) {
     if (width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARG, "bad image size %dx%d", width, height);
-    if (!ranges || !point_list || !means2D || !conic_opacity || !depths || !features || !background || !out_color ||
+    if (!ranges || !point_list || !raster || !features || !background || !out_color ||
         !out_depth || !out_alpha)
         return fail(GSR_ERR_INVALID_ARG, "null pointer");
     gsr::Camera cam = {};
@@ -247,7 +245,7 @@ int gsr_blend(int width, int height, const uint32_t* ranges, const uint32_t* poi
     cam.grid_x = (width + gsr::kTile - 1) / gsr::kTile;
     cam.grid_y = (height + gsr::kTile - 1) / gsr::kTile;
     GSR_HIP(gsr::launch_blend(cam, g_options[GSR_OPT_BLEND_VARIANT], g_options[GSR_OPT_BLEND_LDS_PAD], (const uint2*)ranges, point_list,
-                              (const float2*)means2D, features, depths, (const float4*)conic_opacity, background,
+                              (const gsr::SplatRaster*)raster, features, background,
                               out_color, out_depth, out_alpha, n_contrib, (hipStream_t)stream_));
     return GSR_OK;
 }
@@ -313,9 +311,7 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     GSR_HIP(gsr::scan_temp_bytes(P, &scan_tmp));
     Carver gc;
     gc.take<gsr::ArenaHeader>(1);  // header at the arena's aligned base
-    g_geom_off[GSR_GEOM_DEPTHS] = gc.take<float>(n);
-    g_geom_off[GSR_GEOM_MEANS2D] = gc.take<float2>(n);
-    g_geom_off[GSR_GEOM_CONIC_OPACITY] = gc.take<float4>(n);
+    g_geom_off[GSR_GEOM_RASTER] = gc.take<gsr::SplatRaster>(n);
     g_geom_off[GSR_GEOM_RGB] = gc.take<float>(3 * n);
     g_geom_off[GSR_GEOM_SPLAT_BINS] = gc.take<gsr::SplatBin>(n);
     g_geom_off[GSR_GEOM_INTERNAL_RADII] = gc.take<int>(n);
@@ -348,9 +344,7 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     in.tile_cull = g_options[GSR_OPT_TILE_CULL] != 0;
 
     gsr::GeometryArrays ga;
-    ga.depths = (float*)(gbase + g_geom_off[GSR_GEOM_DEPTHS]);
-    ga.means2D = (float2*)(gbase + g_geom_off[GSR_GEOM_MEANS2D]);
-    ga.conic_opacity = (float4*)(gbase + g_geom_off[GSR_GEOM_CONIC_OPACITY]);
+    ga.raster = (gsr::SplatRaster*)(gbase + g_geom_off[GSR_GEOM_RASTER]);
     ga.rgb = (float*)(gbase + g_geom_off[GSR_GEOM_RGB]);
     ga.bins = (gsr::SplatBin*)(gbase + g_geom_off[GSR_GEOM_SPLAT_BINS]);
     ga.radii = radii ? radii : (int*)(gbase + g_geom_off[GSR_GEOM_INTERNAL_RADII]);
@@ -449,9 +443,7 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
         hg.magic = hb.magic = hi.magic = gsr::kArenaMagic;
         hg.kind = 0; hb.kind = 1; hi.kind = 2;
         hg.count[0] = (uint32_t)P; hg.count[1] = num_rendered; hg.count[2] = num_live;
-        hg.off[0] = (uint64_t)((char*)ga.depths - gbase);
-        hg.off[1] = (uint64_t)((char*)ga.means2D - gbase);
-        hg.off[2] = (uint64_t)((char*)ga.conic_opacity - gbase);
+        hg.off[0] = (uint64_t)((char*)ga.raster - gbase);
         hg.off[3] = (uint64_t)((char*)ga.rgb - gbase);
         hg.off[4] = (uint64_t)(g_geom_off[GSR_GEOM_INTERNAL_RADII] - gshift);
         hb.count[0] = num_live;
@@ -459,13 +451,13 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
         hi.count[0] = (uint32_t)width; hi.count[1] = (uint32_t)height; hi.count[2] = (uint32_t)T;
         hi.off[0] = (uint64_t)((char*)ranges - ibase);
         hi.off[1] = (uint64_t)((char*)n_contrib - ibase);
-        GSR_HIP(gsr::launch_write_header(gbase, hg, stream));
-        GSR_HIP(gsr::launch_write_header(bbase, hb, stream));
-        GSR_HIP(gsr::launch_write_header(ibase, hi, stream));
+        const gsr::ArenaHeader hs[3] = {hg, hb, hi};
+        void* const dsts[3] = {gbase, bbase, ibase};
+        GSR_HIP(gsr::launch_write_headers(dsts, hs, stream));
     }
 
     const float* features = colors_precomp != nullptr ? colors_precomp : ga.rgb;
-    GSR_HIP(gsr::launch_blend(cam, g_options[GSR_OPT_BLEND_VARIANT], g_options[GSR_OPT_BLEND_LDS_PAD], ranges, point_list, ga.means2D, features, ga.depths, ga.conic_opacity, background,
+    GSR_HIP(gsr::launch_blend(cam, g_options[GSR_OPT_BLEND_VARIANT], g_options[GSR_OPT_BLEND_LDS_PAD], ranges, point_list, ga.raster, features, background,
                               out_color, out_depth, out_alpha, n_contrib, stream));
     GSR_STAGE_CHECK("blend");
     stamp(7, stream);

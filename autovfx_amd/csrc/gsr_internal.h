@@ -42,10 +42,18 @@ struct SplatBin {
     uint32_t count;  // live tiles = pairs this splat emits (0 = culled)
 };
 
+// Everything the blend needs about one splat except its colour, in one 32-byte record (never straddles
+// a 64-byte line): a list entry costs one gather here plus one for the colour, not four.
+struct SplatRaster {
+    float x, y;            // pixel centre
+    float cxx, cxy, cyy;   // conic (inverse 2D covariance)
+    float opacity;
+    float depth;           // view-space z
+    float pad;
+};
+
 struct GeometryArrays {
-    float* depths;
-    float2* means2D;
-    float4* conic_opacity;
+    SplatRaster* raster;
     float* rgb;
     SplatBin* bins;
     unsigned long long* pair_totals; // kRectPartials partial sums: (sum of rectangle areas) << 32 | live pairs
@@ -66,9 +74,8 @@ hipError_t launch_tile_ranges(uint32_t num_rendered, int num_tiles, const uint32
                               uint2* ranges, hipStream_t stream);
 // variant 0: one wave per tile, 4 pixels per lane; variant 1: one wave per 8x8 quadrant
 hipError_t launch_blend(const Camera& cam, int variant, int lds_pad_bytes, const uint2* ranges, const uint32_t* point_list,
-                        const float2* means2D, const float* features, const float* depths,
-                        const float4* conic_opacity, const float* background, float* out_color, float* out_depth,
-                        float* out_alpha, uint32_t* n_contrib, hipStream_t stream);
+                        const SplatRaster* raster, const float* features, const float* background, float* out_color,
+                        float* out_depth, float* out_alpha, uint32_t* n_contrib, hipStream_t stream);
 
 // First 256 bytes of each scratch arena: what the backward pass needs to find the forward's arrays
 // again.  The reference re-derives its layout from sizes (rasterizer_impl.cu:381-383 fromChunk);
@@ -81,7 +88,7 @@ struct ArenaHeader {
     uint32_t pad[2];
     uint64_t off[8];    // byte offsets from the header's own address
 };
-hipError_t launch_write_header(void* dst, const ArenaHeader& h, hipStream_t stream);
+hipError_t launch_write_headers(void* const dst[3], const ArenaHeader h[3], hipStream_t stream);
 
 struct BackwardInputs {
     int P, sh_degree, M;
@@ -103,8 +110,8 @@ struct BackwardInputs {
     float* dL_drot;
 };
 hipError_t launch_render_backward(const Camera& cam, const uint2* ranges, const uint32_t* point_list,
-                                  const float* background, const float2* means2D, const float4* conic_opacity,
-                                  const float* colors, const float* depths, const float* accum_alphas,
+                                  const float* background, const SplatRaster* raster, const float* colors,
+                                  const float* accum_alphas,
                                   const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
                                   const float* dL_dpix_alpha, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                                   float* dL_dcolors, float* dL_ddepths, hipStream_t stream);

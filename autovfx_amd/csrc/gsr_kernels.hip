@@ -275,9 +275,9 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
                     *reinterpret_cast<F3*>(out.rgb + 3 * (size_t)i) = col;
                 }
                 const float4 conic_o = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, in.opacities[i]);
-                out.depths[i] = vz;
-                out.means2D[i] = make_float2(px, py);
-                out.conic_opacity[i] = conic_o;
+                float4* rec = reinterpret_cast<float4*>(out.raster + i);  // one 32-byte record, two 16-byte stores
+                rec[0] = make_float4(px, py, conic_o.x, conic_o.y);
+                rec[1] = make_float4(conic_o.z, conic_o.w, vz, 0.f);
                 radius_out = irad;
                 rect_area = area;
                 bin.xy0 = (uint32_t)rc.x0 | ((uint32_t)rc.y0 << 16);
@@ -446,10 +446,8 @@ __device__ __forceinline__ int xcd_band_tile(int b, int T) {
 __global__ void __launch_bounds__(64, 8) blend_kernel(int W, int H, int grid_x, int num_tiles,
                                                    const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ point_list,
-                                                   const float2* __restrict__ means2D,
+                                                   const SplatRaster* __restrict__ raster,
                                                    const float* __restrict__ features,
-                                                   const float* __restrict__ depths,
-                                                   const float4* __restrict__ conic_opacity,
                                                    const float* __restrict__ background,
                                                    float* __restrict__ out_color, float* __restrict__ out_depth,
                                                    float* __restrict__ out_alpha,
@@ -489,10 +487,12 @@ __global__ void __launch_bounds__(64, 8) blend_kernel(int W, int H, int grid_x, 
         const uint32_t e = first + (uint32_t)lane;
         if (e < count) {
             const uint32_t id = point_list[range.x + e];
-            g_xy = means2D[id];
-            g_co = conic_opacity[id];
+            const float4* rec = reinterpret_cast<const float4*>(raster + id);  // 32 bytes, one cache line
+            const float4 r0 = rec[0], r1 = rec[1];
+            g_xy = make_float2(r0.x, r0.y);
+            g_co = make_float4(r0.z, r0.w, r1.x, r1.y);
+            g_z = r1.z;
             g_rgb = ld3(features + 3 * (size_t)id);
-            g_z = depths[id];
         }
     };
     if (count > 0) gather(0);
@@ -581,10 +581,8 @@ __global__ void __launch_bounds__(64, 8) blend_kernel(int W, int H, int grid_x, 
 __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int grid_x, int num_tiles,
                                                             const uint2* __restrict__ ranges,
                                                             const uint32_t* __restrict__ point_list,
-                                                            const float2* __restrict__ means2D,
+                                                            const SplatRaster* __restrict__ raster,
                                                             const float* __restrict__ features,
-                                                            const float* __restrict__ depths,
-                                                            const float4* __restrict__ conic_opacity,
                                                             const float* __restrict__ background,
                                                             float* __restrict__ out_color,
                                                             float* __restrict__ out_depth,
@@ -621,10 +619,12 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
         const uint32_t e = first + (uint32_t)lane;
         if (e < count) {
             const uint32_t id = point_list[range.x + e];
-            g_xy = means2D[id];
-            g_co = conic_opacity[id];
+            const float4* rec = reinterpret_cast<const float4*>(raster + id);  // 32 bytes, one cache line
+            const float4 r0 = rec[0], r1 = rec[1];
+            g_xy = make_float2(r0.x, r0.y);
+            g_co = make_float4(r0.z, r0.w, r1.x, r1.y);
+            g_z = r1.z;
             g_rgb = ld3(features + 3 * (size_t)id);
-            g_z = depths[id];
         }
     };
     if (count > 0) gather(0);
@@ -725,8 +725,7 @@ __device__ __forceinline__ float wave_sum_in_last_lane(float v) {
 __global__ void __launch_bounds__(64, 4) render_backward_kernel(
     int W, int H, int grid_x, int num_tiles, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const float* __restrict__ background,
-    const float2* __restrict__ means2D, const float4* __restrict__ conic_opacity,
-    const float* __restrict__ colors, const float* __restrict__ depths, const float* __restrict__ accum_alphas,
+    const SplatRaster* __restrict__ raster, const float* __restrict__ colors, const float* __restrict__ accum_alphas,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dpixel_alphas,
     float* __restrict__ dL_dmean2D /*[P,3]*/, float* __restrict__ dL_dconic2D /*[P,4]*/,
@@ -788,10 +787,12 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
         const bool mine = e < top;
         if (mine) {
             g_id = point_list[range.x + e];
-            g_xy = means2D[g_id];
-            g_co = conic_opacity[g_id];
+            const float4* rec = reinterpret_cast<const float4*>(raster + g_id);
+            const float4 r0 = rec[0], r1 = rec[1];
+            g_xy = make_float2(r0.x, r0.y);
+            g_co = make_float4(r0.z, r0.w, r1.x, r1.y);
+            g_z = r1.z;
             g_rgb = ld3(colors + 3 * (size_t)g_id);
-            g_z = depths[g_id];
         }
         unsigned long long todo = __ballot(mine && splat_reaches_rect(g_co, g_xy, qx0, qy0, kQ, kQ));
         if (todo == 0ull) continue;
@@ -1206,22 +1207,27 @@ hipError_t launch_tile_ranges(uint32_t num_rendered, int num_tiles, const uint32
     return hipGetLastError();
 }
 
-__global__ void write_header_kernel(ArenaHeader* dst, ArenaHeader h) { *dst = h; }
+struct ArenaHeaders3 { ArenaHeader h[3]; void* dst[3]; };
+__global__ void write_headers_kernel(ArenaHeaders3 a) {
+    if (threadIdx.x < 3) *reinterpret_cast<ArenaHeader*>(a.dst[threadIdx.x]) = a.h[threadIdx.x];
+}
 
-hipError_t launch_write_header(void* dst, const ArenaHeader& h, hipStream_t stream) {
-    hipLaunchKernelGGL(write_header_kernel, dim3(1), dim3(1), 0, stream, reinterpret_cast<ArenaHeader*>(dst), h);
+hipError_t launch_write_headers(void* const dst[3], const ArenaHeader h[3], hipStream_t stream) {
+    ArenaHeaders3 a;
+    for (int i = 0; i < 3; ++i) { a.h[i] = h[i]; a.dst[i] = dst[i]; }
+    hipLaunchKernelGGL(write_headers_kernel, dim3(1), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_render_backward(const Camera& cam, const uint2* ranges, const uint32_t* point_list,
-                                  const float* background, const float2* means2D, const float4* conic_opacity,
-                                  const float* colors, const float* depths, const float* accum_alphas,
+                                  const float* background, const SplatRaster* raster, const float* colors,
+                                  const float* accum_alphas,
                                   const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
                                   const float* dL_dpix_alpha, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                                   float* dL_dcolors, float* dL_ddepths, hipStream_t stream) {
     const int T = cam.grid_x * cam.grid_y;
     hipLaunchKernelGGL(render_backward_kernel, dim3(4 * T), dim3(64), 0, stream, cam.width, cam.height, cam.grid_x, T,
-                       ranges, point_list, background, means2D, conic_opacity, colors, depths, accum_alphas, n_contrib,
+                       ranges, point_list, background, raster, colors, accum_alphas, n_contrib,
                        dL_dpix, dL_dpix_depth, dL_dpix_alpha, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors,
                        dL_ddepths);
     return hipGetLastError();
@@ -1250,20 +1256,20 @@ hipError_t launch_pack_rgba8(const float* color, const float* alpha, uint8_t* ou
 }
 
 hipError_t launch_blend(const Camera& cam, int variant, int lds_pad_bytes, const uint2* ranges,
-                        const uint32_t* point_list, const float2* means2D, const float* features, const float* depths,
-                        const float4* conic_opacity, const float* background, float* out_color, float* out_depth,
-                        float* out_alpha, uint32_t* n_contrib, hipStream_t stream) {
+                        const uint32_t* point_list, const SplatRaster* raster, const float* features,
+                        const float* background, float* out_color, float* out_depth, float* out_alpha,
+                        uint32_t* n_contrib, hipStream_t stream) {
     const int T = cam.grid_x * cam.grid_y;
     if (variant == 1) {
         // lds_pad_bytes of unused dynamic LDS cap how many single-wave workgroups share a CU, which leaves
         // wave slots free for the memory-bound kernels of another frame running on a second stream
         hipLaunchKernelGGL(blend_quadrant_kernel, dim3(4 * T), dim3(64), (size_t)lds_pad_bytes, stream, cam.width, cam.height, cam.grid_x,
-                           T, ranges, point_list, means2D, features, depths, conic_opacity, background, out_color,
+                           T, ranges, point_list, raster, features, background, out_color,
                            out_depth, out_alpha, n_contrib);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(blend_kernel, dim3(T), dim3(64), 0, stream, cam.width, cam.height, cam.grid_x, T, ranges,
-                       point_list, means2D, features, depths, conic_opacity, background, out_color, out_depth,
+                       point_list, raster, features, background, out_color, out_depth,
                        out_alpha, n_contrib);
     return hipGetLastError();
 }

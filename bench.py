@@ -225,13 +225,15 @@ def main():
                   "alg_GBps": round(stage_alg[k] / (v * 1e-3) / 1e9, 1) if v > 0 else None}
               for k, v in stage_ms.items()}
     dom = max(stage_ms, key=stage_ms.get)
+    kernel_of = {"blend": "blend_quadrant_kernel" if _lib.get_option(_lib.OPT_BLEND_VARIANT) == 1 else "blend_kernel",
+                 "preprocess": "preprocess_kernel", "duplicate": "duplicate_kernel", "ranges": "tile_ranges_kernel"}
+    traffic, traffic_src = pmc_traffic(kernel_of.get(dom, dom)) if (args.workload == "c3" and not args.gaussians) else (None, None)
     dom_gbps = stage_alg[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
     frame_gbps = alg["frame"] / (ms_per_step * 1e-3) / 1e9
     roofline = {
-        "bound": "hbm", "kernel": {"blend": "blend_kernel", "preprocess": "preprocess_kernel",
-                                   "duplicate": "duplicate_kernel", "ranges": "tile_ranges_kernel"}.get(dom, dom),
+        "bound": "hbm", "kernel": kernel_of.get(dom, dom),
         "achieved": round(dom_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": round(dom_gbps / HBM_PEAK_GBPS, 4), "traffic": None,
+        "frac": round(dom_gbps / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
         "avg_launch_ms": round(stage_ms[dom], 4), "alg_bytes_per_launch": int(stage_alg[dom]),
         "timed_calls": calls,
         "frame": {"alg_bytes": int(alg["frame"]), "achieved": round(frame_gbps, 1),
@@ -267,6 +269,25 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/): FETCH_SIZE and
+    WRITE_SIZE are KiB counted at the L2's memory side; on gfx950 FETCH_SIZE reports half of a wide coalesced
+    read stream, hence the factor 2 (/opt/skills/guides/MI355X_MICROARCH.md, HBM).  None if no profile exists."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_per_kernel_mean.csv")
+    try:
+        vals = {}
+        with open(path) as f:
+            for line in f:
+                parts = line.strip().split(",")
+                if len(parts) == 4 and parts[0] == kernel and parts[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    vals[parts[1]] = float(parts[2])
+        if len(vals) == 2:
+            return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), "profiles/r01_pmc_per_kernel_mean.csv (2*FETCH_SIZE + WRITE_SIZE, KiB)"
+    except OSError:
+        pass
+    return None, None
 
 
 def run_cpu_baseline(cloud_cpu, cams_cpu, frame, cloud, cams, bg, W, H, budget_s=12.0, max_frames=12):

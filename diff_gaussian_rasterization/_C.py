@@ -183,8 +183,7 @@ def _blend_cached(hit, background, colors, device, H, W, out_color, out_depth, o
     with torch.cuda.device(device):
         rc = _lib.lib.gsr_blend(
             W, H, image.data_ptr() + i["ranges"], binning.data_ptr() + b["point_list"],
-            geom.data_ptr() + g["means2D"], geom.data_ptr() + g["conic_opacity"], geom.data_ptr() + g["depths"],
-            col_.data_ptr(), bg_.data_ptr(), out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(),
+            geom.data_ptr() + g["raster"], col_.data_ptr(), bg_.data_ptr(), out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(),
             image.data_ptr() + i["n_contrib"], ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
     if rc != 0:
         raise RuntimeError(f"gsr_blend failed ({rc}): {_lib.last_error()}")

@@ -99,9 +99,8 @@ GSR_API int gsr_mark_visible(int P, const float* means3D, const float* viewmatri
  * sub-arrays of that call's scratch arenas (gsr_last_*_offsets) or caller tensors; n_contrib may be NULL.
  */
 GSR_API int gsr_blend(int width, int height, const uint32_t* ranges, const uint32_t* point_list,
-                      const float* means2D, const float* conic_opacity, const float* depths,
-                      const float* features, const float* background, float* out_color, float* out_depth,
-                      float* out_alpha, uint32_t* n_contrib /*nullable*/, void* stream);
+                      const float* raster, const float* features, const float* background, float* out_color,
+                      float* out_depth, float* out_alpha, uint32_t* n_contrib /*nullable*/, void* stream);
 
 /* Frame hand-off used by the trajectory driver: planar fp32 color[3,H,W] + alpha[H,W] -> planar
  * uint8 rgba8[4,H,W], quantised as torchvision.utils.save_image does for the RGBA PNGs the reference
@@ -142,9 +141,8 @@ GSR_API int gsr_backward(int P, int D, int M, int R, const float* background, in
 /* Sub-arrays of the geometry / binning / image scratch, as byte offsets from the pointer the
  * callback returned.  Offsets depend only on the sizes given. */
 typedef enum gsr_geom_slot {
-    GSR_GEOM_DEPTHS = 0,        /* f32[P]   view-space z (valid where radii > 0)                  */
-    GSR_GEOM_MEANS2D,           /* f32[2P]  pixel centre                                           */
-    GSR_GEOM_CONIC_OPACITY,     /* f32[4P]  inverse 2D covariance (xx,xy,yy) + opacity             */
+    GSR_GEOM_RASTER = 0,        /* f32[8P]  per splat: pixel x, y, conic xx, xy, yy (inverse 2D covariance),
+                                   opacity, view-space z, pad -- valid where radii > 0             */
     GSR_GEOM_RGB,               /* f32[3P]  SH-evaluated colour (unused with colors_precomp)       */
     GSR_GEOM_SPLAT_BINS,        /* u32[4P]  per splat: first tile x | y << 16, rectangle width, live-tile mask
                                    (~0 = all), live tiles = pairs emitted (0 = culled); GSR_OPT_TILE_CULL */

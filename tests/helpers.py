@@ -98,9 +98,10 @@ def _hip_forward_raw(_C, cloud, cam, device, bg, scale_modifier, sh_degree, cov3
            "alpha": alpha.cpu().numpy(), "radii": radii.cpu().numpy()}
     if P:
         g = lay["geom"]
-        out["depths"] = view(geom, g["depths"], torch.float32, P)
-        out["means2D"] = view(geom, g["means2D"], torch.float32, 2 * P, (P, 2))
-        out["conic_opacity"] = view(geom, g["conic_opacity"], torch.float32, 4 * P, (P, 4))
+        raster = view(geom, g["raster"], torch.float32, 8 * P, (P, 8))   # x y cxx cxy cyy opacity z pad
+        out["depths"] = np.ascontiguousarray(raster[:, 6])
+        out["means2D"] = np.ascontiguousarray(raster[:, 0:2])
+        out["conic_opacity"] = np.ascontiguousarray(raster[:, 2:6])
         out["rgb"] = view(geom, g["rgb"], torch.float32, 3 * P, (P, 3))
         bins = view(geom, g["splat_bins"], torch.int32, 4 * P, (P, 4)).astype(np.uint32)
         out["tiles_touched"] = bins[:, 3].copy()    # live tiles = pairs the splat emits
