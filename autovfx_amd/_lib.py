@@ -24,7 +24,7 @@ ABI_VERSION = 2
 # every symbol include/gsr.h declares
 SYMBOLS = ("gsr_forward", "gsr_mark_visible", "gsr_backward", "gsr_last_geom_offsets", "gsr_last_binning_offsets",
            "gsr_last_image_offsets", "gsr_set_stage_timing", "gsr_get_stage_times", "gsr_last_error",
-           "gsr_abi_version", "gsr_target_arch", "gsr_set_option", "gsr_get_option", "gsr_pack_rgba8", "gsr_last_pair_counts", "gsr_blend")
+           "gsr_abi_version", "gsr_target_arch", "gsr_set_option", "gsr_get_option", "gsr_pack_rgba8", "gsr_last_pair_counts", "gsr_blend", "gsr_composite")
 OPT_TILE_CULL = 0
 OPT_BLEND_VARIANT = 1
 OPT_BLEND_LDS_PAD = 2
@@ -58,6 +58,8 @@ def _load() -> ctypes.CDLL:
         c_f, c_f, c_f, c_f, ctypes.c_int, ctypes.c_void_p]   # out_color out_depth out_alpha radii debug stream
     lib.gsr_mark_visible.restype = ctypes.c_int
     lib.gsr_mark_visible.argtypes = [ctypes.c_int, c_f, c_f, c_f, c_f, ctypes.c_void_p]
+    lib.gsr_composite.restype = ctypes.c_int
+    lib.gsr_composite.argtypes = [ctypes.c_int, ctypes.c_int] + [c_f] * 12 + [ctypes.c_void_p]
     lib.gsr_blend.restype = ctypes.c_int
     lib.gsr_blend.argtypes = [ctypes.c_int, ctypes.c_int] + [c_f] * 9 + [ctypes.c_void_p]
     lib.gsr_last_pair_counts.restype = ctypes.c_int

@@ -1,0 +1,71 @@
+"""GPU compositor for AutoVFX's final blend (``blender/blend_all.py::blend_frames``).
+
+``composite_frame`` takes the layers of one frame as GPU tensors -- RGBA8 ``[H,W,4]`` colour layers and fp32
+``[H,W]`` depth maps, already resized to the background's resolution -- and returns the composited RGBA8
+frame, bit-identical to the reference's numpy arithmetic (``blend_all.py:236-300,341-343``).  File discovery,
+PNG / EXR decoding and the PIL resizes of the reference (``:124-234``) stay with the caller.
+``smoke_depth_fill`` is the one non-pointwise step (``:207-215``): where the smoke layer has alpha its depth
+becomes the layer's 0.001-th percentile, computed here with numpy's "linear" rule.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+def _percentile_linear(values: torch.Tensor, q: float) -> torch.Tensor:
+    """``numpy.percentile(values, q)`` for a float32 array with the default "linear" rule.  numpy keeps the whole
+    computation in the array's dtype (virtual index, its fractional part and the lerp), so this does too."""
+    import numpy as np
+    v = values.reshape(-1).to(torch.float32).sort().values
+    n = v.numel()
+    pos = (np.float32(q) / np.float32(100)) * np.float32(n - 1)
+    lo = int(np.floor(pos))
+    hi = min(lo + 1, n - 1)
+    t = float(np.float32(pos - np.float32(lo)))
+    a, b = v[lo], v[hi]
+    d = b - a
+    one_minus_t = float(np.float32(1) - np.float32(t))
+    return b - d * one_minus_t if t >= 0.5 else a + d * t   # numpy's _lerp, fp32 throughout
+
+
+def smoke_depth_fill(s_f_c: torch.Tensor, s_f_d: torch.Tensor) -> torch.Tensor:
+    mask = (s_f_c[..., 3].to(torch.float32) / 255.0) > 0.0
+    out = s_f_d.clone()
+    out[mask] = _percentile_linear(s_f_d, 0.001)
+    return out
+
+
+def _layer(t: Optional[torch.Tensor], dtype, shape, device, name):
+    if t is None:
+        return None
+    if t.dtype != dtype or tuple(t.shape) != shape or t.device != device:
+        raise RuntimeError(f"{name}: expected {dtype} {shape} on {device}, got {t.dtype} {tuple(t.shape)} on {t.device}")
+    return t.contiguous()
+
+
+def composite_frame(bg_c, o_c, o_d, s_c, s_d, o_s_c, o_gs_c=None, o_gs_d=None, s_f_c=None, s_f_d=None,
+                    s_f_c_pre=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if not bg_c.is_cuda:
+        raise RuntimeError("composite_frame: layers must live on a HIP device (there is no CPU fallback)")
+    dev, (H, W) = bg_c.device, bg_c.shape[:2]
+    rgba, depth = (H, W, 4), (H, W)
+    L = [_layer(bg_c, torch.uint8, rgba, dev, "bg_c"), _layer(o_c, torch.uint8, rgba, dev, "o_c"),
+         _layer(o_d, torch.float32, depth, dev, "o_d"), _layer(s_c, torch.uint8, rgba, dev, "s_c"),
+         _layer(s_d, torch.float32, depth, dev, "s_d"), _layer(o_s_c, torch.uint8, rgba, dev, "o_s_c"),
+         _layer(o_gs_c, torch.uint8, rgba, dev, "o_gs_c"), _layer(o_gs_d, torch.float32, depth, dev, "o_gs_d"),
+         _layer(s_f_c, torch.uint8, rgba, dev, "s_f_c"), _layer(s_f_d, torch.float32, depth, dev, "s_f_d"),
+         _layer(s_f_c_pre, torch.uint8, rgba, dev, "s_f_c_pre")]
+    if out is None:
+        out = torch.empty(rgba, dtype=torch.uint8, device=dev)
+    ptr = lambda t: None if t is None else t.data_ptr()
+    with torch.cuda.device(dev):
+        rc = _lib.lib.gsr_composite(int(W), int(H), *[ptr(t) for t in L], out.data_ptr(),
+                                    ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"gsr_composite failed ({rc}): {_lib.last_error()}")
+    return out

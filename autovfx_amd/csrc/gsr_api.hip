@@ -250,6 +250,19 @@ int gsr_blend(int width, int height, const uint32_t* ranges, const uint32_t* poi
     return GSR_OK;
 }
 
+int gsr_composite(int width, int height, const uint8_t* bg_c, const uint8_t* o_c, const float* o_d, const uint8_t* s_c,
+                  const float* s_d, const uint8_t* o_s_c, const uint8_t* o_gs_c, const float* o_gs_d,
+                  const uint8_t* s_f_c, const float* s_f_d, const uint8_t* s_f_c_pre, uint8_t* out, void* stream_) {
+    if (width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARG, "bad image size %dx%d", width, height);
+    if (!bg_c || !o_c || !o_d || !s_c || !s_d || !o_s_c || !out) return fail(GSR_ERR_INVALID_ARG, "null required layer");
+    if ((o_gs_c != nullptr) != (o_gs_d != nullptr) || (s_f_c != nullptr) != (s_f_d != nullptr))
+        return fail(GSR_ERR_INVALID_ARG, "a colour layer and its depth map must be given together");
+    if (s_f_c_pre != nullptr && s_f_c == nullptr) return fail(GSR_ERR_INVALID_ARG, "fire layer without a smoke layer");
+    GSR_HIP(gsr::launch_composite(width, height, bg_c, o_c, o_d, s_c, s_d, o_s_c, o_gs_c, o_gs_d, s_f_c, s_f_d,
+                                  s_f_c_pre, out, (hipStream_t)stream_));
+    return GSR_OK;
+}
+
 int gsr_pack_rgba8(const float* color, const float* alpha, uint8_t* rgba8, int width, int height, void* stream_) {
     if (width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARG, "bad image size %dx%d", width, height);
     if (!color || !alpha || !rgba8) return fail(GSR_ERR_INVALID_ARG, "null pointer");

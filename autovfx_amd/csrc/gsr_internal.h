@@ -116,6 +116,10 @@ hipError_t launch_render_backward(const Camera& cam, const uint2* ranges, const 
                                   const float* dL_dpix_alpha, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                                   float* dL_dcolors, float* dL_ddepths, hipStream_t stream);
 hipError_t launch_preprocess_backward(const BackwardInputs& b, const Camera& cam, hipStream_t stream);
+hipError_t launch_composite(int width, int height, const void* bg_c, const void* o_c, const float* o_d,
+                            const void* s_c, const float* s_d, const void* o_s_c, const void* o_gs_c,
+                            const float* o_gs_d, const void* s_f_c, const float* s_f_d, const void* s_f_c_pre,
+                            void* out, hipStream_t stream);
 hipError_t launch_pack_rgba8(const float* color, const float* alpha, uint8_t* out, size_t n_pixels,
                              hipStream_t stream);
 

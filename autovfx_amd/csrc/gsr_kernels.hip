@@ -1176,6 +1176,95 @@ __global__ void __launch_bounds__(256) pack_rgba8_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Compositor: the per-pixel layer arithmetic of blender/blend_all.py::blend_frames (:236-300,341-343),
+// one lane per pixel over interleaved RGBA8 layers and fp32 depth maps.  Pure streaming (4-24 B in per
+// layer, 4 B out); fp32 in numpy's operation order, so the uint8 output is bit-identical to the reference.
+// ------------------------------------------------------------------------------------------------
+struct CompositeLayers {
+    const uchar4* bg_c;        // 3DGS background frame
+    const uchar4* o_c;         // Blender object pass
+    const float* o_d;
+    const uchar4* s_c;         // shadow-catcher pass
+    const float* s_d;
+    const uchar4* o_s_c;       // object + shadow-catcher pass
+    const uchar4* o_gs_c;      // nullable: 3DGS objects re-rendered by Blender
+    const float* o_gs_d;
+    const uchar4* s_f_c;       // nullable: smoke / fire
+    const float* s_f_d;
+    const uchar4* s_f_c_pre;   // nullable: premultiplied fire
+    uchar4* out;
+};
+
+__device__ __forceinline__ float4 to_f4(uchar4 v) { return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w); }
+__device__ __forceinline__ float clip01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+__device__ __forceinline__ unsigned char to_u8(float v) { return (unsigned char)(int)fminf(fmaxf(v, 0.f), 255.f); }
+
+__global__ void __launch_bounds__(256) composite_kernel(CompositeLayers L, size_t n_pixels) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pixels) return;
+    const bool has_3dgs = L.o_gs_c != nullptr, has_smoke = L.s_f_c != nullptr, has_fire = L.s_f_c_pre != nullptr;
+    const float4 bg = to_f4(L.bg_c[i]), oc = to_f4(L.o_c[i]), sc = to_f4(L.s_c[i]), osc = to_f4(L.o_s_c[i]);
+    const float od = L.o_d[i], sd = L.s_d[i];
+    float f[4] = {bg.x, bg.y, bg.z, bg.w};
+
+    // step 1: shadows onto the background (blend_all.py:241-280)
+    float non_obj_3dgs_alpha = 1.f;
+    float ogd = 0.f;
+    if (has_3dgs) {
+        ogd = L.o_gs_d[i];
+        non_obj_3dgs_alpha = (sd <= ogd) ? 1.0f : 1.f - to_f4(L.o_gs_c[i]).w / 255.f;
+    }
+    float obj_alpha = oc.w / 255.f;
+    bool depth_mask = od <= sd;
+    float obj_alpha_smoke = 0.f;
+    bool depth_mask_smoke = false;
+    if (has_smoke) {
+        obj_alpha_smoke = to_f4(L.s_f_c[i]).w / 255.f;
+        depth_mask_smoke = L.s_f_d[i] <= sd;
+        obj_alpha = fmaxf(obj_alpha, obj_alpha_smoke);
+        depth_mask = depth_mask || depth_mask_smoke;
+    }
+    const bool obj_mask = obj_alpha > 0.0f;
+    const bool obj_visible = obj_mask && depth_mask;
+    if (!obj_visible) obj_alpha = 0.0f;
+    const float non_object_alpha = 1.f - obj_alpha;
+    if (has_3dgs && ogd <= od) obj_alpha *= non_obj_3dgs_alpha;
+    const float fg_alpha = osc.w / 255.f;
+    const float sca = has_3dgs ? non_object_alpha * fg_alpha * non_obj_3dgs_alpha : non_object_alpha * fg_alpha;
+    float cd[4] = {1.f, 1.f, 1.f, 1.f};
+    if (sca > 0.0f) {
+        cd[0] = osc.x / (sc.x + 1e-6f);
+        cd[1] = osc.y / (sc.y + 1e-6f);
+        cd[2] = osc.z / (sc.z + 1e-6f);
+    }
+    bool all_close = true;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        cd[c] = clip01(cd[c]);
+        all_close = all_close && (fabsf(cd[c] - 1.f) < 0.01f);
+    }
+    if (!all_close) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) f[c] = f[c] * cd[c] * sca + f[c] * (1.f - sca);
+    }
+
+    // step 2: objects (and fire) over the shadowed background (:285-291)
+    const float t[3] = {f[0], f[1], f[2]};
+    if (obj_visible) {
+        f[0] = oc.x * obj_alpha + t[0] * (1.f - obj_alpha);
+        f[1] = oc.y * obj_alpha + t[1] * (1.f - obj_alpha);
+        f[2] = oc.z * obj_alpha + t[2] * (1.f - obj_alpha);
+    }
+    if (has_fire && depth_mask_smoke) {
+        const float4 pre = to_f4(L.s_f_c_pre[i]);
+        f[0] = pre.x + t[0] * (1.f - obj_alpha_smoke);
+        f[1] = pre.y + t[1] * (1.f - obj_alpha_smoke);
+        f[2] = pre.z + t[2] * (1.f - obj_alpha_smoke);
+    }
+    L.out[i] = make_uchar4(to_u8(f[0]), to_u8(f[1]), to_u8(f[2]), to_u8(f[3]));
+}
+
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
 } // namespace
@@ -1242,6 +1331,19 @@ hipError_t launch_preprocess_backward(const BackwardInputs& b, const Camera& cam
     g.dL_dmean3D = b.dL_dmean3D; g.dL_dcov3D = b.dL_dcov3D; g.dL_dsh = b.dL_dsh; g.dL_dscale = b.dL_dscale;
     g.dL_drot = b.dL_drot;
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3(div_up(b.P, 256)), dim3(256), 0, stream, g, cam);
+    return hipGetLastError();
+}
+
+hipError_t launch_composite(int width, int height, const void* bg_c, const void* o_c, const float* o_d,
+                            const void* s_c, const float* s_d, const void* o_s_c, const void* o_gs_c,
+                            const float* o_gs_d, const void* s_f_c, const float* s_f_d, const void* s_f_c_pre,
+                            void* out, hipStream_t stream) {
+    CompositeLayers L;
+    L.bg_c = (const uchar4*)bg_c; L.o_c = (const uchar4*)o_c; L.o_d = o_d; L.s_c = (const uchar4*)s_c; L.s_d = s_d;
+    L.o_s_c = (const uchar4*)o_s_c; L.o_gs_c = (const uchar4*)o_gs_c; L.o_gs_d = o_gs_d;
+    L.s_f_c = (const uchar4*)s_f_c; L.s_f_d = s_f_d; L.s_f_c_pre = (const uchar4*)s_f_c_pre; L.out = (uchar4*)out;
+    const size_t n = (size_t)width * height;
+    hipLaunchKernelGGL(composite_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, L, n);
     return hipGetLastError();
 }
 

@@ -102,6 +102,23 @@ GSR_API int gsr_blend(int width, int height, const uint32_t* ranges, const uint3
                       const float* raster, const float* features, const float* background, float* out_color,
                       float* out_depth, float* out_alpha, uint32_t* n_contrib /*nullable*/, void* stream);
 
+/*
+ * Compositor: the per-pixel layer arithmetic of blender/blend_all.py::blend_frames
+ * (:236-300, :341-343) for ONE frame.  All colour layers are interleaved RGBA8 [H,W,4] and all depth maps fp32
+ * [H,W], already at the output resolution (the reference resizes Blender's layers with PIL first, :217-234):
+ *   bg_c   the 3DGS background frame (images/<n>.png)
+ *   o_c, o_d      Blender object pass;  s_c, s_d  shadow-catcher pass;  o_s_c  object + shadow-catcher pass
+ *   o_gs_c, o_gs_d  (nullable pair) 3DGS objects re-rendered by Blender
+ *   s_f_c, s_f_d    (nullable pair) smoke / fire, s_f_d already filled with its 0.001-th percentile where
+ *                   the layer has alpha (:207-215);  s_f_c_pre (nullable) premultiplied fire
+ * out is RGBA8 [H,W,4], bit-identical to the reference's frame.
+ */
+GSR_API int gsr_composite(int width, int height, const uint8_t* bg_c, const uint8_t* o_c, const float* o_d,
+                          const uint8_t* s_c, const float* s_d, const uint8_t* o_s_c,
+                          const uint8_t* o_gs_c /*nullable*/, const float* o_gs_d /*nullable*/,
+                          const uint8_t* s_f_c /*nullable*/, const float* s_f_d /*nullable*/,
+                          const uint8_t* s_f_c_pre /*nullable*/, uint8_t* out, void* stream);
+
 /* Frame hand-off used by the trajectory driver: planar fp32 color[3,H,W] + alpha[H,W] -> planar
  * uint8 rgba8[4,H,W], quantised as torchvision.utils.save_image does for the RGBA PNGs the reference
  * writes (scene_representation.py:427): clamp(x * 255 + 0.5, 0, 255), truncated. */

@@ -161,3 +161,23 @@ def test_training_step_reduces_loss():
         losses.append(float(loss))
     report("bw:train", first=losses[0], last=losses[-1])
     assert losses[-1] < 0.7 * losses[0], losses
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_backward_randomised_configurations(seed):
+    rng = np.random.default_rng(500 + seed)
+    P = int(rng.choice([1, 3, 64, 65, 400, 2000]))
+    W, H = int(rng.integers(1, 200)), int(rng.integers(1, 150))
+    cloud = scenes.config_c1(P=P, seed=600 + seed)
+    if seed % 3 == 1 and P >= 8:
+        cloud.scales[: P // 8] *= 25.0
+    if seed % 3 == 2:
+        cloud.opacities *= 0.05
+    deg = int(rng.integers(0, 4))
+    bg = tuple(float(v) for v in rng.uniform(0, 1, 3))
+    cam = scenes.c1_camera(W, H, fovx_deg=float(rng.uniform(35, 95)))
+    pg = pixel_grads(cam, seed)
+    kw = oracle_kwargs(cloud, cam, bg=bg, sh_degree=deg)
+    kw.update(pg)
+    hip = hip_backward(cloud, cam, pg, bg=bg, sh_degree=deg, cull=bool(seed % 2))
+    compare(f"rand{seed}", hip, cpu_oracle.backward(**kw), KEYS_SH)

@@ -553,3 +553,34 @@ def test_second_pass_reuses_geometry_bit_for_bit():
     img = rast(means3D=c.means3D, means2D=m2, opacities=c.opacities, colors_precomp=x, scales=c.scales, rotations=c.rotations)[0]
     img.sum().backward()
     assert x.grad is not None and torch.isfinite(x.grad).all() and float(x.grad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_randomised_configurations(seed):
+    """Seeded sweep over the knobs at once: cloud size, image shape, SH degree / precomputed colours, scale
+    modifier, background, a share of huge or needle-like splats, both blend schedules -- each case against the
+    oracle for every stage (culling off) and for the culled lists (culling on)."""
+    from autovfx_amd import _lib
+    rng = np.random.default_rng(1000 + seed)
+    P = int(rng.choice([1, 2, 7, 64, 65, 300, 1500, 4000]))
+    W, H = int(rng.integers(1, 260)), int(rng.integers(1, 200))
+    cloud = scenes.config_c1(P=P, seed=2000 + seed)
+    kind = rng.integers(0, 4)
+    if kind == 1 and P >= 7:           # screen-filling splats
+        cloud.scales[: max(1, P // 8)] *= float(rng.uniform(5, 40))
+    elif kind == 2 and P >= 7:         # needles: one long axis
+        cloud.scales[: max(1, P // 4), 0] *= 30.0
+    elif kind == 3:                    # faint splats: many below the 1/255 threshold
+        cloud.opacities *= 0.02
+    kw = dict(bg=tuple(float(v) for v in rng.uniform(0, 1, 3)), scale_modifier=float(rng.choice([0.5, 1.0, 1.0, 2.2])))
+    if rng.random() < 0.3:
+        cloud = GaussianCloud(cloud.means3D, cloud.opacities, cloud.scales, cloud.rotations, None,
+                              torch.rand(P, 3, generator=torch.Generator().manual_seed(seed)), 0)
+    else:
+        kw["sh_degree"] = int(rng.integers(0, 5))
+    cam = scenes.c1_camera(W, H, fovx_deg=float(rng.uniform(30, 100)))
+    _lib.set_option(_lib.OPT_BLEND_VARIANT, int(seed % 2))
+    try:
+        run_both(f"rand{seed}", cloud, cam, **kw)
+    finally:
+        _lib.set_option(_lib.OPT_BLEND_VARIANT, 1)
