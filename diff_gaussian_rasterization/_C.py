@@ -80,8 +80,6 @@ def _require_gpu(t: torch.Tensor, what: str) -> torch.device:
     return t.device
 
 
-_last_layout = {}
-
 # ---- geometry reuse between consecutive calls -------------------------------------------------------------------
 # gaussian_renderer.render() calls the rasterizer twice per frame with the very same tensor objects for the
 # geometry (means3D, opacity, scales, rotations / cov3D, camera) and only the colour source changed
@@ -111,7 +109,7 @@ def _geometry_key(tensors, scalars):
 def last_layout() -> dict:
     """Byte offsets of every scratch sub-array of this thread's most recent forward call
     (introspection for the parity tests; not part of the reference surface)."""
-    return dict(_last_layout)
+    return dict(getattr(_tls, "last_layout", None) or {})
 
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
@@ -164,11 +162,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
             _tls.call = None
         if rendered < 0:
             raise RuntimeError(f"gsr_forward failed ({rendered}): {_lib.last_error()}")
-        _last_layout.clear()
-        _last_layout.update({"geom": _lib.offsets("geom"), "binning": _lib.offsets("binning"),
-                             "image": _lib.offsets("image"), "counts": _lib.pair_counts()})
+        # per-thread: the library keeps these per calling thread too, and streams are driven by separate threads
+        layout = {"geom": _lib.offsets("geom"), "binning": _lib.offsets("binning"), "image": _lib.offsets("image"),
+                  "counts": _lib.pair_counts()}
+        _tls.last_layout = layout
         if key is not None:
-            _tls.cache = {"key": key, "inputs": geometry_inputs, "layout": {k: dict(v) for k, v in _last_layout.items()},
+            _tls.cache = {"key": key, "inputs": geometry_inputs, "layout": layout,
                           "rendered": rendered, "radii": radii, "geom": scratch.buffers["geom"],
                           "binning": scratch.buffers["binning"], "image": scratch.buffers["image"]}
     return (rendered, out_color, out_depth, out_alpha, radii, scratch.buffers["geom"], scratch.buffers["binning"],
@@ -187,8 +186,7 @@ def _blend_cached(hit, background, colors, device, H, W, out_color, out_depth, o
             image.data_ptr() + i["n_contrib"], ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
     if rc != 0:
         raise RuntimeError(f"gsr_blend failed ({rc}): {_lib.last_error()}")
-    _last_layout.clear()
-    _last_layout.update({k: dict(v) for k, v in lay.items()})
+    _tls.last_layout = lay
     return hit["rendered"], out_color, out_depth, out_alpha, hit["radii"].clone(), geom, binning, image
 
 
