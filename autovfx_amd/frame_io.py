@@ -1,0 +1,70 @@
+"""Frame outputs the reference's frame loop writes (``scene_representation.py:425-438``).
+
+* ``images/<name>.png``  RGBA8, quantised like ``torchvision.utils.save_image``: ``clamp(x*255 + 0.5, 0, 255)``
+  truncated (the fused ``pack_rgba8`` kernel) -- this is the file ``blend_all.py`` composites over;
+* ``depth/<name>.npy``   float32 ``[H,W]`` un-normalised accumulated depth;
+* ``normal/<name>.png``  ``uint8((n + 1) / 2 * 255)`` (truncation), RGB.
+
+The PNG encoder is a dependency-free one (zlib + CRC from the standard library): ``torchvision``, ``cv2`` and
+``imageio`` are not installed here.  The reference's turbo-coloured depth preview (``cv2.applyColorMap``) is a
+visualisation only and is not reproduced.
+"""
+from __future__ import annotations
+
+import os
+import struct
+import zlib
+
+import numpy as np
+import torch
+
+from .frame_parallel import pack_rgba8
+
+
+def encode_png(image: np.ndarray, compress_level: int = 3) -> bytes:
+    """uint8 ``[H,W,3]`` or ``[H,W,4]`` -> PNG bytes (8-bit truecolour, no interlace, filter 0)."""
+    if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] not in (3, 4):
+        raise ValueError("encode_png expects uint8 [H,W,3|4]")
+    h, w, c = image.shape
+    raw = np.concatenate((np.zeros((h, 1), np.uint8), np.ascontiguousarray(image).reshape(h, w * c)), axis=1).tobytes()
+
+    def chunk(tag: bytes, data: bytes) -> bytes:
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    ihdr = struct.pack(">IIBBBBB", w, h, 8, 6 if c == 4 else 2, 0, 0, 0)
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(raw, compress_level))
+            + chunk(b"IEND", b""))
+
+
+def decode_png(data: bytes) -> np.ndarray:
+    """Inverse of ``encode_png`` for the PNGs it writes (filter type 0 only)."""
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w = 8, b"", 0
+    while pos < len(data):
+        n, tag = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        if tag == b"IHDR":
+            w, h, depth, ctype = struct.unpack(">IIBB", body[:10])
+            c = {2: 3, 6: 4}[ctype]
+        elif tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + w * c)
+    assert not rows[:, 0].any(), "only filter type 0 is supported"
+    return rows[:, 1:].reshape(h, w, c).copy()
+
+
+def write_frame_outputs(out_dir: str, name: str, result: dict) -> dict:
+    """Write the three files of one frame from a ``render()`` result dict; returns their paths."""
+    paths = {k: os.path.join(out_dir, k, name + ext) for k, ext in (("images", ".png"), ("depth", ".npy"), ("normal", ".png"))}
+    for p in paths.values():
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+    rgba = result["render"]
+    rgba8 = pack_rgba8(rgba[:3], rgba[3:4]).permute(1, 2, 0).contiguous().cpu().numpy()
+    with open(paths["images"], "wb") as f:
+        f.write(encode_png(rgba8))
+    np.save(paths["depth"], result["depth"].detach().cpu().numpy().astype(np.float32))
+    n = ((result["normal"].detach() + 1.0) / 2.0 * 255.0).to(torch.uint8).cpu().numpy()   # truncation, as the reference
+    with open(paths["normal"], "wb") as f:
+        f.write(encode_png(n))
+    return paths
