@@ -24,7 +24,8 @@ thread_local uint32_t g_counts[2] = {0, 0};  // last call: {num_rendered (refere
 // synchronising between calls.
 constexpr int kTimingRing = 256;
 constexpr int kEventsPerCall = GSR_STAGE_NUM + 1;
-int g_options[GSR_OPT_NUM] = {/*GSR_OPT_TILE_CULL*/ 1, /*GSR_OPT_BLEND_VARIANT*/ 1, /*GSR_OPT_BLEND_LDS_PAD*/ 0};
+int g_options[GSR_OPT_NUM] = {/*GSR_OPT_TILE_CULL*/ 1, /*GSR_OPT_BLEND_VARIANT*/ 1, /*GSR_OPT_BLEND_LDS_PAD*/ 0,
+                              /*GSR_OPT_SORT_IMPL*/ 1};
 bool g_timing = false;
 thread_local hipEvent_t g_ev[kTimingRing][kEventsPerCall];
 thread_local bool g_ev_made = false;
@@ -84,7 +85,7 @@ int tile_key_bits(uint32_t num_tiles) {
     return b;  // bit_length(T) >= bit_length(T - 1): every tile id fits
 }
 
-constexpr size_t kCounterBytes = (gsr::kRectPartials + 1) * sizeof(unsigned long long);
+constexpr size_t kCounterBytes = gsr::kCounterCopyBytes;  // what travels back to the host
 struct Pinned {
     uint32_t* host = nullptr;    // a few KB of pinned memory per calling thread, deliberately never freed:
     hipEvent_t copied = nullptr; // freeing at thread exit can race HIP runtime teardown
@@ -263,6 +264,35 @@ int gsr_composite(int width, int height, const uint8_t* bg_c, const uint8_t* o_c
     return GSR_OK;
 }
 
+namespace {
+constexpr size_t kRadixHeadBytes = (4 * 256 + 16) * sizeof(uint32_t);  // digit counts + tickets, cleared per call
+}
+
+size_t gsr_radix_scratch_bytes(uint32_t n, int bits) {
+    return kRadixHeadBytes + gsr::radix_state_words(n, bits) * sizeof(uint32_t);
+}
+
+int gsr_radix_sort_pairs(uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt, uint32_t* vals, uint32_t* vals_alt,
+                         int iota_payload, void* scratch, size_t scratch_bytes, int* sorted_in_alt, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (bits < 1 || bits > 32 || n > 0x3FFFFFFFu) return fail(GSR_ERR_INVALID_ARG, "bad sort size n=%u bits=%d", n, bits);
+    if (sorted_in_alt) *sorted_in_alt = 0;
+    if (n == 0) return GSR_OK;
+    if (!keys || !keys_alt || !vals_alt || (!vals && !iota_payload) || !scratch)
+        return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    if (scratch_bytes < gsr_radix_scratch_bytes(n, bits)) return fail(GSR_ERR_INVALID_ARG, "sort scratch too small");
+    GSR_HIP(hipMemsetAsync(scratch, 0, kRadixHeadBytes, stream));
+    gsr::RadixScratch rs;
+    rs.hist = (uint32_t*)scratch;
+    rs.tickets = rs.hist + 4 * 256;
+    rs.states = rs.tickets + 16;
+    rs.extra_zero_words = 0;
+    uint32_t *ks = nullptr, *vs = nullptr;
+    GSR_HIP(gsr::radix_sort_pairs(rs, n, bits, keys, keys_alt, vals, vals_alt, iota_payload != 0, true, &ks, &vs, stream));
+    if (sorted_in_alt) *sorted_in_alt = ks == keys_alt;
+    return GSR_OK;
+}
+
 int gsr_pack_rgba8(const float* color, const float* alpha, uint8_t* rgba8, int width, int height, void* stream_) {
     if (width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARG, "bad image size %dx%d", width, height);
     if (!color || !alpha || !rgba8) return fail(GSR_ERR_INVALID_ARG, "null pointer");
@@ -319,9 +349,16 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     }
 
     // ---- geometry arena ----
+    const bool own_sort = g_options[GSR_OPT_SORT_IMPL] != 0 && (unsigned)P <= 0x3FFFFFFFu;
     size_t sort_tmp = 0, scan_tmp = 0;
-    GSR_HIP(gsr::depth_sort_temp_bytes(P, &sort_tmp));
-    GSR_HIP(gsr::scan_temp_bytes(P, &scan_tmp));
+    const size_t dup_blocks = (n + gsr::kDupTile - 1) / gsr::kDupTile;
+    if (own_sort) {
+        // look-back words of the 4 depth passes, then those of the fused scan (u64 each): one zero fill
+        sort_tmp = gsr::radix_state_words((uint32_t)P, 32) * sizeof(uint32_t) + dup_blocks * sizeof(unsigned long long);
+    } else {
+        GSR_HIP(gsr::depth_sort_temp_bytes(P, &sort_tmp));
+        GSR_HIP(gsr::scan_temp_bytes(P, &scan_tmp));
+    }
     Carver gc;
     gc.take<gsr::ArenaHeader>(1);  // header at the arena's aligned base
     g_geom_off[GSR_GEOM_RASTER] = gc.take<gsr::SplatRaster>(n);
@@ -331,8 +368,7 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     const size_t off_keys_a = gc.take<uint32_t>(n), off_keys_b = gc.take<uint32_t>(n);
     const size_t off_ids_a = gc.take<uint32_t>(n), off_ids_b = gc.take<uint32_t>(n);
     g_geom_off[GSR_GEOM_POINT_OFFSETS] = gc.take<uint32_t>(n);
-    // kRectPartials u64 partial sums of rectangle areas, then one u32 error flag
-    const size_t off_flag = gc.take<unsigned long long>(gsr::kRectPartials + 1);
+    const size_t off_flag = gc.take<gsr::FrameCounters>(1);
     const size_t off_tmp = gc.take<char>(sort_tmp > scan_tmp ? sort_tmp : scan_tmp);
     char* graw = geom_alloc(gc.total(), geom_user);
     if (!graw) return fail(GSR_ERR_ALLOC, "geometry scratch callback returned NULL for %zu bytes", gc.total());
@@ -362,14 +398,13 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     ga.bins = (gsr::SplatBin*)(gbase + g_geom_off[GSR_GEOM_SPLAT_BINS]);
     ga.radii = radii ? radii : (int*)(gbase + g_geom_off[GSR_GEOM_INTERNAL_RADII]);
     ga.depth_keys = (uint32_t*)(gbase + off_keys_a);
-    ga.ids = (uint32_t*)(gbase + off_ids_a);
-    ga.pair_totals = (unsigned long long*)(gbase + off_flag);
-    ga.error_flag = (uint32_t*)(ga.pair_totals + gsr::kRectPartials);
+    ga.ids = own_sort ? nullptr : (uint32_t*)(gbase + off_ids_a);  // the first radix pass generates 0..P-1 itself
+    ga.counters = (gsr::FrameCounters*)(gbase + off_flag);
     uint32_t* point_offsets = (uint32_t*)(gbase + g_geom_off[GSR_GEOM_POINT_OFFSETS]);
     void* tmp = gbase + off_tmp;
     const size_t tmp_bytes = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
 
-    GSR_HIP(hipMemsetAsync(gbase + off_flag, 0, kCounterBytes, stream));
+    GSR_HIP(hipMemsetAsync(gbase + off_flag, 0, sizeof(gsr::FrameCounters), stream));
     stamp(0, stream);
     GSR_HIP(gsr::launch_preprocess(in, cam, ga, stream));
     GSR_STAGE_CHECK("preprocess");
@@ -383,23 +418,35 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     GSR_HIP(hipEventRecord(g_pinned.copied, stream));
 
     uint32_t *keys_sorted = nullptr, *order = nullptr;
-    GSR_HIP(gsr::depth_sort(tmp, tmp_bytes, P, ga.depth_keys, (uint32_t*)(gbase + off_keys_b), ga.ids,
-                            (uint32_t*)(gbase + off_ids_b), &keys_sorted, &order, stream));
+    unsigned long long* scan_states = nullptr;
+    if (own_sort) {
+        gsr::RadixScratch rs;
+        rs.hist = ga.counters->depth_hist;
+        rs.tickets = ga.counters->tickets;
+        rs.states = (uint32_t*)tmp;
+        rs.extra_zero_words = (uint32_t)(dup_blocks * 2);
+        scan_states = (unsigned long long*)(rs.states + gsr::radix_state_words((uint32_t)P, 32));
+        GSR_HIP(gsr::radix_sort_pairs(rs, (uint32_t)P, 32, ga.depth_keys, (uint32_t*)(gbase + off_keys_b),
+                                      (uint32_t*)(gbase + off_ids_a), (uint32_t*)(gbase + off_ids_b),
+                                      /*iota_payload=*/true, /*want_sorted_keys=*/false, &keys_sorted, &order, stream));
+    } else {
+        GSR_HIP(gsr::depth_sort(tmp, tmp_bytes, P, ga.depth_keys, (uint32_t*)(gbase + off_keys_b), ga.ids,
+                                (uint32_t*)(gbase + off_ids_b), &keys_sorted, &order, stream));
+    }
     GSR_STAGE_CHECK("depth_sort");
     stamp(2, stream);
     g_geom_off[GSR_GEOM_DEPTH_ORDER] = (size_t)((char*)order - gbase);
 
-    GSR_HIP(gsr::scan_tiles_in_order(tmp, tmp_bytes, P, ga.bins, order, point_offsets, stream));
+    if (!own_sort) GSR_HIP(gsr::scan_tiles_in_order(tmp, tmp_bytes, P, ga.bins, order, point_offsets, stream));
 
     GSR_HIP(hipEventSynchronize(g_pinned.copied));
-    uint32_t flag = 0;
-    memcpy(&flag, hostb + gsr::kRectPartials * sizeof(unsigned long long), sizeof flag);
-    unsigned long long rect_total = 0, live_total = 0;
+    const gsr::FrameCounters* hc = reinterpret_cast<const gsr::FrameCounters*>(hostb);  // first kCounterBytes only
+    const uint32_t flag = hc->error_flag;
+    unsigned long long rect_total = 0, live_total = 0, emitting = 0;
     for (int i = 0; i < gsr::kRectPartials; ++i) {
-        unsigned long long v;
-        memcpy(&v, hostb + i * sizeof v, sizeof v);
-        rect_total += v >> 32;
-        live_total += v & 0xFFFFFFFFull;
+        rect_total += hc->pair_totals[i] >> 32;
+        live_total += hc->pair_totals[i] & 0xFFFFFFFFull;
+        emitting += hc->visible[i];
     }
     if (debug && prefiltered && (flag & 1u))
         return fail(GSR_ERR_PREFILTERED, "a Gaussian was culled although prefiltered is set (auxiliary.h:156-160)");
@@ -414,7 +461,10 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     // ---- binning arena ----
     const size_t nr = num_live ? num_live : 1;
     size_t tsort_tmp = 0;
-    GSR_HIP(gsr::tile_sort_temp_bytes((uint32_t)nr, &tsort_tmp));
+    const int tile_bits = tile_key_bits((uint32_t)T);
+    const bool own_tile_sort = own_sort && nr <= 0x3FFFFFFFu;
+    if (own_tile_sort) tsort_tmp = gsr::radix_state_words((uint32_t)nr, tile_bits) * sizeof(uint32_t);
+    else GSR_HIP(gsr::tile_sort_temp_bytes((uint32_t)nr, &tsort_tmp));
     Carver bc;
     bc.take<gsr::ArenaHeader>(1);
     const size_t off_tk_a = bc.take<uint32_t>(nr), off_tk_b = bc.take<uint32_t>(nr);
@@ -429,13 +479,28 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     uint32_t* n_contrib = (uint32_t*)(iraw + g_img_off[GSR_IMG_N_CONTRIB]);
 
     if (num_live > 0) {
-        GSR_HIP(gsr::launch_duplicate(P, cam, order, point_offsets, ga.bins, tile_keys, point_list, stream));
+        if (own_sort)
+            GSR_HIP(gsr::launch_duplicate_scan(P, (int)emitting, cam, order, ga.bins, scan_states,
+                                               ga.counters->tickets + 8, point_offsets, tile_keys, point_list, stream));
+        else
+            GSR_HIP(gsr::launch_duplicate(P, cam, order, point_offsets, ga.bins, tile_keys, point_list, stream));
         GSR_STAGE_CHECK("duplicate");
         stamp(4, stream);
         uint32_t *tk_sorted = nullptr, *pl_sorted = nullptr;
-        GSR_HIP(gsr::tile_sort(bbase + off_btmp, tsort_tmp, num_live, tile_key_bits((uint32_t)T), tile_keys,
-                               (uint32_t*)(bbase + off_tk_b), point_list, (uint32_t*)(bbase + off_pl_b),
-                               &tk_sorted, &pl_sorted, stream));
+        if (own_tile_sort) {
+            gsr::RadixScratch rs;
+            rs.hist = ga.counters->tile_hist;
+            rs.tickets = ga.counters->tickets + 4;
+            rs.states = (uint32_t*)(bbase + off_btmp);
+            rs.extra_zero_words = 0;
+            GSR_HIP(gsr::radix_sort_pairs(rs, num_live, tile_bits, tile_keys, (uint32_t*)(bbase + off_tk_b), point_list,
+                                          (uint32_t*)(bbase + off_pl_b), /*iota_payload=*/false,
+                                          /*want_sorted_keys=*/true, &tk_sorted, &pl_sorted, stream));
+        } else {
+            GSR_HIP(gsr::tile_sort(bbase + off_btmp, tsort_tmp, num_live, tile_bits, tile_keys,
+                                   (uint32_t*)(bbase + off_tk_b), point_list, (uint32_t*)(bbase + off_pl_b),
+                                   &tk_sorted, &pl_sorted, stream));
+        }
         GSR_STAGE_CHECK("tile_sort");
         stamp(5, stream);
         tile_keys = tk_sorted;

@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
     const float* __restrict__ vm = cam.viewmatrix;
     const float* __restrict__ pm = cam.projmatrix;
 
-    out.ids[i] = (uint32_t)i;
+    if (out.ids != nullptr) out.ids[i] = (uint32_t)i;
     const F3 p = ld3(in.means3D + 3 * (size_t)i);
 
     // auxiliary.h:58-77 (sums left to right)
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
     if (vz <= 0.2f) {
         // The reference printf+traps here when prefiltered is set (auxiliary.h:156-160); we record
         // the violation and keep the context alive.
-        if (in.prefiltered) atomicOr(out.error_flag, 1u);
+        if (in.prefiltered) atomicOr(&out.counters->error_flag, 1u);
     } else {
         const float pw = 1.0f / (hw + 0.0000001f);
         const float ndc_x = hx * pw, ndc_y = hy * pw;
@@ -305,8 +305,12 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
     unsigned long long wave_tot = ((unsigned long long)rect_area << 32) | (unsigned long long)bin.count;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wave_tot += __shfl_xor(wave_tot, d);
-    if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) && wave_tot != 0)
-        atomicAdd(out.pair_totals + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (kRectPartials - 1)), wave_tot);
+    const unsigned long long emitting = __ballot(key != kCulledKey);
+    if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) && emitting != 0ull) {
+        const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) & (kRectPartials - 1);
+        if (wave_tot != 0ull) atomicAdd(out.counters->pair_totals + slot, wave_tot);
+        atomicAdd(out.counters->visible + slot, (uint32_t)__popcll(emitting));
+    }
 }
 
 __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means3D,
@@ -386,6 +390,131 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, int grid_x, int g
             const uint32_t row = local / o_w, col = local - row * o_w;
             tile_keys[base + t] = ((o_xy0 >> 16) + row) * (uint32_t)grid_x + (o_xy0 & 0xFFFFu) + col;
             point_list[base + t] = o_gid;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3': the same expansion with the prefix sum of the pair counts folded in (one launch instead of a
+// device scan + this kernel, and one gather of the splat record instead of two).  A workgroup owns
+// kDupTile consecutive sorted positions (16 chunks of 64, four per wave), sums its counts, publishes the
+// total and finds the sum of all earlier workgroups by decoupled look-back: wave 0 reads 64
+// predecessors' words at a time until it meets an inclusive prefix.  Workgroup order is a ticket.
+// Only the first V sorted positions can emit (culled Gaussians sort to the end), so only they are
+// gathered; point_offsets is still written for all P positions.
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned long long kScanAggregate = 1ull << 62, kScanPrefix = 2ull << 62;
+
+__global__ void __launch_bounds__(256) duplicate_scan_kernel(int P, int V, int grid_x,
+                                                             const uint32_t* __restrict__ depth_order,
+                                                             const SplatBin* __restrict__ bins,
+                                                             unsigned long long* __restrict__ scan_states,
+                                                             uint32_t* __restrict__ ticket,
+                                                             uint32_t* __restrict__ point_offsets,
+                                                             uint32_t* __restrict__ tile_keys,
+                                                             uint32_t* __restrict__ point_list) {
+    constexpr int kChunks = kDupTile / 256;  // 64-position chunks per wave
+    __shared__ uint32_t s_chunk_total[kDupTile / 64];
+    __shared__ uint32_t s_block, s_before;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_block = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t block = s_block;
+
+    uint32_t gid[kChunks], xy0[kChunks], width[kChunks], mask[kChunks], count[kChunks], incl[kChunks];
+#pragma unroll
+    for (int j = 0; j < kChunks; ++j) {
+        const int k = (int)block * kDupTile + (wave * kChunks + j) * 64 + lane;
+        gid[j] = 0u; xy0[j] = 0u; width[j] = 1u; mask[j] = 0xFFFFFFFFu; count[j] = 0u;
+        if (k < V) {
+            gid[j] = depth_order[k];
+            const uint4 b = *reinterpret_cast<const uint4*>(bins + gid[j]);  // one 16-byte gather per splat
+            xy0[j] = b.x; width[j] = b.y; mask[j] = b.z; count[j] = b.w;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kChunks; ++j) {
+        uint32_t v = count[j];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)v, d);
+            if (lane >= d) v += o;
+        }
+        incl[j] = v;
+        if (lane == 63) s_chunk_total[wave * kChunks + j] = v;
+    }
+    __syncthreads();
+
+    if (wave == 0) {
+        uint32_t block_total = 0;
+#pragma unroll
+        for (int c = 0; c < kDupTile / 64; ++c) block_total += s_chunk_total[c];
+        uint32_t before = 0;
+        unsigned long long* mine = scan_states + block;
+        if (block == 0u) {
+            if (lane == 0) __hip_atomic_store(mine, kScanPrefix | block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(mine, kScanAggregate | block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int p = (int)block - 1;
+            while (true) {
+                const int q = p - lane;
+                const unsigned long long s = q >= 0 ? __hip_atomic_load(scan_states + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                    : kScanPrefix;
+                const uint32_t flag = (uint32_t)(s >> 62);
+                const unsigned long long pending = __ballot(flag == 0u), prefixes = __ballot(flag == 2u);
+                const int first_prefix = prefixes != 0ull ? __builtin_ctzll(prefixes) : 64;
+                const unsigned long long needed = first_prefix >= 63 ? ~0ull : ((2ull << first_prefix) - 1ull);
+                if ((pending & needed) != 0ull) {
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                uint32_t v = lane <= first_prefix ? (uint32_t)s : 0u;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
+                before += v;
+                if (first_prefix < 64) break;
+                p -= 64;
+            }
+            if (lane == 0)
+                __hip_atomic_store(mine, kScanPrefix | (unsigned long long)(before + block_total), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) s_before = before;
+    }
+    __syncthreads();
+
+    uint32_t chunk_base = s_before;
+    for (int c = 0; c < wave * kChunks; ++c) chunk_base += s_chunk_total[c];
+#pragma unroll
+    for (int j = 0; j < kChunks; ++j) {
+        const int k = (int)block * kDupTile + (wave * kChunks + j) * 64 + lane;
+        const uint32_t total = s_chunk_total[wave * kChunks + j];  // wave-uniform
+        const uint32_t base = chunk_base;
+        chunk_base += total;
+        if (k < P) point_offsets[k] = base + incl[j];
+        if (total == 0u) continue;
+        const uint32_t incl_rel = incl[j], excl_rel = incl[j] - count[j];
+        for (uint32_t t0 = 0; t0 < total; t0 += 64) {  // wave-uniform trip count: every lane shuffles
+            const uint32_t t = t0 + lane;
+            int lo = 0, hi = 63;  // smallest lane whose inclusive count exceeds t
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const int mid = (lo + hi) >> 1;
+                const uint32_t v = __shfl(incl_rel, mid);
+                if (v > t) hi = mid; else lo = mid + 1;
+            }
+            const uint32_t o_excl = __shfl(excl_rel, lo);
+            const uint32_t o_xy0 = __shfl(xy0[j], lo);
+            const uint32_t o_w = __shfl(width[j], lo);
+            const uint32_t o_gid = __shfl(gid[j], lo);
+            const uint32_t o_mask = __shfl(mask[j], lo);
+            if (t < total) {
+                const uint32_t r = t - o_excl;
+                const uint32_t local = o_mask == 0xFFFFFFFFu ? r : select_set_bit(o_mask, r);
+                const uint32_t row = local / o_w, col = local - row * o_w;
+                tile_keys[base + t] = ((o_xy0 >> 16) + row) * (uint32_t)grid_x + (o_xy0 & 0xFFFFu) + col;
+                point_list[base + t] = o_gid;
+            }
         }
     }
 }
@@ -1286,6 +1415,14 @@ hipError_t launch_duplicate(int P, const Camera& cam, const uint32_t* depth_orde
                             const SplatBin* bins, uint32_t* tile_keys, uint32_t* point_list, hipStream_t stream) {
     hipLaunchKernelGGL(duplicate_kernel, dim3(div_up(P, 256)), dim3(256), 0, stream, P, cam.grid_x, cam.grid_y,
                        depth_order, point_offsets, bins, tile_keys, point_list);
+    return hipGetLastError();
+}
+
+hipError_t launch_duplicate_scan(int P, int V, const Camera& cam, const uint32_t* depth_order, const SplatBin* bins,
+                                 unsigned long long* scan_states, uint32_t* ticket, uint32_t* point_offsets,
+                                 uint32_t* tile_keys, uint32_t* point_list, hipStream_t stream) {
+    hipLaunchKernelGGL(duplicate_scan_kernel, dim3(div_up(P, kDupTile)), dim3(256), 0, stream, P, V, cam.grid_x,
+                       depth_order, bins, scan_states, ticket, point_offsets, tile_keys, point_list);
     return hipGetLastError();
 }
 

@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--blend-variant", type=int, default=None, help="A/B knob: GSR_OPT_BLEND_VARIANT")
     ap.add_argument("--no-cull", action="store_true", help="A/B knob: GSR_OPT_TILE_CULL = 0")
     ap.add_argument("--blend-lds-pad", type=int, default=None, help="A/B knob: GSR_OPT_BLEND_LDS_PAD (bytes)")
+    ap.add_argument("--sort-impl", type=int, default=None, help="A/B knob: GSR_OPT_SORT_IMPL (0 = rocPRIM passes)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -114,6 +115,8 @@ def main():
         _lib.set_option(_lib.OPT_BLEND_VARIANT, args.blend_variant)
     if args.no_cull:
         _lib.set_option(_lib.OPT_TILE_CULL, 0)
+    if args.sort_impl is not None:
+        _lib.set_option(_lib.OPT_SORT_IMPL, args.sort_impl)
     if args.blend_lds_pad is not None:
         _lib.set_option(_lib.OPT_BLEND_LDS_PAD, args.blend_lds_pad)
     wl = WORKLOADS[args.workload]

@@ -125,6 +125,17 @@ GSR_API int gsr_composite(int width, int height, const uint8_t* bg_c, const uint
 GSR_API int gsr_pack_rgba8(const float* color, const float* alpha, uint8_t* rgba8, int width, int height,
                            void* stream);
 
+/* The sort stage on its own (what gsr_forward runs twice per call; replaces the reference's
+ * cub::DeviceRadixSort::SortPairs, rasterizer_impl.cu:304-309): stable ascending sort of n (u32 key, u32
+ * payload) pairs on the low `bits` key bits.  *_alt are ping-pong partners of the same length; on return
+ * *sorted_in_alt says which buffers hold the result.  iota_payload != 0: the payload is 0..n-1 and `vals`
+ * is not read.  scratch: gsr_radix_scratch_bytes(n, bits) bytes of device memory, any content.
+ * Enqueues on `stream`; n < 2^30. */
+GSR_API size_t gsr_radix_scratch_bytes(uint32_t n, int bits);
+GSR_API int gsr_radix_sort_pairs(uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt, uint32_t* vals,
+                                 uint32_t* vals_alt, int iota_payload, void* scratch, size_t scratch_bytes,
+                                 int* sorted_in_alt, void* stream);
+
 /*
  * Backward rasterization: gradients of a gsr_forward call.  Mirrors Rasterizer::backward
  * (rasterizer.h:57-90, rasterizer_impl.cu:343-446) as called by RasterizeGaussiansBackwardCUDA
@@ -204,6 +215,9 @@ typedef enum gsr_option {
     /* [0] Bytes of unused dynamic LDS added to every blend workgroup (variant 1) to cap its occupancy and
      * leave wave slots for the memory-bound stages of another frame on a second stream.  A tuning knob. */
     GSR_OPT_BLEND_LDS_PAD = 2,
+    /* [1] Sort / scan stages: 1 = this library's own one-sweep radix passes and the prefix sum fused into the
+     * pair expansion (no memsets, 13 launches per call), 0 = rocPRIM device primitives.  Same results. */
+    GSR_OPT_SORT_IMPL = 3,
     GSR_OPT_NUM
 } gsr_option;
 GSR_API int gsr_set_option(int option, int value);

@@ -386,6 +386,38 @@ def test_blend_variants_agree_bit_for_bit(case):
             np.testing.assert_array_equal(outs[0][k], other[k], err_msg=f"{case}: {k} differs between blend variants")
 
 
+@pytest.mark.parametrize("case", ["c1", "c2_mid", "big", "ragged", "tiny"])
+@pytest.mark.parametrize("cull", [False, True])
+def test_sort_implementations_agree_bit_for_bit(case, cull):
+    """GSR_OPT_SORT_IMPL 1 (own one-sweep radix passes + scan fused into the pair expansion) and 0 (rocPRIM
+    primitives) must produce the same arrays: depth order, offsets, lists, ranges, images."""
+    from autovfx_amd import _lib
+    if case == "c1":
+        cloud, cam = scenes.config_c1(), scenes.c1_camera()
+    elif case == "c2_mid":
+        cloud, cam = scenes.config_c2(P=300_000, seed=4), orbit_cameras(200, 960, 540)[120]
+    elif case == "big":
+        cloud, cam = scenes.config_c1(P=400, seed=7), scenes.c1_camera(512, 384)
+        cloud.scales[:60] *= 30.0
+    elif case == "tiny":
+        cloud, cam = scenes.config_c1(P=3, seed=2), scenes.c1_camera(64, 48)
+    else:
+        cloud, cam = scenes.config_c1(P=3000, seed=11), scenes.c1_camera(251, 131)
+    outs = []
+    for impl in (0, 1):
+        _lib.set_option(_lib.OPT_SORT_IMPL, impl)
+        try:
+            outs.append(hip_forward_raw(cloud, cam, bg=(0.3, 0.2, 0.1), cull=cull))
+        finally:
+            _lib.set_option(_lib.OPT_SORT_IMPL, 1)
+    a, b = outs
+    V = int((a["radii"] > 0).sum())
+    np.testing.assert_array_equal(a["depth_order"][:V], b["depth_order"][:V], err_msg=f"{case}: depth order")
+    for k in ("color", "depth", "alpha", "n_contrib", "radii", "point_list", "tile_keys", "ranges", "point_offsets",
+              "num_rendered", "live_pairs"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=f"{case}: {k} differs between sort implementations")
+
+
 @pytest.mark.parametrize("hw", [(1080, 1920), (33, 17), (7, 5)])
 def test_pack_rgba8_matches_save_image_rounding(hw):
     """The fused hand-off kernel against the plain torch expression of torchvision's save_image rounding."""

@@ -1,0 +1,66 @@
+"""The hand-written radix sort (gsr_radix.hip) against torch's stable sort, through the C ABI."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def sort_pairs(keys, vals, bits, iota=False):
+    from autovfx_amd import _lib
+    n = keys.numel()
+    dev = keys.device
+    k_alt, v_alt = torch.empty_like(keys), torch.empty_like(keys)
+    v = vals if vals is not None else torch.empty_like(keys)
+    nbytes = int(_lib.lib.gsr_radix_scratch_bytes(n, bits))
+    scratch = torch.randint(0, 255, (max(nbytes, 1),), dtype=torch.uint8, device=dev)   # garbage on purpose
+    where = ctypes.c_int(0)
+    rc = _lib.lib.gsr_radix_sort_pairs(n, bits, keys.data_ptr(), k_alt.data_ptr(), v.data_ptr(), v_alt.data_ptr(),
+                                       int(iota), scratch.data_ptr(), nbytes, ctypes.byref(where),
+                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, _lib.last_error()
+    torch.cuda.synchronize()
+    return (k_alt, v_alt) if where.value else (keys, v)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 4095, 4096, 4097, 8192, 12345, 100_000, 1_000_003, 8_500_000])
+@pytest.mark.parametrize("bits", [13, 32])
+def test_sort_matches_stable_sort(n, bits):
+    g = torch.Generator(device="cuda").manual_seed(n * 31 + bits)
+    hi = (1 << bits) - 1
+    keys = torch.randint(0, min(hi, 2**31 - 1) + 1, (n,), generator=g, device="cuda", dtype=torch.int64)
+    if bits == 32:                       # cover the top bit and heavy duplicates
+        keys = keys * 2 + torch.randint(0, 2, (n,), generator=g, device="cuda", dtype=torch.int64)
+        keys[::7] = keys[0].clone()
+    vals = torch.randint(0, 2**31 - 1, (n,), generator=g, device="cuda", dtype=torch.int64)
+    order = torch.sort(keys, stable=True).indices
+    want_k, want_v = keys[order], vals[order]
+    k32 = keys.to(torch.uint32).view(torch.int32).contiguous()
+    v32 = vals.to(torch.int32).contiguous()
+    got_k, got_v = sort_pairs(k32, v32, bits)
+    assert torch.equal(got_k.view(torch.uint32).to(torch.int64), want_k)
+    assert torch.equal(got_v.to(torch.int64), want_v)
+
+
+@pytest.mark.parametrize("n", [5, 4096 * 3 + 17, 3_000_000])
+def test_iota_payload_gives_the_stable_permutation(n):
+    g = torch.Generator(device="cuda").manual_seed(n)
+    depth = torch.rand(n, generator=g, device="cuda") * 50 + 0.2
+    depth[::5] = depth[1].clone()                                  # ties: broken by index
+    keys = depth.view(torch.int32).clone()
+    keys[::11] = -1                                          # kCulledKey sorts last
+    want = torch.sort(keys.view(torch.uint32).to(torch.int64), stable=True).indices
+    _, got = sort_pairs(keys.clone(), None, 32, iota=True)
+    assert torch.equal(got.to(torch.int64), want)
+
+
+def test_few_distinct_digits_and_repeated_calls():
+    """Every key in one digit bin (the look-back carries whole tiles), and state reuse across calls."""
+    n = 300_000
+    for rep in range(3):
+        keys = torch.full((n,), 7 + rep, device="cuda", dtype=torch.int32)
+        vals = torch.arange(n, device="cuda", dtype=torch.int32)
+        k, v = sort_pairs(keys, vals, 13)
+        assert torch.equal(v, torch.arange(n, device="cuda", dtype=torch.int32)) and bool((k == 7 + rep).all())
