@@ -36,16 +36,20 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, trace: bool = False) -> str:
+    """``trace=True`` builds libgsr_hip_trace.so: the same library with per-workgroup phase timestamps compiled
+    into selected kernels (GSR_KERNEL_TRACE; see scripts/kernel_trace.py).  A profiling aid, never the default."""
     os.makedirs(OUT_DIR, exist_ok=True)
     cc = hipcc()
     objs, jobs = [], []
+    lib = LIB.replace(".so", "_trace.so") if trace else LIB
+    flags = FLAGS + (["-DGSR_KERNEL_TRACE=1"] if trace else [])
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
-        obj = os.path.join(OUT_DIR, src.replace(".hip", ".o"))
+        obj = os.path.join(OUT_DIR, src.replace(".hip", "_trace.o" if trace else ".o"))
         objs.append(obj)
         if force or _stale(obj, [sp] + HEADERS + [__file__]):
-            jobs.append([cc, "-x", "hip", *FLAGS, "-c", sp, "-o", obj])
+            jobs.append([cc, "-x", "hip", *flags, "-c", sp, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -55,11 +59,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
             list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
-        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs,
+    if jobs or force or _stale(lib, objs):
+        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs,
              "-Wl,--exclude-libs,ALL"])
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, trace="--trace" in sys.argv))

@@ -264,31 +264,23 @@ int gsr_composite(int width, int height, const uint8_t* bg_c, const uint8_t* o_c
     return GSR_OK;
 }
 
-namespace {
-constexpr size_t kRadixHeadBytes = (4 * 256 + 16) * sizeof(uint32_t);  // digit counts + tickets, cleared per call
-}
-
 size_t gsr_radix_scratch_bytes(uint32_t n, int bits) {
-    return kRadixHeadBytes + gsr::radix_state_words(n, bits) * sizeof(uint32_t);
+    (void)bits;
+    return gsr::radix_scratch_words(n) * sizeof(uint32_t);
 }
 
 int gsr_radix_sort_pairs(uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt, uint32_t* vals, uint32_t* vals_alt,
                          int iota_payload, void* scratch, size_t scratch_bytes, int* sorted_in_alt, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (bits < 1 || bits > 32 || n > 0x3FFFFFFFu) return fail(GSR_ERR_INVALID_ARG, "bad sort size n=%u bits=%d", n, bits);
+    if (bits < 1 || bits > 32) return fail(GSR_ERR_INVALID_ARG, "bad key width bits=%d", bits);
     if (sorted_in_alt) *sorted_in_alt = 0;
     if (n == 0) return GSR_OK;
     if (!keys || !keys_alt || !vals_alt || (!vals && !iota_payload) || !scratch)
         return fail(GSR_ERR_INVALID_ARG, "null pointer");
     if (scratch_bytes < gsr_radix_scratch_bytes(n, bits)) return fail(GSR_ERR_INVALID_ARG, "sort scratch too small");
-    GSR_HIP(hipMemsetAsync(scratch, 0, kRadixHeadBytes, stream));
-    gsr::RadixScratch rs;
-    rs.hist = (uint32_t*)scratch;
-    rs.tickets = rs.hist + 4 * 256;
-    rs.states = rs.tickets + 16;
-    rs.extra_zero_words = 0;
     uint32_t *ks = nullptr, *vs = nullptr;
-    GSR_HIP(gsr::radix_sort_pairs(rs, n, bits, keys, keys_alt, vals, vals_alt, iota_payload != 0, true, &ks, &vs, stream));
+    GSR_HIP(gsr::radix_sort_pairs((uint32_t*)scratch, n, bits, keys, keys_alt, vals, vals_alt, iota_payload != 0, true, &ks,
+                                  &vs, stream));
     if (sorted_in_alt) *sorted_in_alt = ks == keys_alt;
     return GSR_OK;
 }
@@ -349,12 +341,11 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     }
 
     // ---- geometry arena ----
-    const bool own_sort = g_options[GSR_OPT_SORT_IMPL] != 0 && (unsigned)P <= 0x3FFFFFFFu;
+    const bool own_sort = g_options[GSR_OPT_SORT_IMPL] != 0;
     size_t sort_tmp = 0, scan_tmp = 0;
     const size_t dup_blocks = (n + gsr::kDupTile - 1) / gsr::kDupTile;
     if (own_sort) {
-        // look-back words of the 4 depth passes, then those of the fused scan (u64 each): one zero fill
-        sort_tmp = gsr::radix_state_words((uint32_t)P, 32) * sizeof(uint32_t) + dup_blocks * sizeof(unsigned long long);
+        sort_tmp = gsr::radix_scratch_words((uint32_t)P) * sizeof(uint32_t);
     } else {
         GSR_HIP(gsr::depth_sort_temp_bytes(P, &sort_tmp));
         GSR_HIP(gsr::scan_temp_bytes(P, &scan_tmp));
@@ -369,6 +360,8 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     const size_t off_ids_a = gc.take<uint32_t>(n), off_ids_b = gc.take<uint32_t>(n);
     g_geom_off[GSR_GEOM_POINT_OFFSETS] = gc.take<uint32_t>(n);
     const size_t off_flag = gc.take<gsr::FrameCounters>(1);
+    const size_t off_tile_totals = gc.take<uint32_t>(2 * dup_blocks);  // tile totals, then global offsets at tile ends
+    const size_t off_sorted_bins = gc.take<uint4>(own_sort ? n : 0);  // splat records again, in depth order
     const size_t off_tmp = gc.take<char>(sort_tmp > scan_tmp ? sort_tmp : scan_tmp);
     char* graw = geom_alloc(gc.total(), geom_user);
     if (!graw) return fail(GSR_ERR_ALLOC, "geometry scratch callback returned NULL for %zu bytes", gc.total());
@@ -418,15 +411,8 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     GSR_HIP(hipEventRecord(g_pinned.copied, stream));
 
     uint32_t *keys_sorted = nullptr, *order = nullptr;
-    unsigned long long* scan_states = nullptr;
     if (own_sort) {
-        gsr::RadixScratch rs;
-        rs.hist = ga.counters->depth_hist;
-        rs.tickets = ga.counters->tickets;
-        rs.states = (uint32_t*)tmp;
-        rs.extra_zero_words = (uint32_t)(dup_blocks * 2);
-        scan_states = (unsigned long long*)(rs.states + gsr::radix_state_words((uint32_t)P, 32));
-        GSR_HIP(gsr::radix_sort_pairs(rs, (uint32_t)P, 32, ga.depth_keys, (uint32_t*)(gbase + off_keys_b),
+        GSR_HIP(gsr::radix_sort_pairs((uint32_t*)tmp, (uint32_t)P, 32, ga.depth_keys, (uint32_t*)(gbase + off_keys_b),
                                       (uint32_t*)(gbase + off_ids_a), (uint32_t*)(gbase + off_ids_b),
                                       /*iota_payload=*/true, /*want_sorted_keys=*/false, &keys_sorted, &order, stream));
     } else {
@@ -462,8 +448,8 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     const size_t nr = num_live ? num_live : 1;
     size_t tsort_tmp = 0;
     const int tile_bits = tile_key_bits((uint32_t)T);
-    const bool own_tile_sort = own_sort && nr <= 0x3FFFFFFFu;
-    if (own_tile_sort) tsort_tmp = gsr::radix_state_words((uint32_t)nr, tile_bits) * sizeof(uint32_t);
+    const bool own_tile_sort = own_sort;
+    if (own_tile_sort) tsort_tmp = gsr::radix_scratch_words((uint32_t)nr) * sizeof(uint32_t);
     else GSR_HIP(gsr::tile_sort_temp_bytes((uint32_t)nr, &tsort_tmp));
     Carver bc;
     bc.take<gsr::ArenaHeader>(1);
@@ -478,24 +464,19 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
     uint2* ranges = (uint2*)(iraw + g_img_off[GSR_IMG_RANGES]);
     uint32_t* n_contrib = (uint32_t*)(iraw + g_img_off[GSR_IMG_N_CONTRIB]);
 
+    if (own_sort)  // also when nothing is live: POINT_OFFSETS is an output
+        GSR_HIP(gsr::launch_scan_expand(P, (int)emitting, num_live, cam, order, ga.bins, (uint4*)(gbase + off_sorted_bins),
+                                        (uint32_t*)(gbase + off_tile_totals), point_offsets, tile_keys, point_list, stream));
     if (num_live > 0) {
-        if (own_sort)
-            GSR_HIP(gsr::launch_duplicate_scan(P, (int)emitting, cam, order, ga.bins, scan_states,
-                                               ga.counters->tickets + 8, point_offsets, tile_keys, point_list, stream));
-        else
+        if (!own_sort)
             GSR_HIP(gsr::launch_duplicate(P, cam, order, point_offsets, ga.bins, tile_keys, point_list, stream));
         GSR_STAGE_CHECK("duplicate");
         stamp(4, stream);
         uint32_t *tk_sorted = nullptr, *pl_sorted = nullptr;
         if (own_tile_sort) {
-            gsr::RadixScratch rs;
-            rs.hist = ga.counters->tile_hist;
-            rs.tickets = ga.counters->tickets + 4;
-            rs.states = (uint32_t*)(bbase + off_btmp);
-            rs.extra_zero_words = 0;
-            GSR_HIP(gsr::radix_sort_pairs(rs, num_live, tile_bits, tile_keys, (uint32_t*)(bbase + off_tk_b), point_list,
-                                          (uint32_t*)(bbase + off_pl_b), /*iota_payload=*/false,
-                                          /*want_sorted_keys=*/true, &tk_sorted, &pl_sorted, stream));
+            GSR_HIP(gsr::radix_sort_pairs((uint32_t*)(bbase + off_btmp), num_live, tile_bits, tile_keys,
+                                          (uint32_t*)(bbase + off_tk_b), point_list, (uint32_t*)(bbase + off_pl_b),
+                                          /*iota_payload=*/false, /*want_sorted_keys=*/true, &tk_sorted, &pl_sorted, stream));
         } else {
             GSR_HIP(gsr::tile_sort(bbase + off_btmp, tsort_tmp, num_live, tile_bits, tile_keys,
                                    (uint32_t*)(bbase + off_tk_b), point_list, (uint32_t*)(bbase + off_pl_b),

@@ -10,8 +10,8 @@ namespace gsr {
 constexpr int kTile = 16;                    // tile edge in pixels; part of the result
 constexpr uint32_t kCulledKey = 0xFFFFFFFFu; // depth key of a Gaussian that produces no pairs
 constexpr int kRectPartials = 256;           // partial sums of rectangle areas (power of two)
-constexpr int kRadixTile = 2048;             // fewest pairs per workgroup of a radix pass (sizes the look-back words)
-constexpr int kDupTile = 1024;               // sorted positions per workgroup of the fused scan + pair expansion
+constexpr int kRadixTile = 4096;             // pairs per workgroup of a radix pass (gsr_radix.hip)
+constexpr int kDupTile = 1024;               // sorted positions per workgroup of the record gather + scan
 
 // Device words of one forward call that must be zero before its first kernel: ONE memset clears them all.
 // Only the first kCounterCopyBytes travel back to the host.
@@ -20,11 +20,8 @@ struct FrameCounters {
     uint32_t visible[kRectPartials];                // Gaussians that emit at least the chance of a pair (key != kCulledKey)
     uint32_t error_flag;                            // bit 0 = prefiltered violation
     uint32_t pad[3];
-    uint32_t depth_hist[4 * 256];                   // digit counts of the depth sort, 4 places
-    uint32_t tile_hist[4 * 256];                    // digit counts of the tile sort
-    uint32_t tickets[16];                           // workgroup tickets: [0..3] depth passes, [4..7] tile passes, [8] scan
 };
-constexpr size_t kCounterCopyBytes = offsetof(FrameCounters, depth_hist);
+constexpr size_t kCounterCopyBytes = sizeof(FrameCounters);
 
 struct Camera {
     const float* viewmatrix;  // 16 floats, transposed w2c
@@ -84,11 +81,11 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmat
                                hipStream_t stream);
 hipError_t launch_duplicate(int P, const Camera& cam, const uint32_t* depth_order, const uint32_t* point_offsets,
                             const SplatBin* bins, uint32_t* tile_keys, uint32_t* point_list, hipStream_t stream);
-// Fused scan + expansion (one launch, decoupled look-back over workgroup totals): also writes point_offsets.
-// scan_states: ceil(P / kDupTile) zeroed u64 words; ticket: one zeroed word.
-hipError_t launch_duplicate_scan(int P, int V, const Camera& cam, const uint32_t* depth_order, const SplatBin* bins,
-                                 unsigned long long* scan_states, uint32_t* ticket, uint32_t* point_offsets,
-                                 uint32_t* tile_keys, uint32_t* point_list, hipStream_t stream);
+// Scan + expansion without any spinning, balanced by pairs (bin_gather / bin_offsets / expand kernels): writes
+// point_offsets (global inclusive), tile_keys and point_list.  sorted_bins: V x 16 B, tile_totals: 2 * ceil(P / kDupTile) words.
+hipError_t launch_scan_expand(int P, int V, uint32_t num_pairs, const Camera& cam, const uint32_t* depth_order,
+                              const SplatBin* bins, uint4* sorted_bins, uint32_t* tile_totals, uint32_t* point_offsets,
+                              uint32_t* tile_keys, uint32_t* point_list, hipStream_t stream);
 hipError_t launch_tile_ranges(uint32_t num_rendered, int num_tiles, const uint32_t* sorted_tile_keys,
                               uint2* ranges, hipStream_t stream);
 // variant 0: one wave per tile, 4 pixels per lane; variant 1: one wave per 8x8 quadrant
@@ -161,17 +158,11 @@ hipError_t tile_sort(void* temp, size_t temp_bytes, uint32_t n, int bits, uint32
 
 
 // ---- hand-written radix sort (gsr_radix.hip) ----
-struct RadixScratch {
-    uint32_t* hist;     // 4 x 256 words, zero on entry
-    uint32_t* tickets;  // 4 words, zero on entry
-    uint32_t* states;   // radix_state_words(n, bits) words, any content (the histogram kernel clears them)
-    uint32_t extra_zero_words;  // words right behind `states` the histogram kernel clears as well
-};
-size_t radix_state_words(uint32_t n, int bits);
-extern int g_radix_config;  // tuning knob: workgroup shape / look-back batch of the pass kernel
-// Stable ascending LSD sort on the low `bits` key bits, 8 per pass.  iota_payload: the payload is 0..n-1 and
-// `vals` is not read.  want_sorted_keys = false skips the key stores of the last pass.
-hipError_t radix_sort_pairs(const RadixScratch& scratch, uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt,
+// Stable ascending LSD sort on the low `bits` key bits, 8 per pass (count / scan / scatter kernels, no spinning,
+// nothing to zero-fill).  scratch: radix_scratch_words(n) u32 words of any content.  iota_payload: the payload
+// is 0..n-1 and `vals` is not read.  want_sorted_keys = false skips the key stores of the last pass.
+size_t radix_scratch_words(uint32_t n);
+hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt,
                             uint32_t* vals, uint32_t* vals_alt, bool iota_payload, bool want_sorted_keys,
                             uint32_t** keys_sorted, uint32_t** vals_sorted, hipStream_t stream);
 

@@ -27,6 +27,18 @@
 //     an exact pre-test that skips expf for pairs that cannot reach alpha >= 1/255.
 #include "gsr_internal.h"
 
+// Profiling aid (python -m autovfx_amd.build --trace, scripts/kernel_trace.py): lane 0 of a workgroup stamps the
+// 100 MHz wall clock into slot `slot` of its 8-word record.  Compiled out of the normal library.
+#ifdef GSR_KERNEL_TRACE
+__device__ unsigned long long* g_kernel_trace = nullptr;
+extern "C" __attribute__((visibility("default"))) int gsr_debug_set_trace(void* device_words) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_kernel_trace), &device_words, sizeof device_words);
+}
+#define GSR_KTRACE(id, slot) do { if (threadIdx.x == 0 && g_kernel_trace) g_kernel_trace[(size_t)(id) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define GSR_KTRACE(id, slot) do { } while (0)
+#endif
+
 namespace gsr {
 namespace {
 
@@ -395,127 +407,231 @@ __global__ void __launch_bounds__(256) duplicate_kernel(int P, int grid_x, int g
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3': the same expansion with the prefix sum of the pair counts folded in (one launch instead of a
-// device scan + this kernel, and one gather of the splat record instead of two).  A workgroup owns
-// kDupTile consecutive sorted positions (16 chunks of 64, four per wave), sums its counts, publishes the
-// total and finds the sum of all earlier workgroups by decoupled look-back: wave 0 reads 64
-// predecessors' words at a time until it meets an inclusive prefix.  Workgroup order is a ticket.
-// Only the first V sorted positions can emit (culled Gaussians sort to the end), so only they are
-// gathered; point_offsets is still written for all P positions.
+// K3': scan + pair expansion as three spin-free kernels (GSR_OPT_SORT_IMPL = 1), balanced by PAIRS.
+// Walking the splats in depth order costs one random 16-byte gather per splat (the records were written
+// in Gaussian order); at 3 M splats that gather, not the arithmetic, is what the stage waits on, and the
+// nearest splats emit hundreds of pairs each while the far ones emit one or two, so handing every
+// workgroup the same number of SPLATS leaves the first workgroups running long after the rest are done.
+//   bin_gather_kernel : one workgroup per kDupTile = 1024 sorted positions.  Gathers the records, scans the
+//                       pair counts inside the tile, writes tile-local inclusive offsets, the tile total and
+//                       the records again IN DEPTH ORDER (so nobody gathers a second time).
+//   bin_offsets_kernel: adds the sum of all earlier tile totals (each workgroup sums them itself: 12 KB of
+//                       L2-resident words, no chain, no look-back) -> POINT_OFFSETS, global and inclusive.
+//   expand_kernel     : one workgroup per kPairTile = 4096 PAIRS, 16 consecutive pairs per lane.  Finds its
+//                       first splat with two workgroup-wide counting searches (tile ends, then inside the
+//                       tile), parks the splats' offsets in LDS (batches of 2048), and every lane binary-
+//                       searches the owner of its FIRST pair only, then walks: next tile of the owner, next
+//                       owner.  Every workgroup does the same work and writes one contiguous 32 KB slice of
+//                       the two pair arrays with 16-byte stores.
 // ------------------------------------------------------------------------------------------------
-constexpr unsigned long long kScanAggregate = 1ull << 62, kScanPrefix = 2ull << 62;
+constexpr int kPairTile = 4096;
+static_assert(kDupTile == 1024, "bin_gather_kernel: 256 lanes x 4 consecutive positions");
 
-__global__ void __launch_bounds__(256) duplicate_scan_kernel(int P, int V, int grid_x,
-                                                             const uint32_t* __restrict__ depth_order,
-                                                             const SplatBin* __restrict__ bins,
-                                                             unsigned long long* __restrict__ scan_states,
-                                                             uint32_t* __restrict__ ticket,
-                                                             uint32_t* __restrict__ point_offsets,
-                                                             uint32_t* __restrict__ tile_keys,
-                                                             uint32_t* __restrict__ point_list) {
-    constexpr int kChunks = kDupTile / 256;  // 64-position chunks per wave
-    __shared__ uint32_t s_chunk_total[kDupTile / 64];
-    __shared__ uint32_t s_block, s_before;
+// Sum over the workgroup's 256 lanes, returned to every lane; scratch is 4 words of LDS.
+__device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* scratch) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const uint32_t total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    __syncthreads();
+    return total;
+}
+
+__global__ void __launch_bounds__(256) bin_gather_kernel(int P, int V, const uint32_t* __restrict__ depth_order,
+                                                         const SplatBin* __restrict__ bins,
+                                                         uint4* __restrict__ sorted_bins /*xy0, width, mask, gid*/,
+                                                         uint32_t* __restrict__ local_offsets,
+                                                         uint32_t* __restrict__ tile_totals) {
+    __shared__ uint32_t s_wave[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_block = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const uint32_t block = s_block;
-
-    uint32_t gid[kChunks], xy0[kChunks], width[kChunks], mask[kChunks], count[kChunks], incl[kChunks];
+    const int k0 = (int)blockIdx.x * kDupTile + 4 * tid;  // 4 consecutive positions per lane
+    uint32_t gid[4] = {0u, 0u, 0u, 0u};
+    if (k0 + 3 < V) {
+        const uint4 g = *reinterpret_cast<const uint4*>(depth_order + k0);
+        gid[0] = g.x; gid[1] = g.y; gid[2] = g.z; gid[3] = g.w;
+    } else {
 #pragma unroll
-    for (int j = 0; j < kChunks; ++j) {
-        const int k = (int)block * kDupTile + (wave * kChunks + j) * 64 + lane;
-        gid[j] = 0u; xy0[j] = 0u; width[j] = 1u; mask[j] = 0xFFFFFFFFu; count[j] = 0u;
-        if (k < V) {
-            gid[j] = depth_order[k];
-            const uint4 b = *reinterpret_cast<const uint4*>(bins + gid[j]);  // one 16-byte gather per splat
-            xy0[j] = b.x; width[j] = b.y; mask[j] = b.z; count[j] = b.w;
+        for (int j = 0; j < 4; ++j)
+            if (k0 + j < V) gid[j] = depth_order[k0 + j];
+    }
+    uint4 rec[4];
+    uint32_t count[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        rec[j] = make_uint4(0u, 1u, 0xFFFFFFFFu, gid[j]);
+        count[j] = 0u;
+        if (k0 + j < V) {
+            const uint4 b = *reinterpret_cast<const uint4*>(bins + gid[j]);  // the one random gather per splat
+            rec[j] = make_uint4(b.x, b.y, b.z, gid[j]);
+            count[j] = b.w;
         }
     }
+    const uint32_t mine = count[0] + count[1] + count[2] + count[3];
+    uint32_t incl = mine;
 #pragma unroll
-    for (int j = 0; j < kChunks; ++j) {
-        uint32_t v = count[j];
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)v, d);
-            if (lane >= d) v += o;
-        }
-        incl[j] = v;
-        if (lane == 63) s_chunk_total[wave * kChunks + j] = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += o;
     }
+    if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
-
-    if (wave == 0) {
-        uint32_t block_total = 0;
+    uint32_t before = incl - mine;
 #pragma unroll
-        for (int c = 0; c < kDupTile / 64; ++c) block_total += s_chunk_total[c];
-        uint32_t before = 0;
-        unsigned long long* mine = scan_states + block;
-        if (block == 0u) {
-            if (lane == 0) __hip_atomic_store(mine, kScanPrefix | block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int w = 0; w < 4; ++w)
+        if (w < wave) before += s_wave[w];
+    if (tid == 255) tile_totals[blockIdx.x] = before + mine;
+    const uint32_t o0 = before + count[0], o1 = o0 + count[1], o2 = o1 + count[2], o3 = o2 + count[3];
+    if (k0 + 3 < P) {
+        *reinterpret_cast<uint4*>(local_offsets + k0) = make_uint4(o0, o1, o2, o3);
+    } else {
+        const uint32_t o[4] = {o0, o1, o2, o3};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k0 + j < P) local_offsets[k0 + j] = o[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (k0 + j < V) sorted_bins[k0 + j] = rec[j];
+}
+
+__global__ void __launch_bounds__(256) bin_offsets_kernel(int P, const uint32_t* __restrict__ tile_totals,
+                                                          uint32_t* __restrict__ offsets, uint32_t* __restrict__ tile_ends) {
+    __shared__ uint32_t s_scratch[4];
+    uint32_t part = 0;
+    for (uint32_t t = threadIdx.x; t < blockIdx.x; t += 256) part += tile_totals[t];
+    const uint32_t before = block_sum_256(part, s_scratch);
+    if (threadIdx.x == 0) tile_ends[blockIdx.x] = before + tile_totals[blockIdx.x];
+    const int k0 = (int)blockIdx.x * kDupTile + 4 * (int)threadIdx.x;
+    if (k0 + 3 < P) {
+        uint4* q = reinterpret_cast<uint4*>(offsets + k0);
+        uint4 v = *q;
+        v.x += before; v.y += before; v.z += before; v.w += before;
+        *q = v;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k0 + j < P) offsets[k0 + j] += before;
+    }
+}
+
+// Walks the live tiles of one splat in order: row-major over the rectangle, or over the set bits of the mask.
+struct TileWalker {
+    uint32_t x0, y0, width, gid;
+    uint32_t mask;      // remaining set bits (masked splats)
+    uint32_t row, col;  // next tile (full rectangles)
+    float inv_width;
+    bool full;
+    __device__ __forceinline__ void start(const uint4 rec, uint32_t r /*tiles to skip*/) {
+        x0 = rec.x & 0xFFFFu; y0 = rec.x >> 16; width = rec.y; gid = rec.w;
+        full = rec.z == 0xFFFFFFFFu;
+        if (full) {
+            row = r / width;
+            col = r - row * width;
         } else {
-            if (lane == 0) __hip_atomic_store(mine, kScanAggregate | block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int p = (int)block - 1;
-            while (true) {
-                const int q = p - lane;
-                const unsigned long long s = q >= 0 ? __hip_atomic_load(scan_states + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                                    : kScanPrefix;
-                const uint32_t flag = (uint32_t)(s >> 62);
-                const unsigned long long pending = __ballot(flag == 0u), prefixes = __ballot(flag == 2u);
-                const int first_prefix = prefixes != 0ull ? __builtin_ctzll(prefixes) : 64;
-                const unsigned long long needed = first_prefix >= 63 ? ~0ull : ((2ull << first_prefix) - 1ull);
-                if ((pending & needed) != 0ull) {
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
-                }
-                uint32_t v = lane <= first_prefix ? (uint32_t)s : 0u;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
-                before += v;
-                if (first_prefix < 64) break;
-                p -= 64;
-            }
-            if (lane == 0)
-                __hip_atomic_store(mine, kScanPrefix | (unsigned long long)(before + block_total), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+            mask = rec.z;
+            for (uint32_t i = 0; i < r; ++i) mask &= mask - 1u;  // r < 32
+            inv_width = __builtin_amdgcn_rcpf((float)width);
         }
-        if (lane == 0) s_before = before;
     }
-    __syncthreads();
+    __device__ __forceinline__ uint32_t next(uint32_t grid_x) {
+        uint32_t r_, c_;
+        if (full) {
+            r_ = row; c_ = col;
+            if (++col == width) { col = 0u; ++row; }
+        } else {
+            const uint32_t pos = (uint32_t)__builtin_ctz(mask);
+            mask &= mask - 1u;
+            // pos < 32, width <= 32: (pos + 0.5) / width is at least 0.5 / 32 away from an integer, the
+            // approximate reciprocal is off by parts in 2^22
+            r_ = (uint32_t)(((float)pos + 0.5f) * inv_width);
+            c_ = pos - r_ * width;
+        }
+        return (y0 + r_) * grid_x + x0 + c_;
+    }
+};
 
-    uint32_t chunk_base = s_before;
-    for (int c = 0; c < wave * kChunks; ++c) chunk_base += s_chunk_total[c];
+constexpr int kPairsPerLane = kPairTile / 256;  // consecutive pairs of one lane
+
+__global__ void __launch_bounds__(256) expand_kernel(int V, uint32_t num_pairs, int grid_x,
+                                                     const uint32_t* __restrict__ offsets /*global, inclusive*/,
+                                                     const uint32_t* __restrict__ tile_ends /*offsets at tile ends*/,
+                                                     const uint4* __restrict__ sorted_bins,
+                                                     uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ point_list) {
+    constexpr int kBatch = 2048;            // splats whose offsets are parked in LDS at a time
+    __shared__ uint32_t s_incl[kBatch + 1]; // s_incl[0] = pairs before the batch's first splat
+    __shared__ uint32_t s_scratch[4];
+    const int tid = threadIdx.x;
+    const uint32_t p_begin = blockIdx.x * (uint32_t)kPairTile;
+    const uint32_t p_end = min(num_pairs, p_begin + (uint32_t)kPairTile);
+
+    // first splat whose inclusive offset exceeds p_begin = number of splats with offset <= p_begin
+    const int tiles = (V + kDupTile - 1) / kDupTile;
+    uint32_t n_le = 0;
+    for (int t = tid; t < tiles; t += 256) n_le += tile_ends[t] <= p_begin ? 1u : 0u;
+    const int tile0 = (int)block_sum_256(n_le, s_scratch);  // tiles that end at or before p_begin
+    n_le = 0;
+    {
+        const int k0 = tile0 * kDupTile + 4 * tid;
 #pragma unroll
-    for (int j = 0; j < kChunks; ++j) {
-        const int k = (int)block * kDupTile + (wave * kChunks + j) * 64 + lane;
-        const uint32_t total = s_chunk_total[wave * kChunks + j];  // wave-uniform
-        const uint32_t base = chunk_base;
-        chunk_base += total;
-        if (k < P) point_offsets[k] = base + incl[j];
-        if (total == 0u) continue;
-        const uint32_t incl_rel = incl[j], excl_rel = incl[j] - count[j];
-        for (uint32_t t0 = 0; t0 < total; t0 += 64) {  // wave-uniform trip count: every lane shuffles
-            const uint32_t t = t0 + lane;
-            int lo = 0, hi = 63;  // smallest lane whose inclusive count exceeds t
+        for (int j = 0; j < 4; ++j)
+            if (k0 + j < V) n_le += offsets[k0 + j] <= p_begin ? 1u : 0u;
+    }
+    int s0 = tile0 * kDupTile + (int)block_sum_256(n_le, s_scratch);
+
+    const uint32_t my_begin = p_begin + (uint32_t)(kPairsPerLane * tid);
+    const uint32_t my_end = min(p_end, my_begin + (uint32_t)kPairsPerLane);
+    uint32_t keys[kPairsPerLane], ids[kPairsPerLane];
+    while (s0 < V) {  // workgroup-uniform
+        for (int i = tid; i <= kBatch; i += 256) {
+            const int k = s0 - 1 + i;
+            s_incl[i] = k < 0 ? 0u : offsets[min(k, V - 1)];
+        }
+        __syncthreads();
+        const uint32_t lo_pair = max(my_begin, s_incl[0]);
+        const uint32_t hi_pair = min(my_end, s_incl[kBatch]);
+        if (lo_pair < hi_pair) {
+            int lo = 1, hi = kBatch;  // smallest i with s_incl[i] > lo_pair: the owner of this lane's first pair
 #pragma unroll
-            for (int s = 0; s < 6; ++s) {
+            for (int step = 0; step < 11; ++step) {
                 const int mid = (lo + hi) >> 1;
-                const uint32_t v = __shfl(incl_rel, mid);
-                if (v > t) hi = mid; else lo = mid + 1;
+                if (s_incl[mid] > lo_pair) hi = mid; else lo = mid + 1;
             }
-            const uint32_t o_excl = __shfl(excl_rel, lo);
-            const uint32_t o_xy0 = __shfl(xy0[j], lo);
-            const uint32_t o_w = __shfl(width[j], lo);
-            const uint32_t o_gid = __shfl(gid[j], lo);
-            const uint32_t o_mask = __shfl(mask[j], lo);
-            if (t < total) {
-                const uint32_t r = t - o_excl;
-                const uint32_t local = o_mask == 0xFFFFFFFFu ? r : select_set_bit(o_mask, r);
-                const uint32_t row = local / o_w, col = local - row * o_w;
-                tile_keys[base + t] = ((o_xy0 >> 16) + row) * (uint32_t)grid_x + (o_xy0 & 0xFFFFu) + col;
-                point_list[base + t] = o_gid;
+            int owner = lo;
+            uint32_t owner_end = s_incl[owner];
+            TileWalker w;
+            w.start(sorted_bins[s0 + owner - 1], lo_pair - s_incl[owner - 1]);
+#pragma unroll
+            for (int q = 0; q < kPairsPerLane; ++q) {
+                const uint32_t p = my_begin + (uint32_t)q;
+                if (p >= lo_pair && p < hi_pair) {
+                    if (p >= owner_end) {
+                        do { owner_end = s_incl[++owner]; } while (p >= owner_end);  // splats without live tiles
+                        w.start(sorted_bins[s0 + owner - 1], 0u);
+                    }
+                    keys[q] = w.next((uint32_t)grid_x);
+                    ids[q] = w.gid;
+                }
             }
         }
+        const bool done = s_incl[kBatch] >= p_end;
+        __syncthreads();
+        if (done) break;
+        s0 += kBatch;
+    }
+    if (my_begin + kPairsPerLane <= p_end) {
+#pragma unroll
+        for (int q = 0; q < kPairsPerLane; q += 4) {
+            *reinterpret_cast<uint4*>(tile_keys + my_begin + q) = make_uint4(keys[q], keys[q + 1], keys[q + 2], keys[q + 3]);
+            *reinterpret_cast<uint4*>(point_list + my_begin + q) = make_uint4(ids[q], ids[q + 1], ids[q + 2], ids[q + 3]);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < kPairsPerLane; ++q)
+            if (my_begin + q < p_end) {
+                tile_keys[my_begin + q] = keys[q];
+                point_list[my_begin + q] = ids[q];
+            }
     }
 }
 
@@ -1418,11 +1534,17 @@ hipError_t launch_duplicate(int P, const Camera& cam, const uint32_t* depth_orde
     return hipGetLastError();
 }
 
-hipError_t launch_duplicate_scan(int P, int V, const Camera& cam, const uint32_t* depth_order, const SplatBin* bins,
-                                 unsigned long long* scan_states, uint32_t* ticket, uint32_t* point_offsets,
-                                 uint32_t* tile_keys, uint32_t* point_list, hipStream_t stream) {
-    hipLaunchKernelGGL(duplicate_scan_kernel, dim3(div_up(P, kDupTile)), dim3(256), 0, stream, P, V, cam.grid_x,
-                       depth_order, bins, scan_states, ticket, point_offsets, tile_keys, point_list);
+hipError_t launch_scan_expand(int P, int V, uint32_t num_pairs, const Camera& cam, const uint32_t* depth_order,
+                              const SplatBin* bins, uint4* sorted_bins, uint32_t* tile_totals, uint32_t* point_offsets,
+                              uint32_t* tile_keys, uint32_t* point_list, hipStream_t stream) {
+    const int tiles = div_up(P, kDupTile);
+    hipLaunchKernelGGL(bin_gather_kernel, dim3(tiles), dim3(256), 0, stream, P, V, depth_order, bins, sorted_bins,
+                       point_offsets, tile_totals);
+    uint32_t* tile_ends = tile_totals + tiles;
+    hipLaunchKernelGGL(bin_offsets_kernel, dim3(tiles), dim3(256), 0, stream, P, tile_totals, point_offsets, tile_ends);
+    if (num_pairs > 0)
+        hipLaunchKernelGGL(expand_kernel, dim3((num_pairs + kPairTile - 1) / kPairTile), dim3(256), 0, stream, V, num_pairs,
+                           cam.grid_x, point_offsets, tile_ends, sorted_bins, tile_keys, point_list);
     return hipGetLastError();
 }
 

@@ -27,9 +27,12 @@
 namespace gsr {
 namespace {
 
-constexpr int kHistThreads = 256;
-constexpr int kHistCopies = 8;  // sub-histograms per place: lanes L and L+8 share one (skewed digits serialise LDS atomics)
-constexpr uint32_t kAggregate = 1u << 30, kPrefix = 2u << 30, kCountMask = (1u << 30) - 1u;
+constexpr int kThreads = 256;
+constexpr int kItems = 16;
+constexpr int kTileItems = kThreads * kItems;
+constexpr int kWaves = kThreads / 64;
+constexpr int kCountCopies = 8;  // sub-histograms of the count kernel: lanes L and L+8 share one
+static_assert(kTileItems == kRadixTile, "gsr_internal.h sizes the per-tile counters with kRadixTile");
 
 #ifdef GSR_RADIX_TRACE  // scripts/ubench/radix_trace.hip: per-workgroup phase timestamps (100 MHz wall clock)
 __device__ unsigned long long* g_radix_trace = nullptr;
@@ -37,13 +40,6 @@ __device__ unsigned long long* g_radix_trace = nullptr;
 #else
 #define GSR_TRACE(slot) do { } while (0)
 #endif
-
-__device__ __forceinline__ uint32_t load_state(const uint32_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void store_state(uint32_t* p, uint32_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, int lane) {
 #pragma unroll
@@ -54,91 +50,113 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, int lane) {
     return v;
 }
 
-// Exclusive sum of one value per digit, held by lanes 0..255 (waves 0..3; every wave of the workgroup calls).
-__device__ __forceinline__ uint32_t digits_exclusive_sum(uint32_t v, uint32_t* scratch /*4 words of LDS*/, int tid) {
+// Exclusive sum over the 256 lanes of the workgroup; `scratch` is kWaves words of LDS; *total = sum of all.
+__device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t* scratch, int tid, uint32_t* total = nullptr) {
     const int lane = tid & 63, wave = tid >> 6;
     const uint32_t incl = wave_inclusive_sum(v, lane);
-    if (lane == 63 && wave < 4) scratch[wave] = incl;
+    if (lane == 63) scratch[wave] = incl;
     __syncthreads();
-    uint32_t before = 0;
+    uint32_t before = 0, all = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w)
-        if (w < wave) before += scratch[w];
+    for (int w = 0; w < kWaves; ++w) {
+        const uint32_t t = scratch[w];
+        if (w < wave) before += t;
+        all += t;
+    }
     __syncthreads();
+    if (total) *total = all;
     return before + incl - v;
 }
 
 // ------------------------------------------------------------------------------------------------
-// Digit counts of every place in one pass over the keys, and the zero fill of the look-back words.
-// hist[place * 256 + digit] must be zero on entry (the forward call's counter memset).
+// count: counts[digit * tiles_pad + tile] = number of keys of the tile with that digit.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kHistThreads) radix_histogram_kernel(const uint32_t* __restrict__ keys, uint32_t n,
-                                                                      int places, int bits, uint32_t* __restrict__ hist,
-                                                                      uint32_t* __restrict__ zero_words,
-                                                                      uint32_t num_zero_words) {
-    __shared__ uint32_t s_hist[4 * kHistCopies * 256];
+__global__ void __launch_bounds__(kThreads) radix_count_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
+                                                              uint32_t digit_mask, uint32_t* __restrict__ counts,
+                                                              uint32_t tiles_pad) {
+    __shared__ uint32_t s_hist[kCountCopies][256];
     const int tid = threadIdx.x;
-    for (int i = tid; i < places * kHistCopies * 256; i += kHistThreads) s_hist[i] = 0u;
-    __syncthreads();
-    const uint32_t stride = gridDim.x * kHistThreads;
-    for (uint32_t i = blockIdx.x * kHistThreads + tid; i < num_zero_words; i += stride) zero_words[i] = 0u;
-    uint32_t* mine = s_hist + (tid & (kHistCopies - 1)) * 256;
-    auto count = [&](uint32_t k) {
-        for (int p = 0; p < places; ++p) {
-            const int width = min(8, bits - 8 * p);
-            atomicAdd(&mine[p * kHistCopies * 256 + ((k >> (8 * p)) & ((1u << width) - 1u))], 1u);
-        }
-    };
-    const uint32_t n4 = n / 4u;  // 16-byte loads: the key arrays are 256-byte aligned sub-arrays of an arena
-    const uint4* keys4 = reinterpret_cast<const uint4*>(keys);
-    for (uint32_t i = blockIdx.x * kHistThreads + tid; i < n4; i += stride) {
-        const uint4 k = keys4[i];
-        count(k.x); count(k.y); count(k.z); count(k.w);
-    }
-    if (blockIdx.x == 0 && tid < (int)(n - 4u * n4)) count(keys[4u * n4 + tid]);
-    __syncthreads();
-    for (int i = tid; i < places * 256; i += kHistThreads) {
-        uint32_t c = 0;
+    const uint32_t block = blockIdx.x;
 #pragma unroll
-        for (int j = 0; j < kHistCopies; ++j) c += s_hist[((i >> 8) * kHistCopies + j) * 256 + (i & 255)];
-        if (c != 0u) atomicAdd(&hist[i], c);
+    for (int j = 0; j < kCountCopies; ++j) s_hist[j][tid] = 0u;
+    __syncthreads();
+    uint32_t* mine = s_hist[tid & (kCountCopies - 1)];
+    const uint32_t tile_base = block * (uint32_t)kTileItems;
+    if (tile_base + kTileItems <= n) {  // 16-byte loads: key arrays are 256-byte aligned sub-arrays of an arena
+        const uint4* k4 = reinterpret_cast<const uint4*>(keys + tile_base);
+        uint4 k[kItems / 4];
+#pragma unroll
+        for (int i = 0; i < kItems / 4; ++i) k[i] = k4[i * kThreads + tid];
+#pragma unroll
+        for (int i = 0; i < kItems / 4; ++i) {
+            atomicAdd(&mine[(k[i].x >> shift) & digit_mask], 1u);
+            atomicAdd(&mine[(k[i].y >> shift) & digit_mask], 1u);
+            atomicAdd(&mine[(k[i].z >> shift) & digit_mask], 1u);
+            atomicAdd(&mine[(k[i].w >> shift) & digit_mask], 1u);
+        }
+    } else {
+        for (uint32_t t = tid; tile_base + t < n; t += kThreads) atomicAdd(&mine[(keys[tile_base + t] >> shift) & digit_mask], 1u);
     }
+    __syncthreads();
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < kCountCopies; ++j) c += s_hist[j][tid];
+    counts[(size_t)tid * tiles_pad + block] = c;
 }
 
 // ------------------------------------------------------------------------------------------------
-// One pass.  kThreads x kItems pairs per workgroup; kBatch look-back loads in flight per lane.
-// kIota: payloads are the item indices (first pass of the depth sort: no payload read).
+// scan: one workgroup per digit turns its row of tile counts into exclusive prefixes, in place;
+// totals[digit] = number of keys with that digit.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads) radix_scan_kernel(uint32_t* __restrict__ counts, uint32_t tiles,
+                                                             uint32_t tiles_pad, uint32_t* __restrict__ totals) {
+    __shared__ uint32_t s_scan[kWaves];
+    const int tid = threadIdx.x;
+    uint4* row = reinterpret_cast<uint4*>(counts + (size_t)blockIdx.x * tiles_pad);  // tiles_pad is a multiple of 4
+    uint32_t carry = 0;
+    for (uint32_t t0 = 0; t0 < tiles; t0 += 4u * kThreads) {
+        const uint32_t t = t0 + 4u * tid;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (t < tiles_pad) v = row[t / 4u];
+        if (t + 0 >= tiles) v.x = 0u;
+        if (t + 1 >= tiles) v.y = 0u;
+        if (t + 2 >= tiles) v.z = 0u;
+        if (t + 3 >= tiles) v.w = 0u;
+        uint32_t chunk_total;
+        const uint32_t before = carry + block_exclusive_sum(v.x + v.y + v.z + v.w, s_scan, tid, &chunk_total);
+        if (t < tiles_pad) row[t / 4u] = make_uint4(before, before + v.x, before + v.x + v.y, before + v.x + v.y + v.z);
+        carry += chunk_total;
+    }
+    if (tid == 0) totals[blockIdx.x] = carry;
+}
+
+// ------------------------------------------------------------------------------------------------
+// scatter.  kIota: payloads are the item indices (first pass of the depth sort: no payload read).
 // kKeysOut: false on a last pass whose sorted keys nobody reads.
 // ------------------------------------------------------------------------------------------------
-template <int kThreads, int kItems, int kBatch, bool kIota, bool kKeysOut>
-__global__ void __launch_bounds__(kThreads) radix_pass_kernel(const uint32_t* __restrict__ keys_in,
-                                                             const uint32_t* __restrict__ vals_in,
-                                                             uint32_t* __restrict__ keys_out,
-                                                             uint32_t* __restrict__ vals_out, uint32_t n, int shift,
-                                                             uint32_t digit_mask, const uint32_t* __restrict__ hist,
-                                                             uint32_t* __restrict__ states,
-                                                             uint32_t* __restrict__ ticket) {
-    constexpr int kTileItems = kThreads * kItems;
-    constexpr int kWaves = kThreads / 64;
-    static_assert(kThreads >= 256 && kThreads % 64 == 0, "one lane per digit");
+template <bool kIota, bool kKeysOut>
+__global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
+                                                                const uint32_t* __restrict__ vals_in,
+                                                                uint32_t* __restrict__ keys_out,
+                                                                uint32_t* __restrict__ vals_out, uint32_t n, int shift,
+                                                                uint32_t digit_mask, const uint32_t* __restrict__ offsets,
+                                                                uint32_t tiles_pad, const uint32_t* __restrict__ totals) {
     __shared__ uint32_t s_keys[kTileItems];
     __shared__ uint32_t s_vals[kTileItems];
     __shared__ uint32_t s_count[kWaves][256];  // per-wave digit counts, then per-wave offsets inside the segment
     __shared__ uint32_t s_seg_start[256];      // first in-tile position of each digit segment
     __shared__ uint32_t s_dst_base[256];       // global position of the segment minus s_seg_start (mod 2^32)
-    __shared__ uint32_t s_scan[4];
-    __shared__ uint32_t s_ticket;
+    __shared__ uint32_t s_scan[kWaves];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_ticket = atomicAdd(ticket, 1u);
-    for (int i = tid; i < kWaves * 256; i += kThreads) (&s_count[0][0])[i] = 0u;
-    __syncthreads();
-    const uint32_t block = s_ticket;
+    const uint32_t block = blockIdx.x;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) s_count[w][tid] = 0u;
     const uint32_t tile_base = block * (uint32_t)kTileItems;
     const uint32_t tile_n = min((uint32_t)kTileItems, n - tile_base);
     GSR_TRACE(0);
 
-    // 1. load (wave-striped)
+    // 1. load (wave-striped); the tile's global digit offsets ride along
     uint32_t key[kItems], val[kItems];
     const uint32_t first = (uint32_t)wave * (64u * kItems) + (uint32_t)lane;
 #pragma unroll
@@ -152,6 +170,9 @@ __global__ void __launch_bounds__(kThreads) radix_pass_kernel(const uint32_t* __
         if (kIota) val[i] = tile_base + t;
         else val[i] = t < tile_n ? vals_in[tile_base + t] : 0u;
     }
+    const uint32_t tile_offset = offsets[(size_t)tid * tiles_pad + block];  // keys of digit `tid` in earlier tiles
+    const uint32_t digit_total = totals[tid];
+    __syncthreads();
 
     // 2. stable rank inside the wave
     uint32_t rank[kItems];
@@ -175,57 +196,22 @@ __global__ void __launch_bounds__(kThreads) radix_pass_kernel(const uint32_t* __
     __syncthreads();
     GSR_TRACE(1);
 
-    // 3. digit d is lane d's from here on (lanes 256.. of a larger workgroup idle through steps 3 and 4)
+    // 3. digit d is lane d's from here on
     uint32_t total = 0;
-    if (tid < 256) {
 #pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-            const uint32_t c = s_count[w][tid];
-            s_count[w][tid] = total;
-            total += c;
-        }
+    for (int w = 0; w < kWaves; ++w) {
+        const uint32_t c = s_count[w][tid];
+        s_count[w][tid] = total;
+        total += c;
     }
-    const uint32_t seg_start = digits_exclusive_sum(total, s_scan, tid);
-    const uint32_t digit_start = digits_exclusive_sum(tid < 256 ? hist[tid] : 0u, s_scan, tid);  // global start of the digit
+    const uint32_t seg_start = block_exclusive_sum(total, s_scan, tid);
+    const uint32_t digit_start = block_exclusive_sum(digit_total, s_scan, tid);  // keys with a smaller digit
+    s_seg_start[tid] = seg_start;
+    s_dst_base[tid] = digit_start + tile_offset - seg_start;
+    __syncthreads();
     GSR_TRACE(2);
 
-    // 4. decoupled look-back over this digit's words
-    if (tid < 256) {
-        uint32_t* mine = states + (size_t)block * 256u + tid;
-        uint32_t earlier = 0;
-        if (block == 0u) {
-            store_state(mine, kPrefix | total);
-        } else {
-            store_state(mine, kAggregate | total);
-            int p = (int)block - 1;
-            bool found = false;
-            while (!found) {
-                uint32_t s[kBatch];
-#pragma unroll
-                for (int j = 0; j < kBatch; ++j)
-                    s[j] = p - j >= 0 ? load_state(states + (size_t)(p - j) * 256u + tid) : kPrefix;
-#pragma unroll
-                for (int j = 0; j < kBatch; ++j) {
-                    if (!found) {
-                        while ((s[j] >> 30) == 0u) {
-                            __builtin_amdgcn_s_sleep(1);
-                            s[j] = load_state(states + (size_t)(p - j) * 256u + tid);
-                        }
-                        earlier += s[j] & kCountMask;
-                        found = (s[j] >> 30) == 2u;
-                    }
-                }
-                p -= kBatch;
-            }
-            store_state(mine, kPrefix | (earlier + total));
-        }
-        s_seg_start[tid] = seg_start;
-        s_dst_base[tid] = digit_start + earlier - seg_start;
-    }
-    __syncthreads();
-    GSR_TRACE(3);
-
-    // 5. park in tile order, then stream out
+    // 4. park in tile order, then stream out
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
         if (first + 64u * i < tile_n) {
@@ -236,6 +222,7 @@ __global__ void __launch_bounds__(kThreads) radix_pass_kernel(const uint32_t* __
         }
     }
     __syncthreads();
+    GSR_TRACE(3);
 #pragma unroll
     for (int j = 0; j < kItems; ++j) {
         const uint32_t p = (uint32_t)(j * kThreads + tid);
@@ -249,26 +236,36 @@ __global__ void __launch_bounds__(kThreads) radix_pass_kernel(const uint32_t* __
     GSR_TRACE(4);
 }
 
-template <int kThreads, int kItems, int kBatch>
-hipError_t run_passes(const RadixScratch& scratch, uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt, uint32_t* vals,
-                      uint32_t* vals_alt, bool iota_payload, bool want_sorted_keys, uint32_t** keys_sorted,
-                      uint32_t** vals_sorted, hipStream_t stream) {
-    constexpr uint32_t kTileItems = kThreads * kItems;
-    static_assert(kTileItems >= kRadixTile, "gsr_internal.h sizes the look-back words with kRadixTile");
+} // namespace
+
+size_t radix_scratch_words(uint32_t n) {
+    const size_t tiles = ((size_t)n + kTileItems - 1) / kTileItems;
+    return 256u * ((tiles + 3u) & ~(size_t)3u) + 256u;  // per-digit rows of tile counts, then the digit totals
+}
+
+hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt,
+                            uint32_t* vals, uint32_t* vals_alt, bool iota_payload, bool want_sorted_keys,
+                            uint32_t** keys_sorted, uint32_t** vals_sorted, hipStream_t stream) {
+    *keys_sorted = keys;
+    *vals_sorted = vals;
+    if (n == 0 || bits <= 0) return hipSuccess;
+    if (bits > 32) return hipErrorInvalidValue;
     const int passes = (bits + 7) / 8;
-    const uint32_t blocks = (n + kTileItems - 1) / kTileItems;
+    const uint32_t tiles = (n + kTileItems - 1) / kTileItems;
+    const uint32_t tiles_pad = (tiles + 3u) & ~3u;
+    uint32_t* counts = scratch;
+    uint32_t* totals = scratch + (size_t)256u * tiles_pad;
     uint32_t *kin = keys, *kout = keys_alt, *vin = vals, *vout = vals_alt;
     for (int p = 0; p < passes; ++p) {
         const int width = bits - 8 * p < 8 ? bits - 8 * p : 8;
         const uint32_t mask = (1u << width) - 1u;
-        const uint32_t* hist = scratch.hist + 256 * p;
-        uint32_t* states = scratch.states + (size_t)blocks * 256u * p;
-        uint32_t* ticket = scratch.tickets + p;
         const bool iota = iota_payload && p == 0;
         const bool keys_out = want_sorted_keys || p + 1 < passes;
-#define GSR_RADIX_LAUNCH(I, K)                                                                                  \
-    hipLaunchKernelGGL((radix_pass_kernel<kThreads, kItems, kBatch, I, K>), dim3(blocks), dim3(kThreads), 0, stream, \
-                       kin, vin, kout, vout, n, 8 * p, mask, hist, states, ticket)
+        hipLaunchKernelGGL(radix_count_kernel, dim3(tiles), dim3(kThreads), 0, stream, kin, n, 8 * p, mask, counts, tiles_pad);
+        hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(kThreads), 0, stream, counts, tiles, tiles_pad, totals);
+#define GSR_RADIX_LAUNCH(I, K)                                                                                    \
+    hipLaunchKernelGGL((radix_scatter_kernel<I, K>), dim3(tiles), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, \
+                       8 * p, mask, counts, tiles_pad, totals)
         if (iota && keys_out) GSR_RADIX_LAUNCH(true, true);
         else if (iota) GSR_RADIX_LAUNCH(true, false);
         else if (keys_out) GSR_RADIX_LAUNCH(false, true);
@@ -280,43 +277,6 @@ hipError_t run_passes(const RadixScratch& scratch, uint32_t n, int bits, uint32_
     *keys_sorted = kin;
     *vals_sorted = vin;
     return hipGetLastError();
-}
-
-} // namespace
-
-int g_radix_config = 0;  // tuning knob (scripts/ubench/radix_trace.hip): workgroup shape / look-back batch
-
-size_t radix_state_words(uint32_t n, int bits) {
-    const size_t blocks = ((size_t)n + kRadixTile - 1) / kRadixTile;
-    const size_t passes = (size_t)((bits + 7) / 8);
-    return blocks * 256u * passes;
-}
-
-hipError_t radix_sort_pairs(const RadixScratch& scratch, uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt,
-                            uint32_t* vals, uint32_t* vals_alt, bool iota_payload, bool want_sorted_keys,
-                            uint32_t** keys_sorted, uint32_t** vals_sorted, hipStream_t stream) {
-    *keys_sorted = keys;
-    *vals_sorted = vals;
-    if (n == 0 || bits <= 0) return hipSuccess;
-    if (n > kCountMask || bits > 32) return hipErrorInvalidValue;
-    const int passes = (bits + 7) / 8;
-    const uint32_t hist_blocks = (n / 4u + kHistThreads * 4 - 1) / (kHistThreads * 4) + 1u;
-    hipLaunchKernelGGL(radix_histogram_kernel, dim3(hist_blocks < 1024u ? hist_blocks : 1024u), dim3(kHistThreads), 0,
-                       stream, keys, n, passes, bits, scratch.hist, scratch.states,
-                       (uint32_t)radix_state_words(n, bits) + scratch.extra_zero_words);
-#define GSR_RADIX_RUN(T, I, B) \
-    run_passes<T, I, B>(scratch, n, bits, keys, keys_alt, vals, vals_alt, iota_payload, want_sorted_keys, keys_sorted, vals_sorted, stream)
-    switch (g_radix_config) {
-        case 1: return GSR_RADIX_RUN(256, 16, 16);
-        case 2: return GSR_RADIX_RUN(512, 8, 16);
-        case 3: return GSR_RADIX_RUN(1024, 4, 16);
-        case 4: return GSR_RADIX_RUN(512, 16, 16);
-        case 5: return GSR_RADIX_RUN(1024, 8, 16);
-        case 6: return GSR_RADIX_RUN(256, 8, 16);
-        case 7: return GSR_RADIX_RUN(1024, 8, 4);
-        default: return GSR_RADIX_RUN(256, 16, 4);
-    }
-#undef GSR_RADIX_RUN
 }
 
 } // namespace gsr

@@ -1,0 +1,58 @@
+"""Per-workgroup phase timing of an instrumented kernel (libgsr_hip_trace.so, GSR_KERNEL_TRACE).
+
+    python -m autovfx_amd.build --trace
+    GSR_LIB=autovfx_amd/lib/libgsr_hip_trace.so python scripts/kernel_trace.py [--workload c3] [--slots 4]
+
+Renders a few frames of the bench workload, arms the trace buffer, renders one more and prints, for the
+workgroups that stamped slot 0: start-time quantiles, the kernel's span and the mean time between stamps.
+Which kernel is instrumented is decided in the source (GSR_KTRACE calls); one kernel at a time.
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c3")
+    ap.add_argument("--slots", type=int, default=4)
+    ap.add_argument("--records", type=int, default=1 << 16)
+    args = ap.parse_args()
+    from autovfx_amd import _lib, scenes
+    from autovfx_amd.cameras import orbit_cameras
+    from autovfx_amd.frame_parallel import rasterize
+    import bench
+    wl = bench.WORKLOADS[args.workload]
+    cloud = getattr(scenes, wl["cfg"])().to("cuda")
+    cam = orbit_cameras(wl["frames"], wl["width"], wl["height"])[0].to("cuda")
+    bg = torch.zeros(3, device="cuda")
+    for _ in range(3):
+        rasterize(cloud, cam, bg)
+    torch.cuda.synchronize()
+    trace = torch.zeros(args.records * 8, dtype=torch.int64, device="cuda")
+    _lib.lib.gsr_debug_set_trace.argtypes = [ctypes.c_void_p]
+    assert _lib.lib.gsr_debug_set_trace(trace.data_ptr()) == 0
+    rasterize(cloud, cam, bg)
+    torch.cuda.synchronize()
+    _lib.lib.gsr_debug_set_trace(None)
+    t = trace.cpu().numpy().reshape(-1, 8).astype(np.float64)
+    t = t[t[:, 0] > 0][:, :args.slots] * 0.01          # 100 MHz -> microseconds
+    t0 = t[:, 0].min()
+    q = [0, 25, 50, 75, 100]
+    print(f"workgroups {len(t)}  span {t.max() - t0:.1f} us")
+    print("start quantiles (by record index) us:", " ".join(f"{t[(len(t) - 1) * p // 100, 0] - t0:.1f}" for p in q))
+    for k in range(args.slots - 1):
+        d = t[:, k + 1] - t[:, k]
+        print(f"phase {k}->{k + 1}: mean {d.mean():.2f} us  p50 {np.median(d):.2f}  p95 {np.percentile(d, 95):.2f}  max {d.max():.2f}")
+    life = t[:, args.slots - 1] - t[:, 0]
+    print(f"workgroup life: mean {life.mean():.2f} us  max {life.max():.2f}")
+
+
+if __name__ == "__main__":
+    main()

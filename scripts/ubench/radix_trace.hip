@@ -23,52 +23,53 @@ int main(int argc, char** argv) {
     }
     uint32_t *ka, *kb, *va, *vb, *scratch;
     unsigned long long* trace;
-    const size_t words = 4 * 256 + 16 + gsr::radix_state_words(n, bits);
     CK(hipMalloc(&ka, n * 4)); CK(hipMalloc(&kb, n * 4)); CK(hipMalloc(&va, n * 4)); CK(hipMalloc(&vb, n * 4));
-    CK(hipMalloc(&scratch, words * 4));
+    CK(hipMalloc(&scratch, gsr::radix_scratch_words(n) * 4));
     const size_t trace_words = (size_t)(n / 2048 + 2) * 8;
     CK(hipMalloc(&trace, trace_words * 8));
-    hipEvent_t e0, e1, e2;
-    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
-    for (int cfg = 0; cfg <= 7; ++cfg) {
-        gsr::g_radix_config = cfg;
-        float best_total = 1e9f, best_hist = 0.f;
-        for (int rep = 0; rep < 6; ++rep) {
-            CK(hipMemcpy(ka, h.data(), n * 4, hipMemcpyHostToDevice));
-            CK(hipMemset(scratch, 0, (4 * 256 + 16) * 4));
-            CK(hipMemset(trace, 0, trace_words * 8));
-            unsigned long long* tp = rep == 5 ? trace : nullptr;
-            CK(hipMemcpyToSymbol(HIP_SYMBOL(gsr::g_radix_trace), &tp, sizeof tp));
-            gsr::RadixScratch rs{scratch, scratch + 1024, scratch + 1040, 0};
-            uint32_t *ks, *vs;
-            CK(hipEventRecord(e0));
-            CK(gsr::radix_sort_pairs(rs, n, bits, ka, kb, va, vb, true, true, &ks, &vs, 0));
-            CK(hipEventRecord(e1));
-            CK(hipDeviceSynchronize());
-            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            if (rep < 5) best_total = std::min(best_total, ms);
-            (void)best_hist;
-        }
-        // the traced run was a full sort: the trace holds the LAST pass (each pass overwrites the slots)
-        std::vector<unsigned long long> t(trace_words);
-        CK(hipMemcpy(t.data(), trace, trace_words * 8, hipMemcpyDeviceToHost));
-        unsigned long long t0 = ~0ull, t_end = 0; size_t blocks = 0;
-        double ph[4] = {0, 0, 0, 0};
-        for (size_t b = 0; b * 8 + 4 < trace_words; ++b) {
-            const unsigned long long* r = &t[b * 8];
-            if (!r[0] || !r[4]) continue;
-            ++blocks; t0 = std::min(t0, r[0]); t_end = std::max(t_end, r[4]);
-            for (int k = 0; k < 4; ++k) ph[k] += (double)(r[k + 1] - r[k]) * 0.01;  // us
-        }
-        {   // start time of the workgroup holding ticket q * blocks: is the ticket counter the throttle?
-            printf("   starts(us) at ticket 0/25/50/75/100%%:");
-            for (int q = 0; q <= 4; ++q) { size_t b = (blocks - 1) * q / 4; printf(" %.1f", (double)(t[b * 8] - t0) * 0.01); }
-            printf("\n");
-        }
-        printf("cfg %d n=%u bits=%d: sort %.1f us (%d passes) | last pass: %zu wgs, span %.1f us, mean phase us: load+rank %.1f scan %.1f lookback %.1f park+write %.1f\n",
-               cfg, n, bits, best_total * 1e3, (bits + 7) / 8, blocks, (double)(t_end - t0) * 0.01, ph[0] / blocks,
-               ph[1] / blocks, ph[2] / blocks, ph[3] / blocks);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best_total = 1e9f;
+    uint32_t *ks = nullptr, *vs = nullptr;
+    for (int rep = 0; rep < 6; ++rep) {
+        CK(hipMemcpy(ka, h.data(), n * 4, hipMemcpyHostToDevice));
+        CK(hipMemset(trace, 0, trace_words * 8));
+        unsigned long long* tp = rep == 5 ? trace : nullptr;
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(gsr::g_radix_trace), &tp, sizeof tp));
+        CK(hipEventRecord(e0));
+        CK(gsr::radix_sort_pairs(scratch, n, bits, ka, kb, va, vb, true, true, &ks, &vs, 0));
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep < 5) best_total = std::min(best_total, ms);
     }
-    // verify the last configuration's result on the host
-    return 0;
+    // the traced run was a full sort: the trace holds the LAST pass (each pass overwrites the slots)
+    std::vector<unsigned long long> t(trace_words);
+    CK(hipMemcpy(t.data(), trace, trace_words * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull, t_end = 0; size_t blocks = 0;
+    double ph[4] = {0, 0, 0, 0};
+    for (size_t b = 0; b * 8 + 4 < trace_words; ++b) {
+        const unsigned long long* r = &t[b * 8];
+        if (!r[0] || !r[4]) continue;
+        ++blocks; t0 = std::min(t0, r[0]); t_end = std::max(t_end, r[4]);
+        for (int k = 0; k < 4; ++k) ph[k] += (double)(r[k + 1] - r[k]) * 0.01;  // us
+    }
+    printf("   starts(us) of workgroup 0/25/50/75/100%%:");
+    for (int q = 0; q <= 4; ++q) { size_t b = (blocks - 1) * q / 4; printf(" %.1f", (double)(t[b * 8] - t0) * 0.01); }
+    printf("\n");
+    printf("n=%u bits=%d: sort %.1f us (%d passes) | last scatter: %zu wgs, span %.1f us, mean phase us: load+rank %.1f scans %.1f park %.1f write %.1f\n",
+           n, bits, best_total * 1e3, (bits + 7) / 8, blocks, (double)(t_end - t0) * 0.01, ph[0] / blocks, ph[1] / blocks,
+           ph[2] / blocks, ph[3] / blocks);
+    // check against the host
+    std::vector<uint32_t> gk(n), gv(n);
+    CK(hipMemcpy(gk.data(), ks, n * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(gv.data(), vs, n * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> idx(n);
+    for (uint32_t i = 0; i < n; ++i) idx[i] = i;
+    const uint32_t keep = bits >= 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u);
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return (h[a] & keep) < (h[b] & keep); });
+    size_t bad = 0;
+    for (uint32_t i = 0; i < n; ++i) bad += gv[i] != idx[i] || gk[i] != h[idx[i]];
+    printf("host check: %zu mismatches\n", bad);
+    return bad != 0;
 }
