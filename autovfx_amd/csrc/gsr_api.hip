@@ -285,6 +285,13 @@ int gsr_radix_sort_pairs(uint32_t n, int bits, uint32_t* keys, uint32_t* keys_al
     return GSR_OK;
 }
 
+int gsr_selftest_exp(uint32_t first_bits, uint32_t count, unsigned long long* device_mismatches, void* stream_) {
+    if (!device_mismatches || count > 0x7FFFFFFFu) return fail(GSR_ERR_INVALID_ARG, "bad selftest arguments");
+    if (count == 0) return GSR_OK;
+    GSR_HIP(gsr::launch_exp_selftest(first_bits, count, device_mismatches, (hipStream_t)stream_));
+    return GSR_OK;
+}
+
 int gsr_pack_rgba8(const float* color, const float* alpha, uint8_t* rgba8, int width, int height, void* stream_) {
     if (width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARG, "bad image size %dx%d", width, height);
     if (!color || !alpha || !rgba8) return fail(GSR_ERR_INVALID_ARG, "null pointer");

@@ -86,6 +86,8 @@ hipError_t launch_duplicate(int P, const Camera& cam, const uint32_t* depth_orde
 hipError_t launch_scan_expand(int P, int V, uint32_t num_pairs, const Camera& cam, const uint32_t* depth_order,
                               const SplatBin* bins, uint4* sorted_bins, uint32_t* tile_totals, uint32_t* point_offsets,
                               uint32_t* tile_keys, uint32_t* point_list, hipStream_t stream);
+// counts the floats with bit patterns first_bits .. first_bits + count - 1 on which the blend's exp differs from expf
+hipError_t launch_exp_selftest(uint32_t first_bits, uint32_t count, unsigned long long* mismatches, hipStream_t stream);
 hipError_t launch_tile_ranges(uint32_t num_rendered, int num_tiles, const uint32_t* sorted_tile_keys,
                               uint2* ranges, hipStream_t stream);
 // variant 0: one wave per tile, 4 pixels per lane; variant 1: one wave per 8x8 quadrant

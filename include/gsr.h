@@ -136,6 +136,11 @@ GSR_API int gsr_radix_sort_pairs(uint32_t n, int bits, uint32_t* keys, uint32_t*
                                  uint32_t* vals_alt, int iota_payload, void* scratch, size_t scratch_bytes,
                                  int* sorted_in_alt, void* stream);
 
+/* Self-test of the blend kernel's exp(): adds to *device_mismatches (a zeroed device u64) the number of floats
+ * with bit patterns first_bits .. first_bits + count - 1 whose exp differs from the device library's expf.
+ * The blend evaluates exp only for arguments <= 0; tests sweep every float of [-103, 0]. */
+GSR_API int gsr_selftest_exp(uint32_t first_bits, uint32_t count, unsigned long long* device_mismatches, void* stream);
+
 /*
  * Backward rasterization: gradients of a gsr_forward call.  Mirrors Rasterizer::backward
  * (rasterizer.h:57-90, rasterizer_impl.cu:343-446) as called by RasterizeGaussiansBackwardCUDA

@@ -616,3 +616,26 @@ def test_randomised_configurations(seed):
         run_both(f"rand{seed}", cloud, cam, **kw)
     finally:
         _lib.set_option(_lib.OPT_BLEND_VARIANT, 1)
+
+
+def test_blend_exp_is_expf_on_its_domain():
+    """The blend's exp (the device library's expf without its range clamps) against expf on every float of
+    [-103, -0.0] and on +0.0: bit-identical.  The blend only evaluates it for skip_below <= power <= 0 with
+    skip_below = -ln(255 * opacity) >= -94.3 for any finite opacity (and for an infinite one alpha is 0.99
+    whatever exp returns), so this covers every argument that can influence a pixel."""
+    import ctypes
+    import struct
+    from autovfx_amd import _lib
+    bad = torch.zeros(1, dtype=torch.int64, device="cuda")
+    lo = struct.unpack("<I", struct.pack("<f", -0.0))[0]      # 0x80000000: negative floats ascend in magnitude
+    hi = struct.unpack("<I", struct.pack("<f", -103.0))[0]
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    first, left = lo, hi - lo + 1
+    while left > 0:
+        n = min(left, 1 << 30)
+        assert _lib.lib.gsr_selftest_exp(first, n, bad.data_ptr(), stream) == 0, _lib.last_error()
+        first += n
+        left -= n
+    assert _lib.lib.gsr_selftest_exp(0, 1, bad.data_ptr(), stream) == 0
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0
