@@ -493,14 +493,10 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
         stamp(5, stream);
         tile_keys = tk_sorted;
         point_list = pl_sorted;
-        GSR_HIP(gsr::launch_tile_ranges(num_live, T, tile_keys, ranges, stream));
     } else {
         stamp(4, stream);
         stamp(5, stream);
-        GSR_HIP(hipMemsetAsync(ranges, 0, (size_t)T * sizeof(uint2), stream));  // rasterizer_impl.cu:311
     }
-    GSR_STAGE_CHECK("tile_ranges");
-    stamp(6, stream);
     g_bin_off[GSR_BIN_POINT_LIST] = (size_t)((char*)point_list - braw);
     g_bin_off[GSR_BIN_TILE_KEYS] = (size_t)((char*)tile_keys - braw);
 
@@ -519,7 +515,10 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
         hi.off[1] = (uint64_t)((char*)n_contrib - ibase);
         const gsr::ArenaHeader hs[3] = {hg, hb, hi};
         void* const dsts[3] = {gbase, bbase, ibase};
-        GSR_HIP(gsr::launch_write_headers(dsts, hs, stream));
+        // tile ranges (all (0,0) when nothing is live: rasterizer_impl.cu:311) + the three headers, one launch
+        GSR_HIP(gsr::launch_tile_ranges(num_live, T, tile_keys, ranges, dsts, hs, stream));
+        GSR_STAGE_CHECK("tile_ranges");
+        stamp(6, stream);
     }
 
     const float* features = colors_precomp != nullptr ? colors_precomp : ga.rgb;

@@ -88,8 +88,11 @@ hipError_t launch_scan_expand(int P, int V, uint32_t num_pairs, const Camera& ca
                               uint32_t* tile_keys, uint32_t* point_list, hipStream_t stream);
 // counts the floats with bit patterns first_bits .. first_bits + count - 1 on which the blend's exp differs from expf
 hipError_t launch_exp_selftest(uint32_t first_bits, uint32_t count, unsigned long long* mismatches, hipStream_t stream);
-hipError_t launch_tile_ranges(uint32_t num_rendered, int num_tiles, const uint32_t* sorted_tile_keys,
-                              uint2* ranges, hipStream_t stream);
+struct ArenaHeader;
+// ranges[t] = [first, last) positions of tile t in the sorted keys ((0,0) when empty; num_rendered = 0 clears them all);
+// also stamps the three arena headers.
+hipError_t launch_tile_ranges(uint32_t num_rendered, int num_tiles, const uint32_t* sorted_tile_keys, uint2* ranges,
+                              void* const header_dst[3], const ArenaHeader headers[3], hipStream_t stream);
 // variant 0: one wave per tile, 4 pixels per lane; variant 1: one wave per 8x8 quadrant
 hipError_t launch_blend(const Camera& cam, int variant, int lds_pad_bytes, const uint2* ranges, const uint32_t* point_list,
                         const SplatRaster* raster, const float* features, const float* background, float* out_color,
@@ -106,7 +109,6 @@ struct ArenaHeader {
     uint32_t pad[2];
     uint64_t off[8];    // byte offsets from the header's own address
 };
-hipError_t launch_write_headers(void* const dst[3], const ArenaHeader h[3], hipStream_t stream);
 
 struct BackwardInputs {
     int P, sh_degree, M;

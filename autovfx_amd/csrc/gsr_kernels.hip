@@ -648,9 +648,13 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__
     return lo;
 }
 
+struct ArenaHeaders3 { ArenaHeader h[3]; void* dst[3]; };
+
 __global__ void __launch_bounds__(256) tile_ranges_kernel(uint32_t n, int num_tiles,
                                                           const uint32_t* __restrict__ keys,
-                                                          uint2* __restrict__ ranges) {
+                                                          uint2* __restrict__ ranges, ArenaHeaders3 headers) {
+    // the three arena headers ride along (one launch less per call)
+    if (blockIdx.x == 0 && threadIdx.x < 3) *reinterpret_cast<ArenaHeader*>(headers.dst[threadIdx.x]) = headers.h[threadIdx.x];
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= num_tiles) return;
     const uint32_t b = lower_bound_u32(keys, n, (uint32_t)t);
@@ -678,6 +682,13 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(uint32_t n, int num_ti
 struct BlendEntryA { float x, y, cxx, cxy; };       // ds_read_b128
 struct BlendEntryB { float cyy, skip_below; };      // ds_read_b64
 struct BlendEntryC { float opacity, r, g, b; };     // ds_read_b128, contributing pairs only
+// One 48-byte LDS record per staged list entry (quadrant kernel): a single address register serves the three
+// 16-byte broadcast reads, and (r, g) / (b, z) land in even-aligned register pairs for the packed-fp32 updates.
+struct BlendEntry {
+    float x, y, cxx, cxy;               // every processed entry
+    float cyy, skip_below, opacity, pad;
+    float r, g, b, z;                   // contributing entries only
+};
 
 __device__ __forceinline__ int xcd_band_tile(int b, int T) {
     // Blocks are dealt round-robin to the 8 XCDs (block b -> XCD b % 8).  Give each XCD a contiguous
@@ -856,10 +867,7 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
                                                             float* __restrict__ out_depth,
                                                             float* __restrict__ out_alpha,
                                                             uint32_t* __restrict__ n_contrib) {
-    __shared__ BlendEntryA sA[64];
-    __shared__ BlendEntryB sB[64];
-    __shared__ BlendEntryC sC[64];
-    __shared__ float sD[64];
+    __shared__ BlendEntry s_entry[64];
 
     constexpr int kQ = kTile / 2;
     const int item = xcd_band_tile(blockIdx.x, 4 * num_tiles);  // the 4 quadrants of a tile share an XCD
@@ -881,6 +889,7 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
 
     const uint2 range = ranges[tile];
     const uint32_t count = range.y - range.x;
+    GSR_KTRACE(blockIdx.x, 0);
 
     float2 g_xy = make_float2(0.f, 0.f);
     float4 g_co = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -905,10 +914,10 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
         unsigned long long todo = __ballot(mine && splat_reaches_rect(g_co, g_xy, qx0, qy0, kQ, kQ));
         if (todo != 0ull) {
             __syncthreads();  // single-wave workgroup: orders this wave's LDS reads / writes only
-            sA[lane] = BlendEntryA{g_xy.x, g_xy.y, g_co.x, g_co.y};
-            sB[lane] = BlendEntryB{g_co.z, -logf(255.0f * g_co.w) - 1.0e-4f};
-            sC[lane] = BlendEntryC{g_co.w, g_rgb.x, g_rgb.y, g_rgb.z};
-            sD[lane] = g_z;
+            float4* rec = reinterpret_cast<float4*>(&s_entry[lane]);
+            rec[0] = make_float4(g_xy.x, g_xy.y, g_co.x, g_co.y);
+            rec[1] = make_float4(g_co.z, -logf(255.0f * g_co.w) - 1.0e-4f, g_co.w, 0.f);
+            rec[2] = make_float4(g_rgb.x, g_rgb.y, g_rgb.z, g_z);
             __syncthreads();
         }
         if (first + 64 < count) gather(first + 64);
@@ -916,8 +925,10 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
         while (todo != 0ull) {
             const int j = __builtin_ctzll(todo);
             todo &= todo - 1ull;
-            const BlendEntryA a = sA[j];
-            const BlendEntryB b = sB[j];
+            const float4* rec = reinterpret_cast<const float4*>(&s_entry[j]);
+            const float4 ra = rec[0], rb = rec[1];
+            struct { float x, y, cxx, cxy; } a = {ra.x, ra.y, ra.z, ra.w};
+            struct { float cyy, skip_below, opacity; } b = {rb.x, rb.y, rb.z};
             // One list entry against this lane's pixel: forward.cu:331-364, unchanged arithmetic.
             const float dx = a.x - fx, dy = a.y - fy;
             const float power = -0.5f * (a.cxx * dx * dx + b.cyy * dy * dy) - a.cxy * dx * dy;
@@ -927,8 +938,7 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
             // From here every lane computes (a vector instruction costs the same with 1 or 64 lanes enabled);
             // the outcome of a lane that is not live is masked out below.  All masks stay wave-uniform scalars
             // because they are only combined in uniform control flow.
-            const BlendEntryC c = sC[j];
-            const float alpha = fminf(0.99f, c.opacity * exp_nonpositive(power));
+            const float alpha = fminf(0.99f, b.opacity * exp_nonpositive(power));
             const unsigned long long blends = live & __ballot(!(alpha < 1.0f / 255.0f));
             if (blends == 0ull) continue;
             const float test_T = T * (1.f - alpha);
@@ -936,11 +946,11 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
             done_mask |= stops;
             const unsigned long long adds = blends & ~stops;
             if (adds != 0ull && __builtin_amdgcn_inverse_ballot_w64(adds)) {
-                const float z = sD[j];
-                Cr += c.r * alpha * T;
-                Cg += c.g * alpha * T;
-                Cb += c.b * alpha * T;
-                Dz += z * alpha * T;
+                const float4 c = rec[2];  // r g b z
+                Cr += c.x * alpha * T;
+                Cg += c.y * alpha * T;
+                Cb += c.z * alpha * T;
+                Dz += c.w * alpha * T;
                 T = test_T;
                 last = first + (uint32_t)j + 1u;
             }
@@ -949,6 +959,10 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
         if (done_mask == ~0ull) break;
     }
 
+#ifdef GSR_KERNEL_TRACE
+    GSR_KTRACE(blockIdx.x, 1);
+    if (threadIdx.x == 0 && g_kernel_trace) g_kernel_trace[(size_t)blockIdx.x * 8 + 2] = count;
+#endif
     if (inside) {
         const size_t plane = (size_t)W * (size_t)H;
         const size_t pid = (size_t)W * (size_t)py + (size_t)px;
@@ -1579,22 +1593,12 @@ hipError_t launch_exp_selftest(uint32_t first_bits, uint32_t count, unsigned lon
     return hipGetLastError();
 }
 
-hipError_t launch_tile_ranges(uint32_t num_rendered, int num_tiles, const uint32_t* sorted_tile_keys,
-                              uint2* ranges, hipStream_t stream) {
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(div_up(num_tiles, 256)), dim3(256), 0, stream, num_rendered,
-                       num_tiles, sorted_tile_keys, ranges);
-    return hipGetLastError();
-}
-
-struct ArenaHeaders3 { ArenaHeader h[3]; void* dst[3]; };
-__global__ void write_headers_kernel(ArenaHeaders3 a) {
-    if (threadIdx.x < 3) *reinterpret_cast<ArenaHeader*>(a.dst[threadIdx.x]) = a.h[threadIdx.x];
-}
-
-hipError_t launch_write_headers(void* const dst[3], const ArenaHeader h[3], hipStream_t stream) {
+hipError_t launch_tile_ranges(uint32_t num_rendered, int num_tiles, const uint32_t* sorted_tile_keys, uint2* ranges,
+                              void* const header_dst[3], const ArenaHeader headers[3], hipStream_t stream) {
     ArenaHeaders3 a;
-    for (int i = 0; i < 3; ++i) { a.h[i] = h[i]; a.dst[i] = dst[i]; }
-    hipLaunchKernelGGL(write_headers_kernel, dim3(1), dim3(64), 0, stream, a);
+    for (int i = 0; i < 3; ++i) { a.h[i] = headers[i]; a.dst[i] = header_dst[i]; }
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(div_up(num_tiles, 256)), dim3(256), 0, stream, num_rendered,
+                       num_tiles, sorted_tile_keys, ranges, a);
     return hipGetLastError();
 }
 

@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--gaussians", type=int, default=0, help="override P (parity/debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the final RCCL gather (N > 1)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="render frames on this many HIP streams (one host thread each) so independent frames overlap")
     ap.add_argument("--boundary", choices=["op", "render"], default="op",
                     help="op: one GaussianRasterizer.forward per frame (the headline); render: the reference's "
