@@ -19,7 +19,7 @@ GEOM_SLOTS = ("raster", "rgb", "splat_bins", "internal_radii", "depth_order", "p
 BIN_SLOTS = ("point_list", "tile_keys")
 IMG_SLOTS = ("ranges", "n_contrib")
 STAGES = ("preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "ranges", "blend")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/gsr.h declares
 SYMBOLS = ("gsr_forward", "gsr_mark_visible", "gsr_backward", "gsr_last_geom_offsets", "gsr_last_binning_offsets",
@@ -83,7 +83,7 @@ def _load() -> ctypes.CDLL:
         c_f, c_f, c_f, c_f,                                    # radii geom binning image
         c_f, c_f, c_f, c_f,                                    # accum_alphas dL_dpix dL_dpix_depth dL_dpix_alpha
         c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f,      # dL_dmean2D conic opacity color depth mean3D cov3D sh scale rot
-        ctypes.c_int, ctypes.c_void_p]                         # debug stream
+        c_f, ctypes.c_int, ctypes.c_void_p]                    # accum_scratch debug stream
     for name, n in (("gsr_last_geom_offsets", len(GEOM_SLOTS)), ("gsr_last_binning_offsets", len(BIN_SLOTS)),
                     ("gsr_last_image_offsets", len(IMG_SLOTS))):
         fn = getattr(lib, name)

@@ -177,14 +177,14 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
                  const char* binning_buffer, const char* image_buffer, const float* accum_alphas, const float* dL_dpix,
                  const float* dL_dpix_depth, const float* dL_dpix_alpha, float* dL_dmean2D, float* dL_dconic,
                  float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D,
-                 float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream_) {
+                 float* dL_dsh, float* dL_dscale, float* dL_drot, float* accum_scratch, int debug, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (P < 0 || width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARG, "bad sizes P=%d W=%d H=%d", P, width, height);
     if (P == 0) return GSR_OK;  // rasterize_points.cu:169: gradients stay as the binding zero-filled them
     if (!geom_buffer || !binning_buffer || !image_buffer) return fail(GSR_ERR_INVALID_ARG, "null scratch buffer");
     if (!means3D || !background || !viewmatrix || !projmatrix || !cam_pos || !accum_alphas || !dL_dpix ||
         !dL_dpix_depth || !dL_dpix_alpha || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_ddepth ||
-        !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)
+        !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot || !accum_scratch)
         return fail(GSR_ERR_INVALID_ARG, "null required pointer");
     if (shs != nullptr && (M <= 0 || !dL_dsh)) return fail(GSR_ERR_INVALID_ARG, "shs given with M=%d or no dL_dsh", M);
     if ((scales != nullptr) != (rotations != nullptr) || (scales != nullptr) == (cov3D_precomp != nullptr))
@@ -220,14 +220,15 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     const uint32_t* n_contrib = (const uint32_t*)(bases[2] + h[2].off[1]);
     const float* colors = colors_precomp != nullptr ? colors_precomp : rgb;  // rasterizer_impl.cu:399
 
-    GSR_HIP(gsr::launch_render_backward(cam, ranges, point_list, background, raster, colors,
-                                        accum_alphas, n_contrib, dL_dpix, dL_dpix_depth, dL_dpix_alpha, dL_dmean2D,
-                                        dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, stream));
+    GSR_HIP(hipMemsetAsync(accum_scratch, 0, (size_t)P * 16 * sizeof(float), stream));
+    GSR_HIP(gsr::launch_render_backward(cam, ranges, point_list, background, raster, colors, accum_alphas, n_contrib,
+                                        dL_dpix, dL_dpix_depth, dL_dpix_alpha, accum_scratch, stream));
     GSR_STAGE_CHECK("render_backward");
     gsr::BackwardInputs b;
     b.P = P; b.sh_degree = D; b.M = M; b.means3D = means3D; b.radii = radii; b.shs = shs; b.scales = scales;
     b.rotations = rotations; b.cov3D_precomp = cov3D_precomp; b.scale_modifier = scale_modifier;
-    b.dL_dmean2D = dL_dmean2D; b.dL_dconic = dL_dconic; b.dL_dcolor = dL_dcolor; b.dL_ddepth = dL_ddepth;
+    b.accum = accum_scratch; b.dL_dmean2D = dL_dmean2D; b.dL_dconic = dL_dconic; b.dL_dopacity = dL_dopacity;
+    b.dL_dcolor = dL_dcolor; b.dL_ddepth = dL_ddepth;
     b.dL_dmean3D = dL_dmean3D; b.dL_dcov3D = dL_dcov3D; b.dL_dsh = dL_dsh; b.dL_dscale = dL_dscale; b.dL_drot = dL_drot;
     GSR_HIP(gsr::launch_preprocess_backward(b, cam, stream));
     GSR_STAGE_CHECK("preprocess_backward");

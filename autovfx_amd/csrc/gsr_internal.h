@@ -119,10 +119,12 @@ struct BackwardInputs {
     const float* rotations;      // nullable
     const float* cov3D_precomp;  // nullable
     float scale_modifier;
-    const float* dL_dmean2D;
-    const float* dL_dconic;
-    const float* dL_dcolor;
-    const float* dL_ddepth;
+    const float* accum;  // [P,16] per-Gaussian sums of the render backward (see launch_render_backward)
+    float* dL_dmean2D;   // the five arrays below are written from accum
+    float* dL_dconic;
+    float* dL_dopacity;
+    float* dL_dcolor;
+    float* dL_ddepth;
     float* dL_dmean3D;
     float* dL_dcov3D;
     float* dL_dsh;
@@ -133,8 +135,8 @@ hipError_t launch_render_backward(const Camera& cam, const uint2* ranges, const 
                                   const float* background, const SplatRaster* raster, const float* colors,
                                   const float* accum_alphas,
                                   const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
-                                  const float* dL_dpix_alpha, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                                  float* dL_dcolors, float* dL_ddepths, hipStream_t stream);
+                                  const float* dL_dpix_alpha, float* accum /*[P,16] floats, zero on entry*/,
+                                  hipStream_t stream);
 hipError_t launch_preprocess_backward(const BackwardInputs& b, const Camera& cam, hipStream_t stream);
 hipError_t launch_composite(int width, int height, const void* bg_c, const void* o_c, const float* o_d,
                             const void* s_c, const float* s_d, const void* o_s_c, const void* o_gs_c,

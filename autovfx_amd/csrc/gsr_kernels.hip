@@ -989,23 +989,37 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
 // so the number of global atomics drops 64x and their order (hence the last bits of the sums) is
 // this library's, not the reference's -- parity for gradients is stated with a tolerance.
 // ================================================================================================
-// Sum over the wave with DPP moves (no LDS traffic); the total is valid in lane 63 only.
-// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_ror:4, row_ror:8, row_bcast:15, row_bcast:31 -- the
-// classic GCN wave64 reduction; lanes without a source (row 0 for the broadcasts) add 0.
+// v + (v moved by a DPP control word): cross-lane add without LDS traffic.
 template <int kCtrl>
 __device__ __forceinline__ float dpp_add(float v) {
     const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), kCtrl, 0xF, 0xF, false);
     return v + __int_as_float(moved);
 }
-__device__ __forceinline__ float wave_sum_in_last_lane(float v) {
-    v = dpp_add<0xB1>(v);
-    v = dpp_add<0x4E>(v);
-    v = dpp_add<0x124>(v);
-    v = dpp_add<0x128>(v);
-    v = dpp_add<0x142>(v);
-    v = dpp_add<0x143>(v);
+
+// Reduce-scatter of ten per-lane values over the wave with gfx950's half-swapping permutes: v_permlane32_swap
+// exchanges the upper 32 lanes of one register with the lower 32 of another, so ONE swap + ONE add folds two
+// values by a factor of two at once (lanes 0-31 then hold partial sums of the first, 32-63 of the second);
+// v_permlane16_swap does the same between odd and even rows of 16.  After the two levels three registers hold
+// the ten values, one per row, and four row-rotating DPP adds finish each: 28 instructions instead of the 60 of
+// ten separate butterfly sums.
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float fold32(float a, float b) {  // -> [sum pairs of a | sum pairs of b]
+    const v2u_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float fold16(float a, float b) {  // rows -> [a r0+r1 | b r0+r1 | a r2+r3 | b r2+r3]
+    const v2u_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float row_sum_all_lanes(float v) {  // every lane of a 16-lane row gets the row's sum
+    v = dpp_add<0x128>(v);  // row_ror:8
+    v = dpp_add<0x124>(v);  // row_ror:4
+    v = dpp_add<0x122>(v);  // row_ror:2
+    v = dpp_add<0x121>(v);  // row_ror:1
     return v;
 }
+constexpr int kAccumStride = 16;  // floats per Gaussian in the accumulation scratch: one 64-byte line
+// slots: 0 r, 1 g, 2 b, 3 depth, 4 mean x, 5 mean y, 6 conic xx, 7 conic xy, 8 conic yy, 9 opacity
 
 __global__ void __launch_bounds__(64, 4) render_backward_kernel(
     int W, int H, int grid_x, int num_tiles, const uint2* __restrict__ ranges,
@@ -1013,8 +1027,7 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
     const SplatRaster* __restrict__ raster, const float* __restrict__ colors, const float* __restrict__ accum_alphas,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dpixel_alphas,
-    float* __restrict__ dL_dmean2D /*[P,3]*/, float* __restrict__ dL_dconic2D /*[P,4]*/,
-    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolors /*[P,3]*/, float* __restrict__ dL_ddepths) {
+    float* __restrict__ accum /*[P,16], zero on entry*/) {
     __shared__ BlendEntryA sA[64];
     __shared__ BlendEntryB sB[64];
     __shared__ BlendEntryC sC[64];
@@ -1037,6 +1050,12 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
     const uint32_t count = range.y - range.x;
 
     // forward results for this pixel (backward.cu:459-479)
+    // which slot of a Gaussian's accumulation line this lane adds to after the reduce-scatter (see below)
+    const int red_k = lane & 15, red_row = lane >> 4;
+    const int my_slot = red_k == 0 ? ((red_row & 1) << 1 | (red_row >> 1))
+                      : red_k == 1 ? 4 + ((red_row & 1) << 1 | (red_row >> 1))
+                      : (red_k == 2 && (red_row & 1) == 0) ? 8 + (red_row >> 1) : -1;
+
     const float T_final = inside ? (1.f - accum_alphas[pid]) : 0.f;
     float T = T_final;
     const uint32_t last_contributor = inside ? n_contrib[pid] : 0u;
@@ -1101,7 +1120,7 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
             if (!__any(contrib)) continue;
             const BlendEntryC c = sC[j];
             const float z = sD[j];
-            const float G = expf(power);
+            const float G = exp_nonpositive(power);  // == expf on the contributing lanes' domain (power <= 0)
             const float alpha = fminf(0.99f, c.opacity * G);
             contrib = contrib && !(alpha < 1.0f / 255.0f);
             float g_cr = 0.f, g_cg = 0.f, g_cb = 0.f, g_dep = 0.f, g_mx = 0.f, g_my = 0.f, g_kx = 0.f, g_ky = 0.f,
@@ -1143,23 +1162,13 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
                 g_op = G * dL_dalpha;
             }
             if (!__any(contrib)) continue;
-            g_cr = wave_sum_in_last_lane(g_cr); g_cg = wave_sum_in_last_lane(g_cg);
-            g_cb = wave_sum_in_last_lane(g_cb); g_dep = wave_sum_in_last_lane(g_dep);
-            g_mx = wave_sum_in_last_lane(g_mx); g_my = wave_sum_in_last_lane(g_my);
-            g_kx = wave_sum_in_last_lane(g_kx); g_ky = wave_sum_in_last_lane(g_ky);
-            g_kw = wave_sum_in_last_lane(g_kw); g_op = wave_sum_in_last_lane(g_op);
-            if (lane == 63) {
-                const size_t id = sId[j];
-                atomicAdd(dL_dcolors + 3 * id + 0, g_cr);
-                atomicAdd(dL_dcolors + 3 * id + 1, g_cg);
-                atomicAdd(dL_dcolors + 3 * id + 2, g_cb);
-                atomicAdd(dL_ddepths + id, g_dep);
-                atomicAdd(dL_dmean2D + 3 * id + 0, g_mx);
-                atomicAdd(dL_dmean2D + 3 * id + 1, g_my);
-                atomicAdd(dL_dconic2D + 4 * id + 0, g_kx);
-                atomicAdd(dL_dconic2D + 4 * id + 1, g_ky);
-                atomicAdd(dL_dconic2D + 4 * id + 3, g_kw);
-                atomicAdd(dL_dopacity + id, g_op);
+            // r|g, b|depth, mx|my, kxx|kxy, kyy|opacity -> rows [r b g depth], [mx kxx my kxy], [kyy - opacity -]
+            const float x0 = row_sum_all_lanes(fold16(fold32(g_cr, g_cg), fold32(g_cb, g_dep)));
+            const float x1 = row_sum_all_lanes(fold16(fold32(g_mx, g_my), fold32(g_kx, g_ky)));
+            const float x2 = row_sum_all_lanes(fold16(fold32(g_kw, g_op), 0.f));
+            if (my_slot >= 0) {  // ten lanes, one 64-byte line: a single atomic instruction per (quadrant, entry)
+                const float v = red_k == 0 ? x0 : red_k == 1 ? x1 : x2;
+                atomicAdd(accum + (size_t)kAccumStride * sId[j] + my_slot, v);
             }
         }
     }
@@ -1242,10 +1251,12 @@ struct BackwardArgs {
     const float* rotations;      // nullable
     const float* cov3D_precomp;  // nullable
     float scale_modifier;
-    const float* dL_dmean2D;     // [P,3]
-    const float* dL_dconic;      // [P,4]
-    const float* dL_dcolor;      // [P,3]
-    const float* dL_ddepth;      // [P]
+    const float* accum;          // [P,16] sums of render_backward_kernel (slots: see kAccumStride)
+    float* dL_dmean2D;           // [P,3]  written here from accum
+    float* dL_dconic;            // [P,4]
+    float* dL_dopacity;          // [P]
+    float* dL_dcolor;            // [P,3]
+    float* dL_ddepth;            // [P]
     float* dL_dmean3D;           // [P,3]
     float* dL_dcov3D;            // [P,6]
     float* dL_dsh;               // [P,M,3] nullable
@@ -1255,10 +1266,26 @@ struct BackwardArgs {
 
 __global__ void __launch_bounds__(256) preprocess_backward_kernel(BackwardArgs g, Camera cam) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= g.P || !(g.radii[idx] > 0)) return;
+    if (idx >= g.P || !(g.radii[idx] > 0)) return;  // nothing was accumulated: the caller's zeros stay
     const float* __restrict__ view = cam.viewmatrix;
     const float* __restrict__ proj = cam.projmatrix;
     const F3 mean = ld3(g.means3D + 3 * (size_t)idx);
+
+    // the ten sums of this Gaussian, one 64-byte line; spread into the reference's gradient arrays
+    const float4* line = reinterpret_cast<const float4*>(g.accum + (size_t)kAccumStride * idx);
+    const float4 s0 = line[0], s1 = line[1];
+    const float2 s2 = *reinterpret_cast<const float2*>(line + 2);
+    const float dLc_r = s0.x, dLc_g = s0.y, dLc_b = s0.z, gdep = s0.w;
+    const float g2x = s1.x, g2y = s1.y;
+    const float dLcx = s1.z, dLcy = s1.w, dLcz = s2.x;
+    *reinterpret_cast<F3*>(g.dL_dcolor + 3 * (size_t)idx) = F3{dLc_r, dLc_g, dLc_b};
+    g.dL_ddepth[idx] = gdep;
+    g.dL_dmean2D[3 * (size_t)idx] = g2x;
+    g.dL_dmean2D[3 * (size_t)idx + 1] = g2y;
+    g.dL_dconic[4 * (size_t)idx] = dLcx;
+    g.dL_dconic[4 * (size_t)idx + 1] = dLcy;
+    g.dL_dconic[4 * (size_t)idx + 3] = dLcz;
+    g.dL_dopacity[idx] = s2.y;
 
     // 3D covariance as the forward computed it
     float c3[6];
@@ -1285,7 +1312,6 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(BackwardArgs g
     }
 
     // ---- computeCov2DCUDA (backward.cu:144-276) ----
-    const float dLcx = g.dL_dconic[4 * (size_t)idx], dLcy = g.dL_dconic[4 * (size_t)idx + 1], dLcz = g.dL_dconic[4 * (size_t)idx + 3];
     float tx = view[0] * mean.x + view[4] * mean.y + view[8] * mean.z + view[12];
     float ty = view[1] * mean.x + view[5] * mean.y + view[9] * mean.z + view[13];
     const float tz_ = view[2] * mean.x + view[6] * mean.y + view[10] * mean.z + view[14];
@@ -1355,12 +1381,10 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(BackwardArgs g
     const float m_w = 1.0f / (mhw + 0.0000001f);
     const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
     const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
-    const float g2x = g.dL_dmean2D[3 * (size_t)idx], g2y = g.dL_dmean2D[3 * (size_t)idx + 1];
     dmx += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
     dmy += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
     dmz += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
     const float mul3_ = view[2] * mean.x + view[6] * mean.y + view[10] * mean.z + view[14];
-    const float gdep = g.dL_ddepth[idx];
     dmx += (view[2] - view[3] * mul3_) * gdep;
     dmy += (view[6] - view[7] * mul3_) * gdep;
     dmz += (view[10] - view[11] * mul3_) * gdep;
@@ -1377,10 +1401,9 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(BackwardArgs g
         const float len = sqrtf(o.x * o.x + o.y * o.y + o.z * o.z);
         const float x = o.x / len, y = o.y / len, z = o.z / len;
         // the forward's clamp decision, recomputed with the forward's own arithmetic
-        const float* dLc = g.dL_dcolor + 3 * (size_t)idx;
         F3 pre = sh_unclamped(deg, x, y, z, sh);
-        const float dL0 = dLc[0] * (pre.x < 0 ? 0.f : 1.f), dL1 = dLc[1] * (pre.y < 0 ? 0.f : 1.f),
-                    dL2 = dLc[2] * (pre.z < 0 ? 0.f : 1.f);
+        const float dL0 = dLc_r * (pre.x < 0 ? 0.f : 1.f), dL1 = dLc_g * (pre.y < 0 ? 0.f : 1.f),
+                    dL2 = dLc_b * (pre.z < 0 ? 0.f : 1.f);
         float kk[16];
         sh_coefficient_grads(deg, x, y, z, kk);
         const int ncoef = (deg + 1) * (deg + 1);
@@ -1606,13 +1629,11 @@ hipError_t launch_render_backward(const Camera& cam, const uint2* ranges, const 
                                   const float* background, const SplatRaster* raster, const float* colors,
                                   const float* accum_alphas,
                                   const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
-                                  const float* dL_dpix_alpha, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                                  float* dL_dcolors, float* dL_ddepths, hipStream_t stream) {
+                                  const float* dL_dpix_alpha, float* accum, hipStream_t stream) {
     const int T = cam.grid_x * cam.grid_y;
     hipLaunchKernelGGL(render_backward_kernel, dim3(4 * T), dim3(64), 0, stream, cam.width, cam.height, cam.grid_x, T,
                        ranges, point_list, background, raster, colors, accum_alphas, n_contrib,
-                       dL_dpix, dL_dpix_depth, dL_dpix_alpha, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolors,
-                       dL_ddepths);
+                       dL_dpix, dL_dpix_depth, dL_dpix_alpha, accum);
     return hipGetLastError();
 }
 
@@ -1621,7 +1642,8 @@ hipError_t launch_preprocess_backward(const BackwardInputs& b, const Camera& cam
     g.P = b.P; g.sh_degree = b.sh_degree; g.M = b.M;
     g.means3D = b.means3D; g.radii = b.radii; g.shs = b.shs; g.scales = b.scales; g.rotations = b.rotations;
     g.cov3D_precomp = b.cov3D_precomp; g.scale_modifier = b.scale_modifier;
-    g.dL_dmean2D = b.dL_dmean2D; g.dL_dconic = b.dL_dconic; g.dL_dcolor = b.dL_dcolor; g.dL_ddepth = b.dL_ddepth;
+    g.accum = b.accum; g.dL_dmean2D = b.dL_dmean2D; g.dL_dconic = b.dL_dconic; g.dL_dopacity = b.dL_dopacity;
+    g.dL_dcolor = b.dL_dcolor; g.dL_ddepth = b.dL_ddepth;
     g.dL_dmean3D = b.dL_dmean3D; g.dL_dcov3D = b.dL_dcov3D; g.dL_dsh = b.dL_dsh; g.dL_dscale = b.dL_dscale;
     g.dL_drot = b.dL_drot;
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3(div_up(b.P, 256)), dim3(256), 0, stream, g, cam);

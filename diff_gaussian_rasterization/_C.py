@@ -215,6 +215,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         radii_ = radii.contiguous()
         if radii_.dtype != torch.int32:
             raise RuntimeError(f"radii: expected an int32 tensor, got {radii_.dtype}")
+        accum = torch.empty((P, 16), dtype=torch.float32, device=device)   # cleared by the library
         with torch.cuda.device(device):
             rc = _lib.lib.gsr_backward(
                 P, int(degree), M, int(R), _ptr(bg_), W, H, _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(sc_),
@@ -222,7 +223,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 float(tan_fovy), _ptr(radii_), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(oa_),
                 _ptr(gc_), _ptr(gd_), _ptr(ga_), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(),
                 dL_dcolors.data_ptr(), dL_ddepths.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
-                dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(), dL_drotations.data_ptr(), 1 if debug else 0,
+                dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(), dL_drotations.data_ptr(), accum.data_ptr(),
+                1 if debug else 0,
                 ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
         if rc != 0:
             raise RuntimeError(f"gsr_backward failed ({rc}): {_lib.last_error()}")

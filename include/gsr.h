@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 2
+#define GSR_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define GSR_API __attribute__((visibility("default")))
@@ -152,6 +152,9 @@ GSR_API int gsr_selftest_exp(uint32_t first_bits, uint32_t count, unsigned long 
  *   outputs must arrive zero-filled (the binding does torch::zeros, :158-168): dL_dmean2D[P,3],
  *   dL_dconic[P,4] (xx, xy, unused, yy), dL_dopacity[P], dL_dcolor[P,3], dL_ddepth[P], dL_dmean3D[P,3],
  *   dL_dcov3D[P,6], dL_dsh[P,M,3] (NULL allowed without shs), dL_dscale[P,3], dL_drot[P,4]
+ *   accum_scratch     16*P floats of device memory, any content: the per-pixel pass sums each Gaussian's ten
+ *                     partial gradients into one 64-byte line (one atomic instruction per list entry and
+ *                     8x8 pixel block instead of ten); the per-Gaussian pass spreads them into the arrays above
  * Per-Gaussian sums are formed with one wave-level reduction and one atomic per 8x8 pixel block instead
  * of one atomic per pixel, so their last bits are order-dependent like the reference's.
  * Returns GSR_OK or a negative gsr_status.  Blocks the host once (reads the three arena headers).
@@ -167,7 +170,7 @@ GSR_API int gsr_backward(int P, int D, int M, int R, const float* background, in
                          const float* dL_dpix_depth, const float* dL_dpix_alpha, float* dL_dmean2D,
                          float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepth,
                          float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh /*nullable*/, float* dL_dscale,
-                         float* dL_drot, int debug, void* stream);
+                         float* dL_drot, float* accum_scratch /* 16*P floats, any content */, int debug, void* stream);
 
 /* ---- introspection (used by the parity tests and bench.py; not part of the reference API) ---- */
 

@@ -53,7 +53,7 @@ def test_argument_errors_do_not_need_a_device():
     from autovfx_amd import _lib
     L = _lib.lib
     bw_tail = [None, None, None, None, 1.0, None, None,   # means3D shs colors scales mod rotations cov3D
-               None, None, None, 0.5, 0.5] + [None] * 18 + [0, None]
+               None, None, None, 0.5, 0.5] + [None] * 19 + [0, None]
     assert L.gsr_backward(-1, 0, 0, 0, None, 8, 8, *bw_tail) == -1
     assert L.gsr_backward(0, 0, 0, 0, None, 8, 8, *bw_tail) == 0      # P == 0: nothing to do
     assert L.gsr_backward(4, 0, 0, 0, None, 8, 8, *bw_tail) == -1 and "null" in _lib.last_error()
