@@ -1264,9 +1264,32 @@ struct BackwardArgs {
     float* dL_drot;              // [P,4]
 };
 
-__global__ void __launch_bounds__(256) preprocess_backward_kernel(BackwardArgs g, Camera cam) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= g.P || !(g.radii[idx] > 0)) return;  // nothing was accumulated: the caller's zeros stay
+constexpr int kShStagePitch = 65;  // words between consecutive floats of one lane's record in the LDS stage
+
+// One lane = one Gaussian.  `stage` (nullable) is this lane's column of the wave's LDS stage for dL_dsh: float f of
+// the record goes to stage[f * kShStagePitch]; with stage == nullptr the record is stored straight to HBM.
+__device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, const Camera& cam, int idx, float* stage) {
+    if (!(g.radii[idx] > 0)) {
+        // Not rendered: every gradient of this Gaussian is zero.  The kernel defines ALL output elements, so the
+        // caller does not have to zero-fill a gigabyte of gradient tensors first (dL_dsh alone is 576 MB at 3 M).
+        const F3 z3 = {0.f, 0.f, 0.f};
+        *reinterpret_cast<F3*>(g.dL_dmean2D + 3 * (size_t)idx) = z3;
+        *reinterpret_cast<F4*>(g.dL_dconic + 4 * (size_t)idx) = F4{0.f, 0.f, 0.f, 0.f};
+        g.dL_dopacity[idx] = 0.f;
+        *reinterpret_cast<F3*>(g.dL_dcolor + 3 * (size_t)idx) = z3;
+        g.dL_ddepth[idx] = 0.f;
+        *reinterpret_cast<F3*>(g.dL_dmean3D + 3 * (size_t)idx) = z3;
+        *reinterpret_cast<F3*>(g.dL_dcov3D + 6 * (size_t)idx) = z3;
+        *reinterpret_cast<F3*>(g.dL_dcov3D + 6 * (size_t)idx + 3) = z3;
+        if (stage != nullptr) {
+            for (int f = 0; f < 3 * g.M; ++f) stage[f * kShStagePitch] = 0.f;
+        } else if (g.dL_dsh != nullptr) {
+            for (int k = 0; k < g.M; ++k) *reinterpret_cast<F3*>(g.dL_dsh + 3 * ((size_t)g.M * idx + k)) = z3;
+        }
+        *reinterpret_cast<F3*>(g.dL_dscale + 3 * (size_t)idx) = z3;
+        *reinterpret_cast<F4*>(g.dL_drot + 4 * (size_t)idx) = F4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
     const float* __restrict__ view = cam.viewmatrix;
     const float* __restrict__ proj = cam.projmatrix;
     const F3 mean = ld3(g.means3D + 3 * (size_t)idx);
@@ -1280,11 +1303,8 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(BackwardArgs g
     const float dLcx = s1.z, dLcy = s1.w, dLcz = s2.x;
     *reinterpret_cast<F3*>(g.dL_dcolor + 3 * (size_t)idx) = F3{dLc_r, dLc_g, dLc_b};
     g.dL_ddepth[idx] = gdep;
-    g.dL_dmean2D[3 * (size_t)idx] = g2x;
-    g.dL_dmean2D[3 * (size_t)idx + 1] = g2y;
-    g.dL_dconic[4 * (size_t)idx] = dLcx;
-    g.dL_dconic[4 * (size_t)idx + 1] = dLcy;
-    g.dL_dconic[4 * (size_t)idx + 3] = dLcz;
+    *reinterpret_cast<F3*>(g.dL_dmean2D + 3 * (size_t)idx) = F3{g2x, g2y, 0.f};            // z is never used (backward.cu)
+    *reinterpret_cast<F4*>(g.dL_dconic + 4 * (size_t)idx) = F4{dLcx, dLcy, 0.f, dLcz};   // 2x2 with one unused slot
     g.dL_dopacity[idx] = s2.y;
 
     // 3D covariance as the forward computed it
@@ -1407,9 +1427,20 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(BackwardArgs g
         float kk[16];
         sh_coefficient_grads(deg, x, y, z, kk);
         const int ncoef = (deg + 1) * (deg + 1);
+        if (stage != nullptr) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-            if (k < ncoef) *reinterpret_cast<F3*>(dsh + 3 * k) = F3{kk[k] * dL0, kk[k] * dL1, kk[k] * dL2};
+            for (int k = 0; k < 16; ++k) {  // staged records are M = 16 wide; bands above the degree are zero
+                const float m = k < ncoef ? kk[k] : 0.f;
+                stage[(3 * k + 0) * kShStagePitch] = m * dL0;
+                stage[(3 * k + 1) * kShStagePitch] = m * dL1;
+                stage[(3 * k + 2) * kShStagePitch] = m * dL2;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < ncoef) *reinterpret_cast<F3*>(dsh + 3 * k) = F3{kk[k] * dL0, kk[k] * dL1, kk[k] * dL2};
+            for (int k = ncoef; k < g.M; ++k) *reinterpret_cast<F3*>(dsh + 3 * k) = F3{0.f, 0.f, 0.f};  // bands above the degree
+        }
         const F3 d0 = sh_dir_grads_channel(deg, x, y, z, sh, 0);
         const F3 d1 = sh_dir_grads_channel(deg, x, y, z, sh, 1);
         const F3 d2 = sh_dir_grads_channel(deg, x, y, z, sh, 2);
@@ -1453,6 +1484,37 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(BackwardArgs g
         dq[3] = 2 * r * (D(0, 1) - D(1, 0)) + 2 * x * (D(2, 0) + D(0, 2)) + 2 * y * (D(1, 2) + D(2, 1)) - 4 * z * (D(1, 1) + D(0, 0));
 #undef D
 #undef COL
+    } else {
+        *reinterpret_cast<F3*>(g.dL_dscale + 3 * (size_t)idx) = F3{0.f, 0.f, 0.f};
+        *reinterpret_cast<F4*>(g.dL_drot + 4 * (size_t)idx) = F4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// dL_dsh is 192 bytes per Gaussian: written lane by lane it goes out as 12-byte pieces 192 bytes apart (measured
+// 2.8 TB/s, scripts/ubench/sh_store.hip); staged through LDS ([float][lane], pitch 65: conflict-free both ways) the
+// wave writes its 12 KB as contiguous 16-byte stores (5.9 TB/s).  Taken when M == 16 and the tensor is 16-byte aligned.
+__global__ void __launch_bounds__(256) preprocess_backward_kernel(BackwardArgs g, Camera cam) {
+    __shared__ float s_stage[4][48 * kShStagePitch];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool staged = g.dL_dsh != nullptr && g.M == 16 && (reinterpret_cast<uintptr_t>(g.dL_dsh) & 15u) == 0;  // uniform
+    if (idx < g.P) preprocess_backward_lane(g, cam, idx, staged ? s_stage[wave] + lane : nullptr);
+    if (!staged) return;
+    const int g0 = blockIdx.x * 256 + wave * 64;  // first Gaussian of this wave
+    if (g0 >= g.P) return;
+    __builtin_amdgcn_s_waitcnt(0);       // this wave's own LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    const float* mine = s_stage[wave];
+    float4* dst = reinterpret_cast<float4*>(g.dL_dsh + 48 * (size_t)g0);
+    const int chunks = min(64, g.P - g0) * 12;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const int c = k * 64 + lane;  // 16-byte chunk of the wave's 12 KB
+        if (c < chunks) {
+            const int gi = c / 12, f = (c - gi * 12) * 4;
+            dst[c] = make_float4(mine[(f + 0) * kShStagePitch + gi], mine[(f + 1) * kShStagePitch + gi],
+                                 mine[(f + 2) * kShStagePitch + gi], mine[(f + 3) * kShStagePitch + gi]);
+        }
     }
 }
 

@@ -201,7 +201,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     P = int(means3D.size(0))
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
     M = int(sh.size(1)) if sh.numel() != 0 else 0
-    z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=device)
+    # P == 0: nothing runs, the (empty) results are trivially defined; otherwise gsr_backward writes every element
+    z = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)
     dL_dmeans3D, dL_dmeans2D, dL_dcolors = z(P, 3), z(P, 3), z(P, 3)
     dL_ddepths, dL_dconic, dL_dopacity = z(P, 1), z(P, 2, 2), z(P, 1)   # the first two are intermediates
     dL_dcov3D, dL_dsh, dL_dscales, dL_drotations = z(P, 6), z(P, M, 3), z(P, 3), z(P, 4)

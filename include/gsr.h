@@ -149,7 +149,8 @@ GSR_API int gsr_selftest_exp(uint32_t first_bits, uint32_t count, unsigned long 
  *   geom/binning/image_buffer   the three scratch arenas of that call, untouched since (the pointers the
  *                     scratch callbacks returned); they are self-describing and are validated
  *   accum_alphas      the forward's out_alpha;  dL_dpix[3,H,W], dL_dpix_depth[H,W], dL_dpix_alpha[H,W]
- *   outputs must arrive zero-filled (the binding does torch::zeros, :158-168): dL_dmean2D[P,3],
+ *   outputs (every element is written: unlike the reference, whose binding zero-fills them first, :158-168,
+ *   they may arrive with any content): dL_dmean2D[P,3],
  *   dL_dconic[P,4] (xx, xy, unused, yy), dL_dopacity[P], dL_dcolor[P,3], dL_ddepth[P], dL_dmean3D[P,3],
  *   dL_dcov3D[P,6], dL_dsh[P,M,3] (NULL allowed without shs), dL_dscale[P,3], dL_drot[P,4]
  *   accum_scratch     16*P floats of device memory, any content: the per-pixel pass sums each Gaussian's ten
