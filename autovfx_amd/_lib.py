@@ -25,7 +25,7 @@ ABI_VERSION = 3
 SYMBOLS = ("gsr_forward", "gsr_mark_visible", "gsr_backward", "gsr_last_geom_offsets", "gsr_last_binning_offsets",
            "gsr_last_image_offsets", "gsr_set_stage_timing", "gsr_get_stage_times", "gsr_last_error",
            "gsr_abi_version", "gsr_target_arch", "gsr_set_option", "gsr_get_option", "gsr_pack_rgba8", "gsr_last_pair_counts", "gsr_blend", "gsr_composite",
-           "gsr_radix_scratch_bytes", "gsr_radix_sort_pairs", "gsr_selftest_exp")
+           "gsr_radix_scratch_bytes", "gsr_radix_sort_pairs", "gsr_selftest_exp", "gsr_view_normals", "gsr_normal_maps")
 OPT_TILE_CULL = 0
 OPT_BLEND_VARIANT = 1
 OPT_BLEND_LDS_PAD = 2
@@ -71,6 +71,10 @@ def _load() -> ctypes.CDLL:
     lib.gsr_radix_sort_pairs.restype = ctypes.c_int
     lib.gsr_radix_sort_pairs.argtypes = [ctypes.c_uint32, ctypes.c_int, c_f, c_f, c_f, c_f, ctypes.c_int, c_f,
                                          ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]
+    lib.gsr_view_normals.restype = ctypes.c_int
+    lib.gsr_view_normals.argtypes = [ctypes.c_int, c_f, c_f, c_f, c_f, ctypes.c_void_p]
+    lib.gsr_normal_maps.restype = ctypes.c_int
+    lib.gsr_normal_maps.argtypes = [ctypes.c_int, ctypes.c_int, c_f, c_f, c_f] + [ctypes.c_float] * 4 + [c_f, c_f, ctypes.c_void_p]
     lib.gsr_selftest_exp.restype = ctypes.c_int
     lib.gsr_selftest_exp.argtypes = [ctypes.c_uint32, ctypes.c_uint32, c_f, ctypes.c_void_p]
     lib.gsr_pack_rgba8.restype = ctypes.c_int

@@ -286,6 +286,23 @@ int gsr_radix_sort_pairs(uint32_t n, int bits, uint32_t* keys, uint32_t* keys_al
     return GSR_OK;
 }
 
+int gsr_view_normals(int P, const float* means3D, const float* axis, const float* cam_pos, float* colors, void* stream_) {
+    if (P < 0) return fail(GSR_ERR_INVALID_ARG, "bad size P=%d", P);
+    if (P == 0) return GSR_OK;
+    if (!means3D || !axis || !cam_pos || !colors) return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    GSR_HIP(gsr::launch_view_normals(P, means3D, axis, cam_pos, colors, (hipStream_t)stream_));
+    return GSR_OK;
+}
+
+int gsr_normal_maps(int width, int height, const float* normal_rgb, const float* depth, const float* c2w, float fx,
+                    float fy, float cx, float cy, float* normal, float* pseudo_normal, void* stream_) {
+    if (width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARG, "bad image size %dx%d", width, height);
+    if (!normal_rgb || !depth || !c2w || !normal || !pseudo_normal) return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    GSR_HIP(gsr::launch_normal_maps(width, height, normal_rgb, depth, c2w, fx, fy, cx, cy, normal, pseudo_normal,
+                                    (hipStream_t)stream_));
+    return GSR_OK;
+}
+
 int gsr_selftest_exp(uint32_t first_bits, uint32_t count, unsigned long long* device_mismatches, void* stream_) {
     if (!device_mismatches || count > 0x7FFFFFFFu) return fail(GSR_ERR_INVALID_ARG, "bad selftest arguments");
     if (count == 0) return GSR_OK;

@@ -142,6 +142,11 @@ hipError_t launch_composite(int width, int height, const void* bg_c, const void*
                             const void* s_c, const float* s_d, const void* o_s_c, const void* o_gs_c,
                             const float* o_gs_d, const void* s_f_c, const float* s_f_d, const void* s_f_c_pre,
                             void* out, hipStream_t stream);
+// render()'s elementwise work around the two rasterizer passes (see gsr.h: gsr_view_normals, gsr_normal_maps)
+hipError_t launch_view_normals(int P, const float* means3D, const float* axis, const float* cam_pos, float* out,
+                               hipStream_t stream);
+hipError_t launch_normal_maps(int width, int height, const float* normal_rgb, const float* depth, const float* c2w,
+                              float fx, float fy, float cx, float cy, float* normal, float* pseudo, hipStream_t stream);
 hipError_t launch_pack_rgba8(const float* color, const float* alpha, uint8_t* out, size_t n_pixels,
                              hipStream_t stream);
 

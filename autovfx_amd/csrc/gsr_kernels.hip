@@ -1725,6 +1725,89 @@ hipError_t launch_composite(int width, int height, const void* bg_c, const void*
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// The elementwise work of the reference's per-frame render() around its two rasterizer passes
+// (sugar/gaussian_splatting/gaussian_renderer/__init__.py:118-146,169-208), which PyTorch runs as ~40 small
+// launches (and one 3x3 GEMM over two million rows), as two kernels.  Same formulas, same operation order as the
+// Python (sums left to right, F.normalize's max(norm, 1e-12)); differences against the PyTorch kernels are at
+// the level of their own fused-multiply-add contraction.
+//   view_normals_kernel : per Gaussian, view direction -> flip the shortest-axis normal towards the camera
+//                         (utils/general_utils.py:151-157) -> unit length -> * 0.5 + 0.5  (colours of pass 2)
+//   normal_maps_kernel  : per pixel, (raw - 0.5) * 2 -> unit normal map [H,W,3]; and the pseudo normal from the
+//                         depth map: un-project the 4 neighbours (get_ray_directions :41-80, c2w rotation),
+//                         cross product of the central differences (depth_pcd2normal :22-38), zero border.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ F3 unit3(F3 v) {  // torch.nn.functional.normalize(p=2, eps=1e-12)
+    const float n = fmaxf(sqrtf(v.x * v.x + v.y * v.y + v.z * v.z), 1e-12f);
+    return F3{v.x / n, v.y / n, v.z / n};
+}
+
+__global__ void __launch_bounds__(256) view_normals_kernel(int P, const float* __restrict__ means3D,
+                                                           const float* __restrict__ axis,
+                                                           const float* __restrict__ cam_pos, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const F3 p = ld3(means3D + 3 * (size_t)i), a = ld3(axis + 3 * (size_t)i), c = ld3(cam_pos);
+    const F3 d = {p.x - c.x, p.y - c.y, p.z - c.z};
+    const float len = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+    const F3 dir = {d.x / len, d.y / len, d.z / len};
+    const float dot = a.x * -dir.x + a.y * -dir.y + a.z * -dir.z;
+    const float s = dot >= 0.f ? 1.f : -1.f;
+    const F3 m = {a.x * s, a.y * s, a.z * s};
+    const float ml = sqrtf(m.x * m.x + m.y * m.y + m.z * m.z);
+    *reinterpret_cast<F3*>(out + 3 * (size_t)i) = F3{m.x / ml * 0.5f + 0.5f, m.y / ml * 0.5f + 0.5f, m.z / ml * 0.5f + 0.5f};
+}
+
+struct NormalMapArgs {
+    int W, H;
+    const float* normal_rgb;  // [3,H,W]
+    const float* depth;       // [H,W]
+    const float* c2w;         // device, 16 floats row-major: the 4x4 the Python calls c2w
+    float fx, fy, cx, cy;
+    float* normal;            // [H,W,3]
+    float* pseudo;            // [H,W,3]
+};
+
+__global__ void __launch_bounds__(256) normal_maps_kernel(NormalMapArgs a) {
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63), v = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (u >= a.W || v >= a.H) return;
+    const size_t plane = (size_t)a.W * a.H, pid = (size_t)v * a.W + u;
+    const F3 raw = {a.normal_rgb[pid], a.normal_rgb[plane + pid], a.normal_rgb[2 * plane + pid]};
+    *reinterpret_cast<F3*>(a.normal + 3 * pid) = unit3(F3{(raw.x - 0.5f) * 2.0f, (raw.y - 0.5f) * 2.0f, (raw.z - 0.5f) * 2.0f});
+
+    F3 n = {0.f, 0.f, 0.f};
+    if (u >= 1 && v >= 1 && u < a.W - 1 && v < a.H - 1) {
+        const float* __restrict__ m = a.c2w;  // uniform: scalar loads
+        auto point = [&](int x, int y) {  // rays_o + rays_d * depth
+            const float dx = ((float)x - a.cx + 0.5f) / a.fx, dy = ((float)y - a.cy + 0.5f) / a.fy;
+            const float z = a.depth[(size_t)y * a.W + x];
+            return F3{m[3] + (dx * m[0] + dy * m[1] + m[2]) * z, m[7] + (dx * m[4] + dy * m[5] + m[6]) * z,
+                      m[11] + (dx * m[8] + dy * m[9] + m[10]) * z};
+        };
+        const F3 right = point(u + 1, v), left = point(u - 1, v), top = point(u, v - 1), bottom = point(u, v + 1);
+        const F3 h = {right.x - left.x, right.y - left.y, right.z - left.z};
+        const F3 w = {top.x - bottom.x, top.y - bottom.y, top.z - bottom.z};
+        n = unit3(F3{h.y * w.z - h.z * w.y, h.z * w.x - h.x * w.z, h.x * w.y - h.y * w.x});
+    }
+    *reinterpret_cast<F3*>(a.pseudo + 3 * pid) = n;
+}
+
+hipError_t launch_view_normals(int P, const float* means3D, const float* axis, const float* cam_pos, float* out,
+                               hipStream_t stream) {
+    hipLaunchKernelGGL(view_normals_kernel, dim3(div_up(P, 256)), dim3(256), 0, stream, P, means3D, axis, cam_pos, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_normal_maps(int width, int height, const float* normal_rgb, const float* depth, const float* c2w,
+                              float fx, float fy, float cx, float cy, float* normal, float* pseudo, hipStream_t stream) {
+    NormalMapArgs a;
+    a.W = width; a.H = height; a.normal_rgb = normal_rgb; a.depth = depth;
+    a.c2w = c2w;
+    a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.normal = normal; a.pseudo = pseudo;
+    hipLaunchKernelGGL(normal_maps_kernel, dim3(div_up(width, 64), div_up(height, 4)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack_rgba8(const float* color, const float* alpha, uint8_t* out, size_t n_pixels,
                              hipStream_t stream) {
     const bool vec_ok = n_pixels % 4 == 0 && ((uintptr_t)color % 16 == 0) && ((uintptr_t)alpha % 16 == 0) &&

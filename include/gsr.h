@@ -136,6 +136,19 @@ GSR_API int gsr_radix_sort_pairs(uint32_t n, int bits, uint32_t* keys, uint32_t*
                                  uint32_t* vals_alt, int iota_payload, void* scratch, size_t scratch_bytes,
                                  int* sorted_in_alt, void* stream);
 
+/* The elementwise work of the reference's per-frame render() around its two rasterizer passes
+ * (sugar/gaussian_splatting/gaussian_renderer/__init__.py:118-146,169-208), as two kernels instead of ~40 framework
+ * launches.  Used by autovfx_amd/renderer.py when autograd is off; same formulas and operation order as the Python.
+ *   gsr_view_normals: colors[P,3] = unit(flip_towards_camera(axis[P,3], means3D - cam_pos)) * 0.5 + 0.5
+ *                     (axis = rotation column of the smallest scale, utils/general_utils.py:135-157)
+ *   gsr_normal_maps : normal[H,W,3] = unit((normal_rgb[3,H,W] - 0.5) * 2);  pseudo_normal[H,W,3] = unit normal of the
+ *                     un-projected depth map by central differences (:22-38,:41-80), zero on the border.
+ *                     c2w: 16 device floats, the row-major 4x4 matrix the Python names c2w (rows 0..2 are read). */
+GSR_API int gsr_view_normals(int P, const float* means3D, const float* axis, const float* cam_pos, float* colors,
+                             void* stream);
+GSR_API int gsr_normal_maps(int width, int height, const float* normal_rgb, const float* depth, const float* c2w,
+                            float fx, float fy, float cx, float cy, float* normal, float* pseudo_normal, void* stream);
+
 /* Self-test of the blend kernel's exp(): adds to *device_mismatches (a zeroed device u64) the number of floats
  * with bit patterns first_bits .. first_bits + count - 1 whose exp differs from the device library's expf.
  * The blend evaluates exp only for arguments <= 0; tests sweep every float of [-103, 0]. */

@@ -143,6 +143,39 @@ def test_render_end_to_end_against_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("size", [(320, 200), (97, 61)])
+def test_fused_elementwise_kernels_match_the_pytorch_path(size):
+    """With autograd off render() runs its elementwise work as two kernels (gsr_view_normals / gsr_normal_maps);
+    with autograd on it runs the reference's PyTorch expressions.  Same formulas: results agree to rounding."""
+    from autovfx_amd.cameras import orbit_cameras
+    dev = "cuda:0"
+    cam = orbit_cameras(10, *size)[4].to(dev)
+    m, _ = model(25_000, seed=9)
+    m.to(dev)
+    bg = torch.tensor([0.3, 0.1, 0.2], device=dev)
+    with torch.no_grad():
+        a = renderer.render(cam, m, renderer.PipelineParams, bg)
+    with torch.enable_grad():
+        b = renderer.render(cam, m, renderer.PipelineParams, bg)
+    for k in ("render", "depth", "radii"):
+        assert torch.equal(a[k], b[k].detach()), k           # the rasterizer passes themselves are the same calls
+    solid = a["render"][3] > 0.5                              # unit-normalisation is ill-conditioned where alpha ~ 0
+    assert (a["normal"] - b["normal"].detach())[solid].abs().max() < 2e-4
+    # pseudo normals: compare where the un-projected differences are not degenerate
+    pa, pb = a["pseudo_normal"], b["pseudo_normal"].detach()
+    assert pa.shape == pb.shape and torch.isfinite(pa).all()
+    assert bool((pa[0] == 0).all() and (pa[-1] == 0).all() and (pa[:, 0] == 0).all() and (pa[:, -1] == 0).all())
+    close = (pa - pb).abs().amax(dim=-1) < 1e-3
+    assert close[solid].float().mean() > 0.98
+
+    # the per-Gaussian kernel against the Python expression, directly
+    d = m.get_xyz - cam.camera_center[None]
+    want = m.get_normal(d / d.norm(dim=1, keepdim=True)) * 0.5 + 0.5
+    got = renderer._fused_view_normals(m.get_xyz, m.get_minimum_axis, cam.camera_center)
+    assert (got - want).abs().max() < 1e-6
+
+
+@pytest.mark.gpu
 def test_two_pass_render_is_thread_and_stream_safe():
     """render() (two rasterizer passes, geometry cache, memoised activations) driven from two host threads on
     two HIP streams must give exactly the serial frames."""
