@@ -161,6 +161,37 @@ def gather_frames(local: torch.Tensor, num_frames: int, dst: int = 0, group=None
     return out
 
 
+def render_and_gather(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids: Sequence[int], bg: torch.Tensor,
+                      dst: int = 0, render_fn: RenderFn = rasterize, streams: int = 1, chunks: int = 4,
+                      group=None) -> Optional[torch.Tensor]:
+    """Render ``frame_ids`` (this rank's frames; every rank must pass the same number) and gather the RGBA8 frames
+    to ``dst`` while rendering continues: the shard is cut into ``chunks`` pieces, and as soon as a piece is rendered
+    its ``gather`` is launched asynchronously (RCCL runs it on its own stream over xGMI) behind the next piece's
+    rendering, so only the last piece's transfer is left as a tail.  Returns ``[world, n, 4, H, W]`` on ``dst``
+    (rank-major), ``None`` elsewhere; without a process group ``[1, n, 4, H, W]``."""
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    n = len(frame_ids)
+    chunks = max(1, min(int(chunks), n))
+    bounds = [n * k // chunks for k in range(chunks + 1)]
+    parts, received, works = [], [], []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        part = render_shard(cloud, cameras, list(frame_ids[a:b]), bg, False, render_fn, streams)["rgba8"]
+        parts.append(part)                       # kept alive until the transfers have been waited for
+        if distributed:
+            bufs = [torch.empty_like(part) for _ in range(world)] if rank == dst else None
+            received.append(bufs)
+            works.append(dist.gather(part, bufs, dst=dst, group=group, async_op=True))
+    for w in works:
+        w.wait()
+    if not distributed:
+        return torch.cat(parts, dim=0)[None]
+    if rank != dst:
+        return None
+    return torch.stack([torch.cat([bufs[r] for bufs in received], dim=0) for r in range(world)], dim=0)
+
+
 def render_trajectory(cloud: GaussianCloud, cameras: Sequence[Camera], bg: torch.Tensor, keep_depth: bool = False,
                       dst: int = 0, render_fn: RenderFn = rasterize, streams: int = 1) -> Optional[Dict[str, torch.Tensor]]:
     """Shard -> render -> gather.  Works with or without an initialised process group."""

@@ -76,7 +76,9 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--gaussians", type=int, default=0, help="override P (parity/debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true", help="skip the final RCCL gather (N > 1)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of the frames to rank 0 (N > 1)")
+    ap.add_argument("--gather-chunks", type=int, default=4,
+                    help="N > 1: pieces the per-rank frame stack is gathered in, each overlapped with the next piece's rendering")
     ap.add_argument("--streams", type=int, default=3,
                     help="render frames on this many HIP streams (one host thread each) so independent frames overlap")
     ap.add_argument("--boundary", choices=["op", "render"], default="op",
@@ -108,7 +110,7 @@ def main():
 
     from autovfx_amd import _lib, scenes
     from autovfx_amd.cameras import orbit_cameras
-    from autovfx_amd.frame_parallel import gather_frames, pack_rgba8, rasterize
+    from autovfx_amd.frame_parallel import pack_rgba8, rasterize, render_and_gather
     from diff_gaussian_rasterization import _C
 
     if args.blend_variant is not None:
@@ -143,6 +145,10 @@ def main():
         model = GaussianModel.from_activated(cloud.means3D, cloud.opacities, cloud.scales, cloud.rotations, cloud.shs,
                                              cloud.sh_degree)
 
+        def render_fn_boundary(_cloud, cam, bg_):
+            out = renderer.render(cam, model, renderer.PipelineParams, bg_)
+            return out["render"][:3], out["depth"][None], out["render"][3:4], out["radii"]
+
         def step(i, slot):
             out = renderer.render(cams[frame_of(i)], model, renderer.PipelineParams, bg)
             pack_rgba8(out["render"][:3], out["render"][3:4], out=rgba[slot % K])
@@ -173,6 +179,8 @@ def main():
             th.start()
         for th in threads:
             th.join()
+        for st in streams:   # later work on the caller's stream sees every frame
+            torch.cuda.current_stream(device).wait_stream(st)
 
     with torch.no_grad():
         run_steps(0, Wm)
@@ -181,10 +189,15 @@ def main():
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
-        run_steps(Wm, K)
         gathered = None
         if world > 1 and not args.no_gather:
-            gathered = gather_frames(rgba, K * world, dst=0)
+            # N > 1: the same per-frame work through the frame-parallel driver, whose gather to rank 0 is cut into
+            # pieces that travel over xGMI behind the rendering of the next piece (only the last one is a tail)
+            cam_list = [cams[frame_of(Wm + j)] for j in range(K)]
+            gathered = render_and_gather(cloud, cam_list, list(range(K)), bg, dst=0, streams=S, chunks=args.gather_chunks,
+                                         render_fn=(render_fn_boundary if args.boundary == "render" else rasterize))
+        else:
+            run_steps(Wm, K)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -261,14 +274,15 @@ def main():
                        "boundary": ("render(): activations, SH pass, normal pass (geometry reused), normal/pseudo-normal "
                                     "post-processing, RGBA8 pack per frame" if args.boundary == "render" else
                                     "GaussianRasterizer.forward (SH) + RGBA8 pack per frame")
-                                   + ("; final RCCL gather of RGBA8 frames to rank 0" if world > 1 and not args.no_gather else ""),
+                                   + ("; RCCL gather of the RGBA8 frames to rank 0, pipelined behind the rendering" if world > 1 and not args.no_gather else ""),
                        "parallelism": f"frame-parallel x{world}", "streams_per_gpu": S,
                        "options": {"tile_cull": _lib.get_option(_lib.OPT_TILE_CULL),
                                    "blend_variant": _lib.get_option(_lib.OPT_BLEND_VARIANT)}},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         if gathered is not None:
-            line["config"]["gathered_frames"] = int(gathered.shape[0])
+            line["config"]["gathered_frames"] = int(gathered.shape[0] * gathered.shape[1])
+            line["config"]["gather_chunks"] = args.gather_chunks
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -47,6 +47,37 @@ def _worker(rank, world, port, num_frames, out_path):
         dist.destroy_process_group()
 
 
+def _worker_pipelined(rank, world, port, per_rank, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cloud = scenes.config_c1(P=300, seed=2)
+        cams = orbit_cameras(world * per_rank, 40, 24)
+        mine = [i * world + rank for i in range(per_rank)]          # what bench.py gives rank `rank`
+        res = fp.render_and_gather(cloud, cams, mine, torch.zeros(3), render_fn=oracle_render, chunks=3)
+        if rank == 0:
+            torch.save(res, out_path)
+        else:
+            assert res is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("per_rank", [5, 2])
+def test_pipelined_gather_two_ranks(tmp_path, per_rank):
+    """render_and_gather: chunked asynchronous gathers behind the rendering give every rank's frames, in order."""
+    out = str(tmp_path / "gathered.pt")
+    mp.spawn(_worker_pipelined, args=(2, _free_port(), per_rank, out), nprocs=2, join=True)
+    got = torch.load(out)
+    cloud = scenes.config_c1(P=300, seed=2)
+    cams = orbit_cameras(2 * per_rank, 40, 24)
+    assert got.shape == (2, per_rank, 4, 24, 40) and got.dtype == torch.uint8
+    for r in range(2):
+        ref = fp.render_and_gather(cloud, cams, [i * 2 + r for i in range(per_rank)], torch.zeros(3),
+                                   render_fn=oracle_render, chunks=1)
+        assert ref.shape == (1, per_rank, 4, 24, 40) and torch.equal(got[r], ref[0])
+
+
 def test_shard_frames_round_robin():
     assert fp.shard_frames(10, 0, 4) == [0, 4, 8]
     assert fp.shard_frames(10, 3, 4) == [3, 7]
