@@ -197,11 +197,21 @@ __device__ __forceinline__ bool splat_reaches_tile(float4 co, float2 c, int tile
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Camera cam, GeometryArrays out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= in.P) return;
+    const bool in_range = i < in.P;  // every lane stays to the end: the tile-mask phase below is wave-cooperative
 
     const float* __restrict__ vm = cam.viewmatrix;
     const float* __restrict__ pm = cam.projmatrix;
 
+    int radius_out = 0;
+    uint32_t rect_area = 0;
+    SplatBin bin = {0u, 1u, 0xFFFFFFFFu, 0u};
+    uint32_t key = kCulledKey;
+    // what the tile-mask phase needs of a candidate (a visible splat whose rectangle has <= 32 tiles)
+    bool mask_candidate = false;
+    float4 cand_conic = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 cand_centre = make_float2(0.f, 0.f);
+
+    if (in_range) {
     if (out.ids != nullptr) out.ids[i] = (uint32_t)i;
     const F3 p = ld3(in.means3D + 3 * (size_t)i);
 
@@ -212,11 +222,6 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
     const float vx = vm[0] * p.x + vm[4] * p.y + vm[8] * p.z + vm[12];
     const float vy = vm[1] * p.x + vm[5] * p.y + vm[9] * p.z + vm[13];
     const float vz = vm[2] * p.x + vm[6] * p.y + vm[10] * p.z + vm[14];
-
-    int radius_out = 0;
-    uint32_t rect_area = 0;
-    SplatBin bin = {0u, 1u, 0xFFFFFFFFu, 0u};
-    uint32_t key = kCulledKey;
 
     if (vz <= 0.2f) {
         // The reference printf+traps here when prefiltered is set (auxiliary.h:156-160); we record
@@ -295,21 +300,79 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
                 bin.xy0 = (uint32_t)rc.x0 | ((uint32_t)rc.y0 << 16);
                 bin.width = (uint32_t)(rc.x1 - rc.x0);
                 bin.count = area;
-                if (in.tile_cull && area <= 32u) {  // exact-image tile culling, see above
-                    uint32_t mask = 0u, bit = 0;
-                    for (int ty = rc.y0; ty < rc.y1; ++ty)
-                        for (int tx = rc.x0; tx < rc.x1; ++tx, ++bit)
-                            if (splat_reaches_tile(conic_o, make_float2(px, py), tx, ty)) mask |= 1u << bit;
-                    bin.mask = mask;
-                    bin.count = (uint32_t)__popc(mask);
+                if (in.tile_cull && area <= 32u) {  // exact-image tile culling: mask computed below, by the whole wave
+                    mask_candidate = true;
+                    cand_conic = conic_o;
+                    cand_centre = make_float2(px, py);
                 }
                 key = __float_as_uint(vz);
             }
         }
     }
-    out.radii[i] = radius_out;
-    *reinterpret_cast<uint4*>(out.bins + i) = make_uint4(bin.xy0, bin.width, bin.mask, bin.count);
-    out.depth_keys[i] = key;
+    }  // in_range
+
+    // ---- exact-image tile culling, wave-cooperative ----
+    // A lane looping over the tiles of its own rectangle makes the wave run as long as its largest rectangle
+    // (~25 iterations for ~6 tiles per splat on average: half of this kernel's vector instructions).  Instead the
+    // (splat, tile) tests of the wave's 64 splats are flattened: test t belongs to the splat whose inclusive count
+    // first exceeds t (binary search over the counts parked in LDS), every lane runs one test per iteration, the
+    // ballot of the results is cut back into per-splat masks.  Iterations = total tests / 64.
+    {
+        __shared__ float4 s_conic[4][64];
+        __shared__ float4 s_place[4][64];   // centre x, y, first tile (x | y << 16), rectangle width
+        __shared__ uint32_t s_incl[4][64];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const uint32_t n_tests = mask_candidate ? rect_area : 0u;
+        uint32_t incl = n_tests;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += o;
+        }
+        const uint32_t excl = incl - n_tests;
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+        if (total != 0u) {  // wave-uniform
+            s_conic[wave][lane] = cand_conic;
+            s_place[wave][lane] = make_float4(cand_centre.x, cand_centre.y, __uint_as_float(bin.xy0), __uint_as_float(bin.width));
+            s_incl[wave][lane] = incl;
+            __builtin_amdgcn_s_waitcnt(0);       // this wave's own LDS writes have landed
+            __builtin_amdgcn_wave_barrier();
+            uint32_t mask = 0u;
+            for (uint32_t t0 = 0; t0 < total; t0 += 64u) {
+                const uint32_t t = t0 + (uint32_t)lane;
+                int lo = 0, hi = 63;  // first splat whose inclusive count exceeds t
+#pragma unroll
+                for (int step = 0; step < 6; ++step) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_incl[wave][mid] > t) hi = mid; else lo = mid + 1;
+                }
+                const float4 co = s_conic[wave][lo], pl = s_place[wave][lo];
+                const uint32_t xy0 = __float_as_uint(pl.z), w = __float_as_uint(pl.w);
+                const uint32_t first = lo > 0 ? s_incl[wave][lo - 1] : 0u;
+                const uint32_t local = t - first;  // < 32, w <= 32: (local + 0.5) / w is >= 1/64 away from an integer
+                const uint32_t row = (uint32_t)(((float)local + 0.5f) * __builtin_amdgcn_rcpf((float)w));
+                const uint32_t col = local - row * w;
+                const bool live = t < total && splat_reaches_tile(co, make_float2(pl.x, pl.y), (int)((xy0 & 0xFFFFu) + col),
+                                                                  (int)((xy0 >> 16) + row));
+                const unsigned long long b = __ballot(live);
+                const uint32_t from = max(excl, t0), to = min(incl, t0 + 64u);  // my tests inside this batch
+                if (from < to) {
+                    const uint32_t bits = (uint32_t)(b >> (from - t0)) & (to - from >= 32u ? 0xFFFFFFFFu : (1u << (to - from)) - 1u);
+                    mask |= bits << (from - excl);
+                }
+            }
+            if (mask_candidate) {
+                bin.mask = mask;
+                bin.count = (uint32_t)__popc(mask);
+            }
+        }
+    }
+
+    if (in_range) {
+        out.radii[i] = radius_out;
+        *reinterpret_cast<uint4*>(out.bins + i) = make_uint4(bin.xy0, bin.width, bin.mask, bin.count);
+        out.depth_keys[i] = key;
+    }
     // Pair totals, needed on the host before the binning arena can be sized: the live pairs (what
     // gets expanded and sorted) in the low word and the reference's num_rendered (sum of rectangle
     // areas, part of its return value) in the high word of one 64-bit add.  One atomic per wave,
@@ -318,7 +381,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wave_tot += __shfl_xor(wave_tot, d);
     const unsigned long long emitting = __ballot(key != kCulledKey);
-    if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1)) && emitting != 0ull) {
+    if ((threadIdx.x & 63) == 0 && emitting != 0ull) {
         const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) & (kRectPartials - 1);
         if (wave_tot != 0ull) atomicAdd(out.counters->pair_totals + slot, wave_tot);
         atomicAdd(out.counters->visible + slot, (uint32_t)__popcll(emitting));
