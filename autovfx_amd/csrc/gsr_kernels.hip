@@ -1091,11 +1091,7 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dpixel_alphas,
     float* __restrict__ accum /*[P,16], zero on entry*/) {
-    __shared__ BlendEntryA sA[64];
-    __shared__ BlendEntryB sB[64];
-    __shared__ BlendEntryC sC[64];
-    __shared__ float sD[64];
-    __shared__ uint32_t sId[64];
+    __shared__ BlendEntry s_entry[64];  // the forward's 48-byte record; the Gaussian id rides in its pad word
 
     constexpr int kQ = kTile / 2;
     const int item = xcd_band_tile(blockIdx.x, 4 * num_tiles);
@@ -1137,6 +1133,7 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
     walk = min(walk, count);
     if (walk == 0) return;
 
+    const unsigned long long inside_mask = __ballot(inside);
     float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_a = 0.f;  // accum_rec / accum_red / accum_rea
     float last_alpha = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f, last_depth = 0.f;
     const float bg_dot = (background[0] * dLr + background[1] * dLg) + background[2] * dLb;  // left to right
@@ -1164,32 +1161,43 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
         unsigned long long todo = __ballot(mine && splat_reaches_rect(g_co, g_xy, qx0, qy0, kQ, kQ));
         if (todo == 0ull) continue;
         __syncthreads();
-        sA[lane] = BlendEntryA{g_xy.x, g_xy.y, g_co.x, g_co.y};
-        sB[lane] = BlendEntryB{g_co.z, -logf(255.0f * g_co.w) - 1.0e-4f};
-        sC[lane] = BlendEntryC{g_co.w, g_rgb.x, g_rgb.y, g_rgb.z};
-        sD[lane] = g_z;
-        sId[lane] = g_id;
+        {
+            float4* rec = reinterpret_cast<float4*>(&s_entry[lane]);
+            rec[0] = make_float4(g_xy.x, g_xy.y, g_co.x, g_co.y);
+            rec[1] = make_float4(g_co.z, -logf(255.0f * g_co.w) - 1.0e-4f, g_co.w, __uint_as_float(g_id));
+            rec[2] = make_float4(g_rgb.x, g_rgb.y, g_rgb.z, g_z);
+        }
         __syncthreads();
 
         while (todo != 0ull) {
             const int j = 63 - __builtin_clzll(todo);  // highest position first
             todo &= ~(1ull << j);
             const uint32_t pos = first + (uint32_t)j;
-            const BlendEntryA a = sA[j];
-            const BlendEntryB b = sB[j];
+            const float4* rec = reinterpret_cast<const float4*>(&s_entry[j]);
+            const float4 ra = rec[0], rb = rec[1];
+            struct { float x, y, cxx, cxy; } a = {ra.x, ra.y, ra.z, ra.w};
+            struct { float cyy, skip_below, opacity; } b = {rb.x, rb.y, rb.z};
             const float dx = a.x - fx, dy = a.y - fy;
             const float power = -0.5f * (a.cxx * dx * dx + b.cyy * dy * dy) - a.cxy * dx * dy;
-            bool contrib = inside && pos < last_contributor && !(power > 0.0f) && !(power < b.skip_below);
-            if (!__any(contrib)) continue;
-            const BlendEntryC c = sC[j];
-            const float z = sD[j];
+            // pixel predicates as wave-uniform masks, as in the forward blend (one ballot per comparison)
+            const unsigned long long live = __ballot(pos < last_contributor) & __ballot(!(power > 0.0f)) &
+                                            __ballot(!(power < b.skip_below)) & inside_mask;
+            if (live == 0ull) continue;
             const float G = exp_nonpositive(power);  // == expf on the contributing lanes' domain (power <= 0)
-            const float alpha = fminf(0.99f, c.opacity * G);
-            contrib = contrib && !(alpha < 1.0f / 255.0f);
+            const float alpha = fminf(0.99f, b.opacity * G);
+            const unsigned long long contrib = live & __ballot(!(alpha < 1.0f / 255.0f));
+            if (contrib == 0ull) continue;
+            const float4 cz = rec[2];  // r g b depth
+            struct { float r, g, b, opacity; } c = {cz.x, cz.y, cz.z, b.opacity};
+            const float z = cz.w;
             float g_cr = 0.f, g_cg = 0.f, g_cb = 0.f, g_dep = 0.f, g_mx = 0.f, g_my = 0.f, g_kx = 0.f, g_ky = 0.f,
                   g_kw = 0.f, g_op = 0.f;
-            if (contrib) {
-                T = T / (1.f - alpha);
+            if (__builtin_amdgcn_inverse_ballot_w64(contrib)) {
+                // One reciprocal serves the two divisions by (1 - alpha) (backward.cu:506,548).  Gradients are sums
+                // over atomics whose order is not the reference's anyway; the tolerance of the parity tests covers
+                // the 1-ulp difference between x * rcp(y) and x / y.
+                const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                T = T * inv_1ma;
                 const float dchannel_dcolor = alpha * T;
                 float dL_dalpha = 0.0f;
                 acc_r = last_alpha * last_r + (1.f - last_alpha) * acc_r;
@@ -1212,7 +1220,7 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
                 dL_dalpha += (1.f - acc_a) * dLa;
                 dL_dalpha *= T;
                 last_alpha = alpha;
-                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                dL_dalpha += (-T_final * inv_1ma) * bg_dot;
                 const float dL_dG = c.opacity * dL_dalpha;
                 const float gdx = G * dx, gdy = G * dy;
                 const float dG_ddelx = -gdx * a.cxx - gdy * a.cxy;
@@ -1224,14 +1232,13 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
                 g_kw = -0.5f * gdy * dy * dL_dG;
                 g_op = G * dL_dalpha;
             }
-            if (!__any(contrib)) continue;
             // r|g, b|depth, mx|my, kxx|kxy, kyy|opacity -> rows [r b g depth], [mx kxx my kxy], [kyy - opacity -]
             const float x0 = row_sum_all_lanes(fold16(fold32(g_cr, g_cg), fold32(g_cb, g_dep)));
             const float x1 = row_sum_all_lanes(fold16(fold32(g_mx, g_my), fold32(g_kx, g_ky)));
             const float x2 = row_sum_all_lanes(fold16(fold32(g_kw, g_op), 0.f));
             if (my_slot >= 0) {  // ten lanes, one 64-byte line: a single atomic instruction per (quadrant, entry)
                 const float v = red_k == 0 ? x0 : red_k == 1 ? x1 : x2;
-                atomicAdd(accum + (size_t)kAccumStride * sId[j] + my_slot, v);
+                atomicAdd(accum + (size_t)kAccumStride * __float_as_uint(rb.w) + my_slot, v);
             }
         }
     }
