@@ -639,3 +639,53 @@ def test_blend_exp_is_expf_on_its_domain():
     assert _lib.lib.gsr_selftest_exp(0, 1, bad.data_ptr(), stream) == 0
     torch.cuda.synchronize()
     assert int(bad.item()) == 0
+
+
+@pytest.mark.parametrize("cull", [False, True])
+def test_4k_frame_sort_paths_agree_and_lists_are_ordered(cull):
+    """3840x2160 (32 400 tiles: 15-bit tile keys, second radix pass 7 bits wide), splats from sub-pixel to a third of
+    the screen: both sort implementations give the same arrays, tile keys ascend, depth ascends inside a tile,
+    offsets end at the live-pair count."""
+    from autovfx_amd import _lib
+    cloud = scenes.config_c2(P=200_000, seed=21)
+    cloud.scales[:300] *= 60.0            # screen-filling splats among tiny ones
+    cloud.scales[300:5000] *= 0.05
+    cam = orbit_cameras(50, 3840, 2160)[7]
+    outs = []
+    for impl in (0, 1):
+        _lib.set_option(_lib.OPT_SORT_IMPL, impl)
+        try:
+            outs.append(hip_forward_raw(cloud, cam, bg=(0.0, 0.1, 0.0), debug=False, cull=cull))
+        finally:
+            _lib.set_option(_lib.OPT_SORT_IMPL, 1)
+    a, b = outs
+    for k in ("color", "depth", "alpha", "n_contrib", "radii", "point_list", "tile_keys", "ranges", "point_offsets",
+              "num_rendered", "live_pairs"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=f"4k: {k} differs between sort implementations")
+    tk = b["tile_keys"].astype(np.int64)
+    assert tk.max() < 240 * 135 and (np.diff(tk) >= 0).all()
+    d = b["depths"].view(np.uint32)[b["point_list"]].astype(np.int64)
+    assert (np.diff(d)[np.diff(tk) == 0] >= 0).all()
+    assert int(b["point_offsets"][-1]) == b["live_pairs"] == len(b["point_list"])
+    if not cull:
+        assert b["live_pairs"] == b["num_rendered"] == int(b["tiles_touched"].astype(np.int64).sum())
+    assert b["tiles_touched"].max() > 32        # full-rectangle (unmasked) splats are present
+
+
+def test_nothing_visible_and_single_gaussian():
+    """Degenerate sizes through the whole pipeline: every Gaussian behind the camera (no pairs at all) and P = 1."""
+    cloud, cam = scenes.config_c1(P=500, seed=3), scenes.c1_camera(96, 64)
+    behind = scenes.GaussianCloud(cloud.means3D.clone(), cloud.opacities, cloud.scales, cloud.rotations, cloud.shs, None, 3)
+    vm = torch.as_tensor(cam.world_view_transform, dtype=torch.float32)
+    z_view = behind.means3D @ vm[:3, 2] + vm[3, 2]
+    behind.means3D -= 2.0 * z_view.clamp(min=0.0)[:, None] * vm[:3, 2][None, :] + 1.0 * vm[:3, 2][None, :]   # mirror behind the camera
+    out = hip_forward_raw(behind, cam, bg=(0.2, 0.3, 0.4), cull=True)
+    assert out["num_rendered"] == 0 and out["live_pairs"] == 0 and not out["ranges"].any() and not out["n_contrib"].any()
+    np.testing.assert_array_equal(out["color"], np.broadcast_to(np.float32([0.2, 0.3, 0.4])[:, None, None], out["color"].shape))
+    assert not out["alpha"].any() and not out["radii"].any() and not out["point_offsets"].any()
+    one = scenes.config_c1(P=1, seed=4)
+    ref = cpu_oracle.forward(**oracle_kwargs(one, cam, bg=(0.0, 0.0, 0.0)))
+    got = hip_forward_raw(one, cam, bg=(0.0, 0.0, 0.0), cull=False)
+    np.testing.assert_array_equal(got["radii"], ref["radii"])
+    assert got["num_rendered"] == ref["num_rendered"]
+    np.testing.assert_allclose(got["color"], ref["color"], atol=1e-4)
