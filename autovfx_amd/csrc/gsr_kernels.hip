@@ -198,6 +198,7 @@ __device__ __forceinline__ bool splat_reaches_tile(float4 co, float2 c, int tile
 __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Camera cam, GeometryArrays out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool in_range = i < in.P;  // every lane stays to the end: the tile-mask phase below is wave-cooperative
+    GSR_KTRACE(blockIdx.x, 0);
 
     const float* __restrict__ vm = cam.viewmatrix;
     const float* __restrict__ pm = cam.projmatrix;
@@ -310,6 +311,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
         }
     }
     }  // in_range
+    GSR_KTRACE(blockIdx.x, 1);
 
     // ---- exact-image tile culling, wave-cooperative ----
     // A lane looping over the tiles of its own rectangle makes the wave run as long as its largest rectangle
@@ -368,6 +370,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
         }
     }
 
+    GSR_KTRACE(blockIdx.x, 2);
     if (in_range) {
         out.radii[i] = radius_out;
         *reinterpret_cast<uint4*>(out.bins + i) = make_uint4(bin.xy0, bin.width, bin.mask, bin.count);
@@ -386,6 +389,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
         if (wave_tot != 0ull) atomicAdd(out.counters->pair_totals + slot, wave_tot);
         atomicAdd(out.counters->visible + slot, (uint32_t)__popcll(emitting));
     }
+    GSR_KTRACE(blockIdx.x, 3);
 }
 
 __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means3D,
@@ -952,7 +956,7 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
 
     const uint2 range = ranges[tile];
     const uint32_t count = range.y - range.x;
-    GSR_KTRACE(blockIdx.x, 0);
+    GSR_KTRACE(blockIdx.x, 4);
 
     float2 g_xy = make_float2(0.f, 0.f);
     float4 g_co = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1023,8 +1027,8 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
     }
 
 #ifdef GSR_KERNEL_TRACE
-    GSR_KTRACE(blockIdx.x, 1);
-    if (threadIdx.x == 0 && g_kernel_trace) g_kernel_trace[(size_t)blockIdx.x * 8 + 2] = count;
+    GSR_KTRACE(blockIdx.x, 5);
+    if (threadIdx.x == 0 && g_kernel_trace) g_kernel_trace[(size_t)blockIdx.x * 8 + 6] = count;
 #endif
     if (inside) {
         const size_t plane = (size_t)W * (size_t)H;

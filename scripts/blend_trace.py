@@ -27,8 +27,8 @@ def main():
     rasterize(cloud, cam, bg); torch.cuda.synchronize()
     _lib.lib.gsr_debug_set_trace(None)
     t = trace.cpu().numpy().reshape(-1, 8)
-    t = t[t[:, 0] > 0]
-    start, end, count = t[:, 0] * 0.01, t[:, 1] * 0.01, t[:, 2]
+    t = t[t[:, 4] > 0]
+    start, end, count = t[:, 4] * 0.01, t[:, 5] * 0.01, t[:, 6]   # the blend stamps slots 4, 5, 6 of its record
     t0 = start.min(); start -= t0; end -= t0
     dur = end - start
     print(f"variant {args.variant}: waves {len(t)}  span {end.max():.1f} us  sum of wave lives {dur.sum() / 1e3:.1f} ms  "
