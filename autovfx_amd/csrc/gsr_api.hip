@@ -3,7 +3,8 @@
 // Mirrors what CudaRasterizer::Rasterizer::forward does on the host
 // (DGR/cuda_rasterizer/rasterizer_impl.cu:197-339): carve scratch out of caller-provided arenas
 // (rasterizer_impl.h:22-27,66-72), run the stages, read num_rendered back once to size the binning
-// arena (:282), return it.  The stage list itself is this library's own (see gsr_sort.hip).
+// arena (:282), return it.  The stage list itself is this library's own (gsr_kernels.hip, gsr_radix.hip;
+// gsr_sort.hip holds the rocPRIM passes kept as the GSR_OPT_SORT_IMPL = 0 comparison path).
 #include "../../include/gsr.h"
 #include "gsr_internal.h"
 

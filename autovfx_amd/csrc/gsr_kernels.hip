@@ -307,6 +307,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
                     cand_centre = make_float2(px, py);
                 }
                 key = __float_as_uint(vz);
+                if (key == kCulledKey) key = kCulledKey - 1u;  // a NaN depth with an all-ones payload must not look culled
             }
         }
     }

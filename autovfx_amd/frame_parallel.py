@@ -161,6 +161,38 @@ def gather_frames(local: torch.Tensor, num_frames: int, dst: int = 0, group=None
     return out
 
 
+def broadcast_cloud(cloud: Optional[GaussianCloud], src: int = 0, device=None, group=None) -> GaussianCloud:
+    """Give every rank the Gaussians that only rank ``src`` has loaded: the shapes travel as one
+    small object broadcast, the parameters as ONE broadcast of a flat fp32 buffer (C3: 0.71 GB, once per job).
+    Without a process group it returns ``cloud`` unchanged."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return cloud
+    rank = dist.get_rank(group)
+    names = ("means3D", "opacities", "scales", "rotations", "shs", "colors_precomp")
+    meta = [None]
+    if rank == src:
+        meta = [{"shapes": {n: (None if getattr(cloud, n) is None else tuple(getattr(cloud, n).shape)) for n in names},
+                 "sh_degree": int(cloud.sh_degree)}]
+    dist.broadcast_object_list(meta, src=src, group=group)
+    shapes = meta[0]["shapes"]
+    if device is None:
+        device = cloud.means3D.device if rank == src else torch.device("cpu")
+    sizes = {n: int(torch.Size(sh).numel()) for n, sh in shapes.items() if sh is not None}
+    flat = torch.empty(sum(sizes.values()), dtype=torch.float32, device=device)
+    if rank == src:
+        torch.cat([getattr(cloud, n).detach().to(device=device, dtype=torch.float32).reshape(-1) for n in sizes], out=flat)
+    dist.broadcast(flat, src=src, group=group)
+    parts, at = {}, 0
+    for n in names:
+        if shapes[n] is None:
+            parts[n] = None
+        else:
+            parts[n] = flat[at:at + sizes[n]].view(shapes[n])
+            at += sizes[n]
+    return GaussianCloud(parts["means3D"], parts["opacities"], parts["scales"], parts["rotations"], parts["shs"],
+                         parts["colors_precomp"], meta[0]["sh_degree"])
+
+
 def render_and_gather(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids: Sequence[int], bg: torch.Tensor,
                       dst: int = 0, render_fn: RenderFn = rasterize, streams: int = 1, chunks: int = 4,
                       group=None) -> Optional[torch.Tensor]:

@@ -47,6 +47,29 @@ def _worker(rank, world, port, num_frames, out_path):
         dist.destroy_process_group()
 
 
+def _worker_broadcast(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cloud = scenes.config_c4(P=200, seed=6) if rank == 0 else None      # only rank 0 "has the file"
+        got = fp.broadcast_cloud(cloud, src=0)
+        torch.save({k: getattr(got, k) for k in ("means3D", "opacities", "scales", "rotations", "shs", "colors_precomp",
+                                                   "sh_degree")}, os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_cloud_replicates_rank0(tmp_path):
+    mp.spawn(_worker_broadcast, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    want = scenes.config_c4(P=200, seed=6)
+    for r in range(2):
+        got = torch.load(str(tmp_path / f"rank{r}.pt"))
+        for k in ("means3D", "opacities", "scales", "rotations", "colors_precomp"):
+            assert torch.equal(got[k], getattr(want, k)), (r, k)
+        assert got["shs"] is None and got["sh_degree"] == want.sh_degree
+    assert fp.broadcast_cloud(want) is want      # no process group: identity
+
+
 def _worker_pipelined(rank, world, port, per_rank, out_path):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
