@@ -318,13 +318,17 @@ int gsr_pack_rgba8(const float* color, const float* alpha, uint8_t* rgba8, int w
     return GSR_OK;
 }
 
-int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_alloc, void* binning_user,
-                gsr_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background,
-                int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
-                const float* opacities, const float* scales, float scale_modifier, const float* rotations,
-                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
-                const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
-                float* out_depth, float* out_alpha, int* radii, int debug, void* stream_) {
+} // extern "C"
+
+namespace {
+int forward_impl(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_alloc, void* binning_user,
+                 gsr_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background,
+                 int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                 float* out_depth, float* out_alpha, int* radii, int debug, void* stream_,
+                 const float* extra_features, float* out_extra) {
     hipStream_t stream = (hipStream_t)stream_;
     if (P < 0 || width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARG, "bad sizes P=%d W=%d H=%d", P, width, height);
     if (P == 0) return 0;  // rasterize_points.cu:83: outputs stay as the binding zero-filled them
@@ -542,12 +546,43 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
 
     const float* features = colors_precomp != nullptr ? colors_precomp : ga.rgb;
     GSR_HIP(gsr::launch_blend(cam, g_options[GSR_OPT_BLEND_VARIANT], g_options[GSR_OPT_BLEND_LDS_PAD], ranges, point_list, ga.raster, features, background,
-                              out_color, out_depth, out_alpha, n_contrib, stream));
+                              out_color, out_depth, out_alpha, n_contrib, stream, extra_features, out_extra));
     GSR_STAGE_CHECK("blend");
     stamp(7, stream);
     if (g_timing) ++g_timed_calls;
     g_have_offsets = true;
     return (int)num_rendered;
+}
+} // namespace
+
+extern "C" {
+
+int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_alloc, void* binning_user,
+                gsr_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background,
+                int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
+                const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                float* out_depth, float* out_alpha, int* radii, int debug, void* stream) {
+    return forward_impl(geom_alloc, geom_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background,
+                        width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                        cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color,
+                        out_depth, out_alpha, radii, debug, stream, nullptr, nullptr);
+}
+
+int gsr_forward_extra(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_alloc, void* binning_user,
+                      gsr_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background,
+                      int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
+                      const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                      const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                      const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                      float* out_depth, float* out_alpha, int* radii, const float* extra_features, float* out_extra,
+                      int debug, void* stream) {
+    if (P > 0 && (!extra_features || !out_extra)) return fail(GSR_ERR_INVALID_ARG, "null extra feature pointer");
+    return forward_impl(geom_alloc, geom_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background,
+                        width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                        cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color,
+                        out_depth, out_alpha, radii, debug, stream, extra_features, out_extra);
 }
 
 } // extern "C"

@@ -96,7 +96,9 @@ hipError_t launch_tile_ranges(uint32_t num_rendered, int num_tiles, const uint32
 // variant 0: one wave per tile, 4 pixels per lane; variant 1: one wave per 8x8 quadrant
 hipError_t launch_blend(const Camera& cam, int variant, int lds_pad_bytes, const uint2* ranges, const uint32_t* point_list,
                         const SplatRaster* raster, const float* features, const float* background, float* out_color,
-                        float* out_depth, float* out_alpha, uint32_t* n_contrib, hipStream_t stream);
+                        float* out_depth, float* out_alpha, uint32_t* n_contrib, hipStream_t stream,
+                        const float* extra_features = nullptr /*[P,3]: a second feature set ...*/,
+                        float* out_extra = nullptr /*... composited into [3,H,W] in the same walk*/);
 
 // First 256 bytes of each scratch arena: what the backward pass needs to find the forward's arrays
 // again.  The reference re-derives its layout from sizes (rasterizer_impl.cu:381-383 fromChunk);

@@ -925,17 +925,25 @@ __global__ void exp_selftest_kernel(uint32_t first_bits, uint32_t count, unsigne
     if (__float_as_uint(a) != __float_as_uint(b) && !(a != a && b != b)) atomicAdd(mismatches, 1ull);
 }
 
+// kExtra: a second per-Gaussian feature triple (extra_features[P,3] -> out_extra[3,H,W]) is composited in the
+// same walk with the same alpha and transmittance -- what the reference's render() obtains from a second full
+// rasterizer pass for its normal map (gaussian_renderer/__init__.py:176-184): identical arithmetic per channel,
+// one list walk instead of two.
+template <bool kExtra>
 __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int grid_x, int num_tiles,
                                                             const uint2* __restrict__ ranges,
                                                             const uint32_t* __restrict__ point_list,
                                                             const SplatRaster* __restrict__ raster,
                                                             const float* __restrict__ features,
+                                                            const float* __restrict__ extra_features,
                                                             const float* __restrict__ background,
                                                             float* __restrict__ out_color,
                                                             float* __restrict__ out_depth,
                                                             float* __restrict__ out_alpha,
+                                                            float* __restrict__ out_extra,
                                                             uint32_t* __restrict__ n_contrib) {
     __shared__ BlendEntry s_entry[64];
+    __shared__ float4 s_extra[kExtra ? 64 : 1];
 
     constexpr int kQ = kTile / 2;
     const int item = xcd_band_tile(blockIdx.x, 4 * num_tiles);  // the 4 quadrants of a tile share an XCD
@@ -953,6 +961,7 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
     if (done_mask == ~0ull) return;  // quadrant entirely outside the image: nothing to write
 
     float T = 1.f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dz = 0.f;
+    float Er = 0.f, Eg = 0.f, Eb = 0.f;
     uint32_t last = 0u;
 
     const uint2 range = ranges[tile];
@@ -961,7 +970,7 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
 
     float2 g_xy = make_float2(0.f, 0.f);
     float4 g_co = make_float4(0.f, 0.f, 0.f, 0.f);
-    F3 g_rgb = {0.f, 0.f, 0.f};
+    F3 g_rgb = {0.f, 0.f, 0.f}, g_ext = {0.f, 0.f, 0.f};
     float g_z = 0.f;
     auto gather = [&](uint32_t first) {
         const uint32_t e = first + (uint32_t)lane;
@@ -973,6 +982,7 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
             g_co = make_float4(r0.z, r0.w, r1.x, r1.y);
             g_z = r1.z;
             g_rgb = ld3(features + 3 * (size_t)id);
+            if (kExtra) g_ext = ld3(extra_features + 3 * (size_t)id);
         }
     };
     if (count > 0) gather(0);
@@ -986,6 +996,7 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
             rec[0] = make_float4(g_xy.x, g_xy.y, g_co.x, g_co.y);
             rec[1] = make_float4(g_co.z, -logf(255.0f * g_co.w) - 1.0e-4f, g_co.w, 0.f);
             rec[2] = make_float4(g_rgb.x, g_rgb.y, g_rgb.z, g_z);
+            if (kExtra) s_extra[lane] = make_float4(g_ext.x, g_ext.y, g_ext.z, 0.f);
             __syncthreads();
         }
         if (first + 64 < count) gather(first + 64);
@@ -1019,6 +1030,12 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
                 Cg += c.y * alpha * T;
                 Cb += c.z * alpha * T;
                 Dz += c.w * alpha * T;
+                if (kExtra) {
+                    const float4 e = s_extra[j];
+                    Er += e.x * alpha * T;
+                    Eg += e.y * alpha * T;
+                    Eb += e.z * alpha * T;
+                }
                 T = test_T;
                 last = first + (uint32_t)j + 1u;
             }
@@ -1040,6 +1057,11 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
         out_color[plane + pid] = Cg + T * background[1];
         out_color[2 * plane + pid] = Cb + T * background[2];
         out_depth[pid] = Dz;
+        if (kExtra) {
+            out_extra[pid] = Er + T * background[0];
+            out_extra[plane + pid] = Eg + T * background[1];
+            out_extra[2 * plane + pid] = Eb + T * background[2];
+        }
     }
 }
 
@@ -1896,14 +1918,20 @@ hipError_t launch_pack_rgba8(const float* color, const float* alpha, uint8_t* ou
 hipError_t launch_blend(const Camera& cam, int variant, int lds_pad_bytes, const uint2* ranges,
                         const uint32_t* point_list, const SplatRaster* raster, const float* features,
                         const float* background, float* out_color, float* out_depth, float* out_alpha,
-                        uint32_t* n_contrib, hipStream_t stream) {
+                        uint32_t* n_contrib, hipStream_t stream, const float* extra_features, float* out_extra) {
     const int T = cam.grid_x * cam.grid_y;
+    if (extra_features != nullptr) {  // two feature sets in one walk: the quadrant kernel only
+        hipLaunchKernelGGL(blend_quadrant_kernel<true>, dim3(4 * T), dim3(64), (size_t)lds_pad_bytes, stream, cam.width,
+                           cam.height, cam.grid_x, T, ranges, point_list, raster, features, extra_features, background,
+                           out_color, out_depth, out_alpha, out_extra, n_contrib);
+        return hipGetLastError();
+    }
     if (variant == 1) {
         // lds_pad_bytes of unused dynamic LDS cap how many single-wave workgroups share a CU, which leaves
         // wave slots free for the memory-bound kernels of another frame running on a second stream
-        hipLaunchKernelGGL(blend_quadrant_kernel, dim3(4 * T), dim3(64), (size_t)lds_pad_bytes, stream, cam.width, cam.height, cam.grid_x,
-                           T, ranges, point_list, raster, features, background, out_color,
-                           out_depth, out_alpha, n_contrib);
+        hipLaunchKernelGGL(blend_quadrant_kernel<false>, dim3(4 * T), dim3(64), (size_t)lds_pad_bytes, stream, cam.width, cam.height, cam.grid_x,
+                           T, ranges, point_list, raster, features, (const float*)nullptr, background, out_color,
+                           out_depth, out_alpha, (float*)nullptr, n_contrib);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(blend_kernel, dim3(T), dim3(64), 0, stream, cam.width, cam.height, cam.grid_x, T, ranges,

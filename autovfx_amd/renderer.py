@@ -109,8 +109,9 @@ def render(viewpoint_camera, pc, pipe=PipelineParams, bg_color: Optional[torch.T
     else:
         scales, rotations = pc.get_scaling, pc.get_rotation
 
-    # With autograd off and the data on the GPU, the elementwise work around the two passes runs as two fused
-    # kernels (gsr_view_normals / gsr_normal_maps) instead of ~40 PyTorch launches; same formulas (tests).
+    # With autograd off and the data on the GPU, the elementwise work around the passes runs as two fused kernels
+    # (gsr_view_normals / gsr_normal_maps) instead of ~40 PyTorch launches, and the normal pass is folded into the
+    # first one (gsr_forward_extra); same formulas, same images (tests).
     fused = (not torch.is_grad_enabled()) and xyz.is_cuda and xyz.dtype == torch.float32 and hasattr(pc, "get_minimum_axis")
     dir_pp_normalized = None
     if not fused:
@@ -125,24 +126,34 @@ def render(viewpoint_camera, pc, pipe=PipelineParams, bg_color: Optional[torch.T
     else:
         colors_precomp = override_color
 
-    rendered_image, depth_image, alpha_image, radii = rasterizer(
-        means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity, scales=scales,
-        rotations=rotations, cov3D_precomp=cov3D_precomp)
-    rendered_image = torch.cat((rendered_image, alpha_image), dim=0)
-    depth_image = depth_image.squeeze(0)
-
     h, w = int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)
     fx, fy = fov2focal(viewpoint_camera.FoVx, w), fov2focal(viewpoint_camera.FoVy, h)
     c2w = viewpoint_camera.world_view_transform.inverse()
     if fused:
+        # One pass: the per-Gaussian normals ride through the SAME walk of the per-tile lists as a second feature
+        # set (gsr_forward_extra); the normal image is what the reference's second pass (:176-184) returns, bit for bit.
+        from diff_gaussian_rasterization import _C
         normal_normed = _fused_view_normals(xyz, pc.get_minimum_axis, viewpoint_camera.camera_center)
-    else:
-        normal_normed = pc.get_normal(dir_pp_normalized=dir_pp_normalized) * 0.5 + 0.5
-    normal_image = rasterizer(means3D=means3D, means2D=means2D, shs=None, colors_precomp=normal_normed,
-                              opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)[0]
-    if fused:
+        absent = torch.Tensor([])
+        s_ = settings
+        (_n, rendered_image, depth_image, alpha_image, radii, _g, _b, _i, normal_image) = _C.rasterize_gaussians_extra(
+            s_.bg, means3D, absent if colors_precomp is None else colors_precomp, opacity,
+            absent if scales is None else scales, absent if rotations is None else rotations, s_.scale_modifier,
+            absent if cov3D_precomp is None else cov3D_precomp, s_.viewmatrix, s_.projmatrix, s_.tanfovx, s_.tanfovy,
+            s_.image_height, s_.image_width, absent if shs is None else shs, s_.sh_degree, s_.campos, s_.prefiltered,
+            s_.debug, normal_normed)
+        rendered_image = torch.cat((rendered_image, alpha_image), dim=0)
+        depth_image = depth_image.squeeze(0)
         normal_image, pseudo_normal = _fused_normal_maps(normal_image, depth_image, c2w, fx, fy, w / 2, h / 2)
     else:
+        rendered_image, depth_image, alpha_image, radii = rasterizer(
+            means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity, scales=scales,
+            rotations=rotations, cov3D_precomp=cov3D_precomp)
+        rendered_image = torch.cat((rendered_image, alpha_image), dim=0)
+        depth_image = depth_image.squeeze(0)
+        normal_normed = pc.get_normal(dir_pp_normalized=dir_pp_normalized) * 0.5 + 0.5
+        normal_image = rasterizer(means3D=means3D, means2D=means2D, shs=None, colors_precomp=normal_normed,
+                                  opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)[0]
         normal_image = (normal_image - 0.5) * 2.0
         normal_image = torch.nn.functional.normalize(normal_image.permute(1, 2, 0), p=2, dim=-1)
         directions = get_ray_directions(h, w, fx, fy, w / 2, h / 2, depth_image.device)

@@ -116,6 +116,29 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
                         prefiltered, debug) -> Tuple[int, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor,
                                                      torch.Tensor, torch.Tensor, torch.Tensor]:
+    """The reference's 19-argument forward (``DGR/rasterize_points.h:18-38``) and its 8-tuple."""
+    return _rasterize(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                      viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                      prefiltered, debug, None)[:8]
+
+
+def rasterize_gaussians_extra(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                              viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                              prefiltered, debug, extra_colors):
+    """``rasterize_gaussians`` plus a second feature triple per Gaussian composited in the same pass
+    (``gsr_forward_extra``): returns the 8-tuple and ``extra_image[3,H,W]``, which equals the colour image of a
+    second call with ``colors = extra_colors`` bit for bit.  Not part of the reference surface; used by
+    ``autovfx_amd.renderer.render`` for the normal map."""
+    if extra_colors is None or extra_colors.dim() != 2 or extra_colors.shape != (means3D.size(0), 3):
+        raise RuntimeError("extra_colors must have dimensions (num_points, 3)")
+    return _rasterize(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                      viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                      prefiltered, debug, extra_colors)
+
+
+def _rasterize(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+               viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+               prefiltered, debug, extra_colors):
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     device = _require_gpu(means3D, "means3D")
@@ -128,6 +151,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     out_depth = make((1, H, W), dtype=torch.float32, device=device)
     out_alpha = make((1, H, W), dtype=torch.float32, device=device)
     radii = make((P,), dtype=torch.int32, device=device)
+    out_extra = make((3, H, W), dtype=torch.float32, device=device) if extra_colors is not None else None
     scratch = _CallScratch(device)
     rendered = 0
     geometry_inputs = (means3D, opacity, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos)
@@ -137,7 +161,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                               bool(prefiltered), _lib.get_option(_lib.OPT_TILE_CULL),
                                               torch.cuda.current_stream(device).cuda_stream))
         hit = getattr(_tls, "cache", None)
-        if hit is not None and hit["key"] == key and colors.numel() != 0 and sh.numel() == 0:
+        if hit is not None and hit["key"] == key and colors.numel() != 0 and sh.numel() == 0 and extra_colors is None:
             cache_stats["hits"] += 1
             return _blend_cached(hit, background, colors, device, H, W, out_color, out_depth, out_alpha)
         cache_stats["misses"] += 1
@@ -152,12 +176,17 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         try:
             with torch.cuda.device(device):
                 stream = torch.cuda.current_stream(device).cuda_stream
-                rendered = _lib.lib.gsr_forward(
-                    _GEOM_CB, None, _BINNING_CB, None, _IMAGE_CB, None, P, int(degree), M, _ptr(bg_), W, H,
-                    _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_),
-                    _ptr(cov_), _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx), float(tan_fovy),
-                    1 if prefiltered else 0, out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(),
-                    radii.data_ptr(), 1 if debug else 0, ctypes.c_void_p(stream))
+                head = (_GEOM_CB, None, _BINNING_CB, None, _IMAGE_CB, None, P, int(degree), M, _ptr(bg_), W, H,
+                        _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(op_), _ptr(sc_), float(scale_modifier), _ptr(rot_),
+                        _ptr(cov_), _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx), float(tan_fovy),
+                        1 if prefiltered else 0, out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(),
+                        radii.data_ptr())
+                if extra_colors is None:
+                    rendered = _lib.lib.gsr_forward(*head, 1 if debug else 0, ctypes.c_void_p(stream))
+                else:
+                    ext_ = _f32c("extra_colors", extra_colors, device)
+                    rendered = _lib.lib.gsr_forward_extra(*head, ext_.data_ptr(), out_extra.data_ptr(),
+                                                          1 if debug else 0, ctypes.c_void_p(stream))
         finally:
             _tls.call = None
         if rendered < 0:
@@ -171,7 +200,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                           "rendered": rendered, "radii": radii, "geom": scratch.buffers["geom"],
                           "binning": scratch.buffers["binning"], "image": scratch.buffers["image"]}
     return (rendered, out_color, out_depth, out_alpha, radii, scratch.buffers["geom"], scratch.buffers["binning"],
-            scratch.buffers["image"])
+            scratch.buffers["image"], out_extra)
 
 
 def _blend_cached(hit, background, colors, device, H, W, out_color, out_depth, out_alpha):
@@ -187,7 +216,7 @@ def _blend_cached(hit, background, colors, device, H, W, out_color, out_depth, o
     if rc != 0:
         raise RuntimeError(f"gsr_blend failed ({rc}): {_lib.last_error()}")
     _tls.last_layout = lay
-    return hit["rendered"], out_color, out_depth, out_alpha, hit["radii"].clone(), geom, binning, image
+    return hit["rendered"], out_color, out_depth, out_alpha, hit["radii"].clone(), geom, binning, image, None
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,

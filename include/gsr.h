@@ -86,6 +86,22 @@ GSR_API int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user,
                 float* out_color, float* out_depth, float* out_alpha, int* radii /*nullable*/,
                 int debug, void* stream);
 
+/* gsr_forward with a SECOND per-Gaussian feature triple composited in the same walk of the per-tile lists:
+ * out_extra[3,H,W] = sum_i extra_features[i] * alpha_i * T_i + T_final * background, exactly what a second
+ * gsr_forward call with colors_precomp = extra_features would put into its out_color (same alpha, same
+ * transmittance, same operation order), for the cost of three more multiply-adds per contributing pair instead of
+ * a second pass.  The reference's render() makes that second pass for its normal map
+ * (sugar/gaussian_splatting/gaussian_renderer/__init__.py:176-184). */
+GSR_API int gsr_forward_extra(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_alloc, void* binning_user,
+                              gsr_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background,
+                              int width, int height, const float* means3D, const float* shs /*nullable*/,
+                              const float* colors_precomp /*nullable*/, const float* opacities,
+                              const float* scales /*nullable*/, float scale_modifier, const float* rotations /*nullable*/,
+                              const float* cov3D_precomp /*nullable*/, const float* viewmatrix, const float* projmatrix,
+                              const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                              float* out_depth, float* out_alpha, int* radii /*nullable*/,
+                              const float* extra_features /*[P,3]*/, float* out_extra /*[3,H,W]*/, int debug, void* stream);
+
 /* present[i] = (view-space z of means3D[i]) > 0.2 ; present is a device array of P bytes (bool). */
 GSR_API int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream);

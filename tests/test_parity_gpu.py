@@ -689,3 +689,40 @@ def test_nothing_visible_and_single_gaussian():
     np.testing.assert_array_equal(got["radii"], ref["radii"])
     assert got["num_rendered"] == ref["num_rendered"]
     np.testing.assert_allclose(got["color"], ref["color"], atol=1e-4)
+
+
+@pytest.mark.parametrize("case", ["c1", "c2_mid", "ragged_precomp"])
+def test_second_feature_set_equals_a_second_pass(case):
+    """gsr_forward_extra composites a second feature triple in the same walk: its image must be, bit for bit, the
+    colour image of a second full call with colors_precomp = that triple; everything else equals the plain call."""
+    from diff_gaussian_rasterization import _C
+    dev = "cuda:0"
+    if case == "c1":
+        cloud, cam = scenes.config_c1(), scenes.c1_camera()
+    elif case == "c2_mid":
+        cloud, cam = scenes.config_c2(P=300_000, seed=4), orbit_cameras(200, 960, 540)[120]
+    else:
+        cloud, cam = scenes.config_c4(P=3000, seed=11), scenes.c1_camera(251, 131)
+    c = cloud.to(dev)
+    st = settings_for(cam, dev, (0.2, 0.4, 0.1), 1.0, cloud.sh_degree)
+    e = torch.Tensor([])
+    g = torch.Generator(device=dev).manual_seed(3)
+    extra = torch.rand((cloud.P, 3), generator=g, device=dev)
+    args = lambda colors, sh: (st.bg, c.means3D, colors, c.opacities, c.scales, c.rotations, 1.0, e, st.viewmatrix,
+                               st.projmatrix, st.tanfovx, st.tanfovy, st.image_height, st.image_width, sh, st.sh_degree,
+                               st.campos, False, False)
+    first = (e if c.colors_precomp is None else c.colors_precomp, e if c.shs is None else c.shs)
+    _C.set_geometry_cache(False)
+    try:
+        fused = _C.rasterize_gaussians_extra(*args(*first), extra)
+        plain = _C.rasterize_gaussians(*args(*first))
+        second = _C.rasterize_gaussians(*args(extra, e))
+    finally:
+        _C.set_geometry_cache(True)
+    torch.cuda.synchronize()
+    assert fused[0] == plain[0]
+    for i in (1, 2, 3, 4):
+        assert torch.equal(fused[i], plain[i]), i
+    assert torch.equal(fused[8], second[1])
+    for i in (2, 3):
+        assert torch.equal(second[i], plain[i])
