@@ -18,7 +18,7 @@ from __future__ import annotations
 import json
 import math
 from dataclasses import dataclass
-from typing import List, Sequence
+from typing import List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -74,6 +74,10 @@ class Camera:
     image_name: str = ""
     znear: float = 0.01
     zfar: float = 100.0
+    # ``world_view_transform.inverse()``, which render() needs every frame for the pseudo normals
+    # (gaussian_renderer/__init__.py:199); computing it on the GPU costs a host synchronisation per frame
+    # (torch.linalg.inv reads its status word back), so it is formed once where the camera is built.
+    view_world_transform: Optional[torch.Tensor] = None
 
     @property
     def tanfovx(self) -> float:
@@ -87,7 +91,8 @@ class Camera:
         return Camera(self.image_width, self.image_height, self.FoVx, self.FoVy,
                       self.world_view_transform.to(device), self.projection_matrix.to(device),
                       self.full_proj_transform.to(device), self.camera_center.to(device),
-                      self.image_name, self.znear, self.zfar)
+                      self.image_name, self.znear, self.zfar,
+                      None if self.view_world_transform is None else self.view_world_transform.to(device))
 
     @staticmethod
     def from_Rt(R: np.ndarray, T: np.ndarray, FoVx: float, FoVy: float, width: int, height: int,
@@ -95,8 +100,9 @@ class Camera:
         wv = torch.tensor(world_to_view(R, T)).transpose(0, 1).contiguous()
         pj = projection_matrix(znear, zfar, FoVx, FoVy).transpose(0, 1).contiguous()
         full = wv.unsqueeze(0).bmm(pj.unsqueeze(0)).squeeze(0).contiguous()
-        center = wv.inverse()[3, :3].contiguous()
-        return Camera(int(width), int(height), float(FoVx), float(FoVy), wv, pj, full, center, name, znear, zfar)
+        inv = wv.inverse().contiguous()
+        center = inv[3, :3].contiguous()
+        return Camera(int(width), int(height), float(FoVx), float(FoVy), wv, pj, full, center, name, znear, zfar, inv)
 
     @staticmethod
     def from_c2w(c2w: np.ndarray, fx: float, fy: float, width: int, height: int, name: str = "") -> "Camera":

@@ -89,7 +89,10 @@ def render(viewpoint_camera, pc, pipe=PipelineParams, bg_color: Optional[torch.T
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 
     xyz = pc.get_xyz
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True) + 0
+    if torch.is_grad_enabled():
+        screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True) + 0
+    else:   # only ever read through its gradient (densification statistics): nothing to add to without autograd
+        screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype)
     try:
         screenspace_points.retain_grad()
     except Exception:
@@ -128,7 +131,9 @@ def render(viewpoint_camera, pc, pipe=PipelineParams, bg_color: Optional[torch.T
 
     h, w = int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)
     fx, fy = fov2focal(viewpoint_camera.FoVx, w), fov2focal(viewpoint_camera.FoVy, h)
-    c2w = viewpoint_camera.world_view_transform.inverse()
+    c2w = getattr(viewpoint_camera, "view_world_transform", None)   # formed with the camera when it is ours
+    if c2w is None:
+        c2w = viewpoint_camera.world_view_transform.inverse()
     if fused:
         # One pass: the per-Gaussian normals ride through the SAME walk of the per-tile lists as a second feature
         # set (gsr_forward_extra); the normal image is what the reference's second pass (:176-184) returns, bit for bit.
