@@ -57,6 +57,16 @@ def test_argument_errors_do_not_need_a_device():
     assert L.gsr_backward(-1, 0, 0, 0, None, 8, 8, *bw_tail) == -1
     assert L.gsr_backward(0, 0, 0, 0, None, 8, 8, *bw_tail) == 0      # P == 0: nothing to do
     assert L.gsr_backward(4, 0, 0, 0, None, 8, 8, *bw_tail) == -1 and "null" in _lib.last_error()
+    assert L.gsr_view_normals(-1, None, None, None, None, None) == -1
+    assert L.gsr_view_normals(0, None, None, None, None, None) == 0
+    assert L.gsr_view_normals(5, None, None, None, None, None) == -1 and "null" in _lib.last_error()
+    assert L.gsr_normal_maps(0, 4, None, None, None, 1.0, 1.0, 0.0, 0.0, None, None, None) == -1
+    assert L.gsr_normal_maps(4, 4, None, None, None, 1.0, 1.0, 0.0, 0.0, None, None, None) == -1
+    assert L.gsr_radix_sort_pairs(5, 0, None, None, None, None, 0, None, 0, None, None) == -1      # bits out of range
+    assert L.gsr_radix_sort_pairs(0, 8, None, None, None, None, 0, None, 0, None, None) == 0       # nothing to sort
+    assert L.gsr_radix_sort_pairs(5, 8, None, None, None, None, 0, None, 0, None, None) == -1
+    assert L.gsr_radix_scratch_bytes(4096, 32) == (256 * 4 + 256) * 4 and L.gsr_radix_scratch_bytes(4097, 13) == (256 * 4 + 256) * 4
+    assert L.gsr_selftest_exp(0, 1, None, None) == -1
     assert L.gsr_mark_visible(-1, None, None, None, None, None) == -1
     assert L.gsr_mark_visible(0, None, None, None, None, None) == 0
     null_cb = ctypes.cast(None, _lib.ALLOC_FN)
@@ -70,6 +80,13 @@ def test_argument_errors_do_not_need_a_device():
     assert L.gsr_forward(*args, 5, 3, 16, None, 64, 64, None, None, None, None, None, 1.0, None, None, None, None,
                          None, 0.5, 0.5, 0, *tail) == -1
     assert "null" in _lib.last_error()
+    # the two-feature variant: same checks, plus its own two pointers
+    tail_extra = [None] * 4 + [None, None, 0, None]
+    assert L.gsr_forward_extra(*args, 0, 3, 16, None, 64, 64, None, None, None, None, None, 1.0, None, None, None, None,
+                               None, 0.5, 0.5, 0, *tail_extra) == 0
+    assert L.gsr_forward_extra(*args, 5, 3, 16, None, 64, 64, None, None, None, None, None, 1.0, None, None, None, None,
+                               None, 0.5, 0.5, 0, *tail_extra) == -1
+    assert "extra" in _lib.last_error()
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
