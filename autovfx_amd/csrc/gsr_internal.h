@@ -61,7 +61,7 @@ struct SplatRaster {
     float cxx, cxy, cyy;   // conic (inverse 2D covariance)
     float opacity;
     float depth;           // view-space z
-    float pad;
+    float skip_below;      // -ln(255 * opacity) - 1e-4: a power below this cannot reach alpha >= 1/255 (blend pre-test)
 };
 
 struct GeometryArrays {

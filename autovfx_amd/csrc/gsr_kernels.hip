@@ -171,11 +171,15 @@ __device__ __forceinline__ float edge_q(float A, float B, float C, float dx, flo
 // Pixel rectangle [px_first, px_first + w - 1] x [py_first, py_first + h - 1].
 // The hardware reciprocal / log2 (1 ulp) are enough here: a slightly misplaced edge minimiser
 // changes q only to second order, and the log error (~1e-6) is far inside the 1e-3 margin.
-__device__ __forceinline__ bool splat_reaches_rect(float4 co, float2 c, int px_first, int py_first, int w, int h) {
+// `skip_below` is the splat's -ln(255 o) - 1e-4 (SplatRaster::skip_below, computed once per Gaussian): the budget
+// ln(255 o) is recovered from it; o <= 0 gives budget -inf (nothing visible), NaN keeps the pair.
+__device__ __forceinline__ float blend_skip_below(float opacity) { return -logf(255.0f * opacity) - 1.0e-4f; }
+
+__device__ __forceinline__ bool splat_reaches_rect(float4 co, float skip_below, float2 c, int px_first, int py_first, int w,
+                                                   int h) {
     const float A = co.x, B = co.y, C = co.z;
     if (!(A > 0.f) || !(C > 0.f) || !((B * B) < 0.99f * (A * C))) return true;
-    // ln(255 o); o <= 0 gives -inf (nothing visible), NaN keeps the pair
-    const float budget = 0.69314718f * __builtin_amdgcn_logf(255.0f * co.w);
+    const float budget = -skip_below - 1.0e-4f;
     const float x_lo = c.x - (float)(px_first + w - 1), x_hi = c.x - (float)px_first;
     const float y_lo = c.y - (float)(py_first + h - 1), y_hi = c.y - (float)py_first;
     if (x_lo <= 0.f && x_hi >= 0.f && y_lo <= 0.f && y_hi >= 0.f) return true;  // centre inside the rectangle
@@ -187,8 +191,8 @@ __device__ __forceinline__ bool splat_reaches_rect(float4 co, float2 c, int px_f
     return !(qmin * 0.998f - 1.0e-3f > budget);
 }
 
-__device__ __forceinline__ bool splat_reaches_tile(float4 co, float2 c, int tile_x, int tile_y) {
-    return splat_reaches_rect(co, c, tile_x * kTile, tile_y * kTile, kTile, kTile);
+__device__ __forceinline__ bool splat_reaches_tile(float4 co, float skip_below, float2 c, int tile_x, int tile_y) {
+    return splat_reaches_rect(co, skip_below, c, tile_x * kTile, tile_y * kTile, kTile, kTile);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -295,7 +299,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
                 const float4 conic_o = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, in.opacities[i]);
                 float4* rec = reinterpret_cast<float4*>(out.raster + i);  // one 32-byte record, two 16-byte stores
                 rec[0] = make_float4(px, py, conic_o.x, conic_o.y);
-                rec[1] = make_float4(conic_o.z, conic_o.w, vz, 0.f);
+                const float skip_below = blend_skip_below(conic_o.w);
+                rec[1] = make_float4(conic_o.z, conic_o.w, vz, skip_below);
                 radius_out = irad;
                 rect_area = area;
                 bin.xy0 = (uint32_t)rc.x0 | ((uint32_t)rc.y0 << 16);
@@ -303,7 +308,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
                 bin.count = area;
                 if (in.tile_cull && area <= 32u) {  // exact-image tile culling: mask computed below, by the whole wave
                     mask_candidate = true;
-                    cand_conic = conic_o;
+                    cand_conic = make_float4(conic_o.x, conic_o.y, conic_o.z, skip_below);  // w: the pre-test threshold
                     cand_centre = make_float2(px, py);
                 }
                 key = __float_as_uint(vz);
@@ -355,7 +360,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
                 const uint32_t local = t - first;  // < 32, w <= 32: (local + 0.5) / w is >= 1/64 away from an integer
                 const uint32_t row = (uint32_t)(((float)local + 0.5f) * __builtin_amdgcn_rcpf((float)w));
                 const uint32_t col = local - row * w;
-                const bool live = t < total && splat_reaches_tile(co, make_float2(pl.x, pl.y), (int)((xy0 & 0xFFFFu) + col),
+                const bool live = t < total && splat_reaches_tile(co, co.w, make_float2(pl.x, pl.y), (int)((xy0 & 0xFFFFu) + col),
                                                                   (int)((xy0 >> 16) + row));
                 const unsigned long long b = __ballot(live);
                 const uint32_t from = max(excl, t0), to = min(incl, t0 + 64u);  // my tests inside this batch
@@ -806,7 +811,7 @@ __global__ void __launch_bounds__(64, 8) blend_kernel(int W, int H, int grid_x, 
     float2 g_xy = make_float2(0.f, 0.f);
     float4 g_co = make_float4(0.f, 0.f, 0.f, 0.f);
     F3 g_rgb = {0.f, 0.f, 0.f};
-    float g_z = 0.f;
+    float g_z = 0.f, g_skip = 0.f;
     auto gather = [&](uint32_t first) {
         const uint32_t e = first + (uint32_t)lane;
         if (e < count) {
@@ -816,6 +821,7 @@ __global__ void __launch_bounds__(64, 8) blend_kernel(int W, int H, int grid_x, 
             g_xy = make_float2(r0.x, r0.y);
             g_co = make_float4(r0.z, r0.w, r1.x, r1.y);
             g_z = r1.z;
+            g_skip = r1.w;
             g_rgb = ld3(features + 3 * (size_t)id);
         }
     };
@@ -826,7 +832,7 @@ __global__ void __launch_bounds__(64, 8) blend_kernel(int W, int H, int grid_x, 
         // LDS reads of the previous batch / writes of this one / broadcast reads below)
         __syncthreads();
         sA[lane] = BlendEntryA{g_xy.x, g_xy.y, g_co.x, g_co.y};
-        sB[lane] = BlendEntryB{g_co.z, -logf(255.0f * g_co.w) - 1.0e-4f};
+        sB[lane] = BlendEntryB{g_co.z, g_skip};
         sC[lane] = BlendEntryC{g_co.w, g_rgb.x, g_rgb.y, g_rgb.z};
         sD[lane] = g_z;
         __syncthreads();
@@ -971,7 +977,7 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
     float2 g_xy = make_float2(0.f, 0.f);
     float4 g_co = make_float4(0.f, 0.f, 0.f, 0.f);
     F3 g_rgb = {0.f, 0.f, 0.f}, g_ext = {0.f, 0.f, 0.f};
-    float g_z = 0.f;
+    float g_z = 0.f, g_skip = 0.f;
     auto gather = [&](uint32_t first) {
         const uint32_t e = first + (uint32_t)lane;
         if (e < count) {
@@ -981,6 +987,7 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
             g_xy = make_float2(r0.x, r0.y);
             g_co = make_float4(r0.z, r0.w, r1.x, r1.y);
             g_z = r1.z;
+            g_skip = r1.w;
             g_rgb = ld3(features + 3 * (size_t)id);
             if (kExtra) g_ext = ld3(extra_features + 3 * (size_t)id);
         }
@@ -989,12 +996,12 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
 
     for (uint32_t first = 0; first < count; first += 64) {
         const bool mine = first + (uint32_t)lane < count;
-        unsigned long long todo = __ballot(mine && splat_reaches_rect(g_co, g_xy, qx0, qy0, kQ, kQ));
+        unsigned long long todo = __ballot(mine && splat_reaches_rect(g_co, g_skip, g_xy, qx0, qy0, kQ, kQ));
         if (todo != 0ull) {
             __syncthreads();  // single-wave workgroup: orders this wave's LDS reads / writes only
             float4* rec = reinterpret_cast<float4*>(&s_entry[lane]);
             rec[0] = make_float4(g_xy.x, g_xy.y, g_co.x, g_co.y);
-            rec[1] = make_float4(g_co.z, -logf(255.0f * g_co.w) - 1.0e-4f, g_co.w, 0.f);
+            rec[1] = make_float4(g_co.z, g_skip, g_co.w, 0.f);
             rec[2] = make_float4(g_rgb.x, g_rgb.y, g_rgb.z, g_z);
             if (kExtra) s_extra[lane] = make_float4(g_ext.x, g_ext.y, g_ext.z, 0.f);
             __syncthreads();
@@ -1173,7 +1180,7 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
         float2 g_xy = make_float2(0.f, 0.f);
         float4 g_co = make_float4(0.f, 0.f, 0.f, 0.f);
         F3 g_rgb = {0.f, 0.f, 0.f};
-        float g_z = 0.f;
+        float g_z = 0.f, g_skip = 0.f;
         uint32_t g_id = 0;
         const bool mine = e < top;
         if (mine) {
@@ -1183,15 +1190,16 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
             g_xy = make_float2(r0.x, r0.y);
             g_co = make_float4(r0.z, r0.w, r1.x, r1.y);
             g_z = r1.z;
+            g_skip = r1.w;
             g_rgb = ld3(colors + 3 * (size_t)g_id);
         }
-        unsigned long long todo = __ballot(mine && splat_reaches_rect(g_co, g_xy, qx0, qy0, kQ, kQ));
+        unsigned long long todo = __ballot(mine && splat_reaches_rect(g_co, g_skip, g_xy, qx0, qy0, kQ, kQ));
         if (todo == 0ull) continue;
         __syncthreads();
         {
             float4* rec = reinterpret_cast<float4*>(&s_entry[lane]);
             rec[0] = make_float4(g_xy.x, g_xy.y, g_co.x, g_co.y);
-            rec[1] = make_float4(g_co.z, -logf(255.0f * g_co.w) - 1.0e-4f, g_co.w, __uint_as_float(g_id));
+            rec[1] = make_float4(g_co.z, g_skip, g_co.w, __uint_as_float(g_id));
             rec[2] = make_float4(g_rgb.x, g_rgb.y, g_rgb.z, g_z);
         }
         __syncthreads();

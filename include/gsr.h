@@ -208,7 +208,7 @@ GSR_API int gsr_backward(int P, int D, int M, int R, const float* background, in
  * callback returned.  Offsets depend only on the sizes given. */
 typedef enum gsr_geom_slot {
     GSR_GEOM_RASTER = 0,        /* f32[8P]  per splat: pixel x, y, conic xx, xy, yy (inverse 2D covariance),
-                                   opacity, view-space z, pad -- valid where radii > 0             */
+                                   opacity, view-space z, -ln(255 opacity) - 1e-4 -- valid where radii > 0             */
     GSR_GEOM_RGB,               /* f32[3P]  SH-evaluated colour (unused with colors_precomp)       */
     GSR_GEOM_SPLAT_BINS,        /* u32[4P]  per splat: first tile x | y << 16, rectangle width, live-tile mask
                                    (~0 = all), live tiles = pairs emitted (0 = culled); GSR_OPT_TILE_CULL */
