@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--gaussians", type=int, default=0, help="override P (parity/debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-hip", action="store_true",
+                    help="skip timing the reference's own kernels compiled for gfx950 (oracle/_ref/libgsr_ref_hip.so)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of the frames to rank 0 (N > 1)")
     ap.add_argument("--gather-chunks", type=int, default=4,
                     help="N > 1: pieces the per-rank frame stack is gathered in, each overlapped with the next piece's rendering")
@@ -260,6 +262,9 @@ def main():
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(cloud_cpu, cams_cpu, frame_of(Wm), cloud, cams, bg, W, H)
+    reference_on_gpu = None
+    if rank == 0 and world == 1 and args.boundary == "op" and not args.no_reference_hip:
+        reference_on_gpu = run_reference_on_gpu(cloud, [cams[frame_of(Wm + j)] for j in range(min(K, 24))], bg)
 
     if rank == 0:
         line = {
@@ -280,6 +285,8 @@ def main():
                                    "blend_variant": _lib.get_option(_lib.OPT_BLEND_VARIANT)}},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+        if reference_on_gpu is not None:
+            line["reference_on_gpu"] = reference_on_gpu
         if gathered is not None:
             line["config"]["gathered_frames"] = int(gathered.shape[0] * gathered.shape[1])
             line["config"]["gather_chunks"] = args.gather_chunks
@@ -305,6 +312,31 @@ def pmc_traffic(kernel):
     except OSError:
         pass
     return None, None
+
+
+def run_reference_on_gpu(cloud, cam_list, bg):
+    """The REFERENCE's own rasterizer (its CUDA sources compiled for gfx950 by oracle/build_ref_hip.py, a measuring
+    stick) on the same frames of the same workload on this GPU: what "matching the reference" means here.  One stream,
+    one frame at a time, as the reference runs; its scratch arenas are kept between frames."""
+    try:
+        from oracle import ref_hip
+        if not ref_hip.available():
+            return None
+        dev = cloud.means3D.device
+        H, W = int(cam_list[0].image_height), int(cam_list[0].image_width)
+        outs = (torch.zeros((3, H, W), device=dev), torch.zeros((1, H, W), device=dev), torch.zeros((1, H, W), device=dev),
+                torch.zeros((cloud.P,), dtype=torch.int32, device=dev))
+        for cam in cam_list[:3]:
+            ref_hip.forward(cloud, cam, bg, outs)
+        t0 = time.perf_counter()
+        for cam in cam_list:
+            ref_hip.forward(cloud, cam, bg, outs)
+        dt = time.perf_counter() - t0
+        return {"value": round(len(cam_list) / dt, 2), "unit": "frames/s", "ms_per_frame": round(dt / len(cam_list) * 1e3, 3),
+                "kind": "reference sources (forward.cu, rasterizer_impl.cu; hipCUB for its two CUB calls) compiled for gfx950, "
+                        "-ffp-contract=off", "sample": f"{len(cam_list)} frames of the same workload, one stream"}
+    except Exception as e:  # a measuring stick must not break the headline line
+        return {"error": repr(e)[:200]}
 
 
 def torch_cpu_c1():
