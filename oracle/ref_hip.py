@@ -27,6 +27,9 @@ def lib():
                                                              p, p, p, p, p, ctypes.c_float, ctypes.c_float, p, p, p, p]
         L.gsr_refhip_last_lists.restype = ctypes.c_int
         L.gsr_refhip_last_lists.argtypes = [ctypes.c_int] * 4 + [ctypes.POINTER(p)] * 3
+        L.gsr_refhip_backward.restype = ctypes.c_int
+        L.gsr_refhip_backward.argtypes = ([ctypes.c_int] * 4 + [p, ctypes.c_int, ctypes.c_int] + [p] * 4 + [ctypes.c_float]
+                                          + [p] * 5 + [ctypes.c_float, ctypes.c_float] + [p] * 15)
         _lib = L
     return _lib
 
@@ -53,3 +56,26 @@ def forward(cloud, cam, bg: torch.Tensor, outputs=None):
                                  float(cam.tanfovy), color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), radii.data_ptr())
     torch.cuda.synchronize(dev)
     return n, color, depth, alpha, radii
+
+
+def backward(cloud, cam, bg, n, radii, alpha, dL_dcolor, dL_ddepth, dL_dalpha):
+    """Backward of the preceding ``forward`` call through the reference's own kernels; returns the gradient dict."""
+    dev = cloud.means3D.device
+    P, H, W = cloud.P, int(cam.image_height), int(cam.image_width)
+    M = 0 if cloud.shs is None else int(cloud.shs.shape[1])
+    z = lambda *s: torch.zeros(s, device=dev)
+    g = {"means2D": z(P, 3), "conic": z(P, 4), "opacity": z(P, 1), "colors": z(P, 3), "depths": z(P, 1), "means3D": z(P, 3),
+         "cov3D": z(P, 6), "sh": z(P, max(M, 1), 3), "scales": z(P, 3), "rotations": z(P, 4)}
+    torch.cuda.synchronize(dev)
+    rc = lib().gsr_refhip_backward(
+        P, int(cloud.sh_degree), M, int(n), bg.data_ptr(), W, H, cloud.means3D.data_ptr(), _ptr(cloud.shs),
+        _ptr(cloud.colors_precomp), _ptr(cloud.scales), 1.0, _ptr(cloud.rotations), None, cam.world_view_transform.data_ptr(),
+        cam.full_proj_transform.data_ptr(), cam.camera_center.data_ptr(), float(cam.tanfovx), float(cam.tanfovy),
+        radii.data_ptr(), alpha.data_ptr(), dL_dcolor.contiguous().data_ptr(), dL_ddepth.contiguous().data_ptr(),
+        dL_dalpha.contiguous().data_ptr(), g["means2D"].data_ptr(), g["conic"].data_ptr(), g["opacity"].data_ptr(),
+        g["colors"].data_ptr(), g["depths"].data_ptr(), g["means3D"].data_ptr(), g["cov3D"].data_ptr(), g["sh"].data_ptr(),
+        g["scales"].data_ptr(), g["rotations"].data_ptr())
+    if rc != 0:
+        raise RuntimeError("gsr_refhip_backward: no preceding forward call")
+    torch.cuda.synchronize(dev)
+    return g

@@ -41,6 +41,23 @@ int gsr_refhip_forward(int P, int D, int M, const float* background, int width, 
                                false);
 }
 
+// Backward of the last gsr_refhip_forward call (Rasterizer::backward, rasterizer_impl.cu:343-446) over the arenas that
+// call left behind; the gradient buffers must arrive zero-filled, as the reference's binding provides them.
+int gsr_refhip_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                        const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                        const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                        const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii,
+                        const float* out_alpha, const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dpix_alpha,
+                        float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepth,
+                        float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot) {
+    if (P == 0 || !g_geom.p || !g_binning.p || !g_img.p) return -1;
+    Rasterizer::backward(P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier,
+                         rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, radii, g_geom.p,
+                         g_binning.p, g_img.p, out_alpha, dL_dpix, dL_dpix_depth, dL_dpix_alpha, dL_dmean2D, dL_dconic,
+                         dL_dopacity, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, false);
+    return 0;
+}
+
 // Device pointers into the last call's scratch (the reference's own fromChunk layout): n_contrib[H*W], ranges[T][2],
 // point_list[num_rendered].
 int gsr_refhip_last_lists(int P, int width, int height, int num_rendered, const unsigned** n_contrib,

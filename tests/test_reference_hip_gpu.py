@@ -39,3 +39,36 @@ def test_images_and_counts_match_the_reference_on_this_gpu(case):
     scale = max(1.0, float(d_ref.max()))
     bad = ((depth - d_ref).abs() > 1e-4 * scale).sum()
     assert int(bad) <= 20e-6 * depth.numel()
+
+
+@pytest.mark.parametrize("case", ["c1", "c2_mid"])
+def test_gradients_match_the_reference_on_this_gpu(case):
+    """Forward + backward through the drop-in against the reference's own backward kernels on the same GPU.  Both sum
+    per-Gaussian gradients with atomics, so the comparison carries the tolerance of tests/test_backward_gpu.py."""
+    from autovfx_amd.frame_parallel import settings_for_camera
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = torch.device("cuda", 0)
+    if case == "c1":
+        cloud, cam = scenes.config_c1(), scenes.c1_camera()
+    else:
+        cloud, cam = scenes.config_c2(P=200_000, seed=5), orbit_cameras(200, 960, 540)[60]
+    cloud, cam = cloud.to(dev), cam.to(dev)
+    bg = torch.tensor([0.2, 0.1, 0.0], device=dev)
+    H, W = cam.image_height, cam.image_width
+    g = torch.Generator(device=dev).manual_seed(1)
+    w_c, w_d, w_a = (torch.randn((3, H, W), generator=g, device=dev), torch.randn((1, H, W), generator=g, device=dev) * 0.1,
+                     torch.randn((1, H, W), generator=g, device=dev))
+    n, c_ref, d_ref, a_ref, r_ref = ref_hip.forward(cloud, cam, bg)
+    ref = ref_hip.backward(cloud, cam, bg, n, r_ref, a_ref, w_c, w_d, w_a)
+    leaves = {k: getattr(cloud, k).clone().requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    m2d = torch.zeros_like(leaves["means3D"], requires_grad=True)
+    color, depth, alpha, _ = GaussianRasterizer(settings_for_camera(cam, bg, cloud.sh_degree))(
+        leaves["means3D"], m2d, leaves["opacities"], shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"])
+    ((color * w_c).sum() + (depth * w_d).sum() + (alpha * w_a).sum()).backward()
+    torch.cuda.synchronize()
+    pairs = {"means3D": leaves["means3D"].grad, "opacity": leaves["opacities"].grad, "sh": leaves["shs"].grad,
+             "scales": leaves["scales"].grad, "rotations": leaves["rotations"].grad, "means2D": m2d.grad}
+    for k, got in pairs.items():
+        want = ref[k].reshape(got.shape)
+        tol = 2e-4 * max(1e-6, float(want.abs().max()))
+        assert float((got - want).abs().max()) <= tol, (k, float((got - want).abs().max()), tol)
