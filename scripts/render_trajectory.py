@@ -1,0 +1,81 @@
+#!/usr/bin/env python
+"""Render a camera trajectory of a 3DGS scene to disk: what AutoVFX's ``scene_representation.render_from_3DGS``
+(`scene_representation.py:355-438`) does for the static background, through this repository's drop-in renderer.
+
+    python scripts/render_trajectory.py --ply point_cloud.ply --trajectory custom_camera_path/traj.json --out out/
+    torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 scripts/render_trajectory.py ...   # frames sharded
+
+Per frame it writes images/<i>.png (RGBA8, save_image rounding), depth/<i>.npy (fp32) and normal/<i>.png, the three
+files the reference's frame loop writes and `blender/blend_all.py` consumes.  Rank r renders frames r, r+N, ...; every
+rank writes its own frames (no gather is needed when the output is files).  `--synthetic P` renders the synthetic C2
+cloud with P Gaussians instead of a PLY; `--orbit N WxH` an N-view orbit instead of a trajectory file.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--ply")
+    ap.add_argument("--synthetic", type=int, default=0)
+    ap.add_argument("--trajectory")
+    ap.add_argument("--orbit", nargs=2, metavar=("N", "WxH"))
+    ap.add_argument("--downscale", type=float, default=1.0)
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--white-background", action="store_true")
+    ap.add_argument("--out", required=True)
+    args = ap.parse_args()
+
+    rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
+    if not torch.cuda.is_available():
+        raise SystemExit("needs a HIP device: the render path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from autovfx_amd import cameras, frame_io, renderer, scenes
+    from autovfx_amd.frame_parallel import shard_frames
+    from autovfx_amd.gaussian_model import GaussianModel
+
+    if args.ply:
+        model = GaussianModel(args.sh_degree).load_ply(args.ply, device=str(dev))
+        model.active_sh_degree = model.max_sh_degree
+    else:
+        c = scenes.config_c2(P=args.synthetic or 200_000)
+        model = GaussianModel.from_activated(c.means3D, c.opacities, c.scales, c.rotations, c.shs, c.sh_degree).to(dev)
+    if args.trajectory:
+        cams = cameras.cameras_from_trajectory(args.trajectory, args.downscale)
+    else:
+        n, wh = args.orbit or ("8", "960x540")
+        w, h = (int(v) for v in wh.lower().split("x"))
+        cams = cameras.orbit_cameras(int(n), w, h)
+    bg = torch.tensor([1.0, 1.0, 1.0] if args.white_background else [0.0, 0.0, 0.0], device=dev)
+
+    mine = shard_frames(len(cams), rank, world)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for i in mine:
+            out = renderer.render(cams[i].to(dev), model, renderer.PipelineParams, bg)
+            frame_io.write_frame_outputs(args.out, cams[i].image_name or f"{i:05d}", out)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"rank": rank, "frames": len(mine), "seconds": round(dt, 3),
+                      "frames_per_s_including_png_encode": round(len(mine) / max(dt, 1e-9), 2)}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -30,3 +30,33 @@ def test_write_frame_outputs(tmp_path):
     n = frame_io.decode_png(open(paths["normal"], "rb").read())
     np.testing.assert_array_equal(n, ((result["normal"] + 1) / 2 * 255).to(torch.uint8).numpy())
     assert paths["images"].endswith("images/00007.png") and paths["depth"].endswith("depth/00007.npy")
+
+
+@pytest.mark.gpu
+def test_render_trajectory_script_end_to_end(tmp_path):
+    """PLY + trajectory JSON in, the reference's three per-frame files out (scripts/render_trajectory.py)."""
+    import json
+    import subprocess
+    import sys
+    from autovfx_amd import cameras, scenes
+    from autovfx_amd.gaussian_model import GaussianModel
+    c = scenes.config_c2(P=20_000, seed=3)
+    ply = str(tmp_path / "point_cloud.ply")
+    GaussianModel.from_activated(c.means3D, c.opacities, c.scales, c.rotations, c.shs, 3).save_ply(ply)
+    poses = cameras.orbit_c2w(4.0, 3)
+    fx = cameras.fov2focal(np.deg2rad(60.0), 160)
+    traj = str(tmp_path / "traj.json")
+    with open(traj, "w") as f:
+        json.dump(cameras.trajectory_dict("t", poses, fx, fx, 80, 45, 160, 90), f)
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    out = tmp_path / "out"
+    r = subprocess.run([sys.executable, __import__("os").path.join(root, "scripts", "render_trajectory.py"), "--ply", ply,
+                        "--trajectory", traj, "--out", str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = sorted(p.name for p in (out / "images").iterdir())
+    assert names == ["00000.png", "00001.png", "00002.png"]
+    rgba = frame_io.decode_png((out / "images" / "00001.png").read_bytes())
+    depth = np.load(out / "depth" / "00001.npy")
+    normal = frame_io.decode_png((out / "normal" / "00001.png").read_bytes())
+    assert rgba.shape == (90, 160, 4) and depth.shape == (90, 160) and normal.shape == (90, 160, 3)
+    assert rgba[..., 3].max() > 200 and depth.max() > 1.0          # something was rendered
