@@ -366,11 +366,31 @@ def torch_cpu_c1(threads: int = 16, timeout_s: float = 30.0):
         return {"error": repr(e)[:200]}
 
 
+def host_cpu_budget():
+    """(logical CPUs, CPUs this container may actually use): a cgroup quota caps the second (cpu.max "quota period")."""
+    n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            return n, min(float(n), float(quota) / float(period))
+    except (OSError, ValueError):
+        pass
+    return n, float(n)
+
+
 def run_cpu_baseline(cloud_cpu, cams_cpu, frame, cloud, cams, bg, W, H, budget_s=12.0, max_frames=12):
-    """Time the CPU oracle (all host cores, OpenMP) on a bounded sample of the same workload -- frames of
-    the same orbit until ~budget_s of wall time -- and report the GPU's parity on the first of them."""
+    """Time the CPU oracle (OpenMP over the CPUs this container may use) on a bounded sample of the same workload --
+    frames of the same orbit until ~budget_s of wall time -- and report the GPU's parity on the first of them."""
     from oracle import cpu_oracle
     from autovfx_amd.frame_parallel import rasterize
+    logical, usable = host_cpu_budget()
+    threads = max(1, int(round(usable)))
+    try:   # one OpenMP thread per usable CPU: 256 threads inside a 16-CPU quota only fight each other
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(threads)
+    except OSError:
+        threads = logical
 
     def kw(cam):
         return dict(means3D=cloud_cpu.means3D, opacities=cloud_cpu.opacities, bg=np.zeros(3, np.float32), width=W,
@@ -398,9 +418,10 @@ def run_cpu_baseline(cloud_cpu, cams_cpu, frame, cloud, cams, bg, W, H, budget_s
             model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
     except OSError:
         pass
-    return {"value": round(n / total, 4), "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": round(n / total, 4), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"{n} frames of the same workload at full size (orbit indices {frame}+7k), C+OpenMP oracle, "
-                      f"{total:.2f} s of wall time on {os.cpu_count()} host threads",
+                      f"{total:.2f} s of wall time on {threads} OpenMP threads ({logical} logical CPUs, "
+                      f"cgroup quota {usable:g} CPUs)",
             "cpu_model": model, "torch_cpu_c1": torch_cpu_c1(),
             "parity": {"frame": frame, "rgb_maxabs": float(err.max()), "rgb_px_over_1e-4": int((err > 1e-4).sum()),
                        "alpha_maxabs": float(np.abs(alpha.cpu().numpy() - ref["alpha"]).max()),
