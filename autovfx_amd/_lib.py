@@ -25,7 +25,7 @@ ABI_VERSION = 3
 SYMBOLS = ("gsr_forward", "gsr_mark_visible", "gsr_backward", "gsr_last_geom_offsets", "gsr_last_binning_offsets",
            "gsr_last_image_offsets", "gsr_set_stage_timing", "gsr_get_stage_times", "gsr_last_error",
            "gsr_abi_version", "gsr_target_arch", "gsr_set_option", "gsr_get_option", "gsr_pack_rgba8", "gsr_last_pair_counts", "gsr_blend", "gsr_composite",
-           "gsr_radix_scratch_bytes", "gsr_radix_sort_pairs", "gsr_selftest_exp", "gsr_view_normals", "gsr_normal_maps", "gsr_forward_extra")
+           "gsr_radix_scratch_bytes", "gsr_radix_sort_pairs", "gsr_selftest_exp", "gsr_view_normals", "gsr_normal_maps", "gsr_forward_extra", "gsr_get_call_times")
 OPT_TILE_CULL = 0
 OPT_BLEND_VARIANT = 1
 OPT_BLEND_LDS_PAD = 2
@@ -101,6 +101,8 @@ def _load() -> ctypes.CDLL:
     lib.gsr_get_option.argtypes = [ctypes.c_int]
     lib.gsr_set_stage_timing.restype = None
     lib.gsr_set_stage_timing.argtypes = [ctypes.c_int]
+    lib.gsr_get_call_times.restype = ctypes.c_int
+    lib.gsr_get_call_times.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int]
     lib.gsr_get_stage_times.restype = ctypes.c_int
     lib.gsr_get_stage_times.argtypes = [ctypes.POINTER(ctypes.c_float * len(STAGES))]
     lib.gsr_last_error.restype = ctypes.c_char_p
@@ -148,6 +150,15 @@ def get_option(option: int) -> int:
 
 def set_stage_timing(enable: bool) -> None:
     lib.gsr_set_stage_timing(1 if enable else 0)
+
+
+def call_times_ms(capacity: int = 256) -> list:
+    """Device milliseconds (first kernel to last) of this thread's most recent timed calls, newest first."""
+    arr = (ctypes.c_float * capacity)()
+    n = lib.gsr_get_call_times(arr, capacity)
+    if n < 0:
+        raise RuntimeError(last_error())
+    return [float(arr[i]) for i in range(n)]
 
 
 def stage_times_ms() -> dict:

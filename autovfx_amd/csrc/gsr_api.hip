@@ -139,6 +139,19 @@ int gsr_get_stage_times(float ms[GSR_STAGE_NUM]) {
     return ncalls;
 }
 
+int gsr_get_call_times(float* ms, int capacity) {
+    if (!ms || capacity < 0) return fail(GSR_ERR_INVALID_ARG, "bad arguments");
+    if (g_timed_calls <= 0) return 0;
+    int ncalls = (int)(g_timed_calls < kTimingRing ? g_timed_calls : kTimingRing);
+    if (ncalls > capacity) ncalls = capacity;
+    for (int c = 0; c < ncalls; ++c) {
+        const int slot = (int)((g_timed_calls - 1 - c) % kTimingRing);
+        GSR_HIP(hipEventSynchronize(g_ev[slot][kEventsPerCall - 1]));
+        GSR_HIP(hipEventElapsedTime(&ms[c], g_ev[slot][0], g_ev[slot][kEventsPerCall - 1]));
+    }
+    return ncalls;
+}
+
 int gsr_last_geom_offsets(size_t o[GSR_GEOM_NUM_SLOTS]) {
     if (!g_have_offsets) return fail(GSR_ERR_INVALID_ARG, "no gsr_forward call on this thread");
     memcpy(o, g_geom_off, sizeof g_geom_off);

@@ -212,6 +212,7 @@ def main():
                 step(Wm + j, j)
             torch.cuda.synchronize()
         stage_ms = _lib.stage_times_ms()
+        call_ms = sorted(_lib.call_times_ms())
         _lib.set_stage_timing(False)
 
     if world > 1:
@@ -257,7 +258,10 @@ def main():
         "avg_launch_ms": round(stage_ms[dom], 4), "alg_bytes_per_launch": int(stage_alg[dom]),
         "timed_calls": calls,
         "frame": {"alg_bytes": int(alg["frame"]), "achieved": round(frame_gbps, 1),
-                  "frac": round(frame_gbps / HBM_PEAK_GBPS, 4), "n_pass_ref_sort": alg["n_pass"]},
+                  "frac": round(frame_gbps / HBM_PEAK_GBPS, 4), "n_pass_ref_sort": alg["n_pass"],
+                  # one frame alone on the GPU, first kernel to last (HIP events), over the per-stage replay
+                  "single_stream_ms_p50": round(call_ms[len(call_ms) // 2], 4) if call_ms else None,
+                  "single_stream_ms_p95": round(call_ms[min(len(call_ms) - 1, int(0.95 * len(call_ms)))], 4) if call_ms else None},
         "stages": stages,
     }
 

@@ -278,6 +278,9 @@ GSR_API void gsr_set_stage_timing(int enable);
  * enabled (at most the last 256; synchronises on their events).  Returns the number of calls
  * averaged, or a negative gsr_status.  Early exits (P == 0, errors) are not recorded. */
 GSR_API int gsr_get_stage_times(float ms[GSR_STAGE_NUM]);
+/* First-kernel-to-last-kernel device time of each of the most recent timed gsr_forward calls of this thread, newest
+ * first; returns how many were written (at most `capacity` and at most the ring of 256). */
+GSR_API int gsr_get_call_times(float* ms, int capacity);
 
 GSR_API const char* gsr_last_error(void);
 GSR_API int gsr_abi_version(void);
