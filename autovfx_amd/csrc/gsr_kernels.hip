@@ -14,17 +14,19 @@
 // Results are the reference's: fp32 in the reference's operation order,
 // built with -ffp-contract=off so nothing is fused behind our back.  The *structure* is not the
 // reference's:
-//   * the (tile, depth) order is produced by a 32-bit depth sort of Gaussians followed by a
-//     stable tile-id sort of the expanded pairs, so the duplicate kernel walks Gaussians in depth
-//     order and emits 32-bit tile keys (the reference sorts 64-bit keys once);
-//   * pair expansion is wave-cooperative: 64 lanes share the flattened pair range of their 64
-//     Gaussians (prefix sums + lane binary search through ds_bpermute), so writes are coalesced
-//     and a screen-filling splat does not serialise one lane;
-//   * tile ranges come from two binary searches per tile over the sorted tile keys (no memset,
-//     no pass over all pairs);
-//   * one wave64 blends one 16x16 tile, each lane owning one pixel per 8x8 quadrant: no workgroup
-//     barriers, wave-exact early exit, per-entry LDS broadcast reads amortised over 4 pixels, and
-//     an exact pre-test that skips expf for pairs that cannot reach alpha >= 1/255.
+//   * the (tile, depth) order is produced by a 32-bit depth sort of Gaussians followed by a stable
+//     tile-id sort of the expanded pairs (gsr_radix.hip), not one 64-bit sort;
+//   * preprocess also computes, wave-cooperatively, which tiles of a splat's rectangle can reach
+//     alpha >= 1/255 at all (exact-image tile culling): dead pairs are never emitted;
+//   * scan + pair expansion are three spin-free kernels balanced by PAIRS (bin_gather / bin_offsets /
+//     expand), so the nearest splats, which emit hundreds of pairs each, do not serialise a workgroup;
+//   * tile ranges come from two binary searches per tile over the sorted tile keys;
+//   * one wave64 blends one 8x8 quadrant of a tile, one pixel per lane: no workgroup barriers, a
+//     per-quadrant reach test of every staged list entry, pixel state as wave-uniform scalar masks,
+//     an exact pre-test that skips expf for pairs that cannot reach alpha >= 1/255, and optionally a
+//     second feature set composited in the same walk (blend_quadrant_kernel<true>).
+// The duplicate_kernel / blend_kernel variants are kept as A/B paths (GSR_OPT_SORT_IMPL = 0,
+// GSR_OPT_BLEND_VARIANT = 0) with tests that they give the same bits.
 #include "gsr_internal.h"
 
 // Profiling aid (python -m autovfx_amd.build --trace, scripts/kernel_trace.py): lane 0 of a workgroup stamps the
