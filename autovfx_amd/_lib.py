@@ -19,13 +19,14 @@ GEOM_SLOTS = ("raster", "rgb", "splat_bins", "internal_radii", "depth_order", "p
 BIN_SLOTS = ("point_list", "tile_keys")
 IMG_SLOTS = ("ranges", "n_contrib")
 STAGES = ("preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "ranges", "blend")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/gsr.h declares
 SYMBOLS = ("gsr_forward", "gsr_mark_visible", "gsr_backward", "gsr_last_geom_offsets", "gsr_last_binning_offsets",
            "gsr_last_image_offsets", "gsr_set_stage_timing", "gsr_get_stage_times", "gsr_last_error",
            "gsr_abi_version", "gsr_target_arch", "gsr_set_option", "gsr_get_option", "gsr_pack_rgba8", "gsr_last_pair_counts", "gsr_blend", "gsr_composite",
-           "gsr_radix_scratch_bytes", "gsr_radix_sort_pairs", "gsr_selftest_exp", "gsr_view_normals", "gsr_normal_maps", "gsr_forward_extra", "gsr_get_call_times")
+           "gsr_radix_scratch_bytes", "gsr_radix_sort_pairs", "gsr_selftest_exp", "gsr_view_normals", "gsr_normal_maps", "gsr_forward_extra", "gsr_get_call_times",
+           "gsr_forward_begin", "gsr_forward_finish", "gsr_forward_cancel")
 OPT_TILE_CULL = 0
 OPT_BLEND_VARIANT = 1
 OPT_BLEND_LDS_PAD = 2
@@ -60,6 +61,12 @@ def _load() -> ctypes.CDLL:
         c_f, c_f, c_f, c_f, ctypes.c_int, ctypes.c_void_p]   # out_color out_depth out_alpha radii debug stream
     lib.gsr_forward_extra.restype = ctypes.c_int
     lib.gsr_forward_extra.argtypes = lib.gsr_forward.argtypes[:-2] + [c_f, c_f, ctypes.c_int, ctypes.c_void_p]
+    lib.gsr_forward_begin.restype = ctypes.c_void_p
+    lib.gsr_forward_begin.argtypes = lib.gsr_forward_extra.argtypes
+    lib.gsr_forward_finish.restype = ctypes.c_int
+    lib.gsr_forward_finish.argtypes = [ctypes.c_void_p]
+    lib.gsr_forward_cancel.restype = None
+    lib.gsr_forward_cancel.argtypes = [ctypes.c_void_p]
     lib.gsr_mark_visible.restype = ctypes.c_int
     lib.gsr_mark_visible.argtypes = [ctypes.c_int, c_f, c_f, c_f, c_f, ctypes.c_void_p]
     lib.gsr_composite.restype = ctypes.c_int

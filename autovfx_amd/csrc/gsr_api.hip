@@ -11,6 +11,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <new>
+#include <vector>
 
 namespace {
 
@@ -87,11 +89,6 @@ int tile_key_bits(uint32_t num_tiles) {
 }
 
 constexpr size_t kCounterBytes = gsr::kCounterCopyBytes;  // what travels back to the host
-struct Pinned {
-    uint32_t* host = nullptr;    // a few KB of pinned memory per calling thread, deliberately never freed:
-    hipEvent_t copied = nullptr; // freeing at thread exit can race HIP runtime teardown
-};
-thread_local Pinned g_pinned;
 
 void stamp(int idx, hipStream_t s) {
     if (!g_timing) return;
@@ -334,16 +331,53 @@ int gsr_pack_rgba8(const float* color, const float* alpha, uint8_t* rgba8, int w
 } // extern "C"
 
 namespace {
-int forward_impl(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_alloc, void* binning_user,
-                 gsr_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background,
-                 int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
-                 const float* opacities, const float* scales, float scale_modifier, const float* rotations,
-                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
-                 const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
-                 float* out_depth, float* out_alpha, int* radii, int debug, void* stream_,
-                 const float* extra_features, float* out_extra) {
+// One forward call, split where the host has to learn the pair count.  forward_begin queues the stages
+// whose sizes depend only on P (projection, depth sort) and the copy of the frame counters;
+// forward_finish waits for that copy, sizes the binning arena and queues the rest.  gsr_forward runs the
+// two back to back; gsr_forward_begin / gsr_forward_finish expose the split so that one host thread can
+// keep several frames in flight on several streams without blocking on the newest one.
+struct PinnedSlot {
+    uint32_t* host = nullptr;    // a few KB of pinned memory, pooled per calling thread and deliberately never
+    hipEvent_t copied = nullptr; // freed: freeing at thread exit can race HIP runtime teardown
+};
+thread_local std::vector<PinnedSlot> g_pinned_free;
+
+struct ForwardCall {
+    hipStream_t stream = nullptr;
+    int debug = 0, prefiltered = 0, P = 0, T = 0, width = 0, height = 0, slot = 0;
+    bool own_sort = true, queued = false;
+    gsr::Camera cam;
+    gsr::GeometryArrays ga;
+    gsr_alloc_fn binning_alloc = nullptr;
+    void* binning_user = nullptr;
+    char *gbase = nullptr, *iraw = nullptr, *ibase = nullptr;
+    size_t gshift = 0;
+    size_t geom_off[GSR_GEOM_NUM_SLOTS] = {};
+    size_t img_off[GSR_IMG_NUM_SLOTS] = {};
+    uint32_t *order = nullptr, *point_offsets = nullptr, *tile_totals = nullptr;
+    uint4* sorted_bins = nullptr;
+    const float *colors_precomp = nullptr, *background = nullptr, *extra_features = nullptr;
+    float *out_color = nullptr, *out_depth = nullptr, *out_alpha = nullptr, *out_extra = nullptr;
+    PinnedSlot pinned;
+
+    ~ForwardCall() {
+        if (!pinned.host) return;
+        if (queued) (void)hipEventSynchronize(pinned.copied);  // the copy may still be landing in the buffer
+        g_pinned_free.push_back(pinned);
+    }
+};
+
+int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_alloc,
+                  void* binning_user, gsr_alloc_fn image_alloc, void* image_user, int P, int D, int M,
+                  const float* background, int width, int height, const float* means3D, const float* shs,
+                  const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                  const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                  float* out_depth, float* out_alpha, int* radii, int debug, void* stream_,
+                  const float* extra_features, float* out_extra) {
     hipStream_t stream = (hipStream_t)stream_;
     if (P < 0 || width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARG, "bad sizes P=%d W=%d H=%d", P, width, height);
+    fc.P = P;
     if (P == 0) return 0;  // rasterize_points.cu:83: outputs stay as the binding zero-filled them
     if (!geom_alloc || !binning_alloc || !image_alloc) return fail(GSR_ERR_INVALID_ARG, "null scratch callback");
     if (!means3D || !opacities || !background || !viewmatrix || !projmatrix || !cam_pos || !out_color ||
@@ -356,7 +390,7 @@ int forward_impl(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_
         return fail(GSR_ERR_INVALID_ARG, "provide exactly one of (scales, rotations) / cov3D_precomp");
     if (shs != nullptr && M <= 0) return fail(GSR_ERR_INVALID_ARG, "shs given with M=%d", M);
 
-    gsr::Camera cam;
+    gsr::Camera& cam = fc.cam;
     cam.viewmatrix = viewmatrix;
     cam.projmatrix = projmatrix;
     cam.cam_pos = cam_pos;
@@ -371,20 +405,27 @@ int forward_impl(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_
     if (cam.grid_x > 65535 || cam.grid_y > 65535) return fail(GSR_ERR_INVALID_ARG, "image too large");
     const int T = cam.grid_x * cam.grid_y;
     const size_t n = (size_t)P;
+    fc.stream = stream; fc.debug = debug; fc.prefiltered = prefiltered; fc.T = T; fc.width = width; fc.height = height;
+    fc.binning_alloc = binning_alloc; fc.binning_user = binning_user;
+    fc.colors_precomp = colors_precomp; fc.background = background; fc.extra_features = extra_features;
+    fc.out_color = out_color; fc.out_depth = out_depth; fc.out_alpha = out_alpha; fc.out_extra = out_extra;
 
     if (g_timing && !g_ev_made) {
         for (auto& set : g_ev)
             for (auto& e : set) GSR_HIP(hipEventCreate(&e));
         g_ev_made = true;
     }
-    g_slot = (int)(g_timed_calls % kTimingRing);
-    if (!g_pinned.host) {
-        GSR_HIP(hipHostMalloc((void**)&g_pinned.host, kCounterBytes + 64, hipHostMallocPortable));
-        GSR_HIP(hipEventCreateWithFlags(&g_pinned.copied, hipEventDisableTiming));
+    g_slot = fc.slot = (int)(g_timed_calls % kTimingRing);
+    if (!g_pinned_free.empty()) {
+        fc.pinned = g_pinned_free.back();
+        g_pinned_free.pop_back();
+    } else {
+        GSR_HIP(hipHostMalloc((void**)&fc.pinned.host, kCounterBytes + 64, hipHostMallocPortable));
+        GSR_HIP(hipEventCreateWithFlags(&fc.pinned.copied, hipEventDisableTiming));
     }
 
     // ---- geometry arena ----
-    const bool own_sort = g_options[GSR_OPT_SORT_IMPL] != 0;
+    const bool own_sort = fc.own_sort = g_options[GSR_OPT_SORT_IMPL] != 0;
     size_t sort_tmp = 0, scan_tmp = 0;
     const size_t dup_blocks = (n + gsr::kDupTile - 1) / gsr::kDupTile;
     if (own_sort) {
@@ -393,33 +434,34 @@ int forward_impl(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_
         GSR_HIP(gsr::depth_sort_temp_bytes(P, &sort_tmp));
         GSR_HIP(gsr::scan_temp_bytes(P, &scan_tmp));
     }
+    size_t* geom_off = fc.geom_off;
     Carver gc;
     gc.take<gsr::ArenaHeader>(1);  // header at the arena's aligned base
-    g_geom_off[GSR_GEOM_RASTER] = gc.take<gsr::SplatRaster>(n);
-    g_geom_off[GSR_GEOM_RGB] = gc.take<float>(3 * n);
-    g_geom_off[GSR_GEOM_SPLAT_BINS] = gc.take<gsr::SplatBin>(n);
-    g_geom_off[GSR_GEOM_INTERNAL_RADII] = gc.take<int>(n);
+    geom_off[GSR_GEOM_RASTER] = gc.take<gsr::SplatRaster>(n);
+    geom_off[GSR_GEOM_RGB] = gc.take<float>(3 * n);
+    geom_off[GSR_GEOM_SPLAT_BINS] = gc.take<gsr::SplatBin>(n);
+    geom_off[GSR_GEOM_INTERNAL_RADII] = gc.take<int>(n);
     const size_t off_keys_a = gc.take<uint32_t>(n), off_keys_b = gc.take<uint32_t>(n);
     const size_t off_ids_a = gc.take<uint32_t>(n), off_ids_b = gc.take<uint32_t>(n);
-    g_geom_off[GSR_GEOM_POINT_OFFSETS] = gc.take<uint32_t>(n);
+    geom_off[GSR_GEOM_POINT_OFFSETS] = gc.take<uint32_t>(n);
     const size_t off_flag = gc.take<gsr::FrameCounters>(1);
     const size_t off_tile_totals = gc.take<uint32_t>(2 * dup_blocks);  // tile totals, then global offsets at tile ends
     const size_t off_sorted_bins = gc.take<uint4>(own_sort ? n : 0);  // splat records again, in depth order
     const size_t off_tmp = gc.take<char>(sort_tmp > scan_tmp ? sort_tmp : scan_tmp);
     char* graw = geom_alloc(gc.total(), geom_user);
     if (!graw) return fail(GSR_ERR_ALLOC, "geometry scratch callback returned NULL for %zu bytes", gc.total());
-    char* gbase = align_base(graw);
-    const size_t gshift = (size_t)(gbase - graw);
+    char* gbase = fc.gbase = align_base(graw);
+    fc.gshift = (size_t)(gbase - graw);
 
     // ---- image arena ----
     Carver ic;
     ic.take<gsr::ArenaHeader>(1);
-    g_img_off[GSR_IMG_RANGES] = ic.take<uint2>((size_t)T);
-    g_img_off[GSR_IMG_N_CONTRIB] = ic.take<uint32_t>((size_t)width * height);
-    char* iraw = image_alloc(ic.total(), image_user);
-    if (!iraw) return fail(GSR_ERR_ALLOC, "image scratch callback returned NULL for %zu bytes", ic.total());
-    char* ibase = align_base(iraw);
-    for (auto& o : g_img_off) o += (size_t)(ibase - iraw);
+    fc.img_off[GSR_IMG_RANGES] = ic.take<uint2>((size_t)T);
+    fc.img_off[GSR_IMG_N_CONTRIB] = ic.take<uint32_t>((size_t)width * height);
+    fc.iraw = image_alloc(ic.total(), image_user);
+    if (!fc.iraw) return fail(GSR_ERR_ALLOC, "image scratch callback returned NULL for %zu bytes", ic.total());
+    fc.ibase = align_base(fc.iraw);
+    for (auto& o : fc.img_off) o += (size_t)(fc.ibase - fc.iraw);
 
     gsr::GaussianInputs in;
     in.P = P; in.sh_degree = D; in.M = M;
@@ -428,15 +470,17 @@ int forward_impl(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_
     in.scale_modifier = scale_modifier; in.prefiltered = prefiltered;
     in.tile_cull = g_options[GSR_OPT_TILE_CULL] != 0;
 
-    gsr::GeometryArrays ga;
-    ga.raster = (gsr::SplatRaster*)(gbase + g_geom_off[GSR_GEOM_RASTER]);
-    ga.rgb = (float*)(gbase + g_geom_off[GSR_GEOM_RGB]);
-    ga.bins = (gsr::SplatBin*)(gbase + g_geom_off[GSR_GEOM_SPLAT_BINS]);
-    ga.radii = radii ? radii : (int*)(gbase + g_geom_off[GSR_GEOM_INTERNAL_RADII]);
+    gsr::GeometryArrays& ga = fc.ga;
+    ga.raster = (gsr::SplatRaster*)(gbase + geom_off[GSR_GEOM_RASTER]);
+    ga.rgb = (float*)(gbase + geom_off[GSR_GEOM_RGB]);
+    ga.bins = (gsr::SplatBin*)(gbase + geom_off[GSR_GEOM_SPLAT_BINS]);
+    ga.radii = radii ? radii : (int*)(gbase + geom_off[GSR_GEOM_INTERNAL_RADII]);
     ga.depth_keys = (uint32_t*)(gbase + off_keys_a);
     ga.ids = own_sort ? nullptr : (uint32_t*)(gbase + off_ids_a);  // the first radix pass generates 0..P-1 itself
     ga.counters = (gsr::FrameCounters*)(gbase + off_flag);
-    uint32_t* point_offsets = (uint32_t*)(gbase + g_geom_off[GSR_GEOM_POINT_OFFSETS]);
+    fc.point_offsets = (uint32_t*)(gbase + geom_off[GSR_GEOM_POINT_OFFSETS]);
+    fc.tile_totals = (uint32_t*)(gbase + off_tile_totals);
+    fc.sorted_bins = (uint4*)(gbase + off_sorted_bins);
     void* tmp = gbase + off_tmp;
     const size_t tmp_bytes = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
 
@@ -449,27 +493,40 @@ int forward_impl(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_
     // The one host round trip of the call (rasterizer_impl.cu:282 reads num_rendered back to size the
     // binning arena).  Here the totals come out of the preprocess kernel, so the copy is queued right
     // behind it and the host waits on an event while the GPU is already running the depth sort.
-    char* hostb = reinterpret_cast<char*>(g_pinned.host);
-    GSR_HIP(hipMemcpyAsync(hostb, gbase + off_flag, kCounterBytes, hipMemcpyDeviceToHost, stream));
-    GSR_HIP(hipEventRecord(g_pinned.copied, stream));
+    GSR_HIP(hipMemcpyAsync(fc.pinned.host, gbase + off_flag, kCounterBytes, hipMemcpyDeviceToHost, stream));
+    GSR_HIP(hipEventRecord(fc.pinned.copied, stream));
+    fc.queued = true;
 
-    uint32_t *keys_sorted = nullptr, *order = nullptr;
+    uint32_t* keys_sorted = nullptr;
     if (own_sort) {
         GSR_HIP(gsr::radix_sort_pairs((uint32_t*)tmp, (uint32_t)P, 32, ga.depth_keys, (uint32_t*)(gbase + off_keys_b),
                                       (uint32_t*)(gbase + off_ids_a), (uint32_t*)(gbase + off_ids_b),
-                                      /*iota_payload=*/true, /*want_sorted_keys=*/false, &keys_sorted, &order, stream));
+                                      /*iota_payload=*/true, /*want_sorted_keys=*/false, &keys_sorted, &fc.order, stream));
     } else {
         GSR_HIP(gsr::depth_sort(tmp, tmp_bytes, P, ga.depth_keys, (uint32_t*)(gbase + off_keys_b), ga.ids,
-                                (uint32_t*)(gbase + off_ids_b), &keys_sorted, &order, stream));
+                                (uint32_t*)(gbase + off_ids_b), &keys_sorted, &fc.order, stream));
     }
     GSR_STAGE_CHECK("depth_sort");
     stamp(2, stream);
-    g_geom_off[GSR_GEOM_DEPTH_ORDER] = (size_t)((char*)order - gbase);
+    geom_off[GSR_GEOM_DEPTH_ORDER] = (size_t)((char*)fc.order - gbase);
 
-    if (!own_sort) GSR_HIP(gsr::scan_tiles_in_order(tmp, tmp_bytes, P, ga.bins, order, point_offsets, stream));
+    if (!own_sort) GSR_HIP(gsr::scan_tiles_in_order(tmp, tmp_bytes, P, ga.bins, fc.order, fc.point_offsets, stream));
+    return 0;
+}
 
-    GSR_HIP(hipEventSynchronize(g_pinned.copied));
-    const gsr::FrameCounters* hc = reinterpret_cast<const gsr::FrameCounters*>(hostb);  // first kCounterBytes only
+int forward_finish(ForwardCall& fc) {
+    if (fc.P == 0) return 0;
+    hipStream_t stream = fc.stream;
+    const int debug = fc.debug, P = fc.P, T = fc.T;
+    const bool own_sort = fc.own_sort;
+    const gsr::Camera& cam = fc.cam;
+    const gsr::GeometryArrays& ga = fc.ga;
+    char* const gbase = fc.gbase;
+    g_slot = fc.slot;
+
+    GSR_HIP(hipEventSynchronize(fc.pinned.copied));
+    fc.queued = false;
+    const gsr::FrameCounters* hc = reinterpret_cast<const gsr::FrameCounters*>(fc.pinned.host);  // first kCounterBytes only
     const uint32_t flag = hc->error_flag;
     unsigned long long rect_total = 0, live_total = 0, emitting = 0;
     for (int i = 0; i < gsr::kRectPartials; ++i) {
@@ -477,15 +534,12 @@ int forward_impl(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_
         live_total += hc->pair_totals[i] & 0xFFFFFFFFull;
         emitting += hc->visible[i];
     }
-    if (debug && prefiltered && (flag & 1u))
+    if (debug && fc.prefiltered && (flag & 1u))
         return fail(GSR_ERR_PREFILTERED, "a Gaussian was culled although prefiltered is set (auxiliary.h:156-160)");
     if (rect_total > 0x7FFFFFFFull) return fail(GSR_ERR_INVALID_ARG, "num_rendered %llu overflows int", rect_total);
     const uint32_t num_live = (uint32_t)live_total;
     const uint32_t num_rendered = (uint32_t)rect_total;  // the reference's count; == num_live when culling is off
-    g_counts[0] = num_rendered;
-    g_counts[1] = num_live;
     stamp(3, stream);
-    for (auto& o : g_geom_off) o += gshift;
 
     // ---- binning arena ----
     const size_t nr = num_live ? num_live : 1;
@@ -499,20 +553,20 @@ int forward_impl(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_
     const size_t off_tk_a = bc.take<uint32_t>(nr), off_tk_b = bc.take<uint32_t>(nr);
     const size_t off_pl_a = bc.take<uint32_t>(nr), off_pl_b = bc.take<uint32_t>(nr);
     const size_t off_btmp = bc.take<char>(tsort_tmp);
-    char* braw = binning_alloc(bc.total(), binning_user);
+    char* braw = fc.binning_alloc(bc.total(), fc.binning_user);
     if (!braw) return fail(GSR_ERR_ALLOC, "binning scratch callback returned NULL for %zu bytes", bc.total());
     char* bbase = align_base(braw);
     uint32_t *tile_keys = (uint32_t*)(bbase + off_tk_a), *point_list = (uint32_t*)(bbase + off_pl_a);
 
-    uint2* ranges = (uint2*)(iraw + g_img_off[GSR_IMG_RANGES]);
-    uint32_t* n_contrib = (uint32_t*)(iraw + g_img_off[GSR_IMG_N_CONTRIB]);
+    uint2* ranges = (uint2*)(fc.iraw + fc.img_off[GSR_IMG_RANGES]);
+    uint32_t* n_contrib = (uint32_t*)(fc.iraw + fc.img_off[GSR_IMG_N_CONTRIB]);
 
     if (own_sort)  // also when nothing is live: POINT_OFFSETS is an output
-        GSR_HIP(gsr::launch_scan_expand(P, (int)emitting, num_live, cam, order, ga.bins, (uint4*)(gbase + off_sorted_bins),
-                                        (uint32_t*)(gbase + off_tile_totals), point_offsets, tile_keys, point_list, stream));
+        GSR_HIP(gsr::launch_scan_expand(P, (int)emitting, num_live, cam, fc.order, ga.bins, fc.sorted_bins, fc.tile_totals,
+                                        fc.point_offsets, tile_keys, point_list, stream));
     if (num_live > 0) {
         if (!own_sort)
-            GSR_HIP(gsr::launch_duplicate(P, cam, order, point_offsets, ga.bins, tile_keys, point_list, stream));
+            GSR_HIP(gsr::launch_duplicate(P, cam, fc.order, fc.point_offsets, ga.bins, tile_keys, point_list, stream));
         GSR_STAGE_CHECK("duplicate");
         stamp(4, stream);
         uint32_t *tk_sorted = nullptr, *pl_sorted = nullptr;
@@ -533,8 +587,6 @@ int forward_impl(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_
         stamp(4, stream);
         stamp(5, stream);
     }
-    g_bin_off[GSR_BIN_POINT_LIST] = (size_t)((char*)point_list - braw);
-    g_bin_off[GSR_BIN_TILE_KEYS] = (size_t)((char*)tile_keys - braw);
 
     {   // self-describing arenas for gsr_backward
         gsr::ArenaHeader hg = {}, hb = {}, hi = {};
@@ -543,29 +595,43 @@ int forward_impl(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_
         hg.count[0] = (uint32_t)P; hg.count[1] = num_rendered; hg.count[2] = num_live;
         hg.off[0] = (uint64_t)((char*)ga.raster - gbase);
         hg.off[3] = (uint64_t)((char*)ga.rgb - gbase);
-        hg.off[4] = (uint64_t)(g_geom_off[GSR_GEOM_INTERNAL_RADII] - gshift);
+        hg.off[4] = (uint64_t)fc.geom_off[GSR_GEOM_INTERNAL_RADII];
         hb.count[0] = num_live;
         hb.off[0] = (uint64_t)((char*)point_list - bbase);
-        hi.count[0] = (uint32_t)width; hi.count[1] = (uint32_t)height; hi.count[2] = (uint32_t)T;
-        hi.off[0] = (uint64_t)((char*)ranges - ibase);
-        hi.off[1] = (uint64_t)((char*)n_contrib - ibase);
+        hi.count[0] = (uint32_t)fc.width; hi.count[1] = (uint32_t)fc.height; hi.count[2] = (uint32_t)T;
+        hi.off[0] = (uint64_t)((char*)ranges - fc.ibase);
+        hi.off[1] = (uint64_t)((char*)n_contrib - fc.ibase);
         const gsr::ArenaHeader hs[3] = {hg, hb, hi};
-        void* const dsts[3] = {gbase, bbase, ibase};
+        void* const dsts[3] = {gbase, bbase, fc.ibase};
         // tile ranges (all (0,0) when nothing is live: rasterizer_impl.cu:311) + the three headers, one launch
         GSR_HIP(gsr::launch_tile_ranges(num_live, T, tile_keys, ranges, dsts, hs, stream));
         GSR_STAGE_CHECK("tile_ranges");
         stamp(6, stream);
     }
 
-    const float* features = colors_precomp != nullptr ? colors_precomp : ga.rgb;
-    GSR_HIP(gsr::launch_blend(cam, g_options[GSR_OPT_BLEND_VARIANT], g_options[GSR_OPT_BLEND_LDS_PAD], ranges, point_list, ga.raster, features, background,
-                              out_color, out_depth, out_alpha, n_contrib, stream, extra_features, out_extra));
+    const float* features = fc.colors_precomp != nullptr ? fc.colors_precomp : ga.rgb;
+    GSR_HIP(gsr::launch_blend(cam, g_options[GSR_OPT_BLEND_VARIANT], g_options[GSR_OPT_BLEND_LDS_PAD], ranges, point_list,
+                              ga.raster, features, fc.background, fc.out_color, fc.out_depth, fc.out_alpha, n_contrib,
+                              stream, fc.extra_features, fc.out_extra));
     GSR_STAGE_CHECK("blend");
     stamp(7, stream);
     if (g_timing) ++g_timed_calls;
+
+    // what the gsr_last_* accessors report: the call that finished last on this thread
+    for (int i = 0; i < GSR_GEOM_NUM_SLOTS; ++i) g_geom_off[i] = fc.geom_off[i] + fc.gshift;
+    memcpy(g_img_off, fc.img_off, sizeof g_img_off);
+    g_bin_off[GSR_BIN_POINT_LIST] = (size_t)((char*)point_list - braw);
+    g_bin_off[GSR_BIN_TILE_KEYS] = (size_t)((char*)tile_keys - braw);
+    g_counts[0] = num_rendered;
+    g_counts[1] = num_live;
     g_have_offsets = true;
     return (int)num_rendered;
 }
+
+#define GSR_FORWARD_ARGS                                                                                             \
+    geom_alloc, geom_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background, width, height, \
+        means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,      \
+        projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii, debug, stream
 } // namespace
 
 extern "C" {
@@ -577,10 +643,9 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                 const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
                 float* out_depth, float* out_alpha, int* radii, int debug, void* stream) {
-    return forward_impl(geom_alloc, geom_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background,
-                        width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
-                        cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color,
-                        out_depth, out_alpha, radii, debug, stream, nullptr, nullptr);
+    ForwardCall fc;
+    const int rc = forward_begin(fc, GSR_FORWARD_ARGS, nullptr, nullptr);
+    return rc < 0 ? rc : forward_finish(fc);
 }
 
 int gsr_forward_extra(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_alloc, void* binning_user,
@@ -592,10 +657,43 @@ int gsr_forward_extra(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn bin
                       float* out_depth, float* out_alpha, int* radii, const float* extra_features, float* out_extra,
                       int debug, void* stream) {
     if (P > 0 && (!extra_features || !out_extra)) return fail(GSR_ERR_INVALID_ARG, "null extra feature pointer");
-    return forward_impl(geom_alloc, geom_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background,
-                        width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
-                        cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color,
-                        out_depth, out_alpha, radii, debug, stream, extra_features, out_extra);
+    ForwardCall fc;
+    const int rc = forward_begin(fc, GSR_FORWARD_ARGS, extra_features, out_extra);
+    return rc < 0 ? rc : forward_finish(fc);
 }
+
+void* gsr_forward_begin(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_alloc, void* binning_user,
+                        gsr_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background,
+                        int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
+                        const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                        const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                        const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                        float* out_depth, float* out_alpha, int* radii, const float* extra_features, float* out_extra,
+                        int debug, void* stream) {
+    if ((extra_features != nullptr) != (out_extra != nullptr)) {
+        fail(GSR_ERR_INVALID_ARG, "extra_features and out_extra must be given together");
+        return nullptr;
+    }
+    ForwardCall* fc = new (std::nothrow) ForwardCall;
+    if (!fc) {
+        fail(GSR_ERR_ALLOC, "out of host memory");
+        return nullptr;
+    }
+    if (forward_begin(*fc, GSR_FORWARD_ARGS, extra_features, out_extra) < 0) {
+        delete fc;
+        return nullptr;
+    }
+    return fc;
+}
+
+int gsr_forward_finish(void* call) {
+    if (!call) return fail(GSR_ERR_INVALID_ARG, "null call handle");
+    ForwardCall* fc = static_cast<ForwardCall*>(call);
+    const int rc = forward_finish(*fc);
+    delete fc;
+    return rc;
+}
+
+void gsr_forward_cancel(void* call) { delete static_cast<ForwardCall*>(call); }
 
 } // extern "C"

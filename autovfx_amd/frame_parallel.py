@@ -80,35 +80,110 @@ def rasterize(cloud: GaussianCloud, cam: Camera, bg: torch.Tensor):
                 rotations=cloud.rotations)
 
 
+class PendingFrame:
+    """A frame whose first half is queued (``rasterize_begin``); ``finish()`` queues the rest and returns
+    ``(color, depth, alpha, radii)`` like ``rasterize``."""
+
+    def __init__(self, pending, keep):
+        self._pending, self._keep = pending, keep
+
+    def finish(self):
+        _n, color, depth, alpha, radii = self._pending.finish()[:5]
+        self._keep = None
+        return color, depth, alpha, radii
+
+
+def rasterize_begin(cloud: GaussianCloud, cam: Camera, bg: torch.Tensor) -> PendingFrame:
+    """``rasterize`` in two halves, for inference only (no autograd graph is recorded): projection and depth sort
+    are queued on the current stream and the call returns without waiting for the GPU, so one host thread can hold
+    a frame in flight on each of several streams.  Arguments reach the library in the order
+    ``_RasterizeGaussians.forward`` passes them (reference ``__init__.py:62-82``)."""
+    from diff_gaussian_rasterization import _C
+    s = settings_for_camera(cam, bg, cloud.sh_degree)
+    absent = torch.empty(0, dtype=torch.float32, device=cloud.means3D.device)
+    shs = absent if cloud.colors_precomp is not None else cloud.shs
+    colors = cloud.colors_precomp if cloud.colors_precomp is not None else absent
+    with torch.no_grad():
+        pending = _C.rasterize_gaussians_begin(
+            s.bg, cloud.means3D, colors, cloud.opacities, cloud.scales, cloud.rotations, s.scale_modifier, absent,
+            s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, shs, s.sh_degree,
+            s.campos, s.prefiltered, s.debug)
+    return PendingFrame(pending, (s, absent))
+
+
 RenderFn = Callable[[GaussianCloud, Camera, torch.Tensor], Sequence[torch.Tensor]]
 
 
 def render_shard(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids: Sequence[int], bg: torch.Tensor,
-                 keep_depth: bool = False, render_fn: RenderFn = rasterize, streams: int = 3) -> Dict[str, torch.Tensor]:
+                 keep_depth: bool = False, render_fn: RenderFn = rasterize, streams: int = 3,
+                 driver: str = "auto") -> Dict[str, torch.Tensor]:
     """Render this rank's frames; returns stacked ``rgba8 [n,4,H,W]`` (and ``depth [n,H,W]``).
 
-    ``streams > 1`` (GPU only) renders frame ``slot`` on HIP stream ``slot % streams``, each stream driven by
-    its own host thread.  Frames are independent, and a frame's blend (VALU-bound) overlaps well with
-    other frames' projection and sorts (HBM / latency-bound): three streams (the default) raise throughput by about a
-    quarter at C3 on MI355X without touching per-frame results.  The call returns after all streams drained.
+    ``streams > 1`` (GPU only) renders frame ``slot`` on HIP stream ``slot % streams``.  Frames are independent, and
+    a frame's blend (VALU-bound) overlaps well with other frames' projection and sorts (HBM / latency-bound): three
+    streams (the default) raise throughput by about a quarter at C3 on MI355X without touching per-frame results.
+    Two ways of feeding the streams:
+
+    * ``driver="pipelined"``: ONE host thread.  Each frame's call is split where the host needs the pair count
+      (``rasterize_begin`` / ``finish``): the thread queues the first half of frame ``i + streams - 1`` before it
+      waits for the counters of frame ``i``, so the GPU always has the other streams' work queued and no second
+      thread, lock or GIL hand-over sits on the frame path.  Needs the library's own call, i.e. the default
+      ``render_fn``.
+    * ``driver="threads"``: one host thread per stream, each making ordinary blocking calls (any ``render_fn``).
+
+    ``"auto"`` picks ``pipelined`` when ``render_fn`` is ``rasterize``.  The call returns after all streams drained.
     """
     device = cloud.means3D.device
     n = len(frame_ids)
     H, W = (cameras[0].image_height, cameras[0].image_width) if len(cameras) else (0, 0)
     rgba = torch.empty((n, 4, H, W), dtype=torch.uint8, device=device)
     depth = torch.empty((n, H, W), dtype=torch.float32, device=device) if keep_depth else None
+    if driver not in ("auto", "pipelined", "threads"):
+        raise ValueError(f"unknown driver {driver!r}")
+    if driver == "pipelined" and render_fn is not rasterize:
+        raise ValueError("the pipelined driver needs the default render_fn (it splits the library's own call)")
+    if driver == "auto":
+        driver = "pipelined" if render_fn is rasterize else "threads"
+
+    def keep(slot, color, d, alpha):
+        pack_rgba8(color, alpha, out=rgba[slot])
+        if keep_depth:
+            depth[slot].copy_(d[0])
 
     def render_slots(slots):
         with torch.no_grad():
             for slot in slots:
                 color, d, alpha, _radii = render_fn(cloud, cameras[frame_ids[slot]], bg)
-                pack_rgba8(color, alpha, out=rgba[slot])
-                if keep_depth:
-                    depth[slot].copy_(d[0])
+                keep(slot, color, d, alpha)
 
     streams = max(1, int(streams)) if device.type == "cuda" else 1
     if streams == 1 or n < 2:
         render_slots(range(n))
+    elif driver == "pipelined":
+        from collections import deque
+        caller = torch.cuda.current_stream(device)
+        side = [torch.cuda.Stream(device=device) for _ in range(streams)]
+        for st in side:
+            st.wait_stream(caller)                 # inputs produced on the caller's stream are visible
+        in_flight = deque()
+
+        def finish_oldest():
+            slot, st, pending = in_flight.popleft()
+            with torch.cuda.stream(st):
+                color, d, alpha, _radii = pending.finish()
+                keep(slot, color, d, alpha)
+
+        with torch.no_grad():
+            for slot in range(n):
+                if len(in_flight) == streams:      # stream slot % streams is the oldest frame's: finish it first
+                    finish_oldest()
+                st = side[slot % streams]
+                with torch.cuda.stream(st):
+                    in_flight.append((slot, st, rasterize_begin(cloud, cameras[frame_ids[slot]], bg)))
+            while in_flight:
+                finish_oldest()
+        for st in side:
+            caller.wait_stream(st)                 # results are ordered before later work of the caller
     else:
         import threading
         caller = torch.cuda.current_stream(device)
@@ -195,7 +270,7 @@ def broadcast_cloud(cloud: Optional[GaussianCloud], src: int = 0, device=None, g
 
 def render_and_gather(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids: Sequence[int], bg: torch.Tensor,
                       dst: int = 0, render_fn: RenderFn = rasterize, streams: int = 3, chunks: int = 4,
-                      group=None) -> Optional[torch.Tensor]:
+                      group=None, driver: str = "auto") -> Optional[torch.Tensor]:
     """Render ``frame_ids`` (this rank's frames; every rank must pass the same number) and gather the RGBA8 frames
     to ``dst`` while rendering continues: the shard is cut into ``chunks`` pieces, and as soon as a piece is rendered
     its ``gather`` is launched asynchronously (RCCL runs it on its own stream over xGMI) behind the next piece's
@@ -209,7 +284,7 @@ def render_and_gather(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids
     bounds = [n * k // chunks for k in range(chunks + 1)]
     parts, received, works = [], [], []
     for a, b in zip(bounds[:-1], bounds[1:]):
-        part = render_shard(cloud, cameras, list(frame_ids[a:b]), bg, False, render_fn, streams)["rgba8"]
+        part = render_shard(cloud, cameras, list(frame_ids[a:b]), bg, False, render_fn, streams, driver)["rgba8"]
         parts.append(part)                       # kept alive until the transfers have been waited for
         if distributed:
             bufs = [torch.empty_like(part) for _ in range(world)] if rank == dst else None
@@ -225,13 +300,14 @@ def render_and_gather(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids
 
 
 def render_trajectory(cloud: GaussianCloud, cameras: Sequence[Camera], bg: torch.Tensor, keep_depth: bool = False,
-                      dst: int = 0, render_fn: RenderFn = rasterize, streams: int = 3) -> Optional[Dict[str, torch.Tensor]]:
+                      dst: int = 0, render_fn: RenderFn = rasterize, streams: int = 3,
+                      driver: str = "auto") -> Optional[Dict[str, torch.Tensor]]:
     """Shard -> render -> gather.  Works with or without an initialised process group."""
     if dist.is_available() and dist.is_initialized():
         rank, world = dist.get_rank(), dist.get_world_size()
     else:
         rank, world = 0, 1
     ids = shard_frames(len(cameras), rank, world)
-    local = render_shard(cloud, cameras, ids, bg, keep_depth, render_fn, streams)
+    local = render_shard(cloud, cameras, ids, bg, keep_depth, render_fn, streams, driver)
     gathered = {k: gather_frames(v, len(cameras), dst) for k, v in local.items()}
     return gathered if rank == dst else None

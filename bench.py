@@ -82,7 +82,11 @@ def main():
     ap.add_argument("--gather-chunks", type=int, default=4,
                     help="N > 1: pieces the per-rank frame stack is gathered in, each overlapped with the next piece's rendering")
     ap.add_argument("--streams", type=int, default=3,
-                    help="render frames on this many HIP streams (one host thread each) so independent frames overlap")
+                    help="render frames on this many HIP streams so independent frames overlap")
+    ap.add_argument("--driver", choices=["auto", "pipelined", "threads"], default="auto",
+                    help="how the streams are fed: 'pipelined' = one host thread, each call split where the host needs "
+                         "the pair count; 'threads' = one blocking host thread per stream; auto = pipelined for "
+                         "--boundary op, threads for --boundary render")
     ap.add_argument("--boundary", choices=["op", "render"], default="op",
                     help="op: one GaussianRasterizer.forward per frame (the headline); render: the reference's "
                          "whole per-frame render() = activations + SH pass + normal pass + normal post-processing")
@@ -112,7 +116,7 @@ def main():
 
     from autovfx_amd import _lib, scenes
     from autovfx_amd.cameras import orbit_cameras
-    from autovfx_amd.frame_parallel import pack_rgba8, rasterize, render_and_gather
+    from autovfx_amd.frame_parallel import pack_rgba8, rasterize, rasterize_begin, render_and_gather
     from diff_gaussian_rasterization import _C
 
     if args.blend_variant is not None:
@@ -161,12 +165,39 @@ def main():
 
     S = max(1, args.streams)
     streams = [torch.cuda.Stream(device=device) for _ in range(S)] if S > 1 else []
+    driver = args.driver
+    if driver == "auto":
+        driver = "pipelined" if args.boundary == "op" else "threads"
+    if driver == "pipelined" and args.boundary != "op":
+        raise SystemExit("--driver pipelined splits the rasterizer call; use it with --boundary op")
 
     def run_steps(first, count):
         """Steps first .. first+count-1; with S > 1 streams, step j goes to host thread / stream j % S."""
         if S == 1:
             for j in range(count):
                 step(first + j, j)
+            return
+        if driver == "pipelined":   # one host thread; frame j's second half is queued after frame j+S-1's first half
+            from collections import deque
+            in_flight = deque()
+
+            def finish_oldest():
+                j, st, pending = in_flight.popleft()
+                with torch.cuda.stream(st):
+                    color, _depth, alpha, _radii = pending.finish()
+                    pack_rgba8(color, alpha, out=rgba[j % K])
+
+            with torch.no_grad():
+                for j in range(count):
+                    if len(in_flight) == S:
+                        finish_oldest()
+                    st = streams[j % S]
+                    with torch.cuda.stream(st):
+                        in_flight.append((j, st, rasterize_begin(cloud, cams[frame_of(first + j)], bg)))
+                while in_flight:
+                    finish_oldest()
+            for st in streams:
+                torch.cuda.current_stream(device).wait_stream(st)
             return
         import threading
 
@@ -199,6 +230,7 @@ def main():
             # pieces that travel over xGMI behind the rendering of the next piece (only the last one is a tail)
             cam_list = [cams[frame_of(Wm + j)] for j in range(K)]
             gathered = render_and_gather(cloud, cam_list, list(range(K)), bg, dst=0, streams=S, chunks=args.gather_chunks,
+                                         driver=driver,
                                          render_fn=(render_fn_boundary if args.boundary == "render" else rasterize))
         else:
             run_steps(Wm, K)
@@ -286,7 +318,7 @@ def main():
                                     "post-processing, RGBA8 pack per frame" if args.boundary == "render" else
                                     "GaussianRasterizer.forward (SH) + RGBA8 pack per frame")
                                    + ("; RCCL gather of the RGBA8 frames to rank 0, pipelined behind the rendering" if world > 1 and not args.no_gather else ""),
-                       "parallelism": f"frame-parallel x{world}", "streams_per_gpu": S,
+                       "parallelism": f"frame-parallel x{world}", "streams_per_gpu": S, "stream_driver": driver if S > 1 else "serial",
                        "options": {"tile_cull": _lib.get_option(_lib.OPT_TILE_CULL),
                                    "blend_variant": _lib.get_option(_lib.OPT_BLEND_VARIANT)}},
             "roofline": roofline, "cpu_baseline": cpu_baseline,

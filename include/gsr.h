@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 3
+#define GSR_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define GSR_API __attribute__((visibility("default")))
@@ -101,6 +101,35 @@ GSR_API int gsr_forward_extra(gsr_alloc_fn geom_alloc, void* geom_user, gsr_allo
                               const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
                               float* out_depth, float* out_alpha, int* radii /*nullable*/,
                               const float* extra_features /*[P,3]*/, float* out_extra /*[3,H,W]*/, int debug, void* stream);
+
+/* gsr_forward_extra in two halves, for callers that keep several frames in flight from ONE host thread.
+ *
+ * gsr_forward has one host round trip in the middle (the pair count sizes the binning arena: rasterizer_impl.cu:282),
+ * so a caller that wants frame i+1's projection and depth sort queued while frame i is still on the GPU needs either
+ * a thread per stream or this split:
+ *
+ *   gsr_forward_begin   validates, calls the geometry and image callbacks, queues projection + depth sort and the
+ *                       copy of the frame counters on `stream`, and returns an opaque call handle without waiting
+ *                       (NULL on error, gsr_last_error() says why).  extra_features / out_extra may both be NULL.
+ *   gsr_forward_finish  waits for that call's counters only, calls the binning callback, queues the remaining
+ *                       stages, frees the handle (also on error) and returns what gsr_forward returns.
+ *   gsr_forward_cancel  frees a handle whose finish will not be called (outputs are then undefined).
+ *
+ * begin immediately followed by finish IS gsr_forward_extra: same launches, same results.  Every pointer passed to
+ * begin must stay valid until finish has been called and `stream` has drained; finish must be called on the
+ * thread that called begin (the gsr_last_* accessors then describe that call). */
+GSR_API void* gsr_forward_begin(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_alloc, void* binning_user,
+                                gsr_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background,
+                                int width, int height, const float* means3D, const float* shs /*nullable*/,
+                                const float* colors_precomp /*nullable*/, const float* opacities,
+                                const float* scales /*nullable*/, float scale_modifier,
+                                const float* rotations /*nullable*/, const float* cov3D_precomp /*nullable*/,
+                                const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                                float tan_fovy, int prefiltered, float* out_color, float* out_depth, float* out_alpha,
+                                int* radii /*nullable*/, const float* extra_features /*nullable*/,
+                                float* out_extra /*nullable*/, int debug, void* stream);
+GSR_API int gsr_forward_finish(void* call);
+GSR_API void gsr_forward_cancel(void* call);
 
 /* present[i] = (view-space z of means3D[i]) > 0.2 ; present is a device array of P bytes (bool). */
 GSR_API int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -87,6 +87,15 @@ def test_argument_errors_do_not_need_a_device():
     assert L.gsr_forward_extra(*args, 5, 3, 16, None, 64, 64, None, None, None, None, None, 1.0, None, None, None, None,
                                None, 0.5, 0.5, 0, *tail_extra) == -1
     assert "extra" in _lib.last_error()
+    # the split call: a failed begin returns NULL and says why; finish refuses a NULL handle; cancel accepts one
+    assert L.gsr_forward_begin(*args, 5, 3, 16, None, 64, 64, None, None, None, None, None, 1.0, None, None, None, None,
+                               None, 0.5, 0.5, 0, *tail_extra) is None
+    assert "null" in _lib.last_error()
+    assert L.gsr_forward_finish(None) == -1 and "handle" in _lib.last_error()
+    L.gsr_forward_cancel(None)
+    h = L.gsr_forward_begin(*args, 0, 3, 16, None, 64, 64, None, None, None, None, None, 1.0, None, None, None, None,
+                            None, 0.5, 0.5, 0, *tail_extra)
+    assert h and L.gsr_forward_finish(h) == 0                        # P == 0: a handle with nothing queued
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

@@ -526,8 +526,10 @@ def test_full_size_properties(c3_frame):
     np.testing.assert_array_equal(c["radii"], a["radii"][perm.numpy()])
 
 
-def test_multi_stream_shard_matches_serial():
-    """render_shard(streams=2) (two host threads, two HIP streams) returns exactly the serial result."""
+@pytest.mark.parametrize("driver,streams", [("threads", 2), ("pipelined", 2), ("pipelined", 3), ("pipelined", 5)])
+def test_multi_stream_shard_matches_serial(driver, streams):
+    """render_shard on several HIP streams -- one blocking host thread per stream, or one host thread with every
+    call split at its host round trip -- returns exactly the serial result."""
     from autovfx_amd import frame_parallel as fp
     dev = torch.device("cuda", 0)
     cloud = scenes.config_c2(P=100_000, seed=2).to(dev)
@@ -535,10 +537,67 @@ def test_multi_stream_shard_matches_serial():
     bg = torch.zeros(3, device=dev)
     ids = list(range(9))
     a = fp.render_shard(cloud, cams, ids, bg, keep_depth=True, streams=1)
-    b = fp.render_shard(cloud, cams, ids, bg, keep_depth=True, streams=2)
+    b = fp.render_shard(cloud, cams, ids, bg, keep_depth=True, streams=streams, driver=driver)
     torch.cuda.synchronize()
     assert torch.equal(a["rgba8"], b["rgba8"]) and torch.equal(a["depth"], b["depth"])
     assert len({bytes(f.cpu().numpy().tobytes()) for f in a["rgba8"]}) == 9
+
+
+def test_split_call_is_the_one_shot_call():
+    """gsr_forward_begin + gsr_forward_finish queue the launches of gsr_forward_extra: every output, the scratch
+    layout and the pair counts are identical; calls may be begun in one order and finished in another; a handle
+    that is dropped without finish() is cancelled cleanly; finish() twice is an error."""
+    from diff_gaussian_rasterization import _C
+    from autovfx_amd import frame_parallel as fp
+    dev = torch.device("cuda", 0)
+    cloud = scenes.config_c2(P=60_000, seed=5).to(dev)
+    cams = [c.to(dev) for c in orbit_cameras(4, 256, 144)]
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    extra = torch.rand(cloud.P, 3, device=dev)
+    absent = torch.empty(0, device=dev)
+
+    def args(cam):
+        st = fp.settings_for_camera(cam, bg, cloud.sh_degree)
+        return (st.bg, cloud.means3D, absent, cloud.opacities, cloud.scales, cloud.rotations, st.scale_modifier, absent,
+                st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, st.image_height, st.image_width, cloud.shs,
+                st.sh_degree, st.campos, st.prefiltered, st.debug)
+
+    _C.set_geometry_cache(False)
+    try:
+        whole = [_C.rasterize_gaussians_extra(*args(c), extra) for c in cams]
+        layouts = []
+        for c in cams:
+            _C.rasterize_gaussians_extra(*args(c), extra)
+            layouts.append(_C.last_layout())
+        pending = [_C.rasterize_gaussians_begin(*args(c), extra) for c in cams]     # four calls in flight, one stream
+        halves = {}
+        for k in (2, 0, 3, 1):                                                      # finished out of order
+            halves[k] = pending[k].finish()
+            assert _C.last_layout() == layouts[k]
+        torch.cuda.synchronize()
+        for k, w in enumerate(whole):
+            h = halves[k]
+            assert h[0] == w[0] > 0
+            for i in (1, 2, 3, 4, 8):
+                assert torch.equal(h[i], w[i]), f"frame {k} output {i}"
+            assert h[5].numel() == w[5].numel() and h[6].numel() == w[6].numel() and h[7].numel() == w[7].numel()
+        with pytest.raises(RuntimeError, match="twice"):
+            pending[0].finish()
+        dropped = _C.rasterize_gaussians_begin(*args(cams[0]), None)
+        del dropped                                                                  # cancelled, nothing leaks or hangs
+        again = _C.rasterize_gaussians_begin(*args(cams[1]), None).finish()
+        torch.cuda.synchronize()
+        assert torch.equal(again[1], whole[1][1]) and again[8] is None
+        side = torch.cuda.Stream(device=dev)
+        wrong = _C.rasterize_gaussians_begin(*args(cams[0]), None)
+        with torch.cuda.stream(side), pytest.raises(RuntimeError, match="stream"):
+            wrong.finish()
+        empty = _C.rasterize_gaussians_begin(bg, torch.empty(0, 3, device=dev), absent, absent, absent, absent, 1.0,
+                                             absent, *args(cams[0])[8:14], absent, 3, args(cams[0])[16], False, False)
+        r = empty.finish()
+        assert r[0] == 0 and float(r[1].abs().max()) == 0.0
+    finally:
+        _C.set_geometry_cache(True)
 
 
 def test_second_pass_reuses_geometry_bit_for_bit():
