@@ -112,11 +112,13 @@ def rasterize_begin(cloud: GaussianCloud, cam: Camera, bg: torch.Tensor) -> Pend
 
 
 RenderFn = Callable[[GaussianCloud, Camera, torch.Tensor], Sequence[torch.Tensor]]
+# the split form of a RenderFn: returns an object whose ``finish()`` returns what the RenderFn returns
+BeginFn = Callable[[GaussianCloud, Camera, torch.Tensor], object]
 
 
 def render_shard(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids: Sequence[int], bg: torch.Tensor,
                  keep_depth: bool = False, render_fn: RenderFn = rasterize, streams: int = 3,
-                 driver: str = "auto") -> Dict[str, torch.Tensor]:
+                 driver: str = "auto", begin_fn: Optional[BeginFn] = None) -> Dict[str, torch.Tensor]:
     """Render this rank's frames; returns stacked ``rgba8 [n,4,H,W]`` (and ``depth [n,H,W]``).
 
     ``streams > 1`` (GPU only) renders frame ``slot`` on HIP stream ``slot % streams``.  Frames are independent, and
@@ -127,11 +129,12 @@ def render_shard(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids: Seq
     * ``driver="pipelined"``: ONE host thread.  Each frame's call is split where the host needs the pair count
       (``rasterize_begin`` / ``finish``): the thread queues the first half of frame ``i + streams - 1`` before it
       waits for the counters of frame ``i``, so the GPU always has the other streams' work queued and no second
-      thread, lock or GIL hand-over sits on the frame path.  Needs the library's own call, i.e. the default
-      ``render_fn``.
+      thread, lock or GIL hand-over sits on the frame path.  Needs the call in split form: the default ``render_fn``
+      has one (``rasterize_begin``); for another ``render_fn`` pass its ``begin_fn`` (e.g. one built on
+      ``renderer.render_begin``).
     * ``driver="threads"``: one host thread per stream, each making ordinary blocking calls (any ``render_fn``).
 
-    ``"auto"`` picks ``pipelined`` when ``render_fn`` is ``rasterize``.  The call returns after all streams drained.
+    ``"auto"`` picks ``pipelined`` when a split form is available.  The call returns after all streams drained.
     """
     device = cloud.means3D.device
     n = len(frame_ids)
@@ -140,10 +143,12 @@ def render_shard(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids: Seq
     depth = torch.empty((n, H, W), dtype=torch.float32, device=device) if keep_depth else None
     if driver not in ("auto", "pipelined", "threads"):
         raise ValueError(f"unknown driver {driver!r}")
-    if driver == "pipelined" and render_fn is not rasterize:
-        raise ValueError("the pipelined driver needs the default render_fn (it splits the library's own call)")
+    if begin_fn is None and render_fn is rasterize:
+        begin_fn = rasterize_begin
+    if driver == "pipelined" and begin_fn is None:
+        raise ValueError("the pipelined driver needs begin_fn, the split form of render_fn")
     if driver == "auto":
-        driver = "pipelined" if render_fn is rasterize else "threads"
+        driver = "pipelined" if begin_fn is not None else "threads"
 
     def keep(slot, color, d, alpha):
         pack_rgba8(color, alpha, out=rgba[slot])
@@ -179,7 +184,7 @@ def render_shard(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids: Seq
                     finish_oldest()
                 st = side[slot % streams]
                 with torch.cuda.stream(st):
-                    in_flight.append((slot, st, rasterize_begin(cloud, cameras[frame_ids[slot]], bg)))
+                    in_flight.append((slot, st, begin_fn(cloud, cameras[frame_ids[slot]], bg)))
             while in_flight:
                 finish_oldest()
         for st in side:
@@ -270,7 +275,7 @@ def broadcast_cloud(cloud: Optional[GaussianCloud], src: int = 0, device=None, g
 
 def render_and_gather(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids: Sequence[int], bg: torch.Tensor,
                       dst: int = 0, render_fn: RenderFn = rasterize, streams: int = 3, chunks: int = 4,
-                      group=None, driver: str = "auto") -> Optional[torch.Tensor]:
+                      group=None, driver: str = "auto", begin_fn: Optional[BeginFn] = None) -> Optional[torch.Tensor]:
     """Render ``frame_ids`` (this rank's frames; every rank must pass the same number) and gather the RGBA8 frames
     to ``dst`` while rendering continues: the shard is cut into ``chunks`` pieces, and as soon as a piece is rendered
     its ``gather`` is launched asynchronously (RCCL runs it on its own stream over xGMI) behind the next piece's
@@ -284,7 +289,7 @@ def render_and_gather(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids
     bounds = [n * k // chunks for k in range(chunks + 1)]
     parts, received, works = [], [], []
     for a, b in zip(bounds[:-1], bounds[1:]):
-        part = render_shard(cloud, cameras, list(frame_ids[a:b]), bg, False, render_fn, streams, driver)["rgba8"]
+        part = render_shard(cloud, cameras, list(frame_ids[a:b]), bg, False, render_fn, streams, driver, begin_fn)["rgba8"]
         parts.append(part)                       # kept alive until the transfers have been waited for
         if distributed:
             bufs = [torch.empty_like(part) for _ in range(world)] if rank == dst else None
@@ -301,13 +306,13 @@ def render_and_gather(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids
 
 def render_trajectory(cloud: GaussianCloud, cameras: Sequence[Camera], bg: torch.Tensor, keep_depth: bool = False,
                       dst: int = 0, render_fn: RenderFn = rasterize, streams: int = 3,
-                      driver: str = "auto") -> Optional[Dict[str, torch.Tensor]]:
+                      driver: str = "auto", begin_fn: Optional[BeginFn] = None) -> Optional[Dict[str, torch.Tensor]]:
     """Shard -> render -> gather.  Works with or without an initialised process group."""
     if dist.is_available() and dist.is_initialized():
         rank, world = dist.get_rank(), dist.get_world_size()
     else:
         rank, world = 0, 1
     ids = shard_frames(len(cameras), rank, world)
-    local = render_shard(cloud, cameras, ids, bg, keep_depth, render_fn, streams, driver)
+    local = render_shard(cloud, cameras, ids, bg, keep_depth, render_fn, streams, driver, begin_fn)
     gathered = {k: gather_frames(v, len(cameras), dst) for k, v in local.items()}
     return gathered if rank == dst else None

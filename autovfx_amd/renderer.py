@@ -83,9 +83,40 @@ def get_ray_directions(H: int, W: int, fx: float, fy: float, cx: float, cy: floa
     return torch.stack(((u - cx + 0.5) / fx, (v - cy + 0.5) / fy, torch.ones_like(u)), -1)
 
 
+class PendingRender:
+    """A ``render`` call whose rasterizer call is half queued (``render_begin``); ``finish()`` queues the rest and
+    returns the dict ``render`` returns."""
+
+    def __init__(self, tail):
+        self._tail = tail
+
+    def finish(self):
+        if self._tail is None:
+            raise RuntimeError("PendingRender.finish() called twice")
+        tail, self._tail = self._tail, None
+        return tail()
+
+
+def render_begin(viewpoint_camera, pc, pipe=PipelineParams, bg_color: Optional[torch.Tensor] = None,
+                 scaling_modifier: float = 1.0, override_color: Optional[torch.Tensor] = None) -> PendingRender:
+    """``render`` in two halves for inference loops that keep several frames in flight from one host thread
+    (``frame_parallel.render_shard(driver="pipelined")``): the per-Gaussian normals, the projection and the depth
+    sort are queued on the current stream and the call returns without waiting for the GPU; ``finish()`` (same
+    thread, same current stream) queues the rest.  Needs what the fused single-pass path needs: autograd off, data on
+    the GPU, a model with ``get_minimum_axis``.  Images are those of ``render``, bit for bit."""
+    out = _render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, split=True)
+    if not isinstance(out, PendingRender):
+        raise RuntimeError("render_begin needs torch.no_grad(), float32 data on the GPU and a model with get_minimum_axis")
+    return out
+
+
 def render(viewpoint_camera, pc, pipe=PipelineParams, bg_color: Optional[torch.Tensor] = None,
            scaling_modifier: float = 1.0, override_color: Optional[torch.Tensor] = None):
     """Render one view.  ``pc`` is anything with the ``GaussianModel`` getters; ``bg_color`` lives on the GPU."""
+    return _render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, split=False)
+
+
+def _render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, split):
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 
     xyz = pc.get_xyz
@@ -141,15 +172,26 @@ def render(viewpoint_camera, pc, pipe=PipelineParams, bg_color: Optional[torch.T
         normal_normed = _fused_view_normals(xyz, pc.get_minimum_axis, viewpoint_camera.camera_center)
         absent = torch.Tensor([])
         s_ = settings
-        (_n, rendered_image, depth_image, alpha_image, radii, _g, _b, _i, normal_image) = _C.rasterize_gaussians_extra(
+        call_args = (
             s_.bg, means3D, absent if colors_precomp is None else colors_precomp, opacity,
             absent if scales is None else scales, absent if rotations is None else rotations, s_.scale_modifier,
             absent if cov3D_precomp is None else cov3D_precomp, s_.viewmatrix, s_.projmatrix, s_.tanfovx, s_.tanfovy,
             s_.image_height, s_.image_width, absent if shs is None else shs, s_.sh_degree, s_.campos, s_.prefiltered,
             s_.debug, normal_normed)
-        rendered_image = torch.cat((rendered_image, alpha_image), dim=0)
-        depth_image = depth_image.squeeze(0)
-        normal_image, pseudo_normal = _fused_normal_maps(normal_image, depth_image, c2w, fx, fy, w / 2, h / 2)
+
+        def assemble(result):
+            (_n, rendered_image, depth_image, alpha_image, radii, _g, _b, _i, normal_image) = result
+            rendered_image = torch.cat((rendered_image, alpha_image), dim=0)
+            depth_image = depth_image.squeeze(0)
+            normal_image, pseudo_normal = _fused_normal_maps(normal_image, depth_image, c2w, fx, fy, w / 2, h / 2)
+            return {"render": rendered_image, "depth": depth_image, "normal": normal_image,
+                    "pseudo_normal": pseudo_normal, "viewspace_points": screenspace_points,
+                    "visibility_filter": radii > 0, "radii": radii}
+
+        if split:
+            pending = _C.rasterize_gaussians_begin(*call_args)
+            return PendingRender(lambda: assemble(pending.finish()))
+        return assemble(_C.rasterize_gaussians_extra(*call_args))
     else:
         rendered_image, depth_image, alpha_image, radii = rasterizer(
             means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity, scales=scales,

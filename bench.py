@@ -85,8 +85,7 @@ def main():
                     help="render frames on this many HIP streams so independent frames overlap")
     ap.add_argument("--driver", choices=["auto", "pipelined", "threads"], default="auto",
                     help="how the streams are fed: 'pipelined' = one host thread, each call split where the host needs "
-                         "the pair count; 'threads' = one blocking host thread per stream; auto = pipelined for "
-                         "--boundary op, threads for --boundary render")
+                         "the pair count; 'threads' = one blocking host thread per stream; auto = pipelined")
     ap.add_argument("--boundary", choices=["op", "render"], default="op",
                     help="op: one GaussianRasterizer.forward per frame (the headline); render: the reference's "
                          "whole per-frame render() = activations + SH pass + normal pass + normal post-processing")
@@ -155,10 +154,23 @@ def main():
             out = renderer.render(cam, model, renderer.PipelineParams, bg_)
             return out["render"][:3], out["depth"][None], out["render"][3:4], out["radii"]
 
+        class _PendingBoundary:
+            def __init__(self, pending):
+                self.pending = pending
+
+            def finish(self):
+                out = self.pending.finish()
+                return out["render"][:3], out["depth"][None], out["render"][3:4], out["radii"]
+
+        def begin_fn(_cloud, cam, bg_):
+            return _PendingBoundary(renderer.render_begin(cam, model, renderer.PipelineParams, bg_))
+
         def step(i, slot):
             out = renderer.render(cams[frame_of(i)], model, renderer.PipelineParams, bg)
             pack_rgba8(out["render"][:3], out["render"][3:4], out=rgba[slot % K])
     else:
+        begin_fn = rasterize_begin
+
         def step(i, slot):
             color, _depth, alpha, _radii = rasterize(cloud, cams[frame_of(i)], bg)
             pack_rgba8(color, alpha, out=rgba[slot % K])
@@ -167,9 +179,7 @@ def main():
     streams = [torch.cuda.Stream(device=device) for _ in range(S)] if S > 1 else []
     driver = args.driver
     if driver == "auto":
-        driver = "pipelined" if args.boundary == "op" else "threads"
-    if driver == "pipelined" and args.boundary != "op":
-        raise SystemExit("--driver pipelined splits the rasterizer call; use it with --boundary op")
+        driver = "pipelined"
 
     def run_steps(first, count):
         """Steps first .. first+count-1; with S > 1 streams, step j goes to host thread / stream j % S."""
@@ -193,7 +203,7 @@ def main():
                         finish_oldest()
                     st = streams[j % S]
                     with torch.cuda.stream(st):
-                        in_flight.append((j, st, rasterize_begin(cloud, cams[frame_of(first + j)], bg)))
+                        in_flight.append((j, st, begin_fn(cloud, cams[frame_of(first + j)], bg)))
                 while in_flight:
                     finish_oldest()
             for st in streams:
@@ -230,7 +240,7 @@ def main():
             # pieces that travel over xGMI behind the rendering of the next piece (only the last one is a tail)
             cam_list = [cams[frame_of(Wm + j)] for j in range(K)]
             gathered = render_and_gather(cloud, cam_list, list(range(K)), bg, dst=0, streams=S, chunks=args.gather_chunks,
-                                         driver=driver,
+                                         driver=driver, begin_fn=begin_fn,
                                          render_fn=(render_fn_boundary if args.boundary == "render" else rasterize))
         else:
             run_steps(Wm, K)

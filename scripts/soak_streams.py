@@ -1,5 +1,6 @@
-"""Soak test: render N frames of a workload serially and with 3 streams / host threads through the full render()
-boundary (both cached geometry paths, memoised activations, fused kernels) and require bit-identical frames."""
+"""Soak test: render N frames of a workload serially and with 3 streams -- one host thread with split calls, then one
+blocking host thread per stream -- through the full render() boundary (memoised activations, fused kernels, the
+folded normal pass) and require bit-identical frames."""
 import hashlib, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,16 +20,29 @@ def render_fn(_cloud, cam, bg_):
     o = renderer.render(cam, model, renderer.PipelineParams, bg_)
     return o["render"][:3], torch.cat((o["depth"][None], o["normal"].permute(2, 0, 1), o["pseudo_normal"].permute(2, 0, 1)), 0), o["render"][3:4], o["radii"]
 
+class Pending:
+    def __init__(self, p):
+        self.p = p
+    def finish(self):
+        o = self.p.finish()
+        return o["render"][:3], torch.cat((o["depth"][None], o["normal"].permute(2, 0, 1), o["pseudo_normal"].permute(2, 0, 1)), 0), o["render"][3:4], o["radii"]
+
+def begin_fn(_cloud, cam, bg_):
+    return Pending(renderer.render_begin(cam, model, renderer.PipelineParams, bg_))
+
 cloud = c.to(dev)
-def run(streams):
+def run(streams, driver="threads"):
     t0 = time.perf_counter()
-    out = render_shard(cloud, cams, list(range(n)), bg, keep_depth=True, render_fn=render_fn, streams=streams)
+    out = render_shard(cloud, cams, list(range(n)), bg, keep_depth=True, render_fn=render_fn, streams=streams,
+                       driver=driver, begin_fn=begin_fn)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     h = hashlib.sha256(out["rgba8"].cpu().numpy().tobytes() + out["depth"].cpu().numpy().tobytes()).hexdigest()
     return h, dt
 h1, t1 = run(1)
 for rep in range(3):
-    h3, t3 = run(3)
-    print(f"serial {n / t1:.0f} fps, 3 streams {n / t3:.0f} fps, identical: {h1 == h3}")
-    assert h1 == h3
+    h3, t3 = run(3, "pipelined")
+    h4, t4 = run(3, "threads")
+    print(f"serial {n / t1:.0f} fps, 3 streams pipelined {n / t3:.0f} fps, threads {n / t4:.0f} fps, "
+          f"identical: {h1 == h3 == h4}")
+    assert h1 == h3 == h4

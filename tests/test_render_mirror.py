@@ -210,3 +210,37 @@ def test_two_pass_render_is_thread_and_stream_safe():
     [th.join() for th in threads]
     for a, b in zip(serial, got):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_render_begin_finish_is_render():
+    """render_begin()/finish() give render()'s images bit for bit, with three frames in flight on three streams from
+    one host thread; outside its preconditions render_begin refuses instead of silently taking another path."""
+    from autovfx_amd.cameras import orbit_cameras
+    dev = torch.device("cuda", 0)
+    m, _ = model(40_000, seed=11)
+    m.to(dev)
+    cams = [c.to(dev) for c in orbit_cameras(6, 256, 144)]
+    bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
+    keys = ("render", "depth", "normal", "pseudo_normal", "radii", "visibility_filter")
+    with torch.no_grad():
+        whole = [renderer.render(c, m, renderer.PipelineParams, bg) for c in cams]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+        got = [None] * 6
+        for first in (0, 3):
+            pend = []
+            for k in range(3):
+                with torch.cuda.stream(streams[k]):
+                    pend.append(renderer.render_begin(cams[first + k], m, renderer.PipelineParams, bg))
+            for k in range(3):
+                with torch.cuda.stream(streams[k]):
+                    got[first + k] = pend[k].finish()
+            with pytest.raises(RuntimeError, match="twice"):
+                pend[0].finish()
+        torch.cuda.synchronize()
+    for a, b in zip(whole, got):
+        for k in keys:
+            assert torch.equal(a[k], b[k]), k
+    with torch.enable_grad(), pytest.raises(RuntimeError, match="no_grad"):
+        renderer.render_begin(cams[0], m, renderer.PipelineParams, bg)
