@@ -20,7 +20,7 @@ echo "== bench c3" | tee -a "$OUT/status.txt"
 timeout 900 python bench.py > "$OUT/bench_c3.json" 2> "$OUT/bench_c3.err"
 echo "bench exit $?" | tee -a "$OUT/status.txt"
 echo "== bench c2" | tee -a "$OUT/status.txt"
-timeout 600 python bench.py --workload c2 --no-cpu-baseline --streams 2 > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
+timeout 600 python bench.py --workload c2 --no-cpu-baseline --streams 3 > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"
 echo "bench c2 exit $?" | tee -a "$OUT/status.txt"
 echo "== rocprofv3 kernel trace" | tee -a "$OUT/status.txt"
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/prof" -o c3 -- \
