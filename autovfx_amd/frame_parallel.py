@@ -111,6 +111,21 @@ def rasterize_begin(cloud: GaussianCloud, cam: Camera, bg: torch.Tensor) -> Pend
     return PendingFrame(pending, (s, absent))
 
 
+_SIDE_STREAMS: Dict[tuple, List["torch.cuda.Stream"]] = {}
+
+
+def side_streams(device, count: int) -> List["torch.cuda.Stream"]:
+    """The HIP streams frames are rendered on, created once per device and reused by every call: torch's caching
+    allocator keeps one pool per stream, so fresh streams would pay for fresh device allocations of every frame's
+    scratch (hundreds of MB at C3) each time a shard is rendered."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    have = _SIDE_STREAMS.setdefault(key, [])
+    while len(have) < count:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:count]
+
+
 RenderFn = Callable[[GaussianCloud, Camera, torch.Tensor], Sequence[torch.Tensor]]
 # the split form of a RenderFn: returns an object whose ``finish()`` returns what the RenderFn returns
 BeginFn = Callable[[GaussianCloud, Camera, torch.Tensor], object]
@@ -118,8 +133,14 @@ BeginFn = Callable[[GaussianCloud, Camera, torch.Tensor], object]
 
 def render_shard(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids: Sequence[int], bg: torch.Tensor,
                  keep_depth: bool = False, render_fn: RenderFn = rasterize, streams: int = 3,
-                 driver: str = "auto", begin_fn: Optional[BeginFn] = None) -> Dict[str, torch.Tensor]:
+                 driver: str = "auto", begin_fn: Optional[BeginFn] = None,
+                 chunk_ends: Sequence[int] = (), on_chunk: Optional[Callable[[int, torch.Tensor], None]] = None
+                 ) -> Dict[str, torch.Tensor]:
     """Render this rank's frames; returns stacked ``rgba8 [n,4,H,W]`` (and ``depth [n,H,W]``).
+
+    ``on_chunk(end, rgba8[:end])`` is called -- in the caller's stream context, ordered after the frames it covers --
+    as soon as frame ``end - 1`` is queued, for every ``end`` in ``chunk_ends``, while later frames keep rendering
+    (``render_and_gather`` starts a piece's transfer from it).  Not available with ``driver="threads"``.
 
     ``streams > 1`` (GPU only) renders frame ``slot`` on HIP stream ``slot % streams``.  Frames are independent, and
     a frame's blend (VALU-bound) overlaps well with other frames' projection and sorts (HBM / latency-bound): three
@@ -155,19 +176,25 @@ def render_shard(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids: Seq
         if keep_depth:
             depth[slot].copy_(d[0])
 
-    def render_slots(slots):
+    chunk_ends = set(int(e) for e in chunk_ends) if on_chunk is not None else set()
+
+    def render_slots(slots, report=False):
         with torch.no_grad():
             for slot in slots:
                 color, d, alpha, _radii = render_fn(cloud, cameras[frame_ids[slot]], bg)
                 keep(slot, color, d, alpha)
+                if report and slot + 1 in chunk_ends:
+                    on_chunk(slot + 1, rgba[:slot + 1])
 
     streams = max(1, int(streams)) if device.type == "cuda" else 1
+    if chunk_ends and driver == "threads" and streams > 1 and n >= 2:
+        raise ValueError("on_chunk needs the pipelined (or serial) driver")
     if streams == 1 or n < 2:
-        render_slots(range(n))
+        render_slots(range(n), report=True)
     elif driver == "pipelined":
         from collections import deque
         caller = torch.cuda.current_stream(device)
-        side = [torch.cuda.Stream(device=device) for _ in range(streams)]
+        side = side_streams(device, streams)
         for st in side:
             st.wait_stream(caller)                 # inputs produced on the caller's stream are visible
         in_flight = deque()
@@ -177,6 +204,10 @@ def render_shard(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids: Seq
             with torch.cuda.stream(st):
                 color, d, alpha, _radii = pending.finish()
                 keep(slot, color, d, alpha)
+            if slot + 1 in chunk_ends:             # frames finish in order: everything up to `slot` is queued
+                for other in side:
+                    caller.wait_stream(other)
+                on_chunk(slot + 1, rgba[:slot + 1])
 
         with torch.no_grad():
             for slot in range(n):
@@ -192,7 +223,7 @@ def render_shard(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids: Seq
     else:
         import threading
         caller = torch.cuda.current_stream(device)
-        side = [torch.cuda.Stream(device=device) for _ in range(streams)]
+        side = side_streams(device, streams)
 
         def worker(t):
             torch.cuda.set_device(device)
@@ -279,29 +310,44 @@ def render_and_gather(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids
     """Render ``frame_ids`` (this rank's frames; every rank must pass the same number) and gather the RGBA8 frames
     to ``dst`` while rendering continues: the shard is cut into ``chunks`` pieces, and as soon as a piece is rendered
     its ``gather`` is launched asynchronously (RCCL runs it on its own stream over xGMI) behind the next piece's
-    rendering, so only the last piece's transfer is left as a tail.  Returns ``[world, n, 4, H, W]`` on ``dst``
-    (rank-major), ``None`` elsewhere; without a process group ``[1, n, 4, H, W]``."""
+    rendering, so only the last piece's transfer is left as a tail.  With the pipelined (or serial) driver the
+    frame pipeline is not drained at the piece boundaries; with ``driver="threads"`` each piece is its own
+    ``render_shard`` call.  Returns ``[world, n, 4, H, W]`` on ``dst`` (rank-major), ``None`` elsewhere; without a
+    process group ``[1, n, 4, H, W]``."""
     distributed = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
     n = len(frame_ids)
     chunks = max(1, min(int(chunks), n))
     bounds = [n * k // chunks for k in range(chunks + 1)]
-    parts, received, works = [], [], []
-    for a, b in zip(bounds[:-1], bounds[1:]):
-        part = render_shard(cloud, cameras, list(frame_ids[a:b]), bg, False, render_fn, streams, driver, begin_fn)["rgba8"]
+    parts, works, out = [], [], [None]
+    starts = {b: a for a, b in zip(bounds[:-1], bounds[1:])}
+
+    def transfer(part, end):
         parts.append(part)                       # kept alive until the transfers have been waited for
-        if distributed:
-            bufs = [torch.empty_like(part) for _ in range(world)] if rank == dst else None
-            received.append(bufs)
-            works.append(dist.gather(part, bufs, dst=dst, group=group, async_op=True))
+        if not distributed:
+            return
+        bufs = None
+        if rank == dst:                          # pieces land directly in their place of the result: no re-assembly
+            if out[0] is None:
+                out[0] = torch.empty((world, n) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
+            bufs = [out[0][r, starts[end]:end] for r in range(world)]
+        works.append(dist.gather(part, bufs, dst=dst, group=group, async_op=True))
+
+    split_available = begin_fn is not None or render_fn is rasterize
+    on_gpu = cloud.means3D.device.type == "cuda"
+    threaded = on_gpu and int(streams) > 1 and (driver == "threads" or (driver == "auto" and not split_available))
+    if threaded:
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            transfer(render_shard(cloud, cameras, list(frame_ids[a:b]), bg, False, render_fn, streams, "threads")["rgba8"], b)
+    else:
+        render_shard(cloud, cameras, list(frame_ids), bg, False, render_fn, streams, driver, begin_fn,
+                     chunk_ends=bounds[1:], on_chunk=lambda end, done: transfer(done[starts[end]:end], end))
     for w in works:
         w.wait()
     if not distributed:
         return torch.cat(parts, dim=0)[None]
-    if rank != dst:
-        return None
-    return torch.stack([torch.cat([bufs[r] for bufs in received], dim=0) for r in range(world)], dim=0)
+    return out[0] if rank == dst else None
 
 
 def render_trajectory(cloud: GaussianCloud, cameras: Sequence[Camera], bg: torch.Tensor, keep_depth: bool = False,

@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--no-reference-hip", action="store_true",
                     help="skip timing the reference's own kernels compiled for gfx950 (oracle/_ref/libgsr_ref_hip.so)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of the frames to rank 0 (N > 1)")
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="debug: take the N > 1 code path (process group, barriers, pipelined RCCL gather) even with "
+                         "one rank, so that path can be exercised on a one-GPU box")
     ap.add_argument("--gather-chunks", type=int, default=4,
                     help="N > 1: pieces the per-rank frame stack is gathered in, each overlapped with the next piece's rendering")
     ap.add_argument("--streams", type=int, default=3,
@@ -96,6 +99,12 @@ def main():
     ap.add_argument("--sort-impl", type=int, default=None, help="A/B knob: GSR_OPT_SORT_IMPL (0 = rocPRIM passes)")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner to the C-level stdout when a process
+    # group is created (seen with RCCL 2.26), so the real stdout is set aside for that line and everything else
+    # that writes to file descriptor 1 lands on stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,13 +118,15 @@ def main():
     device = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
-    if world > 1:
+    distributed = world > 1 or args.force_distributed
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
 
     from autovfx_amd import _lib, scenes
     from autovfx_amd.cameras import orbit_cameras
-    from autovfx_amd.frame_parallel import pack_rgba8, rasterize, rasterize_begin, render_and_gather
+    from autovfx_amd.frame_parallel import pack_rgba8, rasterize, rasterize_begin, render_and_gather, side_streams
     from diff_gaussian_rasterization import _C
 
     if args.blend_variant is not None:
@@ -176,7 +187,7 @@ def main():
             pack_rgba8(color, alpha, out=rgba[slot % K])
 
     S = max(1, args.streams)
-    streams = [torch.cuda.Stream(device=device) for _ in range(S)] if S > 1 else []
+    streams = side_streams(device, S) if S > 1 else []   # the driver's own: allocator pools warmed here stay warm there
     driver = args.driver
     if driver == "auto":
         driver = "pipelined"
@@ -229,23 +240,29 @@ def main():
         run_steps(0, Wm)
         if S > 1 and Wm < 2 * S + 2:   # every stream's allocator pool and scratch sizes settle before the clock starts
             run_steps(Wm, min(K, 2 * S + 2 - Wm))   # untimed; these frames are rendered again inside the timed region
+        if distributed and not args.no_gather:
+            # the gather path's own warm-up: the frame stack, the receive buffers and RCCL's first gather are
+            # allocated / initialised by an untimed rehearsal of the same call (its frames are rendered again below)
+            cam_list = [cams[frame_of(Wm + j)] for j in range(K)]
+            render_and_gather(cloud, cam_list, list(range(K)), bg, dst=0, streams=S, chunks=args.gather_chunks,
+                              driver=driver, begin_fn=begin_fn,
+                              render_fn=(render_fn_boundary if args.boundary == "render" else rasterize))
         _lib.set_stage_timing(S == 1)   # per-stage events are per host thread; only read them single-stream
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
         t0 = time.perf_counter()
         gathered = None
-        if world > 1 and not args.no_gather:
+        if distributed and not args.no_gather:
             # N > 1: the same per-frame work through the frame-parallel driver, whose gather to rank 0 is cut into
             # pieces that travel over xGMI behind the rendering of the next piece (only the last one is a tail)
-            cam_list = [cams[frame_of(Wm + j)] for j in range(K)]
             gathered = render_and_gather(cloud, cam_list, list(range(K)), bg, dst=0, streams=S, chunks=args.gather_chunks,
                                          driver=driver, begin_fn=begin_fn,
                                          render_fn=(render_fn_boundary if args.boundary == "render" else rasterize))
         else:
             run_steps(Wm, K)
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         if S > 1:   # stage breakdown from an untimed single-stream replay of the first frames
@@ -257,7 +274,7 @@ def main():
         call_ms = sorted(_lib.call_times_ms())
         _lib.set_stage_timing(False)
 
-    if world > 1:
+    if distributed:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -327,7 +344,7 @@ def main():
                        "boundary": ("render(): activations, SH pass, normal pass (geometry reused), normal/pseudo-normal "
                                     "post-processing, RGBA8 pack per frame" if args.boundary == "render" else
                                     "GaussianRasterizer.forward (SH) + RGBA8 pack per frame")
-                                   + ("; RCCL gather of the RGBA8 frames to rank 0, pipelined behind the rendering" if world > 1 and not args.no_gather else ""),
+                                   + ("; RCCL gather of the RGBA8 frames to rank 0, pipelined behind the rendering" if distributed and not args.no_gather else ""),
                        "parallelism": f"frame-parallel x{world}", "streams_per_gpu": S, "stream_driver": driver if S > 1 else "serial",
                        "options": {"tile_cull": _lib.get_option(_lib.OPT_TILE_CULL),
                                    "blend_variant": _lib.get_option(_lib.OPT_BLEND_VARIANT)}},
@@ -338,8 +355,8 @@ def main():
         if gathered is not None:
             line["config"]["gathered_frames"] = int(gathered.shape[0] * gathered.shape[1])
             line["config"]["gather_chunks"] = args.gather_chunks
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if distributed:
         dist.destroy_process_group()
 
 
