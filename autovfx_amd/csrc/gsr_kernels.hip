@@ -774,6 +774,15 @@ __device__ __forceinline__ int xcd_band_tile(int b, int T) {
     return xcd * q + min(xcd, r) + local;
 }
 
+// C += feature * alpha * T (forward.cu:357-360) with the last product fused into the addition, fma(feature * alpha,
+// T, C): what nvcc, which contracts by default, makes of that line on the reference's own hardware, and one
+// full-rate fused instruction in place of a multiply and an add.  This library is otherwise built without
+// contraction; this is the one place it is written out, because it is on the per-pair-per-pixel path and touches
+// only the float images (transmittance, the stopping rule and every integer output do not depend on it).
+__device__ __forceinline__ float composite(float C, float feature, float alpha, float T) {
+    return __builtin_fmaf(feature * alpha, T, C);
+}
+
 __global__ void __launch_bounds__(64, 8) blend_kernel(int W, int H, int grid_x, int num_tiles,
                                                    const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ point_list,
@@ -872,10 +881,10 @@ __global__ void __launch_bounds__(64, 8) blend_kernel(int W, int H, int grid_x, 
                 if (alpha < 1.0f / 255.0f) continue;
                 const float test_T = T[q] * (1.f - alpha);
                 if (test_T < 0.0001f) { done[q] = true; continue; }
-                Cr[q] += c.r * alpha * T[q];
-                Cg[q] += c.g * alpha * T[q];
-                Cb[q] += c.b * alpha * T[q];
-                Dz[q] += z * alpha * T[q];
+                Cr[q] = composite(Cr[q], c.r, alpha, T[q]);
+                Cg[q] = composite(Cg[q], c.g, alpha, T[q]);
+                Cb[q] = composite(Cb[q], c.b, alpha, T[q]);
+                Dz[q] = composite(Dz[q], z, alpha, T[q]);
                 T[q] = test_T;
                 last[q] = position;
             }
@@ -1035,15 +1044,15 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
             const unsigned long long adds = blends & ~stops;
             if (adds != 0ull && __builtin_amdgcn_inverse_ballot_w64(adds)) {
                 const float4 c = rec[2];  // r g b z
-                Cr += c.x * alpha * T;
-                Cg += c.y * alpha * T;
-                Cb += c.z * alpha * T;
-                Dz += c.w * alpha * T;
+                Cr = composite(Cr, c.x, alpha, T);
+                Cg = composite(Cg, c.y, alpha, T);
+                Cb = composite(Cb, c.z, alpha, T);
+                Dz = composite(Dz, c.w, alpha, T);
                 if (kExtra) {
                     const float4 e = s_extra[j];
-                    Er += e.x * alpha * T;
-                    Eg += e.y * alpha * T;
-                    Eb += e.z * alpha * T;
+                    Er = composite(Er, e.x, alpha, T);
+                    Eg = composite(Eg, e.y, alpha, T);
+                    Eb = composite(Eb, e.z, alpha, T);
                 }
                 T = test_T;
                 last = first + (uint32_t)j + 1u;
