@@ -18,7 +18,10 @@ SOURCES = ["gsr_kernels.hip", "gsr_sort.hip", "gsr_radix.hip", "gsr_api.hip"]
 HEADERS = [os.path.join(CSRC, "gsr_internal.h"), os.path.join(HERE, "..", "include", "gsr.h")]
 # -ffp-contract=off: the parity contract is fp32 in the reference's operation order;
 # no -ffast-math: IEEE divide / sqrt, accurate expf.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
+# -fno-slp-vectorize: on gfx950 packed fp32 multiply / add issue at half rate (only the packed fma is full rate), so
+# pairing scalar fp32 operations buys nothing and costs register shuffles; the one profitable pairing (the blend's
+# compositing fma) is written with vector types in the source.  Same IEEE results either way.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall",
          "-Wno-unused-result", "-fvisibility=hidden", "-DNDEBUG"]
 
 

@@ -782,6 +782,14 @@ __device__ __forceinline__ int xcd_band_tile(int b, int T) {
 __device__ __forceinline__ float composite(float C, float feature, float alpha, float T) {
     return __builtin_fmaf(feature * alpha, T, C);
 }
+// Two channels at once: v_pk_mul_f32 + v_pk_fma_f32.  Of gfx950's packed fp32 instructions only the fma issues at
+// the full rate (packed mul / add take two slots: scripts/ubench/valu_rate.hip), so this file is compiled without
+// the SLP vectorizer, which pairs up plain multiplies and adds at the price of register shuffles, and the one place
+// where pairing pays is written out.  Same roundings as two calls of composite().
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f composite2(v2f C, v2f feature, float alpha, float T) {
+    return __builtin_elementwise_fma(feature * alpha, (v2f){T, T}, C);
+}
 
 __global__ void __launch_bounds__(64, 8) blend_kernel(int W, int H, int grid_x, int num_tiles,
                                                    const uint2* __restrict__ ranges,
@@ -977,8 +985,8 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
     unsigned long long done_mask = __ballot(!inside);
     if (done_mask == ~0ull) return;  // quadrant entirely outside the image: nothing to write
 
-    float T = 1.f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dz = 0.f;
-    float Er = 0.f, Eg = 0.f, Eb = 0.f;
+    float T = 1.f, Eb = 0.f;
+    v2f Crg = {0.f, 0.f}, Cbz = {0.f, 0.f}, Erg = {0.f, 0.f};  // red|green, blue|depth, second set red|green
     uint32_t last = 0u;
 
     const uint2 range = ranges[tile];
@@ -1044,14 +1052,11 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
             const unsigned long long adds = blends & ~stops;
             if (adds != 0ull && __builtin_amdgcn_inverse_ballot_w64(adds)) {
                 const float4 c = rec[2];  // r g b z
-                Cr = composite(Cr, c.x, alpha, T);
-                Cg = composite(Cg, c.y, alpha, T);
-                Cb = composite(Cb, c.z, alpha, T);
-                Dz = composite(Dz, c.w, alpha, T);
+                Crg = composite2(Crg, (v2f){c.x, c.y}, alpha, T);
+                Cbz = composite2(Cbz, (v2f){c.z, c.w}, alpha, T);
                 if (kExtra) {
                     const float4 e = s_extra[j];
-                    Er = composite(Er, e.x, alpha, T);
-                    Eg = composite(Eg, e.y, alpha, T);
+                    Erg = composite2(Erg, (v2f){e.x, e.y}, alpha, T);
                     Eb = composite(Eb, e.z, alpha, T);
                 }
                 T = test_T;
@@ -1071,13 +1076,13 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
         const size_t pid = (size_t)W * (size_t)py + (size_t)px;
         out_alpha[pid] = 1.f - T;
         if (n_contrib != nullptr) n_contrib[pid] = last;
-        out_color[pid] = Cr + T * background[0];
-        out_color[plane + pid] = Cg + T * background[1];
-        out_color[2 * plane + pid] = Cb + T * background[2];
-        out_depth[pid] = Dz;
+        out_color[pid] = Crg.x + T * background[0];
+        out_color[plane + pid] = Crg.y + T * background[1];
+        out_color[2 * plane + pid] = Cbz.x + T * background[2];
+        out_depth[pid] = Cbz.y;
         if (kExtra) {
-            out_extra[pid] = Er + T * background[0];
-            out_extra[plane + pid] = Eg + T * background[1];
+            out_extra[pid] = Erg.x + T * background[0];
+            out_extra[plane + pid] = Erg.y + T * background[1];
             out_extra[2 * plane + pid] = Eb + T * background[2];
         }
     }
@@ -1239,6 +1244,9 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
             float g_cr = 0.f, g_cg = 0.f, g_cb = 0.f, g_dep = 0.f, g_mx = 0.f, g_my = 0.f, g_kx = 0.f, g_ky = 0.f,
                   g_kw = 0.f, g_op = 0.f;
             if (__builtin_amdgcn_inverse_ballot_w64(contrib)) {
+                // Products feeding sums are fused in this block (as nvcc does for the reference): it only forms
+                // gradients, which are stated with a tolerance; alpha, T and the contributor tests above are not in it.
+#pragma clang fp contract(fast)
                 // One reciprocal serves the two divisions by (1 - alpha) (backward.cu:506,548).  Gradients are sums
                 // over atomics whose order is not the reference's anyway; the tolerance of the parity tests covers
                 // the 1-ulp difference between x * rcp(y) and x / y.
