@@ -1030,7 +1030,11 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
         while (todo != 0ull) {
             const int j = __builtin_ctzll(todo);
             todo &= todo - 1ull;
-            const float4* rec = reinterpret_cast<const float4*>(&s_entry[j]);
+            // The entry's LDS offset is wave-uniform; parked in ONE vector register (opaque to the compiler, which
+            // would otherwise re-create it from the scalar before each of the three reads of the record).
+            uint32_t entry_offset;
+            asm("v_mov_b32 %0, %1" : "=v"(entry_offset) : "s"(j * (int)sizeof(BlendEntry)));
+            const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_entry) + entry_offset);
             const float4 ra = rec[0], rb = rec[1];
             struct { float x, y, cxx, cxy; } a = {ra.x, ra.y, ra.z, ra.w};
             struct { float cyy, skip_below, opacity; } b = {rb.x, rb.y, rb.z};
@@ -1224,7 +1228,9 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
             const int j = 63 - __builtin_clzll(todo);  // highest position first
             todo &= ~(1ull << j);
             const uint32_t pos = first + (uint32_t)j;
-            const float4* rec = reinterpret_cast<const float4*>(&s_entry[j]);
+            uint32_t entry_offset;  // as in the forward blend: one vector register for the record's three reads
+            asm("v_mov_b32 %0, %1" : "=v"(entry_offset) : "s"(j * (int)sizeof(BlendEntry)));
+            const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_entry) + entry_offset);
             const float4 ra = rec[0], rb = rec[1];
             struct { float x, y, cxx, cxy; } a = {ra.x, ra.y, ra.z, ra.w};
             struct { float cyy, skip_below, opacity; } b = {rb.x, rb.y, rb.z};
@@ -1287,9 +1293,13 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
                 g_op = G * dL_dalpha;
             }
             // r|g, b|depth, mx|my, kxx|kxy, kyy|opacity -> rows [r b g depth], [mx kxx my kxy], [kyy - opacity -]
-            const float x0 = row_sum_all_lanes(fold16(fold32(g_cr, g_cg), fold32(g_cb, g_dep)));
-            const float x1 = row_sum_all_lanes(fold16(fold32(g_mx, g_my), fold32(g_kx, g_ky)));
-            const float x2 = row_sum_all_lanes(fold16(fold32(g_kw, g_op), 0.f));
+            float x0 = row_sum_all_lanes(fold16(fold32(g_cr, g_cg), fold32(g_cb, g_dep)));
+            float x1 = row_sum_all_lanes(fold16(fold32(g_mx, g_my), fold32(g_kx, g_ky)));
+            asm volatile("" : "+v"(x0), "+v"(x1));
+            float x2 = row_sum_all_lanes(fold16(fold32(g_kw, g_op), 0.f));
+            // keep the last row-rotate add out here, where it is one DPP instruction per value (sunk into the branch
+            // below it becomes a zero-fill, a DPP move and an add)
+            asm volatile("" : "+v"(x2));
             if (my_slot >= 0) {  // ten lanes, one 64-byte line: a single atomic instruction per (quadrant, entry)
                 const float v = red_k == 0 ? x0 : red_k == 1 ? x1 : x2;
                 atomicAdd(accum + (size_t)kAccumStride * __float_as_uint(rb.w) + my_slot, v);
