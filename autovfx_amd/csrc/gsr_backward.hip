@@ -1,0 +1,603 @@
+// gsr_backward.hip -- the backward pass of the rasterizer.
+//
+//   render_backward_kernel      <- BACKWARD::renderCUDA   DGR/cuda_rasterizer/backward.cu:415-599
+//   preprocess_backward_kernel  <- BACKWARD::preprocess   backward.cu:144-413 (+ SH :20-138, cov3D :278-342)
+//
+// Its own translation unit because it wants different code generation from the forward kernels: this file is built
+// with -fno-slp-vectorize.  The SLP vectorizer pairs scalar fp32 multiplies and adds into v_pk_mul_f32 / v_pk_add_f32
+// at the price of register shuffles; in these two kernels, which are long stretches of scalar fp32 algebra, that cost
+// 117 instead of 91 VGPRs and a third more vector instructions in preprocess_backward and made a training-style
+// iteration at C3 10 % slower (2.90 vs 2.62 ms on MI355X).  The forward kernels keep the vectorizer (same-box A/B:
+// 1.3 % faster with it).  IEEE results do not depend on the choice.
+#include "gsr_device.h"
+
+namespace gsr {
+namespace {
+
+// ================================================================================================
+// BACKWARD PASS
+//   render_backward_kernel     <- BACKWARD::renderCUDA       DGR/cuda_rasterizer/backward.cu:415-599
+//   preprocess_backward_kernel <- computeCov2DCUDA           backward.cu:144-276
+//                                 + preprocessCUDA (bwd)     backward.cu:346-413
+//                                 + computeColorFromSH (bwd) backward.cu:20-138
+//                                 + computeCov3D (bwd)       backward.cu:278-342
+// Per-pixel and per-Gaussian arithmetic follow the reference's operation order.  What differs is
+// how per-Gaussian sums are formed: the reference issues one atomicAdd per (pixel, Gaussian, value);
+// here the 64 pixels of a quadrant are summed inside the wave first and one lane adds the result,
+// so the number of global atomics drops 64x and their order (hence the last bits of the sums) is
+// this library's, not the reference's -- parity for gradients is stated with a tolerance.
+// ================================================================================================
+// v + (v moved by a DPP control word): cross-lane add without LDS traffic.
+template <int kCtrl>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), kCtrl, 0xF, 0xF, false);
+    return v + __int_as_float(moved);
+}
+
+// Reduce-scatter of ten per-lane values over the wave with gfx950's half-swapping permutes: v_permlane32_swap
+// exchanges the upper 32 lanes of one register with the lower 32 of another, so ONE swap + ONE add folds two
+// values by a factor of two at once (lanes 0-31 then hold partial sums of the first, 32-63 of the second);
+// v_permlane16_swap does the same between odd and even rows of 16.  After the two levels three registers hold
+// the ten values, one per row, and four row-rotating DPP adds finish each: 28 instructions instead of the 60 of
+// ten separate butterfly sums.
+typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float fold32(float a, float b) {  // -> [sum pairs of a | sum pairs of b]
+    const v2u_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float fold16(float a, float b) {  // rows -> [a r0+r1 | b r0+r1 | a r2+r3 | b r2+r3]
+    const v2u_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float row_sum_all_lanes(float v) {  // every lane of a 16-lane row gets the row's sum
+    v = dpp_add<0x128>(v);  // row_ror:8
+    v = dpp_add<0x124>(v);  // row_ror:4
+    v = dpp_add<0x122>(v);  // row_ror:2
+    v = dpp_add<0x121>(v);  // row_ror:1
+    return v;
+}
+constexpr int kAccumStride = 16;  // floats per Gaussian in the accumulation scratch: one 64-byte line
+// slots: 0 r, 1 g, 2 b, 3 depth, 4 mean x, 5 mean y, 6 conic xx, 7 conic xy, 8 conic yy, 9 opacity
+
+__global__ void __launch_bounds__(64, 4) render_backward_kernel(
+    int W, int H, int grid_x, int num_tiles, const uint2* __restrict__ ranges,
+    const uint32_t* __restrict__ point_list, const float* __restrict__ background,
+    const SplatRaster* __restrict__ raster, const float* __restrict__ colors, const float* __restrict__ accum_alphas,
+    const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
+    const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dpixel_alphas,
+    float* __restrict__ accum /*[P,16], zero on entry*/) {
+    __shared__ BlendEntry s_entry[64];  // the forward's 48-byte record; the Gaussian id rides in its pad word
+
+    constexpr int kQ = kTile / 2;
+    const int item = xcd_band_tile(blockIdx.x, 4 * num_tiles);
+    const int tile = item >> 2, quad = item & 3;
+    const int lane = threadIdx.x;
+    const int qx0 = (tile % grid_x) * kTile + kQ * (quad & 1);
+    const int qy0 = (tile / grid_x) * kTile + kQ * (quad >> 1);
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const float fx = (float)px, fy = (float)py;
+    const bool inside = px < W && py < H;
+    const size_t pid = (size_t)W * (size_t)py + (size_t)px;
+    const size_t plane = (size_t)W * (size_t)H;
+
+    const uint2 range = ranges[tile];
+    const uint32_t count = range.y - range.x;
+
+    // forward results for this pixel (backward.cu:459-479)
+    // which slot of a Gaussian's accumulation line this lane adds to after the reduce-scatter (see below)
+    const int red_k = lane & 15, red_row = lane >> 4;
+    const int my_slot = red_k == 0 ? ((red_row & 1) << 1 | (red_row >> 1))
+                      : red_k == 1 ? 4 + ((red_row & 1) << 1 | (red_row >> 1))
+                      : (red_k == 2 && (red_row & 1) == 0) ? 8 + (red_row >> 1) : -1;
+
+    const float T_final = inside ? (1.f - accum_alphas[pid]) : 0.f;
+    float T = T_final;
+    const uint32_t last_contributor = inside ? n_contrib[pid] : 0u;
+    float dLr = 0.f, dLg = 0.f, dLb = 0.f, dLd = 0.f, dLa = 0.f;
+    if (inside) {
+        dLr = dL_dpixels[pid];
+        dLg = dL_dpixels[plane + pid];
+        dLb = dL_dpixels[2 * plane + pid];
+        dLd = dL_dpixel_depths[pid];
+        dLa = dL_dpixel_alphas[pid];
+    }
+    // entries at list positions >= every pixel's last contributor are skipped by every pixel
+    uint32_t walk = last_contributor;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) walk = max(walk, (uint32_t)__shfl_xor((int)walk, d));
+    walk = min(walk, count);
+    if (walk == 0) return;
+
+    const unsigned long long inside_mask = __ballot(inside);
+    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_a = 0.f;  // accum_rec / accum_red / accum_rea
+    float last_alpha = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f, last_depth = 0.f;
+    const float bg_dot = (background[0] * dLr + background[1] * dLg) + background[2] * dLb;  // left to right
+    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
+
+    // back to front: batches of 64 positions, highest first
+    for (uint32_t top = walk; top > 0; top = top > 64 ? top - 64 : 0) {
+        const uint32_t first = top > 64 ? top - 64 : 0;  // batch covers positions [first, top)
+        const uint32_t e = first + (uint32_t)lane;
+        float2 g_xy = make_float2(0.f, 0.f);
+        float4 g_co = make_float4(0.f, 0.f, 0.f, 0.f);
+        F3 g_rgb = {0.f, 0.f, 0.f};
+        float g_z = 0.f, g_skip = 0.f;
+        uint32_t g_id = 0;
+        const bool mine = e < top;
+        if (mine) {
+            g_id = point_list[range.x + e];
+            const float4* rec = reinterpret_cast<const float4*>(raster + g_id);
+            const float4 r0 = rec[0], r1 = rec[1];
+            g_xy = make_float2(r0.x, r0.y);
+            g_co = make_float4(r0.z, r0.w, r1.x, r1.y);
+            g_z = r1.z;
+            g_skip = r1.w;
+            g_rgb = ld3(colors + 3 * (size_t)g_id);
+        }
+        unsigned long long todo = __ballot(mine && splat_reaches_rect(g_co, g_skip, g_xy, qx0, qy0, kQ, kQ));
+        if (todo == 0ull) continue;
+        __syncthreads();
+        {
+            float4* rec = reinterpret_cast<float4*>(&s_entry[lane]);
+            rec[0] = make_float4(g_xy.x, g_xy.y, g_co.x, g_co.y);
+            rec[1] = make_float4(g_co.z, g_skip, g_co.w, __uint_as_float(g_id));
+            rec[2] = make_float4(g_rgb.x, g_rgb.y, g_rgb.z, g_z);
+        }
+        __syncthreads();
+
+        while (todo != 0ull) {
+            const int j = 63 - __builtin_clzll(todo);  // highest position first
+            todo &= ~(1ull << j);
+            const uint32_t pos = first + (uint32_t)j;
+            uint32_t entry_offset;  // as in the forward blend: one vector register for the record's three reads
+            asm("v_mov_b32 %0, %1" : "=v"(entry_offset) : "s"(j * (int)sizeof(BlendEntry)));
+            const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_entry) + entry_offset);
+            const float4 ra = rec[0], rb = rec[1];
+            struct { float x, y, cxx, cxy; } a = {ra.x, ra.y, ra.z, ra.w};
+            struct { float cyy, skip_below, opacity; } b = {rb.x, rb.y, rb.z};
+            const float dx = a.x - fx, dy = a.y - fy;
+            const float power = -0.5f * (a.cxx * dx * dx + b.cyy * dy * dy) - a.cxy * dx * dy;
+            // pixel predicates as wave-uniform masks, as in the forward blend (one ballot per comparison)
+            const unsigned long long live = __ballot(pos < last_contributor) & __ballot(!(power > 0.0f)) &
+                                            __ballot(!(power < b.skip_below)) & inside_mask;
+            if (live == 0ull) continue;
+            const float G = exp_nonpositive(power);  // == expf on the contributing lanes' domain (power <= 0)
+            const float alpha = fminf(0.99f, b.opacity * G);
+            const unsigned long long contrib = live & __ballot(!(alpha < 1.0f / 255.0f));
+            if (contrib == 0ull) continue;
+            const float4 cz = rec[2];  // r g b depth
+            struct { float r, g, b, opacity; } c = {cz.x, cz.y, cz.z, b.opacity};
+            const float z = cz.w;
+            float g_cr = 0.f, g_cg = 0.f, g_cb = 0.f, g_dep = 0.f, g_mx = 0.f, g_my = 0.f, g_kx = 0.f, g_ky = 0.f,
+                  g_kw = 0.f, g_op = 0.f;
+            if (__builtin_amdgcn_inverse_ballot_w64(contrib)) {
+                // Products feeding sums are fused in this block (as nvcc does for the reference): it only forms
+                // gradients, which are stated with a tolerance; alpha, T and the contributor tests above are not in it.
+#pragma clang fp contract(fast)
+                // One reciprocal serves the two divisions by (1 - alpha) (backward.cu:506,548).  Gradients are sums
+                // over atomics whose order is not the reference's anyway; the tolerance of the parity tests covers
+                // the 1-ulp difference between x * rcp(y) and x / y.
+                const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                T = T * inv_1ma;
+                const float dchannel_dcolor = alpha * T;
+                float dL_dalpha = 0.0f;
+                acc_r = last_alpha * last_r + (1.f - last_alpha) * acc_r;
+                last_r = c.r;
+                dL_dalpha += (c.r - acc_r) * dLr;
+                g_cr = dchannel_dcolor * dLr;
+                acc_g = last_alpha * last_g + (1.f - last_alpha) * acc_g;
+                last_g = c.g;
+                dL_dalpha += (c.g - acc_g) * dLg;
+                g_cg = dchannel_dcolor * dLg;
+                acc_b = last_alpha * last_b + (1.f - last_alpha) * acc_b;
+                last_b = c.b;
+                dL_dalpha += (c.b - acc_b) * dLb;
+                g_cb = dchannel_dcolor * dLb;
+                acc_d = last_alpha * last_depth + (1.f - last_alpha) * acc_d;
+                last_depth = z;
+                dL_dalpha += (z - acc_d) * dLd;
+                g_dep = dchannel_dcolor * dLd;
+                acc_a = last_alpha + (1.f - last_alpha) * acc_a;
+                dL_dalpha += (1.f - acc_a) * dLa;
+                dL_dalpha *= T;
+                last_alpha = alpha;
+                dL_dalpha += (-T_final * inv_1ma) * bg_dot;
+                const float dL_dG = c.opacity * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                const float dG_ddelx = -gdx * a.cxx - gdy * a.cxy;
+                const float dG_ddely = -gdy * b.cyy - gdx * a.cxy;
+                g_mx = dL_dG * dG_ddelx * ddelx_dx;
+                g_my = dL_dG * dG_ddely * ddely_dy;
+                g_kx = -0.5f * gdx * dx * dL_dG;
+                g_ky = -0.5f * gdx * dy * dL_dG;
+                g_kw = -0.5f * gdy * dy * dL_dG;
+                g_op = G * dL_dalpha;
+            }
+            // r|g, b|depth, mx|my, kxx|kxy, kyy|opacity -> rows [r b g depth], [mx kxx my kxy], [kyy - opacity -]
+            float x0 = row_sum_all_lanes(fold16(fold32(g_cr, g_cg), fold32(g_cb, g_dep)));
+            float x1 = row_sum_all_lanes(fold16(fold32(g_mx, g_my), fold32(g_kx, g_ky)));
+            asm volatile("" : "+v"(x0), "+v"(x1));
+            float x2 = row_sum_all_lanes(fold16(fold32(g_kw, g_op), 0.f));
+            // keep the last row-rotate add out here, where it is one DPP instruction per value (sunk into the branch
+            // below it becomes a zero-fill, a DPP move and an add)
+            asm volatile("" : "+v"(x2));
+            if (my_slot >= 0) {  // ten lanes, one 64-byte line: a single atomic instruction per (quadrant, entry)
+                const float v = red_k == 0 ? x0 : red_k == 1 ? x1 : x2;
+                atomicAdd(accum + (size_t)kAccumStride * __float_as_uint(rb.w) + my_slot, v);
+            }
+        }
+    }
+}
+
+// auxiliary.h:103-114
+__device__ __forceinline__ F3 dnormvdv3(F3 v, F3 dv) {
+    const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    F3 o;
+    o.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
+    o.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
+    o.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
+    return o;
+}
+
+// backward.cu:20-138, split in two: d(colour)/d(sh_k) is a scalar per coefficient shared by the
+// three channels (written as one 12-byte store per coefficient), d(colour)/d(dir) is per channel.
+__device__ __forceinline__ void sh_coefficient_grads(int deg, float x, float y, float z, float k[16]) {
+    k[0] = kSH0;
+    if (deg > 0) {
+        k[1] = -kSH1 * y;
+        k[2] = kSH1 * z;
+        k[3] = -kSH1 * x;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            k[4] = kSH2_0 * xy;
+            k[5] = kSH2_1 * yz;
+            k[6] = kSH2_2 * (2.f * zz - xx - yy);
+            k[7] = kSH2_3 * xz;
+            k[8] = kSH2_4 * (xx - yy);
+            if (deg > 2) {
+                k[9] = kSH3_0 * y * (3.f * xx - yy);
+                k[10] = kSH3_1 * xy * z;
+                k[11] = kSH3_2 * y * (4.f * zz - xx - yy);
+                k[12] = kSH3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                k[13] = kSH3_4 * x * (4.f * zz - xx - yy);
+                k[14] = kSH3_5 * z * (xx - yy);
+                k[15] = kSH3_6 * x * (xx - 3.f * yy);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ F3 sh_dir_grads_channel(int deg, float x, float y, float z, const float* __restrict__ sh, int c) {
+#define SHC(k) sh[3 * (k) + c]
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (deg > 0) {
+        dx = -kSH1 * SHC(3);
+        dy = -kSH1 * SHC(1);
+        dz = kSH1 * SHC(2);
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            dx += kSH2_0 * y * SHC(4) + kSH2_2 * 2.f * -x * SHC(6) + kSH2_3 * z * SHC(7) + kSH2_4 * 2.f * x * SHC(8);
+            dy += kSH2_0 * x * SHC(4) + kSH2_1 * z * SHC(5) + kSH2_2 * 2.f * -y * SHC(6) + kSH2_4 * 2.f * -y * SHC(8);
+            dz += kSH2_1 * y * SHC(5) + kSH2_2 * 2.f * 2.f * z * SHC(6) + kSH2_3 * x * SHC(7);
+            if (deg > 2) {
+                dx += (kSH3_0 * SHC(9) * 3.f * 2.f * xy + kSH3_1 * SHC(10) * yz + kSH3_2 * SHC(11) * -2.f * xy +
+                       kSH3_3 * SHC(12) * -3.f * 2.f * xz + kSH3_4 * SHC(13) * (-3.f * xx + 4.f * zz - yy) +
+                       kSH3_5 * SHC(14) * 2.f * xz + kSH3_6 * SHC(15) * 3.f * (xx - yy));
+                dy += (kSH3_0 * SHC(9) * 3.f * (xx - yy) + kSH3_1 * SHC(10) * xz +
+                       kSH3_2 * SHC(11) * (-3.f * yy + 4.f * zz - xx) + kSH3_3 * SHC(12) * -3.f * 2.f * yz +
+                       kSH3_4 * SHC(13) * -2.f * xy + kSH3_5 * SHC(14) * -2.f * yz + kSH3_6 * SHC(15) * -3.f * 2.f * xy);
+                dz += (kSH3_1 * SHC(10) * xy + kSH3_2 * SHC(11) * 4.f * 2.f * yz +
+                       kSH3_3 * SHC(12) * 3.f * (2.f * zz - xx - yy) + kSH3_4 * SHC(13) * 4.f * 2.f * xz +
+                       kSH3_5 * SHC(14) * (xx - yy));
+            }
+        }
+    }
+#undef SHC
+    return F3{dx, dy, dz};
+}
+
+struct BackwardArgs {
+    int P, sh_degree, M;
+    const float* means3D;
+    const int* radii;
+    const float* shs;            // nullable
+    const float* scales;         // nullable
+    const float* rotations;      // nullable
+    const float* cov3D_precomp;  // nullable
+    float scale_modifier;
+    const float* accum;          // [P,16] sums of render_backward_kernel (slots: see kAccumStride)
+    float* dL_dmean2D;           // [P,3]  written here from accum
+    float* dL_dconic;            // [P,4]
+    float* dL_dopacity;          // [P]
+    float* dL_dcolor;            // [P,3]
+    float* dL_ddepth;            // [P]
+    float* dL_dmean3D;           // [P,3]
+    float* dL_dcov3D;            // [P,6]
+    float* dL_dsh;               // [P,M,3] nullable
+    float* dL_dscale;            // [P,3]
+    float* dL_drot;              // [P,4]
+};
+
+constexpr int kShStagePitch = 65;  // words between consecutive floats of one lane's record in the LDS stage
+
+// One lane = one Gaussian.  `stage` (nullable) is this lane's column of the wave's LDS stage for dL_dsh: float f of
+// the record goes to stage[f * kShStagePitch]; with stage == nullptr the record is stored straight to HBM.
+__device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, const Camera& cam, int idx, float* stage) {
+    if (!(g.radii[idx] > 0)) {
+        // Not rendered: every gradient of this Gaussian is zero.  The kernel defines ALL output elements, so the
+        // caller does not have to zero-fill a gigabyte of gradient tensors first (dL_dsh alone is 576 MB at 3 M).
+        const F3 z3 = {0.f, 0.f, 0.f};
+        *reinterpret_cast<F3*>(g.dL_dmean2D + 3 * (size_t)idx) = z3;
+        *reinterpret_cast<F4*>(g.dL_dconic + 4 * (size_t)idx) = F4{0.f, 0.f, 0.f, 0.f};
+        g.dL_dopacity[idx] = 0.f;
+        *reinterpret_cast<F3*>(g.dL_dcolor + 3 * (size_t)idx) = z3;
+        g.dL_ddepth[idx] = 0.f;
+        *reinterpret_cast<F3*>(g.dL_dmean3D + 3 * (size_t)idx) = z3;
+        *reinterpret_cast<F3*>(g.dL_dcov3D + 6 * (size_t)idx) = z3;
+        *reinterpret_cast<F3*>(g.dL_dcov3D + 6 * (size_t)idx + 3) = z3;
+        if (stage != nullptr) {
+            for (int f = 0; f < 3 * g.M; ++f) stage[f * kShStagePitch] = 0.f;
+        } else if (g.dL_dsh != nullptr) {
+            for (int k = 0; k < g.M; ++k) *reinterpret_cast<F3*>(g.dL_dsh + 3 * ((size_t)g.M * idx + k)) = z3;
+        }
+        *reinterpret_cast<F3*>(g.dL_dscale + 3 * (size_t)idx) = z3;
+        *reinterpret_cast<F4*>(g.dL_drot + 4 * (size_t)idx) = F4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    const float* __restrict__ view = cam.viewmatrix;
+    const float* __restrict__ proj = cam.projmatrix;
+    const F3 mean = ld3(g.means3D + 3 * (size_t)idx);
+
+    // the ten sums of this Gaussian, one 64-byte line; spread into the reference's gradient arrays
+    const float4* line = reinterpret_cast<const float4*>(g.accum + (size_t)kAccumStride * idx);
+    const float4 s0 = line[0], s1 = line[1];
+    const float2 s2 = *reinterpret_cast<const float2*>(line + 2);
+    const float dLc_r = s0.x, dLc_g = s0.y, dLc_b = s0.z, gdep = s0.w;
+    const float g2x = s1.x, g2y = s1.y;
+    const float dLcx = s1.z, dLcy = s1.w, dLcz = s2.x;
+    *reinterpret_cast<F3*>(g.dL_dcolor + 3 * (size_t)idx) = F3{dLc_r, dLc_g, dLc_b};
+    g.dL_ddepth[idx] = gdep;
+    *reinterpret_cast<F3*>(g.dL_dmean2D + 3 * (size_t)idx) = F3{g2x, g2y, 0.f};            // z is never used (backward.cu)
+    *reinterpret_cast<F4*>(g.dL_dconic + 4 * (size_t)idx) = F4{dLcx, dLcy, 0.f, dLcz};   // 2x2 with one unused slot
+    g.dL_dopacity[idx] = s2.y;
+
+    // 3D covariance as the forward computed it
+    float c3[6];
+    Mat3 R = {}, S = {};
+    float sx = 0.f, sy = 0.f, sz = 0.f, qr = 0.f, qx = 0.f, qy = 0.f, qz = 0.f;
+    if (g.cov3D_precomp != nullptr) {
+        const float* c = g.cov3D_precomp + 6 * (size_t)idx;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c3[k] = c[k];
+    } else {
+        const F3 s = ld3(g.scales + 3 * (size_t)idx);
+        const F4 q = *reinterpret_cast<const F4*>(g.rotations + 4 * (size_t)idx);
+        qr = q.x; qx = q.y; qy = q.z; qz = q.w;
+        sx = g.scale_modifier * s.x; sy = g.scale_modifier * s.y; sz = g.scale_modifier * s.z;
+        S.m[0][0] = sx; S.m[1][1] = sy; S.m[2][2] = sz;
+        const float r = qr, x = qx, y = qy, z = qz;
+        R.m[0][0] = 1.f - 2.f * (y * y + z * z); R.m[1][0] = 2.f * (x * y - r * z);       R.m[2][0] = 2.f * (x * z + r * y);
+        R.m[0][1] = 2.f * (x * y + r * z);       R.m[1][1] = 1.f - 2.f * (x * x + z * z); R.m[2][1] = 2.f * (y * z - r * x);
+        R.m[0][2] = 2.f * (x * z - r * y);       R.m[1][2] = 2.f * (y * z + r * x);       R.m[2][2] = 1.f - 2.f * (x * x + y * y);
+        const Mat3 Mm = mul3(S, R);
+        const Mat3 Sg = mul3(transpose3(Mm), Mm);
+        c3[0] = Sg.m[0][0]; c3[1] = Sg.m[1][0]; c3[2] = Sg.m[2][0];
+        c3[3] = Sg.m[1][1]; c3[4] = Sg.m[2][1]; c3[5] = Sg.m[2][2];
+    }
+
+    // ---- computeCov2DCUDA (backward.cu:144-276) ----
+    float tx = view[0] * mean.x + view[4] * mean.y + view[8] * mean.z + view[12];
+    float ty = view[1] * mean.x + view[5] * mean.y + view[9] * mean.z + view[13];
+    const float tz_ = view[2] * mean.x + view[6] * mean.y + view[10] * mean.z + view[14];
+    const float h_x = cam.focal_x, h_y = cam.focal_y;
+    const float limx = 1.3f * cam.tan_fovx, limy = 1.3f * cam.tan_fovy;
+    const float txtz = tx / tz_, tytz = ty / tz_;
+    tx = fminf(limx, fmaxf(-limx, txtz)) * tz_;
+    ty = fminf(limy, fmaxf(-limy, tytz)) * tz_;
+    const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+    const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+    Mat3 J = {{{h_x / tz_, 0.f, 0.f}, {0.f, h_y / tz_, 0.f}, {-(h_x * tx) / (tz_ * tz_), -(h_y * ty) / (tz_ * tz_), 0.f}}};
+    Mat3 Wm;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) Wm.m[a][b] = view[4 * a + b];
+    const Mat3 T = mul3(Wm, J);
+    Mat3 V = {{{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}}};
+    const Mat3 cov = mul3(mul3(transpose3(T), transpose3(V)), T);
+#define TG(c, r) T.m[r][c]
+#define VG(c, r) V.m[r][c]
+#define WG(c, r) Wm.m[r][c]
+    const float a = cov.m[0][0] + 0.3f, b = cov.m[1][0], c_ = cov.m[1][1] + 0.3f;
+    const float denom = a * c_ - b * b;
+    float dL_da = 0, dL_db = 0, dL_dc = 0;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    float dcov[6];
+    if (denom2inv != 0) {
+        dL_da = denom2inv * (-c_ * c_ * dLcx + 2 * b * c_ * dLcy + (denom - a * c_) * dLcz);
+        dL_dc = denom2inv * (-a * a * dLcz + 2 * a * b * dLcy + (denom - a * c_) * dLcx);
+        dL_db = denom2inv * 2 * (b * c_ * dLcx - (denom + 2 * b * b) * dLcy + a * b * dLcz);
+        dcov[0] = (TG(0, 0) * TG(0, 0) * dL_da + TG(0, 0) * TG(1, 0) * dL_db + TG(1, 0) * TG(1, 0) * dL_dc);
+        dcov[3] = (TG(0, 1) * TG(0, 1) * dL_da + TG(0, 1) * TG(1, 1) * dL_db + TG(1, 1) * TG(1, 1) * dL_dc);
+        dcov[5] = (TG(0, 2) * TG(0, 2) * dL_da + TG(0, 2) * TG(1, 2) * dL_db + TG(1, 2) * TG(1, 2) * dL_dc);
+        dcov[1] = 2 * TG(0, 0) * TG(0, 1) * dL_da + (TG(0, 0) * TG(1, 1) + TG(0, 1) * TG(1, 0)) * dL_db + 2 * TG(1, 0) * TG(1, 1) * dL_dc;
+        dcov[2] = 2 * TG(0, 0) * TG(0, 2) * dL_da + (TG(0, 0) * TG(1, 2) + TG(0, 2) * TG(1, 0)) * dL_db + 2 * TG(1, 0) * TG(1, 2) * dL_dc;
+        dcov[4] = 2 * TG(0, 2) * TG(0, 1) * dL_da + (TG(0, 1) * TG(1, 2) + TG(0, 2) * TG(1, 1)) * dL_db + 2 * TG(1, 1) * TG(1, 2) * dL_dc;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dcov[i] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) g.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+    const float dL_dT00 = 2 * (TG(0, 0) * VG(0, 0) + TG(0, 1) * VG(0, 1) + TG(0, 2) * VG(0, 2)) * dL_da + (TG(1, 0) * VG(0, 0) + TG(1, 1) * VG(0, 1) + TG(1, 2) * VG(0, 2)) * dL_db;
+    const float dL_dT01 = 2 * (TG(0, 0) * VG(1, 0) + TG(0, 1) * VG(1, 1) + TG(0, 2) * VG(1, 2)) * dL_da + (TG(1, 0) * VG(1, 0) + TG(1, 1) * VG(1, 1) + TG(1, 2) * VG(1, 2)) * dL_db;
+    const float dL_dT02 = 2 * (TG(0, 0) * VG(2, 0) + TG(0, 1) * VG(2, 1) + TG(0, 2) * VG(2, 2)) * dL_da + (TG(1, 0) * VG(2, 0) + TG(1, 1) * VG(2, 1) + TG(1, 2) * VG(2, 2)) * dL_db;
+    const float dL_dT10 = 2 * (TG(1, 0) * VG(0, 0) + TG(1, 1) * VG(0, 1) + TG(1, 2) * VG(0, 2)) * dL_dc + (TG(0, 0) * VG(0, 0) + TG(0, 1) * VG(0, 1) + TG(0, 2) * VG(0, 2)) * dL_db;
+    const float dL_dT11 = 2 * (TG(1, 0) * VG(1, 0) + TG(1, 1) * VG(1, 1) + TG(1, 2) * VG(1, 2)) * dL_dc + (TG(0, 0) * VG(1, 0) + TG(0, 1) * VG(1, 1) + TG(0, 2) * VG(1, 2)) * dL_db;
+    const float dL_dT12 = 2 * (TG(1, 0) * VG(2, 0) + TG(1, 1) * VG(2, 1) + TG(1, 2) * VG(2, 2)) * dL_dc + (TG(0, 0) * VG(2, 0) + TG(0, 1) * VG(2, 1) + TG(0, 2) * VG(2, 2)) * dL_db;
+    const float dL_dJ00 = WG(0, 0) * dL_dT00 + WG(0, 1) * dL_dT01 + WG(0, 2) * dL_dT02;
+    const float dL_dJ02 = WG(2, 0) * dL_dT00 + WG(2, 1) * dL_dT01 + WG(2, 2) * dL_dT02;
+    const float dL_dJ11 = WG(1, 0) * dL_dT10 + WG(1, 1) * dL_dT11 + WG(1, 2) * dL_dT12;
+    const float dL_dJ12 = WG(2, 0) * dL_dT10 + WG(2, 1) * dL_dT11 + WG(2, 2) * dL_dT12;
+#undef TG
+#undef VG
+#undef WG
+    const float tzi = 1.f / tz_, tz2 = tzi * tzi, tz3 = tz2 * tzi;
+    const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+    const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+    const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * tx) * tz3 * dL_dJ02 + (2 * h_y * ty) * tz3 * dL_dJ12;
+    float dmx = view[0] * dL_dtx + view[1] * dL_dty + view[2] * dL_dtz;   // transformVec4x3Transpose
+    float dmy = view[4] * dL_dtx + view[5] * dL_dty + view[6] * dL_dtz;
+    float dmz = view[8] * dL_dtx + view[9] * dL_dty + view[10] * dL_dtz;
+
+    // ---- preprocessCUDA backward (backward.cu:346-413) ----
+    const float mhw = proj[3] * mean.x + proj[7] * mean.y + proj[11] * mean.z + proj[15];
+    const float m_w = 1.0f / (mhw + 0.0000001f);
+    const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
+    const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
+    dmx += (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+    dmy += (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+    dmz += (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+    const float mul3_ = view[2] * mean.x + view[6] * mean.y + view[10] * mean.z + view[14];
+    dmx += (view[2] - view[3] * mul3_) * gdep;
+    dmy += (view[6] - view[7] * mul3_) * gdep;
+    dmz += (view[10] - view[11] * mul3_) * gdep;
+
+    if (g.shs != nullptr) {
+        int deg = g.sh_degree;
+        if (deg > 2 && g.M < 16) deg = 2;
+        if (deg > 1 && g.M < 9) deg = 1;
+        if (deg > 0 && g.M < 4) deg = 0;
+        const float* sh = g.shs + 3 * (size_t)g.M * idx;
+        float* dsh = g.dL_dsh + 3 * (size_t)g.M * idx;
+        const F3 cp = ld3(cam.cam_pos);
+        const F3 o = F3{mean.x - cp.x, mean.y - cp.y, mean.z - cp.z};
+        const float len = sqrtf(o.x * o.x + o.y * o.y + o.z * o.z);
+        const float x = o.x / len, y = o.y / len, z = o.z / len;
+        // the forward's clamp decision, recomputed with the forward's own arithmetic
+        F3 pre = sh_unclamped(deg, x, y, z, sh);
+        const float dL0 = dLc_r * (pre.x < 0 ? 0.f : 1.f), dL1 = dLc_g * (pre.y < 0 ? 0.f : 1.f),
+                    dL2 = dLc_b * (pre.z < 0 ? 0.f : 1.f);
+        float kk[16];
+        sh_coefficient_grads(deg, x, y, z, kk);
+        const int ncoef = (deg + 1) * (deg + 1);
+        if (stage != nullptr) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {  // staged records are M = 16 wide; bands above the degree are zero
+                const float m = k < ncoef ? kk[k] : 0.f;
+                stage[(3 * k + 0) * kShStagePitch] = m * dL0;
+                stage[(3 * k + 1) * kShStagePitch] = m * dL1;
+                stage[(3 * k + 2) * kShStagePitch] = m * dL2;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < ncoef) *reinterpret_cast<F3*>(dsh + 3 * k) = F3{kk[k] * dL0, kk[k] * dL1, kk[k] * dL2};
+            for (int k = ncoef; k < g.M; ++k) *reinterpret_cast<F3*>(dsh + 3 * k) = F3{0.f, 0.f, 0.f};  // bands above the degree
+        }
+        const F3 d0 = sh_dir_grads_channel(deg, x, y, z, sh, 0);
+        const F3 d1 = sh_dir_grads_channel(deg, x, y, z, sh, 1);
+        const F3 d2 = sh_dir_grads_channel(deg, x, y, z, sh, 2);
+        const F3 ddir = F3{d0.x * dL0 + d1.x * dL1 + d2.x * dL2, d0.y * dL0 + d1.y * dL1 + d2.y * dL2,
+                           d0.z * dL0 + d1.z * dL1 + d2.z * dL2};
+        const F3 dm = dnormvdv3(o, ddir);
+        dmx += dm.x; dmy += dm.y; dmz += dm.z;
+    }
+    g.dL_dmean3D[3 * (size_t)idx + 0] = dmx;
+    g.dL_dmean3D[3 * (size_t)idx + 1] = dmy;
+    g.dL_dmean3D[3 * (size_t)idx + 2] = dmz;
+
+    if (g.scales != nullptr) {
+        // computeCov3D backward (backward.cu:278-342)
+        const Mat3 Mm = mul3(S, R);
+        Mat3 dSig = {{{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]}, {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                      {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}}};
+        Mat3 M2;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) M2.m[i][j] = 2.0f * Mm.m[i][j];
+        const Mat3 dM = mul3(M2, dSig);
+        const Mat3 Rt = transpose3(R);
+        Mat3 dMt = transpose3(dM);
+#define COL(Mx, c, r) Mx.m[r][c]
+        const float sv[3] = {sx, sy, sz};
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            g.dL_dscale[3 * (size_t)idx + c] = COL(Rt, c, 0) * COL(dMt, c, 0) + COL(Rt, c, 1) * COL(dMt, c, 1) + COL(Rt, c, 2) * COL(dMt, c, 2);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) COL(dMt, c, rr) *= sv[c];
+#define D(c, rr) COL(dMt, c, rr)
+        const float r = qr, x = qx, y = qy, z = qz;
+        float* dq = g.dL_drot + 4 * (size_t)idx;
+        dq[0] = 2 * z * (D(0, 1) - D(1, 0)) + 2 * y * (D(2, 0) - D(0, 2)) + 2 * x * (D(1, 2) - D(2, 1));
+        dq[1] = 2 * y * (D(1, 0) + D(0, 1)) + 2 * z * (D(2, 0) + D(0, 2)) + 2 * r * (D(1, 2) - D(2, 1)) - 4 * x * (D(2, 2) + D(1, 1));
+        dq[2] = 2 * x * (D(1, 0) + D(0, 1)) + 2 * r * (D(2, 0) - D(0, 2)) + 2 * z * (D(1, 2) + D(2, 1)) - 4 * y * (D(2, 2) + D(0, 0));
+        dq[3] = 2 * r * (D(0, 1) - D(1, 0)) + 2 * x * (D(2, 0) + D(0, 2)) + 2 * y * (D(1, 2) + D(2, 1)) - 4 * z * (D(1, 1) + D(0, 0));
+#undef D
+#undef COL
+    } else {
+        *reinterpret_cast<F3*>(g.dL_dscale + 3 * (size_t)idx) = F3{0.f, 0.f, 0.f};
+        *reinterpret_cast<F4*>(g.dL_drot + 4 * (size_t)idx) = F4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// dL_dsh is 192 bytes per Gaussian: written lane by lane it goes out as 12-byte pieces 192 bytes apart (measured
+// 2.8 TB/s, scripts/ubench/sh_store.hip); staged through LDS ([float][lane], pitch 65: conflict-free both ways) the
+// wave writes its 12 KB as contiguous 16-byte stores (5.9 TB/s).  Taken when M == 16 and the tensor is 16-byte aligned.
+__global__ void __launch_bounds__(256) preprocess_backward_kernel(BackwardArgs g, Camera cam) {
+    __shared__ float s_stage[4][48 * kShStagePitch];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool staged = g.dL_dsh != nullptr && g.M == 16 && (reinterpret_cast<uintptr_t>(g.dL_dsh) & 15u) == 0;  // uniform
+    if (idx < g.P) preprocess_backward_lane(g, cam, idx, staged ? s_stage[wave] + lane : nullptr);
+    if (!staged) return;
+    const int g0 = blockIdx.x * 256 + wave * 64;  // first Gaussian of this wave
+    if (g0 >= g.P) return;
+    __builtin_amdgcn_s_waitcnt(0);       // this wave's own LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    const float* mine = s_stage[wave];
+    float4* dst = reinterpret_cast<float4*>(g.dL_dsh + 48 * (size_t)g0);
+    const int chunks = min(64, g.P - g0) * 12;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const int c = k * 64 + lane;  // 16-byte chunk of the wave's 12 KB
+        if (c < chunks) {
+            const int gi = c / 12, f = (c - gi * 12) * 4;
+            dst[c] = make_float4(mine[(f + 0) * kShStagePitch + gi], mine[(f + 1) * kShStagePitch + gi],
+                                 mine[(f + 2) * kShStagePitch + gi], mine[(f + 3) * kShStagePitch + gi]);
+        }
+    }
+}
+
+} // namespace
+
+hipError_t launch_render_backward(const Camera& cam, const uint2* ranges, const uint32_t* point_list,
+                                  const float* background, const SplatRaster* raster, const float* colors,
+                                  const float* accum_alphas,
+                                  const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
+                                  const float* dL_dpix_alpha, float* accum, hipStream_t stream) {
+    const int T = cam.grid_x * cam.grid_y;
+    hipLaunchKernelGGL(render_backward_kernel, dim3(4 * T), dim3(64), 0, stream, cam.width, cam.height, cam.grid_x, T,
+                       ranges, point_list, background, raster, colors, accum_alphas, n_contrib,
+                       dL_dpix, dL_dpix_depth, dL_dpix_alpha, accum);
+    return hipGetLastError();
+}
+
+hipError_t launch_preprocess_backward(const BackwardInputs& b, const Camera& cam, hipStream_t stream) {
+    BackwardArgs g;
+    g.P = b.P; g.sh_degree = b.sh_degree; g.M = b.M;
+    g.means3D = b.means3D; g.radii = b.radii; g.shs = b.shs; g.scales = b.scales; g.rotations = b.rotations;
+    g.cov3D_precomp = b.cov3D_precomp; g.scale_modifier = b.scale_modifier;
+    g.accum = b.accum; g.dL_dmean2D = b.dL_dmean2D; g.dL_dconic = b.dL_dconic; g.dL_dopacity = b.dL_dopacity;
+    g.dL_dcolor = b.dL_dcolor; g.dL_ddepth = b.dL_ddepth;
+    g.dL_dmean3D = b.dL_dmean3D; g.dL_dcov3D = b.dL_dcov3D; g.dL_dsh = b.dL_dsh; g.dL_dscale = b.dL_dscale;
+    g.dL_drot = b.dL_drot;
+    hipLaunchKernelGGL(preprocess_backward_kernel, dim3(div_up(b.P, 256)), dim3(256), 0, stream, g, cam);
+    return hipGetLastError();
+}
+
+} // namespace gsr

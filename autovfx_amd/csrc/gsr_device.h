@@ -1,0 +1,201 @@
+// gsr_device.h -- device-side helpers shared by the two kernel translation units (gsr_kernels.hip: forward and
+// auxiliary kernels; gsr_backward.hip: the backward pass, built with different code-generation flags, see
+// autovfx_amd/build.py).  Everything here is inline and lives in an unnamed namespace: each unit gets its own copy.
+#pragma once
+#include "gsr_internal.h"
+
+namespace gsr {
+namespace {
+
+inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+// 4-byte aligned aggregates: the compiler may still fuse them into dwordx3/x4 accesses, but no
+// 16-byte alignment is assumed of caller tensors.
+struct __attribute__((aligned(4))) F3 { float x, y, z; };
+struct __attribute__((aligned(4))) F4 { float x, y, z, w; };
+
+struct Mat3 { float m[3][3]; };  // m[row][col]
+
+// k = 0,1,2 summed left to right: glm's mat3 * mat3 (type_mat3x3.inl:486-518) in math notation.
+__device__ __forceinline__ Mat3 mul3(const Mat3& a, const Mat3& b) {
+    Mat3 r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            r.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j];
+    return r;
+}
+__device__ __forceinline__ Mat3 transpose3(const Mat3& a) {
+    Mat3 r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r.m[i][j] = a.m[j][i];
+    return r;
+}
+
+// float -> int, round toward zero, saturating, NaN -> 0 (what the GPU conversion does; spelled
+// out so host oracle and device agree by construction).
+__device__ __forceinline__ int f2i_sat(float v) {
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)v;
+}
+
+__device__ __forceinline__ float ndc_to_pix(float v, int S) {
+    return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5);  // auxiliary.h:41-44 is double math
+}
+
+struct TileRect { int x0, y0, x1, y1; };
+
+__device__ __forceinline__ TileRect tile_rect(float px, float py, int radius, int gx, int gy) {
+    TileRect r;
+    r.x0 = min(gx, max(0, f2i_sat((px - radius) / kTile)));
+    r.y0 = min(gy, max(0, f2i_sat((py - radius) / kTile)));
+    r.x1 = min(gx, max(0, f2i_sat((px + radius + kTile - 1) / kTile)));
+    r.y1 = min(gy, max(0, f2i_sat((py + radius + kTile - 1) / kTile)));
+    return r;
+}
+
+// SH basis constants (auxiliary.h:22-39).
+constexpr float kSH0 = 0.28209479177387814f;
+constexpr float kSH1 = 0.4886025119029199f;
+constexpr float kSH2_0 = 1.0925484305920792f, kSH2_1 = -1.0925484305920792f, kSH2_2 = 0.31539156525252005f,
+                kSH2_3 = -1.0925484305920792f, kSH2_4 = 0.5462742152960396f;
+constexpr float kSH3_0 = -0.5900435899266435f, kSH3_1 = 2.890611442640554f, kSH3_2 = -0.4570457994644658f,
+                kSH3_3 = 0.3731763325901154f, kSH3_4 = -0.4570457994644658f, kSH3_5 = 1.445305721320277f,
+                kSH3_6 = -0.5900435899266435f;
+
+__device__ __forceinline__ F3 ld3(const float* p) { return *reinterpret_cast<const F3*>(p); }
+__device__ __forceinline__ F3 axpy(F3 acc, float s, F3 v) {  // acc + s * v, unfused
+    return F3{acc.x + s * v.x, acc.y + s * v.y, acc.z + s * v.z};
+}
+__device__ __forceinline__ F3 axmy(F3 acc, float s, F3 v) {  // acc - s * v, unfused
+    return F3{acc.x - s * v.x, acc.y - s * v.y, acc.z - s * v.z};
+}
+
+// forward.cu:20-71 up to (and including) the +0.5, before the clamp.  (x, y, z) is the unit view
+// direction; `sh` points at this Gaussian's [M,3] block; deg already clamped to what M holds.
+__device__ __forceinline__ F3 sh_unclamped(int deg, float x, float y, float z, const float* sh) {
+    F3 c = ld3(sh);
+    F3 v = F3{kSH0 * c.x, kSH0 * c.y, kSH0 * c.z};
+    if (deg > 0) {
+        v = axmy(v, kSH1 * y, ld3(sh + 3));
+        v = axpy(v, kSH1 * z, ld3(sh + 6));
+        v = axmy(v, kSH1 * x, ld3(sh + 9));
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            v = axpy(v, kSH2_0 * xy, ld3(sh + 12));
+            v = axpy(v, kSH2_1 * yz, ld3(sh + 15));
+            v = axpy(v, kSH2_2 * (2.0f * zz - xx - yy), ld3(sh + 18));
+            v = axpy(v, kSH2_3 * xz, ld3(sh + 21));
+            v = axpy(v, kSH2_4 * (xx - yy), ld3(sh + 24));
+            if (deg > 2) {
+                v = axpy(v, kSH3_0 * y * (3.0f * xx - yy), ld3(sh + 27));
+                v = axpy(v, kSH3_1 * xy * z, ld3(sh + 30));
+                v = axpy(v, kSH3_2 * y * (4.0f * zz - xx - yy), ld3(sh + 33));
+                v = axpy(v, kSH3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), ld3(sh + 36));
+                v = axpy(v, kSH3_4 * x * (4.0f * zz - xx - yy), ld3(sh + 39));
+                v = axpy(v, kSH3_5 * z * (xx - yy), ld3(sh + 42));
+                v = axpy(v, kSH3_6 * x * (xx - 3.0f * yy), ld3(sh + 45));
+            }
+        }
+    }
+    v.x += 0.5f; v.y += 0.5f; v.z += 0.5f;
+    return v;
+}
+
+__device__ __forceinline__ F3 sh_to_rgb(int deg, F3 pos, F3 cam, const float* sh) {
+    float dx = pos.x - cam.x, dy = pos.y - cam.y, dz = pos.z - cam.z;
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    const F3 v = sh_unclamped(deg, dx / len, dy / len, dz / len, sh);
+    return F3{fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f)};
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact-image tile culling.  The reference pairs a splat with every tile of the bounding square of
+// its 3-sigma circle; for many of those tiles no pixel can reach alpha >= 1/255, so the blend
+// would skip the pair at every pixel.  This predicate returns false only when that is provable:
+// with q(d) = 0.5 (A dx^2 + C dy^2) + B dx dy  (power = -q, forward.cu:338), alpha >= 1/255 needs
+// q <= ln(255 o); q is convex, so its minimum over the tile's pixel rectangle is 0 if the centre is
+// inside and otherwise lies on one of the four edges, where it has a closed form.  The comparison
+// keeps a 0.2 % + 1e-3 margin, ~10x the worst-case fp32 rounding of q for |rho| < 0.995
+// (error <= 4e-7 (1+|rho|)/(1-|rho|) q); anything less regular is never culled.  Dropping such a
+// pair cannot change any pixel, bit for bit (tests compare culled and unculled renders exactly).
+// The test runs in the preprocess kernel, where the splat's conic is in registers and the ALU is
+// idle behind HBM: a splat whose rectangle has <= 32 tiles gets a 32-bit mask of live tiles and its
+// pair count becomes popcount(mask), so dead pairs are never written, sorted or ranged.  Larger
+// splats keep their full rectangle (their dead corners are a small fraction and a per-lane loop
+// over hundreds of tiles would serialise the wave).
+// The same predicate on an 8x8 quadrant lets the quadrant blend skip list entries wholesale.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float edge_q(float A, float B, float C, float dx, float dy) {
+    return 0.5f * (A * dx * dx + C * dy * dy) + B * dx * dy;
+}
+
+// Pixel rectangle [px_first, px_first + w - 1] x [py_first, py_first + h - 1].
+// The hardware reciprocal / log2 (1 ulp) are enough here: a slightly misplaced edge minimiser
+// changes q only to second order, and the log error (~1e-6) is far inside the 1e-3 margin.
+// `skip_below` is the splat's -ln(255 o) - 1e-4 (SplatRaster::skip_below, computed once per Gaussian): the budget
+// ln(255 o) is recovered from it; o <= 0 gives budget -inf (nothing visible), NaN keeps the pair.
+__device__ __forceinline__ float blend_skip_below(float opacity) { return -logf(255.0f * opacity) - 1.0e-4f; }
+
+__device__ __forceinline__ bool splat_reaches_rect(float4 co, float skip_below, float2 c, int px_first, int py_first, int w,
+                                                   int h) {
+    const float A = co.x, B = co.y, C = co.z;
+    if (!(A > 0.f) || !(C > 0.f) || !((B * B) < 0.99f * (A * C))) return true;
+    const float budget = -skip_below - 1.0e-4f;
+    const float x_lo = c.x - (float)(px_first + w - 1), x_hi = c.x - (float)px_first;
+    const float y_lo = c.y - (float)(py_first + h - 1), y_hi = c.y - (float)py_first;
+    if (x_lo <= 0.f && x_hi >= 0.f && y_lo <= 0.f && y_hi >= 0.f) return true;  // centre inside the rectangle
+    const float nb_c = -B * __builtin_amdgcn_rcpf(C), nb_a = -B * __builtin_amdgcn_rcpf(A);
+    float qmin = edge_q(A, B, C, x_lo, fminf(y_hi, fmaxf(y_lo, nb_c * x_lo)));
+    qmin = fminf(qmin, edge_q(A, B, C, x_hi, fminf(y_hi, fmaxf(y_lo, nb_c * x_hi))));
+    qmin = fminf(qmin, edge_q(A, B, C, fminf(x_hi, fmaxf(x_lo, nb_a * y_lo)), y_lo));
+    qmin = fminf(qmin, edge_q(A, B, C, fminf(x_hi, fmaxf(x_lo, nb_a * y_hi)), y_hi));
+    return !(qmin * 0.998f - 1.0e-3f > budget);
+}
+
+__device__ __forceinline__ bool splat_reaches_tile(float4 co, float skip_below, float2 c, int tile_x, int tile_y) {
+    return splat_reaches_rect(co, skip_below, c, tile_x * kTile, tile_y * kTile, kTile, kTile);
+}
+
+struct BlendEntryA { float x, y, cxx, cxy; };       // ds_read_b128
+struct BlendEntryB { float cyy, skip_below; };      // ds_read_b64
+struct BlendEntryC { float opacity, r, g, b; };     // ds_read_b128, contributing pairs only
+// One 48-byte LDS record per staged list entry (quadrant kernel): a single address register serves the three
+// 16-byte broadcast reads, and (r, g) / (b, z) land in even-aligned register pairs for the packed-fp32 updates.
+struct BlendEntry {
+    float x, y, cxx, cxy;               // every processed entry
+    float cyy, skip_below, opacity, pad;
+    float r, g, b, z;                   // contributing entries only
+};
+
+__device__ __forceinline__ int xcd_band_tile(int b, int T) {
+    // Blocks are dealt round-robin to the 8 XCDs (block b -> XCD b % 8).  Give each XCD a contiguous
+    // band of tile rows so neighbouring tiles, which share splats, hit the same L2.  Bijective for
+    // any T.  Placement is a speed hint only; results do not depend on it.
+    const int q = T >> 3, r = T & 7;
+    const int xcd = b & 7, local = b >> 3;
+    return xcd * q + min(xcd, r) + local;
+}
+
+// expf for the blend loop: the instruction sequence of the device library's expf (extended-precision
+// x * log2(e), round to nearest, v_exp_f32 of the remainder, ldexp) without its two range clamps, which only
+// act for x < -103.97 or x > 88.72.  The blend calls it with power <= 0 (or NaN); together with the
+// finite-opacity skip threshold the results are bit-identical to expf there (tests/test_parity_gpu.py
+// compares all floats of [-103, 0] through gsr_selftest_exp).  4 of 13 VALU instructions saved per call.
+__device__ __forceinline__ float exp_nonpositive(float x) {
+    const float log2e_hi = __uint_as_float(0x3fb8aa3bu), log2e_lo = __uint_as_float(0x32a5705fu);
+    const float t = x * log2e_hi;
+    const float r = __builtin_rintf(t);
+    float e = __builtin_fmaf(x, log2e_hi, -t);  // low part of the product, exact
+    e = __builtin_fmaf(x, log2e_lo, e);
+    const float m = __builtin_amdgcn_exp2f((t - r) + e);
+    return __builtin_ldexpf(m, (int)r);
+}
+
+} // namespace
+} // namespace gsr
