@@ -832,8 +832,11 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
         if (todo != 0ull) {
             __syncthreads();  // single-wave workgroup: orders this wave's LDS reads / writes only
             float4* rec = reinterpret_cast<float4*>(&s_entry[lane]);
-            rec[0] = make_float4(g_xy.x, g_xy.y, g_co.x, g_co.y);
-            rec[1] = make_float4(g_co.z, g_skip, g_co.w, 0.f);
+            // The conic's diagonal is parked already multiplied by -0.5: scaling by a power of two commutes with every
+            // rounding of -0.5 * (cxx*dx*dx + cyy*dy*dy), so the walk below gets the same bits with one multiply less
+            // per (entry, pixel).
+            rec[0] = make_float4(g_xy.x, g_xy.y, -0.5f * g_co.x, g_co.y);
+            rec[1] = make_float4(-0.5f * g_co.z, g_skip, g_co.w, 0.f);
             rec[2] = make_float4(g_rgb.x, g_rgb.y, g_rgb.z, g_z);
             if (kExtra) s_extra[lane] = make_float4(g_ext.x, g_ext.y, g_ext.z, 0.f);
             __syncthreads();
@@ -849,11 +852,12 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(int W, int H, int
             asm("v_mov_b32 %0, %1" : "=v"(entry_offset) : "s"(j * (int)sizeof(BlendEntry)));
             const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_entry) + entry_offset);
             const float4 ra = rec[0], rb = rec[1];
-            struct { float x, y, cxx, cxy; } a = {ra.x, ra.y, ra.z, ra.w};
-            struct { float cyy, skip_below, opacity; } b = {rb.x, rb.y, rb.z};
-            // One list entry against this lane's pixel: forward.cu:331-364, unchanged arithmetic.
+            struct { float x, y, mh_cxx, cxy; } a = {ra.x, ra.y, ra.z, ra.w};   // mh_ = times minus one half
+            struct { float mh_cyy, skip_below, opacity; } b = {rb.x, rb.y, rb.z};
+            // One list entry against this lane's pixel: forward.cu:331-364, same bits as
+            // -0.5f * (cxx * dx * dx + cyy * dy * dy) - cxy * dx * dy.
             const float dx = a.x - fx, dy = a.y - fy;
-            const float power = -0.5f * (a.cxx * dx * dx + b.cyy * dy * dy) - a.cxy * dx * dy;
+            const float power = (a.mh_cxx * dx * dx + b.mh_cyy * dy * dy) - a.cxy * dx * dy;
             // (one ballot per comparison: the ballot of a conjunction goes through a vector register and back)
             const unsigned long long live = __ballot(!(power > 0.0f)) & __ballot(!(power < b.skip_below)) & ~done_mask;
             if (live == 0ull) continue;
