@@ -71,8 +71,8 @@ def algorithmic_bytes(P, V, D, T, W, H, M=16):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--gaussians", type=int, default=0, help="override P (parity/debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

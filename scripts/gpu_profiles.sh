@@ -1,0 +1,14 @@
+#!/bin/bash
+# The three profile sets kept under profiles/: kernel stats of the bench command (product only), kernel stats of the
+# forward+backward iteration, PMC passes.  usage: gpu_profiles.sh tag
+set -u
+TAG=${1:-profiles}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/prof" -o c3 -- \
+    python "$GRAFT_REPO_ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-reference-hip --streams 1 > "$GRAFT_REPO_ROOT/$OUT/prof_bench.json" 2> "$GRAFT_REPO_ROOT/$OUT/prof.err" )
+echo "rocprof bench exit $?"
+cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/c3_kernel_stats.csv
+find $OUT/prof -type f -size +8M -delete
+bash scripts/gpu_prof_bw.sh $TAG/bw c3 > $OUT/bw.txt 2>&1; echo "rocprof backward exit $?"
+bash scripts/gpu_pmc.sh $TAG/pmc > $OUT/pmc.txt 2>&1; echo "pmc exit $?"
+python scripts/pmc_reduce.py $OUT/pmc $OUT/pmc_per_kernel_mean.csv > /dev/null
+head -12 $OUT/c3_kernel_stats.csv | cut -c1-100; grep "blend_quadrant" $OUT/pmc_per_kernel_mean.csv
