@@ -19,13 +19,15 @@ HEADERS = [os.path.join(CSRC, "gsr_internal.h"), os.path.join(CSRC, "gsr_device.
            os.path.join(HERE, "..", "include", "gsr.h")]
 # -ffp-contract=off: the parity contract is fp32 in the reference's operation order;
 # no -ffast-math: IEEE divide / sqrt, accurate expf.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
+# -fno-slp-vectorize: on gfx950 packed fp32 multiply / add issue at half rate (only the packed fma is full rate), so
+# the SLP vectorizer's pairing of scalar fp32 work buys no issue slots and costs register shuffles.  Same-box A/B on
+# MI355X: the backward kernels, long stretches of scalar fp32 algebra, are 10 % faster without it (VGPRs 117 -> 91 in
+# preprocess_backward); the forward path is 0.5 % faster without it in the 3-stream regime, where vector issue is the
+# contended resource, and 1.3 % slower single-stream, where it is memory-bound and the vectorizer's wider accesses
+# help.  The one profitable pairing, the blend's compositing fma, is written with vector types.  Same IEEE results.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-Wall",
          "-Wno-unused-result", "-fvisibility=hidden", "-DNDEBUG"]
-# Per-file additions.  The backward kernels are long stretches of scalar fp32 algebra; the SLP vectorizer pairs that
-# into packed multiplies / adds plus register shuffles, which costs them registers and issue slots (measured: a C3
-# training-style iteration 2.90 ms with it, 2.62 ms without), while the forward kernels are 1.3 % faster with it
-# (same-box A/B).  Same IEEE results either way.
-FILE_FLAGS = {"gsr_backward.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {}   # per-file additions, if a unit ever needs its own
 
 
 def hipcc() -> str:

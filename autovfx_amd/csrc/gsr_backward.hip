@@ -3,12 +3,11 @@
 //   render_backward_kernel      <- BACKWARD::renderCUDA   DGR/cuda_rasterizer/backward.cu:415-599
 //   preprocess_backward_kernel  <- BACKWARD::preprocess   backward.cu:144-413 (+ SH :20-138, cov3D :278-342)
 //
-// Its own translation unit because it wants different code generation from the forward kernels: this file is built
-// with -fno-slp-vectorize.  The SLP vectorizer pairs scalar fp32 multiplies and adds into v_pk_mul_f32 / v_pk_add_f32
-// at the price of register shuffles; in these two kernels, which are long stretches of scalar fp32 algebra, that cost
-// 117 instead of 91 VGPRs and a third more vector instructions in preprocess_backward and made a training-style
-// iteration at C3 10 % slower (2.90 vs 2.62 ms on MI355X).  The forward kernels keep the vectorizer (same-box A/B:
-// 1.3 % faster with it).  IEEE results do not depend on the choice.
+// Its own translation unit: the backward pass shares only the inline helpers of gsr_device.h with the forward
+// kernels.  Like the rest of the library it is built with -fno-slp-vectorize (autovfx_amd/build.py): these two kernels
+// are long stretches of scalar fp32 algebra, which the SLP vectorizer turns into half-rate packed multiplies / adds plus
+// register shuffles -- 117 instead of 91 VGPRs in preprocess_backward and a training-style iteration at C3 10 % slower
+// (2.90 vs 2.62 ms on MI355X).
 #include "gsr_device.h"
 
 namespace gsr {
