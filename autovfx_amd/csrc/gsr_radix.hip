@@ -185,6 +185,7 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t*
         unsigned long long peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
+            if ((digit_mask >> b) == 0u) break;  // wave-uniform: a narrow last digit needs fewer ballots
             const bool set = (d >> b) & 1u;
             const unsigned long long with_bit = __ballot(set);
             peers &= set ? with_bit : ~with_bit;
