@@ -185,6 +185,42 @@ class GaussianModel:
         self.active_sh_degree = self.max_sh_degree
         return self
 
+    # the six entries of a SuGaR checkpoint's ``state_dict`` that ``scene_representation.load_scene`` reads (:200-205)
+    _SUGAR_KEYS = {"_xyz": "_points", "_opacity": "all_densities", "_features_dc": "_sh_coordinates_dc",
+                   "_features_rest": "_sh_coordinates_rest", "_scaling": "_scales", "_rotation": "_quaternions"}
+
+    def load_sugar_checkpoint(self, path: str, device: Optional[str] = None) -> "GaussianModel":
+        """Parameters of a (coarse or refined) SuGaR ``.pt`` checkpoint, the way ``scene_representation.py:192-214``
+        takes them: six tensors out of ``checkpoint['state_dict']``, stored raw (pre-activation) exactly like a PLY's
+        columns, ``active_sh_degree = max_sh_degree``."""
+        checkpoint = torch.load(path, map_location="cpu", weights_only=False)
+        state = checkpoint["state_dict"] if "state_dict" in checkpoint else checkpoint
+        missing = [k for k in self._SUGAR_KEYS.values() if k not in state]
+        if missing:
+            raise KeyError(f"{path}: not a SuGaR checkpoint, state_dict lacks {missing}")
+        for attr, key in self._SUGAR_KEYS.items():
+            setattr(self, attr, state[key].detach().to(dtype=torch.float32, device=device).contiguous())
+        P = self._xyz.shape[0]
+        if self._features_dc.shape != (P, 1, 3) or self._features_rest.dim() != 3 or self._features_rest.shape[::2] != (P, 3):
+            raise ValueError(f"{path}: SH tensors have shapes {tuple(self._features_dc.shape)}, "
+                             f"{tuple(self._features_rest.shape)}; expected [P,1,3] and [P,K,3]")
+        # No check of K against max_sh_degree, as in the reference: its SuGaR hparams say max_sh_degree = 4 for
+        # checkpoints holding 16 coefficients (sh_levels = 4), and the rasterizer evaluates degrees above 3 as 3.
+        self.active_sh_degree = self.max_sh_degree
+        self.__dict__.pop("_memo_cache", None)
+        return self
+
+
+def load_scene(path: str, max_sh_degree: int = 4, device: Optional[str] = None) -> GaussianModel:
+    """``scene_representation.load_scene`` (:192-221): a SuGaR ``.pt`` checkpoint is read with ``max_sh_degree``
+    (SuGaR's hparams use 4: the reference's own comment "SuGaR: 4, vanilla 3DGS: 3"), a vanilla 3DGS ``.ply`` with
+    ``max_sh_degree - 1``."""
+    if path.endswith(".pt"):
+        return GaussianModel(max_sh_degree).load_sugar_checkpoint(path, device)
+    if path.endswith(".ply"):
+        return GaussianModel(max_sh_degree - 1).load_ply(path, device)
+    raise ValueError(f"{path}: expected a SuGaR .pt checkpoint or a 3DGS .ply")
+
 
 _PLY_TYPES = {"float": "<f4", "float32": "<f4", "double": "<f8", "float64": "<f8", "uchar": "u1", "uint8": "u1",
               "char": "i1", "int8": "i1", "short": "<i2", "int16": "<i2", "ushort": "<u2", "uint16": "<u2",

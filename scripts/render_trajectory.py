@@ -24,7 +24,9 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--ply")
+    ap.add_argument("--ply", help="vanilla 3DGS point_cloud.ply (read with --sh-degree)")
+    ap.add_argument("--checkpoint", help="SuGaR .pt checkpoint or 3DGS .ply, dispatched like scene_representation.load_scene "
+                                         "(--sh-degree + 1 plays the role of its max_sh_degree)")
     ap.add_argument("--synthetic", type=int, default=0)
     ap.add_argument("--trajectory")
     ap.add_argument("--orbit", nargs=2, metavar=("N", "WxH"))
@@ -48,7 +50,10 @@ def main():
     from autovfx_amd.frame_parallel import shard_frames
     from autovfx_amd.gaussian_model import GaussianModel
 
-    if args.ply:
+    if args.checkpoint:
+        from autovfx_amd.gaussian_model import load_scene
+        model = load_scene(args.checkpoint, args.sh_degree + 1, device=str(dev))
+    elif args.ply:
         model = GaussianModel(args.sh_degree).load_ply(args.ply, device=str(dev))
         model.active_sh_degree = model.max_sh_degree
     else:

@@ -244,3 +244,29 @@ def test_render_begin_finish_is_render():
             assert torch.equal(a[k], b[k]), k
     with torch.enable_grad(), pytest.raises(RuntimeError, match="no_grad"):
         renderer.render_begin(cams[0], m, renderer.PipelineParams, bg)
+
+
+def test_sugar_checkpoint_and_load_scene(tmp_path):
+    """``load_scene`` dispatches like scene_representation.py:192-221: SuGaR ``.pt`` -> the six state_dict tensors, raw,
+    with max_sh_degree; ``.ply`` -> vanilla 3DGS with max_sh_degree - 1."""
+    from autovfx_amd.gaussian_model import load_scene
+    m, _ = model(300, seed=21)
+    state = {"_points": m._xyz, "all_densities": m._opacity, "_sh_coordinates_dc": m._features_dc,
+             "_sh_coordinates_rest": m._features_rest, "_scales": m._scaling, "_quaternions": m._rotation,
+             "_unrelated": torch.zeros(3)}
+    pt = str(tmp_path / "coarse.pt")
+    torch.save({"state_dict": state, "epoch": 7}, pt)
+    got = load_scene(pt, max_sh_degree=4)
+    assert got.max_sh_degree == 4 and got.active_sh_degree == 4
+    for k in ("_xyz", "_opacity", "_features_dc", "_features_rest", "_scaling", "_rotation"):
+        assert torch.equal(getattr(got, k), getattr(m, k)), k
+    assert torch.equal(got.get_features, m.get_features) and torch.equal(got.get_scaling, m.get_scaling)
+    ply = str(tmp_path / "point_cloud.ply")
+    m.save_ply(ply)
+    got = load_scene(ply, max_sh_degree=4)
+    assert got.max_sh_degree == 3 and torch.equal(got._xyz, m._xyz) and torch.equal(got._features_rest, m._features_rest)
+    torch.save({"state_dict": {"_points": m._xyz}}, pt)
+    with pytest.raises(KeyError, match="SuGaR"):
+        load_scene(pt)
+    with pytest.raises(ValueError, match="expected"):
+        load_scene(str(tmp_path / "scene.obj"))
