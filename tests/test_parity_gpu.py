@@ -785,3 +785,15 @@ def test_second_feature_set_equals_a_second_pass(case):
     assert torch.equal(fused[8], second[1])
     for i in (2, 3):
         assert torch.equal(second[i], plain[i])
+
+
+def test_sh_degree_above_three_is_degree_three():
+    """SuGaR checkpoints reach the rasterizer with active_sh_degree = 4 and 16 coefficients
+    (scene_representation.py:196,213); computeColorFromSH (forward.cu:20-71) only tests deg > 0, > 1, > 2, so the
+    result is the degree-3 one -- here too, forward and backward."""
+    cloud = scenes.config_c1(seed=4)
+    cam = orbit_cameras(6, 128, 96)[2]
+    a = run_hip(cloud, cam, sh_degree=3)
+    b = run_hip(cloud, cam, sh_degree=4)
+    for k in ("color", "depth", "alpha", "radii"):
+        np.testing.assert_array_equal(a[k], b[k])
