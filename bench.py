@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--force-distributed", action="store_true",
                     help="debug: take the N > 1 code path (process group, barriers, pipelined RCCL gather) even with "
                          "one rank, so that path can be exercised on a one-GPU box")
-    ap.add_argument("--gather-chunks", type=int, default=4,
+    ap.add_argument("--gather-chunks", type=int, default=16,
                     help="N > 1: pieces the per-rank frame stack is gathered in, each overlapped with the next piece's rendering")
     ap.add_argument("--streams", type=int, default=3,
                     help="render frames on this many HIP streams so independent frames overlap")
