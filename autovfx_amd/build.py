@@ -30,6 +30,24 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 FILE_FLAGS = {}   # per-file additions, if a unit ever needs its own
 
 
+EXAMPLE_SRC = os.path.join(HERE, "..", "examples", "render_raw.cpp")
+EXAMPLE_BIN = os.path.join(HERE, "..", "examples", "bin", "render_raw")
+
+
+def build_examples(force: bool = False, verbose: bool = False) -> str:
+    """examples/render_raw: the C ABI driven from plain C++ / HIP (no Python, no torch); linked against the in-tree
+    library with a relative rpath so the binary travels with the repository."""
+    lib = build()
+    if force or _stale(EXAMPLE_BIN, [EXAMPLE_SRC, lib] + HEADERS):
+        os.makedirs(os.path.dirname(EXAMPLE_BIN), exist_ok=True)
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", EXAMPLE_SRC, "-o", EXAMPLE_BIN, "-L", OUT_DIR,
+               "-lgsr_hip", "-Wl,-rpath,$ORIGIN/../../autovfx_amd/lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return EXAMPLE_BIN
+
+
 def hipcc() -> str:
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
