@@ -30,22 +30,26 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 FILE_FLAGS = {}   # per-file additions, if a unit ever needs its own
 
 
-EXAMPLE_SRC = os.path.join(HERE, "..", "examples", "render_raw.cpp")
-EXAMPLE_BIN = os.path.join(HERE, "..", "examples", "bin", "render_raw")
+EXAMPLES_DIR = os.path.join(HERE, "..", "examples")
+EXAMPLES = ("render_raw", "render_stream")
 
 
-def build_examples(force: bool = False, verbose: bool = False) -> str:
-    """examples/render_raw: the C ABI driven from plain C++ / HIP (no Python, no torch); linked against the in-tree
-    library with a relative rpath so the binary travels with the repository."""
+def build_examples(force: bool = False, verbose: bool = False):
+    """examples/*.cpp: the C ABI driven from plain C++ / HIP (no Python, no torch); linked against the in-tree library
+    with a relative rpath so the binaries travel with the repository.  Returns their paths."""
     lib = build()
-    if force or _stale(EXAMPLE_BIN, [EXAMPLE_SRC, lib] + HEADERS):
-        os.makedirs(os.path.dirname(EXAMPLE_BIN), exist_ok=True)
-        cmd = [hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", EXAMPLE_SRC, "-o", EXAMPLE_BIN, "-L", OUT_DIR,
-               "-lgsr_hip", "-Wl,-rpath,$ORIGIN/../../autovfx_amd/lib"]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-    return EXAMPLE_BIN
+    out = []
+    for name in EXAMPLES:
+        src, exe = os.path.join(EXAMPLES_DIR, name + ".cpp"), os.path.join(EXAMPLES_DIR, "bin", name)
+        if force or _stale(exe, [src, lib] + HEADERS):
+            os.makedirs(os.path.dirname(exe), exist_ok=True)
+            cmd = [hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", src, "-o", exe, "-L", OUT_DIR, "-lgsr_hip",
+                   "-Wl,-rpath,$ORIGIN/../../autovfx_amd/lib"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        out.append(exe)
+    return out
 
 
 def hipcc() -> str:

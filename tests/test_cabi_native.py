@@ -38,11 +38,35 @@ def read_out(path, P, W, H):
     return n, out
 
 
-def test_example_source_uses_only_the_public_header():
-    src = open(os.path.join(ROOT, "examples", "render_raw.cpp")).read()
+STREAM_BIN = os.path.join(ROOT, "examples", "bin", "render_stream")
+
+
+@pytest.mark.parametrize("name", ["render_raw", "render_stream"])
+def test_example_source_uses_only_the_public_header(name):
+    src = open(os.path.join(ROOT, "examples", name + ".cpp")).read()
     includes = [l.split()[1] for l in src.splitlines() if l.startswith("#include")]
     assert '"../include/gsr.h"' in includes
     assert not any("torch" in i or "gsr_internal" in i or "Python" in i for i in includes)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("streams", [1, 3, 4])
+def test_native_pipelined_frames_equal_the_one_shot_call(tmp_path, streams):
+    """examples/render_stream.cpp keeps `streams` frames in flight from one host thread with gsr_forward_begin /
+    gsr_forward_finish; its last frame must be byte-identical to render_raw's gsr_forward of the same scene."""
+    assert os.path.exists(BIN) and os.path.exists(STREAM_BIN), "examples are not built: run __graft_entry__.build()"
+    W, H = 400, 240
+    cloud = scenes.config_c2(P=50_000, seed=17)
+    cam = orbit_cameras(9, W, H)[5]
+    scene = str(tmp_path / "scene.bin")
+    write_scene(scene, cloud, cam, torch.tensor([0.0, 0.2, 0.4]), W, H)
+    one, many = str(tmp_path / "one.bin"), str(tmp_path / "many.bin")
+    r = subprocess.run([BIN, scene, one], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([STREAM_BIN, scene, many, "23", str(streams)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "frames/s" in r.stderr
+    assert open(one, "rb").read() == open(many, "rb").read()
 
 
 @pytest.mark.gpu
