@@ -133,8 +133,9 @@ class GaussianModel:
 
     @property
     def get_minimum_axis(self):
+        # (made contiguous once here: the strided column view would be copied by every frame's kernel call)
         return self._memo("min_axis", (self._scaling, self._rotation),
-                          lambda: get_minimum_axis(self.get_scaling, self.get_rotation))
+                          lambda: get_minimum_axis(self.get_scaling, self.get_rotation).contiguous())
 
     def get_normal(self, dir_pp_normalized=None):
         normal_axis, _ = flip_align_view(self.get_minimum_axis, dir_pp_normalized)

@@ -122,8 +122,9 @@ def _render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_col
     xyz = pc.get_xyz
     if torch.is_grad_enabled():
         screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True) + 0
-    else:   # only ever read through its gradient (densification statistics): nothing to add to without autograd
-        screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype)
+    else:   # only ever read through its gradient (densification statistics): without autograd it is P x 3 zeros that
+        # nobody reads, returned as a broadcast view instead of a fresh 12-byte-per-Gaussian fill per frame
+        screenspace_points = torch.zeros((1, 1), dtype=xyz.dtype, device=xyz.device).expand(xyz.shape)
     try:
         screenspace_points.retain_grad()
     except Exception:
@@ -181,7 +182,7 @@ def _render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_col
 
         def assemble(result):
             (_n, rendered_image, depth_image, alpha_image, radii, _g, _b, _i, normal_image) = result
-            rendered_image = torch.cat((rendered_image, alpha_image), dim=0)
+            rendered_image = _C.rgba_planes(rendered_image, alpha_image)   # torch.cat((colour, alpha)) without the copy
             depth_image = depth_image.squeeze(0)
             normal_image, pseudo_normal = _fused_normal_maps(normal_image, depth_image, c2w, fx, fy, w / 2, h / 2)
             return {"render": rendered_image, "depth": depth_image, "normal": normal_image,

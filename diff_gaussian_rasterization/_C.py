@@ -106,6 +106,17 @@ def _geometry_key(tensors, scalars):
                  for t in tensors) + tuple(scalars)
 
 
+def rgba_planes(color: torch.Tensor, alpha: torch.Tensor) -> torch.Tensor:
+    """``torch.cat((color, alpha), dim=0)`` -- without the copy when the two are the planes of one forward call's
+    output buffer (they are whenever they come from this module)."""
+    base = color._base
+    if (base is not None and alpha._base is base and base.dim() == 3 and base.shape[0] == 4 and base.is_contiguous()
+            and color.shape[0] == 3 and alpha.shape[0] == 1 and color.data_ptr() == base.data_ptr()
+            and alpha.data_ptr() == base.data_ptr() + 3 * base.stride(0) * base.element_size()):
+        return base
+    return torch.cat((color, alpha), dim=0)
+
+
 def last_layout() -> dict:
     """Byte offsets of every scratch sub-array of this thread's most recent forward call
     (introspection for the parity tests; not part of the reference surface)."""
@@ -147,9 +158,11 @@ def _rasterize(background, means3D, colors, opacity, scales, rotations, scale_mo
     # The reference zero-fills its outputs (rasterize_points.cu:68-71), which only matters for P == 0:
     # with P > 0 every pixel and every radius is written by the kernels, so the fills are skipped.
     make = torch.zeros if P == 0 else torch.empty
-    out_color = make((3, H, W), dtype=torch.float32, device=device)
+    # colour and alpha are the first three and the fourth plane of ONE buffer, so a caller that wants RGBA
+    # (render() does: gaussian_renderer/__init__.py:161) gets it without a copy (rgba_planes below)
+    rgba = make((4, H, W), dtype=torch.float32, device=device)
+    out_color, out_alpha = rgba[:3], rgba[3:4]
     out_depth = make((1, H, W), dtype=torch.float32, device=device)
-    out_alpha = make((1, H, W), dtype=torch.float32, device=device)
     radii = make((P,), dtype=torch.int32, device=device)
     out_extra = make((3, H, W), dtype=torch.float32, device=device) if extra_colors is not None else None
     scratch = _CallScratch(device)
@@ -259,9 +272,11 @@ def rasterize_gaussians_begin(background, means3D, colors, opacity, scales, rota
     if extra_colors is not None and (extra_colors.dim() != 2 or extra_colors.shape != (P, 3)):
         raise RuntimeError("extra_colors must have dimensions (num_points, 3)")
     make = torch.zeros if P == 0 else torch.empty
-    out_color = make((3, H, W), dtype=torch.float32, device=device)
+    # colour and alpha are the first three and the fourth plane of ONE buffer, so a caller that wants RGBA
+    # (render() does: gaussian_renderer/__init__.py:161) gets it without a copy (rgba_planes below)
+    rgba = make((4, H, W), dtype=torch.float32, device=device)
+    out_color, out_alpha = rgba[:3], rgba[3:4]
     out_depth = make((1, H, W), dtype=torch.float32, device=device)
-    out_alpha = make((1, H, W), dtype=torch.float32, device=device)
     radii = make((P,), dtype=torch.int32, device=device)
     out_extra = make((3, H, W), dtype=torch.float32, device=device) if extra_colors is not None else None
     scratch = _CallScratch(device)
