@@ -369,8 +369,11 @@ def pmc_traffic(kernel):
         vals = {}
         with open(path) as f:
             for line in f:
-                parts = line.strip().split(",")
-                if len(parts) == 4 and parts[0] == kernel and parts[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+                parts = line.strip().rsplit(",", 3)   # template arguments in the kernel name may hold commas
+                if len(parts) != 4 or parts[1] not in ("FETCH_SIZE", "WRITE_SIZE"):
+                    continue
+                name = parts[0]
+                if name == kernel or (name.split("<")[0] == kernel and name.endswith("<false>")):   # the plain variant
                     vals[parts[1]] = float(parts[2])
         if len(vals) == 2:
             return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), "profiles/r01_pmc_per_kernel_mean.csv (2*FETCH_SIZE + WRITE_SIZE, KiB)"

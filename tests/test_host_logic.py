@@ -61,3 +61,18 @@ def test_algorithmic_bytes_worked_example():
     assert b["n_pass"] == 6
     assert abs(b["frame"] / 1e9 - 3.94) < 0.02
     assert b["blend"] == 44 * 15_000_000 + 24 * 1920 * 1080
+
+
+def test_bench_finds_the_committed_pmc_traffic():
+    """bench.py's roofline.traffic comes from profiles/r01_pmc_per_kernel_mean.csv; kernel names there carry template
+    arguments (`blend_quadrant_kernel<false>`, `radix_scatter_kernel<false, true>`)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    traffic, source = bench.pmc_traffic("blend_quadrant_kernel")
+    assert traffic is not None and 3e8 < traffic < 9e8 and "r01_pmc_per_kernel_mean.csv" in source
+    assert bench.pmc_traffic("preprocess_kernel")[0] > 5e8
+    assert bench.pmc_traffic("no_such_kernel") == (None, None)
