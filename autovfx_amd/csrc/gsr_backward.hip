@@ -464,7 +464,7 @@ __device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, 
     dmz += (view[10] - view[11] * mul3_) * gdep;
 
     if (g.shs != nullptr) {
-        int deg = g.sh_degree;
+        int deg = g.sh_degree < 3 ? g.sh_degree : 3;  // bands above 3 do not exist here (backward.cu:20-138): M = 25 gets 9 zero bands
         if (deg > 2 && g.M < 16) deg = 2;
         if (deg > 1 && g.M < 9) deg = 1;
         if (deg > 0 && g.M < 4) deg = 0;

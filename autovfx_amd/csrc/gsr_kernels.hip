@@ -140,8 +140,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
             const uint32_t area = (uint32_t)(rc.x1 - rc.x0) * (uint32_t)(rc.y1 - rc.y0);
             if (area != 0) {
                 if (in.colors_precomp == nullptr) {
-                    int deg = in.sh_degree;  // never read past M coefficients (D may be 4 with M = 16)
-                    if (deg > 2 && in.M < 16) deg = 2;
+                    int deg = in.sh_degree < 3 ? in.sh_degree : 3;  // forward.cu:20-71 knows bands 0..3 (D may be 4)
+                    if (deg > 2 && in.M < 16) deg = 2;  // never read past M coefficients
                     if (deg > 1 && in.M < 9) deg = 1;
                     if (deg > 0 && in.M < 4) deg = 0;
                     const F3 cp = ld3(cam.cam_pos);

@@ -181,3 +181,34 @@ def test_backward_randomised_configurations(seed):
     kw.update(pg)
     hip = hip_backward(cloud, cam, pg, bg=bg, sh_degree=deg, cull=bool(seed % 2))
     compare(f"rand{seed}", hip, cpu_oracle.backward(**kw), KEYS_SH)
+
+
+def test_backward_c2_full_size_vs_oracle():
+    """BASELINE configs[1] stand-in at full size (1 M Gaussians, 960x540, orbit frame 100): every gradient against the
+    CPU oracle's backward, same bar as the small cases."""
+    cloud, cam = scenes.config_c2(), orbit_cameras(200, 960, 540)[100]
+    pg = pixel_grads(cam, 5)
+    kw = oracle_kwargs(cloud, cam)
+    kw.update(pg)
+    ref = cpu_oracle.backward(**kw)
+    hip = hip_backward(cloud, cam, pg)
+    np.testing.assert_array_equal(hip["radii"], ref["radii"])
+    compare("c2_full_1M", hip, ref, KEYS_SH)
+
+
+def test_backward_sh_degree_four_with_25_coefficients_leaves_higher_bands_zero():
+    """A vanilla GaussianModel(sh_degree=4) carries M = 25 coefficients; computeColorFromSH (forward.cu:20-71 and its
+    backward, backward.cu:20-138) only knows bands 0..3, so coefficients 16..24 receive exactly zero gradient (the
+    reference's binding zero-fills dL_dsh, rasterize_points.cu:158-168) and the first 16 equal the M = 16 result."""
+    cloud, cam = scenes.config_c1(P=3000, seed=41), scenes.c1_camera(128, 96)
+    g = torch.Generator().manual_seed(2)
+    wide = GaussianCloud(cloud.means3D, cloud.opacities, cloud.scales, cloud.rotations,
+                         torch.cat((cloud.shs, torch.randn(cloud.P, 9, 3, generator=g)), 1).contiguous(), None, 4)
+    pg = pixel_grads(cam, 9)
+    a = hip_backward(cloud, cam, pg, sh_degree=3)
+    b = hip_backward(wide, cam, pg, sh_degree=4)
+    assert b["dL_dsh"].shape == (cloud.P, 25, 3)
+    assert not b["dL_dsh"][:, 16:].any(), "bands above degree 3 must get zero gradient"
+    np.testing.assert_array_equal(np.isfinite(b["dL_dsh"]), True)
+    np.testing.assert_allclose(b["dL_dsh"][:, :16], a["dL_dsh"], rtol=0, atol=REL * float(np.abs(a["dL_dsh"]).max()) + ABS)
+    np.testing.assert_array_equal(a["color"], b["color"])

@@ -797,3 +797,26 @@ def test_sh_degree_above_three_is_degree_three():
     b = run_hip(cloud, cam, sh_degree=4)
     for k in ("color", "depth", "alpha", "radii"):
         np.testing.assert_array_equal(a[k], b[k])
+
+
+# ---- BASELINE configs at full size against the oracle (every stage) ----------------------------------------------
+
+@pytest.mark.parametrize("frame", [0, 100, 199])
+def test_c2_full_frames_vs_oracle(frame):
+    """BASELINE configs[1] stand-in at full size: 1 M Gaussians, 960x540, orbit frames 0 / 100 / 199.  Every integer
+    array (radii, pair counts, depth order, offsets, point_list, tile keys, ranges) and every per-Gaussian fp32 array
+    bit-exact against the oracle, images within 1e-4 with the flip census; tile culling on/off bit-identical."""
+    cloud = scenes.config_c2()
+    cam = orbit_cameras(200, 960, 540)[frame]
+    hip, ref = run_both(f"c2_full_f{frame}", cloud, cam)
+    report(f"c2_full_f{frame}:size", P=cloud.P, V=int((ref["radii"] > 0).sum()), D=int(ref["num_rendered"]))
+
+
+@pytest.mark.parametrize("frame", [0, 400, 799])
+def test_c3_full_frames_vs_oracle(frame):
+    """BASELINE configs[2] (the headline workload) at full size: 3 M Gaussians, 1920x1080, orbit frames 0 / 400 / 799,
+    same bars as above (the radix sorts run with 3 M keys and ~13.5 M pairs, expand with ~3 300 pair tiles)."""
+    cloud = scenes.config_c3()
+    cam = orbit_cameras(800, 1920, 1080)[frame]
+    hip, ref = run_both(f"c3_full_f{frame}", cloud, cam)
+    report(f"c3_full_f{frame}:size", P=cloud.P, V=int((ref["radii"] > 0).sum()), D=int(ref["num_rendered"]))
