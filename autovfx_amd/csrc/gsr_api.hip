@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -33,7 +34,10 @@ bool g_timing = false;
 thread_local hipEvent_t g_ev[kTimingRing][kEventsPerCall];
 thread_local bool g_ev_made = false;
 thread_local long g_timed_calls = 0;   // completed timed calls since timing was (re)enabled
-thread_local int g_slot = 0;           // ring slot of the call in progress
+thread_local long g_begun_calls = 0;   // timed calls begun since then: several may be in flight (split calls), each owns a slot
+thread_local int g_inflight = 0;       // timed calls begun and not yet finished / cancelled
+thread_local bool g_stamp = false;     // whether the call being queued records events
+thread_local int g_slot = 0;           // ring slot of the call being queued
 
 int fail(gsr_status code, const char* fmt, ...) {
     va_list ap;
@@ -80,6 +84,38 @@ char* align_base(char* p) {
     return reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 255) & ~uintptr_t(255));
 }
 
+// What gsr_backward needs to know about the three arenas of a forward call is written into their headers on the
+// device; reading it back costs a copy and a stream drain per training iteration, which the reference's backward
+// does not have.  The same headers are therefore remembered on the host, keyed by the three aligned arena
+// addresses: a backward call that finds its buffers here (the normal case: same process, buffers untouched since)
+// never waits for the GPU.  Anything else -- buffers from another process, an entry pushed out of the small
+// table -- takes the validated device read.  An arena that is reused by a later forward call replaces its entry.
+struct HeaderRecord { const char* base[3]; gsr::ArenaHeader h[3]; };
+constexpr int kHeaderRecords = 64;
+std::mutex g_header_mutex;
+HeaderRecord g_header_records[kHeaderRecords];
+int g_header_next = 0;
+
+void remember_headers(const char* const base[3], const gsr::ArenaHeader h[3]) {
+    std::lock_guard<std::mutex> lock(g_header_mutex);
+    int at = -1;
+    for (int i = 0; i < kHeaderRecords; ++i)  // an arena that is written again invalidates what was known about it
+        for (int k = 0; k < 3; ++k)
+            if (g_header_records[i].base[k] == base[k]) { g_header_records[i].base[0] = g_header_records[i].base[1] = g_header_records[i].base[2] = nullptr; at = i; }
+    if (at < 0) { at = g_header_next; g_header_next = (g_header_next + 1) % kHeaderRecords; }
+    for (int k = 0; k < 3; ++k) { g_header_records[at].base[k] = base[k]; g_header_records[at].h[k] = h[k]; }
+}
+
+bool recall_headers(const char* const base[3], gsr::ArenaHeader h[3]) {
+    std::lock_guard<std::mutex> lock(g_header_mutex);
+    for (int i = 0; i < kHeaderRecords; ++i)
+        if (g_header_records[i].base[0] == base[0] && g_header_records[i].base[1] == base[1] && g_header_records[i].base[2] == base[2] && base[0]) {
+            for (int k = 0; k < 3; ++k) h[k] = g_header_records[i].h[k];
+            return true;
+        }
+    return false;
+}
+
 // Bits of tile id to sort on: position of the highest set bit of T, plus one
 // (rasterizer_impl.cu:35-50 getHigherMsb restated as a plain loop).
 int tile_key_bits(uint32_t num_tiles) {
@@ -91,7 +127,7 @@ int tile_key_bits(uint32_t num_tiles) {
 constexpr size_t kCounterBytes = gsr::kCounterCopyBytes;  // what travels back to the host
 
 void stamp(int idx, hipStream_t s) {
-    if (!g_timing) return;
+    if (!g_stamp) return;
     (void)hipEventRecord(g_ev[g_slot][idx], s);
 }
 
@@ -116,15 +152,18 @@ int gsr_get_option(int option) {
 void gsr_set_stage_timing(int enable) {
     g_timing = enable != 0;
     g_timed_calls = 0;
+    g_begun_calls = 0;
+    g_inflight = 0;
 }
 
 int gsr_get_stage_times(float ms[GSR_STAGE_NUM]) {
     for (int i = 0; i < GSR_STAGE_NUM; ++i) ms[i] = 0.f;
     if (g_timed_calls <= 0) return fail(GSR_ERR_INVALID_ARG, "no timed gsr_forward call on this thread");
+    if (g_inflight != 0) return fail(GSR_ERR_INVALID_ARG, "a split call is still in flight on this thread");
     const int ncalls = (int)(g_timed_calls < kTimingRing ? g_timed_calls : kTimingRing);
     double sum[GSR_STAGE_NUM] = {0};
     for (int c = 0; c < ncalls; ++c) {
-        const int slot = (int)((g_timed_calls - 1 - c) % kTimingRing);
+        const int slot = (int)((g_begun_calls - 1 - c) % kTimingRing);
         GSR_HIP(hipEventSynchronize(g_ev[slot][kEventsPerCall - 1]));
         for (int i = 0; i < GSR_STAGE_NUM; ++i) {
             float t = 0.f;
@@ -139,10 +178,11 @@ int gsr_get_stage_times(float ms[GSR_STAGE_NUM]) {
 int gsr_get_call_times(float* ms, int capacity) {
     if (!ms || capacity < 0) return fail(GSR_ERR_INVALID_ARG, "bad arguments");
     if (g_timed_calls <= 0) return 0;
+    if (g_inflight != 0) return fail(GSR_ERR_INVALID_ARG, "a split call is still in flight on this thread");
     int ncalls = (int)(g_timed_calls < kTimingRing ? g_timed_calls : kTimingRing);
     if (ncalls > capacity) ncalls = capacity;
     for (int c = 0; c < ncalls; ++c) {
-        const int slot = (int)((g_timed_calls - 1 - c) % kTimingRing);
+        const int slot = (int)((g_begun_calls - 1 - c) % kTimingRing);
         GSR_HIP(hipEventSynchronize(g_ev[slot][kEventsPerCall - 1]));
         GSR_HIP(hipEventElapsedTime(&ms[c], g_ev[slot][0], g_ev[slot][kEventsPerCall - 1]));
     }
@@ -204,8 +244,10 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     const char* bases[3] = {align_base(const_cast<char*>(geom_buffer)), align_base(const_cast<char*>(binning_buffer)),
                             align_base(const_cast<char*>(image_buffer))};
     gsr::ArenaHeader h[3];
-    for (int i = 0; i < 3; ++i) GSR_HIP(hipMemcpyAsync(&h[i], bases[i], sizeof h[i], hipMemcpyDeviceToHost, stream));
-    GSR_HIP(hipStreamSynchronize(stream));
+    if (debug || !recall_headers(bases, h)) {  // not a forward call this process remembers (or debug): read and validate
+        for (int i = 0; i < 3; ++i) GSR_HIP(hipMemcpyAsync(&h[i], bases[i], sizeof h[i], hipMemcpyDeviceToHost, stream));
+        GSR_HIP(hipStreamSynchronize(stream));
+    }
     for (int i = 0; i < 3; ++i)
         if (h[i].magic != gsr::kArenaMagic || h[i].kind != (uint32_t)i)
             return fail(GSR_ERR_INVALID_ARG, "scratch buffer %d was not produced by gsr_forward", i);
@@ -345,7 +387,7 @@ thread_local std::vector<PinnedSlot> g_pinned_free;
 struct ForwardCall {
     hipStream_t stream = nullptr;
     int debug = 0, prefiltered = 0, P = 0, T = 0, width = 0, height = 0, slot = 0;
-    bool own_sort = true, queued = false;
+    bool own_sort = true, queued = false, timed = false;
     gsr::Camera cam;
     gsr::GeometryArrays ga;
     gsr_alloc_fn binning_alloc = nullptr;
@@ -361,6 +403,7 @@ struct ForwardCall {
     PinnedSlot pinned;
 
     ~ForwardCall() {
+        if (timed && g_inflight > 0) --g_inflight;  // (a call cancelled while timing is on leaves a stale slot in the ring)
         if (!pinned.host) return;
         if (queued) (void)hipEventSynchronize(pinned.copied);  // the copy may still be landing in the buffer
         g_pinned_free.push_back(pinned);
@@ -415,7 +458,9 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
             for (auto& e : set) GSR_HIP(hipEventCreate(&e));
         g_ev_made = true;
     }
-    g_slot = fc.slot = (int)(g_timed_calls % kTimingRing);
+    g_slot = fc.slot = (int)(g_begun_calls % kTimingRing);  // one slot per call in flight (ring of 256: more than any driver keeps)
+    g_stamp = fc.timed = g_timing;
+    if (fc.timed) { ++g_begun_calls; ++g_inflight; }
     if (!g_pinned_free.empty()) {
         fc.pinned = g_pinned_free.back();
         g_pinned_free.pop_back();
@@ -523,6 +568,7 @@ int forward_finish(ForwardCall& fc) {
     const gsr::GeometryArrays& ga = fc.ga;
     char* const gbase = fc.gbase;
     g_slot = fc.slot;
+    g_stamp = fc.timed;
 
     GSR_HIP(hipEventSynchronize(fc.pinned.copied));
     fc.queued = false;
@@ -603,6 +649,8 @@ int forward_finish(ForwardCall& fc) {
         hi.off[1] = (uint64_t)((char*)n_contrib - fc.ibase);
         const gsr::ArenaHeader hs[3] = {hg, hb, hi};
         void* const dsts[3] = {gbase, bbase, fc.ibase};
+        const char* const bases[3] = {gbase, bbase, fc.ibase};
+        remember_headers(bases, hs);
         // tile ranges (all (0,0) when nothing is live: rasterizer_impl.cu:311) + the three headers, one launch
         GSR_HIP(gsr::launch_tile_ranges(num_live, T, tile_keys, ranges, dsts, hs, stream));
         GSR_STAGE_CHECK("tile_ranges");
@@ -615,7 +663,7 @@ int forward_finish(ForwardCall& fc) {
                               stream, fc.extra_features, fc.out_extra));
     GSR_STAGE_CHECK("blend");
     stamp(7, stream);
-    if (g_timing) ++g_timed_calls;
+    if (fc.timed) ++g_timed_calls;
 
     // what the gsr_last_* accessors report: the call that finished last on this thread
     for (int i = 0; i < GSR_GEOM_NUM_SLOTS; ++i) g_geom_off[i] = fc.geom_off[i] + fc.gshift;

@@ -85,30 +85,39 @@ class GaussianModel:
     def to(self, device) -> "GaussianModel":
         for k in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
             setattr(self, k, getattr(self, k).to(device))
+        self.__dict__.pop("_memo_cache", None)
         return self
 
     # ---- getters (gaussian_model.py:95-128) ----
     # The reference recomputes every activation on every frame (at C3 the SH concat alone copies 1.1 GB).
     # The results only depend on the parameters, so while autograd is off they are memoised on the
-    # parameters' identity + in-place version; any optimizer step or edit invalidates them.
+    # parameters' identity + in-place version; any optimizer step or edit invalidates them.  The entry keeps the
+    # parameter tensors it was computed from alive, so `is` cannot be fooled by a recycled id / address.
+    # Contract: a write that does not go through the tensor's version counter (`param.data.add_()`, a raw-pointer
+    # write from another extension) is invisible here -- call `invalidate_cache()` after such a write.
+    def invalidate_cache(self) -> None:
+        self.__dict__.pop("_memo_cache", None)
+
     def _memo(self, name, deps, fn):
         if torch.is_grad_enabled() and any(t.requires_grad for t in deps):
             return fn()
-        key = tuple((id(t), t._version, t.data_ptr(), tuple(t.shape)) for t in deps)
+        versions = tuple((t._version, t.data_ptr(), tuple(t.shape)) for t in deps)
         cache = self.__dict__.setdefault("_memo_cache", {})
         hit = cache.get(name)
-        if hit is None or hit[0] != key:
+        if hit is None or len(hit[0]) != len(deps) or any(a is not b for a, b in zip(hit[0], deps)) or hit[1] != versions:
             with torch.no_grad():
                 value = fn()
             ready = None
             if value.is_cuda:   # consumers on other HIP streams (multi-stream rendering) must wait for the producer
                 ready = torch.cuda.Event()
                 ready.record(torch.cuda.current_stream(value.device))
-            hit = (key, value, ready)
+            hit = (tuple(deps), versions, value, ready)
             cache[name] = hit
-        elif hit[2] is not None:
-            torch.cuda.current_stream(hit[1].device).wait_event(hit[2])
-        return hit[1]
+        elif hit[3] is not None:
+            cur = torch.cuda.current_stream(hit[2].device)
+            cur.wait_event(hit[3])
+            hit[2].record_stream(cur)   # the allocator must not recycle the block while this stream still reads it
+        return hit[2]
 
     @property
     def get_scaling(self):
@@ -184,6 +193,7 @@ class GaussianModel:
         self._features_dc = t(dc).transpose(1, 2).contiguous()
         self._features_rest = t(rest).transpose(1, 2).contiguous()
         self.active_sh_degree = self.max_sh_degree
+        self.invalidate_cache()
         return self
 
     # the six entries of a SuGaR checkpoint's ``state_dict`` that ``scene_representation.load_scene`` reads (:200-205)

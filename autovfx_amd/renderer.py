@@ -83,6 +83,40 @@ def get_ray_directions(H: int, W: int, fx: float, fy: float, cx: float, cy: floa
     return torch.stack(((u - cx + 0.5) / fx, (v - cy + 0.5) / fy, torch.ones_like(u)), -1)
 
 
+def sh_basis(deg: int, dirs: torch.Tensor) -> torch.Tensor:
+    """Real spherical-harmonics basis of bands 0..deg at unit directions ``dirs[N,3]`` -> ``[N,(deg+1)^2]``, with the
+    sign / ordering convention of the rasterizer's constants (``DGR/cuda_rasterizer/auxiliary.h:22-39``,
+    ``utils/sh_utils.py:24-55``).  Bands above 3 are not evaluated by the rasterizer and not offered here."""
+    if not 0 <= deg <= 3:
+        raise ValueError("sh_basis: degree must be 0..3")
+    x, y, z = dirs.unbind(-1)
+    cols = [torch.full_like(x, 0.28209479177387814)]
+    if deg > 0:
+        c1 = 0.4886025119029199
+        cols += [-c1 * y, c1 * z, -c1 * x]
+    if deg > 1:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        cols += [1.0925484305920792 * xy, -1.0925484305920792 * yz, 0.31539156525252005 * (2.0 * zz - xx - yy),
+                 -1.0925484305920792 * xz, 0.5462742152960396 * (xx - yy)]
+    if deg > 2:
+        cols += [-0.5900435899266435 * y * (3 * xx - yy), 2.890611442640554 * xy * z,
+                 -0.4570457994644658 * y * (4 * zz - xx - yy), 0.3731763325901154 * z * (2 * zz - 3 * xx - 3 * yy),
+                 -0.4570457994644658 * x * (4 * zz - xx - yy), 1.445305721320277 * z * (xx - yy),
+                 -0.5900435899266435 * x * (xx - 3 * yy)]
+    return torch.stack(cols, dim=-1)
+
+
+def sh_to_rgb_python(deg: int, features: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:
+    """What ``render()`` does with ``pipe.convert_SHs_python`` (``gaussian_renderer/__init__.py:141-146``):
+    ``clamp_min(eval_sh(deg, shs, dir) + 0.5, 0)`` with ``features[N,M,3]`` in the rasterizer's layout, evaluated as one
+    basis matrix times the coefficients (differentiable; sums in a different order than ``eval_sh``: last-ulp
+    differences).  ``deg`` above 3 evaluates bands 0..3, like the rasterizer."""
+    deg = min(int(deg), 3)
+    k = (deg + 1) ** 2
+    basis = sh_basis(deg, dirs)                                   # [N,k]
+    return torch.clamp_min((features[:, :k, :] * basis.unsqueeze(-1)).sum(dim=1) + 0.5, 0.0)
+
+
 class PendingRender:
     """A ``render`` call whose rasterizer call is half queued (``render_begin``); ``finish()`` queues the rest and
     returns the dict ``render`` returns."""
@@ -149,15 +183,16 @@ def _render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_col
     # first one (gsr_forward_extra); same formulas, same images (tests).
     fused = (not torch.is_grad_enabled()) and xyz.is_cuda and xyz.dtype == torch.float32 and hasattr(pc, "get_minimum_axis")
     dir_pp_normalized = None
-    if not fused:
+    if not fused or (override_color is None and pipe.convert_SHs_python):
         dir_pp = xyz - viewpoint_camera.camera_center.repeat(xyz.shape[0], 1)
         dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
 
     shs = colors_precomp = None
     if override_color is None:
-        if pipe.convert_SHs_python:
-            raise NotImplementedError("convert_SHs_python: the SH evaluation lives in the rasterizer")
-        shs = pc.get_features
+        if pipe.convert_SHs_python:   # :141-146: colours from the SH in PyTorch, handed over as colors_precomp
+            colors_precomp = sh_to_rgb_python(pc.active_sh_degree, pc.get_features, dir_pp_normalized)
+        else:
+            shs = pc.get_features
     else:
         colors_precomp = override_color
 

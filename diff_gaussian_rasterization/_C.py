@@ -80,14 +80,21 @@ def _require_gpu(t: torch.Tensor, what: str) -> torch.device:
     return t.device
 
 
-# ---- geometry reuse between consecutive calls -------------------------------------------------------------------
+# ---- geometry reuse between the two passes of render() -------------------------------------------------------------
 # gaussian_renderer.render() calls the rasterizer twice per frame with the very same tensor objects for the
 # geometry (means3D, opacity, scales, rotations / cov3D, camera) and only the colour source changed
 # (gaussian_renderer/__init__.py:151-159 then :176-184).  When a call arrives whose geometry inputs are the SAME
-# tensor objects at the SAME autograd version as the previous call on this thread and stream, and it brings
-# precomputed colours, everything up to the per-tile lists is reused and only the blend kernel runs.  The
-# previous call's inputs and scratch are kept alive by the cache, so object identity cannot be recycled.
-# Disable with GSR_GEOMETRY_CACHE=0.
+# tensor objects at the SAME autograd version as the call just before it on this thread and stream, and it brings
+# precomputed colours, everything up to the per-tile lists is reused and only the blend kernel runs.
+# Contract (also in INTEGRATION.md):
+#   * one follow-up per full call: the entry is dropped by the first hit (and by any miss), so a stale hit can only
+#     ever be the call immediately after the one that computed the geometry, and the previous call's scratch
+#     (~300 MB at 3 M Gaussians) is pinned no longer than that;
+#   * identity + version: the previous call's input tensors are kept alive by the entry, so an id / address cannot
+#     be recycled; any in-place operation PyTorch knows about bumps `_version` and misses;
+#   * what it cannot see: writes that bypass the version counter between the two calls (`t.data.add_()`, a raw
+#     pointer write from another extension, a DLPack alias).  Code that does that between two rasterizer calls on
+#     the same tensors must call set_geometry_cache(False) or run with GSR_GEOMETRY_CACHE=0.
 import os as _os
 
 _GEOMETRY_CACHE = _os.environ.get("GSR_GEOMETRY_CACHE", "1") != "0"
@@ -174,9 +181,11 @@ def _rasterize(background, means3D, colors, opacity, scales, rotations, scale_mo
                                               bool(prefiltered), _lib.get_option(_lib.OPT_TILE_CULL),
                                               torch.cuda.current_stream(device).cuda_stream))
         hit = getattr(_tls, "cache", None)
+        _tls.cache = None   # whatever happens next, the entry has had its one chance
         if hit is not None and hit["key"] == key and colors.numel() != 0 and sh.numel() == 0 and extra_colors is None:
             cache_stats["hits"] += 1
             return _blend_cached(hit, background, colors, device, H, W, out_color, out_depth, out_alpha)
+        del hit
         cache_stats["misses"] += 1
     if P != 0:
         M = int(sh.size(1)) if sh.numel() != 0 else 0
@@ -208,7 +217,7 @@ def _rasterize(background, means3D, colors, opacity, scales, rotations, scale_mo
         layout = {"geom": _lib.offsets("geom"), "binning": _lib.offsets("binning"), "image": _lib.offsets("image"),
                   "counts": _lib.pair_counts()}
         _tls.last_layout = layout
-        if key is not None:
+        if key is not None and extra_colors is None:   # (a fused two-feature call has no second pass to wait for)
             _tls.cache = {"key": key, "inputs": geometry_inputs, "layout": layout,
                           "rendered": rendered, "radii": radii, "geom": scratch.buffers["geom"],
                           "binning": scratch.buffers["binning"], "image": scratch.buffers["image"]}

@@ -629,6 +629,13 @@ def test_second_pass_reuses_geometry_bit_for_bit():
     assert _C.cache_stats["hits"] == h0 + 1, "second pass did not hit the geometry cache"
     for x, y in zip(ref_a + ref_b, got_a + got_b):
         assert torch.equal(x, y)
+    # one follow-up per full call: a third pass over the same geometry recomputes (the entry, and the ~scratch it
+    # pins, is dropped by the first hit), with the same result
+    with torch.no_grad():
+        third = GaussianRasterizer(st)(means3D=c.means3D, means2D=m2, opacities=c.opacities, colors_precomp=normals,
+                                       scales=c.scales, rotations=c.rotations)
+    assert _C.cache_stats["hits"] == h0 + 1 and torch.equal(third[0], ref_b[0])
+    assert getattr(_C._tls, "cache", None) is not None      # ... and is itself a full call that a next pass may follow
     # in-place edit bumps the tensor version: next colour pass must recompute (and differ)
     rast = GaussianRasterizer(st)
     with torch.no_grad():

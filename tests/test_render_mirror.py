@@ -107,6 +107,51 @@ def test_render_helpers_match_reference_python():
     assert torch.equal(got, want)
 
 
+@needs_reference
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_convert_shs_python_matches_reference_eval_sh(deg):
+    """render()'s convert_SHs_python branch (gaussian_renderer/__init__.py:141-146) against the reference's own
+    eval_sh on the same features and directions (different summation order: a few ulp)."""
+    ref = _import_reference("utils.sh_utils")
+    g = torch.Generator().manual_seed(20 + deg)
+    feats = torch.randn(500, 16, 3, generator=g)
+    dirs = torch.nn.functional.normalize(torch.randn(500, 3, generator=g), dim=1)
+    want = torch.clamp_min(ref.eval_sh(deg, feats.transpose(1, 2).reshape(-1, 3, 16), dirs) + 0.5, 0.0)
+    got = renderer.sh_to_rgb_python(deg, feats, dirs)
+    assert got.shape == (500, 3)
+    torch.testing.assert_close(got, want, rtol=0, atol=2e-6)
+    assert torch.equal(renderer.sh_to_rgb_python(4, feats, dirs), renderer.sh_to_rgb_python(3, feats, dirs))
+
+
+@pytest.mark.gpu
+def test_render_convert_shs_python_equals_the_in_rasterizer_sh():
+    """pipe.convert_SHs_python: the colours come from PyTorch and reach the rasterizer as colors_precomp; the frame must
+    equal the default path's (SH inside the rasterizer) to within the summation-order ulps, radii identical."""
+    from autovfx_amd.cameras import orbit_cameras
+    dev = "cuda:0"
+    cam = orbit_cameras(10, 320, 200)[6].to(dev)
+    m, _ = model(20_000, seed=6)
+    m.to(dev)
+    bg = torch.tensor([0.3, 0.1, 0.2], device=dev)
+
+    class Pipe(renderer.PipelineParams):
+        convert_SHs_python = True
+
+    with torch.no_grad():
+        a = renderer.render(cam, m, renderer.PipelineParams, bg)
+        b = renderer.render(cam, m, Pipe, bg)
+    torch.cuda.synchronize()
+    assert torch.equal(a["radii"], b["radii"])
+    assert float((a["render"] - b["render"]).abs().max()) < 1e-5
+    assert float((a["depth"] - b["depth"]).abs().max()) == 0.0
+    # and with autograd on the colours carry the gradient back to the SH coefficients
+    m._features_dc.requires_grad_(True)
+    out = renderer.render(cam, m, Pipe, bg)
+    out["render"][:3].sum().backward()
+    assert m._features_dc.grad is not None and float(m._features_dc.grad.abs().sum()) > 0
+    m._features_dc.requires_grad_(False)
+
+
 @pytest.mark.gpu
 def test_render_end_to_end_against_oracle():
     """render(): RGBA, depth, normal, pseudo-normal, radii -- against the same function with both rasterizer
