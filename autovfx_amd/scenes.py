@@ -76,6 +76,29 @@ def config_c3(P: int = 3_000_000, seed: int = 2) -> GaussianCloud:
     return _cloud(P, seed, "normal", math.log(0.005), 0.6)
 
 
+def config_heavy(P: int = 1_000_000, seed: int = 5, log_scale_mu: float = math.log(0.0045), log_scale_sigma: float = 1.2,
+                 max_anisotropy: float = 10.0) -> GaussianCloud:
+    """A trained-scene-like stress cloud (not a BASELINE config): what optimised scenes look like and the C2 / C3
+    stand-ins do not -- heavy-tailed sizes (log-normal, sigma 1.2: a few splats cover a third of the screen), needle /
+    disc anisotropy up to 10:1 (log-uniform stretch of one axis, the third axis squeezed), bimodal opacity (60 % near
+    opaque, 40 % faint).  At 960x540 that is ~20 (tile, Gaussian) pairs of the reference per Gaussian and per-tile lists
+    in the thousands, most of them from splats whose bounding square covers hundreds of tiles."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    xyz = torch.randn(P, 3, generator=g).clamp_(-3.0, 3.0)
+    base = torch.randn(P, 1, generator=g) * log_scale_sigma + log_scale_mu
+    stretch = torch.rand(P, 1, generator=g) * math.log(max_anisotropy)
+    scales = torch.exp(torch.cat((base + stretch, base, base - 0.5 * stretch), dim=1))
+    q = torch.randn(P, 4, generator=g)
+    q = q / q.norm(dim=1, keepdim=True)
+    solid = torch.rand(P, 1, generator=g) < 0.6
+    opac = torch.where(solid, torch.sigmoid(torch.randn(P, 1, generator=g) * 0.7 + 3.0),
+                       torch.sigmoid(torch.randn(P, 1, generator=g) * 0.7 - 3.0))
+    dc = torch.randn(P, 1, 3, generator=g)
+    rest = torch.randn(P, 15, 3, generator=g) * 0.2
+    return GaussianCloud(xyz.contiguous(), opac.contiguous(), scales.contiguous(), q.contiguous(),
+                         torch.cat((dc, rest), dim=1).contiguous(), None, 3)
+
+
 def config_c4(P: int = 200_000, seed: int = 3, extent: float = 3.0) -> GaussianCloud:
     """C4: SuGaR-style flat, surface-bound Gaussians with precomputed colours.
 
