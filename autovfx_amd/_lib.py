@@ -18,19 +18,21 @@ ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 GEOM_SLOTS = ("raster", "rgb", "splat_bins", "internal_radii", "depth_order", "point_offsets")
 BIN_SLOTS = ("point_list", "tile_keys")
 IMG_SLOTS = ("ranges", "n_contrib")
-STAGES = ("preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "ranges", "blend")
-ABI_VERSION = 4
+STAGES = ("preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "ranges", "blend", "colour")
+ABI_VERSION = 5
+MAX_SLABS = 8
+FORWARD_INFERENCE = 1
 
 # every symbol include/gsr.h declares
 SYMBOLS = ("gsr_forward", "gsr_mark_visible", "gsr_backward", "gsr_last_geom_offsets", "gsr_last_binning_offsets",
            "gsr_last_image_offsets", "gsr_set_stage_timing", "gsr_get_stage_times", "gsr_last_error",
            "gsr_abi_version", "gsr_target_arch", "gsr_set_option", "gsr_get_option", "gsr_pack_rgba8", "gsr_last_pair_counts", "gsr_blend", "gsr_composite",
            "gsr_radix_scratch_bytes", "gsr_radix_sort_pairs", "gsr_selftest_exp", "gsr_view_normals", "gsr_normal_maps", "gsr_forward_extra", "gsr_get_call_times",
-           "gsr_forward_begin", "gsr_forward_finish", "gsr_forward_cancel")
+           "gsr_forward_begin", "gsr_forward_finish", "gsr_forward_cancel", "gsr_last_slab_pairs")
 OPT_TILE_CULL = 0
-OPT_BLEND_VARIANT = 1
-OPT_BLEND_LDS_PAD = 2
-OPT_SORT_IMPL = 3
+OPT_SLABS = 1
+OPT_SLAB_FIRST = 2
+OPT_DEFER_COLOUR = 3
 
 
 class GsrLibraryError(ImportError):
@@ -60,7 +62,7 @@ def _load() -> ctypes.CDLL:
         c_f, c_f, c_f, ctypes.c_float, ctypes.c_float, ctypes.c_int,  # view proj campos tanx tany prefiltered
         c_f, c_f, c_f, c_f, ctypes.c_int, ctypes.c_void_p]   # out_color out_depth out_alpha radii debug stream
     lib.gsr_forward_extra.restype = ctypes.c_int
-    lib.gsr_forward_extra.argtypes = lib.gsr_forward.argtypes[:-2] + [c_f, c_f, ctypes.c_int, ctypes.c_void_p]
+    lib.gsr_forward_extra.argtypes = lib.gsr_forward.argtypes[:-2] + [c_f, c_f, ctypes.c_uint, ctypes.c_int, ctypes.c_void_p]
     lib.gsr_forward_begin.restype = ctypes.c_void_p
     lib.gsr_forward_begin.argtypes = lib.gsr_forward_extra.argtypes
     lib.gsr_forward_finish.restype = ctypes.c_int
@@ -72,7 +74,9 @@ def _load() -> ctypes.CDLL:
     lib.gsr_composite.restype = ctypes.c_int
     lib.gsr_composite.argtypes = [ctypes.c_int, ctypes.c_int] + [c_f] * 12 + [ctypes.c_void_p]
     lib.gsr_blend.restype = ctypes.c_int
-    lib.gsr_blend.argtypes = [ctypes.c_int, ctypes.c_int] + [c_f] * 9 + [ctypes.c_void_p]
+    lib.gsr_blend.argtypes = [c_f, c_f, c_f, ctypes.c_int, ctypes.c_int] + [c_f] * 5 + [ctypes.c_void_p]
+    lib.gsr_last_slab_pairs.restype = ctypes.c_int
+    lib.gsr_last_slab_pairs.argtypes = [ctypes.POINTER(ctypes.c_uint32 * MAX_SLABS)]
     lib.gsr_last_pair_counts.restype = ctypes.c_int
     lib.gsr_last_pair_counts.argtypes = [ctypes.POINTER(ctypes.c_uint32 * 2)]
     lib.gsr_radix_scratch_bytes.restype = ctypes.c_size_t
@@ -144,6 +148,15 @@ def pair_counts() -> dict:
     if lib.gsr_last_pair_counts(ctypes.byref(arr)) != 0:
         raise RuntimeError(last_error())
     return {"num_rendered": int(arr[0]), "live_pairs": int(arr[1])}
+
+
+def slab_pairs() -> list:
+    """Pairs in the list of each depth slab of this thread's last forward call (waits for that call's stream)."""
+    arr = (ctypes.c_uint32 * MAX_SLABS)()
+    n = lib.gsr_last_slab_pairs(ctypes.byref(arr))
+    if n < 0:
+        raise RuntimeError(last_error())
+    return [int(arr[i]) for i in range(n)]
 
 
 def set_option(option: int, value: int) -> None:

@@ -3,8 +3,8 @@
 // Mirrors what CudaRasterizer::Rasterizer::forward does on the host
 // (DGR/cuda_rasterizer/rasterizer_impl.cu:197-339): carve scratch out of caller-provided arenas
 // (rasterizer_impl.h:22-27,66-72), run the stages, read num_rendered back once to size the binning
-// arena (:282), return it.  The stage list itself is this library's own (gsr_kernels.hip, gsr_radix.hip;
-// gsr_sort.hip holds the rocPRIM passes kept as the GSR_OPT_SORT_IMPL = 0 comparison path).
+// arena (:282), return it.  The stage list itself is this library's own (gsr_kernels.hip, gsr_binning.hip,
+// gsr_radix.hip, gsr_blend.hip).
 #include "../../include/gsr.h"
 #include "gsr_internal.h"
 
@@ -22,16 +22,32 @@ thread_local size_t g_geom_off[GSR_GEOM_NUM_SLOTS];
 thread_local size_t g_bin_off[GSR_BIN_NUM_SLOTS];
 thread_local size_t g_img_off[GSR_IMG_NUM_SLOTS];
 thread_local bool g_have_offsets = false;
-thread_local uint32_t g_counts[2] = {0, 0};  // last call: {num_rendered (reference), live pairs}
+// The pair counts of a call past the first host read live on the device (one SlabInfo per depth slab); the call
+// queues a copy of that table into pinned memory at its end, and the accessors below wait for it only when asked.
+struct PinnedSlot {
+    uint32_t* host = nullptr;     // a few KB of pinned memory, pooled per calling thread and deliberately never
+    hipEvent_t copied = nullptr;  // freed: freeing at thread exit can race HIP runtime teardown
+    hipEvent_t finished = nullptr;
+};
+thread_local std::vector<PinnedSlot> g_pinned_free;
+thread_local PinnedSlot g_last_slot;           // holds the slab table of the call that finished last on this thread
+thread_local uint32_t g_last_num_rendered = 0; // ... its reference pair count
+thread_local int g_last_slabs = 0;             // ... and how many slabs it used (0: nothing to wait for)
+constexpr size_t kCounterBytes = gsr::kCounterCopyBytes;          // what travels back to the host in the middle of a call
+constexpr size_t kSlabTableAt = (kCounterBytes + 63) & ~size_t(63);  // byte offset of the slab table in a pinned slot
+constexpr size_t kPinnedBytes = kSlabTableAt + sizeof(gsr::SlabInfo) * gsr::kMaxSlabs;
 
 // Stage timing: a ring of event sets so a whole timed region can be averaged afterwards without
-// synchronising between calls.
+// synchronising between calls.  Events of one call: start, after projection, after the depth sort, after the host
+// has the pair count; then per depth slab: after binning, tile sort, ranges, colours, blend.
 constexpr int kTimingRing = 256;
-constexpr int kEventsPerCall = GSR_STAGE_NUM + 1;
-int g_options[GSR_OPT_NUM] = {/*GSR_OPT_TILE_CULL*/ 1, /*GSR_OPT_BLEND_VARIANT*/ 1, /*GSR_OPT_BLEND_LDS_PAD*/ 0,
-                              /*GSR_OPT_SORT_IMPL*/ 1};
+constexpr int kHeadEvents = 4, kSlabEvents = 5;
+constexpr int kEventsPerCall = kHeadEvents + kSlabEvents * gsr::kMaxSlabs;
+int g_options[GSR_OPT_NUM] = {/*GSR_OPT_TILE_CULL*/ 1, /*GSR_OPT_SLABS*/ 0, /*GSR_OPT_SLAB_FIRST*/ 400,
+                              /*GSR_OPT_DEFER_COLOUR*/ 1};
 bool g_timing = false;
 thread_local hipEvent_t g_ev[kTimingRing][kEventsPerCall];
+thread_local int g_ev_slabs[kTimingRing];  // depth slabs of the call recorded in each slot
 thread_local bool g_ev_made = false;
 thread_local long g_timed_calls = 0;   // completed timed calls since timing was (re)enabled
 thread_local long g_begun_calls = 0;   // timed calls begun since then: several may be in flight (split calls), each owns a slot
@@ -124,7 +140,6 @@ int tile_key_bits(uint32_t num_tiles) {
     return b;  // bit_length(T) >= bit_length(T - 1): every tile id fits
 }
 
-constexpr size_t kCounterBytes = gsr::kCounterCopyBytes;  // what travels back to the host
 
 void stamp(int idx, hipStream_t s) {
     if (!g_stamp) return;
@@ -162,13 +177,22 @@ int gsr_get_stage_times(float ms[GSR_STAGE_NUM]) {
     if (g_inflight != 0) return fail(GSR_ERR_INVALID_ARG, "a split call is still in flight on this thread");
     const int ncalls = (int)(g_timed_calls < kTimingRing ? g_timed_calls : kTimingRing);
     double sum[GSR_STAGE_NUM] = {0};
+    // per-slab intervals -> stage: binning (gather / scan / recount / expansion), tile sort, ranges, colours, blend
+    static const int slab_stage[kSlabEvents] = {GSR_STAGE_DUPLICATE, GSR_STAGE_TILE_SORT, GSR_STAGE_RANGES, GSR_STAGE_COLOUR,
+                                                GSR_STAGE_BLEND};
     for (int c = 0; c < ncalls; ++c) {
         const int slot = (int)((g_begun_calls - 1 - c) % kTimingRing);
-        GSR_HIP(hipEventSynchronize(g_ev[slot][kEventsPerCall - 1]));
-        for (int i = 0; i < GSR_STAGE_NUM; ++i) {
+        const int last = kHeadEvents - 1 + kSlabEvents * g_ev_slabs[slot];
+        GSR_HIP(hipEventSynchronize(g_ev[slot][last]));
+        for (int i = 0; i + 1 < kHeadEvents; ++i) {  // preprocess, depth sort, scan (= the host's wait for the pair count)
             float t = 0.f;
             GSR_HIP(hipEventElapsedTime(&t, g_ev[slot][i], g_ev[slot][i + 1]));
             sum[i] += t;
+        }
+        for (int e = kHeadEvents; e <= last; ++e) {
+            float t = 0.f;
+            GSR_HIP(hipEventElapsedTime(&t, g_ev[slot][e - 1], g_ev[slot][e]));
+            sum[slab_stage[(e - kHeadEvents) % kSlabEvents]] += t;
         }
     }
     for (int i = 0; i < GSR_STAGE_NUM; ++i) ms[i] = (float)(sum[i] / ncalls);
@@ -183,8 +207,9 @@ int gsr_get_call_times(float* ms, int capacity) {
     if (ncalls > capacity) ncalls = capacity;
     for (int c = 0; c < ncalls; ++c) {
         const int slot = (int)((g_begun_calls - 1 - c) % kTimingRing);
-        GSR_HIP(hipEventSynchronize(g_ev[slot][kEventsPerCall - 1]));
-        GSR_HIP(hipEventElapsedTime(&ms[c], g_ev[slot][0], g_ev[slot][kEventsPerCall - 1]));
+        const int last = kHeadEvents - 1 + kSlabEvents * g_ev_slabs[slot];
+        GSR_HIP(hipEventSynchronize(g_ev[slot][last]));
+        GSR_HIP(hipEventElapsedTime(&ms[c], g_ev[slot][0], g_ev[slot][last]));
     }
     return ncalls;
 }
@@ -199,10 +224,22 @@ int gsr_last_binning_offsets(size_t o[GSR_BIN_NUM_SLOTS]) {
     memcpy(o, g_bin_off, sizeof g_bin_off);
     return GSR_OK;
 }
-int gsr_last_pair_counts(uint32_t counts[2]) {
+int gsr_last_slab_pairs(uint32_t pairs[GSR_MAX_SLABS]) {
     if (!g_have_offsets) return fail(GSR_ERR_INVALID_ARG, "no gsr_forward call on this thread");
-    counts[0] = g_counts[0];
-    counts[1] = g_counts[1];
+    for (int i = 0; i < GSR_MAX_SLABS; ++i) pairs[i] = 0u;
+    if (g_last_slabs == 0) return 0;
+    GSR_HIP(hipEventSynchronize(g_last_slot.finished));  // the call's last copy has landed
+    const gsr::SlabInfo* t = reinterpret_cast<const gsr::SlabInfo*>(reinterpret_cast<const char*>(g_last_slot.host) + kSlabTableAt);
+    for (int i = 0; i < g_last_slabs; ++i) pairs[i] = t[i].pairs;
+    return g_last_slabs;
+}
+int gsr_last_pair_counts(uint32_t counts[2]) {
+    uint32_t pairs[GSR_MAX_SLABS];
+    const int n = gsr_last_slab_pairs(pairs);
+    if (n < 0) return n;
+    counts[0] = g_last_num_rendered;
+    counts[1] = 0u;
+    for (int i = 0; i < n; ++i) counts[1] += pairs[i];
     return GSR_OK;
 }
 int gsr_last_image_offsets(size_t o[GSR_IMG_NUM_SLOTS]) {
@@ -251,6 +288,10 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     for (int i = 0; i < 3; ++i)
         if (h[i].magic != gsr::kArenaMagic || h[i].kind != (uint32_t)i)
             return fail(GSR_ERR_INVALID_ARG, "scratch buffer %d was not produced by gsr_forward", i);
+    if (h[0].count[2] != 1u || h[0].count[3] != 0u)
+        return fail(GSR_ERR_INVALID_ARG, "the forward call was an inference call (GSR_FORWARD_INFERENCE): its lists are cut into "
+                                         "%u depth slabs without the tiles finished early; run the forward without that flag "
+                                         "to differentiate it", h[0].count[2]);
     if (h[0].count[0] != (uint32_t)P || h[0].count[1] != (uint32_t)R || h[2].count[0] != (uint32_t)width ||
         h[2].count[1] != (uint32_t)height)
         return fail(GSR_ERR_INVALID_ARG, "scratch buffers belong to a different call (P %u/%d, R %u/%d, %ux%u/%dx%d)",
@@ -268,8 +309,8 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     const gsr::SplatRaster* raster = (const gsr::SplatRaster*)(bases[0] + h[0].off[0]);
     const float* rgb = (const float*)(bases[0] + h[0].off[3]);
     if (radii == nullptr) radii = (const int*)(bases[0] + h[0].off[4]);
-    const uint32_t* point_list = (const uint32_t*)(bases[1] + h[1].off[0]);
-    const uint2* ranges = (const uint2*)(bases[2] + h[2].off[0]);
+    const uint32_t* point_list = (const uint32_t*)(bases[1] + h[1].slab_off[0]);
+    const uint2* ranges = (const uint2*)(bases[2] + h[2].slab_off[0]);
     const uint32_t* n_contrib = (const uint32_t*)(bases[2] + h[2].off[1]);
     const float* colors = colors_precomp != nullptr ? colors_precomp : rgb;  // rasterizer_impl.cu:399
 
@@ -288,20 +329,41 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     return GSR_OK;
 }
 
-int gsr_blend(int width, int height, const uint32_t* ranges, const uint32_t* point_list, const float* raster,
-              const float* features, const float* background,
-              float* out_color, float* out_depth, float* out_alpha, uint32_t* n_contrib, void* stream_) {
+int gsr_blend(const char* geom_buffer, const char* binning_buffer, const char* image_buffer, int width, int height,
+              const float* features, const float* background, float* out_color, float* out_depth, float* out_alpha,
+              void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
     if (width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARG, "bad image size %dx%d", width, height);
-    if (!ranges || !point_list || !raster || !features || !background || !out_color ||
-        !out_depth || !out_alpha)
+    if (!geom_buffer || !binning_buffer || !image_buffer || !features || !background || !out_color || !out_depth || !out_alpha)
         return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    const char* bases[3] = {align_base(const_cast<char*>(geom_buffer)), align_base(const_cast<char*>(binning_buffer)),
+                            align_base(const_cast<char*>(image_buffer))};
+    gsr::ArenaHeader h[3];
+    if (!recall_headers(bases, h)) {
+        for (int i = 0; i < 3; ++i) GSR_HIP(hipMemcpyAsync(&h[i], bases[i], sizeof h[i], hipMemcpyDeviceToHost, stream));
+        GSR_HIP(hipStreamSynchronize(stream));
+    }
+    for (int i = 0; i < 3; ++i)
+        if (h[i].magic != gsr::kArenaMagic || h[i].kind != (uint32_t)i)
+            return fail(GSR_ERR_INVALID_ARG, "scratch buffer %d was not produced by gsr_forward", i);
+    if (h[2].count[0] != (uint32_t)width || h[2].count[1] != (uint32_t)height)
+        return fail(GSR_ERR_INVALID_ARG, "scratch buffers belong to a %ux%u frame, not %dx%d", h[2].count[0], h[2].count[1], width, height);
+    const int slabs = (int)h[0].count[2];
+    if (slabs < 1 || slabs > gsr::kMaxSlabs) return fail(GSR_ERR_INVALID_ARG, "bad slab count %d in the geometry header", slabs);
     gsr::Camera cam = {};
     cam.width = width; cam.height = height;
     cam.grid_x = (width + gsr::kTile - 1) / gsr::kTile;
     cam.grid_y = (height + gsr::kTile - 1) / gsr::kTile;
-    GSR_HIP(gsr::launch_blend(cam, g_options[GSR_OPT_BLEND_VARIANT], g_options[GSR_OPT_BLEND_LDS_PAD], (const uint2*)ranges, point_list,
-                              (const gsr::SplatRaster*)raster, features, background,
-                              out_color, out_depth, out_alpha, n_contrib, (hipStream_t)stream_));
+    gsr::BlendSegments segs = {};
+    for (int k = 0; k < slabs; ++k) {
+        segs.ranges[k] = (const uint2*)(bases[2] + h[2].slab_off[k]);
+        segs.point_list[k] = (const uint32_t*)(bases[1] + h[1].slab_off[k]);
+    }
+    // one launch over every segment of the tile's list; the per-pixel last-contributor positions are only rewritten
+    // for a single-slab call (they are the same values: same lists, same geometry)
+    uint32_t* n_contrib = slabs == 1 ? (uint32_t*)(bases[2] + h[2].off[1]) : nullptr;
+    GSR_HIP(gsr::launch_blend(cam, segs, 0, slabs, /*fresh=*/true, /*final=*/true, (const gsr::SplatRaster*)(bases[0] + h[0].off[0]),
+                              features, background, out_color, out_depth, out_alpha, n_contrib, nullptr, nullptr, 0, stream));
     return GSR_OK;
 }
 
@@ -378,17 +440,12 @@ namespace {
 // forward_finish waits for that copy, sizes the binning arena and queues the rest.  gsr_forward runs the
 // two back to back; gsr_forward_begin / gsr_forward_finish expose the split so that one host thread can
 // keep several frames in flight on several streams without blocking on the newest one.
-struct PinnedSlot {
-    uint32_t* host = nullptr;    // a few KB of pinned memory, pooled per calling thread and deliberately never
-    hipEvent_t copied = nullptr; // freed: freeing at thread exit can race HIP runtime teardown
-};
-thread_local std::vector<PinnedSlot> g_pinned_free;
-
 struct ForwardCall {
     hipStream_t stream = nullptr;
     int debug = 0, prefiltered = 0, P = 0, T = 0, width = 0, height = 0, slot = 0;
-    bool own_sort = true, queued = false, timed = false;
+    bool queued = false, timed = false, inference = false, defer_colour = false;
     gsr::Camera cam;
+    gsr::GaussianInputs in;
     gsr::GeometryArrays ga;
     gsr_alloc_fn binning_alloc = nullptr;
     void* binning_user = nullptr;
@@ -396,7 +453,9 @@ struct ForwardCall {
     size_t gshift = 0;
     size_t geom_off[GSR_GEOM_NUM_SLOTS] = {};
     size_t img_off[GSR_IMG_NUM_SLOTS] = {};
-    uint32_t *order = nullptr, *point_offsets = nullptr, *tile_totals = nullptr;
+    size_t off_slabs = 0, off_quad = 0, off_rows = 0, off_radix_tmp = 0;
+    int row_words = 0;
+    uint32_t *order = nullptr, *point_offsets = nullptr, *slab_offsets = nullptr, *tile_totals = nullptr, *slab_tile_totals = nullptr;
     uint4* sorted_bins = nullptr;
     const float *colors_precomp = nullptr, *background = nullptr, *extra_features = nullptr;
     float *out_color = nullptr, *out_depth = nullptr, *out_alpha = nullptr, *out_extra = nullptr;
@@ -410,6 +469,41 @@ struct ForwardCall {
     }
 };
 
+// Depth slabs of an inference call.  Slab s takes the splats whose inclusive pair offset (over the depth order) lies in
+// (cut[s-1], cut[s]]: the first slab holds ~`first` pairs per tile -- enough to finish most tiles of a scene with an
+// opaque front -- and every further one three times as many as the one before.  bound[s] is what the launches and the
+// arrays of slab s are sized for.
+struct SlabPlan {
+    int slabs = 1;
+    uint32_t cut[gsr::kMaxSlabs] = {};    // slabs - 1 entries
+    uint32_t bound[gsr::kMaxSlabs] = {};
+};
+
+SlabPlan plan_slabs(bool inference, uint32_t live_bound, int T, int done_words) {
+    SlabPlan p;
+    p.bound[0] = live_bound;
+    const int max_slabs = g_options[GSR_OPT_SLABS] > 0 ? g_options[GSR_OPT_SLABS] : gsr::kMaxSlabs;
+    const unsigned long long first = (unsigned long long)(g_options[GSR_OPT_SLAB_FIRST] > 0 ? g_options[GSR_OPT_SLAB_FIRST] : 400) *
+                                     (unsigned long long)T;
+    if (!inference || max_slabs < 2 || done_words > 4096 || (unsigned long long)live_bound < 2ull * first) return p;
+    unsigned long long at = first, size = first;
+    int n = 0;
+    while (n < max_slabs - 1 && n < gsr::kMaxSlabs - 1 && at < (unsigned long long)live_bound) {
+        p.cut[n++] = (uint32_t)at;
+        size *= 3ull;
+        at += size;
+    }
+    p.slabs = n + 1;
+    for (int k = 0; k < p.slabs; ++k) {
+        const unsigned long long lo = k == 0 ? 0ull : p.cut[k - 1];
+        const unsigned long long hi = k == p.slabs - 1 ? (unsigned long long)live_bound : p.cut[k];
+        unsigned long long b = hi - lo + (k == 0 ? 0ull : (unsigned long long)T);  // a splat at the cut brings at most T pairs along
+        if (b > live_bound) b = live_bound;
+        p.bound[k] = (uint32_t)b;
+    }
+    return p;
+}
+
 int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_alloc,
                   void* binning_user, gsr_alloc_fn image_alloc, void* image_user, int P, int D, int M,
                   const float* background, int width, int height, const float* means3D, const float* shs,
@@ -417,7 +511,7 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
                   const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                   const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
                   float* out_depth, float* out_alpha, int* radii, int debug, void* stream_,
-                  const float* extra_features, float* out_extra) {
+                  const float* extra_features, float* out_extra, unsigned flags) {
     hipStream_t stream = (hipStream_t)stream_;
     if (P < 0 || width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARG, "bad sizes P=%d W=%d H=%d", P, width, height);
     fc.P = P;
@@ -432,6 +526,7 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     if ((scales != nullptr) != (rotations != nullptr) || have_sr == (cov3D_precomp != nullptr))
         return fail(GSR_ERR_INVALID_ARG, "provide exactly one of (scales, rotations) / cov3D_precomp");
     if (shs != nullptr && M <= 0) return fail(GSR_ERR_INVALID_ARG, "shs given with M=%d", M);
+    if ((flags & ~(unsigned)GSR_FORWARD_INFERENCE) != 0u) return fail(GSR_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
 
     gsr::Camera& cam = fc.cam;
     cam.viewmatrix = viewmatrix;
@@ -452,6 +547,9 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     fc.binning_alloc = binning_alloc; fc.binning_user = binning_user;
     fc.colors_precomp = colors_precomp; fc.background = background; fc.extra_features = extra_features;
     fc.out_color = out_color; fc.out_depth = out_depth; fc.out_alpha = out_alpha; fc.out_extra = out_extra;
+    fc.inference = (flags & GSR_FORWARD_INFERENCE) != 0u;
+    // SH colours only for the splats that reach a list: needs the lists first, i.e. an inference call
+    fc.defer_colour = fc.inference && shs != nullptr && g_options[GSR_OPT_DEFER_COLOUR] != 0;
 
     if (g_timing && !g_ev_made) {
         for (auto& set : g_ev)
@@ -460,25 +558,22 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     }
     g_slot = fc.slot = (int)(g_begun_calls % kTimingRing);  // one slot per call in flight (ring of 256: more than any driver keeps)
     g_stamp = fc.timed = g_timing;
-    if (fc.timed) { ++g_begun_calls; ++g_inflight; }
+    if (fc.timed) { ++g_begun_calls; ++g_inflight; g_ev_slabs[fc.slot] = 0; }
     if (!g_pinned_free.empty()) {
         fc.pinned = g_pinned_free.back();
         g_pinned_free.pop_back();
     } else {
-        GSR_HIP(hipHostMalloc((void**)&fc.pinned.host, kCounterBytes + 64, hipHostMallocPortable));
+        GSR_HIP(hipHostMalloc((void**)&fc.pinned.host, kPinnedBytes, hipHostMallocPortable));
         GSR_HIP(hipEventCreateWithFlags(&fc.pinned.copied, hipEventDisableTiming));
+        GSR_HIP(hipEventCreateWithFlags(&fc.pinned.finished, hipEventDisableTiming));
     }
 
     // ---- geometry arena ----
-    const bool own_sort = fc.own_sort = g_options[GSR_OPT_SORT_IMPL] != 0;
-    size_t sort_tmp = 0, scan_tmp = 0;
     const size_t dup_blocks = (n + gsr::kDupTile - 1) / gsr::kDupTile;
-    if (own_sort) {
-        sort_tmp = gsr::radix_scratch_words((uint32_t)P) * sizeof(uint32_t);
-    } else {
-        GSR_HIP(gsr::depth_sort_temp_bytes(P, &sort_tmp));
-        GSR_HIP(gsr::scan_temp_bytes(P, &scan_tmp));
-    }
+    const size_t sort_tmp = gsr::radix_scratch_words((uint32_t)P) * sizeof(uint32_t);
+    const size_t quad_words = ((size_t)4 * T + 31) / 32;
+    fc.row_words = (cam.grid_x + 31) / 32;
+    const size_t rows_words = (size_t)cam.grid_y * fc.row_words;
     size_t* geom_off = fc.geom_off;
     Carver gc;
     gc.take<gsr::ArenaHeader>(1);  // header at the arena's aligned base
@@ -489,10 +584,18 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     const size_t off_keys_a = gc.take<uint32_t>(n), off_keys_b = gc.take<uint32_t>(n);
     const size_t off_ids_a = gc.take<uint32_t>(n), off_ids_b = gc.take<uint32_t>(n);
     geom_off[GSR_GEOM_POINT_OFFSETS] = gc.take<uint32_t>(n);
+    const size_t off_slab_offsets = gc.take<uint32_t>(fc.inference ? n : 0);
+    // the words of a call that must be zero before its first kernel, cleared by ONE memset: frame counters, the table of
+    // depth slabs, one bit per finished 8x8 quadrant, one bit per finished tile (a row of bits per tile row)
     const size_t off_flag = gc.take<gsr::FrameCounters>(1);
+    fc.off_slabs = gc.take<gsr::SlabInfo>(gsr::kMaxSlabs);
+    fc.off_quad = gc.take<uint32_t>(quad_words);
+    fc.off_rows = gc.take<uint32_t>(rows_words);
+    const size_t zero_end = gc.off;
     const size_t off_tile_totals = gc.take<uint32_t>(2 * dup_blocks);  // tile totals, then global offsets at tile ends
-    const size_t off_sorted_bins = gc.take<uint4>(own_sort ? n : 0);  // splat records again, in depth order
-    const size_t off_tmp = gc.take<char>(sort_tmp > scan_tmp ? sort_tmp : scan_tmp);
+    const size_t off_slab_totals = gc.take<uint32_t>(fc.inference ? 2 * dup_blocks : 0);
+    const size_t off_sorted_bins = gc.take<uint4>(n);  // splat records again, in depth order
+    fc.off_radix_tmp = gc.take<char>(sort_tmp);
     char* graw = geom_alloc(gc.total(), geom_user);
     if (!graw) return fail(GSR_ERR_ALLOC, "geometry scratch callback returned NULL for %zu bytes", gc.total());
     char* gbase = fc.gbase = align_base(graw);
@@ -501,19 +604,20 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     // ---- image arena ----
     Carver ic;
     ic.take<gsr::ArenaHeader>(1);
-    fc.img_off[GSR_IMG_RANGES] = ic.take<uint2>((size_t)T);
+    fc.img_off[GSR_IMG_RANGES] = ic.take<uint2>((size_t)T * (fc.inference ? gsr::kMaxSlabs : 1));  // one table per depth slab
     fc.img_off[GSR_IMG_N_CONTRIB] = ic.take<uint32_t>((size_t)width * height);
     fc.iraw = image_alloc(ic.total(), image_user);
     if (!fc.iraw) return fail(GSR_ERR_ALLOC, "image scratch callback returned NULL for %zu bytes", ic.total());
     fc.ibase = align_base(fc.iraw);
     for (auto& o : fc.img_off) o += (size_t)(fc.ibase - fc.iraw);
 
-    gsr::GaussianInputs in;
+    gsr::GaussianInputs& in = fc.in;
     in.P = P; in.sh_degree = D; in.M = M;
     in.means3D = means3D; in.scales = scales; in.rotations = rotations; in.cov3D_precomp = cov3D_precomp;
     in.opacities = opacities; in.shs = shs; in.colors_precomp = colors_precomp;
     in.scale_modifier = scale_modifier; in.prefiltered = prefiltered;
     in.tile_cull = g_options[GSR_OPT_TILE_CULL] != 0;
+    in.defer_colour = fc.defer_colour ? 1 : 0;
 
     gsr::GeometryArrays& ga = fc.ga;
     ga.raster = (gsr::SplatRaster*)(gbase + geom_off[GSR_GEOM_RASTER]);
@@ -521,15 +625,15 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     ga.bins = (gsr::SplatBin*)(gbase + geom_off[GSR_GEOM_SPLAT_BINS]);
     ga.radii = radii ? radii : (int*)(gbase + geom_off[GSR_GEOM_INTERNAL_RADII]);
     ga.depth_keys = (uint32_t*)(gbase + off_keys_a);
-    ga.ids = own_sort ? nullptr : (uint32_t*)(gbase + off_ids_a);  // the first radix pass generates 0..P-1 itself
+    ga.ids = nullptr;  // the first radix pass generates 0..P-1 itself
     ga.counters = (gsr::FrameCounters*)(gbase + off_flag);
     fc.point_offsets = (uint32_t*)(gbase + geom_off[GSR_GEOM_POINT_OFFSETS]);
+    fc.slab_offsets = (uint32_t*)(gbase + off_slab_offsets);
     fc.tile_totals = (uint32_t*)(gbase + off_tile_totals);
+    fc.slab_tile_totals = (uint32_t*)(gbase + off_slab_totals);
     fc.sorted_bins = (uint4*)(gbase + off_sorted_bins);
-    void* tmp = gbase + off_tmp;
-    const size_t tmp_bytes = sort_tmp > scan_tmp ? sort_tmp : scan_tmp;
 
-    GSR_HIP(hipMemsetAsync(gbase + off_flag, 0, sizeof(gsr::FrameCounters), stream));
+    GSR_HIP(hipMemsetAsync(gbase + off_flag, 0, zero_end - off_flag, stream));
     stamp(0, stream);
     GSR_HIP(gsr::launch_preprocess(in, cam, ga, stream));
     GSR_STAGE_CHECK("preprocess");
@@ -543,19 +647,12 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     fc.queued = true;
 
     uint32_t* keys_sorted = nullptr;
-    if (own_sort) {
-        GSR_HIP(gsr::radix_sort_pairs((uint32_t*)tmp, (uint32_t)P, 32, ga.depth_keys, (uint32_t*)(gbase + off_keys_b),
-                                      (uint32_t*)(gbase + off_ids_a), (uint32_t*)(gbase + off_ids_b),
-                                      /*iota_payload=*/true, /*want_sorted_keys=*/false, &keys_sorted, &fc.order, stream));
-    } else {
-        GSR_HIP(gsr::depth_sort(tmp, tmp_bytes, P, ga.depth_keys, (uint32_t*)(gbase + off_keys_b), ga.ids,
-                                (uint32_t*)(gbase + off_ids_b), &keys_sorted, &fc.order, stream));
-    }
+    GSR_HIP(gsr::radix_sort_pairs((uint32_t*)(gbase + fc.off_radix_tmp), (uint32_t)P, 32, ga.depth_keys, (uint32_t*)(gbase + off_keys_b),
+                                  (uint32_t*)(gbase + off_ids_a), (uint32_t*)(gbase + off_ids_b),
+                                  /*iota_payload=*/true, /*want_sorted_keys=*/false, &keys_sorted, &fc.order, stream));
     GSR_STAGE_CHECK("depth_sort");
     stamp(2, stream);
     geom_off[GSR_GEOM_DEPTH_ORDER] = (size_t)((char*)fc.order - gbase);
-
-    if (!own_sort) GSR_HIP(gsr::scan_tiles_in_order(tmp, tmp_bytes, P, ga.bins, fc.order, fc.point_offsets, stream));
     return 0;
 }
 
@@ -563,7 +660,6 @@ int forward_finish(ForwardCall& fc) {
     if (fc.P == 0) return 0;
     hipStream_t stream = fc.stream;
     const int debug = fc.debug, P = fc.P, T = fc.T;
-    const bool own_sort = fc.own_sort;
     const gsr::Camera& cam = fc.cam;
     const gsr::GeometryArrays& ga = fc.ga;
     char* const gbase = fc.gbase;
@@ -574,104 +670,144 @@ int forward_finish(ForwardCall& fc) {
     fc.queued = false;
     const gsr::FrameCounters* hc = reinterpret_cast<const gsr::FrameCounters*>(fc.pinned.host);  // first kCounterBytes only
     const uint32_t flag = hc->error_flag;
-    unsigned long long rect_total = 0, live_total = 0, emitting = 0;
+    unsigned long long rect_total = 0, live_total = 0, emitting = 0, pool_rows = 0;
     for (int i = 0; i < gsr::kRectPartials; ++i) {
         rect_total += hc->pair_totals[i] >> 32;
         live_total += hc->pair_totals[i] & 0xFFFFFFFFull;
         emitting += hc->visible[i];
+        pool_rows += hc->big_rows[i];
     }
     if (debug && fc.prefiltered && (flag & 1u))
         return fail(GSR_ERR_PREFILTERED, "a Gaussian was culled although prefiltered is set (auxiliary.h:156-160)");
     if (rect_total > 0x7FFFFFFFull) return fail(GSR_ERR_INVALID_ARG, "num_rendered %llu overflows int", rect_total);
-    const uint32_t num_live = (uint32_t)live_total;
-    const uint32_t num_rendered = (uint32_t)rect_total;  // the reference's count; == num_live when culling is off
+    if (live_total > 0xFFFFFFFFull) return fail(GSR_ERR_INVALID_ARG, "pair count %llu overflows 32 bits", live_total);
+    const uint32_t live_bound = (uint32_t)live_total;    // upper bound of the pairs that will be expanded (exact without large splats)
+    const uint32_t num_rendered = (uint32_t)rect_total;  // the reference's count
+    if (!fc.in.tile_cull) pool_rows = 0;                 // (every row of a large splat is its full width)
     stamp(3, stream);
 
-    // ---- binning arena ----
-    const size_t nr = num_live ? num_live : 1;
-    size_t tsort_tmp = 0;
+    // ---- depth slabs and the binning arena ----
+    const SlabPlan plan = plan_slabs(fc.inference, live_bound, T, cam.grid_y * fc.row_words);
+    const int S = plan.slabs;
+    uint32_t max_bound = 1;
+    for (int k = 0; k < S; ++k) max_bound = plan.bound[k] > max_bound ? plan.bound[k] : max_bound;
     const int tile_bits = tile_key_bits((uint32_t)T);
-    const bool own_tile_sort = own_sort;
-    if (own_tile_sort) tsort_tmp = gsr::radix_scratch_words((uint32_t)nr) * sizeof(uint32_t);
-    else GSR_HIP(gsr::tile_sort_temp_bytes((uint32_t)nr, &tsort_tmp));
+    const int passes = (tile_bits + 7) / 8;
+    const size_t tsort_tmp = gsr::radix_scratch_words(max_bound) * sizeof(uint32_t);
     Carver bc;
     bc.take<gsr::ArenaHeader>(1);
-    const size_t off_tk_a = bc.take<uint32_t>(nr), off_tk_b = bc.take<uint32_t>(nr);
-    const size_t off_pl_a = bc.take<uint32_t>(nr), off_pl_b = bc.take<uint32_t>(nr);
+    // tile keys ping-pong: shared by the slabs (nobody reads a slab's keys once its ranges are known)
+    const size_t off_tk_a = bc.take<uint32_t>(max_bound), off_tk_b = bc.take<uint32_t>(max_bound);
+    // point lists: the buffer a slab's sorted list ends up in is the slab's own (the lists stay valid after the call:
+    // backward pass, second blend over the same geometry), its ping-pong partner is shared
+    size_t off_list[gsr::kMaxSlabs];
+    for (int k = 0; k < S; ++k) off_list[k] = bc.take<uint32_t>(plan.bound[k] ? plan.bound[k] : 1);
+    const size_t off_pl_shared = bc.take<uint32_t>(max_bound);
+    const size_t off_pool = bc.take<uint32_t>((size_t)pool_rows);
     const size_t off_btmp = bc.take<char>(tsort_tmp);
     char* braw = fc.binning_alloc(bc.total(), fc.binning_user);
     if (!braw) return fail(GSR_ERR_ALLOC, "binning scratch callback returned NULL for %zu bytes", bc.total());
     char* bbase = align_base(braw);
-    uint32_t *tile_keys = (uint32_t*)(bbase + off_tk_a), *point_list = (uint32_t*)(bbase + off_pl_a);
 
-    uint2* ranges = (uint2*)(fc.iraw + fc.img_off[GSR_IMG_RANGES]);
+    gsr::BinningArrays ba;
+    ba.P = P; ba.V = (int)emitting; ba.grid_x = cam.grid_x; ba.grid_y = cam.grid_y;
+    ba.depth_order = fc.order; ba.bins = ga.bins; ba.raster = ga.raster; ba.sorted_bins = fc.sorted_bins;
+    ba.offsets = fc.point_offsets; ba.tile_totals = fc.tile_totals;
+    ba.slab_offsets = fc.slab_offsets; ba.slab_tile_totals = fc.slab_tile_totals;
+    ba.run_pool = (uint32_t*)(bbase + off_pool); ba.pool_rows = (uint32_t)pool_rows;
+    ba.counters = ga.counters;
+    ba.slabs = (gsr::SlabInfo*)(gbase + fc.off_slabs);
+    ba.quad_done = (uint32_t*)(gbase + fc.off_quad);
+    ba.done_rows = (uint32_t*)(gbase + fc.off_rows);
+    ba.row_words = fc.row_words;
+    ba.tile_cull = fc.in.tile_cull;
+
     uint32_t* n_contrib = (uint32_t*)(fc.iraw + fc.img_off[GSR_IMG_N_CONTRIB]);
+    gsr::BlendSegments segs = {};
+    uint32_t* list_of[gsr::kMaxSlabs] = {};
+    uint32_t* tile_keys_sorted = nullptr;
 
-    if (own_sort)  // also when nothing is live: POINT_OFFSETS is an output
-        GSR_HIP(gsr::launch_scan_expand(P, (int)emitting, num_live, cam, fc.order, ga.bins, fc.sorted_bins, fc.tile_totals,
-                                        fc.point_offsets, tile_keys, point_list, stream));
-    if (num_live > 0) {
-        if (!own_sort)
-            GSR_HIP(gsr::launch_duplicate(P, cam, fc.order, fc.point_offsets, ga.bins, tile_keys, point_list, stream));
-        GSR_STAGE_CHECK("duplicate");
-        stamp(4, stream);
-        uint32_t *tk_sorted = nullptr, *pl_sorted = nullptr;
-        if (own_tile_sort) {
-            GSR_HIP(gsr::radix_sort_pairs((uint32_t*)(bbase + off_btmp), num_live, tile_bits, tile_keys,
-                                          (uint32_t*)(bbase + off_tk_b), point_list, (uint32_t*)(bbase + off_pl_b),
-                                          /*iota_payload=*/false, /*want_sorted_keys=*/true, &tk_sorted, &pl_sorted, stream));
-        } else {
-            GSR_HIP(gsr::tile_sort(bbase + off_btmp, tsort_tmp, num_live, tile_bits, tile_keys,
-                                   (uint32_t*)(bbase + off_tk_b), point_list, (uint32_t*)(bbase + off_pl_b),
-                                   &tk_sorted, &pl_sorted, stream));
-        }
+    // self-describing arenas (gsr_backward, gsr_blend): stamped by the last ranges launch
+    gsr::ArenaHeader hg = {}, hb = {}, hi = {};
+    hg.magic = hb.magic = hi.magic = gsr::kArenaMagic;
+    hg.kind = 0; hb.kind = 1; hi.kind = 2;
+    hg.count[0] = (uint32_t)P; hg.count[1] = num_rendered; hg.count[2] = (uint32_t)S; hg.count[3] = fc.inference ? 1u : 0u;
+    hg.off[0] = (uint64_t)((char*)ga.raster - gbase);
+    hg.off[3] = (uint64_t)((char*)ga.rgb - gbase);
+    hg.off[4] = (uint64_t)fc.geom_off[GSR_GEOM_INTERNAL_RADII];
+    hg.off[5] = (uint64_t)fc.off_slabs;
+    hb.count[0] = (uint32_t)S;
+    hi.count[0] = (uint32_t)fc.width; hi.count[1] = (uint32_t)fc.height; hi.count[2] = (uint32_t)T; hi.count[3] = (uint32_t)S;
+    hi.off[1] = (uint64_t)((char*)n_contrib - fc.ibase);
+
+    GSR_HIP(gsr::launch_bin_scan(ba, cam, S, plan.cut, stream));
+    GSR_STAGE_CHECK("bin_scan");
+    const float* features = fc.colors_precomp != nullptr ? fc.colors_precomp : ga.rgb;
+    for (int k = 0; k < S; ++k) {
+        const gsr::SlabInfo* slab = ba.slabs + k;
+        uint2* ranges = (uint2*)(fc.iraw + fc.img_off[GSR_IMG_RANGES]) + (size_t)k * T;
+        // expansion writes the "primary" buffers; an even number of radix passes brings the result back into them
+        uint32_t* own_list = (uint32_t*)(bbase + off_list[k]);
+        uint32_t* shared_list = (uint32_t*)(bbase + off_pl_shared);
+        uint32_t* list_in = (passes % 2 == 0) ? own_list : shared_list;
+        uint32_t* list_alt = (passes % 2 == 0) ? shared_list : own_list;
+        uint32_t *keys_in = (uint32_t*)(bbase + off_tk_a), *keys_alt = (uint32_t*)(bbase + off_tk_b);
+        if (k > 0) GSR_HIP(gsr::launch_slab_recount(ba, k, stream));
+        GSR_HIP(gsr::launch_expand(ba, k, plan.bound[k], keys_in, list_in, stream));
+        GSR_STAGE_CHECK("expand");
+        stamp(kHeadEvents + kSlabEvents * k + 0, stream);
+        uint32_t *tk_sorted = keys_in, *pl_sorted = list_in;
+        if (plan.bound[k] > 0)
+            GSR_HIP(gsr::radix_sort_pairs((uint32_t*)(bbase + off_btmp), plan.bound[k], tile_bits, keys_in, keys_alt, list_in, list_alt,
+                                          /*iota_payload=*/false, /*want_sorted_keys=*/true, &tk_sorted, &pl_sorted, stream,
+                                          &slab->pairs));
+        else
+            pl_sorted = own_list;
         GSR_STAGE_CHECK("tile_sort");
-        stamp(5, stream);
-        tile_keys = tk_sorted;
-        point_list = pl_sorted;
-    } else {
-        stamp(4, stream);
-        stamp(5, stream);
-    }
-
-    {   // self-describing arenas for gsr_backward
-        gsr::ArenaHeader hg = {}, hb = {}, hi = {};
-        hg.magic = hb.magic = hi.magic = gsr::kArenaMagic;
-        hg.kind = 0; hb.kind = 1; hi.kind = 2;
-        hg.count[0] = (uint32_t)P; hg.count[1] = num_rendered; hg.count[2] = num_live;
-        hg.off[0] = (uint64_t)((char*)ga.raster - gbase);
-        hg.off[3] = (uint64_t)((char*)ga.rgb - gbase);
-        hg.off[4] = (uint64_t)fc.geom_off[GSR_GEOM_INTERNAL_RADII];
-        hb.count[0] = num_live;
-        hb.off[0] = (uint64_t)((char*)point_list - bbase);
-        hi.count[0] = (uint32_t)fc.width; hi.count[1] = (uint32_t)fc.height; hi.count[2] = (uint32_t)T;
-        hi.off[0] = (uint64_t)((char*)ranges - fc.ibase);
-        hi.off[1] = (uint64_t)((char*)n_contrib - fc.ibase);
+        stamp(kHeadEvents + kSlabEvents * k + 1, stream);
+        list_of[k] = pl_sorted;
+        tile_keys_sorted = tk_sorted;
+        segs.ranges[k] = ranges;
+        segs.point_list[k] = pl_sorted;
+        hb.slab_off[k] = (uint64_t)((char*)pl_sorted - bbase);
+        hi.slab_off[k] = (uint64_t)((char*)ranges - fc.ibase);
+        const bool last = k == S - 1;
         const gsr::ArenaHeader hs[3] = {hg, hb, hi};
         void* const dsts[3] = {gbase, bbase, fc.ibase};
-        const char* const bases[3] = {gbase, bbase, fc.ibase};
-        remember_headers(bases, hs);
-        // tile ranges (all (0,0) when nothing is live: rasterizer_impl.cu:311) + the three headers, one launch
-        GSR_HIP(gsr::launch_tile_ranges(num_live, T, tile_keys, ranges, dsts, hs, stream));
+        // tile ranges (all (0,0) when nothing is live: rasterizer_impl.cu:311); the last launch also stamps the headers
+        GSR_HIP(gsr::launch_tile_ranges(slab, T, tk_sorted, ranges, last ? dsts : nullptr, hs, stream));
         GSR_STAGE_CHECK("tile_ranges");
-        stamp(6, stream);
+        stamp(kHeadEvents + kSlabEvents * k + 2, stream);
+        if (fc.defer_colour)
+            GSR_HIP(gsr::launch_sh_colour(fc.in, cam, ba.V, slab, fc.order, k == 0 ? fc.point_offsets : fc.slab_offsets, ga.rgb, stream));
+        stamp(kHeadEvents + kSlabEvents * k + 3, stream);
+        GSR_HIP(gsr::launch_blend(cam, segs, k, k + 1, /*fresh=*/k == 0, /*final=*/last, ga.raster, features, fc.background,
+                                  fc.out_color, fc.out_depth, fc.out_alpha, n_contrib, ba.quad_done, ba.done_rows, fc.row_words, stream,
+                                  fc.extra_features, fc.out_extra));
+        GSR_STAGE_CHECK("blend");
+        stamp(kHeadEvents + kSlabEvents * k + 4, stream);
+        if (last) {
+            const char* const bases[3] = {gbase, bbase, fc.ibase};
+            remember_headers(bases, hs);
+        }
     }
+    if (fc.timed) { g_ev_slabs[fc.slot] = S; ++g_timed_calls; }
 
-    const float* features = fc.colors_precomp != nullptr ? fc.colors_precomp : ga.rgb;
-    GSR_HIP(gsr::launch_blend(cam, g_options[GSR_OPT_BLEND_VARIANT], g_options[GSR_OPT_BLEND_LDS_PAD], ranges, point_list,
-                              ga.raster, features, fc.background, fc.out_color, fc.out_depth, fc.out_alpha, n_contrib,
-                              stream, fc.extra_features, fc.out_extra));
-    GSR_STAGE_CHECK("blend");
-    stamp(7, stream);
-    if (fc.timed) ++g_timed_calls;
+    // the pair counts of the slabs travel to pinned memory behind everything else; whoever asks for them waits then
+    GSR_HIP(hipMemcpyAsync(reinterpret_cast<char*>(fc.pinned.host) + kSlabTableAt, ba.slabs, sizeof(gsr::SlabInfo) * S,
+                           hipMemcpyDeviceToHost, stream));
+    GSR_HIP(hipEventRecord(fc.pinned.finished, stream));
+    if (g_last_slot.host) g_pinned_free.push_back(g_last_slot);
+    g_last_slot = fc.pinned;
+    fc.pinned = PinnedSlot();
+    g_last_slabs = S;
+    g_last_num_rendered = num_rendered;
 
     // what the gsr_last_* accessors report: the call that finished last on this thread
     for (int i = 0; i < GSR_GEOM_NUM_SLOTS; ++i) g_geom_off[i] = fc.geom_off[i] + fc.gshift;
     memcpy(g_img_off, fc.img_off, sizeof g_img_off);
-    g_bin_off[GSR_BIN_POINT_LIST] = (size_t)((char*)point_list - braw);
-    g_bin_off[GSR_BIN_TILE_KEYS] = (size_t)((char*)tile_keys - braw);
-    g_counts[0] = num_rendered;
-    g_counts[1] = num_live;
+    g_bin_off[GSR_BIN_POINT_LIST] = (size_t)((char*)list_of[0] - braw);
+    g_bin_off[GSR_BIN_TILE_KEYS] = (size_t)((char*)tile_keys_sorted - braw);
     g_have_offsets = true;
     return (int)num_rendered;
 }
@@ -692,7 +828,7 @@ int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_a
                 const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
                 float* out_depth, float* out_alpha, int* radii, int debug, void* stream) {
     ForwardCall fc;
-    const int rc = forward_begin(fc, GSR_FORWARD_ARGS, nullptr, nullptr);
+    const int rc = forward_begin(fc, GSR_FORWARD_ARGS, nullptr, nullptr, 0u);
     return rc < 0 ? rc : forward_finish(fc);
 }
 
@@ -703,10 +839,11 @@ int gsr_forward_extra(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn bin
                       const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                       const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
                       float* out_depth, float* out_alpha, int* radii, const float* extra_features, float* out_extra,
-                      int debug, void* stream) {
-    if (P > 0 && (!extra_features || !out_extra)) return fail(GSR_ERR_INVALID_ARG, "null extra feature pointer");
+                      unsigned flags, int debug, void* stream) {
+    if ((extra_features != nullptr) != (out_extra != nullptr))
+        return fail(GSR_ERR_INVALID_ARG, "extra_features and out_extra must be given together");
     ForwardCall fc;
-    const int rc = forward_begin(fc, GSR_FORWARD_ARGS, extra_features, out_extra);
+    const int rc = forward_begin(fc, GSR_FORWARD_ARGS, extra_features, out_extra, flags);
     return rc < 0 ? rc : forward_finish(fc);
 }
 
@@ -717,7 +854,7 @@ void* gsr_forward_begin(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn b
                         const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                         const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
                         float* out_depth, float* out_alpha, int* radii, const float* extra_features, float* out_extra,
-                        int debug, void* stream) {
+                        unsigned flags, int debug, void* stream) {
     if ((extra_features != nullptr) != (out_extra != nullptr)) {
         fail(GSR_ERR_INVALID_ARG, "extra_features and out_extra must be given together");
         return nullptr;
@@ -727,7 +864,7 @@ void* gsr_forward_begin(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn b
         fail(GSR_ERR_ALLOC, "out of host memory");
         return nullptr;
     }
-    if (forward_begin(*fc, GSR_FORWARD_ARGS, extra_features, out_extra) < 0) {
+    if (forward_begin(*fc, GSR_FORWARD_ARGS, extra_features, out_extra, flags) < 0) {
         delete fc;
         return nullptr;
     }

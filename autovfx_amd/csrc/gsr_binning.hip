@@ -1,0 +1,589 @@
+// gsr_binning.hip -- from the depth order of the Gaussians to per-tile lists, for gfx950.
+//
+// What it replaces in the reference (DGR = sugar/gaussian_splatting/submodules/diff-gaussian-rasterization):
+//   cub::DeviceScan::InclusiveSum over tiles_touched    DGR/cuda_rasterizer/rasterizer_impl.cu:278
+//   duplicateWithKeys                                   DGR/cuda_rasterizer/rasterizer_impl.cu:70-111
+//   identifyTileRanges                                  DGR/cuda_rasterizer/rasterizer_impl.cu:116-138
+// (the sort between the last two is gsr_radix.hip).
+//
+// The reference expands every splat into one pair per tile of the bounding square of its 3-sigma circle and sorts all
+// of them.  Here a pair is only ever written if some pixel can use it:
+//   * pairs whose tile cannot reach alpha >= 1/255 are never emitted (exact-image tile culling: bit masks for small
+//     tight rectangles from the projection kernel, one run of live columns per tile row for large splats, worked out
+//     here in closed form -- gsr_device.h: live_region / row_run);
+//   * the depth-sorted splats are expanded, sorted and blended in front-to-back SLABS (inference calls); a slab drops
+//     every pair whose tile has all 256 pixels finished by the slabs in front of it (the reference's block-wide early
+//     exit, forward.cu:312-314, applied before the pair is written instead of after it was sorted).
+// Stages, all spin-free (no workgroup ever waits for another one):
+//   bin_gather_kernel   : one workgroup per kDupTile = 1024 positions of the depth order.  The one random gather per
+//                         splat (its 16-byte record; for large splats also the conic, to compute their runs), live
+//                         pair counts, scan inside the tile, records re-written IN DEPTH ORDER.
+//   bin_offsets_kernel  : adds the sum of all earlier tile totals (each workgroup sums them itself: a few KB of
+//                         L2-resident words, no chain, no look-back) -> POINT_OFFSETS, global and inclusive.
+//   slab_bounds_kernel  : cuts the depth order into slabs at the given pair counts.
+//   slab_recount_kernel / slab_offsets_kernel (slabs > 0): drop finished tiles from the records, re-scan.
+//   expand_kernel       : one workgroup per kPairTile = 4096 PAIRS, 16 consecutive pairs per lane: every workgroup
+//                         does the same work whatever the splat sizes, and writes one contiguous 32 KB slice of the
+//                         two pair arrays with 16-byte stores.
+//   tile_ranges_kernel  : two binary searches per tile over the sorted tile keys.
+// Every pair count past the first host read-back lives in device memory (SlabInfo::pairs): launches are sized for an
+// upper bound and surplus workgroups leave at once.
+#include "gsr_device.h"
+
+namespace gsr {
+namespace {
+
+constexpr int kPairTile = 4096;
+constexpr int kPairsPerLane = kPairTile / 256;  // consecutive pairs of one lane
+constexpr int kMaxDoneWords = 4096;             // tile bit rows held in LDS by the slab kernels (16 KB)
+static_assert(kDupTile == 1024, "256 lanes x 4 consecutive positions");
+
+// Sum over the workgroup's 256 lanes, returned to every lane; scratch is 4 words of LDS.
+__device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* scratch) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const uint32_t total = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    __syncthreads();
+    return total;
+}
+
+// Inclusive scan of one value per lane over the 256 lanes; returns the exclusive prefix, *total = sum of all.
+__device__ __forceinline__ uint32_t block_exclusive_256(uint32_t mine, uint32_t* s_wave, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t before = incl - mine, all = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) before += s_wave[w];
+        all += s_wave[w];
+    }
+    __syncthreads();
+    *total = all;
+    return before;
+}
+
+__device__ __forceinline__ bool rec_is_masked(uint32_t wh) { return (wh & 0xFFFFu) * (wh >> 16) <= kMaskTiles; }
+
+// Bits [x0, x0 + w) of tile bit row `ty` (w <= 64), right-aligned.
+__device__ __forceinline__ unsigned long long done_bits(const uint32_t* rows, int row_words, uint32_t ty, uint32_t x0, uint32_t w) {
+    const uint32_t* r = rows + ty * (uint32_t)row_words;
+    const uint32_t wi = x0 >> 5, sh = x0 & 31u;
+    const uint32_t last = (uint32_t)row_words - 1u;
+    const unsigned long long a = (unsigned long long)r[min(wi, last)] | ((unsigned long long)(wi + 1 <= last ? r[wi + 1] : 0u) << 32);
+    unsigned long long v = a >> sh;
+    if (sh + w > 64u) v |= (unsigned long long)(wi + 2 <= last ? r[wi + 2] : 0u) << (64u - sh);
+    return w >= 64u ? v : v & ((1ull << w) - 1ull);
+}
+
+// The finished tiles of a masked splat's rectangle, in the bit order of its mask (row-major).
+__device__ __forceinline__ unsigned long long done_rect(const uint32_t* rows, int row_words, uint32_t xy0, uint32_t wh) {
+    const uint32_t x0 = xy0 & 0xFFFFu, y0 = xy0 >> 16, w = wh & 0xFFFFu, h = wh >> 16;
+    unsigned long long d = 0ull;
+    for (uint32_t j = 0; j < h; ++j) d |= done_bits(rows, row_words, y0 + j, x0, w) << (j * w);
+    return d;
+}
+
+// Walks the live tiles of one splat in row-major order: the set bits of a mask, or the runs of a large splat
+// (minus the tiles that are already finished, when a table of those is given).
+struct TileWalker {
+    uint32_t x0, y0, width;
+    bool masked;
+    // masked
+    unsigned long long mask;
+    float inv_width;
+    // runs
+    const uint32_t* runs;   // this splat's rows in the pool, or nullptr: every row is the full width
+    const uint32_t* done;   // tile bit rows (LDS), or nullptr
+    int row_words;
+    uint32_t height, row, ca, cb, col_base, cur;
+
+    __device__ __forceinline__ void load_run() {
+        if (runs != nullptr) {
+            const uint32_t r = runs[row];
+            ca = r & 0xFFFFu; cb = r >> 16;
+        } else {
+            ca = x0; cb = x0 + width;
+        }
+    }
+    __device__ __forceinline__ void load_word() {  // live, unfinished tiles among columns [col_base, col_base + 32) of `row`
+        const uint32_t lo = max(ca, col_base), hi = min(cb, col_base + 32u);
+        uint32_t bits = 0u;
+        if (lo < hi) {
+            const uint32_t n = hi - lo;
+            bits = (n >= 32u ? ~0u : ((1u << n) - 1u)) << (lo - col_base);
+        }
+        if (done != nullptr) bits &= ~done[(y0 + row) * (uint32_t)row_words + (col_base >> 5)];
+        cur = bits;
+    }
+    __device__ __forceinline__ void next_word() {
+        col_base += 32u;
+        while (col_base >= cb) {  // this row is exhausted (or its run is empty)
+            if (++row >= height) { cur = 0u; return; }
+            load_run();
+            col_base = ca < cb ? (ca & ~31u) : cb;  // empty run: straight to the next row
+        }
+        load_word();
+    }
+    // live tiles of the whole splat (runs only)
+    __device__ __forceinline__ uint32_t count_all() {
+        uint32_t n = 0;
+        for (row = 0; row < height; ++row) {
+            load_run();
+            for (col_base = ca & ~31u; col_base < cb; col_base += 32u) {
+                load_word();
+                n += (uint32_t)__popc(cur);
+            }
+        }
+        return n;
+    }
+    __device__ __forceinline__ void init(const uint4 rec, const uint32_t* pool, const uint32_t* done_rows_, int row_words_) {
+        x0 = rec.x & 0xFFFFu; y0 = rec.x >> 16; width = rec.y & 0xFFFFu; height = rec.y >> 16;
+        masked = width * height <= kMaskTiles;
+        done = done_rows_; row_words = row_words_;
+        runs = (!masked && rec.z != 0xFFFFFFFFu) ? pool + rec.z : nullptr;
+        mask = (unsigned long long)rec.z | ((unsigned long long)rec.w << 32);
+    }
+    // position on the r-th (0-based) live tile
+    __device__ __forceinline__ void start(const uint4 rec, uint32_t r, const uint32_t* pool, const uint32_t* done_rows_, int row_words_) {
+        init(rec, pool, done_rows_, row_words_);
+        if (masked) {
+            for (uint32_t i = 0; i < r; ++i) mask &= mask - 1ull;  // r < 64
+            inv_width = __builtin_amdgcn_rcpf((float)width);
+        } else {
+            row = 0;
+            load_run();
+            if (ca < cb) { col_base = ca & ~31u; load_word(); } else { col_base = cb; cur = 0u; }
+            for (;;) {  // skip r live tiles, a word at a time
+                while (cur == 0u && row < height) next_word();
+                if (row >= height) break;
+                const uint32_t c = (uint32_t)__popc(cur);
+                if (r < c) break;
+                r -= c;
+                cur = 0u;
+            }
+            for (uint32_t i = 0; i < r; ++i) cur &= cur - 1u;
+        }
+    }
+    __device__ __forceinline__ uint32_t next(uint32_t grid_x) {
+        if (masked) {
+            const uint32_t pos = (uint32_t)__builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            // pos < 64, width <= 64: (pos + 0.5) / width is at least 0.5 / 64 away from an integer, the
+            // approximate reciprocal is off by parts in 2^22
+            const uint32_t r_ = (uint32_t)(((float)pos + 0.5f) * inv_width);
+            return (y0 + r_) * grid_x + x0 + (pos - r_ * width);
+        }
+        while (cur == 0u && row < height) next_word();
+        const uint32_t pos = (uint32_t)__builtin_ctz(cur);
+        cur &= cur - 1u;
+        return (y0 + row) * grid_x + col_base + pos;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// bin_gather: positions [0, V) of the depth order.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bin_gather_kernel(BinningArrays a) {
+    __shared__ uint32_t s_wave[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int V = a.V;
+    const int k0 = (int)blockIdx.x * kDupTile + 4 * tid;  // 4 consecutive positions per lane
+    uint32_t gid[4] = {0u, 0u, 0u, 0u};
+    if (k0 + 3 < V) {
+        const uint4 g = *reinterpret_cast<const uint4*>(a.depth_order + k0);
+        gid[0] = g.x; gid[1] = g.y; gid[2] = g.z; gid[3] = g.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k0 + j < V) gid[j] = a.depth_order[k0 + j];
+    }
+    uint4 rec[4];
+    uint32_t count[4];
+    uint32_t rows_needed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        rec[j] = make_uint4(0u, 0u, 0u, 0u);
+        count[j] = 0u;
+        if (k0 + j < V) {
+            rec[j] = *reinterpret_cast<const uint4*>(a.bins + gid[j]);  // the one random gather per splat
+            if (rec_is_masked(rec[j].y)) count[j] = (uint32_t)__popc(rec[j].z) + (uint32_t)__popc(rec[j].w);
+            else if (a.tile_cull) rows_needed += rec[j].y >> 16;
+        }
+    }
+    // Large splats: one run of live columns per tile row, parked in the pool.  Rows are handed out with one atomic per
+    // wave; a splat that does not get its rows (cannot happen: the pool is sized from the projection kernel's count)
+    // keeps its full rectangle, which is only less culled, never wrong.
+    const unsigned long long any_big = __ballot(rows_needed != 0u);
+    uint32_t pool_at = 0u;
+    if (any_big != 0ull) {
+        uint32_t incl = rows_needed;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += o;
+        }
+        uint32_t base = 0u;
+        if (lane == 63) base = atomicAdd(&a.counters->pool_used, incl);
+        base = (uint32_t)__shfl((int)base, 63);
+        pool_at = base + incl - rows_needed;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (k0 + j >= V || rec_is_masked(rec[j].y)) continue;
+        const uint32_t x0 = rec[j].x & 0xFFFFu, y0 = rec[j].x >> 16, w = rec[j].y & 0xFFFFu, h = rec[j].y >> 16;
+        if (!a.tile_cull || pool_at + h > a.pool_rows) {
+            rec[j].z = 0xFFFFFFFFu;  // every row is the full width
+            count[j] = w * h;
+        } else {
+            const float4* rr = reinterpret_cast<const float4*>(a.raster + gid[j]);
+            const float4 r0 = rr[0], r1 = rr[1];  // x y cxx cxy | cyy opacity depth skip_below
+            const LiveRegion g = live_region(r0.z, r0.w, r1.x, r1.w);
+            uint32_t n = 0;
+            for (uint32_t r = 0; r < h; ++r) {
+                int ca, cb;
+                row_run(g, r0.x, r0.y, (int)(y0 + r), (int)x0, (int)(x0 + w), &ca, &cb);
+                a.run_pool[pool_at + r] = (uint32_t)ca | ((uint32_t)cb << 16);
+                n += (uint32_t)(cb - ca);
+            }
+            rec[j].z = pool_at;
+            count[j] = n;
+            pool_at += h;
+        }
+        rec[j].w = count[j];
+    }
+    const uint32_t mine = count[0] + count[1] + count[2] + count[3];
+    uint32_t tile_total;
+    const uint32_t before = block_exclusive_256(mine, s_wave, &tile_total);
+    if (tid == 0) a.tile_totals[blockIdx.x] = tile_total;
+    const uint32_t o0 = before + count[0], o1 = o0 + count[1], o2 = o1 + count[2], o3 = o2 + count[3];
+    if (k0 + 3 < V) {
+        *reinterpret_cast<uint4*>(a.offsets + k0) = make_uint4(o0, o1, o2, o3);
+    } else {
+        const uint32_t o[4] = {o0, o1, o2, o3};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k0 + j < V) a.offsets[k0 + j] = o[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (k0 + j < V) a.sorted_bins[k0 + j] = rec[j];
+}
+
+// P - V trailing positions (culled Gaussians) repeat the total so that POINT_OFFSETS is defined over all P, as
+// the reference's inclusive scan is.
+__global__ void __launch_bounds__(256) bin_offsets_kernel(int P, int V, const uint32_t* __restrict__ tile_totals,
+                                                          uint32_t* __restrict__ offsets, uint32_t* __restrict__ tile_ends) {
+    __shared__ uint32_t s_scratch[4];
+    const int tiles_v = (V + kDupTile - 1) / kDupTile;
+    const int upto = min((int)blockIdx.x, tiles_v);
+    uint32_t part = 0;
+    for (int t = threadIdx.x; t < upto; t += 256) part += tile_totals[t];
+    const uint32_t before = block_sum_256(part, s_scratch);
+    if (threadIdx.x == 0 && (int)blockIdx.x < tiles_v) tile_ends[blockIdx.x] = before + tile_totals[blockIdx.x];
+    // positions past V (culled Gaussians) carry the grand total: the tile that straddles V is the last one with pairs
+    const uint32_t total = (int)blockIdx.x < tiles_v ? before + tile_totals[blockIdx.x] : before;
+    const int k0 = (int)blockIdx.x * kDupTile + 4 * (int)threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + j;
+        if (k < V) offsets[k] += before;
+        else if (k < P) offsets[k] = total;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// slab boundaries: slab s = positions whose inclusive offset lies in (cut[s-1], cut[s]]; one workgroup per slab.
+// ------------------------------------------------------------------------------------------------
+struct SlabCuts { uint32_t cut[kMaxSlabs]; };
+
+// number of positions [0, V) whose inclusive offset is <= limit (offsets ascend: they form a prefix)
+__device__ __forceinline__ uint32_t positions_upto(uint32_t limit, int V, const uint32_t* __restrict__ offsets,
+                                                   const uint32_t* __restrict__ tile_ends, uint32_t* s_scratch) {
+    const int tiles = (V + kDupTile - 1) / kDupTile;
+    uint32_t n_le = 0;
+    for (int t = threadIdx.x; t < tiles; t += 256) n_le += tile_ends[t] <= limit ? 1u : 0u;
+    const int tile0 = (int)block_sum_256(n_le, s_scratch);  // tiles that end at or before the limit
+    n_le = 0;
+    const int k0 = tile0 * kDupTile + 4 * (int)threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (k0 + j < V) n_le += offsets[k0 + j] <= limit ? 1u : 0u;
+    return (uint32_t)tile0 * kDupTile + block_sum_256(n_le, s_scratch);
+}
+
+__global__ void __launch_bounds__(256) slab_bounds_kernel(int V, int num_slabs, SlabCuts cuts, const uint32_t* __restrict__ offsets,
+                                                          const uint32_t* __restrict__ tile_ends, SlabInfo* __restrict__ slabs) {
+    __shared__ uint32_t s_scratch[4];
+    const int s = blockIdx.x;
+    const uint32_t first = s == 0 ? 0u : positions_upto(cuts.cut[s - 1], V, offsets, tile_ends, s_scratch);
+    const uint32_t end = s == num_slabs - 1 ? (uint32_t)V : positions_upto(cuts.cut[s], V, offsets, tile_ends, s_scratch);
+    if (threadIdx.x == 0) {
+        SlabInfo info;
+        info.first = first; info.end = end; info.pad = 0u;
+        // slab 0 is expanded from the global offsets as they are; later slabs set their count when they re-scan
+        info.pairs = (s == 0 && end > 0u) ? offsets[end - 1] : 0u;
+        slabs[s] = info;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// slabs > 0: drop the tiles finished by the slabs in front (bit rows written by the blend), count again, scan
+// inside 1024-position tiles that start at the slab's first position.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_done_rows(uint32_t* s_done, const uint32_t* __restrict__ done_rows, int words) {
+    for (int i = threadIdx.x; i < words; i += 256) s_done[i] = done_rows[i];
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) slab_recount_kernel(BinningArrays a, int slab) {
+    __shared__ uint32_t s_done[kMaxDoneWords];
+    __shared__ uint32_t s_wave[4];
+    const SlabInfo info = a.slabs[slab];
+    const uint32_t first = info.first, end = min(info.end, (uint32_t)a.V);
+    const uint32_t k0 = first + blockIdx.x * (uint32_t)kDupTile + 4u * threadIdx.x;
+    if (first + blockIdx.x * (uint32_t)kDupTile >= end) return;  // workgroup-uniform
+    load_done_rows(s_done, a.done_rows, a.grid_y * a.row_words);
+    uint32_t count[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        count[j] = 0u;
+        const uint32_t k = k0 + j;
+        if (k >= end) continue;
+        uint4 rec = a.sorted_bins[k];
+        if (rec.y == 0u) continue;
+        if (rec_is_masked(rec.y)) {
+            const unsigned long long m = (unsigned long long)rec.z | ((unsigned long long)rec.w << 32);
+            const unsigned long long left = m & ~done_rect(s_done, a.row_words, rec.x, rec.y);
+            if (left != m) {
+                rec.z = (uint32_t)left; rec.w = (uint32_t)(left >> 32);
+                a.sorted_bins[k] = rec;
+            }
+            count[j] = (uint32_t)__popcll(left);
+        } else {
+            TileWalker w;
+            w.init(rec, a.run_pool, s_done, a.row_words);
+            count[j] = w.count_all();
+        }
+    }
+    const uint32_t mine = count[0] + count[1] + count[2] + count[3];
+    uint32_t tile_total;
+    const uint32_t before = block_exclusive_256(mine, s_wave, &tile_total);
+    if (threadIdx.x == 0) a.slab_tile_totals[blockIdx.x] = tile_total;
+    uint32_t run = before;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        run += count[j];
+        if (k0 + j < end) a.slab_offsets[k0 + j] = run;
+    }
+}
+
+__global__ void __launch_bounds__(256) slab_offsets_kernel(int V, SlabInfo* __restrict__ slabs, int slab,
+                                                           const uint32_t* __restrict__ tile_totals, uint32_t* __restrict__ offsets,
+                                                           uint32_t* __restrict__ tile_ends) {
+    __shared__ uint32_t s_scratch[4];
+    const SlabInfo info = slabs[slab];
+    const uint32_t first = info.first, end = min(info.end, (uint32_t)V);
+    const uint32_t tiles = end > first ? (end - first + kDupTile - 1) / kDupTile : 0u;
+    if (blockIdx.x == 0) {  // the slab's pair count (also when the slab is empty)
+        uint32_t part = 0;
+        for (uint32_t t = threadIdx.x; t < tiles; t += 256) part += tile_totals[t];
+        const uint32_t all = block_sum_256(part, s_scratch);
+        if (threadIdx.x == 0) slabs[slab].pairs = all;
+    }
+    if (blockIdx.x >= tiles) return;
+    uint32_t part = 0;
+    for (uint32_t t = threadIdx.x; t < blockIdx.x; t += 256) part += tile_totals[t];
+    const uint32_t before = block_sum_256(part, s_scratch);
+    if (threadIdx.x == 0) tile_ends[blockIdx.x] = before + tile_totals[blockIdx.x];
+    const uint32_t k0 = first + blockIdx.x * (uint32_t)kDupTile + 4u * threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (k0 + j < end) offsets[k0 + j] += before;
+}
+
+// ------------------------------------------------------------------------------------------------
+// expand: pairs [blockIdx.x * 4096, +4096) of one slab.  `offsets` counts pairs inclusively from the slab's first
+// position on, `tile_ends` are those counts at the ends of the slab's 1024-position tiles.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, const uint32_t* __restrict__ offsets_all,
+                                                     const uint32_t* __restrict__ tile_ends,
+                                                     uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ point_list) {
+    constexpr int kBatch = 2048;            // splats whose offsets are parked in LDS at a time
+    __shared__ uint32_t s_incl[kBatch + 1]; // s_incl[0] = pairs before the batch's first splat
+    __shared__ uint32_t s_scratch[4];
+    __shared__ uint32_t s_done[kMaxDoneWords];
+    const int tid = threadIdx.x;
+    const SlabInfo info = a.slabs[slab];
+    const uint32_t num_pairs = info.pairs;
+    const uint32_t p_begin = blockIdx.x * (uint32_t)kPairTile;
+    if (p_begin >= num_pairs) return;  // the launch was sized for an upper bound
+    const uint32_t p_end = min(num_pairs, p_begin + (uint32_t)kPairTile);
+    const uint32_t first = info.first;
+    const int V = (int)(min(info.end, (uint32_t)a.V) - first);  // positions of this slab: local index i <-> position first + i
+    const uint32_t* __restrict__ offsets = offsets_all + first;
+    const uint4* __restrict__ sorted_bins = a.sorted_bins + first;
+    const uint32_t* __restrict__ order = a.depth_order + first;
+    const uint32_t* done = nullptr;
+    if (slab > 0) {
+        load_done_rows(s_done, a.done_rows, a.grid_y * a.row_words);
+        done = s_done;
+    }
+    const uint32_t grid_x = (uint32_t)a.grid_x;
+
+    // first splat whose inclusive offset exceeds p_begin = number of splats with offset <= p_begin
+    const int tiles = (V + kDupTile - 1) / kDupTile;
+    uint32_t n_le = 0;
+    for (int t = tid; t < tiles; t += 256) n_le += tile_ends[t] <= p_begin ? 1u : 0u;
+    const int tile0 = (int)block_sum_256(n_le, s_scratch);  // tiles that end at or before p_begin
+    n_le = 0;
+    {
+        const int k0 = tile0 * kDupTile + 4 * tid;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k0 + j < V) n_le += offsets[k0 + j] <= p_begin ? 1u : 0u;
+    }
+    int s0 = tile0 * kDupTile + (int)block_sum_256(n_le, s_scratch);
+
+    const uint32_t my_begin = p_begin + (uint32_t)(kPairsPerLane * tid);
+    const uint32_t my_end = min(p_end, my_begin + (uint32_t)kPairsPerLane);
+    uint32_t keys[kPairsPerLane], ids[kPairsPerLane];
+    while (s0 < V) {  // workgroup-uniform
+        for (int i = tid; i <= kBatch; i += 256) {
+            const int k = s0 - 1 + i;
+            s_incl[i] = k < 0 ? 0u : offsets[min(k, V - 1)];
+        }
+        __syncthreads();
+        const uint32_t lo_pair = max(my_begin, s_incl[0]);
+        const uint32_t hi_pair = min(my_end, s_incl[kBatch]);
+        if (lo_pair < hi_pair) {
+            int lo = 1, hi = kBatch;  // smallest i with s_incl[i] > lo_pair: the owner of this lane's first pair
+#pragma unroll
+            for (int step = 0; step < 11; ++step) {
+                const int mid = (lo + hi) >> 1;
+                if (s_incl[mid] > lo_pair) hi = mid; else lo = mid + 1;
+            }
+            int owner = lo;
+            uint32_t owner_end = s_incl[owner];
+            TileWalker w;
+            w.start(sorted_bins[s0 + owner - 1], lo_pair - s_incl[owner - 1], a.run_pool, done, a.row_words);
+            uint32_t gid = order[s0 + owner - 1];
+#pragma unroll
+            for (int q = 0; q < kPairsPerLane; ++q) {
+                const uint32_t p = my_begin + (uint32_t)q;
+                if (p >= lo_pair && p < hi_pair) {
+                    if (p >= owner_end) {
+                        do { owner_end = s_incl[++owner]; } while (p >= owner_end);  // splats without live tiles
+                        w.start(sorted_bins[s0 + owner - 1], 0u, a.run_pool, done, a.row_words);
+                        gid = order[s0 + owner - 1];
+                    }
+                    keys[q] = w.next(grid_x);
+                    ids[q] = gid;
+                }
+            }
+        }
+        const bool finished = s_incl[kBatch] >= p_end;
+        __syncthreads();
+        if (finished) break;
+        s0 += kBatch;
+    }
+    if (my_begin + kPairsPerLane <= p_end) {
+#pragma unroll
+        for (int q = 0; q < kPairsPerLane; q += 4) {
+            *reinterpret_cast<uint4*>(tile_keys + my_begin + q) = make_uint4(keys[q], keys[q + 1], keys[q + 2], keys[q + 3]);
+            *reinterpret_cast<uint4*>(point_list + my_begin + q) = make_uint4(ids[q], ids[q + 1], ids[q + 2], ids[q + 3]);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < kPairsPerLane; ++q)
+            if (my_begin + q < p_end) {
+                tile_keys[my_begin + q] = keys[q];
+                point_list[my_begin + q] = ids[q];
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: ranges[t] = [lower_bound(t), lower_bound(t+1)) over the sorted tile keys; (0,0) when empty,
+// which is what the reference's memset + boundary scan leaves behind.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__ a, uint32_t n, uint32_t v) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+struct ArenaHeaders3 { ArenaHeader h[3]; void* dst[3]; };
+
+__global__ void __launch_bounds__(256) tile_ranges_kernel(const SlabInfo* __restrict__ slab, int num_tiles,
+                                                          const uint32_t* __restrict__ keys,
+                                                          uint2* __restrict__ ranges, ArenaHeaders3 headers) {
+    // the three arena headers ride along (one launch less per call)
+    if (blockIdx.x == 0 && threadIdx.x < 3 && headers.dst[threadIdx.x] != nullptr)
+        *reinterpret_cast<ArenaHeader*>(headers.dst[threadIdx.x]) = headers.h[threadIdx.x];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= num_tiles) return;
+    const uint32_t n = slab->pairs;
+    const uint32_t b = lower_bound_u32(keys, n, (uint32_t)t);
+    const uint32_t e = lower_bound_u32(keys, n, (uint32_t)t + 1u);
+    ranges[t] = (e > b) ? make_uint2(b, e) : make_uint2(0u, 0u);
+}
+
+} // namespace
+
+hipError_t launch_bin_scan(const BinningArrays& a, const Camera& cam, int num_slabs, const uint32_t* pair_cuts, hipStream_t stream) {
+    (void)cam;
+    const int tiles_p = div_up(a.P, kDupTile), tiles_v = div_up(a.V, kDupTile);
+    if (tiles_v > 0) hipLaunchKernelGGL(bin_gather_kernel, dim3(tiles_v), dim3(256), 0, stream, a);
+    uint32_t* tile_ends = a.tile_totals + tiles_p;
+    hipLaunchKernelGGL(bin_offsets_kernel, dim3(tiles_p), dim3(256), 0, stream, a.P, a.V, a.tile_totals, a.offsets, tile_ends);
+    SlabCuts cuts = {};
+    for (int s = 0; s + 1 < num_slabs; ++s) cuts.cut[s] = pair_cuts[s];
+    hipLaunchKernelGGL(slab_bounds_kernel, dim3(num_slabs), dim3(256), 0, stream, a.V, num_slabs, cuts, a.offsets, tile_ends, a.slabs);
+    return hipGetLastError();
+}
+
+hipError_t launch_slab_recount(const BinningArrays& a, int slab, hipStream_t stream) {
+    const int tiles_v = div_up(a.V, kDupTile), tiles_p = div_up(a.P, kDupTile);
+    // (an empty slab still needs its pair count set: slab_offsets_kernel's first workgroup does that)
+    if (tiles_v > 0) hipLaunchKernelGGL(slab_recount_kernel, dim3(tiles_v), dim3(256), 0, stream, a, slab);
+    hipLaunchKernelGGL(slab_offsets_kernel, dim3(tiles_v > 0 ? tiles_v : 1), dim3(256), 0, stream, a.V, a.slabs, slab,
+                       a.slab_tile_totals, a.slab_offsets, a.slab_tile_totals + tiles_p);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand(const BinningArrays& a, int slab, uint32_t pairs_bound, uint32_t* tile_keys, uint32_t* point_list,
+                         hipStream_t stream) {
+    if (pairs_bound == 0) return hipSuccess;
+    const int tiles_p = div_up(a.P, kDupTile);
+    const uint32_t* offsets = slab == 0 ? a.offsets : a.slab_offsets;
+    const uint32_t* tile_ends = (slab == 0 ? a.tile_totals : a.slab_tile_totals) + tiles_p;
+    hipLaunchKernelGGL(expand_kernel, dim3((pairs_bound + kPairTile - 1) / kPairTile), dim3(256), 0, stream, a, slab, offsets,
+                       tile_ends, tile_keys, point_list);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_ranges(const SlabInfo* slab, int num_tiles, const uint32_t* sorted_tile_keys, uint2* ranges,
+                              void* const header_dst[3], const ArenaHeader headers[3], hipStream_t stream) {
+    ArenaHeaders3 a = {};
+    for (int i = 0; i < 3; ++i) {
+        a.dst[i] = header_dst ? header_dst[i] : nullptr;
+        if (header_dst) a.h[i] = headers[i];
+    }
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(div_up(num_tiles, 256)), dim3(256), 0, stream, slab, num_tiles,
+                       sorted_tile_keys, ranges, a);
+    return hipGetLastError();
+}
+
+} // namespace gsr

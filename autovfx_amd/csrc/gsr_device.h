@@ -162,9 +162,94 @@ __device__ __forceinline__ bool splat_reaches_tile(float4 co, float skip_below, 
     return splat_reaches_rect(co, skip_below, c, tile_x * kTile, tile_y * kTile, kTile, kTile);
 }
 
-struct BlendEntryA { float x, y, cxx, cxy; };       // ds_read_b128
-struct BlendEntryB { float cyy, skip_below; };      // ds_read_b64
-struct BlendEntryC { float opacity, r, g, b; };     // ds_read_b128, contributing pairs only
+// ------------------------------------------------------------------------------------------------
+// The same bound as a REGION instead of a per-tile predicate: {d : q(d) <= beta} is an ellipse around the splat's
+// centre.  Its bounding box cuts the reference's rectangle (the bounding square of the 3-sigma CIRCLE of the major
+// axis: far too large for needles and for faint splats) down to the "tight" rectangle; and for splats whose tight
+// rectangle is still too large for a bit mask, the ellipse cut with the pixel rows of one tile row is convex, so the
+// live tiles of that row are ONE run of columns with a closed form (the ellipse's extreme point in x if it lies in the
+// strip, else the intersection with the nearer strip edge).  beta carries the margin of splat_reaches_rect
+// (q * 0.998 - 1e-3 <= budget), the extents another 0.1 % + 0.02 px: a tile is dropped only when that is provable.
+// ------------------------------------------------------------------------------------------------
+struct LiveRegion {
+    float A, B, C;      // conic
+    float beta;         // q <= beta is necessary for alpha >= 1/255
+    float u_ext, v_ext; // half extents of the ellipse's bounding box (pixels)
+    int kind;           // 0: cannot be bounded (irregular conic, NaN): everything stays; 1: the ellipse; 2: nothing is live
+};
+
+__device__ __forceinline__ LiveRegion live_region(float A, float B, float C, float skip_below) {
+    LiveRegion r;
+    r.A = A; r.B = B; r.C = C;
+    r.beta = ((-skip_below - 1.0e-4f) + 1.0e-3f) * 1.0021f;
+    r.u_ext = r.v_ext = 0.f;
+    r.kind = 0;
+    if (!(A > 0.f) || !(C > 0.f) || !((B * B) < 0.99f * (A * C)) || !(r.beta == r.beta)) return r;
+    if (r.beta < 0.f) { r.kind = 2; return r; }   // alpha < 1/255 even at the centre
+    const float det = A * C - B * B;                // > 0.01 A C
+    const float k = 2.0f * r.beta / det;
+    r.u_ext = sqrtf(k * C) * 1.001f + 0.02f;        // (+inf for an infinite opacity: nothing is cut)
+    r.v_ext = sqrtf(k * A) * 1.001f + 0.02f;
+    if (!(r.u_ext == r.u_ext) || !(r.v_ext == r.v_ext)) return r;
+    r.kind = 1;
+    return r;
+}
+
+// The reference's tile rectangle [x0, x1) x [y0, y1) cut down to the tiles the region's bounding box overlaps.
+__device__ __forceinline__ TileRect tight_rect(const LiveRegion& g, float cx, float cy, TileRect rc) {
+    if (g.kind == 0) return rc;
+    if (g.kind == 2) { rc.x1 = rc.x0; rc.y1 = rc.y0; return rc; }
+    // tile column of a pixel coordinate, clamped in float first (the extents may be infinite)
+    const float fx0 = floorf((cx - g.u_ext) * (1.0f / kTile)), fx1 = floorf((cx + g.u_ext) * (1.0f / kTile));
+    const float fy0 = floorf((cy - g.v_ext) * (1.0f / kTile)), fy1 = floorf((cy + g.v_ext) * (1.0f / kTile));
+    const int nx0 = (int)fminf(fmaxf(fx0, (float)rc.x0), (float)rc.x1);
+    const int nx1 = (int)fminf(fmaxf(fx1 + 1.0f, (float)rc.x0), (float)rc.x1);
+    const int ny0 = (int)fminf(fmaxf(fy0, (float)rc.y0), (float)rc.y1);
+    const int ny1 = (int)fminf(fmaxf(fy1 + 1.0f, (float)rc.y0), (float)rc.y1);
+    TileRect t = {nx0, ny0, nx1 > nx0 ? nx1 : nx0, ny1 > ny0 ? ny1 : ny0};
+    if (t.x1 == t.x0 || t.y1 == t.y0) { t.x1 = t.x0; t.y1 = t.y0; }
+    return t;
+}
+
+// Live columns [*ca, *cb) of tile row `ty` inside [x0, x1): empty when ca >= cb.
+__device__ __forceinline__ void row_run(const LiveRegion& g, float cx, float cy, int ty, int x0, int x1, int* ca, int* cb) {
+    *ca = x0; *cb = x1;
+    if (g.kind == 0) return;
+    if (g.kind == 2) { *cb = x0; return; }
+    // d = pixel - centre; the strip of this tile row's pixel rows
+    const float v0 = (float)(ty * kTile) - cy, v1 = (float)(ty * kTile + kTile - 1) - cy;
+    if (v0 > g.v_ext || v1 < -g.v_ext) { *cb = x0; return; }   // the strip misses the ellipse
+    const float A = g.A, B = g.B, C = g.C;
+    const float slope = -B / C;                      // the ellipse's extreme points in u sit at v = slope * u
+    const float two_a_beta = 2.0f * A * g.beta, det = A * C - B * B;
+    float u_hi, u_lo;
+    {
+        const float ve = slope * g.u_ext;            // right extreme (+u_ext, ve)
+        if (ve >= v0 && ve <= v1) u_hi = g.u_ext;
+        else {
+            const float vb = ve < v0 ? v0 : v1;
+            const float disc = two_a_beta - det * vb * vb;
+            u_hi = (-B * vb + sqrtf(fmaxf(disc, 0.f))) / A;
+            u_hi = u_hi + fabsf(u_hi) * 1.0e-3f + 0.02f;
+        }
+    }
+    {
+        const float ve = -slope * g.u_ext;           // left extreme (-u_ext, ve)
+        if (ve >= v0 && ve <= v1) u_lo = -g.u_ext;
+        else {
+            const float vb = ve < v0 ? v0 : v1;
+            const float disc = two_a_beta - det * vb * vb;
+            u_lo = (-B * vb - sqrtf(fmaxf(disc, 0.f))) / A;
+            u_lo = u_lo - fabsf(u_lo) * 1.0e-3f - 0.02f;
+        }
+    }
+    if (!(u_lo == u_lo) || !(u_hi == u_hi)) return;  // keep the whole row
+    const float f0 = floorf((cx + u_lo) * (1.0f / kTile)), f1 = floorf((cx + u_hi) * (1.0f / kTile)) + 1.0f;
+    const int a = (int)fminf(fmaxf(f0, (float)x0), (float)x1), b = (int)fminf(fmaxf(f1, (float)x0), (float)x1);
+    *ca = a;
+    *cb = b > a ? b : a;
+}
+
 // One 48-byte LDS record per staged list entry (quadrant kernel): a single address register serves the three
 // 16-byte broadcast reads, and (r, g) / (b, z) land in even-aligned register pairs for the packed-fp32 updates.
 struct BlendEntry {

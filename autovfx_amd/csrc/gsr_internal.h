@@ -12,14 +12,18 @@ constexpr uint32_t kCulledKey = 0xFFFFFFFFu; // depth key of a Gaussian that pro
 constexpr int kRectPartials = 256;           // partial sums of rectangle areas (power of two)
 constexpr int kRadixTile = 4096;             // pairs per workgroup of a radix pass (gsr_radix.hip)
 constexpr int kDupTile = 1024;               // sorted positions per workgroup of the record gather + scan
+constexpr int kMaxSlabs = 8;                 // front-to-back depth slabs of one call (occlusion culling between slabs)
+constexpr uint32_t kMaskTiles = 64;          // tight rectangles up to this many tiles carry a bit mask of live tiles
 
 // Device words of one forward call that must be zero before its first kernel: ONE memset clears them all.
 // Only the first kCounterCopyBytes travel back to the host.
 struct FrameCounters {
-    unsigned long long pair_totals[kRectPartials];  // (sum of rectangle areas) << 32 | live pairs
+    unsigned long long pair_totals[kRectPartials];  // (sum of rectangle areas) << 32 | upper bound of the live pairs
     uint32_t visible[kRectPartials];                // Gaussians that emit at least the chance of a pair (key != kCulledKey)
+    uint32_t big_rows[kRectPartials];               // tile rows of the splats too large for a mask (sizes the run pool)
     uint32_t error_flag;                            // bit 0 = prefiltered violation
-    uint32_t pad[3];
+    uint32_t pool_used;                             // run pool: rows handed out so far (bin_gather_kernel)
+    uint32_t pad[2];
 };
 constexpr size_t kCounterCopyBytes = sizeof(FrameCounters);
 
@@ -43,15 +47,30 @@ struct GaussianInputs {
     float scale_modifier;
     int prefiltered;
     int tile_cull;  // GSR_OPT_TILE_CULL
+    int defer_colour;  // SH colours are evaluated later, only for the splats that reach a list (sh_colour_kernel)
 };
 
-// Everything the pair expansion needs about one splat, in one 16-byte record so that walking the
-// splats in depth order costs one gather per splat instead of three.
+// Everything the pair expansion needs about one splat, in one 16-byte record so that walking the splats in depth
+// order costs one gather per splat.  The rectangle is the reference's (getRect) cut down to the bounding box of the
+// region where the splat can reach alpha >= 1/255 at all ("tight"); num_rendered keeps counting the reference's.
+//   w * h <= kMaskTiles : (lo, hi) is the 64-bit mask of live tiles, row-major over the tight rectangle
+//   w * h >  kMaskTiles : lo = hi = ~0 here; the live tiles are one run of columns per tile row, worked out when the
+//                         splats are gathered in depth order (bin_gather_kernel) and kept in the run pool
 struct SplatBin {
-    uint32_t xy0;    // first tile of the rectangle: x | y << 16
-    uint32_t width;  // rectangle width in tiles
-    uint32_t mask;   // bit i = i-th tile (row-major) is live; all ones = the whole rectangle
-    uint32_t count;  // live tiles = pairs this splat emits (0 = culled)
+    uint32_t xy0;   // first tile of the tight rectangle: x | y << 16
+    uint32_t wh;    // its size in tiles: w | h << 16; 0 = emits nothing
+    uint32_t lo, hi;
+};
+// The same splat once gathered into depth order (`sorted_bins`): x = xy0, y = wh, and
+//   masked : z, w = the mask (updated in place when a later slab drops tiles that are already finished)
+//   runs   : z = first row of the splat in the run pool, w = live tiles (sum of the run lengths)
+// A pool entry is first_column | end_column << 16 (absolute tile columns, end exclusive; empty when equal).
+
+// One front-to-back depth slab of a call: sorted positions [first, end), and how many pairs it put into its lists.
+struct SlabInfo {
+    uint32_t first, end;
+    uint32_t pairs;        // live pairs expanded for this slab = length of its sorted list (device-side count)
+    uint32_t pad;
 };
 
 // Everything the blend needs about one splat except its colour, in one 32-byte record (never straddles
@@ -74,31 +93,69 @@ struct GeometryArrays {
     uint32_t* ids;        // 0..P-1, the sort payload; nullptr when the sort generates it itself
 };
 
-// ---- kernels (gsr_kernels.hip) ----
+// ---- kernels (gsr_kernels.hip: per-Gaussian and per-pixel streaming kernels) ----
 hipError_t launch_preprocess(const GaussianInputs& in, const Camera& cam, const GeometryArrays& out,
                              hipStream_t stream);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
                                hipStream_t stream);
-hipError_t launch_duplicate(int P, const Camera& cam, const uint32_t* depth_order, const uint32_t* point_offsets,
-                            const SplatBin* bins, uint32_t* tile_keys, uint32_t* point_list, hipStream_t stream);
-// Scan + expansion without any spinning, balanced by pairs (bin_gather / bin_offsets / expand kernels): writes
-// point_offsets (global inclusive), tile_keys and point_list.  sorted_bins: V x 16 B, tile_totals: 2 * ceil(P / kDupTile) words.
-hipError_t launch_scan_expand(int P, int V, uint32_t num_pairs, const Camera& cam, const uint32_t* depth_order,
-                              const SplatBin* bins, uint4* sorted_bins, uint32_t* tile_totals, uint32_t* point_offsets,
-                              uint32_t* tile_keys, uint32_t* point_list, hipStream_t stream);
+// SH colours of the splats of one slab that reached a list (GaussianInputs::defer_colour): positions
+// [slab.first, slab.end) of the depth order whose pair offset moved; rgb[gid] is written.
+hipError_t launch_sh_colour(const GaussianInputs& in, const Camera& cam, int V, const SlabInfo* slab,
+                            const uint32_t* depth_order, const uint32_t* offsets /*inclusive, indexed by position*/,
+                            float* rgb, hipStream_t stream);
+
+// ---- binning (gsr_binning.hip): from the depth order to per-tile lists, slab by slab ----
+// What the binning kernels share for one call.
+struct BinningArrays {
+    int P;                        // Gaussians of the call
+    int V;                        // splats that may emit pairs (visible); positions [0, V) of the depth order
+    int grid_x, grid_y;
+    const uint32_t* depth_order;  // [P] Gaussian ids, ascending depth
+    const SplatBin* bins;         // [P] in Gaussian order (preprocess)
+    const SplatRaster* raster;    // [P] (centre, conic, opacity: the run computation of large splats)
+    uint4* sorted_bins;           // [V] records in depth order
+    uint32_t* offsets;            // [P] POINT_OFFSETS: inclusive live-pair count over the depth order
+    uint32_t* tile_totals;        // [2 * ceil(P / kDupTile)] per-1024-position totals, then offsets at their ends
+    uint32_t* slab_offsets;       // [P] inclusive pair count inside the slab a position belongs to (slabs > 0)
+    uint32_t* slab_tile_totals;   // [2 * ceil(P / kDupTile)] the same for the slab being processed
+    uint32_t* run_pool;           // [pool_rows] column runs of the large splats
+    uint32_t pool_rows;
+    FrameCounters* counters;
+    SlabInfo* slabs;              // [kMaxSlabs] device
+    uint32_t* quad_done;          // [ceil(4T / 32)] one bit per 8x8 quadrant whose 64 pixels have all stopped
+    uint32_t* done_rows;          // [grid_y * row_words] the same per tile, one bit row per tile row
+    int row_words;                // 32-bit words per bit row
+    int tile_cull;
+};
+// gather + tile-local scan + global offsets over all V positions, then the slab boundaries: slab s takes the positions
+// whose inclusive offset lies in (pair_cut[s-1], pair_cut[s]] (pair_cut[num_slabs - 1] = everything that is left).
+hipError_t launch_bin_scan(const BinningArrays& a, const Camera& cam, int num_slabs, const uint32_t* pair_cuts /*host, num_slabs - 1*/,
+                           hipStream_t stream);
+// slabs > 0: drop the tiles finished by the slabs before (done_rows), re-scan inside the slab, set slabs[s].pairs
+hipError_t launch_slab_recount(const BinningArrays& a, int slab, hipStream_t stream);
+// (tile id, Gaussian id) pairs of one slab in depth order; at most pairs_bound of them (the grid is sized for it)
+hipError_t launch_expand(const BinningArrays& a, int slab, uint32_t pairs_bound, uint32_t* tile_keys, uint32_t* point_list,
+                         hipStream_t stream);
+struct ArenaHeader;
+// ranges[t] = [first, last) positions of tile t in the sorted keys ((0,0) when empty); the number of keys is read from
+// slab->pairs.  header_dst may be null; otherwise the three arena headers are stamped by the same launch.
+hipError_t launch_tile_ranges(const SlabInfo* slab, int num_tiles, const uint32_t* sorted_tile_keys, uint2* ranges,
+                              void* const header_dst[3], const ArenaHeader headers[3], hipStream_t stream);
+
+// ---- blend (gsr_blend.hip) ----
+// One list segment per slab; a launch walks segments [seg_begin, seg_end).  `fresh`: pixels start from T = 1 (else
+// the state the previous launch left in the output images is resumed); `final`: every pixel's result is written
+// (else quadrants with live pixels park their state and finished quadrants are marked in quad_done / done_rows).
+struct BlendSegments {
+    const uint2* ranges[kMaxSlabs];
+    const uint32_t* point_list[kMaxSlabs];
+};
+hipError_t launch_blend(const Camera& cam, const BlendSegments& segs, int seg_begin, int seg_end, bool fresh, bool final,
+                        const SplatRaster* raster, const float* features, const float* background, float* out_color,
+                        float* out_depth, float* out_alpha, uint32_t* n_contrib, uint32_t* quad_done, uint32_t* done_rows,
+                        int row_words, hipStream_t stream, const float* extra_features = nullptr, float* out_extra = nullptr);
 // counts the floats with bit patterns first_bits .. first_bits + count - 1 on which the blend's exp differs from expf
 hipError_t launch_exp_selftest(uint32_t first_bits, uint32_t count, unsigned long long* mismatches, hipStream_t stream);
-struct ArenaHeader;
-// ranges[t] = [first, last) positions of tile t in the sorted keys ((0,0) when empty; num_rendered = 0 clears them all);
-// also stamps the three arena headers.
-hipError_t launch_tile_ranges(uint32_t num_rendered, int num_tiles, const uint32_t* sorted_tile_keys, uint2* ranges,
-                              void* const header_dst[3], const ArenaHeader headers[3], hipStream_t stream);
-// variant 0: one wave per tile, 4 pixels per lane; variant 1: one wave per 8x8 quadrant
-hipError_t launch_blend(const Camera& cam, int variant, int lds_pad_bytes, const uint2* ranges, const uint32_t* point_list,
-                        const SplatRaster* raster, const float* features, const float* background, float* out_color,
-                        float* out_depth, float* out_alpha, uint32_t* n_contrib, hipStream_t stream,
-                        const float* extra_features = nullptr /*[P,3]: a second feature set ...*/,
-                        float* out_extra = nullptr /*... composited into [3,H,W] in the same walk*/);
 
 // First 256 bytes of each scratch arena: what the backward pass needs to find the forward's arrays
 // again.  The reference re-derives its layout from sizes (rasterizer_impl.cu:381-383 fromChunk);
@@ -107,10 +164,13 @@ constexpr uint32_t kArenaMagic = 0x47535231u;  // "GSR1"
 struct ArenaHeader {
     uint32_t magic;
     uint32_t kind;      // 0 geometry, 1 binning, 2 image
-    uint32_t count[4];  // geometry: P, num_rendered (reference), live pairs; binning: live pairs; image: W, H, T
+    uint32_t count[4];  // geometry: P, num_rendered (reference), slabs, inference flag; binning: slabs; image: W, H, T, slabs
     uint32_t pad[2];
-    uint64_t off[8];    // byte offsets from the header's own address
+    uint64_t off[8];    // byte offsets from the header's own address (geometry: 0 raster, 3 rgb, 4 radii, 5 slab table,
+                        // 6 quadrant bits, 7 tile bit rows; image: 1 n_contrib)
+    uint64_t slab_off[kMaxSlabs];  // binning: the sorted point list of slab s; image: its tile ranges
 };
+static_assert(sizeof(ArenaHeader) <= 256, "arena headers occupy the first 256 bytes");
 
 struct BackwardInputs {
     int P, sh_degree, M;
@@ -152,31 +212,16 @@ hipError_t launch_normal_maps(int width, int height, const float* normal_rgb, co
 hipError_t launch_pack_rgba8(const float* color, const float* alpha, uint8_t* out, size_t n_pixels,
                              hipStream_t stream);
 
-// ---- device-wide primitives (gsr_sort.hip) ----
-// All three follow the two-call protocol: with temp == nullptr they only report temp_bytes.
-hipError_t depth_sort_temp_bytes(int P, size_t* temp_bytes);
-// Stable ascending sort of (depth_keys, ids) over all 32 key bits.  Buffers *_alt are the ping-pong
-// partners; on return *keys_sorted / *ids_sorted point at whichever buffer holds the result.
-hipError_t depth_sort(void* temp, size_t temp_bytes, int P, uint32_t* keys, uint32_t* keys_alt, uint32_t* ids,
-                      uint32_t* ids_alt, uint32_t** keys_sorted, uint32_t** ids_sorted, hipStream_t stream);
-hipError_t scan_temp_bytes(int P, size_t* temp_bytes);
-// offsets[k] = sum_{j<=k} bins[order[j]].count
-hipError_t scan_tiles_in_order(void* temp, size_t temp_bytes, int P, const SplatBin* bins, const uint32_t* order,
-                               uint32_t* offsets, hipStream_t stream);
-hipError_t tile_sort_temp_bytes(uint32_t n, size_t* temp_bytes);
-// Stable ascending sort of (tile_keys, point_list) on the low `bits` key bits.
-hipError_t tile_sort(void* temp, size_t temp_bytes, uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt,
-                     uint32_t* vals, uint32_t* vals_alt, uint32_t** keys_sorted, uint32_t** vals_sorted,
-                     hipStream_t stream);
-
-
 // ---- hand-written radix sort (gsr_radix.hip) ----
 // Stable ascending LSD sort on the low `bits` key bits, 8 per pass (count / scan / scatter kernels, no spinning,
 // nothing to zero-fill).  scratch: radix_scratch_words(n) u32 words of any content.  iota_payload: the payload
 // is 0..n-1 and `vals` is not read.  want_sorted_keys = false skips the key stores of the last pass.
+// n_device (nullable): the number of pairs is read from this device word by every kernel (it must not exceed n, which
+// then only sizes the launches and the scratch layout): a sort can be queued before its size is known on the host.
 size_t radix_scratch_words(uint32_t n);
 hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt,
                             uint32_t* vals, uint32_t* vals_alt, bool iota_payload, bool want_sorted_keys,
-                            uint32_t** keys_sorted, uint32_t** vals_sorted, hipStream_t stream);
+                            uint32_t** keys_sorted, uint32_t** vals_sorted, hipStream_t stream,
+                            const uint32_t* n_device = nullptr);
 
 } // namespace gsr

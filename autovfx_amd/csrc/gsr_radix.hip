@@ -73,10 +73,12 @@ __device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t* sc
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kThreads) radix_count_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
                                                               uint32_t digit_mask, uint32_t* __restrict__ counts,
-                                                              uint32_t tiles_pad) {
+                                                              uint32_t tiles_pad, const uint32_t* __restrict__ n_device) {
     __shared__ uint32_t s_hist[kCountCopies][256];
     const int tid = threadIdx.x;
     const uint32_t block = blockIdx.x;
+    if (n_device != nullptr) n = *n_device;  // the launch was sized for an upper bound
+    if (block * (uint32_t)kTileItems >= n) return;
 #pragma unroll
     for (int j = 0; j < kCountCopies; ++j) s_hist[j][tid] = 0u;
     __syncthreads();
@@ -109,9 +111,11 @@ __global__ void __launch_bounds__(kThreads) radix_count_kernel(const uint32_t* _
 // totals[digit] = number of keys with that digit.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kThreads) radix_scan_kernel(uint32_t* __restrict__ counts, uint32_t tiles,
-                                                             uint32_t tiles_pad, uint32_t* __restrict__ totals) {
+                                                             uint32_t tiles_pad, uint32_t* __restrict__ totals,
+                                                             const uint32_t* __restrict__ n_device) {
     __shared__ uint32_t s_scan[kWaves];
     const int tid = threadIdx.x;
+    if (n_device != nullptr) tiles = (*n_device + (uint32_t)kTileItems - 1u) / (uint32_t)kTileItems;
     uint4* row = reinterpret_cast<uint4*>(counts + (size_t)blockIdx.x * tiles_pad);  // tiles_pad is a multiple of 4
     uint32_t carry = 0;
     for (uint32_t t0 = 0; t0 < tiles; t0 += 4u * kThreads) {
@@ -140,7 +144,8 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t*
                                                                 uint32_t* __restrict__ keys_out,
                                                                 uint32_t* __restrict__ vals_out, uint32_t n, int shift,
                                                                 uint32_t digit_mask, const uint32_t* __restrict__ offsets,
-                                                                uint32_t tiles_pad, const uint32_t* __restrict__ totals) {
+                                                                uint32_t tiles_pad, const uint32_t* __restrict__ totals,
+                                                                const uint32_t* __restrict__ n_device) {
     __shared__ uint32_t s_keys[kTileItems];
     __shared__ uint32_t s_vals[kTileItems];
     __shared__ uint32_t s_count[kWaves][256];  // per-wave digit counts, then per-wave offsets inside the segment
@@ -150,6 +155,8 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t*
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t block = blockIdx.x;
+    if (n_device != nullptr) n = *n_device;  // the launch was sized for an upper bound
+    if (block * (uint32_t)kTileItems >= n) return;
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) s_count[w][tid] = 0u;
     const uint32_t tile_base = block * (uint32_t)kTileItems;
@@ -246,7 +253,7 @@ size_t radix_scratch_words(uint32_t n) {
 
 hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt,
                             uint32_t* vals, uint32_t* vals_alt, bool iota_payload, bool want_sorted_keys,
-                            uint32_t** keys_sorted, uint32_t** vals_sorted, hipStream_t stream) {
+                            uint32_t** keys_sorted, uint32_t** vals_sorted, hipStream_t stream, const uint32_t* n_device) {
     *keys_sorted = keys;
     *vals_sorted = vals;
     if (n == 0 || bits <= 0) return hipSuccess;
@@ -262,11 +269,11 @@ hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* k
         const uint32_t mask = (1u << width) - 1u;
         const bool iota = iota_payload && p == 0;
         const bool keys_out = want_sorted_keys || p + 1 < passes;
-        hipLaunchKernelGGL(radix_count_kernel, dim3(tiles), dim3(kThreads), 0, stream, kin, n, 8 * p, mask, counts, tiles_pad);
-        hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(kThreads), 0, stream, counts, tiles, tiles_pad, totals);
+        hipLaunchKernelGGL(radix_count_kernel, dim3(tiles), dim3(kThreads), 0, stream, kin, n, 8 * p, mask, counts, tiles_pad, n_device);
+        hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(kThreads), 0, stream, counts, tiles, tiles_pad, totals, n_device);
 #define GSR_RADIX_LAUNCH(I, K)                                                                                    \
     hipLaunchKernelGGL((radix_scatter_kernel<I, K>), dim3(tiles), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, \
-                       8 * p, mask, counts, tiles_pad, totals)
+                       8 * p, mask, counts, tiles_pad, totals, n_device)
         if (iota && keys_out) GSR_RADIX_LAUNCH(true, true);
         else if (iota) GSR_RADIX_LAUNCH(true, false);
         else if (keys_out) GSR_RADIX_LAUNCH(false, true);

@@ -107,7 +107,7 @@ def rasterize_begin(cloud: GaussianCloud, cam: Camera, bg: torch.Tensor) -> Pend
         pending = _C.rasterize_gaussians_begin(
             s.bg, cloud.means3D, colors, cloud.opacities, cloud.scales, cloud.rotations, s.scale_modifier, absent,
             s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, shs, s.sh_degree,
-            s.campos, s.prefiltered, s.debug)
+            s.campos, s.prefiltered, s.debug, inference=True)
     return PendingFrame(pending, (s, absent))
 
 

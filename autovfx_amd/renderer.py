@@ -225,9 +225,9 @@ def _render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_col
                     "visibility_filter": radii > 0, "radii": radii}
 
         if split:
-            pending = _C.rasterize_gaussians_begin(*call_args)
+            pending = _C.rasterize_gaussians_begin(*call_args, inference=True)   # (fused: autograd is off)
             return PendingRender(lambda: assemble(pending.finish()))
-        return assemble(_C.rasterize_gaussians_extra(*call_args))
+        return assemble(_C.rasterize_gaussians_extra(*call_args, inference=True))
     else:
         rendered_image, depth_image, alpha_image, radii = rasterizer(
             means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity, scales=scales,

@@ -93,10 +93,10 @@ def main():
                     help="op: one GaussianRasterizer.forward per frame (the headline); render: the reference's "
                          "whole per-frame render() = activations + SH pass + normal pass + normal post-processing")
     ap.add_argument("--no-geometry-cache", action="store_true", help="A/B knob: recompute geometry for the 2nd pass")
-    ap.add_argument("--blend-variant", type=int, default=None, help="A/B knob: GSR_OPT_BLEND_VARIANT")
     ap.add_argument("--no-cull", action="store_true", help="A/B knob: GSR_OPT_TILE_CULL = 0")
-    ap.add_argument("--blend-lds-pad", type=int, default=None, help="A/B knob: GSR_OPT_BLEND_LDS_PAD (bytes)")
-    ap.add_argument("--sort-impl", type=int, default=None, help="A/B knob: GSR_OPT_SORT_IMPL (0 = rocPRIM passes)")
+    ap.add_argument("--slabs", type=int, default=None, help="A/B knob: GSR_OPT_SLABS (1 = no depth slabs; default: as the scene calls for)")
+    ap.add_argument("--slab-first", type=int, default=None, help="A/B knob: GSR_OPT_SLAB_FIRST (pairs per tile in the first slab)")
+    ap.add_argument("--no-defer-colour", action="store_true", help="A/B knob: GSR_OPT_DEFER_COLOUR = 0")
     args = ap.parse_args()
 
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner to the C-level stdout when a process
@@ -129,14 +129,14 @@ def main():
     from autovfx_amd.frame_parallel import pack_rgba8, rasterize, rasterize_begin, render_and_gather, side_streams
     from diff_gaussian_rasterization import _C
 
-    if args.blend_variant is not None:
-        _lib.set_option(_lib.OPT_BLEND_VARIANT, args.blend_variant)
     if args.no_cull:
         _lib.set_option(_lib.OPT_TILE_CULL, 0)
-    if args.sort_impl is not None:
-        _lib.set_option(_lib.OPT_SORT_IMPL, args.sort_impl)
-    if args.blend_lds_pad is not None:
-        _lib.set_option(_lib.OPT_BLEND_LDS_PAD, args.blend_lds_pad)
+    if args.slabs is not None:
+        _lib.set_option(_lib.OPT_SLABS, args.slabs)
+    if args.slab_first is not None:
+        _lib.set_option(_lib.OPT_SLAB_FIRST, args.slab_first)
+    if args.no_defer_colour:
+        _lib.set_option(_lib.OPT_DEFER_COLOUR, 0)
     wl = WORKLOADS[args.workload]
     W, H, F = wl["width"], wl["height"], wl["frames"]
     cfg = getattr(scenes, wl["cfg"])
@@ -300,13 +300,13 @@ def main():
 
     calls = stage_ms.pop("calls")
     stage_alg = {"preprocess": alg["preprocess"], "depth_sort": 0, "scan": alg["scan"], "duplicate": alg["duplicate"],
-                 "tile_sort": alg["sort"], "ranges": alg["ranges"], "blend": alg["blend"]}
+                 "tile_sort": alg["sort"], "ranges": alg["ranges"], "blend": alg["blend"], "colour": 0}
     stages = {k: {"ms": round(v, 4), "alg_bytes": int(stage_alg[k]),
                   "alg_GBps": round(stage_alg[k] / (v * 1e-3) / 1e9, 1) if v > 0 else None}
               for k, v in stage_ms.items()}
     dom = max(stage_ms, key=stage_ms.get)
-    kernel_of = {"blend": "blend_quadrant_kernel" if _lib.get_option(_lib.OPT_BLEND_VARIANT) == 1 else "blend_kernel",
-                 "preprocess": "preprocess_kernel", "duplicate": "duplicate_kernel", "ranges": "tile_ranges_kernel"}
+    kernel_of = {"blend": "blend_quadrant_kernel", "preprocess": "preprocess_kernel", "duplicate": "expand_kernel",
+                 "ranges": "tile_ranges_kernel", "colour": "sh_colour_kernel"}
     traffic, traffic_src = pmc_traffic(kernel_of.get(dom, dom)) if (args.workload == "c3" and not args.gaussians) else (None, None)
     dom_gbps = stage_alg[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
     frame_gbps = alg["frame"] / (ms_per_step * 1e-3) / 1e9
@@ -347,7 +347,8 @@ def main():
                                    + ("; RCCL gather of the RGBA8 frames to rank 0, pipelined behind the rendering" if distributed and not args.no_gather else ""),
                        "parallelism": f"frame-parallel x{world}", "streams_per_gpu": S, "stream_driver": driver if S > 1 else "serial",
                        "options": {"tile_cull": _lib.get_option(_lib.OPT_TILE_CULL),
-                                   "blend_variant": _lib.get_option(_lib.OPT_BLEND_VARIANT)}},
+                                   "slabs": _lib.get_option(_lib.OPT_SLABS), "slab_first": _lib.get_option(_lib.OPT_SLAB_FIRST),
+                                   "defer_colour": _lib.get_option(_lib.OPT_DEFER_COLOUR)}},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         if reference_on_gpu is not None:

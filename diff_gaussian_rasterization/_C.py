@@ -125,24 +125,35 @@ def rgba_planes(color: torch.Tensor, alpha: torch.Tensor) -> torch.Tensor:
 
 
 def last_layout() -> dict:
-    """Byte offsets of every scratch sub-array of this thread's most recent forward call
-    (introspection for the parity tests; not part of the reference surface)."""
-    return dict(getattr(_tls, "last_layout", None) or {})
+    """Byte offsets of every scratch sub-array of this thread's most recent forward call, and its pair counts
+    (introspection for the parity tests; not part of the reference surface).  The pair counts past the sizing
+    read-back stay on the device during a call: asking for them here waits for that call's stream."""
+    lay = dict(getattr(_tls, "last_layout", None) or {})
+    if lay and "counts" not in lay:
+        lay["counts"] = _lib.pair_counts()
+        lay["slab_pairs"] = _lib.slab_pairs()
+    return lay
 
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug) -> Tuple[int, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor,
-                                                     torch.Tensor, torch.Tensor, torch.Tensor]:
-    """The reference's 19-argument forward (``DGR/rasterize_points.h:18-38``) and its 8-tuple."""
+                        prefiltered, debug, *, inference: bool = False
+                        ) -> Tuple[int, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor,
+                                   torch.Tensor, torch.Tensor, torch.Tensor]:
+    """The reference's 19-argument forward (``DGR/rasterize_points.h:18-38``) and its 8-tuple.
+
+    ``inference`` (keyword only, not in the reference): the caller will not differentiate this call, so the library
+    may cut the lists into depth slabs and skip what finished tiles no longer need (``GSR_FORWARD_INFERENCE``); the
+    images, radii and the returned count are bit-identical either way, the scratch buffers are only good for a second
+    blend, not for ``rasterize_gaussians_backward``."""
     return _rasterize(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                       viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                      prefiltered, debug, None)[:8]
+                      prefiltered, debug, None, inference)[:8]
 
 
 def rasterize_gaussians_extra(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                               viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                              prefiltered, debug, extra_colors):
+                              prefiltered, debug, extra_colors, *, inference: bool = False):
     """``rasterize_gaussians`` plus a second feature triple per Gaussian composited in the same pass
     (``gsr_forward_extra``): returns the 8-tuple and ``extra_image[3,H,W]``, which equals the colour image of a
     second call with ``colors = extra_colors`` bit for bit.  Not part of the reference surface; used by
@@ -151,12 +162,12 @@ def rasterize_gaussians_extra(background, means3D, colors, opacity, scales, rota
         raise RuntimeError("extra_colors must have dimensions (num_points, 3)")
     return _rasterize(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                       viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                      prefiltered, debug, extra_colors)
+                      prefiltered, debug, extra_colors, inference)
 
 
 def _rasterize(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-               prefiltered, debug, extra_colors):
+               prefiltered, debug, extra_colors, inference=False):
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     device = _require_gpu(means3D, "means3D")
@@ -178,7 +189,7 @@ def _rasterize(background, means3D, colors, opacity, scales, rotations, scale_mo
     key = None
     if P != 0 and _GEOMETRY_CACHE:
         key = _geometry_key(geometry_inputs, (float(scale_modifier), float(tan_fovx), float(tan_fovy), H, W,
-                                              bool(prefiltered), _lib.get_option(_lib.OPT_TILE_CULL),
+                                              bool(prefiltered), _lib.get_option(_lib.OPT_TILE_CULL), bool(inference),
                                               torch.cuda.current_stream(device).cuda_stream))
         hit = getattr(_tls, "cache", None)
         _tls.cache = None   # whatever happens next, the entry has had its one chance
@@ -203,22 +214,22 @@ def _rasterize(background, means3D, colors, opacity, scales, rotations, scale_mo
                         _ptr(cov_), _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx), float(tan_fovy),
                         1 if prefiltered else 0, out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(),
                         radii.data_ptr())
-                if extra_colors is None:
+                flags = _lib.FORWARD_INFERENCE if inference else 0
+                if extra_colors is None and not flags:
                     rendered = _lib.lib.gsr_forward(*head, 1 if debug else 0, ctypes.c_void_p(stream))
                 else:
-                    ext_ = _f32c("extra_colors", extra_colors, device)
-                    rendered = _lib.lib.gsr_forward_extra(*head, ext_.data_ptr(), out_extra.data_ptr(),
-                                                          1 if debug else 0, ctypes.c_void_p(stream))
+                    ext_ = None if extra_colors is None else _f32c("extra_colors", extra_colors, device)
+                    rendered = _lib.lib.gsr_forward_extra(*head, _ptr(ext_), None if ext_ is None else out_extra.data_ptr(),
+                                                          flags, 1 if debug else 0, ctypes.c_void_p(stream))
         finally:
             _tls.call = None
         if rendered < 0:
             raise RuntimeError(f"gsr_forward failed ({rendered}): {_lib.last_error()}")
         # per-thread: the library keeps these per calling thread too, and streams are driven by separate threads
-        layout = {"geom": _lib.offsets("geom"), "binning": _lib.offsets("binning"), "image": _lib.offsets("image"),
-                  "counts": _lib.pair_counts()}
-        _tls.last_layout = layout
+        # (the pair counts are fetched by last_layout() on demand: they would cost a wait for the stream here)
+        _tls.last_layout = {"geom": _lib.offsets("geom"), "binning": _lib.offsets("binning"), "image": _lib.offsets("image")}
         if key is not None and extra_colors is None:   # (a fused two-feature call has no second pass to wait for)
-            _tls.cache = {"key": key, "inputs": geometry_inputs, "layout": layout,
+            _tls.cache = {"key": key, "inputs": geometry_inputs,
                           "rendered": rendered, "radii": radii, "geom": scratch.buffers["geom"],
                           "binning": scratch.buffers["binning"], "image": scratch.buffers["image"]}
     return (rendered, out_color, out_depth, out_alpha, radii, scratch.buffers["geom"], scratch.buffers["binning"],
@@ -256,7 +267,7 @@ class PendingForward:
             if rendered < 0:
                 raise RuntimeError(f"gsr_forward_finish failed ({rendered}): {_lib.last_error()}")
             _tls.last_layout = {"geom": _lib.offsets("geom"), "binning": _lib.offsets("binning"),
-                                "image": _lib.offsets("image"), "counts": _lib.pair_counts()}
+                                "image": _lib.offsets("image")}
         b = self._scratch.buffers
         self._inputs = None
         return rendered, out_color, out_depth, out_alpha, radii, b["geom"], b["binning"], b["image"], out_extra
@@ -268,7 +279,7 @@ class PendingForward:
 
 def rasterize_gaussians_begin(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                               viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                              prefiltered, debug, extra_colors=None) -> PendingForward:
+                              prefiltered, debug, extra_colors=None, *, inference: bool = False) -> PendingForward:
     """First half of ``rasterize_gaussians`` (same 19 arguments): everything up to the point where the host has to
     learn the pair count is queued on the current stream and the call returns without waiting.  ``finish()`` on the
     result queues the rest.  One host thread can so keep a frame in flight on each of several streams; results are
@@ -309,7 +320,7 @@ def rasterize_gaussians_begin(background, means3D, colors, opacity, scales, rota
                 _ptr(cov_), _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx), float(tan_fovy),
                 1 if prefiltered else 0, out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(),
                 radii.data_ptr(), _ptr(ext_), None if ext_ is None else out_extra.data_ptr(),
-                1 if debug else 0, ctypes.c_void_p(stream))
+                _lib.FORWARD_INFERENCE if inference else 0, 1 if debug else 0, ctypes.c_void_p(stream))
     finally:
         _tls.call = None
     if not handle:
@@ -318,18 +329,15 @@ def rasterize_gaussians_begin(background, means3D, colors, opacity, scales, rota
 
 
 def _blend_cached(hit, background, colors, device, H, W, out_color, out_depth, out_alpha):
-    """Second pass over cached geometry: one blend launch (gsr_blend)."""
-    lay, geom, binning, image = hit["layout"], hit["geom"], hit["binning"], hit["image"]
+    """Second pass over cached geometry: one blend launch over the first pass's lists (gsr_blend)."""
+    geom, binning, image = hit["geom"], hit["binning"], hit["image"]
     bg_, col_ = _f32c("background", background, device), _f32c("colors", colors, device)
-    g, b, i = lay["geom"], lay["binning"], lay["image"]
     with torch.cuda.device(device):
-        rc = _lib.lib.gsr_blend(
-            W, H, image.data_ptr() + i["ranges"], binning.data_ptr() + b["point_list"],
-            geom.data_ptr() + g["raster"], col_.data_ptr(), bg_.data_ptr(), out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(),
-            image.data_ptr() + i["n_contrib"], ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+        rc = _lib.lib.gsr_blend(geom.data_ptr(), binning.data_ptr(), image.data_ptr(), W, H, col_.data_ptr(), bg_.data_ptr(),
+                                out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(),
+                                ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
     if rc != 0:
         raise RuntimeError(f"gsr_blend failed ({rc}): {_lib.last_error()}")
-    _tls.last_layout = lay
     return hit["rendered"], out_color, out_depth, out_alpha, hit["radii"].clone(), geom, binning, image, None
 
 

@@ -14,6 +14,7 @@ Forward and backward are both native (``gsr_forward`` / ``gsr_backward``), so th
 """
 from __future__ import annotations
 
+import functools
 from typing import NamedTuple, Optional
 
 import torch
@@ -72,8 +73,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         native_args = (s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp,
                        s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, sh,
                        s.sh_degree, s.campos, s.prefiltered, s.debug)
+        # Nothing upstream wants a gradient (torch.no_grad(), or plain tensors): the binding may say so, and the library
+        # then builds its lists the cheaper way (include/gsr.h: GSR_FORWARD_INFERENCE); same images, same radii.
+        inference = not any(ctx.needs_input_grad)
+        forward_fn = functools.partial(_C.rasterize_gaussians, inference=inference)
         (num_rendered, color, depth, alpha, radii, geom_buffer, binning_buffer, img_buffer) = _call_with_snapshot(
-            _C.rasterize_gaussians, native_args, s.debug, _SNAPSHOT_FW, "forward")
+            forward_fn, native_args, s.debug, _SNAPSHOT_FW, "forward")
         ctx.raster_settings = s
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buffer,

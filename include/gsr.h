@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 4
+#define GSR_ABI_VERSION 5
 
 #if defined(__GNUC__)
 #define GSR_API __attribute__((visibility("default")))
@@ -86,6 +86,19 @@ GSR_API int gsr_forward(gsr_alloc_fn geom_alloc, void* geom_user,
                 float* out_color, float* out_depth, float* out_alpha, int* radii /*nullable*/,
                 int debug, void* stream);
 
+/* Per-call flags of gsr_forward_extra / gsr_forward_begin (gsr_forward itself always makes a full call: 0).
+ *
+ * GSR_FORWARD_INFERENCE: the caller will not run gsr_backward on this call's scratch (the reference's binding cannot
+ * know that; a Python binding can: nothing requires a gradient).  The images, radii and the returned num_rendered are
+ * bit-identical with or without the flag; what changes is how the lists are built:
+ *   - the depth-sorted splats are expanded, sorted and blended in front-to-back depth SLABS, and a slab drops every
+ *     (tile, Gaussian) pair whose tile has all its 256 pixels finished by the slabs in front of it -- the reference's
+ *     block-wide early exit (forward.cu:312-314) applied before the pair is written instead of after it was sorted;
+ *   - SH colours are evaluated only for the splats that reach a list (the reference evaluates every visible one).
+ * The scratch then holds one list per slab (gsr_blend walks them; gsr_backward rejects them with a clear error). */
+#define GSR_FORWARD_INFERENCE 1u
+#define GSR_MAX_SLABS 8
+
 /* gsr_forward with a SECOND per-Gaussian feature triple composited in the same walk of the per-tile lists:
  * out_extra[3,H,W] = sum_i extra_features[i] * alpha_i * T_i + T_final * background, exactly what a second
  * gsr_forward call with colors_precomp = extra_features would put into its out_color (same alpha, same
@@ -100,7 +113,8 @@ GSR_API int gsr_forward_extra(gsr_alloc_fn geom_alloc, void* geom_user, gsr_allo
                               const float* cov3D_precomp /*nullable*/, const float* viewmatrix, const float* projmatrix,
                               const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
                               float* out_depth, float* out_alpha, int* radii /*nullable*/,
-                              const float* extra_features /*[P,3]*/, float* out_extra /*[3,H,W]*/, int debug, void* stream);
+                              const float* extra_features /*[P,3], nullable*/, float* out_extra /*[3,H,W], nullable*/,
+                              unsigned flags, int debug, void* stream);
 
 /* gsr_forward_extra in two halves, for callers that keep several frames in flight from ONE host thread.
  *
@@ -127,7 +141,7 @@ GSR_API void* gsr_forward_begin(gsr_alloc_fn geom_alloc, void* geom_user, gsr_al
                                 const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
                                 float tan_fovy, int prefiltered, float* out_color, float* out_depth, float* out_alpha,
                                 int* radii /*nullable*/, const float* extra_features /*nullable*/,
-                                float* out_extra /*nullable*/, int debug, void* stream);
+                                float* out_extra /*nullable*/, unsigned flags, int debug, void* stream);
 GSR_API int gsr_forward_finish(void* call);
 GSR_API void gsr_forward_cancel(void* call);
 
@@ -137,15 +151,17 @@ GSR_API int gsr_mark_visible(int P, const float* means3D, const float* viewmatri
 
 /*
  * The blend stage on its own (renderCUDA, DGR/cuda_rasterizer/forward.cu:261-378): composite `features`
- * [P,3] over the per-tile lists of an earlier gsr_forward call.  gaussian_renderer.render() rasterizes every
+ * [P,3] over the per-tile lists of an earlier forward call.  gaussian_renderer.render() rasterizes every
  * frame twice over identical geometry -- SH colours, then normals as colors_precomp
  * (gaussian_renderer/__init__.py:151-159,176-184) -- and the reference recomputes projection, keys and the
- * sort for the second pass; with this entry point the second pass costs one kernel.  All pointers are
- * sub-arrays of that call's scratch arenas (gsr_last_*_offsets) or caller tensors; n_contrib may be NULL.
+ * sort for the second pass; with this entry point the second pass costs one kernel.
+ *   geom/binning/image_buffer   the three scratch arenas of that call, untouched since (the pointers its scratch
+ *                     callbacks returned); they are self-describing, any number of depth slabs is handled
+ * The outputs are those of a forward call with colors_precomp = features over the same geometry, bit for bit.
  */
-GSR_API int gsr_blend(int width, int height, const uint32_t* ranges, const uint32_t* point_list,
-                      const float* raster, const float* features, const float* background, float* out_color,
-                      float* out_depth, float* out_alpha, uint32_t* n_contrib /*nullable*/, void* stream);
+GSR_API int gsr_blend(const char* geom_buffer, const char* binning_buffer, const char* image_buffer, int width, int height,
+                      const float* features, const float* background, float* out_color, float* out_depth,
+                      float* out_alpha, void* stream);
 
 /*
  * Compositor: the per-pixel layer arithmetic of blender/blend_all.py::blend_frames
@@ -239,8 +255,9 @@ typedef enum gsr_geom_slot {
     GSR_GEOM_RASTER = 0,        /* f32[8P]  per splat: pixel x, y, conic xx, xy, yy (inverse 2D covariance),
                                    opacity, view-space z, -ln(255 opacity) - 1e-4 -- valid where radii > 0             */
     GSR_GEOM_RGB,               /* f32[3P]  SH-evaluated colour (unused with colors_precomp)       */
-    GSR_GEOM_SPLAT_BINS,        /* u32[4P]  per splat: first tile x | y << 16, rectangle width, live-tile mask
-                                   (~0 = all), live tiles = pairs emitted (0 = culled); GSR_OPT_TILE_CULL */
+    GSR_GEOM_SPLAT_BINS,        /* u32[4P]  per splat: first tile x | y << 16 and size w | h << 16 of its tight rectangle
+                                   (0 = emits nothing), then the 64-bit mask of its live tiles when w * h <= 64 (all ones
+                                   for a larger splat, whose live tiles are found later); GSR_OPT_TILE_CULL */
     GSR_GEOM_INTERNAL_RADII,    /* i32[P]   used when the caller passes radii == NULL              */
     GSR_GEOM_DEPTH_ORDER,       /* u32[P]   Gaussian ids, ascending (depth bits, id); culled last  */
     GSR_GEOM_POINT_OFFSETS,     /* u32[P]   inclusive scan of the pair counts in DEPTH_ORDER order     */
@@ -248,13 +265,15 @@ typedef enum gsr_geom_slot {
 } gsr_geom_slot;
 
 typedef enum gsr_binning_slot {
-    GSR_BIN_POINT_LIST = 0,     /* u32[live pairs] Gaussian ids sorted by (tile, depth bits, id); see GSR_OPT_TILE_CULL */
-    GSR_BIN_TILE_KEYS,          /* u32[live pairs] tile id of each entry of POINT_LIST                */
+    GSR_BIN_POINT_LIST = 0,     /* u32[live pairs] Gaussian ids sorted by (tile, depth bits, id); see GSR_OPT_TILE_CULL.
+                                   An inference call has one list per depth slab: this is the first slab's. */
+    GSR_BIN_TILE_KEYS,          /* u32[live pairs] tile id of each entry of the LAST slab's list (full calls: of POINT_LIST) */
     GSR_BIN_NUM_SLOTS
 } gsr_binning_slot;
 
 typedef enum gsr_image_slot {
-    GSR_IMG_RANGES = 0,         /* u32[2T] [begin,end) into POINT_LIST per 16x16 tile; (0,0) if empty */
+    GSR_IMG_RANGES = 0,         /* u32[2T] [begin,end) into POINT_LIST per 16x16 tile; (0,0) if empty (inference calls:
+                                   one such table per depth slab, back to back) */
     GSR_IMG_N_CONTRIB,          /* u32[W*H] 1-based list position of the last blended entry          */
     GSR_IMG_NUM_SLOTS
 } gsr_image_slot;
@@ -264,8 +283,12 @@ GSR_API int gsr_last_geom_offsets(size_t offsets[GSR_GEOM_NUM_SLOTS]);
 GSR_API int gsr_last_binning_offsets(size_t offsets[GSR_BIN_NUM_SLOTS]);
 GSR_API int gsr_last_image_offsets(size_t offsets[GSR_IMG_NUM_SLOTS]);
 /* counts[0] = num_rendered as the reference defines it (sum of rectangle areas, the return value of
- * gsr_forward); counts[1] = live pairs = length of POINT_LIST / TILE_KEYS. */
+ * gsr_forward); counts[1] = live pairs = pairs that were expanded and sorted (the length of POINT_LIST for a full
+ * call).  Past the sizing read-back a call keeps its pair counts on the device; this accessor waits for the call's
+ * stream to reach the copy it queued at its end. */
 GSR_API int gsr_last_pair_counts(uint32_t counts[2]);
+/* Pairs in the list of each depth slab of that call; returns the number of slabs (1 for a full call). */
+GSR_API int gsr_last_slab_pairs(uint32_t pairs[GSR_MAX_SLABS]);
 
 /* ---- options (process-wide; defaults in brackets) ---- */
 typedef enum gsr_option {
@@ -273,18 +296,19 @@ typedef enum gsr_option {
      * no pixel of the tile can reach alpha >= 1/255 is never expanded, sorted or blended.
      * color / depth / alpha / radii and the returned num_rendered are bit-identical with the option
      * on or off; POINT_LIST then holds only the live pairs (a subsequence of the reference's list,
-     * same order), and SPLAT_BINS / POINT_OFFSETS / RANGES / N_CONTRIB count live pairs.
+     * same order), and SPLAT_BINS / POINT_OFFSETS / RANGES / N_CONTRIB count live pairs.  Splats of any size are
+     * culled: a bit mask over the tight rectangle up to 64 tiles, one run of live columns per tile row above.
      * 0 reproduces the reference's lists exactly. */
     GSR_OPT_TILE_CULL = 0,
-    /* [1] Blend kernel shape: 0 = one wave64 per 16x16 tile (4 pixels per lane), 1 = one wave64 per
-     * 8x8 quadrant with per-quadrant entry skipping.  Same results; a tuning / A-B knob. */
-    GSR_OPT_BLEND_VARIANT = 1,
-    /* [0] Bytes of unused dynamic LDS added to every blend workgroup (variant 1) to cap its occupancy and
-     * leave wave slots for the memory-bound stages of another frame on a second stream.  A tuning knob. */
-    GSR_OPT_BLEND_LDS_PAD = 2,
-    /* [1] Sort / scan stages: 1 = this library's own one-sweep radix passes and the prefix sum fused into the
-     * pair expansion (no memsets, 13 launches per call), 0 = rocPRIM device primitives.  Same results. */
-    GSR_OPT_SORT_IMPL = 3,
+    /* [0 = as many as the scene calls for, up to GSR_MAX_SLABS] Most depth slabs an inference call
+     * (GSR_FORWARD_INFERENCE) may use; 1 switches the occlusion culling between slabs off.  Same images. */
+    GSR_OPT_SLABS = 1,
+    /* [400] Pairs per tile, on average, that the first depth slab holds; every further slab is three times as large
+     * as the one before.  A tuning knob: the first slab should finish most tiles of a scene with an opaque front. */
+    GSR_OPT_SLAB_FIRST = 2,
+    /* [1] Inference calls evaluate SH colours only for the splats that reach a list (0: for every visible one, in the
+     * projection kernel, as full calls do).  Same bits wherever a colour is used. */
+    GSR_OPT_DEFER_COLOUR = 3,
     GSR_OPT_NUM
 } gsr_option;
 GSR_API int gsr_set_option(int option, int value);
@@ -294,11 +318,12 @@ GSR_API int gsr_get_option(int option);
 typedef enum gsr_stage {
     GSR_STAGE_PREPROCESS = 0,   /* per-Gaussian projection, covariance, SH                         */
     GSR_STAGE_DEPTH_SORT,       /* radix sort of P depth keys                                       */
-    GSR_STAGE_SCAN,             /* inclusive scan of tile counts (+ the host read of num_rendered) */
-    GSR_STAGE_DUPLICATE,        /* (tile, id) pair expansion                                        */
+    GSR_STAGE_SCAN,             /* the host's wait for the pair count (the GPU is idle here only if the depth sort is done) */
+    GSR_STAGE_DUPLICATE,        /* gather + scan of the pair counts, (tile, id) pair expansion (all depth slabs)  */
     GSR_STAGE_TILE_SORT,        /* stable radix sort of pairs by tile id                            */
     GSR_STAGE_RANGES,           /* per-tile [begin,end)                                             */
     GSR_STAGE_BLEND,            /* per-tile front-to-back compositing                               */
+    GSR_STAGE_COLOUR,           /* SH colours of the listed splats (inference calls; else part of PREPROCESS)      */
     GSR_STAGE_NUM
 } gsr_stage;
 /* Enabling (or re-enabling) resets the per-thread record of timed calls. */

@@ -142,7 +142,7 @@ int main(int argc, char** argv) {
         s.call = gsr_forward_begin(grow, &s.geom, grow, &s.binning, grow, &s.image, P, D, M, d_bg, W, H, d_means,
                                    M ? d_shs : nullptr, nullptr, d_opac, d_scales, params[2], d_rots, nullptr, d_view, d_proj,
                                    d_campos, params[0], params[1], prefiltered, s.color, s.depth, s.alpha, s.radii,
-                                   /*extra_features=*/nullptr, /*out_extra=*/nullptr, /*debug=*/0, s.stream);
+                                   /*extra_features=*/nullptr, /*out_extra=*/nullptr, GSR_FORWARD_INFERENCE, /*debug=*/0, s.stream);
         return s.call != nullptr;
     };
     int rendered = 0;

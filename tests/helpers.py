@@ -63,7 +63,7 @@ def run_hip(cloud: GaussianCloud, cam: Camera, device="cuda:0", bg=(0.0, 0.0, 0.
 
 def hip_forward_raw(cloud: GaussianCloud, cam: Camera, device="cuda:0", bg=(0.0, 0.0, 0.0), scale_modifier=1.0,
                     sh_degree=None, cov3D_precomp=None, debug=True, cull=False):
-    """Call ``_C.rasterize_gaussians`` directly and decode every scratch sub-array.
+    """Call ``_C.rasterize_gaussians`` directly (a full, differentiable call) and decode every scratch sub-array.
     ``cull=False`` switches exact-image tile culling off so the lists are the reference's."""
     from autovfx_amd import _lib
     from diff_gaussian_rasterization import _C
@@ -72,6 +72,37 @@ def hip_forward_raw(cloud: GaussianCloud, cam: Camera, device="cuda:0", bg=(0.0,
         return _hip_forward_raw(_C, cloud, cam, device, bg, scale_modifier, sh_degree, cov3D_precomp, debug)
     finally:
         _lib.set_option(_lib.OPT_TILE_CULL, 1)
+
+
+def hip_forward_inference(cloud: GaussianCloud, cam: Camera, device="cuda:0", bg=(0.0, 0.0, 0.0), scale_modifier=1.0,
+                          sh_degree=None, cov3D_precomp=None, debug=False, slabs=0, slab_first=400, defer_colour=1):
+    """An inference call (``GSR_FORWARD_INFERENCE``: depth slabs with occlusion culling between them, colours only for
+    listed splats): the public outputs and how many pairs each slab put into its list."""
+    from autovfx_amd import _lib
+    from diff_gaussian_rasterization import _C
+    _C.set_geometry_cache(False)
+    _lib.set_option(_lib.OPT_SLABS, slabs)
+    _lib.set_option(_lib.OPT_SLAB_FIRST, slab_first)
+    _lib.set_option(_lib.OPT_DEFER_COLOUR, defer_colour)
+    try:
+        c = cloud.to(device)
+        st = settings_for(cam, device, bg, scale_modifier, cloud.sh_degree if sh_degree is None else sh_degree)
+        e = torch.Tensor([])
+        cov = e if cov3D_precomp is None else torch.as_tensor(cov3D_precomp, dtype=torch.float32, device=device)
+        (n, color, depth, alpha, radii, _g, _b, _i) = _C.rasterize_gaussians(
+            st.bg, c.means3D, e if c.colors_precomp is None else c.colors_precomp, c.opacities,
+            e if cov3D_precomp is not None else c.scales, e if cov3D_precomp is not None else c.rotations,
+            scale_modifier, cov, st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, st.image_height,
+            st.image_width, e if c.shs is None else c.shs, st.sh_degree, st.campos, False, debug, inference=True)
+        torch.cuda.synchronize()
+        lay = _C.last_layout() if cloud.P else {"slab_pairs": []}
+        return {"num_rendered": n, "color": color.cpu().numpy(), "depth": depth.cpu().numpy(), "alpha": alpha.cpu().numpy(),
+                "radii": radii.cpu().numpy(), "slab_pairs": lay["slab_pairs"]}
+    finally:
+        _lib.set_option(_lib.OPT_SLABS, 0)
+        _lib.set_option(_lib.OPT_SLAB_FIRST, 400)
+        _lib.set_option(_lib.OPT_DEFER_COLOUR, 1)
+        _C.set_geometry_cache(True)
 
 
 def _hip_forward_raw(_C, cloud, cam, device, bg, scale_modifier, sh_degree, cov3D_precomp, debug):
@@ -85,7 +116,7 @@ def _hip_forward_raw(_C, cloud, cam, device, bg, scale_modifier, sh_degree, cov3
         scale_modifier, cov, st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy, st.image_height,
         st.image_width, e if c.shs is None else c.shs, st.sh_degree, st.campos, False, debug)
     torch.cuda.synchronize()
-    lay = _C.last_layout()
+    lay = _C.last_layout() if cloud.P else {}
     P, W, H = cloud.P, cam.image_width, cam.image_height
     T = ((W + 15) // 16) * ((H + 15) // 16)
 
@@ -104,10 +135,14 @@ def _hip_forward_raw(_C, cloud, cam, device, bg, scale_modifier, sh_degree, cov3
         out["conic_opacity"] = np.ascontiguousarray(raster[:, 2:6])
         out["rgb"] = view(geom, g["rgb"], torch.float32, 3 * P, (P, 3))
         bins = view(geom, g["splat_bins"], torch.int32, 4 * P, (P, 4)).astype(np.uint32)
-        out["tiles_touched"] = bins[:, 3].copy()    # live tiles = pairs the splat emits
-        out["live_mask"] = bins[:, 2].copy()
+        out["tight_rect"] = np.stack((bins[:, 0] & 0xFFFF, bins[:, 0] >> 16, bins[:, 1] & 0xFFFF, bins[:, 1] >> 16), 1)   # x0 y0 w h
+        out["live_mask"] = bins[:, 2].astype(np.uint64) | (bins[:, 3].astype(np.uint64) << np.uint64(32))
         out["depth_order"] = view(geom, g["depth_order"], torch.int32, P).astype(np.uint32)
         out["point_offsets"] = view(geom, g["point_offsets"], torch.int32, P).astype(np.uint32)
+        # live tiles = pairs each splat emits: the steps of the inclusive offsets over the depth order
+        tt = np.zeros(P, np.uint32)
+        tt[out["depth_order"]] = np.diff(out["point_offsets"].astype(np.int64), prepend=0).astype(np.uint32)
+        out["tiles_touched"] = tt
         b = lay["binning"]
         live = lay["counts"]["live_pairs"]
         assert lay["counts"]["num_rendered"] == n

@@ -72,10 +72,14 @@ def test_surface_matches_reference_source_and_snapshot_is_fresh():
 def test_native_module_surface():
     from diff_gaussian_rasterization import _C, GaussianRasterizationSettings
     # DGR/ext.cpp:16-18 and DGR/rasterize_points.h:18-38,67-70
-    assert list(inspect.signature(_C.rasterize_gaussians).parameters) == [
+    # the reference's 19 positional arguments, in its order; one keyword-only addition that defaults to its behaviour
+    params = inspect.signature(_C.rasterize_gaussians).parameters
+    positional = [n for n, p in params.items() if p.kind is not inspect.Parameter.KEYWORD_ONLY]
+    assert positional == [
         "background", "means3D", "colors", "opacity", "scales", "rotations", "scale_modifier", "cov3D_precomp",
         "viewmatrix", "projmatrix", "tan_fovx", "tan_fovy", "image_height", "image_width", "sh", "degree", "campos",
         "prefiltered", "debug"]
+    assert [n for n in params if n not in positional] == ["inference"] and params["inference"].default is False
     assert list(inspect.signature(_C.mark_visible).parameters) == ["means3D", "viewmatrix", "projmatrix"]
     assert list(inspect.signature(_C.rasterize_gaussians_backward).parameters) == [
         "background", "means3D", "radii", "colors", "scales", "rotations", "scale_modifier", "cov3D_precomp",

@@ -81,12 +81,15 @@ def test_argument_errors_do_not_need_a_device():
                          None, 0.5, 0.5, 0, *tail) == -1
     assert "null" in _lib.last_error()
     # the two-feature variant: same checks, plus its own two pointers
-    tail_extra = [None] * 4 + [None, None, 0, None]
+    tail_extra = [None] * 4 + [None, None, 0, 0, None]          # ... extra_features, out_extra, flags, debug, stream
     assert L.gsr_forward_extra(*args, 0, 3, 16, None, 64, 64, None, None, None, None, None, 1.0, None, None, None, None,
                                None, 0.5, 0.5, 0, *tail_extra) == 0
     assert L.gsr_forward_extra(*args, 5, 3, 16, None, 64, 64, None, None, None, None, None, 1.0, None, None, None, None,
-                               None, 0.5, 0.5, 0, *tail_extra) == -1
-    assert "extra" in _lib.last_error()
+                               None, 0.5, 0.5, 0, *([None] * 4 + [4096, None, 0, 0, None])) == -1
+    assert "extra" in _lib.last_error()                           # the two extra pointers come together or not at all
+    assert L.gsr_forward_extra(*args, 5, 3, 16, None, 64, 64, None, None, None, None, None, 1.0, None, None, None, None,
+                               None, 0.5, 0.5, 0, *([None] * 4 + [None, None, 0x80, 0, None])) == -1   # unknown flag ...
+    assert "null" in _lib.last_error() or "flags" in _lib.last_error()   # ... or the null callbacks, whichever is seen first
     # the split call: a failed begin returns NULL and says why; finish refuses a NULL handle; cancel accepts one
     assert L.gsr_forward_begin(*args, 5, 3, 16, None, 64, 64, None, None, None, None, None, 1.0, None, None, None, None,
                                None, 0.5, 0.5, 0, *tail_extra) is None

@@ -25,7 +25,7 @@ from autovfx_amd.cameras import Camera, orbit_cameras
 from autovfx_amd.scenes import GaussianCloud
 from oracle import cpu_oracle
 
-from helpers import hip_forward_raw, oracle_kwargs, run_hip, settings_for
+from helpers import hip_forward_inference, hip_forward_raw, oracle_kwargs, run_hip, settings_for
 
 pytestmark = pytest.mark.gpu
 
@@ -125,8 +125,6 @@ def assert_culled_lists(name, on, ref, W, H):
         assert i == len(lhip), f"{name}: tile {t} list is not a subsequence of the reference list"
         kept += len(lhip)
     assert kept == on["live_pairs"] == on["point_list"].size and kept == int(on["tiles_touched"].sum())
-    small = ref["tiles_touched"] <= 32
-    assert (on["live_mask"][~small] == 0xFFFFFFFF).all(), "large rectangles must not be culled"
     assert (on["tiles_touched"] <= ref["tiles_touched"]).all()
     report(name + ":cull", kept=kept, dropped=dropped, kept_frac=kept / max(1, kept + dropped))
     return kept, dropped
@@ -151,6 +149,16 @@ def run_both(name, cloud, cam, stage=True, **kw):
     assert on["num_rendered"] == hip["num_rendered"]
     if stage and ref["num_rendered"] <= 400_000:
         assert_culled_lists(name, on, ref, cam.image_width, cam.image_height)
+    # inference calls (depth slabs with occlusion culling between them, colours only for listed splats): the public
+    # outputs bit for bit, with the default slab sizes and with slabs small enough that even this scene is cut up
+    for label, opts in (("inference", {}), ("inference_small_slabs", {"slab_first": 6}), ("inference_one_slab", {"slabs": 1})):
+        inf = hip_forward_inference(cloud, cam, **opts, **kw)
+        for k in ("color", "depth", "alpha", "radii"):
+            np.testing.assert_array_equal(inf[k], hip[k], err_msg=f"{name}: {k} changed by the {label} call")
+        assert inf["num_rendered"] == hip["num_rendered"]
+        report(f"{name}:{label}", slabs=len(inf["slab_pairs"]), pairs=int(sum(inf["slab_pairs"])), full_call_pairs=int(on["live_pairs"]),
+               reference_pairs=int(ref["num_rendered"]))
+        assert sum(inf["slab_pairs"]) <= on["live_pairs"]
     return hip, ref
 
 
@@ -358,64 +366,6 @@ def test_argument_validation_matches_reference():
     out = rast(x, m2, c.opacities, shs=c.shs, scales=c.scales, rotations=c.rotations)[0]
     out.sum().backward()
     assert x.grad is not None and x.grad.shape == (10, 3) and torch.isfinite(x.grad).all()
-
-
-@pytest.mark.parametrize("case", ["c1", "c2_mid", "big", "ragged"])
-def test_blend_variants_agree_bit_for_bit(case):
-    """GSR_OPT_BLEND_VARIANT 0 (wave per tile) and 1 (wave per quadrant) are two schedules of the same
-    per-pixel arithmetic: every output, n_contrib included, must be identical."""
-    from autovfx_amd import _lib
-    if case == "c1":
-        cloud, cam = scenes.config_c1(), scenes.c1_camera()
-    elif case == "c2_mid":
-        cloud, cam = scenes.config_c2(P=300_000, seed=4), orbit_cameras(200, 960, 540)[120]
-    elif case == "big":
-        cloud, cam = scenes.config_c1(P=400, seed=7), scenes.c1_camera(512, 384)
-        cloud.scales[:60] *= 30.0
-    else:
-        cloud, cam = scenes.config_c1(P=3000, seed=11), scenes.c1_camera(251, 131)
-    outs = []
-    for variant in (0, 1):
-        _lib.set_option(_lib.OPT_BLEND_VARIANT, variant)
-        try:
-            outs.append(hip_forward_raw(cloud, cam, bg=(0.3, 0.2, 0.1), cull=True))
-        finally:
-            _lib.set_option(_lib.OPT_BLEND_VARIANT, 1)
-    for other in outs[1:]:
-        for k in ("color", "depth", "alpha", "n_contrib", "radii", "point_list", "ranges"):
-            np.testing.assert_array_equal(outs[0][k], other[k], err_msg=f"{case}: {k} differs between blend variants")
-
-
-@pytest.mark.parametrize("case", ["c1", "c2_mid", "big", "ragged", "tiny"])
-@pytest.mark.parametrize("cull", [False, True])
-def test_sort_implementations_agree_bit_for_bit(case, cull):
-    """GSR_OPT_SORT_IMPL 1 (own one-sweep radix passes + scan fused into the pair expansion) and 0 (rocPRIM
-    primitives) must produce the same arrays: depth order, offsets, lists, ranges, images."""
-    from autovfx_amd import _lib
-    if case == "c1":
-        cloud, cam = scenes.config_c1(), scenes.c1_camera()
-    elif case == "c2_mid":
-        cloud, cam = scenes.config_c2(P=300_000, seed=4), orbit_cameras(200, 960, 540)[120]
-    elif case == "big":
-        cloud, cam = scenes.config_c1(P=400, seed=7), scenes.c1_camera(512, 384)
-        cloud.scales[:60] *= 30.0
-    elif case == "tiny":
-        cloud, cam = scenes.config_c1(P=3, seed=2), scenes.c1_camera(64, 48)
-    else:
-        cloud, cam = scenes.config_c1(P=3000, seed=11), scenes.c1_camera(251, 131)
-    outs = []
-    for impl in (0, 1):
-        _lib.set_option(_lib.OPT_SORT_IMPL, impl)
-        try:
-            outs.append(hip_forward_raw(cloud, cam, bg=(0.3, 0.2, 0.1), cull=cull))
-        finally:
-            _lib.set_option(_lib.OPT_SORT_IMPL, 1)
-    a, b = outs
-    V = int((a["radii"] > 0).sum())
-    np.testing.assert_array_equal(a["depth_order"][:V], b["depth_order"][:V], err_msg=f"{case}: depth order")
-    for k in ("color", "depth", "alpha", "n_contrib", "radii", "point_list", "tile_keys", "ranges", "point_offsets",
-              "num_rendered", "live_pairs"):
-        np.testing.assert_array_equal(a[k], b[k], err_msg=f"{case}: {k} differs between sort implementations")
 
 
 @pytest.mark.parametrize("hw", [(1080, 1920), (33, 17), (7, 5)])
@@ -657,8 +607,7 @@ def test_second_pass_reuses_geometry_bit_for_bit():
 def test_randomised_configurations(seed):
     """Seeded sweep over the knobs at once: cloud size, image shape, SH degree / precomputed colours, scale
     modifier, background, a share of huge or needle-like splats, both blend schedules -- each case against the
-    oracle for every stage (culling off) and for the culled lists (culling on)."""
-    from autovfx_amd import _lib
+    oracle for every stage (culling off), for the culled lists (culling on) and through inference calls."""
     rng = np.random.default_rng(1000 + seed)
     P = int(rng.choice([1, 2, 7, 64, 65, 300, 1500, 4000]))
     W, H = int(rng.integers(1, 260)), int(rng.integers(1, 200))
@@ -677,11 +626,7 @@ def test_randomised_configurations(seed):
     else:
         kw["sh_degree"] = int(rng.integers(0, 5))
     cam = scenes.c1_camera(W, H, fovx_deg=float(rng.uniform(30, 100)))
-    _lib.set_option(_lib.OPT_BLEND_VARIANT, int(seed % 2))
-    try:
-        run_both(f"rand{seed}", cloud, cam, **kw)
-    finally:
-        _lib.set_option(_lib.OPT_BLEND_VARIANT, 1)
+    run_both(f"rand{seed}", cloud, cam, **kw)
 
 
 def test_blend_exp_is_expf_on_its_domain():
@@ -708,26 +653,15 @@ def test_blend_exp_is_expf_on_its_domain():
 
 
 @pytest.mark.parametrize("cull", [False, True])
-def test_4k_frame_sort_paths_agree_and_lists_are_ordered(cull):
+def test_4k_frame_lists_are_ordered(cull):
     """3840x2160 (32 400 tiles: 15-bit tile keys, second radix pass 7 bits wide), splats from sub-pixel to a third of
-    the screen: both sort implementations give the same arrays, tile keys ascend, depth ascends inside a tile,
-    offsets end at the live-pair count."""
-    from autovfx_amd import _lib
+    the screen: tile keys ascend, depth ascends inside a tile, offsets end at the live-pair count; the inference call
+    gives the same frame."""
     cloud = scenes.config_c2(P=200_000, seed=21)
     cloud.scales[:300] *= 60.0            # screen-filling splats among tiny ones
     cloud.scales[300:5000] *= 0.05
     cam = orbit_cameras(50, 3840, 2160)[7]
-    outs = []
-    for impl in (0, 1):
-        _lib.set_option(_lib.OPT_SORT_IMPL, impl)
-        try:
-            outs.append(hip_forward_raw(cloud, cam, bg=(0.0, 0.1, 0.0), debug=False, cull=cull))
-        finally:
-            _lib.set_option(_lib.OPT_SORT_IMPL, 1)
-    a, b = outs
-    for k in ("color", "depth", "alpha", "n_contrib", "radii", "point_list", "tile_keys", "ranges", "point_offsets",
-              "num_rendered", "live_pairs"):
-        np.testing.assert_array_equal(a[k], b[k], err_msg=f"4k: {k} differs between sort implementations")
+    b = hip_forward_raw(cloud, cam, bg=(0.0, 0.1, 0.0), debug=False, cull=cull)
     tk = b["tile_keys"].astype(np.int64)
     assert tk.max() < 240 * 135 and (np.diff(tk) >= 0).all()
     d = b["depths"].view(np.uint32)[b["point_list"]].astype(np.int64)
@@ -735,7 +669,13 @@ def test_4k_frame_sort_paths_agree_and_lists_are_ordered(cull):
     assert int(b["point_offsets"][-1]) == b["live_pairs"] == len(b["point_list"])
     if not cull:
         assert b["live_pairs"] == b["num_rendered"] == int(b["tiles_touched"].astype(np.int64).sum())
-    assert b["tiles_touched"].max() > 32        # full-rectangle (unmasked) splats are present
+    assert (b["tight_rect"][:, 2] * b["tight_rect"][:, 3]).max() > 64        # splats too large for a mask are present
+    if cull:
+        inf = hip_forward_inference(cloud, cam, bg=(0.0, 0.1, 0.0))
+        for k in ("color", "depth", "alpha", "radii"):
+            np.testing.assert_array_equal(inf[k], b[k], err_msg=f"4k: {k}")
+        report("4k:inference", slabs=len(inf["slab_pairs"]), pairs=int(sum(inf["slab_pairs"])), full_call_pairs=int(b["live_pairs"]),
+               reference_pairs=int(b["num_rendered"]))
 
 
 def test_nothing_visible_and_single_gaussian():
