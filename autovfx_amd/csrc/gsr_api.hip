@@ -456,6 +456,7 @@ struct ForwardCall {
     size_t off_slabs = 0, off_quad = 0, off_rows = 0, off_radix_tmp = 0;
     int row_words = 0;
     uint32_t *order = nullptr, *point_offsets = nullptr, *slab_offsets = nullptr, *tile_totals = nullptr, *slab_tile_totals = nullptr;
+    uint32_t *slab_cpos = nullptr, *slab_coffs = nullptr;
     uint4* sorted_bins = nullptr;
     const float *colors_precomp = nullptr, *background = nullptr, *extra_features = nullptr;
     float *out_color = nullptr, *out_depth = nullptr, *out_alpha = nullptr, *out_extra = nullptr;
@@ -585,6 +586,8 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     const size_t off_ids_a = gc.take<uint32_t>(n), off_ids_b = gc.take<uint32_t>(n);
     geom_off[GSR_GEOM_POINT_OFFSETS] = gc.take<uint32_t>(n);
     const size_t off_slab_offsets = gc.take<uint32_t>(fc.inference ? n : 0);
+    const size_t off_slab_cpos = gc.take<uint32_t>(fc.inference ? n : 0);
+    const size_t off_slab_coffs = gc.take<uint32_t>(fc.inference ? n : 0);
     // the words of a call that must be zero before its first kernel, cleared by ONE memset: frame counters, the table of
     // depth slabs, one bit per finished 8x8 quadrant, one bit per finished tile (a row of bits per tile row)
     const size_t off_flag = gc.take<gsr::FrameCounters>(1);
@@ -629,6 +632,8 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     ga.counters = (gsr::FrameCounters*)(gbase + off_flag);
     fc.point_offsets = (uint32_t*)(gbase + geom_off[GSR_GEOM_POINT_OFFSETS]);
     fc.slab_offsets = (uint32_t*)(gbase + off_slab_offsets);
+    fc.slab_cpos = (uint32_t*)(gbase + off_slab_cpos);
+    fc.slab_coffs = (uint32_t*)(gbase + off_slab_coffs);
     fc.tile_totals = (uint32_t*)(gbase + off_tile_totals);
     fc.slab_tile_totals = (uint32_t*)(gbase + off_slab_totals);
     fc.sorted_bins = (uint4*)(gbase + off_sorted_bins);
@@ -714,6 +719,7 @@ int forward_finish(ForwardCall& fc) {
     ba.depth_order = fc.order; ba.bins = ga.bins; ba.raster = ga.raster; ba.sorted_bins = fc.sorted_bins;
     ba.offsets = fc.point_offsets; ba.tile_totals = fc.tile_totals;
     ba.slab_offsets = fc.slab_offsets; ba.slab_tile_totals = fc.slab_tile_totals;
+    ba.slab_cpos = fc.slab_cpos; ba.slab_coffs = fc.slab_coffs; ba.tiles_p = (P + gsr::kDupTile - 1) / gsr::kDupTile;
     ba.run_pool = (uint32_t*)(bbase + off_pool); ba.pool_rows = (uint32_t)pool_rows;
     ba.counters = ga.counters;
     ba.slabs = (gsr::SlabInfo*)(gbase + fc.off_slabs);
@@ -779,7 +785,8 @@ int forward_finish(ForwardCall& fc) {
         GSR_STAGE_CHECK("tile_ranges");
         stamp(kHeadEvents + kSlabEvents * k + 2, stream);
         if (fc.defer_colour)
-            GSR_HIP(gsr::launch_sh_colour(fc.in, cam, ba.V, slab, fc.order, k == 0 ? fc.point_offsets : fc.slab_offsets, ga.rgb, stream));
+            GSR_HIP(gsr::launch_sh_colour(fc.in, cam, ba.V, slab, fc.order, k == 0 ? fc.point_offsets : fc.slab_offsets,
+                                          k == 0 ? nullptr : fc.slab_cpos, ga.rgb, stream));
         stamp(kHeadEvents + kSlabEvents * k + 3, stream);
         GSR_HIP(gsr::launch_blend(cam, segs, k, k + 1, /*fresh=*/k == 0, /*final=*/last, ga.raster, features, fc.background,
                                   fc.out_color, fc.out_depth, fc.out_alpha, n_contrib, ba.quad_done, ba.done_rows, fc.row_words, stream,

@@ -21,7 +21,9 @@
 //   bin_offsets_kernel  : adds the sum of all earlier tile totals (each workgroup sums them itself: a few KB of
 //                         L2-resident words, no chain, no look-back) -> POINT_OFFSETS, global and inclusive.
 //   slab_bounds_kernel  : cuts the depth order into slabs at the given pair counts.
-//   slab_recount_kernel / slab_offsets_kernel (slabs > 0): drop finished tiles from the records, re-scan.
+//   slab_recount_kernel / slab_compact_kernel (slabs > 0): drop finished tiles from the records, re-scan, and list the
+//                         positions that still have a live pair (behind an opaque front nine splats in ten have none:
+//                         the expansion walks the compacted list, not the depth order).
 //   expand_kernel       : one workgroup per kPairTile = 4096 PAIRS, 16 consecutive pairs per lane: every workgroup
 //                         does the same work whatever the splat sizes, and writes one contiguous 32 KB slice of the
 //                         two pair arrays with 16-byte stores.
@@ -328,7 +330,7 @@ __global__ void __launch_bounds__(256) slab_bounds_kernel(int V, int num_slabs, 
     const uint32_t end = s == num_slabs - 1 ? (uint32_t)V : positions_upto(cuts.cut[s], V, offsets, tile_ends, s_scratch);
     if (threadIdx.x == 0) {
         SlabInfo info;
-        info.first = first; info.end = end; info.pad = 0u;
+        info.first = first; info.end = end; info.emitters = end - first;
         // slab 0 is expanded from the global offsets as they are; later slabs set their count when they re-scan
         info.pairs = (s == 0 && end > 0u) ? offsets[end - 1] : 0u;
         slabs[s] = info;
@@ -377,7 +379,12 @@ __global__ void __launch_bounds__(256) slab_recount_kernel(BinningArrays a, int 
     const uint32_t mine = count[0] + count[1] + count[2] + count[3];
     uint32_t tile_total;
     const uint32_t before = block_exclusive_256(mine, s_wave, &tile_total);
-    if (threadIdx.x == 0) a.slab_tile_totals[blockIdx.x] = tile_total;
+    const uint32_t emitting = (count[0] != 0u) + (count[1] != 0u) + (count[2] != 0u) + (count[3] != 0u);
+    const uint32_t tile_emitting = block_sum_256(emitting, s_wave);
+    if (threadIdx.x == 0) {
+        a.slab_tile_totals[blockIdx.x] = tile_total;
+        a.slab_tile_totals[a.tiles_p + blockIdx.x] = tile_emitting;
+    }
     uint32_t run = before;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -386,39 +393,63 @@ __global__ void __launch_bounds__(256) slab_recount_kernel(BinningArrays a, int 
     }
 }
 
-__global__ void __launch_bounds__(256) slab_offsets_kernel(int V, SlabInfo* __restrict__ slabs, int slab,
-                                                           const uint32_t* __restrict__ tile_totals, uint32_t* __restrict__ offsets,
-                                                           uint32_t* __restrict__ tile_ends) {
+// Second half of the re-scan: tile-local offsets become slab-wide, and the positions that kept a live pair are listed
+// in order (`cpos`: position - slab.first; `coffs`: inclusive pair offset after it) -- the arrays the expansion walks.
+__global__ void __launch_bounds__(256) slab_compact_kernel(BinningArrays a, int slab) {
     __shared__ uint32_t s_scratch[4];
-    const SlabInfo info = slabs[slab];
-    const uint32_t first = info.first, end = min(info.end, (uint32_t)V);
+    __shared__ uint32_t s_wave[4];
+    const SlabInfo info = a.slabs[slab];
+    const uint32_t first = info.first, end = min(info.end, (uint32_t)a.V);
     const uint32_t tiles = end > first ? (end - first + kDupTile - 1) / kDupTile : 0u;
-    if (blockIdx.x == 0) {  // the slab's pair count (also when the slab is empty)
-        uint32_t part = 0;
-        for (uint32_t t = threadIdx.x; t < tiles; t += 256) part += tile_totals[t];
-        const uint32_t all = block_sum_256(part, s_scratch);
-        if (threadIdx.x == 0) slabs[slab].pairs = all;
+    const uint32_t* __restrict__ pair_totals = a.slab_tile_totals;
+    const uint32_t* __restrict__ emit_totals = a.slab_tile_totals + a.tiles_p;
+    if (blockIdx.x == 0) {  // the slab's counts (also when the slab is empty)
+        uint32_t pp = 0, ee = 0;
+        for (uint32_t t = threadIdx.x; t < tiles; t += 256) { pp += pair_totals[t]; ee += emit_totals[t]; }
+        const uint32_t all_pairs = block_sum_256(pp, s_scratch);
+        const uint32_t all_emit = block_sum_256(ee, s_scratch);
+        if (threadIdx.x == 0) { a.slabs[slab].pairs = all_pairs; a.slabs[slab].emitters = all_emit; }
     }
     if (blockIdx.x >= tiles) return;
-    uint32_t part = 0;
-    for (uint32_t t = threadIdx.x; t < blockIdx.x; t += 256) part += tile_totals[t];
-    const uint32_t before = block_sum_256(part, s_scratch);
-    if (threadIdx.x == 0) tile_ends[blockIdx.x] = before + tile_totals[blockIdx.x];
-    const uint32_t k0 = first + blockIdx.x * (uint32_t)kDupTile + 4u * threadIdx.x;
+    uint32_t pp = 0, ee = 0;
+    for (uint32_t t = threadIdx.x; t < blockIdx.x; t += 256) { pp += pair_totals[t]; ee += emit_totals[t]; }
+    const uint32_t pairs_before = block_sum_256(pp, s_scratch);
+    const uint32_t emit_before = block_sum_256(ee, s_scratch);
+    const uint32_t tile_first = first + blockIdx.x * (uint32_t)kDupTile;
+    const uint32_t k0 = tile_first + 4u * threadIdx.x;
+    uint32_t incl[4], prev = 0u;  // tile-local inclusive offsets of my 4 positions, and of the position before them
+    if (threadIdx.x != 0 && k0 - 1u < end) prev = a.slab_offsets[k0 - 1u];
+    uint32_t flags = 0u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (k0 + j < end) offsets[k0 + j] += before;
+    for (int j = 0; j < 4; ++j) {
+        incl[j] = k0 + j < end ? a.slab_offsets[k0 + j] : prev;
+        if (incl[j] != prev) flags |= 1u << j;
+        prev = incl[j];
+    }
+    uint32_t tile_emit;
+    uint32_t rank = emit_before + block_exclusive_256((uint32_t)__popc(flags), s_wave, &tile_emit);  // (syncs: reads above, writes below)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (k0 + j >= end) continue;
+        const uint32_t global_incl = incl[j] + pairs_before;
+        a.slab_offsets[k0 + j] = global_incl;
+        if (flags & (1u << j)) {
+            a.slab_cpos[rank] = k0 + j - first;
+            a.slab_coffs[rank] = global_incl;
+            ++rank;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// expand: pairs [blockIdx.x * 4096, +4096) of one slab.  `offsets` counts pairs inclusively from the slab's first
-// position on, `tile_ends` are those counts at the ends of the slab's 1024-position tiles.
+// expand: pairs [blockIdx.x * 4096, +4096) of one slab.  The splats that own them are items 0 .. n-1 of a list with
+// ascending inclusive pair offsets: for slab 0 the positions of the depth order themselves (global POINT_OFFSETS); for
+// a later slab the compacted list of the positions that still have a live pair (slab_compact_kernel).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, const uint32_t* __restrict__ offsets_all,
-                                                     const uint32_t* __restrict__ tile_ends,
-                                                     uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ point_list) {
-    constexpr int kBatch = 2048;            // splats whose offsets are parked in LDS at a time
-    __shared__ uint32_t s_incl[kBatch + 1]; // s_incl[0] = pairs before the batch's first splat
+__global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, uint32_t* __restrict__ tile_keys,
+                                                     uint32_t* __restrict__ point_list) {
+    constexpr int kBatch = 2048;            // items whose offsets are parked in LDS at a time
+    __shared__ uint32_t s_incl[kBatch + 1]; // s_incl[0] = pairs before the batch's first item
     __shared__ uint32_t s_scratch[4];
     __shared__ uint32_t s_done[kMaxDoneWords];
     const int tid = threadIdx.x;
@@ -428,8 +459,11 @@ __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, 
     if (p_begin >= num_pairs) return;  // the launch was sized for an upper bound
     const uint32_t p_end = min(num_pairs, p_begin + (uint32_t)kPairTile);
     const uint32_t first = info.first;
-    const int V = (int)(min(info.end, (uint32_t)a.V) - first);  // positions of this slab: local index i <-> position first + i
-    const uint32_t* __restrict__ offsets = offsets_all + first;
+    const bool compacted = slab > 0;
+    // item i <-> position first + (compacted ? cpos[i] : i)
+    const int V = compacted ? (int)info.emitters : (int)(min(info.end, (uint32_t)a.V) - first);
+    const uint32_t* __restrict__ offsets = compacted ? a.slab_coffs : a.offsets + first;
+    const uint32_t* __restrict__ cpos = a.slab_cpos;
     const uint4* __restrict__ sorted_bins = a.sorted_bins + first;
     const uint32_t* __restrict__ order = a.depth_order + first;
     const uint32_t* done = nullptr;
@@ -439,10 +473,11 @@ __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, 
     }
     const uint32_t grid_x = (uint32_t)a.grid_x;
 
-    // first splat whose inclusive offset exceeds p_begin = number of splats with offset <= p_begin
+    // first item whose inclusive offset exceeds p_begin = number of items with offset <= p_begin: whole 1024-item
+    // tiles first (their last offsets), then inside the tile that straddles p_begin
     const int tiles = (V + kDupTile - 1) / kDupTile;
     uint32_t n_le = 0;
-    for (int t = tid; t < tiles; t += 256) n_le += tile_ends[t] <= p_begin ? 1u : 0u;
+    for (int t = tid; t < tiles; t += 256) n_le += offsets[min((t + 1) * kDupTile, V) - 1] <= p_begin ? 1u : 0u;
     const int tile0 = (int)block_sum_256(n_le, s_scratch);  // tiles that end at or before p_begin
     n_le = 0;
     {
@@ -452,6 +487,7 @@ __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, 
             if (k0 + j < V) n_le += offsets[k0 + j] <= p_begin ? 1u : 0u;
     }
     int s0 = tile0 * kDupTile + (int)block_sum_256(n_le, s_scratch);
+    auto position_of = [&](int item) -> uint32_t { return compacted ? cpos[item] : (uint32_t)item; };
 
     const uint32_t my_begin = p_begin + (uint32_t)(kPairsPerLane * tid);
     const uint32_t my_end = min(p_end, my_begin + (uint32_t)kPairsPerLane);
@@ -474,16 +510,18 @@ __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, 
             int owner = lo;
             uint32_t owner_end = s_incl[owner];
             TileWalker w;
-            w.start(sorted_bins[s0 + owner - 1], lo_pair - s_incl[owner - 1], a.run_pool, done, a.row_words);
-            uint32_t gid = order[s0 + owner - 1];
+            uint32_t pos = position_of(s0 + owner - 1);
+            w.start(sorted_bins[pos], lo_pair - s_incl[owner - 1], a.run_pool, done, a.row_words);
+            uint32_t gid = order[pos];
 #pragma unroll
             for (int q = 0; q < kPairsPerLane; ++q) {
                 const uint32_t p = my_begin + (uint32_t)q;
                 if (p >= lo_pair && p < hi_pair) {
                     if (p >= owner_end) {
                         do { owner_end = s_incl[++owner]; } while (p >= owner_end);  // splats without live tiles
-                        w.start(sorted_bins[s0 + owner - 1], 0u, a.run_pool, done, a.row_words);
-                        gid = order[s0 + owner - 1];
+                        pos = position_of(s0 + owner - 1);
+                        w.start(sorted_bins[pos], 0u, a.run_pool, done, a.row_words);
+                        gid = order[pos];
                     }
                     keys[q] = w.next(grid_x);
                     ids[q] = gid;
@@ -556,21 +594,18 @@ hipError_t launch_bin_scan(const BinningArrays& a, const Camera& cam, int num_sl
 
 hipError_t launch_slab_recount(const BinningArrays& a, int slab, hipStream_t stream) {
     const int tiles_v = div_up(a.V, kDupTile), tiles_p = div_up(a.P, kDupTile);
-    // (an empty slab still needs its pair count set: slab_offsets_kernel's first workgroup does that)
+    (void)tiles_p;
+    // (an empty slab still needs its counts set: slab_compact_kernel's first workgroup does that)
     if (tiles_v > 0) hipLaunchKernelGGL(slab_recount_kernel, dim3(tiles_v), dim3(256), 0, stream, a, slab);
-    hipLaunchKernelGGL(slab_offsets_kernel, dim3(tiles_v > 0 ? tiles_v : 1), dim3(256), 0, stream, a.V, a.slabs, slab,
-                       a.slab_tile_totals, a.slab_offsets, a.slab_tile_totals + tiles_p);
+    hipLaunchKernelGGL(slab_compact_kernel, dim3(tiles_v > 0 ? tiles_v : 1), dim3(256), 0, stream, a, slab);
     return hipGetLastError();
 }
 
 hipError_t launch_expand(const BinningArrays& a, int slab, uint32_t pairs_bound, uint32_t* tile_keys, uint32_t* point_list,
                          hipStream_t stream) {
     if (pairs_bound == 0) return hipSuccess;
-    const int tiles_p = div_up(a.P, kDupTile);
-    const uint32_t* offsets = slab == 0 ? a.offsets : a.slab_offsets;
-    const uint32_t* tile_ends = (slab == 0 ? a.tile_totals : a.slab_tile_totals) + tiles_p;
-    hipLaunchKernelGGL(expand_kernel, dim3((pairs_bound + kPairTile - 1) / kPairTile), dim3(256), 0, stream, a, slab, offsets,
-                       tile_ends, tile_keys, point_list);
+    hipLaunchKernelGGL(expand_kernel, dim3((pairs_bound + kPairTile - 1) / kPairTile), dim3(256), 0, stream, a, slab, tile_keys,
+                       point_list);
     return hipGetLastError();
 }
 

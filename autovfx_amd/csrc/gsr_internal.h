@@ -70,7 +70,7 @@ struct SplatBin {
 struct SlabInfo {
     uint32_t first, end;
     uint32_t pairs;        // live pairs expanded for this slab = length of its sorted list (device-side count)
-    uint32_t pad;
+    uint32_t emitters;     // positions of the slab that put at least one pair into it (slab 0: all of them)
 };
 
 // Everything the blend needs about one splat except its colour, in one 32-byte record (never straddles
@@ -100,8 +100,10 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmat
                                hipStream_t stream);
 // SH colours of the splats of one slab that reached a list (GaussianInputs::defer_colour): positions
 // [slab.first, slab.end) of the depth order whose pair offset moved; rgb[gid] is written.
+// `cpos` (nullable): the slab's compacted list of emitting positions (slabs > 0); without it every position of the slab
+// is looked at and `offsets` (inclusive, indexed by position) says which ones emit.
 hipError_t launch_sh_colour(const GaussianInputs& in, const Camera& cam, int V, const SlabInfo* slab,
-                            const uint32_t* depth_order, const uint32_t* offsets /*inclusive, indexed by position*/,
+                            const uint32_t* depth_order, const uint32_t* offsets, const uint32_t* cpos,
                             float* rgb, hipStream_t stream);
 
 // ---- binning (gsr_binning.hip): from the depth order to per-tile lists, slab by slab ----
@@ -117,7 +119,11 @@ struct BinningArrays {
     uint32_t* offsets;            // [P] POINT_OFFSETS: inclusive live-pair count over the depth order
     uint32_t* tile_totals;        // [2 * ceil(P / kDupTile)] per-1024-position totals, then offsets at their ends
     uint32_t* slab_offsets;       // [P] inclusive pair count inside the slab a position belongs to (slabs > 0)
-    uint32_t* slab_tile_totals;   // [2 * ceil(P / kDupTile)] the same for the slab being processed
+    uint32_t* slab_tile_totals;   // [2 * ceil(P / kDupTile)] per-1024-position pair totals of the slab being processed, then
+                                  // how many of those positions still have a live pair
+    uint32_t* slab_cpos;          // [P] slabs > 0: the positions (minus slab.first) that still have a live pair, ascending
+    uint32_t* slab_coffs;         // [P] ... and the inclusive pair offset behind each of them
+    int tiles_p;                  // ceil(P / kDupTile)
     uint32_t* run_pool;           // [pool_rows] column runs of the large splats
     uint32_t pool_rows;
     FrameCounters* counters;

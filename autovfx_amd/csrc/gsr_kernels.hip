@@ -272,15 +272,20 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
 __global__ void __launch_bounds__(256) sh_colour_kernel(GaussianInputs in, const float* __restrict__ cam_pos, int V,
                                                         const SlabInfo* __restrict__ slab,
                                                         const uint32_t* __restrict__ depth_order,
-                                                        const uint32_t* __restrict__ offsets, float* __restrict__ rgb) {
+                                                        const uint32_t* __restrict__ offsets,
+                                                        const uint32_t* __restrict__ cpos, float* __restrict__ rgb) {
     const uint32_t first = slab->first, end = min(slab->end, (uint32_t)V);
-    const uint32_t k = first + blockIdx.x * 256u + threadIdx.x;
-    if (k >= end) return;
-    // `offsets` counts pairs inclusively from the slab's first position on (slab 0: from position 0, the global
-    // POINT_OFFSETS; later slabs: the slab's own recount): a position whose count moved has pairs in this slab's lists
-    const uint32_t before = k > first ? offsets[k - 1] : 0u;
-    const bool emits = offsets[k] != before;
-    if (!emits) return;
+    uint32_t k = first + blockIdx.x * 256u + threadIdx.x;
+    if (cpos != nullptr) {  // later slabs: the positions that kept a live pair are listed (slab_compact_kernel)
+        const uint32_t item = blockIdx.x * 256u + threadIdx.x;
+        if (item >= slab->emitters) return;
+        k = first + cpos[item];
+    } else {
+        if (k >= end) return;
+        // `offsets` counts pairs inclusively (slab 0: the global POINT_OFFSETS): a position whose count moved has pairs
+        const uint32_t before = k > first ? offsets[k - 1] : 0u;
+        if (offsets[k] == before) return;
+    }
     const uint32_t i = depth_order[k];
     int deg = in.sh_degree < 3 ? in.sh_degree : 3;
     if (deg > 2 && in.M < 16) deg = 2;
@@ -428,10 +433,11 @@ hipError_t launch_preprocess(const GaussianInputs& in, const Camera& cam, const 
 }
 
 hipError_t launch_sh_colour(const GaussianInputs& in, const Camera& cam, int V, const SlabInfo* slab,
-                            const uint32_t* depth_order, const uint32_t* offsets, float* rgb, hipStream_t stream) {
+                            const uint32_t* depth_order, const uint32_t* offsets, const uint32_t* cpos, float* rgb,
+                            hipStream_t stream) {
     if (V <= 0) return hipSuccess;
     hipLaunchKernelGGL(sh_colour_kernel, dim3(div_up(V, 256)), dim3(256), 0, stream, in, cam.cam_pos, V, slab, depth_order,
-                       offsets, rgb);
+                       offsets, cpos, rgb);
     return hipGetLastError();
 }
 
