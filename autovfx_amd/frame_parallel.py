@@ -134,13 +134,17 @@ BeginFn = Callable[[GaussianCloud, Camera, torch.Tensor], object]
 def render_shard(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids: Sequence[int], bg: torch.Tensor,
                  keep_depth: bool = False, render_fn: RenderFn = rasterize, streams: int = 3,
                  driver: str = "auto", begin_fn: Optional[BeginFn] = None,
-                 chunk_ends: Sequence[int] = (), on_chunk: Optional[Callable[[int, torch.Tensor], None]] = None
-                 ) -> Dict[str, torch.Tensor]:
+                 chunk_ends: Sequence[int] = (), on_chunk: Optional[Callable[[int, torch.Tensor], None]] = None,
+                 pad_to: int = 0) -> Dict[str, torch.Tensor]:
     """Render this rank's frames; returns stacked ``rgba8 [n,4,H,W]`` (and ``depth [n,H,W]``).
 
     ``on_chunk(end, rgba8[:end])`` is called -- in the caller's stream context, ordered after the frames it covers --
     as soon as frame ``end - 1`` is queued, for every ``end`` in ``chunk_ends``, while later frames keep rendering
     (``render_and_gather`` starts a piece's transfer from it).  Not available with ``driver="threads"``.
+
+    ``pad_to`` > n: the stacks get ``pad_to`` rows, the rows past this rank's n frames zero (round-robin shards differ
+    by at most one frame; a collective wants equal pieces), and chunk ends past n are reported once the last real
+    frame is queued.
 
     ``streams > 1`` (GPU only) renders frame ``slot`` on HIP stream ``slot % streams``.  Frames are independent, and
     a frame's blend (VALU-bound) overlaps well with other frames' projection and sorts (HBM / latency-bound): three
@@ -159,13 +163,21 @@ def render_shard(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids: Seq
     """
     device = cloud.means3D.device
     n = len(frame_ids)
+    rows = max(n, int(pad_to))
     H, W = (cameras[0].image_height, cameras[0].image_width) if len(cameras) else (0, 0)
-    rgba = torch.empty((n, 4, H, W), dtype=torch.uint8, device=device)
-    depth = torch.empty((n, H, W), dtype=torch.float32, device=device) if keep_depth else None
+    rgba = torch.empty((rows, 4, H, W), dtype=torch.uint8, device=device)
+    depth = torch.empty((rows, H, W), dtype=torch.float32, device=device) if keep_depth else None
+    if rows > n:
+        rgba[n:].zero_()
+        if keep_depth:
+            depth[n:].zero_()
     if driver not in ("auto", "pipelined", "threads"):
         raise ValueError(f"unknown driver {driver!r}")
     if begin_fn is None and render_fn is rasterize:
         begin_fn = rasterize_begin
+    elif begin_fn is not None and render_fn is rasterize:   # only the split form was given: the blocking form is begin + finish
+        split = begin_fn
+        render_fn = lambda c, cam, b: split(c, cam, b).finish()
     if driver == "pipelined" and begin_fn is None:
         raise ValueError("the pipelined driver needs begin_fn, the split form of render_fn")
     if driver == "auto":
@@ -177,6 +189,7 @@ def render_shard(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids: Seq
             depth[slot].copy_(d[0])
 
     chunk_ends = set(int(e) for e in chunk_ends) if on_chunk is not None else set()
+    late_ends = sorted(e for e in chunk_ends if e > n)   # pieces that end in the padding rows
 
     def render_slots(slots, report=False):
         with torch.no_grad():
@@ -186,27 +199,36 @@ def render_shard(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids: Seq
                 if report and slot + 1 in chunk_ends:
                     on_chunk(slot + 1, rgba[:slot + 1])
 
-    streams = max(1, int(streams)) if device.type == "cuda" else 1
+    on_gpu = device.type == "cuda"
+    # (without a GPU there are no streams to overlap; the pipelined driver still runs there -- same control flow, the
+    #  stream hand-overs become no-ops -- which is how the world-size-2 gloo tests exercise it)
+    streams = max(1, int(streams)) if (on_gpu or driver == "pipelined") else 1
     if chunk_ends and driver == "threads" and streams > 1 and n >= 2:
         raise ValueError("on_chunk needs the pipelined (or serial) driver")
     if streams == 1 or n < 2:
         render_slots(range(n), report=True)
+        for e in late_ends:
+            on_chunk(e, rgba[:e])
     elif driver == "pipelined":
         from collections import deque
-        caller = torch.cuda.current_stream(device)
-        side = side_streams(device, streams)
+        import contextlib
+        caller = torch.cuda.current_stream(device) if on_gpu else None
+        side = side_streams(device, streams) if on_gpu else [None] * streams
+        on_stream = (lambda st: torch.cuda.stream(st)) if on_gpu else (lambda st: contextlib.nullcontext())
         for st in side:
-            st.wait_stream(caller)                 # inputs produced on the caller's stream are visible
+            if on_gpu:
+                st.wait_stream(caller)             # inputs produced on the caller's stream are visible
         in_flight = deque()
 
         def finish_oldest():
             slot, st, pending = in_flight.popleft()
-            with torch.cuda.stream(st):
+            with on_stream(st):
                 color, d, alpha, _radii = pending.finish()
                 keep(slot, color, d, alpha)
             if slot + 1 in chunk_ends:             # frames finish in order: everything up to `slot` is queued
                 for other in side:
-                    caller.wait_stream(other)
+                    if on_gpu:
+                        caller.wait_stream(other)
                 on_chunk(slot + 1, rgba[:slot + 1])
 
         with torch.no_grad():
@@ -214,12 +236,15 @@ def render_shard(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids: Seq
                 if len(in_flight) == streams:      # stream slot % streams is the oldest frame's: finish it first
                     finish_oldest()
                 st = side[slot % streams]
-                with torch.cuda.stream(st):
+                with on_stream(st):
                     in_flight.append((slot, st, begin_fn(cloud, cameras[frame_ids[slot]], bg)))
             while in_flight:
                 finish_oldest()
         for st in side:
-            caller.wait_stream(st)                 # results are ordered before later work of the caller
+            if on_gpu:
+                caller.wait_stream(st)             # results are ordered before later work of the caller
+        for e in late_ends:
+            on_chunk(e, rgba[:e])
     else:
         import threading
         caller = torch.cuda.current_stream(device)
@@ -306,19 +331,33 @@ def broadcast_cloud(cloud: Optional[GaussianCloud], src: int = 0, device=None, g
 
 def render_and_gather(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids: Sequence[int], bg: torch.Tensor,
                       dst: int = 0, render_fn: RenderFn = rasterize, streams: int = 3, chunks: int = 4,
-                      group=None, driver: str = "auto", begin_fn: Optional[BeginFn] = None) -> Optional[torch.Tensor]:
-    """Render ``frame_ids`` (this rank's frames; every rank must pass the same number) and gather the RGBA8 frames
-    to ``dst`` while rendering continues: the shard is cut into ``chunks`` pieces, and as soon as a piece is rendered
-    its ``gather`` is launched asynchronously (RCCL runs it on its own stream over xGMI) behind the next piece's
-    rendering, so only the last piece's transfer is left as a tail.  With the pipelined (or serial) driver the
-    frame pipeline is not drained at the piece boundaries; with ``driver="threads"`` each piece is its own
-    ``render_shard`` call.  Returns ``[world, n, 4, H, W]`` on ``dst`` (rank-major), ``None`` elsewhere; without a
-    process group ``[1, n, 4, H, W]``."""
+                      group=None, driver: str = "auto", begin_fn: Optional[BeginFn] = None,
+                      rows: Optional[int] = None, stats: Optional[dict] = None) -> Optional[torch.Tensor]:
+    """Render ``frame_ids`` (this rank's frames) and gather the RGBA8 frames to ``dst`` while rendering continues: the
+    shard is cut into ``chunks`` pieces, and as soon as a piece is rendered its ``gather`` is launched asynchronously
+    (RCCL runs it on its own stream over xGMI) behind the next piece's rendering, so only the last piece's transfer is
+    left as a tail.  With the pipelined (or serial) driver the frame pipeline is not drained at the piece boundaries;
+    with ``driver="threads"`` each piece is its own ``render_shard`` call.
+
+    Shards may differ in length (round-robin over F frames not divisible by the world size): every rank's stack is
+    padded with zero frames to ``rows`` = the longest shard (given, or agreed on with one small all-reduce).  Returns
+    ``[world, rows, 4, H, W]`` on ``dst`` (rank-major; ``frames_in_order`` puts it into frame order), ``None``
+    elsewhere; without a process group ``[1, n, 4, H, W]``.  ``stats`` (optional dict) receives ``render_s`` (host
+    time until the last frame and the last piece's gather are queued) and ``gather_tail_s`` (the wait after that)."""
+    import time
     distributed = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
-    n = len(frame_ids)
+    n_own = len(frame_ids)
+    if rows is None:
+        rows = n_own
+        if distributed and world > 1:
+            t = torch.tensor([n_own], dtype=torch.int64, device=cloud.means3D.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            rows = int(t.item())
+    n = max(int(rows), n_own)
     chunks = max(1, min(int(chunks), n))
+    t_start = time.perf_counter()
     bounds = [n * k // chunks for k in range(chunks + 1)]
     parts, works, out = [], [], [None]
     starts = {b: a for a, b in zip(bounds[:-1], bounds[1:])}
@@ -336,18 +375,36 @@ def render_and_gather(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids
 
     split_available = begin_fn is not None or render_fn is rasterize
     on_gpu = cloud.means3D.device.type == "cuda"
+    if driver == "auto" and begin_fn is not None:
+        driver = "pipelined"
     threaded = on_gpu and int(streams) > 1 and (driver == "threads" or (driver == "auto" and not split_available))
     if threaded:
         for a, b in zip(bounds[:-1], bounds[1:]):
-            transfer(render_shard(cloud, cameras, list(frame_ids[a:b]), bg, False, render_fn, streams, "threads")["rgba8"], b)
+            transfer(render_shard(cloud, cameras, list(frame_ids[a:b]), bg, False, render_fn, streams, "threads",
+                                  pad_to=b - a)["rgba8"], b)
     else:
         render_shard(cloud, cameras, list(frame_ids), bg, False, render_fn, streams, driver, begin_fn,
-                     chunk_ends=bounds[1:], on_chunk=lambda end, done: transfer(done[starts[end]:end], end))
+                     chunk_ends=bounds[1:], on_chunk=lambda end, done: transfer(done[starts[end]:end], end), pad_to=n)
+    t_queued = time.perf_counter()
     for w in works:
         w.wait()
+    if stats is not None:
+        if cloud.means3D.device.type == "cuda":
+            torch.cuda.synchronize(cloud.means3D.device)
+        stats["render_s"] = t_queued - t_start
+        stats["gather_tail_s"] = time.perf_counter() - t_queued
     if not distributed:
         return torch.cat(parts, dim=0)[None]
     return out[0] if rank == dst else None
+
+
+def frames_in_order(gathered: torch.Tensor, num_frames: int) -> torch.Tensor:
+    """``render_and_gather``'s rank-major ``[world, rows, ...]`` result of a round-robin job as ``[num_frames, ...]`` in
+    frame order (frame ``f`` is row ``f // world`` of rank ``f % world``); the padding rows are dropped."""
+    world, rows = int(gathered.shape[0]), int(gathered.shape[1])
+    if num_frames > world * rows:
+        raise ValueError(f"{num_frames} frames do not fit {world} x {rows} rows")
+    return gathered.transpose(0, 1).reshape((world * rows,) + tuple(gathered.shape[2:]))[:num_frames]
 
 
 def render_trajectory(cloud: GaussianCloud, cameras: Sequence[Camera], bg: torch.Tensor, keep_depth: bool = False,

@@ -101,6 +101,69 @@ def test_pipelined_gather_two_ranks(tmp_path, per_rank):
         assert ref.shape == (1, per_rank, 4, 24, 40) and torch.equal(got[r], ref[0])
 
 
+class _FakePending:
+    """GPU-shaped stand-in for ``rasterize_begin``'s result: the work happens in ``finish()``, and the object records
+    in which order the driver began and finished frames."""
+    log = []
+
+    def __init__(self, cloud, cam, bg, tag):
+        self.args, self.tag = (cloud, cam, bg), tag
+        _FakePending.log.append(("begin", tag))
+
+    def finish(self):
+        _FakePending.log.append(("finish", self.tag))
+        return oracle_render(*self.args)
+
+
+def _fake_begin(cloud, cam, bg):
+    return _FakePending(cloud, cam, bg, float(cam.camera_center[0]))
+
+
+def _worker_uneven(rank, world, port, num_frames, split, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cloud = scenes.config_c1(P=300, seed=2)
+        cams = orbit_cameras(num_frames, 40, 24)
+        mine = fp.shard_frames(num_frames, rank, world)               # lengths differ when world does not divide F
+        stats = {}
+        kw = dict(begin_fn=_fake_begin, driver="pipelined", streams=3) if split else dict(render_fn=oracle_render)
+        res = fp.render_and_gather(cloud, cams, mine, torch.zeros(3), chunks=3, stats=stats, **kw)
+        assert stats["render_s"] >= 0.0 and stats["gather_tail_s"] >= 0.0
+        if split:   # three frames in flight: the third is begun before the first is finished
+            kinds = [k for k, _ in _FakePending.log]
+            assert kinds[:min(3, len(mine))] == ["begin"] * min(3, len(mine))
+            assert kinds.count("begin") == kinds.count("finish") == len(mine)
+        if rank == 0:
+            torch.save(fp.frames_in_order(res, num_frames), out_path)
+        else:
+            assert res is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_frames,split", [(5, False), (7, True), (1, True), (6, True)])
+def test_uneven_shards_and_pipelined_driver_two_ranks(tmp_path, num_frames, split):
+    """render_and_gather with F not divisible by the world size (zero-padded last piece), through the blocking
+    render_fn and through the pipelined driver (split calls, three in flight, on_chunk + asynchronous gathers) fed by
+    a GPU-shaped fake: frame for frame what one process renders."""
+    out = str(tmp_path / "gathered.pt")
+    mp.spawn(_worker_uneven, args=(2, _free_port(), num_frames, split, out), nprocs=2, join=True)
+    got = torch.load(out)
+    cloud = scenes.config_c1(P=300, seed=2)
+    cams = orbit_cameras(num_frames, 40, 24)
+    ref = fp.render_trajectory(cloud, cams, torch.zeros(3), render_fn=oracle_render)["rgba8"]
+    assert got.shape == (num_frames, 4, 24, 40) and torch.equal(got, ref)
+
+
+def test_frames_in_order():
+    g = torch.arange(2 * 3).reshape(2, 3, 1)          # rank-major: rank 0 holds frames 0, 2, 4; rank 1 holds 1, 3, (pad)
+    g[0, :, 0] = torch.tensor([0, 2, 4]); g[1, :, 0] = torch.tensor([1, 3, 99])
+    assert fp.frames_in_order(g, 5)[:, 0].tolist() == [0, 1, 2, 3, 4]
+    with pytest.raises(ValueError):
+        fp.frames_in_order(g, 7)
+
+
 def test_shard_frames_round_robin():
     assert fp.shard_frames(10, 0, 4) == [0, 4, 8]
     assert fp.shard_frames(10, 3, 4) == [3, 7]
