@@ -33,6 +33,7 @@ OPT_TILE_CULL = 0
 OPT_SLABS = 1
 OPT_SLAB_FIRST = 2
 OPT_DEFER_COLOUR = 3
+OPT_SLAB_MIN_REST = 4
 
 
 class GsrLibraryError(ImportError):

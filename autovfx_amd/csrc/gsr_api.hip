@@ -43,8 +43,8 @@ constexpr size_t kPinnedBytes = kSlabTableAt + sizeof(gsr::SlabInfo) * gsr::kMax
 constexpr int kTimingRing = 256;
 constexpr int kHeadEvents = 4, kSlabEvents = 5;
 constexpr int kEventsPerCall = kHeadEvents + kSlabEvents * gsr::kMaxSlabs;
-int g_options[GSR_OPT_NUM] = {/*GSR_OPT_TILE_CULL*/ 1, /*GSR_OPT_SLABS*/ 0, /*GSR_OPT_SLAB_FIRST*/ 400,
-                              /*GSR_OPT_DEFER_COLOUR*/ 1};
+int g_options[GSR_OPT_NUM] = {/*GSR_OPT_TILE_CULL*/ 1, /*GSR_OPT_SLABS*/ 2, /*GSR_OPT_SLAB_FIRST*/ 400,
+                              /*GSR_OPT_DEFER_COLOUR*/ 1, /*GSR_OPT_SLAB_MIN_REST*/ 3000000};
 bool g_timing = false;
 thread_local hipEvent_t g_ev[kTimingRing][kEventsPerCall];
 thread_local int g_ev_slabs[kTimingRing];  // depth slabs of the call recorded in each slot
@@ -486,7 +486,10 @@ SlabPlan plan_slabs(bool inference, uint32_t live_bound, int T, int done_words) 
     const int max_slabs = g_options[GSR_OPT_SLABS] > 0 ? g_options[GSR_OPT_SLABS] : gsr::kMaxSlabs;
     const unsigned long long first = (unsigned long long)(g_options[GSR_OPT_SLAB_FIRST] > 0 ? g_options[GSR_OPT_SLAB_FIRST] : 400) *
                                      (unsigned long long)T;
-    if (!inference || max_slabs < 2 || done_words > 4096 || (unsigned long long)live_bound < 2ull * first) return p;
+    const unsigned long long min_rest = (unsigned long long)(g_options[GSR_OPT_SLAB_MIN_REST] > 0 ? g_options[GSR_OPT_SLAB_MIN_REST] : 0);
+    if (!inference || max_slabs < 2 || done_words > 4096 || (unsigned long long)live_bound < 2ull * first ||
+        (unsigned long long)live_bound - first < min_rest)
+        return p;
     unsigned long long at = first, size = first;
     int n = 0;
     while (n < max_slabs - 1 && n < gsr::kMaxSlabs - 1 && at < (unsigned long long)live_bound) {
@@ -784,7 +787,9 @@ int forward_finish(ForwardCall& fc) {
         GSR_HIP(gsr::launch_tile_ranges(slab, T, tk_sorted, ranges, last ? dsts : nullptr, hs, stream));
         GSR_STAGE_CHECK("tile_ranges");
         stamp(kHeadEvents + kSlabEvents * k + 2, stream);
-        if (fc.defer_colour)
+        if (fc.defer_colour && S == 1)
+            GSR_HIP(gsr::launch_sh_colour_all(fc.in, cam, ga.bins, ga.rgb, stream));
+        else if (fc.defer_colour)
             GSR_HIP(gsr::launch_sh_colour(fc.in, cam, ba.V, slab, fc.order, k == 0 ? fc.point_offsets : fc.slab_offsets,
                                           k == 0 ? nullptr : fc.slab_cpos, ga.rgb, stream));
         stamp(kHeadEvents + kSlabEvents * k + 3, stream);

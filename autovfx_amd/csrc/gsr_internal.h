@@ -106,6 +106,9 @@ hipError_t launch_sh_colour(const GaussianInputs& in, const Camera& cam, int V, 
                             const uint32_t* depth_order, const uint32_t* offsets, const uint32_t* cpos,
                             float* rgb, hipStream_t stream);
 
+// ... of every splat that emits pairs at all, in Gaussian order (a deferred-colour call that needs no depth slabs)
+hipError_t launch_sh_colour_all(const GaussianInputs& in, const Camera& cam, const SplatBin* bins, float* rgb, hipStream_t stream);
+
 // ---- binning (gsr_binning.hip): from the depth order to per-tile lists, slab by slab ----
 // What the binning kernels share for one call.
 struct BinningArrays {

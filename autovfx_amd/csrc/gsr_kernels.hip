@@ -296,6 +296,22 @@ __global__ void __launch_bounds__(256) sh_colour_kernel(GaussianInputs in, const
     *reinterpret_cast<F3*>(rgb + 3 * (size_t)i) = col;
 }
 
+// The same for a call that turned out to need no depth slabs (the host learns that only after the projection kernel
+// ran without colours): every splat that emits pairs at all, in GAUSSIAN order, so that the 192-byte records are read
+// as the projection kernel would have read them (lane-strided, every line used) instead of gathered in depth order.
+__global__ void __launch_bounds__(256) sh_colour_all_kernel(GaussianInputs in, const float* __restrict__ cam_pos,
+                                                            const SplatBin* __restrict__ bins, float* __restrict__ rgb) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= in.P || bins[i].wh == 0u) return;
+    int deg = in.sh_degree < 3 ? in.sh_degree : 3;
+    if (deg > 2 && in.M < 16) deg = 2;
+    if (deg > 1 && in.M < 9) deg = 1;
+    if (deg > 0 && in.M < 4) deg = 0;
+    const F3 p = ld3(in.means3D + 3 * (size_t)i);
+    const F3 col = sh_to_rgb(deg, p, ld3(cam_pos), in.shs + 3 * (size_t)in.M * i);
+    *reinterpret_cast<F3*>(rgb + 3 * (size_t)i) = col;
+}
+
 __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means3D,
                                                            const float* __restrict__ vm,
                                                            uint8_t* __restrict__ present) {
@@ -438,6 +454,12 @@ hipError_t launch_sh_colour(const GaussianInputs& in, const Camera& cam, int V, 
     if (V <= 0) return hipSuccess;
     hipLaunchKernelGGL(sh_colour_kernel, dim3(div_up(V, 256)), dim3(256), 0, stream, in, cam.cam_pos, V, slab, depth_order,
                        offsets, cpos, rgb);
+    return hipGetLastError();
+}
+
+hipError_t launch_sh_colour_all(const GaussianInputs& in, const Camera& cam, const SplatBin* bins, float* rgb, hipStream_t stream) {
+    if (in.P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sh_colour_all_kernel, dim3(div_up(in.P, 256)), dim3(256), 0, stream, in, cam.cam_pos, bins, rgb);
     return hipGetLastError();
 }
 

@@ -5,32 +5,44 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A *step* is one ``GaussianRasterizer.forward`` call (SH colour path) on one frame of the workload's
-orbit trajectory, plus the RGBA8 pack of that frame; with N > 1 ranks the frames are dealt
-round-robin (frame-parallel, weak scaling: every rank renders K frames) and the packed frames are
-gathered to rank 0 with one RCCL gather inside the timed region.  Within a GPU the K frames are
-issued on ``--streams`` HIP streams (default 2, one host thread each; 1 = strictly serial calls) so
-that one frame's VALU-bound blend overlaps the next frame's HBM-bound projection and sorts; every
-frame is still one complete forward call and all K are finished inside the timed region.  Inputs (Gaussians, camera
-matrices) are resident in HBM before the clock starts.  Rank 0 prints ONE JSON line.
+A *step* is one ``GaussianRasterizer.forward`` call (SH colour path, an inference call: nothing requires a gradient)
+on one frame of the workload's orbit trajectory, plus the RGBA8 pack of that frame.  Inputs (Gaussians, camera
+matrices) are resident in HBM before the clock starts.  Within a GPU the K frames are issued on ``--streams`` HIP
+streams (default 3) by ONE host thread that splits every call where the host needs the pair count (``--driver
+pipelined``), so that one frame's VALU-bound blend overlaps other frames' HBM- and latency-bound stages; every frame is
+still one complete forward call and all K are finished inside the timed region.
 
-Workload (default ``c3``) = BASELINE.json configs[2] shape on one GPU: 3 M synthetic Gaussians,
-1920x1080, 800-frame orbit, SH degree 3 (M = 16), bg = 0.  ``--workload c2`` is the 1 M / 960x540
-stand-in.  Weights are random by construction (there are no checkpoints offline): data = synthetic.
+The timed region -- W untimed warm-up steps once, then EXACTLY K steps between ``barrier + synchronize`` on both
+sides, max over ranks -- is repeated ``--regions`` times (default 5): ``value`` / ``ms_per_step`` are the MEDIAN
+region, ``regions`` lists them all.
+
+With N > 1 ranks (weak scaling, the default): every rank renders K frames dealt round-robin and the packed frames are
+gathered to rank 0 with RCCL inside the timed region, in pieces that travel behind the rendering of the next piece.
+``--job-frames F`` instead times ONE fixed job (strong scaling; BASELINE configs[2] is 800 frames on 8 GPUs): rank 0
+owns the cloud, one broadcast, F frames dealt round-robin (shards may differ by one frame), pipelined gather.
+
+Workload (default ``c3``) = BASELINE.json configs[2] shape on one GPU: 3 M synthetic Gaussians, 1920x1080, 800-frame
+orbit, SH degree 3 (M = 16), bg = 0.  Other workloads (``--workload``; short runs of them also ride on the default
+line under ``also``): ``c2`` 1 M / 960x540; ``heavy`` a trained-scene-like stress cloud (heavy-tailed sizes, 10:1
+anisotropy, bimodal opacity); ``c4`` 200 k flat SuGaR-style Gaussians, RGB + normal + depth in one fused call;
+``c5`` C2 frames -> RGBA8 -> composited with synthetic Blender layers.  Data is synthetic by construction.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel of the frame, measured live with HIP events recorded by the library
-                on the launch stream during the timed region; ``frame`` holds the whole-frame figure
-                against SURVEY.md section 8d's B_alg.
-  cpu_baseline  the CPU oracle (C + OpenMP restatement of the reference kernels, oracle/) timed on
-                this box's host cores on a bounded sample (rank 0, N = 1 only), with the parity of
-                the GPU frame against it.
+  roofline      dominant kernel of the frame (the blend): algorithmic bytes per launch / average launch time, measured
+                with HIP events recorded by the library on the launch stream in an untimed single-stream replay right
+                after the timed regions (``stage_replay_calls`` frames; rocprofv3 of ``--streams 1`` agrees);
+                ``traffic`` = HBM bytes per launch from the committed PMC passes (profiles/, stamped with the commit they
+                were taken at); ``frame`` = the whole frame against SURVEY.md 8d's B_alg and against counter traffic.
+  cpu_baseline  the CPU oracle (C + OpenMP restatement of the reference kernels, oracle/) and the PyTorch-CPU splat
+                (oracle/torch_splat.py) timed on this box's host cores on a bounded sample (rank 0, N = 1 only), with
+                the parity of the GPU frames against the oracle (first / middle / last frame of the orbit).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -48,6 +60,17 @@ WORKLOADS = {
                cfg="config_c3", width=1920, height=1080, frames=800),
     "c2": dict(name="C2 stand-in: 1M synthetic Gaussians, 960x540, 200-frame orbit (BASELINE configs[1])",
                cfg="config_c2", width=960, height=540, frames=200),
+    "heavy": dict(name="heavy: 1M trained-scene-like Gaussians (log-normal sizes sigma 1.2, 10:1 anisotropy, bimodal "
+                       "opacity), 960x540, 200-frame orbit (stress workload, not a BASELINE config)",
+                  cfg="config_heavy", width=960, height=540, frames=200),
+    "heavy1080": dict(name="heavy at 1920x1080 (stress workload, not a BASELINE config)",
+                      cfg="config_heavy", width=1920, height=1080, frames=200),
+    "c4": dict(name="C4: 200k flat SuGaR-style Gaussians, colors_precomp, RGB + normal + depth in one fused call, "
+                    "960x540, 50-frame orbit (BASELINE configs[3])",
+               cfg="config_c4", width=960, height=540, frames=50),
+    "c5": dict(name="C5: C2 frames -> RGBA8 -> composite with synthetic Blender layers (object, shadow catcher, 3DGS "
+                    "object, smoke + fire), 960x540, 400 frames (BASELINE configs[4])",
+               cfg="config_c2", width=960, height=540, frames=400),
 }
 
 
@@ -55,8 +78,9 @@ def algorithmic_bytes(P, V, D, T, W, H, M=16):
     """SURVEY.md section 8d, per stage (bytes per frame)."""
     bit = max(1, int(T).bit_length())
     n_pass = -(-(32 + bit) // 8)
+    vis = (32 + 12 * M + 40) if M else (32 + 12 + 40)   # colors_precomp: 12 B read instead of the SH record
     st = {
-        "preprocess": 20 * P + (32 + 12 * M + 40) * V,
+        "preprocess": 20 * P + vis * V,
         "scan": 8 * P,
         "duplicate": 20 * V + 12 * D,
         "sort": 24 * D * n_pass,
@@ -68,16 +92,224 @@ def algorithmic_bytes(P, V, D, T, W, H, M=16):
     return st
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# one workload on this rank's GPU
+# ---------------------------------------------------------------------------------------------------------------------
+class Bench:
+    """A workload resident on the GPU and the ways of pushing frames through it."""
+
+    def __init__(self, key, device, args, boundary="op", gaussians=0):
+        from autovfx_amd import scenes
+        from autovfx_amd.cameras import orbit_cameras
+        self.key, self.device, self.boundary = key, device, boundary
+        wl = WORKLOADS[key]
+        self.name, self.W, self.H, self.F = wl["name"], wl["width"], wl["height"], wl["frames"]
+        cfg = getattr(scenes, wl["cfg"])
+        self.cloud_cpu = cfg(P=gaussians) if gaussians else cfg()
+        self.cloud = self.cloud_cpu.to(device)
+        self.cams_cpu = orbit_cameras(self.F, self.W, self.H)
+        self._cams = {}
+        self.bg = torch.zeros(3, dtype=torch.float32, device=device)
+        self.P = self.cloud.P
+        self.M = int(self.cloud.shs.shape[1]) if self.cloud.shs is not None else 0
+        self.T = ((self.W + 15) // 16) * ((self.H + 15) // 16)
+        self.extra = None
+        self.layers = None
+        self.model = None
+        if key == "c4":   # the per-Gaussian normals SuGaR renders beside the colours (sugar_model.py:2174-2183)
+            n = self.cloud.means3D / self.cloud.means3D.norm(dim=1, keepdim=True)
+            self.extra = (n * 0.5 + 0.5).contiguous()
+        if key == "c5":
+            self.layers = synthetic_blender_layers(self.W, self.H, device)
+        if boundary == "render":
+            from autovfx_amd.gaussian_model import GaussianModel
+            c = self.cloud
+            self.model = GaussianModel.from_activated(c.means3D, c.opacities, c.scales, c.rotations, c.shs, c.sh_degree)
+
+    def cam(self, f):
+        f %= self.F
+        if f not in self._cams:
+            self._cams[f] = self.cams_cpu[f].to(self.device)
+        return self._cams[f]
+
+    # -- the per-frame call, in split form: begin(frame) -> pending; finish(pending) -> (color, depth, alpha, radii) --
+    def begin(self, f):
+        cam = self.cam(f)
+        if self.boundary == "render":
+            from autovfx_amd import renderer
+            return renderer.render_begin(cam, self.model, renderer.PipelineParams, self.bg)
+        if self.extra is not None:
+            from diff_gaussian_rasterization import _C
+            from autovfx_amd.frame_parallel import settings_for_camera
+            s = settings_for_camera(cam, self.bg, self.cloud.sh_degree)
+            e = torch.empty(0, dtype=torch.float32, device=self.device)
+            return _C.rasterize_gaussians_begin(
+                s.bg, self.cloud.means3D, self.cloud.colors_precomp, self.cloud.opacities, self.cloud.scales,
+                self.cloud.rotations, s.scale_modifier, e, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy,
+                s.image_height, s.image_width, e, s.sh_degree, s.campos, s.prefiltered, s.debug, self.extra, inference=True)
+        from autovfx_amd.frame_parallel import rasterize_begin
+        return rasterize_begin(self.cloud, cam, self.bg)
+
+    def finish(self, pending):
+        out = pending.finish()
+        if self.boundary == "render":
+            return out["render"][:3], out["depth"][None], out["render"][3:4], out["radii"]
+        if self.extra is not None:
+            _n, color, depth, alpha, radii, _g, _b, _i, normal = out
+            return color, depth, alpha, radii
+        return out
+
+    def consume(self, slot, result, rgba, composed=None):
+        from autovfx_amd.frame_parallel import pack_rgba8
+        color, _depth, alpha, _radii = result
+        pack_rgba8(color, alpha, out=rgba[slot])
+        if self.layers is not None:   # C5: the frame is the background layer of the composite (blend_all.py:236-300)
+            from autovfx_amd.compositor import composite_frame
+            L = self.layers
+            bg_c = rgba[slot].permute(1, 2, 0).contiguous()   # planar RGBA8 -> the interleaved layout image files have
+            composite_frame(bg_c, L["o_c"], L["o_d"], L["s_c"], L["s_d"], L["o_s_c"], L["o_gs_c"], L["o_gs_d"],
+                            L["s_f_c"], L["s_f_d"], L["s_f_c_pre"], out=composed[slot])
+
+    def run(self, frames, rgba, streams, side, composed=None):
+        """Render `frames` (orbit indices) into rgba[0..]; S > 1: one host thread keeps S split calls in flight."""
+        with torch.no_grad():
+            if streams <= 1:
+                for j, f in enumerate(frames):
+                    self.consume(j % rgba.shape[0], self.finish(self.begin(f)), rgba, composed)
+                return
+            from collections import deque
+            in_flight = deque()
+
+            def finish_oldest():
+                j, st, pending = in_flight.popleft()
+                with torch.cuda.stream(st):
+                    self.consume(j % rgba.shape[0], self.finish(pending), rgba, composed)
+
+            for j, f in enumerate(frames):
+                if len(in_flight) == streams:
+                    finish_oldest()
+                st = side[j % streams]
+                with torch.cuda.stream(st):
+                    in_flight.append((j, st, self.begin(f)))
+            while in_flight:
+                finish_oldest()
+            for st in side:
+                torch.cuda.current_stream(self.device).wait_stream(st)
+
+    def stats(self, frames):
+        """(mean visible, mean num_rendered) over `frames` (untimed)."""
+        from diff_gaussian_rasterization import _C
+        Vs, Ds = [], []
+        e = torch.Tensor([])
+        c = self.cloud
+        with torch.no_grad():
+            for f in frames:
+                cam = self.cam(f)
+                n, _c, _d, _a, radii, *_ = _C.rasterize_gaussians(
+                    self.bg, c.means3D, e if c.colors_precomp is None else c.colors_precomp, c.opacities, c.scales,
+                    c.rotations, 1.0, e, cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy,
+                    self.H, self.W, e if c.shs is None else c.shs, c.sh_degree, cam.camera_center, False, False,
+                    inference=True)
+                Ds.append(int(n))
+                Vs.append(int((radii > 0).sum().item()))
+        return float(np.mean(Vs)), float(np.mean(Ds))
+
+
+def synthetic_blender_layers(W, H, device, seed=11):
+    """The layers blend_all.py reads from Blender's output folders, synthetic and resident: an object pass, a shadow
+    catcher pass and their union, a re-rendered 3DGS object, smoke + premultiplied fire; RGBA8 [H,W,4] + fp32 depth."""
+    from autovfx_amd.compositor import smoke_depth_fill
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+
+    def blob(cx, cy, r):
+        d2 = ((xx - cx * W) / (r * W)) ** 2 + ((yy - cy * H) / (r * W)) ** 2
+        return torch.clamp(1.5 - d2, 0.0, 1.0)
+
+    def rgba(alpha, tint):
+        rgb = torch.rand(H, W, 3, generator=g) * 0.3 + torch.tensor(tint).view(1, 1, 3) * 0.7
+        return torch.cat((rgb * 255.0, alpha[..., None] * 255.0), dim=2).clamp(0, 255).to(torch.uint8)
+
+    a_obj, a_gs, a_smoke = blob(0.45, 0.55, 0.12), blob(0.62, 0.5, 0.08), blob(0.5, 0.35, 0.2) * 0.6
+    far = torch.full((H, W), 1e10)
+    L = {
+        "o_c": rgba(a_obj, (0.8, 0.3, 0.2)), "o_d": torch.where(a_obj > 0, 3.0 + torch.rand(H, W, generator=g), far),
+        "s_c": rgba(torch.ones(H, W), (0.7, 0.7, 0.7)), "s_d": 4.0 + torch.rand(H, W, generator=g),
+        "o_s_c": rgba(torch.clamp(blob(0.45, 0.62, 0.16), 0, 1), (0.4, 0.4, 0.4)),
+        "o_gs_c": rgba(a_gs, (0.2, 0.6, 0.3)), "o_gs_d": torch.where(a_gs > 0, 2.5 + torch.rand(H, W, generator=g), far),
+        "s_f_c": rgba(a_smoke, (0.5, 0.5, 0.5)), "s_f_d": 2.0 + 3.0 * torch.rand(H, W, generator=g),
+        "s_f_c_pre": rgba(a_smoke * 0.5, (0.9, 0.5, 0.1)),
+    }
+    L = {k: v.contiguous().to(device) for k, v in L.items()}
+    L["s_f_d"] = smoke_depth_fill(L["s_f_c"], L["s_f_d"])
+    return L
+
+
+def timed_regions(fn, regions, distributed, device):
+    """[seconds] of `regions` executions of fn(), each bracketed by barrier + synchronize; max over ranks."""
+    import torch.distributed as dist
+    out = []
+    for _ in range(regions):
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        out.append(time.perf_counter() - t0)
+    if distributed:
+        t = torch.tensor(out, dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out = [float(v) for v in t.tolist()]
+    return out
+
+
+def quick(key, device, side, streams, steps, warmup, regions, boundary="op", gaussians=0):
+    """A short run of another workload for the `also` object: median-region frames/s, single-stream stage times."""
+    from autovfx_amd import _lib
+    b = Bench(key, device, None, boundary=boundary, gaussians=gaussians)
+    rgba = torch.empty((min(steps, 64), 4, b.H, b.W), dtype=torch.uint8, device=device)
+    composed = torch.empty((min(steps, 64), b.H, b.W, 4), dtype=torch.uint8, device=device) if b.layers is not None else None
+    frames = [(warmup + j) % b.F for j in range(steps)]
+    for f in frames:   # camera matrices resident before the clock starts
+        b.cam(f)
+    b.run([j % b.F for j in range(warmup)], rgba, streams, side, composed)
+    secs = timed_regions(lambda: b.run(frames, rgba, streams, side, composed), regions, False, device)
+    med = sorted(secs)[len(secs) // 2]
+    _lib.set_stage_timing(True)
+    b.run(frames[:12], rgba, 1, side, composed)
+    torch.cuda.synchronize()
+    st = _lib.stage_times_ms()
+    call_ms = sorted(_lib.call_times_ms())
+    _lib.set_stage_timing(False)
+    st.pop("calls")
+    V, D = b.stats(frames[::max(1, steps // 4)])
+    out = {"workload": b.name, "boundary": boundary, "value": round(steps / med, 1), "unit": "frames/s", "steps": steps,
+           "regions": regions, "streams": streams, "ms_per_step": round(med / steps * 1e3, 4),
+           "single_stream_ms_p50": round(call_ms[len(call_ms) // 2], 4) if call_ms else None,
+           "stage_ms": {k: round(v, 4) for k, v in st.items()}, "P": b.P, "visible_mean": round(V, 1),
+           "num_rendered_mean": round(D, 1), "pairs_per_gaussian": round(D / max(1, b.P), 2)}
+    return b, out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--regions", type=int, default=5, help="how many times the K-step timed region is repeated (median reported)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--gaussians", type=int, default=0, help="override P (parity/debug only; invalidates the metric)")
+    ap.add_argument("--job-frames", type=int, default=0,
+                    help="strong scaling: time ONE job of this many frames over all ranks (cloud broadcast from rank 0, "
+                         "round-robin shards, pipelined gather) instead of K frames per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-hip", action="store_true",
                     help="skip timing the reference's own kernels compiled for gfx950 (oracle/_ref/libgsr_ref_hip.so)")
+    ap.add_argument("--no-also", action="store_true", help="skip the short runs of the other workloads (`also`)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of the frames to rank 0 (N > 1)")
     ap.add_argument("--force-distributed", action="store_true",
                     help="debug: take the N > 1 code path (process group, barriers, pipelined RCCL gather) even with "
@@ -87,16 +319,16 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="render frames on this many HIP streams so independent frames overlap")
     ap.add_argument("--driver", choices=["auto", "pipelined", "threads"], default="auto",
-                    help="how the streams are fed: 'pipelined' = one host thread, each call split where the host needs "
-                         "the pair count; 'threads' = one blocking host thread per stream; auto = pipelined")
+                    help="N > 1 path only: how render_and_gather feeds the streams (auto = pipelined)")
     ap.add_argument("--boundary", choices=["op", "render"], default="op",
                     help="op: one GaussianRasterizer.forward per frame (the headline); render: the reference's "
                          "whole per-frame render() = activations + SH pass + normal pass + normal post-processing")
-    ap.add_argument("--no-geometry-cache", action="store_true", help="A/B knob: recompute geometry for the 2nd pass")
     ap.add_argument("--no-cull", action="store_true", help="A/B knob: GSR_OPT_TILE_CULL = 0")
     ap.add_argument("--slabs", type=int, default=None, help="A/B knob: GSR_OPT_SLABS (1 = no depth slabs; default: as the scene calls for)")
     ap.add_argument("--slab-first", type=int, default=None, help="A/B knob: GSR_OPT_SLAB_FIRST (pairs per tile in the first slab)")
     ap.add_argument("--no-defer-colour", action="store_true", help="A/B knob: GSR_OPT_DEFER_COLOUR = 0")
+    ap.add_argument("--profile-run", action="store_true",
+                    help="for rocprofv3: only warm-up + ONE timed region of uniform calls (no replay, statistics, baselines)")
     args = ap.parse_args()
 
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner to the C-level stdout when a process
@@ -124,10 +356,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
 
-    from autovfx_amd import _lib, scenes
-    from autovfx_amd.cameras import orbit_cameras
-    from autovfx_amd.frame_parallel import pack_rgba8, rasterize, rasterize_begin, render_and_gather, side_streams
-    from diff_gaussian_rasterization import _C
+    from autovfx_amd import _lib
+    from autovfx_amd.frame_parallel import (broadcast_cloud, frames_in_order, rasterize, rasterize_begin, render_and_gather,
+                                            shard_frames, side_streams)
 
     if args.no_cull:
         _lib.set_option(_lib.OPT_TILE_CULL, 0)
@@ -137,166 +368,107 @@ def main():
         _lib.set_option(_lib.OPT_SLAB_FIRST, args.slab_first)
     if args.no_defer_colour:
         _lib.set_option(_lib.OPT_DEFER_COLOUR, 0)
-    wl = WORKLOADS[args.workload]
-    W, H, F = wl["width"], wl["height"], wl["frames"]
-    cfg = getattr(scenes, wl["cfg"])
-    cloud_cpu = cfg(P=args.gaussians) if args.gaussians else cfg()
-    cloud = cloud_cpu.to(device)
-    cams_cpu = orbit_cameras(F, W, H)
-    K, Wm = args.steps, args.warmup
+
+    b = Bench(args.workload, device, args, boundary=args.boundary, gaussians=args.gaussians)
+    W, H, F, P, M, T = b.W, b.H, b.F, b.P, b.M, b.T
+    K, Wm, R = args.steps, args.warmup, max(1, args.regions)
+    if args.profile_run:
+        R = 1
+    S = max(1, args.streams)
+    side = side_streams(device, S) if S > 1 else []   # the driver's own: allocator pools warmed here stay warm there
+    driver = "pipelined" if args.driver == "auto" else args.driver
+    strong = args.job_frames > 0
     # rank r renders frames r, r+N, ... ; warm-up frames precede the timed ones on the same orbit
     frame_of = lambda i: (i * world + rank) % F
-    need = sorted({frame_of(i) for i in range(Wm + K)})
-    cams = {f: cams_cpu[f].to(device) for f in need}
-    bg = torch.zeros(3, dtype=torch.float32, device=device)
-    rgba = torch.empty((K, 4, H, W), dtype=torch.uint8, device=device)
-    P, M = cloud.P, int(cloud.shs.shape[1])
-    T = ((W + 15) // 16) * ((H + 15) // 16)
+    if strong:
+        my_ids = shard_frames(args.job_frames, rank, world)
+        K = (args.job_frames + world - 1) // world   # "steps" = frames of the longest shard
+    rgba = torch.empty((max(1, min(K, 256)), 4, H, W), dtype=torch.uint8, device=device)
+    composed = torch.empty((rgba.shape[0], H, W, 4), dtype=torch.uint8, device=device) if b.layers is not None else None
 
-    if args.no_geometry_cache:
-        _C.set_geometry_cache(False)
-    if args.boundary == "render":
+    def render_fn_boundary(_cloud, cam, bg_):
         from autovfx_amd import renderer
-        from autovfx_amd.gaussian_model import GaussianModel
-        model = GaussianModel.from_activated(cloud.means3D, cloud.opacities, cloud.scales, cloud.rotations, cloud.shs,
-                                             cloud.sh_degree)
+        out = renderer.render(cam, b.model, renderer.PipelineParams, bg_)
+        return out["render"][:3], out["depth"][None], out["render"][3:4], out["radii"]
 
-        def render_fn_boundary(_cloud, cam, bg_):
-            out = renderer.render(cam, model, renderer.PipelineParams, bg_)
+    class _PendingBoundary:
+        def __init__(self, pending):
+            self.pending = pending
+
+        def finish(self):
+            out = self.pending.finish()
             return out["render"][:3], out["depth"][None], out["render"][3:4], out["radii"]
 
-        class _PendingBoundary:
-            def __init__(self, pending):
-                self.pending = pending
+    def begin_fn_boundary(_cloud, cam, bg_):
+        from autovfx_amd import renderer
+        return _PendingBoundary(renderer.render_begin(cam, b.model, renderer.PipelineParams, bg_))
 
-            def finish(self):
-                out = self.pending.finish()
-                return out["render"][:3], out["depth"][None], out["render"][3:4], out["radii"]
+    begin_fn = begin_fn_boundary if args.boundary == "render" else rasterize_begin
+    render_fn = render_fn_boundary if args.boundary == "render" else rasterize
+    gather_stats, gathered_shape = {}, [None]
 
-        def begin_fn(_cloud, cam, bg_):
-            return _PendingBoundary(renderer.render_begin(cam, model, renderer.PipelineParams, bg_))
+    timed_frames = [frame_of(Wm + j) for j in range(K)]
+    for f in timed_frames:   # camera matrices resident before the clock starts
+        b.cam(f)
+    if distributed and not args.no_gather and not strong:
+        cam_list = [b.cam(f) for f in timed_frames]
 
-        def step(i, slot):
-            out = renderer.render(cams[frame_of(i)], model, renderer.PipelineParams, bg)
-            pack_rgba8(out["render"][:3], out["render"][3:4], out=rgba[slot % K])
+        def region():
+            g = render_and_gather(b.cloud, cam_list, list(range(K)), b.bg, dst=0, streams=S, chunks=args.gather_chunks,
+                                  driver=driver, begin_fn=begin_fn, render_fn=render_fn, rows=K, stats=gather_stats)
+            gathered_shape[0] = None if g is None else tuple(g.shape)
+    elif strong:
+        job_cams = [b.cam(f) for f in range(min(args.job_frames, F))]
+        job_cams = [job_cams[f % len(job_cams)] for f in range(args.job_frames)]
+        src_cloud = b.cloud
+
+        def region():
+            # the whole job: the cloud reaches every rank (rank 0 "has the file"), shards, pipelined gather
+            cloud = broadcast_cloud(src_cloud if rank == 0 else None, src=0, device=device) if distributed else src_cloud
+            g = render_and_gather(cloud, job_cams, my_ids, b.bg, dst=0, streams=S, chunks=args.gather_chunks, driver=driver,
+                                  begin_fn=begin_fn, render_fn=render_fn, rows=K, stats=gather_stats)
+            if g is not None:
+                gathered_shape[0] = tuple(frames_in_order(g, args.job_frames).shape) if distributed else tuple(g.shape)
     else:
-        begin_fn = rasterize_begin
-
-        def step(i, slot):
-            color, _depth, alpha, _radii = rasterize(cloud, cams[frame_of(i)], bg)
-            pack_rgba8(color, alpha, out=rgba[slot % K])
-
-    S = max(1, args.streams)
-    streams = side_streams(device, S) if S > 1 else []   # the driver's own: allocator pools warmed here stay warm there
-    driver = args.driver
-    if driver == "auto":
-        driver = "pipelined"
-
-    def run_steps(first, count):
-        """Steps first .. first+count-1; with S > 1 streams, step j goes to host thread / stream j % S."""
-        if S == 1:
-            for j in range(count):
-                step(first + j, j)
-            return
-        if driver == "pipelined":   # one host thread; frame j's second half is queued after frame j+S-1's first half
-            from collections import deque
-            in_flight = deque()
-
-            def finish_oldest():
-                j, st, pending = in_flight.popleft()
-                with torch.cuda.stream(st):
-                    color, _depth, alpha, _radii = pending.finish()
-                    pack_rgba8(color, alpha, out=rgba[j % K])
-
-            with torch.no_grad():
-                for j in range(count):
-                    if len(in_flight) == S:
-                        finish_oldest()
-                    st = streams[j % S]
-                    with torch.cuda.stream(st):
-                        in_flight.append((j, st, begin_fn(cloud, cams[frame_of(first + j)], bg)))
-                while in_flight:
-                    finish_oldest()
-            for st in streams:
-                torch.cuda.current_stream(device).wait_stream(st)
-            return
-        import threading
-
-        def worker(t):
-            torch.cuda.set_device(device)
-            with torch.no_grad(), torch.cuda.stream(streams[t]):
-                for j in range(t, count, S):
-                    step(first + j, j)
-
-        threads = [threading.Thread(target=worker, args=(t,)) for t in range(S)]
-        for th in threads:
-            th.start()
-        for th in threads:
-            th.join()
-        for st in streams:   # later work on the caller's stream sees every frame
-            torch.cuda.current_stream(device).wait_stream(st)
+        def region():
+            b.run(timed_frames, rgba, S, side, composed)
 
     with torch.no_grad():
-        run_steps(0, Wm)
+        b.run([frame_of(i) for i in range(Wm)], rgba, S, side, composed)
         if S > 1 and Wm < 2 * S + 2:   # every stream's allocator pool and scratch sizes settle before the clock starts
-            run_steps(Wm, min(K, 2 * S + 2 - Wm))   # untimed; these frames are rendered again inside the timed region
-        if distributed and not args.no_gather:
-            # the gather path's own warm-up: the frame stack, the receive buffers and RCCL's first gather are
-            # allocated / initialised by an untimed rehearsal of the same call (its frames are rendered again below)
-            cam_list = [cams[frame_of(Wm + j)] for j in range(K)]
-            render_and_gather(cloud, cam_list, list(range(K)), bg, dst=0, streams=S, chunks=args.gather_chunks,
-                              driver=driver, begin_fn=begin_fn,
-                              render_fn=(render_fn_boundary if args.boundary == "render" else rasterize))
-        _lib.set_stage_timing(S == 1)   # per-stage events are per host thread; only read them single-stream
-        torch.cuda.synchronize()
+            b.run(timed_frames[:2 * S + 2 - Wm], rgba, S, side, composed)
+        if distributed or strong:
+            region()   # the gather path's own rehearsal: frame stack, receive buffers, RCCL's first gather (untimed)
+        _lib.set_stage_timing(False)
+        secs = timed_regions(region, R, distributed, device)
+
+    if args.profile_run:
+        if rank == 0:
+            os.write(json_fd, (json.dumps({"profile_run": True, "steps": K, "warmup": Wm, "streams": S,
+                                           "ms_per_step": round(secs[0] / K * 1e3, 4)}) + "\n").encode())
         if distributed:
-            dist.barrier()
-        t0 = time.perf_counter()
-        gathered = None
-        if distributed and not args.no_gather:
-            # N > 1: the same per-frame work through the frame-parallel driver, whose gather to rank 0 is cut into
-            # pieces that travel over xGMI behind the rendering of the next piece (only the last one is a tail)
-            gathered = render_and_gather(cloud, cam_list, list(range(K)), bg, dst=0, streams=S, chunks=args.gather_chunks,
-                                         driver=driver, begin_fn=begin_fn,
-                                         render_fn=(render_fn_boundary if args.boundary == "render" else rasterize))
-        else:
-            run_steps(Wm, K)
+            dist.destroy_process_group()
+        return
+
+    # ---- stage breakdown: an untimed single-stream replay of the first timed frames, HIP events on the launch stream ----
+    with torch.no_grad():
+        _lib.set_stage_timing(True)
+        b.run(timed_frames[:min(K, 32)], rgba, 1, side, composed)
         torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
-        if S > 1:   # stage breakdown from an untimed single-stream replay of the first frames
-            _lib.set_stage_timing(True)
-            for j in range(min(K, 16)):
-                step(Wm + j, j)
-            torch.cuda.synchronize()
         stage_ms = _lib.stage_times_ms()
         call_ms = sorted(_lib.call_times_ms())
+        slab_pairs = _lib.slab_pairs()
         _lib.set_stage_timing(False)
 
-    if distributed:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    order = sorted(secs)
+    med = order[len(order) // 2]
+    total_frames = args.job_frames if strong else K * world
+    fps = lambda s: total_frames / s
+    ms_per_step = med / K * 1e3
 
     # ---- per-frame workload statistics (untimed): V and D of this rank's timed frames ----
-    Vs, Ds = [], []
-    sample = list(range(0, K, max(1, K // 8)))
-    with torch.no_grad():
-        e = torch.Tensor([])
-        for i in sample:
-            cam = cams[frame_of(Wm + i)]
-            n, _c, _d, _a, radii, *_ = _C.rasterize_gaussians(
-                bg, cloud.means3D, e, cloud.opacities, cloud.scales, cloud.rotations, 1.0, e,
-                cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy, H, W, cloud.shs,
-                cloud.sh_degree, cam.camera_center, False, False)
-            Ds.append(int(n))
-            Vs.append(int((radii > 0).sum().item()))
-    V, D = float(np.mean(Vs)), float(np.mean(Ds))
+    V, D = b.stats(timed_frames[::max(1, K // 8)])
     alg = algorithmic_bytes(P, V, D, T, W, H, M)
-
-    fps = K * world / elapsed
-    ms_per_step = elapsed / K * 1e3
 
     calls = stage_ms.pop("calls")
     stage_alg = {"preprocess": alg["preprocess"], "depth_sort": 0, "scan": alg["scan"], "duplicate": alg["duplicate"],
@@ -304,83 +476,193 @@ def main():
     stages = {k: {"ms": round(v, 4), "alg_bytes": int(stage_alg[k]),
                   "alg_GBps": round(stage_alg[k] / (v * 1e-3) / 1e9, 1) if v > 0 else None}
               for k, v in stage_ms.items()}
+    # the dominant kernel of the frame is the blend; an inference call launches it once per depth slab, so "per launch"
+    # figures are the frame's blend figures divided by the launches of a frame (what rocprofv3's per-kernel average is)
     dom = max(stage_ms, key=stage_ms.get)
     kernel_of = {"blend": "blend_quadrant_kernel", "preprocess": "preprocess_kernel", "duplicate": "expand_kernel",
                  "ranges": "tile_ranges_kernel", "colour": "sh_colour_kernel"}
-    traffic, traffic_src = pmc_traffic(kernel_of.get(dom, dom)) if (args.workload == "c3" and not args.gaussians) else (None, None)
+    launches = max(1, len(slab_pairs)) if dom in ("blend", "duplicate", "ranges", "colour", "tile_sort") else 1
+    traffic = pmc_traffic(T_key=args.workload if not args.gaussians else None)
+    dom_kernel = kernel_of.get(dom, dom)
+    dom_traffic = None
+    if traffic is not None and dom_kernel in traffic["kernels"]:
+        dom_traffic = int(traffic["kernels"][dom_kernel]["bytes_per_launch"])
     dom_gbps = stage_alg[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
     frame_gbps = alg["frame"] / (ms_per_step * 1e-3) / 1e9
+    frame = {"alg_bytes": int(alg["frame"]), "achieved": round(frame_gbps, 1),
+             "frac": round(frame_gbps / HBM_PEAK_GBPS, 4), "n_pass_ref_sort": alg["n_pass"],
+             # one frame alone on the GPU, first kernel to last (HIP events), over the per-stage replay
+             "single_stream_ms_p50": round(call_ms[len(call_ms) // 2], 4) if call_ms else None,
+             "single_stream_ms_p95": round(call_ms[min(len(call_ms) - 1, int(0.95 * len(call_ms)))], 4) if call_ms else None}
+    if traffic is not None:
+        tr_gbps = traffic["frame_bytes"] / (ms_per_step * 1e-3) / 1e9
+        frame.update({"traffic": int(traffic["frame_bytes"]), "achieved_traffic": round(tr_gbps, 1),
+                      "frac_traffic": round(tr_gbps / HBM_PEAK_GBPS, 4)})
     roofline = {
-        "bound": "hbm", "kernel": kernel_of.get(dom, dom),
+        "bound": "hbm", "kernel": dom_kernel,
         "achieved": round(dom_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": round(dom_gbps / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-        "avg_launch_ms": round(stage_ms[dom], 4), "alg_bytes_per_launch": int(stage_alg[dom]),
-        "timed_calls": calls,
-        "frame": {"alg_bytes": int(alg["frame"]), "achieved": round(frame_gbps, 1),
-                  "frac": round(frame_gbps / HBM_PEAK_GBPS, 4), "n_pass_ref_sort": alg["n_pass"],
-                  # one frame alone on the GPU, first kernel to last (HIP events), over the per-stage replay
-                  "single_stream_ms_p50": round(call_ms[len(call_ms) // 2], 4) if call_ms else None,
-                  "single_stream_ms_p95": round(call_ms[min(len(call_ms) - 1, int(0.95 * len(call_ms)))], 4) if call_ms else None},
-        "stages": stages,
+        "frac": round(dom_gbps / HBM_PEAK_GBPS, 4), "traffic": dom_traffic,
+        "traffic_source": None if traffic is None else traffic["source"],
+        "traffic_measured_at": None if traffic is None else traffic["commit"],
+        "launches_per_frame": launches, "avg_launch_ms": round(stage_ms[dom] / launches, 4),
+        "alg_bytes_per_launch": int(stage_alg[dom] / launches), "per_frame_ms": round(stage_ms[dom], 4),
+        "alg_bytes_per_frame": int(stage_alg[dom]), "stage_replay_calls": calls,
+        "note": "vector-instruction-issue bound, not HBM bound (DESIGN.md section 4): frac is algorithmic bytes over HBM peak",
+        "frame": frame, "stages": stages, "slab_pairs_last_frame": slab_pairs,
     }
 
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(cloud_cpu, cams_cpu, frame_of(Wm), cloud, cams, bg, W, H)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.boundary == "op" and b.key in ("c3", "c2", "heavy", "heavy1080"):
+        cpu_baseline = run_cpu_baseline(b)
     reference_on_gpu = None
-    if rank == 0 and world == 1 and args.boundary == "op" and not args.no_reference_hip:
-        reference_on_gpu = run_reference_on_gpu(cloud, [cams[frame_of(Wm + j)] for j in range(min(K, 24))], bg)
+    if rank == 0 and world == 1 and args.boundary == "op" and not args.no_reference_hip and b.extra is None and b.layers is None:
+        reference_on_gpu = run_reference_on_gpu(b.cloud, [b.cam(f) for f in timed_frames[:24]], b.bg)
+
+    also = None
+    if rank == 0 and world == 1 and not args.no_also and args.workload == "c3" and not args.gaussians and args.boundary == "op":
+        also = run_also(device, side, S)
 
     if rank == 0:
+        metric = ("rendered frames/sec at 1920x1080, 3M Gaussians" if args.workload == "c3" and not args.gaussians
+                  else f"rendered frames/sec at {W}x{H}, {P} Gaussians ({args.workload})")
         line = {
-            "metric": ("rendered frames/sec at 1920x1080, 3M Gaussians" if args.workload == "c3" and not args.gaussians
-                       else f"rendered frames/sec at {W}x{H}, {P} Gaussians")
-                      + (" [render() boundary]" if args.boundary == "render" else ""),
-            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl["name"], "P": P, "sh_coeffs": M, "width": W, "height": H, "tiles": T,
+            "metric": metric + (" [render() boundary]" if args.boundary == "render" else ""),
+            "value": round(fps(med), 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "regions": {"count": R, "steps_each": K, "value_median": round(fps(med), 2), "value_min": round(fps(order[-1]), 2),
+                        "value_max": round(fps(order[0]), 2), "values": [round(fps(s), 2) for s in secs]},
+            "config": {"workload": b.name, "P": P, "sh_coeffs": M, "width": W, "height": H, "tiles": T,
                        "visible_mean": round(V, 1), "num_rendered_mean": round(D, 1),
-                       "boundary": ("render(): activations, SH pass, normal pass (geometry reused), normal/pseudo-normal "
+                       "boundary": ("render(): activations, SH pass, normal pass (folded into the first), normal/pseudo-normal "
                                     "post-processing, RGBA8 pack per frame" if args.boundary == "render" else
-                                    "GaussianRasterizer.forward (SH) + RGBA8 pack per frame")
-                                   + ("; RCCL gather of the RGBA8 frames to rank 0, pipelined behind the rendering" if distributed and not args.no_gather else ""),
-                       "parallelism": f"frame-parallel x{world}", "streams_per_gpu": S, "stream_driver": driver if S > 1 else "serial",
+                                    "GaussianRasterizer.forward + RGBA8 pack per frame")
+                                   + ("; composite with 5 Blender layers per frame" if b.layers is not None else "")
+                                   + ("; RCCL gather of the RGBA8 frames to rank 0, pipelined behind the rendering"
+                                      if distributed and not args.no_gather else "")
+                                   + ("; ONE job: cloud broadcast from rank 0 + round-robin shards + gather, all timed" if strong else ""),
+                       "parallelism": f"frame-parallel x{world}", "streams_per_gpu": S,
+                       "stream_driver": ("pipelined" if not (distributed or strong) else driver) if S > 1 else "serial",
                        "options": {"tile_cull": _lib.get_option(_lib.OPT_TILE_CULL),
                                    "slabs": _lib.get_option(_lib.OPT_SLABS), "slab_first": _lib.get_option(_lib.OPT_SLAB_FIRST),
                                    "defer_colour": _lib.get_option(_lib.OPT_DEFER_COLOUR)}},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+        if strong:
+            line["config"]["job_frames"] = args.job_frames
+        if gather_stats:
+            line["config"]["gather"] = {"chunks": args.gather_chunks, "gathered_shape": gathered_shape[0],
+                                        "last_region_render_s": round(gather_stats.get("render_s", 0.0), 5),
+                                        "last_region_gather_tail_ms": round(gather_stats.get("gather_tail_s", 0.0) * 1e3, 3),
+                                        "per_rank_frames_per_s_rank0": round(K / max(1e-9, gather_stats.get("render_s", 0.0)), 1)}
         if reference_on_gpu is not None:
             line["reference_on_gpu"] = reference_on_gpu
-        if gathered is not None:
-            line["config"]["gathered_frames"] = int(gathered.shape[0] * gathered.shape[1])
-            line["config"]["gather_chunks"] = args.gather_chunks
+        if also is not None:
+            line["also"] = also
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if distributed:
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/): FETCH_SIZE and
-    WRITE_SIZE are KiB counted at the L2's memory side; on gfx950 FETCH_SIZE reports half of a wide coalesced
-    read stream, hence the factor 2 (/opt/skills/guides/MI355X_MICROARCH.md, HBM).  None if no profile exists."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_per_kernel_mean.csv")
+def run_also(device, side, S):
+    """Short runs of the other BASELINE configs and boundaries, so that their figures are on the driver-observed line."""
+    also = {}
+
+    def guarded(name, fn):
+        try:
+            also[name] = fn()
+        except Exception as e:   # an extra must not break the headline line
+            also[name] = {"error": repr(e)[:300]}
+        torch.cuda.empty_cache()
+
+    guarded("c2_op", lambda: quick("c2", device, side, S, 200, 20, 3)[1])
+    guarded("c3_render_boundary", lambda: quick("c3", device, side, S, 60, 10, 3, boundary="render")[1])
+
+    def heavy(key):
+        b, out = quick(key, device, side, S, 60, 8, 3)
+        ref = run_reference_on_gpu(b.cloud, [b.cam(f) for f in range(8, 20)], b.bg)
+        if ref is not None:
+            out["reference_on_gpu"] = ref
+            if "value" in ref:
+                out["vs_reference_kernels"] = round(out["value"] / ref["value"], 2)
+        return out
+
+    guarded("heavy_op", lambda: heavy("heavy"))
+    guarded("heavy1080_op", lambda: heavy("heavy1080"))
+    guarded("c4_fused_rgb_normal_depth", lambda: quick("c4", device, side, S, 50, 10, 3)[1])
+
+    def c5():
+        from autovfx_amd.compositor import composite_frame
+        b, out = quick("c5", device, side, S, 400, 20, 3)
+        # the compositor alone: 52 B per pixel with every layer present (4 B x 6 colour layers + 4 B x 4 depth maps in,
+        # ... 4 B out; DESIGN.md section 6), HIP events around 200 launches
+        L = b.layers
+        bg_c = torch.zeros((b.H, b.W, 4), dtype=torch.uint8, device=device)
+        dst = torch.empty_like(bg_c)
+        args = (bg_c, L["o_c"], L["o_d"], L["s_c"], L["s_d"], L["o_s_c"], L["o_gs_c"], L["o_gs_d"], L["s_f_c"], L["s_f_d"], L["s_f_c_pre"])
+        for _ in range(10):
+            composite_frame(*args, out=dst)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200):
+            composite_frame(*args, out=dst)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 200
+        nbytes = 52 * b.W * b.H
+        out["compositor"] = {"avg_launch_ms": round(ms, 5), "alg_bytes_per_launch": nbytes,
+                             "achieved_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                             "frac_of_hbm_peak": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+        out["disk_io"] = time_frame_files(b, 8)
+        return out
+
+    guarded("c5_render_and_composite", c5)
+    return also
+
+
+def time_frame_files(b, n):
+    """What the reference writes per frame (scene_representation.py:425-438: RGBA PNG, depth .npy, normal PNG), timed
+    separately from the render + composite rate: host-side zlib + file system, on `n` frames."""
+    import tempfile
+    from autovfx_amd import renderer
+    from autovfx_amd.frame_io import write_frame_outputs
+    from autovfx_amd.gaussian_model import GaussianModel
     try:
-        vals = {}
-        with open(path) as f:
-            for line in f:
-                parts = line.strip().rsplit(",", 3)   # template arguments in the kernel name may hold commas
-                if len(parts) != 4 or parts[1] not in ("FETCH_SIZE", "WRITE_SIZE"):
-                    continue
-                name = parts[0]
-                if name == kernel or (name.split("<")[0] == kernel and name.endswith("<false>")):   # the plain variant
-                    vals[parts[1]] = float(parts[2])
-        if len(vals) == 2:
-            return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), "profiles/r01_pmc_per_kernel_mean.csv (2*FETCH_SIZE + WRITE_SIZE, KiB)"
-    except OSError:
-        pass
-    return None, None
+        c = b.cloud
+        model = GaussianModel.from_activated(c.means3D, c.opacities, c.scales, c.rotations, c.shs, c.sh_degree)
+        with torch.no_grad(), tempfile.TemporaryDirectory() as d:
+            t_total = 0.0
+            for j in range(n):
+                res = renderer.render(b.cam(j * 7), model, renderer.PipelineParams, b.bg)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                write_frame_outputs(d, f"{j:05d}", res)
+                t_total += time.perf_counter() - t0
+        return {"frames": n, "ms_per_frame": round(t_total / n * 1e3, 2),
+                "what": "RGBA PNG + depth .npy + normal PNG per frame (D2H copies, zlib level 3, file writes), one host thread"}
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+
+
+def pmc_traffic(T_key):
+    """HBM-side bytes per launch of each kernel and per frame, from the newest committed rocprofv3 PMC summary
+    (profiles/r*_traffic.json, written by scripts/pmc_reduce.py from separate --pmc passes of `bench.py --profile-run
+    --streams 1` on the C3 workload): 2 * FETCH_SIZE + WRITE_SIZE in KiB -- every L2 miss is a 128-byte request that
+    FETCH_SIZE tallies at 64 bytes (calibrated on known byte counts, streaming AND random-gather patterns:
+    profiles/r02_pmc_calibration.csv).  Stamped with the commit the passes were taken at.  None if there is none."""
+    if T_key != "c3":
+        return None
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not paths:
+        return None
+    try:
+        with open(paths[-1]) as f:
+            t = json.load(f)
+        t["source"] = os.path.relpath(paths[-1], ROOT) + " (2*FETCH_SIZE + WRITE_SIZE, KiB; separate --pmc passes)"
+        return t
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def run_reference_on_gpu(cloud, cam_list, bg):
@@ -408,29 +690,31 @@ def run_reference_on_gpu(cloud, cam_list, bg):
         return {"error": repr(e)[:200]}
 
 
-def torch_cpu_c1(threads: int = 16, timeout_s: float = 30.0):
-    """The PyTorch-CPU restatement of the splat (oracle/torch_splat.py, BASELINE configs[0]: 10 k Gaussians, one
-    256x256 camera) timed on the same host: the "CPU-only PyTorch splat path" figure, at the one size it finishes in
-    well under a second.  Runs in a subprocess with a hard time limit and a bounded thread count (with one thread per
-    core of a 256-thread host its many small tensor ops take minutes, not seconds)."""
-    import subprocess
+def torch_cpu_frame(cfg, W, H, F, frame, threads, timeout_s, label):
+    """The PyTorch-CPU restatement of the splat (oracle/torch_splat.py: the "CPU-only PyTorch splat path" of the north
+    star) on ONE frame of a workload, in a subprocess with a hard time limit and a bounded thread count (with one thread
+    per core of a 256-thread host its many small tensor ops take minutes, not seconds).  Seconds per frame as measured;
+    a frame that does not finish inside the limit is reported as such, not extrapolated."""
     code = (
         "import sys, time, json, torch; sys.path.insert(0, %r); torch.set_num_threads(%d)\n"
-        "from oracle import torch_splat; from autovfx_amd import scenes\n"
-        "cloud, cam = scenes.config_c1(), scenes.c1_camera()\n"
+        "from oracle import torch_splat; from autovfx_amd import scenes; from autovfx_amd.cameras import orbit_cameras\n"
+        "cloud = scenes.%s()\n"
+        "cam = scenes.c1_camera() if %r == 'config_c1' else orbit_cameras(%d, %d, %d)[%d]\n"
         "kw = dict(means3D=cloud.means3D, opacities=cloud.opacities, width=cam.image_width, height=cam.image_height,"
         " viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, campos=cam.camera_center,"
         " tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, sh_degree=cloud.sh_degree, scale_modifier=1.0, shs=cloud.shs,"
         " scales=cloud.scales, rotations=cloud.rotations)\n"
-        "best = 1e9\n"
-        "for _ in range(2):\n"
-        "    t0 = time.perf_counter(); torch_splat.forward(bg=torch.zeros(3), **kw); best = min(best, time.perf_counter() - t0)\n"
-        "print(json.dumps({'s': best}))\n") % (ROOT, threads)
+        "t0 = time.perf_counter(); torch_splat.forward(bg=torch.zeros(3), **kw); dt = time.perf_counter() - t0\n"
+        "print(json.dumps({'s': dt}))\n") % (ROOT, threads, cfg, cfg, F, W, H, frame)
+    t0 = time.perf_counter()
     try:
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout_s)
-        best = json.loads(r.stdout.strip().splitlines()[-1])["s"]
-        return {"value": round(1.0 / best, 3), "unit": "frames/s", "cores": threads,
-                "sample": "C1 (10k Gaussians, 256x256), oracle/torch_splat.py, best of 2"}
+        s = json.loads(r.stdout.strip().splitlines()[-1])["s"]
+        return {"seconds_per_frame": round(s, 3), "value": round(1.0 / s, 4), "unit": "frames/s", "cores": threads,
+                "sample": f"{label}, frame {frame}, oracle/torch_splat.py, one run"}
+    except subprocess.TimeoutExpired:
+        return {"timeout": True, "limit_s": timeout_s, "cores": threads, "sample": f"{label}, frame {frame}: not finished after "
+                f"{time.perf_counter() - t0:.0f} s (no extrapolation)"}
     except Exception as e:  # the headline line must not depend on this extra
         return {"error": repr(e)[:200]}
 
@@ -448,9 +732,10 @@ def host_cpu_budget():
     return n, float(n)
 
 
-def run_cpu_baseline(cloud_cpu, cams_cpu, frame, cloud, cams, bg, W, H, budget_s=12.0, max_frames=12):
+def run_cpu_baseline(b, budget_s=12.0, max_frames=12):
     """Time the CPU oracle (OpenMP over the CPUs this container may use) on a bounded sample of the same workload --
-    frames of the same orbit until ~budget_s of wall time -- and report the GPU's parity on the first of them."""
+    the first, middle and last frame of the orbit, then more frames until ~budget_s of wall time -- and report the
+    GPU's parity on those three; then the PyTorch-CPU splat on one frame of C1, C2 and of this workload."""
     from oracle import cpu_oracle
     from autovfx_amd.frame_parallel import rasterize
     logical, usable = host_cpu_budget()
@@ -460,43 +745,52 @@ def run_cpu_baseline(cloud_cpu, cams_cpu, frame, cloud, cams, bg, W, H, budget_s
         ctypes.CDLL("libgomp.so.1").omp_set_num_threads(threads)
     except OSError:
         threads = logical
+    c, W, H, F = b.cloud_cpu, b.W, b.H, b.F
 
     def kw(cam):
-        return dict(means3D=cloud_cpu.means3D, opacities=cloud_cpu.opacities, bg=np.zeros(3, np.float32), width=W,
+        return dict(means3D=c.means3D, opacities=c.opacities, bg=np.zeros(3, np.float32), width=W,
                     height=H, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
                     campos=cam.camera_center, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
-                    sh_degree=cloud_cpu.sh_degree, shs=cloud_cpu.shs, scales=cloud_cpu.scales,
-                    rotations=cloud_cpu.rotations)
+                    sh_degree=c.sh_degree, shs=c.shs, scales=c.scales, rotations=c.rotations)
 
     cpu_oracle.lib()
-    ref, total, n = None, 0.0, 0
-    F = len(cams_cpu)
-    while n < max_frames and total < budget_s:
+    parity_frames = [0, F // 2, F - 1]
+    sample = parity_frames + [(20 + 7 * n) % F for n in range(max_frames)]
+    total, n, parity = 0.0, 0, []
+    for f in sample:
+        if n >= len(parity_frames) and (n >= max_frames or total >= budget_s):
+            break
         t0 = time.perf_counter()
-        out = cpu_oracle.forward(**kw(cams_cpu[(frame + 7 * n) % F]))
+        ref = cpu_oracle.forward(**kw(b.cams_cpu[f]))
         total += time.perf_counter() - t0
-        ref = out if ref is None else ref
         n += 1
-    with torch.no_grad():
-        color, depth, alpha, radii = rasterize(cloud, cams[frame], bg)
-    torch.cuda.synchronize()
-    err = np.abs(color.cpu().numpy() - ref["color"]).max(axis=0)
+        if f in parity_frames and len(parity) < len(parity_frames):
+            with torch.no_grad():
+                color, depth, alpha, radii = rasterize(b.cloud, b.cam(f), b.bg)
+            torch.cuda.synchronize()
+            err = np.abs(color.cpu().numpy() - ref["color"]).max(axis=0)
+            parity.append({"frame": f, "rgb_maxabs": float(err.max()), "rgb_px_over_1e-4": int((err > 1e-4).sum()),
+                           "alpha_maxabs": float(np.abs(alpha.cpu().numpy() - ref["alpha"]).max()),
+                           "depth_maxabs": float(np.abs(depth.cpu().numpy() - ref["depth"]).max()),
+                           "radii_equal": bool((radii.cpu().numpy() == ref["radii"]).all()), "pixels": int(W * H)})
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
             model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
     except OSError:
         pass
-    return {"value": round(n / total, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{n} frames of the same workload at full size (orbit indices {frame}+7k), C+OpenMP oracle, "
-                      f"{total:.2f} s of wall time on {threads} OpenMP threads ({logical} logical CPUs, "
-                      f"cgroup quota {usable:g} CPUs)",
-            "cpu_model": model, "torch_cpu_c1": torch_cpu_c1(),
-            "parity": {"frame": frame, "rgb_maxabs": float(err.max()), "rgb_px_over_1e-4": int((err > 1e-4).sum()),
-                       "alpha_maxabs": float(np.abs(alpha.cpu().numpy() - ref["alpha"]).max()),
-                       "depth_maxabs": float(np.abs(depth.cpu().numpy() - ref["depth"]).max()),
-                       "radii_equal": bool((radii.cpu().numpy() == ref["radii"]).all()),
-                       "pixels": int(W * H)}}
+    wl = WORKLOADS[b.key]
+    out = {"value": round(n / total, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+           "seconds_per_frame": round(total / n, 3),
+           "sample": f"{n} frames of the same workload at full size (orbit frames {sample[:n]}), C+OpenMP oracle, "
+                     f"{total:.2f} s of wall time on {threads} OpenMP threads ({logical} logical CPUs, "
+                     f"cgroup quota {usable:g} CPUs)",
+           "cpu_model": model, "parity": parity,
+           "torch_cpu_c1": torch_cpu_frame("config_c1", 256, 256, 1, 0, threads, 30.0, "C1 (10k Gaussians, 256x256)"),
+           "torch_cpu_c2": torch_cpu_frame("config_c2", 960, 540, 200, 100, threads, 60.0, "C2 (1M Gaussians, 960x540)")}
+    if b.key == "c3":
+        out["torch_cpu_c3"] = torch_cpu_frame(wl["cfg"], W, H, F, F // 2, threads, 150.0, "C3 (3M Gaussians, 1920x1080)")
+    return out
 
 
 if __name__ == "__main__":

@@ -24,7 +24,7 @@ timeout 600 python bench.py --workload c2 --no-cpu-baseline --streams 3 > "$OUT/
 echo "bench c2 exit $?" | tee -a "$OUT/status.txt"
 echo "== rocprofv3 kernel trace" | tee -a "$OUT/status.txt"
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/prof" -o c3 -- \
-    python "$GRAFT_REPO_ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-reference-hip --streams 1 > "$GRAFT_REPO_ROOT/$OUT/prof_bench.json" 2> "$GRAFT_REPO_ROOT/$OUT/prof.err" )
+    python "$GRAFT_REPO_ROOT/bench.py" --steps 20 --warmup 5 --profile-run --streams 1 > "$GRAFT_REPO_ROOT/$OUT/prof_bench.json" 2> "$GRAFT_REPO_ROOT/$OUT/prof.err" )
 echo "rocprof exit $?" | tee -a "$OUT/status.txt"
 find "$OUT/prof" -name "*kernel_stats*" -o -name "*_stats.csv" 2>/dev/null | head
 # keep only the small summaries (traces can be tens of MB)

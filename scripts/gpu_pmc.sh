@@ -11,7 +11,7 @@ rocprofv3 -L > "$OUT/counters_list.txt" 2>&1
 run() { # name, counters...
   local name=$1; shift
   timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -o p -- \
-    python "$GRAFT_REPO_ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-reference-hip --streams 1 > "$OUT/$name.json" 2> "$OUT/$name.err"
+    python "$GRAFT_REPO_ROOT/bench.py" --steps 6 --warmup 2 --profile-run --streams 1 > "$OUT/$name.json" 2> "$OUT/$name.err"
   echo "$name exit $?"
 }
 run sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU

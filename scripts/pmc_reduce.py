@@ -24,3 +24,33 @@ with open(dst, "w") as f:
     for (k, c), (tot, n) in sorted(acc.items()):
         f.write(f"{k},{c},{tot / n:.1f},{n}\n")
 print(open(dst).read()[:3000])
+
+# ---- HBM traffic per launch and per frame (bench.py's roofline.traffic / roofline.frame.traffic) ----
+# usage: ... pmc_reduce.py <passes dir> <out.csv> [<traffic.json> <commit>]
+if len(sys.argv) >= 5:
+    import json
+    fetch = {k: v for (k, c), v in acc.items() if c == "FETCH_SIZE"}
+    write = {k: v for (k, c), v in acc.items() if c == "WRITE_SIZE"}
+    frames = next((n for k, (tot, n) in fetch.items() if k.startswith("preprocess_kernel")), 0)
+    per_variant, frame_bytes = {}, 0.0
+    for k in sorted(set(fetch) & set(write)):
+        f_kib, nf = fetch[k][0] / fetch[k][1], fetch[k][1]
+        w_kib = write[k][0] / write[k][1]
+        b = (2.0 * f_kib + w_kib) * 1024.0   # every L2 miss is a 128-byte request tallied at 64 (profiles/r02_pmc_calibration.csv)
+        per_variant[k] = {"bytes_per_launch": b, "launches_per_frame": nf / frames if frames else None,
+                          "fetch_kib": f_kib, "write_kib": w_kib}
+        if frames:
+            frame_bytes += b * nf / frames
+    kernels = {}
+    for k, v in per_variant.items():   # template variants of one kernel: launch-weighted mean
+        base = k.split("<")[0]
+        e = kernels.setdefault(base, {"bytes": 0.0, "launches": 0.0})
+        e["bytes"] += v["bytes_per_launch"] * (v["launches_per_frame"] or 0.0)
+        e["launches"] += v["launches_per_frame"] or 0.0
+    kernels = {k: {"bytes_per_launch": e["bytes"] / e["launches"] if e["launches"] else 0.0, "launches_per_frame": e["launches"]}
+               for k, e in kernels.items()}
+    with open(sys.argv[3], "w") as f:
+        json.dump({"commit": sys.argv[4], "workload": "c3", "command": "bench.py --profile-run --steps 6 --warmup 2 --streams 1",
+                   "formula": "(2 * FETCH_SIZE + WRITE_SIZE) KiB * 1024, mean per launch; frame = sum over kernels x launches per frame",
+                   "frames_profiled": frames, "frame_bytes": frame_bytes, "kernels": kernels, "variants": per_variant}, f, indent=1)
+    print("frame traffic bytes:", int(frame_bytes))

@@ -75,15 +75,18 @@ def hip_forward_raw(cloud: GaussianCloud, cam: Camera, device="cuda:0", bg=(0.0,
 
 
 def hip_forward_inference(cloud: GaussianCloud, cam: Camera, device="cuda:0", bg=(0.0, 0.0, 0.0), scale_modifier=1.0,
-                          sh_degree=None, cov3D_precomp=None, debug=False, slabs=0, slab_first=400, defer_colour=1):
+                          sh_degree=None, cov3D_precomp=None, debug=False, slabs=0, slab_first=400, defer_colour=1,
+                          slab_min_rest=0):
     """An inference call (``GSR_FORWARD_INFERENCE``: depth slabs with occlusion culling between them, colours only for
-    listed splats): the public outputs and how many pairs each slab put into its list."""
+    listed splats): the public outputs and how many pairs each slab put into its list.  ``slab_min_rest=0``: the slab
+    machinery runs whenever the scene is larger than two first slabs, whatever the library's pay-off threshold says."""
     from autovfx_amd import _lib
     from diff_gaussian_rasterization import _C
     _C.set_geometry_cache(False)
     _lib.set_option(_lib.OPT_SLABS, slabs)
     _lib.set_option(_lib.OPT_SLAB_FIRST, slab_first)
     _lib.set_option(_lib.OPT_DEFER_COLOUR, defer_colour)
+    _lib.set_option(_lib.OPT_SLAB_MIN_REST, slab_min_rest)
     try:
         c = cloud.to(device)
         st = settings_for(cam, device, bg, scale_modifier, cloud.sh_degree if sh_degree is None else sh_degree)
@@ -99,9 +102,10 @@ def hip_forward_inference(cloud: GaussianCloud, cam: Camera, device="cuda:0", bg
         return {"num_rendered": n, "color": color.cpu().numpy(), "depth": depth.cpu().numpy(), "alpha": alpha.cpu().numpy(),
                 "radii": radii.cpu().numpy(), "slab_pairs": lay["slab_pairs"]}
     finally:
-        _lib.set_option(_lib.OPT_SLABS, 0)
+        _lib.set_option(_lib.OPT_SLABS, 2)
         _lib.set_option(_lib.OPT_SLAB_FIRST, 400)
         _lib.set_option(_lib.OPT_DEFER_COLOUR, 1)
+        _lib.set_option(_lib.OPT_SLAB_MIN_REST, 3000000)
         _C.set_geometry_cache(True)
 
 

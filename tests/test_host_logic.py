@@ -64,15 +64,18 @@ def test_algorithmic_bytes_worked_example():
 
 
 def test_bench_finds_the_committed_pmc_traffic():
-    """bench.py's roofline.traffic comes from profiles/r01_pmc_per_kernel_mean.csv; kernel names there carry template
-    arguments (`blend_quadrant_kernel<false>`, `radix_scatter_kernel<false, true>`)."""
+    """bench.py's roofline.traffic / roofline.frame.traffic come from the newest profiles/r*_traffic.json (written by
+    scripts/pmc_reduce.py from separate --pmc passes, stamped with the commit they were taken at)."""
     import importlib.util
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    traffic, source = bench.pmc_traffic("blend_quadrant_kernel")
-    assert traffic is not None and 3e8 < traffic < 9e8 and "r01_pmc_per_kernel_mean.csv" in source
-    assert bench.pmc_traffic("preprocess_kernel")[0] > 5e8
-    assert bench.pmc_traffic("no_such_kernel") == (None, None)
+    t = bench.pmc_traffic("c3")
+    assert t is not None and "_traffic.json" in t["source"] and len(t["commit"]) >= 7
+    blend = t["kernels"]["blend_quadrant_kernel"]
+    assert 1e8 < blend["bytes_per_launch"] < 9e8 and 1.0 <= blend["launches_per_frame"] <= 8.0
+    assert t["kernels"]["preprocess_kernel"]["bytes_per_launch"] > 1e8
+    assert 1e9 < t["frame_bytes"] < 5e9
+    assert bench.pmc_traffic("c2") is None and bench.pmc_traffic(None) is None   # only the C3 passes are kept

@@ -151,7 +151,8 @@ def run_both(name, cloud, cam, stage=True, **kw):
         assert_culled_lists(name, on, ref, cam.image_width, cam.image_height)
     # inference calls (depth slabs with occlusion culling between them, colours only for listed splats): the public
     # outputs bit for bit, with the default slab sizes and with slabs small enough that even this scene is cut up
-    for label, opts in (("inference", {}), ("inference_small_slabs", {"slab_first": 6}), ("inference_one_slab", {"slabs": 1})):
+    for label, opts in (("inference", {}), ("inference_small_slabs", {"slab_first": 6}), ("inference_one_slab", {"slabs": 1}),
+                        ("inference_library_policy", {"slab_min_rest": 3_000_000})):
         inf = hip_forward_inference(cloud, cam, **opts, **kw)
         for k in ("color", "depth", "alpha", "radii"):
             np.testing.assert_array_equal(inf[k], hip[k], err_msg=f"{name}: {k} changed by the {label} call")
@@ -767,3 +768,25 @@ def test_c3_full_frames_vs_oracle(frame):
     cam = orbit_cameras(800, 1920, 1080)[frame]
     hip, ref = run_both(f"c3_full_f{frame}", cloud, cam)
     report(f"c3_full_f{frame}:size", P=cloud.P, V=int((ref["radii"] > 0).sum()), D=int(ref["num_rendered"]))
+
+
+# ---- a trained-scene-like cloud: heavy-tailed sizes, needles and discs, bimodal opacity (scenes.config_heavy) ---------
+
+@pytest.mark.parametrize("P,wh,frame", [(15_000, (960, 540), 3), (1_000_000, (960, 540), 0), (1_000_000, (960, 540), 100)])
+def test_heavy_scene_every_stage_vs_oracle(P, wh, frame):
+    """~22 reference pairs per Gaussian, per-tile lists in the thousands, most pairs from splats whose rectangle covers
+    hundreds of tiles (run-culled, not mask-culled): every stage against the oracle, every inference mode bit-identical."""
+    cloud = scenes.config_heavy(P=P)
+    cam = orbit_cameras(200, *wh)[frame]
+    hip, ref = run_both(f"heavy_{P}_f{frame}", cloud, cam)
+    report(f"heavy_{P}_f{frame}:size", P=cloud.P, V=int((ref["radii"] > 0).sum()), D=int(ref["num_rendered"]),
+           pairs_per_gaussian=float(ref["num_rendered"]) / P)
+
+
+def test_heavy_scene_1080p_images_vs_oracle():
+    """The same cloud at 1920x1080 (~80 M reference pairs): images and public outputs against the oracle, full call
+    and every inference mode bit-identical to each other (the lists themselves are checked at 960x540 above)."""
+    cloud = scenes.config_heavy()
+    cam = orbit_cameras(200, 1920, 1080)[50]
+    hip, ref = run_both("heavy_1080p_f50", cloud, cam, stage=False)
+    report("heavy_1080p_f50:size", P=cloud.P, V=int((ref["radii"] > 0).sum()), D=int(ref["num_rendered"]))
