@@ -453,7 +453,7 @@ struct ForwardCall {
     size_t gshift = 0;
     size_t geom_off[GSR_GEOM_NUM_SLOTS] = {};
     size_t img_off[GSR_IMG_NUM_SLOTS] = {};
-    size_t off_slabs = 0, off_quad = 0, off_rows = 0, off_radix_tmp = 0;
+    size_t off_slabs = 0, off_quad = 0, off_rows = 0, off_listed = 0, off_radix_tmp = 0;
     int row_words = 0;
     uint32_t *order = nullptr, *point_offsets = nullptr, *slab_offsets = nullptr, *tile_totals = nullptr, *slab_tile_totals = nullptr;
     uint32_t *slab_cpos = nullptr, *slab_coffs = nullptr;
@@ -597,6 +597,7 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     fc.off_slabs = gc.take<gsr::SlabInfo>(gsr::kMaxSlabs);
     fc.off_quad = gc.take<uint32_t>(quad_words);
     fc.off_rows = gc.take<uint32_t>(rows_words);
+    fc.off_listed = gc.take<uint8_t>(fc.defer_colour ? n : 0);  // one byte per Gaussian: which slab listed it
     const size_t zero_end = gc.off;
     const size_t off_tile_totals = gc.take<uint32_t>(2 * dup_blocks);  // tile totals, then global offsets at tile ends
     const size_t off_slab_totals = gc.take<uint32_t>(fc.inference ? 2 * dup_blocks : 0);
@@ -730,6 +731,7 @@ int forward_finish(ForwardCall& fc) {
     ba.done_rows = (uint32_t*)(gbase + fc.off_rows);
     ba.row_words = fc.row_words;
     ba.tile_cull = fc.in.tile_cull;
+    ba.listed = (fc.defer_colour && S > 1) ? (uint8_t*)(gbase + fc.off_listed) : nullptr;
 
     uint32_t* n_contrib = (uint32_t*)(fc.iraw + fc.img_off[GSR_IMG_N_CONTRIB]);
     gsr::BlendSegments segs = {};
@@ -790,8 +792,7 @@ int forward_finish(ForwardCall& fc) {
         if (fc.defer_colour && S == 1)
             GSR_HIP(gsr::launch_sh_colour_all(fc.in, cam, ga.bins, ga.rgb, stream));
         else if (fc.defer_colour)
-            GSR_HIP(gsr::launch_sh_colour(fc.in, cam, ba.V, slab, fc.order, k == 0 ? fc.point_offsets : fc.slab_offsets,
-                                          k == 0 ? nullptr : fc.slab_cpos, ga.rgb, stream));
+            GSR_HIP(gsr::launch_sh_colour_listed(fc.in, cam, ba.listed, k + 1, ga.rgb, stream));
         stamp(kHeadEvents + kSlabEvents * k + 3, stream);
         GSR_HIP(gsr::launch_blend(cam, segs, k, k + 1, /*fresh=*/k == 0, /*final=*/last, ga.raster, features, fc.background,
                                   fc.out_color, fc.out_depth, fc.out_alpha, n_contrib, ba.quad_done, ba.done_rows, fc.row_words, stream,

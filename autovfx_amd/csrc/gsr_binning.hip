@@ -24,7 +24,7 @@
 //   slab_recount_kernel / slab_compact_kernel (slabs > 0): drop finished tiles from the records, re-scan, and list the
 //                         positions that still have a live pair (behind an opaque front nine splats in ten have none:
 //                         the expansion walks the compacted list, not the depth order).
-//   expand_kernel       : one workgroup per kPairTile = 4096 PAIRS, 16 consecutive pairs per lane: every workgroup
+//   expand_kernel       : one workgroup per kPairTile = 4096 PAIRS (fewer when few are left), 16 consecutive pairs per lane: every workgroup
 //                         does the same work whatever the splat sizes, and writes one contiguous 32 KB slice of the
 //                         two pair arrays with 16-byte stores.
 //   tile_ranges_kernel  : two binary searches per tile over the sorted tile keys.
@@ -455,9 +455,15 @@ __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, 
     const int tid = threadIdx.x;
     const SlabInfo info = a.slabs[slab];
     const uint32_t num_pairs = info.pairs;
-    const uint32_t p_begin = blockIdx.x * (uint32_t)kPairTile;
-    if (p_begin >= num_pairs) return;  // the launch was sized for an upper bound
-    const uint32_t p_end = min(num_pairs, p_begin + (uint32_t)kPairTile);
+    // The launch was sized for an upper bound of the pairs.  When far fewer are left (a slab behind an opaque front keeps a
+    // few per cent), 4096 pairs per workgroup would leave most of the GPU idle behind a handful of long serial walks:
+    // the pairs of a lane shrink (16, 8 or 4) until the workgroups of the launch are all needed.
+    uint32_t per_lane = (uint32_t)kPairsPerLane;
+    while (per_lane > 4u && (unsigned long long)gridDim.x * 256ull * (per_lane >> 1) >= (unsigned long long)num_pairs) per_lane >>= 1;
+    const uint32_t pair_tile = 256u * per_lane;
+    const uint32_t p_begin = blockIdx.x * pair_tile;
+    if (p_begin >= num_pairs) return;
+    const uint32_t p_end = min(num_pairs, p_begin + pair_tile);
     const uint32_t first = info.first;
     const bool compacted = slab > 0;
     // item i <-> position first + (compacted ? cpos[i] : i)
@@ -489,8 +495,8 @@ __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, 
     int s0 = tile0 * kDupTile + (int)block_sum_256(n_le, s_scratch);
     auto position_of = [&](int item) -> uint32_t { return compacted ? cpos[item] : (uint32_t)item; };
 
-    const uint32_t my_begin = p_begin + (uint32_t)(kPairsPerLane * tid);
-    const uint32_t my_end = min(p_end, my_begin + (uint32_t)kPairsPerLane);
+    const uint32_t my_begin = p_begin + per_lane * (uint32_t)tid;
+    const uint32_t my_end = min(p_end, my_begin + per_lane);
     uint32_t keys[kPairsPerLane], ids[kPairsPerLane];
     while (s0 < V) {  // workgroup-uniform
         for (int i = tid; i <= kBatch; i += 256) {
@@ -513,6 +519,7 @@ __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, 
             uint32_t pos = position_of(s0 + owner - 1);
             w.start(sorted_bins[pos], lo_pair - s_incl[owner - 1], a.run_pool, done, a.row_words);
             uint32_t gid = order[pos];
+            if (a.listed != nullptr) a.listed[gid] = (uint8_t)(slab + 1);  // (several lanes may say so: same value)
 #pragma unroll
             for (int q = 0; q < kPairsPerLane; ++q) {
                 const uint32_t p = my_begin + (uint32_t)q;
@@ -522,6 +529,7 @@ __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, 
                         pos = position_of(s0 + owner - 1);
                         w.start(sorted_bins[pos], 0u, a.run_pool, done, a.row_words);
                         gid = order[pos];
+                        if (a.listed != nullptr) a.listed[gid] = (uint8_t)(slab + 1);
                     }
                     keys[q] = w.next(grid_x);
                     ids[q] = gid;
@@ -533,16 +541,17 @@ __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, 
         if (finished) break;
         s0 += kBatch;
     }
-    if (my_begin + kPairsPerLane <= p_end) {
+    if (my_begin + per_lane <= p_end) {   // (per_lane is a multiple of 4 and so is my_begin: 16-byte stores)
 #pragma unroll
         for (int q = 0; q < kPairsPerLane; q += 4) {
+            if ((uint32_t)q >= per_lane) break;
             *reinterpret_cast<uint4*>(tile_keys + my_begin + q) = make_uint4(keys[q], keys[q + 1], keys[q + 2], keys[q + 3]);
             *reinterpret_cast<uint4*>(point_list + my_begin + q) = make_uint4(ids[q], ids[q + 1], ids[q + 2], ids[q + 3]);
         }
     } else {
 #pragma unroll
         for (int q = 0; q < kPairsPerLane; ++q)
-            if (my_begin + q < p_end) {
+            if ((uint32_t)q < per_lane && my_begin + q < p_end) {
                 tile_keys[my_begin + q] = keys[q];
                 point_list[my_begin + q] = ids[q];
             }

@@ -98,14 +98,10 @@ hipError_t launch_preprocess(const GaussianInputs& in, const Camera& cam, const 
                              hipStream_t stream);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
                                hipStream_t stream);
-// SH colours of the splats of one slab that reached a list (GaussianInputs::defer_colour): positions
-// [slab.first, slab.end) of the depth order whose pair offset moved; rgb[gid] is written.
-// `cpos` (nullable): the slab's compacted list of emitting positions (slabs > 0); without it every position of the slab
-// is looked at and `offsets` (inclusive, indexed by position) says which ones emit.
-hipError_t launch_sh_colour(const GaussianInputs& in, const Camera& cam, int V, const SlabInfo* slab,
-                            const uint32_t* depth_order, const uint32_t* offsets, const uint32_t* cpos,
-                            float* rgb, hipStream_t stream);
-
+// SH colours of the Gaussians the pair expansion of one slab marked (`listed[gid] == tag`, tag = slab + 1;
+// GaussianInputs::defer_colour), evaluated in Gaussian order; rgb[gid] is written.
+hipError_t launch_sh_colour_listed(const GaussianInputs& in, const Camera& cam, const uint8_t* listed, int tag, float* rgb,
+                                   hipStream_t stream);
 // ... of every splat that emits pairs at all, in Gaussian order (a deferred-colour call that needs no depth slabs)
 hipError_t launch_sh_colour_all(const GaussianInputs& in, const Camera& cam, const SplatBin* bins, float* rgb, hipStream_t stream);
 
@@ -127,6 +123,7 @@ struct BinningArrays {
     uint32_t* slab_cpos;          // [P] slabs > 0: the positions (minus slab.first) that still have a live pair, ascending
     uint32_t* slab_coffs;         // [P] ... and the inclusive pair offset behind each of them
     int tiles_p;                  // ceil(P / kDupTile)
+    uint8_t* listed;              // [P] nullable: expand_kernel writes slab + 1 for every Gaussian it puts into a list (zero on entry)
     uint32_t* run_pool;           // [pool_rows] column runs of the large splats
     uint32_t pool_rows;
     FrameCounters* counters;

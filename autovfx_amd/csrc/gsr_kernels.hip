@@ -7,7 +7,7 @@
 //                          (+ in_frustum auxiliary.h:139-164, computeCov3D forward.cu:118-152,
 //                           computeCov2D forward.cu:74-113, getRect auxiliary.h:46-56,
 //                           ndc2Pix auxiliary.h:41-44, computeColorFromSH forward.cu:20-71)
-//   sh_colour_kernel    <- computeColorFromSH   forward.cu:20-71, for the splats that reach a list only
+//   sh_colour_listed_kernel / sh_colour_all_kernel <- computeColorFromSH   forward.cu:20-71, for the splats that reach a list only
 //   mark_visible_kernel <- checkFrustum         DGR/cuda_rasterizer/rasterizer_impl.cu:54-66
 // The binning stages (duplicateWithKeys, identifyTileRanges) live in gsr_binning.hip, the sort in gsr_radix.hip, the
 // blend (renderCUDA) in gsr_blend.hip, the backward pass in gsr_backward.hip; helpers shared by them in gsr_device.h.
@@ -265,28 +265,18 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
 // ------------------------------------------------------------------------------------------------
 // SH colours for the splats of one depth slab that reached a list (inference calls: GaussianInputs::defer_colour).
 // The reference evaluates the SH of every visible Gaussian (forward.cu:241-247); behind an opaque front most of them
-// are never composited, and the 192 bytes of coefficients per Gaussian are the largest read of the frame.  One lane
-// per position of the depth order: a position whose inclusive pair offset moved has pairs in this slab's lists.
-// Same arithmetic as the in-line evaluation (sh_to_rgb), so rgb[] holds the same bits wherever it is read.
+// are never composited, and the 192 bytes of coefficients per Gaussian are the largest read of the frame.  The pair
+// expansion marks every Gaussian it lists (`listed[gid]` = slab + 1); this kernel walks the Gaussians in THEIR order and
+// evaluates the marked ones, so the records are read as the projection kernel would have read them -- ascending
+// addresses, neighbouring lanes sharing lines -- rather than gathered in depth order (measured: the gather moved 495 MB
+// per C3 frame for 163 MB of records, every 128-byte line fetched about three times).  Same arithmetic as the in-line
+// evaluation (sh_to_rgb), so rgb[] holds the same bits wherever it is read.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) sh_colour_kernel(GaussianInputs in, const float* __restrict__ cam_pos, int V,
-                                                        const SlabInfo* __restrict__ slab,
-                                                        const uint32_t* __restrict__ depth_order,
-                                                        const uint32_t* __restrict__ offsets,
-                                                        const uint32_t* __restrict__ cpos, float* __restrict__ rgb) {
-    const uint32_t first = slab->first, end = min(slab->end, (uint32_t)V);
-    uint32_t k = first + blockIdx.x * 256u + threadIdx.x;
-    if (cpos != nullptr) {  // later slabs: the positions that kept a live pair are listed (slab_compact_kernel)
-        const uint32_t item = blockIdx.x * 256u + threadIdx.x;
-        if (item >= slab->emitters) return;
-        k = first + cpos[item];
-    } else {
-        if (k >= end) return;
-        // `offsets` counts pairs inclusively (slab 0: the global POINT_OFFSETS): a position whose count moved has pairs
-        const uint32_t before = k > first ? offsets[k - 1] : 0u;
-        if (offsets[k] == before) return;
-    }
-    const uint32_t i = depth_order[k];
+__global__ void __launch_bounds__(256) sh_colour_listed_kernel(GaussianInputs in, const float* __restrict__ cam_pos,
+                                                               const uint8_t* __restrict__ listed, int tag,
+                                                               float* __restrict__ rgb) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= in.P || listed[i] != (uint8_t)tag) return;
     int deg = in.sh_degree < 3 ? in.sh_degree : 3;
     if (deg > 2 && in.M < 16) deg = 2;
     if (deg > 1 && in.M < 9) deg = 1;
@@ -448,12 +438,10 @@ hipError_t launch_preprocess(const GaussianInputs& in, const Camera& cam, const 
     return hipGetLastError();
 }
 
-hipError_t launch_sh_colour(const GaussianInputs& in, const Camera& cam, int V, const SlabInfo* slab,
-                            const uint32_t* depth_order, const uint32_t* offsets, const uint32_t* cpos, float* rgb,
-                            hipStream_t stream) {
-    if (V <= 0) return hipSuccess;
-    hipLaunchKernelGGL(sh_colour_kernel, dim3(div_up(V, 256)), dim3(256), 0, stream, in, cam.cam_pos, V, slab, depth_order,
-                       offsets, cpos, rgb);
+hipError_t launch_sh_colour_listed(const GaussianInputs& in, const Camera& cam, const uint8_t* listed, int tag, float* rgb,
+                                   hipStream_t stream) {
+    if (in.P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sh_colour_listed_kernel, dim3(div_up(in.P, 256)), dim3(256), 0, stream, in, cam.cam_pos, listed, tag, rgb);
     return hipGetLastError();
 }
 

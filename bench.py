@@ -480,7 +480,7 @@ def main():
     # figures are the frame's blend figures divided by the launches of a frame (what rocprofv3's per-kernel average is)
     dom = max(stage_ms, key=stage_ms.get)
     kernel_of = {"blend": "blend_quadrant_kernel", "preprocess": "preprocess_kernel", "duplicate": "expand_kernel",
-                 "ranges": "tile_ranges_kernel", "colour": "sh_colour_kernel"}
+                 "ranges": "tile_ranges_kernel", "colour": "sh_colour_listed_kernel"}
     launches = max(1, len(slab_pairs)) if dom in ("blend", "duplicate", "ranges", "colour", "tile_sort") else 1
     traffic = pmc_traffic(T_key=args.workload if not args.gaussians else None)
     dom_kernel = kernel_of.get(dom, dom)
