@@ -154,7 +154,11 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
                         const unsigned long long all = tarea == 64u ? ~0ull : (1ull << tarea) - 1ull;
                         bin.lo = (uint32_t)all; bin.hi = (uint32_t)(all >> 32);
                         live_bound = tarea;
-                        if (in.tile_cull) {
+                        // A tight rectangle one tile wide (or high) has no dead tile: it is the bounding box of the ellipse
+                        // {q <= beta}, so every tile row it spans contains the ellipse's extreme point of that side, and
+                        // with a single column that point lies in the row's only tile.  Only rectangles of at least
+                        // 2 x 2 tiles have corners to test (a third of C3's splats).
+                        if (in.tile_cull && tw >= 2u && th >= 2u) {
                             mask_candidate = true;
                             cand_tests = tarea;
                             cand_conic = make_float4(conic_o.x, conic_o.y, conic_o.z, skip_below);  // w: the pre-test threshold
