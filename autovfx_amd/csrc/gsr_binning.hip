@@ -24,8 +24,8 @@
 //   slab_recount_kernel / slab_compact_kernel (slabs > 0): drop finished tiles from the records, re-scan, and list the
 //                         positions that still have a live pair (behind an opaque front nine splats in ten have none:
 //                         the expansion walks the compacted list, not the depth order).
-//   expand_kernel       : one workgroup per kPairTile = 4096 PAIRS (fewer when few are left), 16 consecutive pairs per lane: every workgroup
-//                         does the same work whatever the splat sizes, and writes one contiguous 32 KB slice of the
+//   expand_kernel       : one workgroup per kPairTile = 2048 PAIRS (fewer when few are left), 8 consecutive pairs per lane: every workgroup
+//                         does the same work whatever the splat sizes, and writes one contiguous 16 KB slice of the
 //                         two pair arrays with 16-byte stores.
 //   tile_ranges_kernel  : two binary searches per tile over the sorted tile keys.
 // Every pair count past the first host read-back lives in device memory (SlabInfo::pairs): launches are sized for an
@@ -35,7 +35,7 @@
 namespace gsr {
 namespace {
 
-constexpr int kPairTile = 4096;
+constexpr int kPairTile = 2048;
 constexpr int kPairsPerLane = kPairTile / 256;  // consecutive pairs of one lane
 constexpr int kMaxDoneWords = 4096;             // tile bit rows held in LDS by the slab kernels (16 KB)
 static_assert(kDupTile == 1024, "256 lanes x 4 consecutive positions");
@@ -456,8 +456,9 @@ __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, 
     const SlabInfo info = a.slabs[slab];
     const uint32_t num_pairs = info.pairs;
     // The launch was sized for an upper bound of the pairs.  When far fewer are left (a slab behind an opaque front keeps a
-    // few per cent), 4096 pairs per workgroup would leave most of the GPU idle behind a handful of long serial walks:
-    // the pairs of a lane shrink (16, 8 or 4) until the workgroups of the launch are all needed.
+    // few per cent), 2048 pairs per workgroup would leave most of the GPU idle behind a handful of long serial walks:
+    // the pairs of a lane shrink (8 or 4) until the workgroups of the launch are all needed.  (2048 / 1024 / 4096 pairs
+    // per workgroup at C3: 181 / 180 / 187 us of binning per frame.)
     uint32_t per_lane = (uint32_t)kPairsPerLane;
     while (per_lane > 4u && (unsigned long long)gridDim.x * 256ull * (per_lane >> 1) >= (unsigned long long)num_pairs) per_lane >>= 1;
     const uint32_t pair_tile = 256u * per_lane;
