@@ -135,18 +135,6 @@ struct TileWalker {
         }
         load_word();
     }
-    // live tiles of the whole splat (runs only)
-    __device__ __forceinline__ uint32_t count_all() {
-        uint32_t n = 0;
-        for (row = 0; row < height; ++row) {
-            load_run();
-            for (col_base = ca & ~31u; col_base < cb; col_base += 32u) {
-                load_word();
-                n += (uint32_t)__popc(cur);
-            }
-        }
-        return n;
-    }
     __device__ __forceinline__ void init(const uint4 rec, const uint32_t* pool, const uint32_t* done_rows_, int row_words_) {
         x0 = rec.x & 0xFFFFu; y0 = rec.x >> 16; width = rec.y & 0xFFFFu; height = rec.y >> 16;
         masked = width * height <= kMaskTiles;
@@ -196,6 +184,12 @@ struct TileWalker {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) bin_gather_kernel(BinningArrays a) {
     __shared__ uint32_t s_wave[4];
+    // per wave: the large splats of one round, flattened to (splat, tile row) items (see below)
+    __shared__ float4 s_reg0[4][64];     // conic A, B, C, beta
+    __shared__ float4 s_reg1[4][64];     // half extents u, v, centre x, y
+    __shared__ uint4 s_geo[4][64];       // first tile x | y << 16, width | kind << 16, first row in the pool
+    __shared__ uint32_t s_rows[4][64];   // inclusive row counts
+    __shared__ uint32_t s_live[4][64];   // live tiles, summed over the rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int V = a.V;
     const int k0 = (int)blockIdx.x * kDupTile + 4 * tid;  // 4 consecutive positions per lane
@@ -225,8 +219,7 @@ __global__ void __launch_bounds__(256) bin_gather_kernel(BinningArrays a) {
     // wave; a splat that does not get its rows (cannot happen: the pool is sized from the projection kernel's count)
     // keeps its full rectangle, which is only less culled, never wrong.
     const unsigned long long any_big = __ballot(rows_needed != 0u);
-    uint32_t pool_at = 0u;
-    if (any_big != 0ull) {
+    if (any_big != 0ull) {   // wave-uniform
         uint32_t incl = rows_needed;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -236,31 +229,89 @@ __global__ void __launch_bounds__(256) bin_gather_kernel(BinningArrays a) {
         uint32_t base = 0u;
         if (lane == 63) base = atomicAdd(&a.counters->pool_used, incl);
         base = (uint32_t)__shfl((int)base, 63);
-        pool_at = base + incl - rows_needed;
-    }
+        uint32_t pool_at = base + incl - rows_needed;
+        // A lane walking the tile rows of its own splats makes the wave run as long as its tallest splat (up to the
+        // whole image height) while the other lanes wait.  Instead the (splat, tile row) items of the wave are
+        // flattened, one of the lane's four positions at a time: item t belongs to the splat whose inclusive row count
+        // first exceeds t (binary search in LDS), every lane computes one run per iteration, the run lengths are summed
+        // per splat with LDS atomics.  Iterations = rows of the wave's large splats / 64.
+        const int wave = tid >> 6;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (k0 + j >= V || rec_is_masked(rec[j].y)) continue;
-        const uint32_t x0 = rec[j].x & 0xFFFFu, y0 = rec[j].x >> 16, w = rec[j].y & 0xFFFFu, h = rec[j].y >> 16;
-        if (!a.tile_cull || pool_at + h > a.pool_rows) {
-            rec[j].z = 0xFFFFFFFFu;  // every row is the full width
-            count[j] = w * h;
-        } else {
-            const float4* rr = reinterpret_cast<const float4*>(a.raster + gid[j]);
-            const float4 r0 = rr[0], r1 = rr[1];  // x y cxx cxy | cyy opacity depth skip_below
-            const LiveRegion g = live_region(r0.z, r0.w, r1.x, r1.w);
-            uint32_t n = 0;
-            for (uint32_t r = 0; r < h; ++r) {
-                int ca, cb;
-                row_run(g, r0.x, r0.y, (int)(y0 + r), (int)x0, (int)(x0 + w), &ca, &cb);
-                a.run_pool[pool_at + r] = (uint32_t)ca | ((uint32_t)cb << 16);
-                n += (uint32_t)(cb - ca);
+        for (int j = 0; j < 4; ++j) {
+            const bool large = k0 + j < V && !rec_is_masked(rec[j].y);
+            const uint32_t h = large ? rec[j].y >> 16 : 0u;
+            bool walk = false;
+            if (large) {
+                if (pool_at + h > a.pool_rows) {
+                    rec[j].z = 0xFFFFFFFFu;  // every row is the full width
+                    count[j] = (rec[j].y & 0xFFFFu) * h;
+                    rec[j].w = count[j];
+                } else {
+                    walk = true;
+                }
             }
-            rec[j].z = pool_at;
-            count[j] = n;
-            pool_at += h;
+            const uint32_t rows = walk ? h : 0u;
+            uint32_t rincl = rows;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)rincl, d);
+                if (lane >= d) rincl += o;
+            }
+            const uint32_t total = (uint32_t)__shfl((int)rincl, 63);
+            if (total != 0u) {   // wave-uniform
+                if (walk) {
+                    const float4* rr = reinterpret_cast<const float4*>(a.raster + gid[j]);
+                    const float4 r0 = rr[0], r1 = rr[1];  // x y cxx cxy | cyy opacity depth skip_below
+                    const LiveRegion g = live_region(r0.z, r0.w, r1.x, r1.w);
+                    s_reg0[wave][lane] = make_float4(g.A, g.B, g.C, g.beta);
+                    s_reg1[wave][lane] = make_float4(g.u_ext, g.v_ext, r0.x, r0.y);
+                    s_geo[wave][lane] = make_uint4(rec[j].x, (rec[j].y & 0xFFFFu) | ((uint32_t)g.kind << 16), pool_at, 0u);
+                }
+                s_rows[wave][lane] = rincl;
+                s_live[wave][lane] = 0u;
+                __builtin_amdgcn_s_waitcnt(0);       // this wave's own LDS writes have landed
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t t0 = 0; t0 < total; t0 += 64u) {
+                    const uint32_t t = t0 + (uint32_t)lane;
+                    if (t < total) {
+                        int lo = 0, hi = 63;  // first splat whose inclusive row count exceeds t
+#pragma unroll
+                        for (int step = 0; step < 6; ++step) {
+                            const int mid = (lo + hi) >> 1;
+                            if (s_rows[wave][mid] > t) hi = mid; else lo = mid + 1;
+                        }
+                        const uint32_t r = t - (lo > 0 ? s_rows[wave][lo - 1] : 0u);
+                        const float4 q0 = s_reg0[wave][lo], q1 = s_reg1[wave][lo];
+                        const uint4 ge = s_geo[wave][lo];
+                        LiveRegion g;
+                        g.A = q0.x; g.B = q0.y; g.C = q0.z; g.beta = q0.w; g.u_ext = q1.x; g.v_ext = q1.y; g.kind = (int)(ge.y >> 16);
+                        const uint32_t x0 = ge.x & 0xFFFFu, y0 = ge.x >> 16, w = ge.y & 0xFFFFu;
+                        int ca, cb;
+                        row_run(g, q1.z, q1.w, (int)(y0 + r), (int)x0, (int)(x0 + w), &ca, &cb);
+                        a.run_pool[ge.z + r] = (uint32_t)ca | ((uint32_t)cb << 16);
+                        atomicAdd(&s_live[wave][lo], (uint32_t)(cb - ca));
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_wave_barrier();
+                if (walk) {
+                    count[j] = s_live[wave][lane];
+                    rec[j].z = pool_at;
+                    rec[j].w = count[j];
+                }
+                __builtin_amdgcn_wave_barrier();     // (the next round overwrites the tables)
+            }
+            if (walk) pool_at += h;
         }
-        rec[j].w = count[j];
+    }
+    if (!a.tile_cull) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k0 + j < V && !rec_is_masked(rec[j].y)) {
+                rec[j].z = 0xFFFFFFFFu;  // every row is the full width
+                count[j] = (rec[j].y & 0xFFFFu) * (rec[j].y >> 16);
+                rec[j].w = count[j];
+            }
     }
     const uint32_t mine = count[0] + count[1] + count[2] + count[3];
     uint32_t tile_total;
@@ -349,31 +400,85 @@ __device__ __forceinline__ void load_done_rows(uint32_t* s_done, const uint32_t*
 __global__ void __launch_bounds__(256) slab_recount_kernel(BinningArrays a, int slab) {
     __shared__ uint32_t s_done[kMaxDoneWords];
     __shared__ uint32_t s_wave[4];
+    __shared__ uint4 s_geo[4][64];       // the large splats of one round: their records
+    __shared__ uint32_t s_rows[4][64];   // inclusive row counts
+    __shared__ uint32_t s_live[4][64];   // live unfinished tiles, summed over the rows
     const SlabInfo info = a.slabs[slab];
     const uint32_t first = info.first, end = min(info.end, (uint32_t)a.V);
     const uint32_t k0 = first + blockIdx.x * (uint32_t)kDupTile + 4u * threadIdx.x;
     if (first + blockIdx.x * (uint32_t)kDupTile >= end) return;  // workgroup-uniform
     load_done_rows(s_done, a.done_rows, a.grid_y * a.row_words);
     uint32_t count[4];
+    uint4 rec[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         count[j] = 0u;
+        rec[j] = make_uint4(0u, 0u, 0u, 0u);
         const uint32_t k = k0 + j;
         if (k >= end) continue;
-        uint4 rec = a.sorted_bins[k];
-        if (rec.y == 0u) continue;
-        if (rec_is_masked(rec.y)) {
-            const unsigned long long m = (unsigned long long)rec.z | ((unsigned long long)rec.w << 32);
-            const unsigned long long left = m & ~done_rect(s_done, a.row_words, rec.x, rec.y);
-            if (left != m) {
-                rec.z = (uint32_t)left; rec.w = (uint32_t)(left >> 32);
-                a.sorted_bins[k] = rec;
+        rec[j] = a.sorted_bins[k];
+        if (rec[j].y == 0u || !rec_is_masked(rec[j].y)) continue;
+        const unsigned long long m = (unsigned long long)rec[j].z | ((unsigned long long)rec[j].w << 32);
+        const unsigned long long left = m & ~done_rect(s_done, a.row_words, rec[j].x, rec[j].y);
+        if (left != m) {
+            rec[j].z = (uint32_t)left; rec[j].w = (uint32_t)(left >> 32);
+            a.sorted_bins[k] = rec[j];
+        }
+        count[j] = (uint32_t)__popcll(left);
+    }
+    // Large splats: the live, unfinished tiles of every tile row, the rows of the wave's splats flattened over its lanes
+    // exactly as bin_gather_kernel flattens them (one of the lane's four positions at a time).
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool large = k0 + j < end && rec[j].y != 0u && !rec_is_masked(rec[j].y);
+            const uint32_t rows = large ? rec[j].y >> 16 : 0u;
+            uint32_t rincl = rows;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)rincl, d);
+                if (lane >= d) rincl += o;
             }
-            count[j] = (uint32_t)__popcll(left);
-        } else {
-            TileWalker w;
-            w.init(rec, a.run_pool, s_done, a.row_words);
-            count[j] = w.count_all();
+            const uint32_t total = (uint32_t)__shfl((int)rincl, 63);
+            if (total == 0u) continue;   // wave-uniform
+            s_geo[wave][lane] = rec[j];
+            s_rows[wave][lane] = rincl;
+            s_live[wave][lane] = 0u;
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t t0 = 0; t0 < total; t0 += 64u) {
+                const uint32_t t = t0 + (uint32_t)lane;
+                if (t < total) {
+                    int lo = 0, hi = 63;
+#pragma unroll
+                    for (int step = 0; step < 6; ++step) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_rows[wave][mid] > t) hi = mid; else lo = mid + 1;
+                    }
+                    const uint32_t r = t - (lo > 0 ? s_rows[wave][lo - 1] : 0u);
+                    const uint4 ge = s_geo[wave][lo];
+                    const uint32_t x0 = ge.x & 0xFFFFu, y0 = ge.x >> 16, w = ge.y & 0xFFFFu;
+                    uint32_t ca = x0, cb = x0 + w;
+                    if (ge.z != 0xFFFFFFFFu) {
+                        const uint32_t run = a.run_pool[ge.z + r];
+                        ca = run & 0xFFFFu; cb = run >> 16;
+                    }
+                    uint32_t n = 0u;
+                    for (uint32_t col = ca & ~31u; col < cb; col += 32u) {   // live, unfinished tiles of columns [col, col + 32)
+                        const uint32_t lo_c = max(ca, col), hi_c = min(cb, col + 32u);
+                        const uint32_t len = hi_c - lo_c;
+                        uint32_t bits = (len >= 32u ? ~0u : ((1u << len) - 1u)) << (lo_c - col);
+                        bits &= ~s_done[(y0 + r) * (uint32_t)a.row_words + (col >> 5)];
+                        n += (uint32_t)__popc(bits);
+                    }
+                    if (n != 0u) atomicAdd(&s_live[wave][lo], n);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+            if (large) count[j] = s_live[wave][lane];
+            __builtin_amdgcn_wave_barrier();
         }
     }
     const uint32_t mine = count[0] + count[1] + count[2] + count[3];
