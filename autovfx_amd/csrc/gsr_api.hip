@@ -597,8 +597,9 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     fc.off_slabs = gc.take<gsr::SlabInfo>(gsr::kMaxSlabs);
     fc.off_quad = gc.take<uint32_t>(quad_words);
     fc.off_rows = gc.take<uint32_t>(rows_words);
-    fc.off_listed = gc.take<uint8_t>(fc.defer_colour ? n : 0);  // one byte per Gaussian: which slab listed it
     const size_t zero_end = gc.off;
+    fc.off_listed = gc.take<uint8_t>(fc.defer_colour ? n : 0);  // one byte per Gaussian: which slab listed it (cleared only by
+                                                                // a call that does get cut into slabs: forward_finish)
     const size_t off_tile_totals = gc.take<uint32_t>(2 * dup_blocks);  // tile totals, then global offsets at tile ends
     const size_t off_slab_totals = gc.take<uint32_t>(fc.inference ? 2 * dup_blocks : 0);
     const size_t off_sorted_bins = gc.take<uint4>(n);  // splat records again, in depth order
@@ -732,6 +733,7 @@ int forward_finish(ForwardCall& fc) {
     ba.row_words = fc.row_words;
     ba.tile_cull = fc.in.tile_cull;
     ba.listed = (fc.defer_colour && S > 1) ? (uint8_t*)(gbase + fc.off_listed) : nullptr;
+    if (ba.listed != nullptr) GSR_HIP(hipMemsetAsync(ba.listed, 0, (size_t)P, stream));
 
     uint32_t* n_contrib = (uint32_t*)(fc.iraw + fc.img_off[GSR_IMG_N_CONTRIB]);
     gsr::BlendSegments segs = {};
