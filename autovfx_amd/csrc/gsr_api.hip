@@ -714,6 +714,7 @@ int forward_finish(ForwardCall& fc) {
     for (int k = 0; k < S; ++k) off_list[k] = bc.take<uint32_t>(plan.bound[k] ? plan.bound[k] : 1);
     const size_t off_pl_shared = bc.take<uint32_t>(max_bound);
     const size_t off_pool = bc.take<uint32_t>((size_t)pool_rows);
+    const size_t off_pool_incl = bc.take<uint32_t>((size_t)pool_rows);
     const size_t off_btmp = bc.take<char>(tsort_tmp);
     char* braw = fc.binning_alloc(bc.total(), fc.binning_user);
     if (!braw) return fail(GSR_ERR_ALLOC, "binning scratch callback returned NULL for %zu bytes", bc.total());
@@ -726,6 +727,7 @@ int forward_finish(ForwardCall& fc) {
     ba.slab_offsets = fc.slab_offsets; ba.slab_tile_totals = fc.slab_tile_totals;
     ba.slab_cpos = fc.slab_cpos; ba.slab_coffs = fc.slab_coffs; ba.tiles_p = (P + gsr::kDupTile - 1) / gsr::kDupTile;
     ba.run_pool = (uint32_t*)(bbase + off_pool); ba.pool_rows = (uint32_t)pool_rows;
+    ba.run_incl = (uint32_t*)(bbase + off_pool_incl);
     ba.counters = ga.counters;
     ba.slabs = (gsr::SlabInfo*)(gbase + fc.off_slabs);
     ba.quad_done = (uint32_t*)(gbase + fc.off_quad);

@@ -104,6 +104,7 @@ struct TileWalker {
     float inv_width;
     // runs
     const uint32_t* runs;   // this splat's rows in the pool, or nullptr: every row is the full width
+    const uint32_t* incl;   // ... and the live tiles of rows 0..i, inclusive
     const uint32_t* done;   // tile bit rows (LDS), or nullptr
     int row_words;
     uint32_t height, row, ca, cb, col_base, cur;
@@ -135,19 +136,44 @@ struct TileWalker {
         }
         load_word();
     }
-    __device__ __forceinline__ void init(const uint4 rec, const uint32_t* pool, const uint32_t* done_rows_, int row_words_) {
+    __device__ __forceinline__ void init(const uint4 rec, const uint32_t* pool, const uint32_t* pool_incl, const uint32_t* done_rows_,
+                                         int row_words_) {
         x0 = rec.x & 0xFFFFu; y0 = rec.x >> 16; width = rec.y & 0xFFFFu; height = rec.y >> 16;
         masked = width * height <= kMaskTiles;
         done = done_rows_; row_words = row_words_;
         runs = (!masked && rec.z != 0xFFFFFFFFu) ? pool + rec.z : nullptr;
+        incl = runs != nullptr ? pool_incl + rec.z : nullptr;
         mask = (unsigned long long)rec.z | ((unsigned long long)rec.w << 32);
     }
     // position on the r-th (0-based) live tile
-    __device__ __forceinline__ void start(const uint4 rec, uint32_t r, const uint32_t* pool, const uint32_t* done_rows_, int row_words_) {
-        init(rec, pool, done_rows_, row_words_);
+    __device__ __forceinline__ void start(const uint4 rec, uint32_t r, const uint32_t* pool, const uint32_t* pool_incl,
+                                          const uint32_t* done_rows_, int row_words_) {
+        init(rec, pool, pool_incl, done_rows_, row_words_);
         if (masked) {
             for (uint32_t i = 0; i < r; ++i) mask &= mask - 1ull;  // r < 64
             inv_width = __builtin_amdgcn_rcpf((float)width);
+        } else if (done == nullptr) {
+            // nothing is finished yet (the first slab, full calls): the r-th live tile is found directly -- by division in
+            // a full rectangle, by a binary search over the rows' inclusive counts (bin_gather_kernel) otherwise -- where a
+            // walk from the first row would make every lane of a splat with thousands of tiles walk most of its rows
+            uint32_t rem;
+            if (runs == nullptr) {
+                row = r / width;
+                rem = r - row * width;
+            } else {
+                uint32_t lo = 0u, hi = height - 1u;   // first row whose inclusive count exceeds r
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (incl[mid] > r) hi = mid; else lo = mid + 1u;
+                }
+                row = lo;
+                rem = r - (row > 0u ? incl[row - 1u] : 0u);
+            }
+            load_run();
+            const uint32_t col = ca + rem;
+            col_base = col & ~31u;
+            load_word();
+            cur &= ~((1u << (col - col_base)) - 1u);
         } else {
             row = 0;
             load_run();
@@ -273,8 +299,11 @@ __global__ void __launch_bounds__(256) bin_gather_kernel(BinningArrays a) {
                 __builtin_amdgcn_wave_barrier();
                 for (uint32_t t0 = 0; t0 < total; t0 += 64u) {
                     const uint32_t t = t0 + (uint32_t)lane;
+                    int lo = 64;            // (no item: a segment of its own)
+                    uint32_t len = 0u, before = 0u, pool_row = 0u, run = 0u;
                     if (t < total) {
-                        int lo = 0, hi = 63;  // first splat whose inclusive row count exceeds t
+                        lo = 0;
+                        int hi = 63;  // first splat whose inclusive row count exceeds t
 #pragma unroll
                         for (int step = 0; step < 6; ++step) {
                             const int mid = (lo + hi) >> 1;
@@ -288,9 +317,28 @@ __global__ void __launch_bounds__(256) bin_gather_kernel(BinningArrays a) {
                         const uint32_t x0 = ge.x & 0xFFFFu, y0 = ge.x >> 16, w = ge.y & 0xFFFFu;
                         int ca, cb;
                         row_run(g, q1.z, q1.w, (int)(y0 + r), (int)x0, (int)(x0 + w), &ca, &cb);
-                        a.run_pool[ge.z + r] = (uint32_t)ca | ((uint32_t)cb << 16);
-                        atomicAdd(&s_live[wave][lo], (uint32_t)(cb - ca));
+                        run = (uint32_t)ca | ((uint32_t)cb << 16);
+                        len = (uint32_t)(cb - ca);
+                        pool_row = ge.z + r;
+                        before = s_live[wave][lo];   // live tiles of the splat's rows handled by earlier iterations
                     }
+                    // inclusive live-tile count through this row: the items of a splat are consecutive lanes, rows ascending
+                    uint32_t incl_len = len;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t o_len = (uint32_t)__shfl_up((int)incl_len, d);
+                        const int o_seg = __shfl_up(lo, d);
+                        if (lane >= d && o_seg == lo) incl_len += o_len;
+                    }
+                    __builtin_amdgcn_s_waitcnt(0);       // every lane has read `before` ...
+                    __builtin_amdgcn_wave_barrier();     // ... before anybody adds to it
+                    if (t < total) {
+                        a.run_pool[pool_row] = run;
+                        a.run_incl[pool_row] = before + incl_len;
+                        if (len != 0u) atomicAdd(&s_live[wave][lo], len);
+                    }
+                    __builtin_amdgcn_s_waitcnt(0);
+                    __builtin_amdgcn_wave_barrier();
                 }
                 __builtin_amdgcn_s_waitcnt(0);
                 __builtin_amdgcn_wave_barrier();
@@ -623,7 +671,7 @@ __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, 
             uint32_t owner_end = s_incl[owner];
             TileWalker w;
             uint32_t pos = position_of(s0 + owner - 1);
-            w.start(sorted_bins[pos], lo_pair - s_incl[owner - 1], a.run_pool, done, a.row_words);
+            w.start(sorted_bins[pos], lo_pair - s_incl[owner - 1], a.run_pool, a.run_incl, done, a.row_words);
             uint32_t gid = order[pos];
             if (a.listed != nullptr) a.listed[gid] = (uint8_t)(slab + 1);  // (several lanes may say so: same value)
 #pragma unroll
@@ -633,7 +681,7 @@ __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, 
                     if (p >= owner_end) {
                         do { owner_end = s_incl[++owner]; } while (p >= owner_end);  // splats without live tiles
                         pos = position_of(s0 + owner - 1);
-                        w.start(sorted_bins[pos], 0u, a.run_pool, done, a.row_words);
+                        w.start(sorted_bins[pos], 0u, a.run_pool, a.run_incl, done, a.row_words);
                         gid = order[pos];
                         if (a.listed != nullptr) a.listed[gid] = (uint8_t)(slab + 1);
                     }

@@ -125,6 +125,7 @@ struct BinningArrays {
     int tiles_p;                  // ceil(P / kDupTile)
     uint8_t* listed;              // [P] nullable: expand_kernel writes slab + 1 for every Gaussian it puts into a list (zero on entry)
     uint32_t* run_pool;           // [pool_rows] column runs of the large splats
+    uint32_t* run_incl;           // [pool_rows] live tiles of the splat's rows up to and including this one
     uint32_t pool_rows;
     FrameCounters* counters;
     SlabInfo* slabs;              // [kMaxSlabs] device
