@@ -8,7 +8,9 @@ from autovfx_amd.cameras import orbit_cameras
 from autovfx_amd.frame_parallel import render_shard
 
 dev = torch.device("cuda", 0)
-cases = [("c2", scenes.config_c2(), 960, 540, 240), ("c3", scenes.config_c3(), 1920, 1080, 96)]
+cases = [("c2", scenes.config_c2(), 960, 540, 240), ("c3", scenes.config_c3(), 1920, 1080, 96),
+         ("heavy", scenes.config_heavy(), 960, 540, 120)]   # (C3 and heavy are cut into depth slabs, C2 is not)
+REPS = int(os.environ.get("STRESS_REPS", "2"))
 bg = torch.zeros(3, device=dev)
 bad = 0
 for name, cloud, W, H, n in cases:
@@ -24,7 +26,7 @@ for name, cloud, W, H, n in cases:
     ref, t1 = run(1, "auto")
     for S in (2, 3, 4, 5, 7):
         for driver in ("pipelined", "threads"):
-            for rep in range(2):
+            for rep in range(REPS):
                 hs, dt = run(S, driver)
                 diff = sum(a != b for a, b in zip(ref, hs))
                 bad += diff
