@@ -54,17 +54,74 @@ def decode_png(data: bytes) -> np.ndarray:
     return rows[:, 1:].reshape(h, w, c).copy()
 
 
-def write_frame_outputs(out_dir: str, name: str, result: dict) -> dict:
-    """Write the three files of one frame from a ``render()`` result dict; returns their paths."""
+def _frame_paths(out_dir: str, name: str) -> dict:
     paths = {k: os.path.join(out_dir, k, name + ext) for k, ext in (("images", ".png"), ("depth", ".npy"), ("normal", ".png"))}
     for p in paths.values():
         os.makedirs(os.path.dirname(p), exist_ok=True)
+    return paths
+
+
+def _frame_to_host(result: dict):
+    """What the three files hold, as host arrays: the quantisation runs where the tensors live (on the GPU: the fused
+    ``pack_rgba8`` kernel), only bytes that end up in the files cross to the host."""
     rgba = result["render"]
     rgba8 = pack_rgba8(rgba[:3], rgba[3:4]).permute(1, 2, 0).contiguous().cpu().numpy()
+    depth = result["depth"].detach().to(torch.float32).cpu().numpy()
+    normal = ((result["normal"].detach() + 1.0) / 2.0 * 255.0).to(torch.uint8).cpu().numpy()   # truncation, as the reference
+    return rgba8, depth, normal
+
+
+def _write_host_frame(paths: dict, rgba8: np.ndarray, depth: np.ndarray, normal: np.ndarray, compress_level: int = 3) -> dict:
     with open(paths["images"], "wb") as f:
-        f.write(encode_png(rgba8))
-    np.save(paths["depth"], result["depth"].detach().cpu().numpy().astype(np.float32))
-    n = ((result["normal"].detach() + 1.0) / 2.0 * 255.0).to(torch.uint8).cpu().numpy()   # truncation, as the reference
+        f.write(encode_png(rgba8, compress_level))
+    np.save(paths["depth"], depth)
     with open(paths["normal"], "wb") as f:
-        f.write(encode_png(n))
+        f.write(encode_png(normal, compress_level))
     return paths
+
+
+def write_frame_outputs(out_dir: str, name: str, result: dict) -> dict:
+    """Write the three files of one frame from a ``render()`` result dict; returns their paths."""
+    return _write_host_frame(_frame_paths(out_dir, name), *_frame_to_host(result))
+
+
+class FrameWriter:
+    """The same three files per frame, encoded and written by a pool of host threads behind the rendering loop.
+
+    ``submit`` quantises on the device and copies the frame to the host (in the caller's thread and stream: the frame is
+    complete when it returns, the tensors may be reused), then hands the host arrays to a worker; zlib and file writes
+    release the interpreter lock, so the workers run beside each other and beside the loop.  The reference writes its
+    frames inline (``scene_representation.py:425-438``: ``save_image`` + ``np.save`` per frame), which at 960x540 costs
+    more host time per frame than the GPU needs for two hundred frames.  ``close()`` (or leaving the ``with`` block)
+    waits for everything and re-raises the first error."""
+
+    def __init__(self, out_dir: str, workers: int = 0, compress_level: int = 3, max_pending: int = 0):
+        from concurrent.futures import ThreadPoolExecutor
+        if workers <= 0:
+            workers = max(1, min(32, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+        self.out_dir, self.compress_level = out_dir, compress_level
+        self._pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="frame-writer")
+        self._pending = []
+        self._max_pending = max_pending if max_pending > 0 else 4 * workers   # bounds the host memory held by queued frames
+
+    def submit(self, name: str, result: dict) -> None:
+        arrays = _frame_to_host(result)
+        paths = _frame_paths(self.out_dir, name)
+        while len(self._pending) >= self._max_pending:
+            self._pending.pop(0).result()
+        self._pending.append(self._pool.submit(_write_host_frame, paths, *arrays, self.compress_level))
+
+    def close(self) -> None:
+        pending, self._pending = self._pending, []
+        try:
+            for f in pending:
+                f.result()
+        finally:
+            self._pool.shutdown(wait=True)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False

@@ -638,8 +638,20 @@ def time_frame_files(b, n):
                 t0 = time.perf_counter()
                 write_frame_outputs(d, f"{j:05d}", res)
                 t_total += time.perf_counter() - t0
+            # the same files through the pool of host threads scripts/render_trajectory.py uses (FrameWriter)
+            from autovfx_amd.frame_io import FrameWriter
+            m = 4 * n
+            frames = [renderer.render(b.cam(j * 7), model, renderer.PipelineParams, b.bg) for j in range(4)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with FrameWriter(d) as w:
+                workers = w._pool._max_workers
+                for j in range(m):
+                    w.submit(f"p{j:05d}", frames[j % 4])
+            t_pool = time.perf_counter() - t0
         return {"frames": n, "ms_per_frame": round(t_total / n * 1e3, 2),
-                "what": "RGBA PNG + depth .npy + normal PNG per frame (D2H copies, zlib level 3, file writes), one host thread"}
+                "what": "RGBA PNG + depth .npy + normal PNG per frame (D2H copies, zlib level 3, file writes), one host thread",
+                "writer_pool": {"frames": m, "threads": workers, "ms_per_frame": round(t_pool / m * 1e3, 2)}}
     except Exception as e:
         return {"error": repr(e)[:200]}
 

@@ -69,15 +69,10 @@ def main():
 
     mine = shard_frames(len(cams), rank, world)
     t0 = time.perf_counter()
-    with torch.no_grad():
-        previous = None   # frame i is read back and encoded on the host while the GPU renders frame i + 1
+    with torch.no_grad(), frame_io.FrameWriter(args.out) as writer:   # PNG / .npy encoding on a pool of host threads
         for i in mine:
             out = renderer.render(cams[i].to(dev), model, renderer.PipelineParams, bg)
-            if previous is not None:
-                frame_io.write_frame_outputs(args.out, *previous)
-            previous = (cams[i].image_name or f"{i:05d}", out)
-        if previous is not None:
-            frame_io.write_frame_outputs(args.out, *previous)
+            writer.submit(cams[i].image_name or f"{i:05d}", out)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(json.dumps({"rank": rank, "frames": len(mine), "seconds": round(dt, 3),

@@ -32,6 +32,30 @@ def test_write_frame_outputs(tmp_path):
     assert paths["images"].endswith("images/00007.png") and paths["depth"].endswith("depth/00007.npy")
 
 
+def test_frame_writer_pool_writes_the_same_files(tmp_path):
+    """FrameWriter (encoding on host threads behind the loop) leaves byte-identical files; errors surface in close()."""
+    g = torch.Generator().manual_seed(1)
+    H, W = 18, 31
+    frames = [{"render": torch.rand(4, H, W, generator=g), "depth": torch.rand(H, W, generator=g) * 5,
+               "normal": torch.nn.functional.normalize(torch.randn(H, W, 3, generator=g), dim=-1)} for _ in range(9)]
+    a, b = tmp_path / "serial", tmp_path / "pool"
+    for i, fr in enumerate(frames):
+        frame_io.write_frame_outputs(str(a), f"{i:05d}", fr)
+    with frame_io.FrameWriter(str(b), workers=3, max_pending=2) as w:
+        for i, fr in enumerate(frames):
+            w.submit(f"{i:05d}", fr)
+            fr["render"].zero_()          # the frame was copied out: the caller may reuse its tensors at once
+    for sub in ("images", "depth", "normal"):
+        names = sorted(p.name for p in (a / sub).iterdir())
+        assert names == sorted(p.name for p in (b / sub).iterdir()) and len(names) == 9
+        for n in names:
+            assert (a / sub / n).read_bytes() == (b / sub / n).read_bytes(), (sub, n)
+    w = frame_io.FrameWriter(str(tmp_path / "bad"), workers=1)
+    w.submit("x", {"render": torch.rand(4, 4, 4), "depth": torch.rand(4, 4), "normal": torch.rand(4, 4, 2)})   # 2 channels: no PNG
+    with pytest.raises(ValueError):
+        w.close()
+
+
 @pytest.mark.gpu
 def test_render_trajectory_script_end_to_end(tmp_path):
     """PLY + trajectory JSON in, the reference's three per-frame files out (scripts/render_trajectory.py)."""
