@@ -733,11 +733,15 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const SlabInfo* __rest
     // the three arena headers ride along (one launch less per call)
     if (blockIdx.x == 0 && threadIdx.x < 3 && headers.dst[threadIdx.x] != nullptr)
         *reinterpret_cast<ArenaHeader*>(headers.dst[threadIdx.x]) = headers.h[threadIdx.x];
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= num_tiles) return;
+    // One binary search per tile (a chain of ~22 dependent loads: the kernel is that latency): the end of a tile's
+    // list is the beginning of the next tile's, taken from the neighbouring lane through LDS.
+    __shared__ uint32_t s_first[256];
+    const int t = blockIdx.x * 255 + threadIdx.x;   // 256 boundaries per workgroup = 255 tiles
     const uint32_t n = slab->pairs;
-    const uint32_t b = lower_bound_u32(keys, n, (uint32_t)t);
-    const uint32_t e = lower_bound_u32(keys, n, (uint32_t)t + 1u);
+    s_first[threadIdx.x] = lower_bound_u32(keys, n, (uint32_t)min(t, num_tiles));
+    __syncthreads();
+    if (threadIdx.x == 255 || t >= num_tiles) return;
+    const uint32_t b = s_first[threadIdx.x], e = s_first[threadIdx.x + 1];
     ranges[t] = (e > b) ? make_uint2(b, e) : make_uint2(0u, 0u);
 }
 
@@ -779,7 +783,7 @@ hipError_t launch_tile_ranges(const SlabInfo* slab, int num_tiles, const uint32_
         a.dst[i] = header_dst ? header_dst[i] : nullptr;
         if (header_dst) a.h[i] = headers[i];
     }
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(div_up(num_tiles, 256)), dim3(256), 0, stream, slab, num_tiles,
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(div_up(num_tiles, 255)), dim3(256), 0, stream, slab, num_tiles,
                        sorted_tile_keys, ranges, a);
     return hipGetLastError();
 }
