@@ -19,7 +19,7 @@ GEOM_SLOTS = ("raster", "rgb", "splat_bins", "internal_radii", "depth_order", "p
 BIN_SLOTS = ("point_list", "tile_keys")
 IMG_SLOTS = ("ranges", "n_contrib")
 STAGES = ("preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "ranges", "blend", "colour")
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_SLABS = 8
 FORWARD_INFERENCE = 1
 
@@ -28,7 +28,7 @@ SYMBOLS = ("gsr_forward", "gsr_mark_visible", "gsr_backward", "gsr_last_geom_off
            "gsr_last_image_offsets", "gsr_set_stage_timing", "gsr_get_stage_times", "gsr_last_error",
            "gsr_abi_version", "gsr_target_arch", "gsr_set_option", "gsr_get_option", "gsr_pack_rgba8", "gsr_last_pair_counts", "gsr_blend", "gsr_composite",
            "gsr_radix_scratch_bytes", "gsr_radix_sort_pairs", "gsr_selftest_exp", "gsr_view_normals", "gsr_normal_maps", "gsr_forward_extra", "gsr_get_call_times",
-           "gsr_forward_begin", "gsr_forward_finish", "gsr_forward_cancel", "gsr_last_slab_pairs")
+           "gsr_forward_begin", "gsr_forward_finish", "gsr_forward_cancel", "gsr_last_slab_pairs", "gsr_plan_slabs")
 OPT_TILE_CULL = 0
 OPT_SLABS = 1
 OPT_SLAB_FIRST = 2
@@ -77,6 +77,8 @@ def _load() -> ctypes.CDLL:
     lib.gsr_blend.restype = ctypes.c_int
     lib.gsr_blend.argtypes = [c_f, c_f, c_f, ctypes.c_int, ctypes.c_int] + [c_f] * 5 + [ctypes.c_void_p]
     lib.gsr_last_slab_pairs.restype = ctypes.c_int
+    lib.gsr_plan_slabs.restype = ctypes.c_int
+    lib.gsr_plan_slabs.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32 * MAX_SLABS)]
     lib.gsr_last_slab_pairs.argtypes = [ctypes.POINTER(ctypes.c_uint32 * MAX_SLABS)]
     lib.gsr_last_pair_counts.restype = ctypes.c_int
     lib.gsr_last_pair_counts.argtypes = [ctypes.POINTER(ctypes.c_uint32 * 2)]
@@ -158,6 +160,16 @@ def slab_pairs() -> list:
     if n < 0:
         raise RuntimeError(last_error())
     return [int(arr[i]) for i in range(n)]
+
+
+def plan_slabs(live_pairs: int, width: int, height: int) -> list:
+    """Inclusive pair offsets at which an inference call with that many live pairs would cut its depth slabs under the
+    current options ([] = one slab).  Host logic only."""
+    arr = (ctypes.c_uint32 * MAX_SLABS)()
+    n = lib.gsr_plan_slabs(int(live_pairs), int(width), int(height), ctypes.byref(arr))
+    if n < 0:
+        raise RuntimeError(last_error())
+    return [int(arr[i]) for i in range(n - 1)]
 
 
 def set_option(option: int, value: int) -> None:

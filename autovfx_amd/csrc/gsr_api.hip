@@ -898,4 +898,12 @@ int gsr_forward_finish(void* call) {
 
 void gsr_forward_cancel(void* call) { delete static_cast<ForwardCall*>(call); }
 
+int gsr_plan_slabs(uint32_t live_pairs, int width, int height, uint32_t cuts[GSR_MAX_SLABS]) {
+    if (width <= 0 || height <= 0 || !cuts) return fail(GSR_ERR_INVALID_ARG, "bad arguments");
+    const int gx = (width + gsr::kTile - 1) / gsr::kTile, gy = (height + gsr::kTile - 1) / gsr::kTile;
+    const SlabPlan p = plan_slabs(true, live_pairs, gx * gy, gy * ((gx + 31) / 32));
+    for (int i = 0; i < GSR_MAX_SLABS; ++i) cuts[i] = i + 1 < p.slabs ? p.cut[i] : 0u;
+    return p.slabs;
+}
+
 } // extern "C"

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 5
+#define GSR_ABI_VERSION 6
 
 #if defined(__GNUC__)
 #define GSR_API __attribute__((visibility("default")))
@@ -318,6 +318,10 @@ typedef enum gsr_option {
     GSR_OPT_NUM
 } gsr_option;
 GSR_API int gsr_set_option(int option, int value);
+/* How an inference call with `live_pairs` pairs (after tile culling) on a `width` x `height` image would be cut into
+ * depth slabs under the current options: cuts[i] = inclusive pair offset at which slab i ends (slabs - 1 entries are
+ * written); returns the number of slabs (1 = not cut).  Host logic only: no device is touched. */
+GSR_API int gsr_plan_slabs(uint32_t live_pairs, int width, int height, uint32_t cuts[GSR_MAX_SLABS]);
 GSR_API int gsr_get_option(int option);
 
 /* Per-stage device timing of gsr_forward via hipEvents on `stream` (off by default). */

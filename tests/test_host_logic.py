@@ -79,3 +79,30 @@ def test_bench_finds_the_committed_pmc_traffic():
     assert t["kernels"]["preprocess_kernel"]["bytes_per_launch"] > 1e8
     assert 1e9 < t["frame_bytes"] < 5e9
     assert bench.pmc_traffic("c2") is None and bench.pmc_traffic(None) is None   # only the C3 passes are kept
+
+
+def test_slab_policy_is_host_logic():
+    """Which inference calls are cut into depth slabs (gsr_plan_slabs; no device needed): the measured configurations
+    land where the A/B runs put them, and the knobs do what include/gsr.h says."""
+    from autovfx_amd import _lib
+    T1080, T540 = 120 * 68, 60 * 34
+    try:
+        assert _lib.plan_slabs(8_900_000, 1920, 1080) == [400 * T1080]          # C3: 5.6 M pairs behind the first slab
+        assert _lib.plan_slabs(2_310_000, 960, 540) == []                         # C2: 1.5 M behind it, below the pay-off
+        assert _lib.plan_slabs(6_000_000, 960, 540) == [400 * T540]               # heavy cloud
+        assert _lib.plan_slabs(17_700_000, 1920, 1080) == [400 * T1080]           # heavy at 1080p: still two slabs at most
+        assert _lib.plan_slabs(0, 960, 540) == [] and _lib.plan_slabs(2 * 400 * T540 - 1, 960, 540) == []
+        _lib.set_option(_lib.OPT_SLABS, 0)                                        # as many as the sizes call for: x3 each
+        assert _lib.plan_slabs(17_700_000, 1920, 1080) == [400 * T1080, 1600 * T1080]
+        _lib.set_option(_lib.OPT_SLABS, 1)
+        assert _lib.plan_slabs(17_700_000, 1920, 1080) == []
+        _lib.set_option(_lib.OPT_SLABS, 2)
+        _lib.set_option(_lib.OPT_SLAB_MIN_REST, 0)
+        assert _lib.plan_slabs(2_310_000, 960, 540) == [400 * T540]
+        _lib.set_option(_lib.OPT_SLAB_FIRST, 6)
+        assert _lib.plan_slabs(100 * T540, 960, 540) == [6 * T540]
+        assert _lib.plan_slabs(10_000_000, 70_000, 70_000) == []                  # tile bit rows would not fit the LDS table
+    finally:
+        _lib.set_option(_lib.OPT_SLABS, 2)
+        _lib.set_option(_lib.OPT_SLAB_FIRST, 400)
+        _lib.set_option(_lib.OPT_SLAB_MIN_REST, 3_000_000)
