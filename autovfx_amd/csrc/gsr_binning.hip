@@ -16,8 +16,9 @@
 //     exit, forward.cu:312-314, applied before the pair is written instead of after it was sorted).
 // Stages, all spin-free (no workgroup ever waits for another one):
 //   bin_gather_kernel   : one workgroup per kDupTile = 1024 positions of the depth order.  The one random gather per
-//                         splat (its 16-byte record; for large splats also the conic, to compute their runs), live
-//                         pair counts, scan inside the tile, records re-written IN DEPTH ORDER.
+//                         splat (its 16-byte record; for large splats also the conic, to compute their runs -- the tile
+//                         rows of a wave's large splats flattened over its lanes), live pair counts, scan inside the
+//                         tile, records re-written IN DEPTH ORDER.
 //   bin_offsets_kernel  : adds the sum of all earlier tile totals (each workgroup sums them itself: a few KB of
 //                         L2-resident words, no chain, no look-back) -> POINT_OFFSETS, global and inclusive.
 //   slab_bounds_kernel  : cuts the depth order into slabs at the given pair counts.
@@ -27,7 +28,7 @@
 //   expand_kernel       : one workgroup per kPairTile = 2048 PAIRS (fewer when few are left), 8 consecutive pairs per lane: every workgroup
 //                         does the same work whatever the splat sizes, and writes one contiguous 16 KB slice of the
 //                         two pair arrays with 16-byte stores.
-//   tile_ranges_kernel  : two binary searches per tile over the sorted tile keys.
+//   tile_ranges_kernel  : one binary search per tile over the sorted tile keys (a list ends where the next tile's begins).
 // Every pair count past the first host read-back lives in device memory (SlabInfo::pairs): launches are sized for an
 // upper bound and surplus workgroups leave at once.
 #include "gsr_device.h"

@@ -124,11 +124,9 @@ __device__ __forceinline__ F3 sh_to_rgb(int deg, F3 pos, F3 cam, const float* sh
 // keeps a 0.2 % + 1e-3 margin, ~10x the worst-case fp32 rounding of q for |rho| < 0.995
 // (error <= 4e-7 (1+|rho|)/(1-|rho|) q); anything less regular is never culled.  Dropping such a
 // pair cannot change any pixel, bit for bit (tests compare culled and unculled renders exactly).
-// The test runs in the preprocess kernel, where the splat's conic is in registers and the ALU is
-// idle behind HBM: a splat whose rectangle has <= 32 tiles gets a 32-bit mask of live tiles and its
-// pair count becomes popcount(mask), so dead pairs are never written, sorted or ranged.  Larger
-// splats keep their full rectangle (their dead corners are a small fraction and a per-lane loop
-// over hundreds of tiles would serialise the wave).
+// The test runs in the preprocess kernel, where the splat's conic is in registers: a splat whose tight rectangle (below)
+// has <= 64 tiles gets a 64-bit mask of live tiles and its pair count becomes popcount(mask), so dead pairs are never
+// written, sorted or ranged.  Larger splats get one run of live columns per tile row (row_run, below).
 // The same predicate on an 8x8 quadrant lets the quadrant blend skip list entries wholesale.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float edge_q(float A, float B, float C, float dx, float dy) {
