@@ -425,6 +425,12 @@ int gsr_selftest_exp(uint32_t first_bits, uint32_t count, unsigned long long* de
     return GSR_OK;
 }
 
+int gsr_selftest_lds_atomic_order(uint32_t workgroups, uint32_t rounds, uint32_t seed, unsigned long long* device_mismatches, void* stream_) {
+    if (!device_mismatches || workgroups == 0 || workgroups > (1u << 20)) return fail(GSR_ERR_INVALID_ARG, "bad selftest arguments");
+    GSR_HIP(gsr::launch_lds_atomic_order_selftest(workgroups, rounds, seed, device_mismatches, (hipStream_t)stream_));
+    return GSR_OK;
+}
+
 int gsr_pack_rgba8(const float* color, const float* alpha, uint8_t* rgba8, int width, int height, void* stream_) {
     if (width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARG, "bad image size %dx%d", width, height);
     if (!color || !alpha || !rgba8) return fail(GSR_ERR_INVALID_ARG, "null pointer");

@@ -225,6 +225,9 @@ hipError_t launch_pack_rgba8(const float* color, const float* alpha, uint8_t* ou
 // is 0..n-1 and `vals` is not read.  want_sorted_keys = false skips the key stores of the last pass.
 // n_device (nullable): the number of pairs is read from this device word by every kernel (it must not exceed n, which
 // then only sizes the launches and the scratch layout): a sort can be queued before its size is known on the host.
+// counts the returning LDS adds whose result was not (value before the instruction) + (lower lanes on the same counter)
+hipError_t launch_lds_atomic_order_selftest(uint32_t workgroups, uint32_t rounds, uint32_t seed, unsigned long long* mismatches,
+                                            hipStream_t stream);
 size_t radix_scratch_words(uint32_t n);
 hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt,
                             uint32_t* vals, uint32_t* vals_alt, bool iota_payload, bool want_sorted_keys,

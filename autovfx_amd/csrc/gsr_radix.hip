@@ -17,8 +17,13 @@
 //
 // Scatter kernel, one workgroup = 256 lanes (4 wave64) x 16 items = 4096 pairs:
 //   1. keys are loaded wave-striped (item i of lane L at wave_base + 64 i + L: coalesced);
-//   2. stable rank inside the wave by digit matching: 8 ballots give the mask of lanes holding the same digit,
-//      popcount below the lane is the rank, the highest peer bumps the wave's LDS counter of that digit;
+//   2. stable rank inside the wave: one returning LDS add per item on the wave's counter of the item's digit.  Lanes
+//      of one instruction that hit the same counter are served in ascending lane order and a wave's instructions
+//      retire in program order, so the values returned number the wave's items of a digit in tile order.  (That
+//      order is what gfx950's LDS does, pinned by gsr_selftest_lds_atomic_order / tests/test_radix_gpu.py; the
+//      ballot-matching form -- 8 ballots per item, popcount below the lane -- is kept behind
+//      GSR_RADIX_RANK_BY_LDS_ATOMICS=0.  The atomics cut the kernel's vector instructions by about 40 %: C3 frame
+//      -30 us single-stream, +1.4 % with 3 streams, same box.)
 //   3. counters are turned into (wave, digit) offsets, a 256-wide scan gives the digit segments of the tile;
 //   4. pairs are parked in LDS at their in-tile position and written out in that order, so every digit
 //      segment is a contiguous, coalesced run in HBM.
@@ -27,6 +32,9 @@
 namespace gsr {
 namespace {
 
+#ifndef GSR_RADIX_RANK_BY_LDS_ATOMICS
+#define GSR_RADIX_RANK_BY_LDS_ATOMICS 1
+#endif
 constexpr int kThreads = 256;
 constexpr int kItems = 16;
 constexpr int kTileItems = kThreads * kItems;
@@ -183,8 +191,19 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t*
 
     // 2. stable rank inside the wave
     uint32_t rank[kItems];
-    const unsigned long long below = (1ull << lane) - 1ull;
     uint32_t* my_count = s_count[wave];
+#if GSR_RADIX_RANK_BY_LDS_ATOMICS
+    // One returning LDS add per item on the wave's counter of its digit: lanes that hit the same counter in one
+    // instruction are served in ascending lane order and instructions retire in program order, so the returned values
+    // number the wave's items of a digit in tile order (item i of lane L sits at 64 i + L) -- the rank the ballots compute.
+#pragma unroll
+    for (int i = 0; i < kItems; ++i) {
+        const bool valid = first + 64u * i < tile_n;
+        const uint32_t d = (key[i] >> shift) & digit_mask;
+        rank[i] = valid ? atomicAdd(&my_count[d], 1u) : 0u;
+    }
+#else
+    const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
         const bool valid = first + 64u * i < tile_n;
@@ -201,6 +220,7 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t*
         rank[i] = before + (uint32_t)__popcll(peers & below);
         if (valid && (peers >> lane) == 1ull) my_count[d] = before + (uint32_t)__popcll(peers);  // highest peer
     }
+#endif
     __syncthreads();
     GSR_TRACE(1);
 
@@ -245,6 +265,67 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t*
 }
 
 } // namespace
+
+namespace {
+// Self-test of what the scatter kernel's ranking relies on: 4 waves of a workgroup each issue `rounds` returning LDS
+// adds on 256 counters with pseudo-random lane -> counter maps of every density (all lanes on one counter ... all on
+// different ones); the value a lane gets back must be the counter's value before the instruction plus the number of
+// LOWER lanes of the same instruction on the same counter.  Counts violations.
+__global__ void __launch_bounds__(256) lds_atomic_order_selftest_kernel(uint32_t rounds, uint32_t seed, unsigned long long* mismatches) {
+    __shared__ uint32_t s_ctr[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    s_ctr[wave][tid & 255] = 0u;
+    s_ctr[wave][(tid + 64) & 255] = 0u; s_ctr[wave][(tid + 128) & 255] = 0u; s_ctr[wave][(tid + 192) & 255] = 0u;
+    __syncthreads();
+    uint32_t expect_total[4] = {0u, 0u, 0u, 0u};   // shadow of 4 of the wave's counters per lane: counter 4 * lane + q
+    uint32_t bad = 0u;
+    uint32_t x = seed ^ (blockIdx.x * 0x9E3779B9u) ^ ((uint32_t)wave << 20);
+    for (uint32_t r = 0; r < rounds; ++r) {
+        x = x * 1664525u + 1013904223u;                       // wave-uniform round parameters
+        const uint32_t spread = 1u << ((x >> 8) % 9u);        // 1, 2, 4, ... 256 counters in play this round
+        uint32_t h = (x + (uint32_t)lane * 0x85EBCA6Bu); h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+        const uint32_t d = h & (spread - 1u) & 255u;
+        const uint32_t got = atomicAdd(&s_ctr[wave][d], 1u);
+        // what it must be: this lane's peers on counter d, and the counter's value before the instruction
+        unsigned long long peers = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool set = (d >> b) & 1u;
+            const unsigned long long with_bit = __ballot(set);
+            peers &= set ? with_bit : ~with_bit;
+        }
+        // the counter's previous value is tracked by its owner lane (counter c is shadowed by lane c / 4, slot c % 4)
+        const uint32_t owner = d >> 2, slot = d & 3u;
+        uint32_t prev = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t v = (uint32_t)__shfl((int)expect_total[q], (int)owner);
+            if ((uint32_t)q == slot) prev = v;
+        }
+        if (got != prev + (uint32_t)__popcll(peers & ((1ull << lane) - 1ull))) ++bad;
+        // owners update their shadows: counter 4 * lane + q gained popcount(lanes whose d equals it)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t c = 4u * (uint32_t)lane + (uint32_t)q;
+            unsigned long long hit = ~0ull;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const unsigned long long with_bit = __ballot((d >> b) & 1u);
+                hit &= ((c >> b) & 1u) ? with_bit : ~with_bit;
+            }
+            expect_total[q] += (uint32_t)__popcll(hit);
+        }
+    }
+    if (bad != 0u) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
+} // namespace
+
+hipError_t launch_lds_atomic_order_selftest(uint32_t workgroups, uint32_t rounds, uint32_t seed, unsigned long long* mismatches,
+                                            hipStream_t stream) {
+    hipLaunchKernelGGL(lds_atomic_order_selftest_kernel, dim3(workgroups), dim3(256), 0, stream, rounds, seed, mismatches);
+    return hipGetLastError();
+}
 
 size_t radix_scratch_words(uint32_t n) {
     const size_t tiles = ((size_t)n + kTileItems - 1) / kTileItems;

@@ -214,6 +214,13 @@ GSR_API int gsr_normal_maps(int width, int height, const float* normal_rgb, cons
  * with bit patterns first_bits .. first_bits + count - 1 whose exp differs from the device library's expf.
  * The blend evaluates exp only for arguments <= 0; tests sweep every float of [-103, 0]. */
 GSR_API int gsr_selftest_exp(uint32_t first_bits, uint32_t count, unsigned long long* device_mismatches, void* stream);
+/* Self-test of the hardware behaviour the radix sort's ranking relies on: when several lanes of one wave64 instruction
+ * add to the same LDS counter with a returning atomic, the lanes are served in ascending lane order (and instructions of
+ * a wave in program order).  `workgroups` x 4 waves x `rounds` instructions with lane -> counter maps of every density;
+ * *device_mismatches (caller-zeroed) counts the lanes whose returned value is not (the counter before the instruction) +
+ * (lower lanes on the same counter).  tests/test_radix_gpu.py requires 0. */
+GSR_API int gsr_selftest_lds_atomic_order(uint32_t workgroups, uint32_t rounds, uint32_t seed, unsigned long long* device_mismatches,
+                                          void* stream);
 
 /*
  * Backward rasterization: gradients of a gsr_forward call.  Mirrors Rasterizer::backward

@@ -64,3 +64,17 @@ def test_few_distinct_digits_and_repeated_calls():
         vals = torch.arange(n, device="cuda", dtype=torch.int32)
         k, v = sort_pairs(keys, vals, 13)
         assert torch.equal(v, torch.arange(n, device="cuda", dtype=torch.int32)) and bool((k == 7 + rep).all())
+
+
+def test_lds_atomics_serve_lanes_in_order():
+    """What the scatter kernel's ranking relies on (gsr_radix.hip): lanes of one wave64 instruction that add to the same
+    LDS counter with a returning atomic get the counter's values in ascending lane order.  2048 workgroups x 4 waves x
+    512 instructions, from all 64 lanes on one counter to all on different ones: no lane may see anything else."""
+    import ctypes
+    from autovfx_amd import _lib
+    bad = torch.zeros(1, dtype=torch.int64, device="cuda")
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for seed in (1, 2, 3):
+        assert _lib.lib.gsr_selftest_lds_atomic_order(2048, 512, seed, bad.data_ptr(), stream) == 0, _lib.last_error()
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0
