@@ -8,7 +8,7 @@
 A *step* is one ``GaussianRasterizer.forward`` call (SH colour path, an inference call: nothing requires a gradient)
 on one frame of the workload's orbit trajectory, plus the RGBA8 pack of that frame.  Inputs (Gaussians, camera
 matrices) are resident in HBM before the clock starts.  Within a GPU the K frames are issued on ``--streams`` HIP
-streams (default 3) by ONE host thread that splits every call where the host needs the pair count (``--driver
+streams (default 11, on the runtime's 4 hardware queues) by ONE host thread that splits every call where the host needs the pair count (``--driver
 pipelined``), so that one frame's VALU-bound blend overlaps other frames' HBM- and latency-bound stages; every frame is
 still one complete forward call and all K are finished inside the timed region.
 
@@ -316,8 +316,9 @@ def main():
                          "one rank, so that path can be exercised on a one-GPU box")
     ap.add_argument("--gather-chunks", type=int, default=16,
                     help="N > 1: pieces the per-rank frame stack is gathered in, each overlapped with the next piece's rendering")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="render frames on this many HIP streams so independent frames overlap")
+    ap.add_argument("--streams", type=int, default=11,
+                    help="render frames on this many HIP streams so independent frames overlap (frame_parallel.DEFAULT_STREAMS: "
+                         "the runtime spreads them over 4 hardware queues; same-box A/B in scripts/gpu_ab_flags.sh)")
     ap.add_argument("--driver", choices=["auto", "pipelined", "threads"], default="auto",
                     help="N > 1 path only: how render_and_gather feeds the streams (auto = pipelined)")
     ap.add_argument("--boundary", choices=["op", "render"], default="op",

@@ -1,11 +1,10 @@
 #!/bin/bash
+# experiment: hardware queue count x stream count (GPU_MAX_HW_QUEUES, default 4), same box, alternating
 set -u
 TAG=${1:-exp}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-run() { name=$1; shift
-  timeout 300 python bench.py --no-cpu-baseline --no-reference-hip --no-also --regions 5 "$@" > $OUT/$name.json 2> $OUT/$name.err || echo "FAILED $name"
-  python -c "import json; d=json.load(open('$OUT/$name.json')); print('$name', d['value'], d['ms_per_step'], d['roofline']['frame']['single_stream_ms_p50'])"; }
+run() { q=$1; s=$2
+  GPU_MAX_HW_QUEUES=$q timeout 300 python bench.py --no-cpu-baseline --no-reference-hip --no-also --regions 5 --streams $s 2>/dev/null | tail -1 \
+    | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('queues=$q streams=$s', d['value'])"; }
 for rep in 1 2; do
-run base
-GSR_EXPERIMENT_EMPTY_LAUNCHES=10 run empty10
-GSR_EXPERIMENT_EMPTY_LAUNCHES=20 run empty20
+run 4 3; run 4 7; run 4 11; run 8 3; run 8 7; run 8 8; run 8 11; run 16 11; run 16 15; run 2 3; run 1 3
 done
