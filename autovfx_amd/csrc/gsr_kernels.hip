@@ -279,8 +279,8 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
 __global__ void __launch_bounds__(256) sh_colour_listed_kernel(GaussianInputs in, const float* __restrict__ cam_pos,
                                                                const uint8_t* __restrict__ listed, int tag,
                                                                float* __restrict__ rgb) {
-    // A wave looks at 256 consecutive Gaussians (4 marks per lane), packs the marked ones into a list in LDS (ballot +
-    // popcount below the lane: their order is kept, so addresses still ascend) and evaluates that list with full
+    // A wave looks at 256 consecutive Gaussians (4 marks per lane), packs the marked ones into a list in LDS (a scan of
+    // the lanes' counts: their order is kept, so addresses still ascend) and evaluates that list with full
     // lanes.  One Gaussian per lane would run the whole evaluation for every wave that holds a single marked Gaussian:
     // at C3's 22 % that was 9.8 M vector instructions per launch for 1.5 M worth of work.
     __shared__ uint32_t s_list[4][256];
@@ -293,14 +293,26 @@ __global__ void __launch_bounds__(256) sh_colour_listed_kernel(GaussianInputs in
     else
         for (int j = 0; j < 4; ++j)
             if (i0 + j < in.P) marks |= (uint32_t)listed[i0 + j] << (8 * j);
-    uint32_t n = 0u;
+    // list position of a marked Gaussian = marked Gaussians before it: the lanes' counts scanned over the wave, then the
+    // lane's own four in order -- the list is in Gaussian order, so neighbouring lanes read neighbouring records
+    bool mine[4];
+    uint32_t cnt = 0u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {   // list order = Gaussian order within each j; the four passes interleave, which is fine
-        const bool mine = ((marks >> (8 * j)) & 0xFFu) == (uint32_t)tag;
-        const unsigned long long m = __ballot(mine);
-        if (mine) s_list[wave][n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(i0 + j);
-        n += (uint32_t)__popcll(m);
+    for (int j = 0; j < 4; ++j) {
+        mine[j] = ((marks >> (8 * j)) & 0xFFu) == (uint32_t)tag;
+        cnt += mine[j] ? 1u : 0u;
     }
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += o;
+    }
+    const uint32_t n = (uint32_t)__shfl((int)incl, 63);
+    uint32_t at = incl - cnt;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (mine[j]) s_list[wave][at++] = (uint32_t)(i0 + j);
     if (n == 0u) return;   // wave-uniform
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
