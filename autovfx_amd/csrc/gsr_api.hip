@@ -902,6 +902,16 @@ int gsr_forward_finish(void* call) {
     return rc;
 }
 
+int gsr_forward_ready(void* call) {
+    if (!call) return fail(GSR_ERR_INVALID_ARG, "null call handle");
+    ForwardCall* fc = static_cast<ForwardCall*>(call);
+    if (fc->P == 0 || !fc->queued) return 1;
+    const hipError_t e = hipEventQuery(fc->pinned.copied);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) return 0;
+    return fail(GSR_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
+}
+
 void gsr_forward_cancel(void* call) { delete static_cast<ForwardCall*>(call); }
 
 int gsr_plan_slabs(uint32_t live_pairs, int width, int height, uint32_t cuts[GSR_MAX_SLABS]) {

@@ -87,6 +87,9 @@ class PendingFrame:
     def __init__(self, pending, keep):
         self._pending, self._keep = pending, keep
 
+    def ready(self) -> bool:
+        return self._pending.ready()
+
     def finish(self):
         _n, color, depth, alpha, radii = self._pending.finish()[:5]
         self._keep = None
@@ -238,9 +241,15 @@ def render_shard(cloud: GaussianCloud, cameras: Sequence[Camera], frame_ids: Seq
                         caller.wait_stream(other)
                 on_chunk(slot + 1, rgba[:slot + 1])
 
+        def oldest_ready():
+            r = getattr(in_flight[0][2], "ready", None)
+            return r is not None and r()
+
         with torch.no_grad():
             for slot in range(n):
-                if len(in_flight) == streams:      # stream slot % streams is the oldest frame's: finish it first
+                # finish what can be finished without waiting (its counters are on the host already) before queueing more
+                # first halves; and the oldest frame in any case when every stream holds one (stream slot % streams is its)
+                while in_flight and (len(in_flight) == streams or oldest_ready()):
                     finish_oldest()
                 st = side[slot % streams]
                 with on_stream(st):

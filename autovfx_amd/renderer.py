@@ -121,8 +121,12 @@ class PendingRender:
     """A ``render`` call whose rasterizer call is half queued (``render_begin``); ``finish()`` queues the rest and
     returns the dict ``render`` returns."""
 
-    def __init__(self, tail):
-        self._tail = tail
+    def __init__(self, tail, ready=None):
+        self._tail, self._ready = tail, ready
+
+    def ready(self) -> bool:
+        """True when ``finish()`` will not wait for the GPU."""
+        return True if self._ready is None else self._ready()
 
     def finish(self):
         if self._tail is None:
@@ -226,7 +230,7 @@ def _render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_col
 
         if split:
             pending = _C.rasterize_gaussians_begin(*call_args, inference=True)   # (fused: autograd is off)
-            return PendingRender(lambda: assemble(pending.finish()))
+            return PendingRender(lambda: assemble(pending.finish()), pending.ready)
         return assemble(_C.rasterize_gaussians_extra(*call_args, inference=True))
     else:
         rendered_image, depth_image, alpha_image, radii = rasterizer(

@@ -185,8 +185,12 @@ class Bench:
                 with torch.cuda.stream(st):
                     self.consume(j % rgba.shape[0], self.finish(pending), rgba, composed)
 
+            def oldest_ready():
+                r = getattr(in_flight[0][2], "ready", None)
+                return r is not None and r()
+
             for j, f in enumerate(frames):
-                if len(in_flight) == streams:
+                while in_flight and (len(in_flight) == streams or oldest_ready()):   # (as frame_parallel.render_shard does)
                     finish_oldest()
                 st = side[j % streams]
                 with torch.cuda.stream(st):
@@ -395,6 +399,9 @@ def main():
     class _PendingBoundary:
         def __init__(self, pending):
             self.pending = pending
+
+        def ready(self):
+            return self.pending.ready()
 
         def finish(self):
             out = self.pending.finish()

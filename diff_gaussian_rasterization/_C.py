@@ -244,6 +244,15 @@ class PendingForward:
         self._handle, self._device, self._stream = handle, device, stream
         self._scratch, self._inputs, self._outputs = scratch, inputs, outputs
 
+    def ready(self) -> bool:
+        """True when ``finish()`` will not wait for the GPU: the call's counters have reached the host."""
+        if self._handle is None:
+            return True
+        r = _lib.lib.gsr_forward_ready(ctypes.c_void_p(self._handle))
+        if r < 0:
+            raise RuntimeError(f"gsr_forward_ready failed ({r}): {_lib.last_error()}")
+        return r != 0
+
     def finish(self):
         """Queue the rest of the call; returns what ``rasterize_gaussians_extra`` returns.  Call it on the thread
         and with the current stream that ``rasterize_gaussians_begin`` ran on."""

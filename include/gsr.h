@@ -127,6 +127,8 @@ GSR_API int gsr_forward_extra(gsr_alloc_fn geom_alloc, void* geom_user, gsr_allo
  *                       (NULL on error, gsr_last_error() says why).  extra_features / out_extra may both be NULL.
  *   gsr_forward_finish  waits for that call's counters only, calls the binning callback, queues the remaining
  *                       stages, frees the handle (also on error) and returns what gsr_forward returns.
+ *   gsr_forward_ready   1 when the call's counters have reached the host (gsr_forward_finish will not wait), 0 when not
+ *                       yet, negative on error: lets a driver finish frames as they become ready instead of in lock step.
  *   gsr_forward_cancel  frees a handle whose finish will not be called (outputs are then undefined).
  *
  * begin immediately followed by finish IS gsr_forward_extra: same launches, same results.  Every pointer passed to
@@ -143,6 +145,7 @@ GSR_API void* gsr_forward_begin(gsr_alloc_fn geom_alloc, void* geom_user, gsr_al
                                 int* radii /*nullable*/, const float* extra_features /*nullable*/,
                                 float* out_extra /*nullable*/, unsigned flags, int debug, void* stream);
 GSR_API int gsr_forward_finish(void* call);
+GSR_API int gsr_forward_ready(void* call);
 GSR_API void gsr_forward_cancel(void* call);
 
 /* present[i] = (view-space z of means3D[i]) > 0.2 ; present is a device array of P bytes (bool). */
