@@ -600,12 +600,25 @@ def test_second_pass_reuses_geometry_bit_for_bit():
     assert _C.cache_stats["hits"] == h0 + 1, "second pass did not hit the geometry cache"
     for x, y in zip(ref_a + ref_b, got_a + got_b):
         assert torch.equal(x, y)
+    # the same when the first pass was cut into depth slabs (forced here: the scene is small): the second pass walks
+    # the per-slab list segments in one blend launch
+    from autovfx_amd import _lib
+    _lib.set_option(_lib.OPT_SLABS, 0); _lib.set_option(_lib.OPT_SLAB_FIRST, 20); _lib.set_option(_lib.OPT_SLAB_MIN_REST, 0)
+    try:
+        h_s = _C.cache_stats["hits"]
+        slab_a, slab_b = two_passes()
+        assert _C.cache_stats["hits"] == h_s + 1 and len(_C.last_layout()["slab_pairs"]) > 2
+        for x, y in zip(ref_a + ref_b, slab_a + slab_b):
+            assert torch.equal(x, y)
+    finally:
+        _lib.set_option(_lib.OPT_SLABS, 2); _lib.set_option(_lib.OPT_SLAB_FIRST, 400); _lib.set_option(_lib.OPT_SLAB_MIN_REST, 3_000_000)
     # one follow-up per full call: a third pass over the same geometry recomputes (the entry, and the ~scratch it
     # pins, is dropped by the first hit), with the same result
+    h2 = _C.cache_stats["hits"]
     with torch.no_grad():
         third = GaussianRasterizer(st)(means3D=c.means3D, means2D=m2, opacities=c.opacities, colors_precomp=normals,
                                        scales=c.scales, rotations=c.rotations)
-    assert _C.cache_stats["hits"] == h0 + 1 and torch.equal(third[0], ref_b[0])
+    assert _C.cache_stats["hits"] == h2 and torch.equal(third[0], ref_b[0])
     assert getattr(_C._tls, "cache", None) is not None      # ... and is itself a full call that a next pass may follow
     # in-place edit bumps the tensor version: next colour pass must recompute (and differ)
     rast = GaussianRasterizer(st)
