@@ -766,6 +766,22 @@ def test_second_feature_set_equals_a_second_pass(case):
     assert torch.equal(fused[8], second[1])
     for i in (2, 3):
         assert torch.equal(second[i], plain[i])
+    # the same as an inference call cut into depth slabs (forced: the scenes are small): the second feature set's
+    # partial sums are parked and resumed between the slabs' blend launches like the colours
+    from autovfx_amd import _lib
+    _lib.set_option(_lib.OPT_SLABS, 0); _lib.set_option(_lib.OPT_SLAB_FIRST, 12); _lib.set_option(_lib.OPT_SLAB_MIN_REST, 0)
+    _C.set_geometry_cache(False)
+    try:
+        slabbed = _C.rasterize_gaussians_extra(*args(*first), extra, inference=True)
+        torch.cuda.synchronize()
+        n_slabs = len(_C.last_layout()["slab_pairs"])
+    finally:
+        _C.set_geometry_cache(True)
+        _lib.set_option(_lib.OPT_SLABS, 2); _lib.set_option(_lib.OPT_SLAB_FIRST, 400); _lib.set_option(_lib.OPT_SLAB_MIN_REST, 3_000_000)
+    assert n_slabs > 1 or case == "ragged_precomp"
+    assert slabbed[0] == plain[0]
+    for i in (1, 2, 3, 4, 8):
+        assert torch.equal(slabbed[i], fused[i]), (i, n_slabs)
 
 
 def test_sh_degree_above_three_is_degree_three():
