@@ -212,3 +212,34 @@ def test_backward_sh_degree_four_with_25_coefficients_leaves_higher_bands_zero()
     np.testing.assert_array_equal(np.isfinite(b["dL_dsh"]), True)
     np.testing.assert_allclose(b["dL_dsh"][:, :16], a["dL_dsh"], rtol=0, atol=REL * float(np.abs(a["dL_dsh"]).max()) + ABS)
     np.testing.assert_array_equal(a["color"], b["color"])
+
+
+def test_backward_rejects_the_scratch_of_an_inference_call():
+    """An inference call (GSR_FORWARD_INFERENCE) may cut its lists into depth slabs and drop finished tiles' pairs: its
+    scratch cannot be differentiated, and gsr_backward says so instead of reading lists that are not there.  (The
+    autograd Function only makes inference calls when no input requires a gradient, so this needs the raw binding.)"""
+    from diff_gaussian_rasterization import _C
+    dev = "cuda:0"
+    cloud, cam = scenes.config_c1(P=3000, seed=4), scenes.c1_camera(96, 64)
+    c = cloud.to(dev)
+    st = settings_for(cam, dev, (0.0, 0.0, 0.0), 1.0, cloud.sh_degree)
+    e = torch.Tensor([])
+    fwd_args = (st.bg, c.means3D, e, c.opacities, c.scales, c.rotations, 1.0, e, st.viewmatrix, st.projmatrix, st.tanfovx,
+                st.tanfovy, st.image_height, st.image_width, c.shs, st.sh_degree, st.campos, False, False)
+    _C.set_geometry_cache(False)
+    try:
+        for inference in (True, False):
+            n, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians(*fwd_args, inference=inference)
+            bw = lambda: _C.rasterize_gaussians_backward(
+                st.bg, c.means3D, radii, e, c.scales, c.rotations, 1.0, e, st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy,
+                torch.ones_like(color), torch.zeros_like(depth), torch.zeros_like(alpha), c.shs, st.sh_degree, st.campos, geom, n,
+                binning, img, alpha, False)
+            if inference:
+                with pytest.raises(RuntimeError, match="inference call"):
+                    bw()
+            else:
+                grads = bw()
+                torch.cuda.synchronize()
+                assert torch.isfinite(grads[3]).all() and float(grads[3].abs().sum()) > 0   # dL_dmeans3D
+    finally:
+        _C.set_geometry_cache(True)
