@@ -802,7 +802,7 @@ int forward_finish(ForwardCall& fc) {
         if (fc.defer_colour && S == 1)
             GSR_HIP(gsr::launch_sh_colour_all(fc.in, cam, ga.bins, ga.rgb, stream));
         else if (fc.defer_colour)
-            GSR_HIP(gsr::launch_sh_colour_listed(fc.in, cam, ba.listed, k + 1, ga.rgb, stream));
+            GSR_HIP(gsr::launch_sh_colour_listed(fc.in, cam, ba.listed, k + 1, slab, ga.rgb, stream));
         stamp(kHeadEvents + kSlabEvents * k + 3, stream);
         GSR_HIP(gsr::launch_blend(cam, segs, k, k + 1, /*fresh=*/k == 0, /*final=*/last, ga.raster, features, fc.background,
                                   fc.out_color, fc.out_depth, fc.out_alpha, n_contrib, ba.quad_done, ba.done_rows, fc.row_words, stream,

@@ -457,6 +457,15 @@ __global__ void __launch_bounds__(256) slab_recount_kernel(BinningArrays a, int 
     const uint32_t k0 = first + blockIdx.x * (uint32_t)kDupTile + 4u * threadIdx.x;
     if (first + blockIdx.x * (uint32_t)kDupTile >= end) return;  // workgroup-uniform
     load_done_rows(s_done, a.done_rows, a.grid_y * a.row_words);
+    // Every tile finished already (a scene with an opaque front: the first slab is often all it takes)?  Then no splat of
+    // this slab has a live pair and the records need not even be read: the counts below stay zero.
+    uint32_t done_tiles = 0;
+    for (int i = threadIdx.x; i < a.grid_y * a.row_words; i += 256) {
+        const int word = i % a.row_words;
+        const uint32_t cols = (uint32_t)min(32, a.grid_x - 32 * word);
+        done_tiles += (uint32_t)__popc(s_done[i] & (cols >= 32u ? ~0u : (1u << cols) - 1u));
+    }
+    const bool nothing_left = block_sum_256(done_tiles, s_wave) == (uint32_t)(a.grid_x * a.grid_y);
     uint32_t count[4];
     uint4 rec[4];
 #pragma unroll
@@ -464,7 +473,7 @@ __global__ void __launch_bounds__(256) slab_recount_kernel(BinningArrays a, int 
         count[j] = 0u;
         rec[j] = make_uint4(0u, 0u, 0u, 0u);
         const uint32_t k = k0 + j;
-        if (k >= end) continue;
+        if (k >= end || nothing_left) continue;
         rec[j] = a.sorted_bins[k];
         if (rec[j].y == 0u || !rec_is_masked(rec[j].y)) continue;
         const unsigned long long m = (unsigned long long)rec[j].z | ((unsigned long long)rec[j].w << 32);

@@ -100,8 +100,8 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmat
                                hipStream_t stream);
 // SH colours of the Gaussians the pair expansion of one slab marked (`listed[gid] == tag`, tag = slab + 1;
 // GaussianInputs::defer_colour), evaluated in Gaussian order; rgb[gid] is written.
-hipError_t launch_sh_colour_listed(const GaussianInputs& in, const Camera& cam, const uint8_t* listed, int tag, float* rgb,
-                                   hipStream_t stream);
+hipError_t launch_sh_colour_listed(const GaussianInputs& in, const Camera& cam, const uint8_t* listed, int tag, const SlabInfo* slab,
+                                   float* rgb, hipStream_t stream);
 // ... of every splat that emits pairs at all, in Gaussian order (a deferred-colour call that needs no depth slabs)
 hipError_t launch_sh_colour_all(const GaussianInputs& in, const Camera& cam, const SplatBin* bins, float* rgb, hipStream_t stream);
 

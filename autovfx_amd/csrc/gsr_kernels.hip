@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) sh_colour_listed_kernel(GaussianInputs in, const float* __restrict__ cam_pos,
                                                                const uint8_t* __restrict__ listed, int tag,
-                                                               float* __restrict__ rgb) {
+                                                               const SlabInfo* __restrict__ slab, float* __restrict__ rgb) {
     // A wave looks at 256 consecutive Gaussians (4 marks per lane), packs the marked ones into a list in LDS (a scan of
     // the lanes' counts: their order is kept, so addresses still ascend) and evaluates that list with full
     // lanes.  One Gaussian per lane would run the whole evaluation for every wave that holds a single marked Gaussian:
@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(256) sh_colour_listed_kernel(GaussianInputs in
     __shared__ uint32_t s_list[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int first = (blockIdx.x * 4 + wave) * 256;   // this wave's 256 Gaussians
-    if (first >= in.P) return;
+    if (first >= in.P || slab->pairs == 0u) return;    // (a slab that found every tile finished lists nothing)
     const int i0 = first + 4 * lane;
     uint32_t marks = 0u;   // one byte per Gaussian
     if (i0 + 3 < in.P) marks = *reinterpret_cast<const uint32_t*>(listed + i0);   // (listed is 256-byte aligned, i0 a multiple of 4)
@@ -481,10 +481,10 @@ hipError_t launch_preprocess(const GaussianInputs& in, const Camera& cam, const 
     return hipGetLastError();
 }
 
-hipError_t launch_sh_colour_listed(const GaussianInputs& in, const Camera& cam, const uint8_t* listed, int tag, float* rgb,
-                                   hipStream_t stream) {
+hipError_t launch_sh_colour_listed(const GaussianInputs& in, const Camera& cam, const uint8_t* listed, int tag, const SlabInfo* slab,
+                                   float* rgb, hipStream_t stream) {
     if (in.P <= 0) return hipSuccess;
-    hipLaunchKernelGGL(sh_colour_listed_kernel, dim3(div_up(in.P, 1024)), dim3(256), 0, stream, in, cam.cam_pos, listed, tag, rgb);
+    hipLaunchKernelGGL(sh_colour_listed_kernel, dim3(div_up(in.P, 1024)), dim3(256), 0, stream, in, cam.cam_pos, listed, tag, slab, rgb);
     return hipGetLastError();
 }
 
