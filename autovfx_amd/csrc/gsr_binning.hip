@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(256) bin_gather_kernel(BinningArrays a) {
                 }
                 s_rows[wave][lane] = rincl;
                 s_live[wave][lane] = 0u;
-                __builtin_amdgcn_s_waitcnt(0);       // this wave's own LDS writes have landed
+                GSR_WAIT_LDS();                      // this wave's own LDS writes have landed
                 __builtin_amdgcn_wave_barrier();
                 for (uint32_t t0 = 0; t0 < total; t0 += 64u) {
                     const uint32_t t = t0 + (uint32_t)lane;
@@ -331,17 +331,17 @@ __global__ void __launch_bounds__(256) bin_gather_kernel(BinningArrays a) {
                         const int o_seg = __shfl_up(lo, d);
                         if (lane >= d && o_seg == lo) incl_len += o_len;
                     }
-                    __builtin_amdgcn_s_waitcnt(0);       // every lane has read `before` ...
+                    GSR_WAIT_LDS();                      // every lane has read `before` ...
                     __builtin_amdgcn_wave_barrier();     // ... before anybody adds to it
                     if (t < total) {
                         a.run_pool[pool_row] = run;
                         a.run_incl[pool_row] = before + incl_len;
                         if (len != 0u) atomicAdd(&s_live[wave][lo], len);
                     }
-                    __builtin_amdgcn_s_waitcnt(0);
+                    GSR_WAIT_LDS();                      // (not for the two pool stores: nobody in this kernel reads them)
                     __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_s_waitcnt(0);
+                GSR_WAIT_LDS();
                 __builtin_amdgcn_wave_barrier();
                 if (walk) {
                     count[j] = s_live[wave][lane];
@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(256) slab_recount_kernel(BinningArrays a, int 
             s_geo[wave][lane] = rec[j];
             s_rows[wave][lane] = rincl;
             s_live[wave][lane] = 0u;
-            __builtin_amdgcn_s_waitcnt(0);
+            GSR_WAIT_LDS();
             __builtin_amdgcn_wave_barrier();
             for (uint32_t t0 = 0; t0 < total; t0 += 64u) {
                 const uint32_t t = t0 + (uint32_t)lane;
@@ -533,7 +533,7 @@ __global__ void __launch_bounds__(256) slab_recount_kernel(BinningArrays a, int 
                     if (n != 0u) atomicAdd(&s_live[wave][lo], n);
                 }
             }
-            __builtin_amdgcn_s_waitcnt(0);
+            GSR_WAIT_LDS();
             __builtin_amdgcn_wave_barrier();
             if (large) count[j] = s_live[wave][lane];
             __builtin_amdgcn_wave_barrier();

@@ -9,6 +9,10 @@ namespace {
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
+// Wait for this wave's outstanding LDS operations only (lgkmcnt = 0; the vector-memory and export counters are left at
+// their maxima): the wave-level hand-overs through LDS below must not also wait for global stores still in flight.
+#define GSR_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xC07F)
+
 // 4-byte aligned aggregates: the compiler may still fuse them into dwordx3/x4 accesses, but no
 // 16-byte alignment is assumed of caller tensors.
 struct __attribute__((aligned(4))) F3 { float x, y, z; };
