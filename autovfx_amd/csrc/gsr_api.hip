@@ -604,8 +604,8 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     fc.off_quad = gc.take<uint32_t>(quad_words);
     fc.off_rows = gc.take<uint32_t>(rows_words);
     const size_t zero_end = gc.off;
-    fc.off_listed = gc.take<uint8_t>(fc.defer_colour ? n : 0);  // one byte per Gaussian: which slab listed it (cleared only by
-                                                                // a call that does get cut into slabs: forward_finish)
+    fc.off_listed = gc.take<uint8_t>(fc.defer_colour ? n : 0);  // one byte per Gaussian: which slab listed it (cleared by the
+                                                                // projection kernel among its other per-Gaussian stores)
     const size_t off_tile_totals = gc.take<uint32_t>(2 * dup_blocks);  // tile totals, then global offsets at tile ends
     const size_t off_slab_totals = gc.take<uint32_t>(fc.inference ? 2 * dup_blocks : 0);
     const size_t off_sorted_bins = gc.take<uint4>(n);  // splat records again, in depth order
@@ -640,6 +640,7 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     ga.radii = radii ? radii : (int*)(gbase + geom_off[GSR_GEOM_INTERNAL_RADII]);
     ga.depth_keys = (uint32_t*)(gbase + off_keys_a);
     ga.ids = nullptr;  // the first radix pass generates 0..P-1 itself
+    ga.listed = fc.defer_colour ? (uint8_t*)(gbase + fc.off_listed) : nullptr;
     ga.counters = (gsr::FrameCounters*)(gbase + off_flag);
     fc.point_offsets = (uint32_t*)(gbase + geom_off[GSR_GEOM_POINT_OFFSETS]);
     fc.slab_offsets = (uint32_t*)(gbase + off_slab_offsets);
@@ -741,7 +742,6 @@ int forward_finish(ForwardCall& fc) {
     ba.row_words = fc.row_words;
     ba.tile_cull = fc.in.tile_cull;
     ba.listed = (fc.defer_colour && S > 1) ? (uint8_t*)(gbase + fc.off_listed) : nullptr;
-    if (ba.listed != nullptr) GSR_HIP(hipMemsetAsync(ba.listed, 0, (size_t)P, stream));
 
     uint32_t* n_contrib = (uint32_t*)(fc.iraw + fc.img_off[GSR_IMG_N_CONTRIB]);
     gsr::BlendSegments segs = {};

@@ -91,6 +91,7 @@ struct GeometryArrays {
     int* radii;           // caller's radii or the internal array
     uint32_t* depth_keys; // sort keys (float bits of depth, kCulledKey if culled)
     uint32_t* ids;        // 0..P-1, the sort payload; nullptr when the sort generates it itself
+    uint8_t* listed;      // nullable: one byte per Gaussian, cleared here for the pair expansion's marks (deferred colours)
 };
 
 // ---- kernels (gsr_kernels.hip: per-Gaussian and per-pixel streaming kernels) ----

@@ -243,6 +243,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
         out.radii[i] = radius_out;
         *reinterpret_cast<uint4*>(out.bins + i) = make_uint4(bin.xy0, bin.wh, bin.lo, bin.hi);
         out.depth_keys[i] = key;
+        if (out.listed != nullptr) out.listed[i] = 0u;   // (a 3 MB memset queued beside other frames' blends took ~100 us)
     }
     // Pair totals, needed on the host before the binning arena can be sized: an upper bound of the live pairs (what
     // gets expanded and sorted; exact but for the splats too large for a mask) in the low word and the reference's

@@ -20,7 +20,7 @@ span = t_hi - t_lo
 print(f"window {span / 1e6:.2f} ms, {len(win)} kernels, GPU busy {100 * busy / span:.1f} %, mean concurrency while busy {conc_time / busy:.2f}")
 d = defaultdict(list)
 for s, e, n, q in win: d[n].append(e - s)
-nblend = max(1, sum(len(v) for n, v in d.items() if n.startswith("blend_quadrant_kernel")))
+nblend = max(1, sum(len(v) for n, v in d.items() if n.startswith("preprocess_kernel")))   # frames = projection launches
 print(f"frames in window ~{nblend}: {span / nblend / 1e3:.1f} us per frame; sum of kernel durations per frame {sum(sum(v) for v in d.values()) / nblend / 1e3:.1f} us")
-for n, v in sorted(d.items(), key=lambda kv: -sum(kv[1]))[:14]:
+for n, v in sorted(d.items(), key=lambda kv: -sum(kv[1]))[:18]:
     print(f"  {n[:44]:44s} calls/frame {len(v) / nblend:5.2f}  mean {sum(v) / len(v) / 1e3:8.1f} us  total/frame {sum(v) / nblend / 1e3:8.1f} us")
