@@ -19,7 +19,7 @@ GEOM_SLOTS = ("raster", "rgb", "splat_bins", "internal_radii", "depth_order", "p
 BIN_SLOTS = ("point_list", "tile_keys")
 IMG_SLOTS = ("ranges", "n_contrib")
 STAGES = ("preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "ranges", "blend", "colour")
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_SLABS = 8
 FORWARD_INFERENCE = 1
 
@@ -34,6 +34,8 @@ OPT_SLABS = 1
 OPT_SLAB_FIRST = 2
 OPT_DEFER_COLOUR = 3
 OPT_SLAB_MIN_REST = 4
+OPT_RADIX_RANK = 5           # 0 ballots, 1 LDS adds, 2 (default) LDS adds where the per-device self-test passed
+OPT_RADIX_RANK_ACTIVE = 6    # read-only: what the current device uses (1 LDS adds, 0 ballots)
 
 
 class GsrLibraryError(ImportError):

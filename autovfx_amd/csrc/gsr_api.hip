@@ -10,6 +10,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -30,6 +31,7 @@ struct PinnedSlot {
     hipEvent_t finished = nullptr;
 };
 thread_local std::vector<PinnedSlot> g_pinned_free;
+thread_local std::vector<PinnedSlot> g_pinned_draining;  // retired slots whose last copy / `finished` event may still be pending
 thread_local PinnedSlot g_last_slot;           // holds the slab table of the call that finished last on this thread
 thread_local uint32_t g_last_num_rendered = 0; // ... its reference pair count
 thread_local int g_last_slabs = 0;             // ... and how many slabs it used (0: nothing to wait for)
@@ -44,10 +46,14 @@ constexpr int kTimingRing = 256;
 constexpr int kHeadEvents = 4, kSlabEvents = 5;
 constexpr int kEventsPerCall = kHeadEvents + kSlabEvents * gsr::kMaxSlabs;
 int g_options[GSR_OPT_NUM] = {/*GSR_OPT_TILE_CULL*/ 1, /*GSR_OPT_SLABS*/ 2, /*GSR_OPT_SLAB_FIRST*/ 400,
-                              /*GSR_OPT_DEFER_COLOUR*/ 1, /*GSR_OPT_SLAB_MIN_REST*/ 3000000};
+                              /*GSR_OPT_DEFER_COLOUR*/ 1, /*GSR_OPT_SLAB_MIN_REST*/ 3000000,
+                              /*GSR_OPT_RADIX_RANK (kept by gsr_radix.hip)*/ 2, /*GSR_OPT_RADIX_RANK_ACTIVE (read-only)*/ 0};
 bool g_timing = false;
+std::atomic<long> g_timing_epoch{0};       // bumped by gsr_set_stage_timing: every thread restarts its record at its next call
+thread_local long g_epoch_seen = -1;
 thread_local hipEvent_t g_ev[kTimingRing][kEventsPerCall];
-thread_local int g_ev_slabs[kTimingRing];  // depth slabs of the call recorded in each slot
+thread_local int g_ev_slabs[kTimingRing];  // depth slabs of the call recorded in each slot; 0 = begun but never completed
+                                           // (failed or cancelled after its first half): the readers skip such slots
 thread_local bool g_ev_made = false;
 thread_local long g_timed_calls = 0;   // completed timed calls since timing was (re)enabled
 thread_local long g_begun_calls = 0;   // timed calls begun since then: several may be in flight (split calls), each owns a slot
@@ -156,32 +162,57 @@ const char* gsr_target_arch(void) { return "gfx950"; }
 
 int gsr_set_option(int option, int value) {
     if (option < 0 || option >= GSR_OPT_NUM) return fail(GSR_ERR_INVALID_ARG, "unknown option %d", option);
+    if (option == GSR_OPT_RADIX_RANK_ACTIVE) return fail(GSR_ERR_INVALID_ARG, "GSR_OPT_RADIX_RANK_ACTIVE is read-only");
+    if (option == GSR_OPT_RADIX_RANK) {
+        if (value < 0 || value > 2) return fail(GSR_ERR_INVALID_ARG, "GSR_OPT_RADIX_RANK must be 0, 1 or 2");
+        gsr::radix_set_rank_request(value);
+    }
     g_options[option] = value;
     return GSR_OK;
 }
 int gsr_get_option(int option) {
     if (option < 0 || option >= GSR_OPT_NUM) return fail(GSR_ERR_INVALID_ARG, "unknown option %d", option);
+    if (option == GSR_OPT_RADIX_RANK) return gsr::radix_rank_request();
+    if (option == GSR_OPT_RADIX_RANK_ACTIVE) return gsr::radix_rank_mode(nullptr, nullptr);  // (self-test on the null stream if due)
     return g_options[option];
 }
 
 void gsr_set_stage_timing(int enable) {
     g_timing = enable != 0;
+    g_timing_epoch.fetch_add(1);   // other threads drop their records when they next begin a call
+    g_epoch_seen = g_timing_epoch.load();
     g_timed_calls = 0;
     g_begun_calls = 0;
     g_inflight = 0;
 }
 
+namespace {
+// Ring slots of this thread's completed timed calls, newest first (at most `want`); slots of calls that were begun but
+// never finished are skipped.
+int completed_slots(int want, int* slots) {
+    const long span = g_begun_calls < kTimingRing ? g_begun_calls : kTimingRing;
+    int n = 0;
+    for (long c = 0; c < span && n < want; ++c) {
+        const int slot = (int)((g_begun_calls - 1 - c) % kTimingRing);
+        if (g_ev_slabs[slot] > 0) slots[n++] = slot;
+    }
+    return n;
+}
+} // namespace
+
 int gsr_get_stage_times(float ms[GSR_STAGE_NUM]) {
     for (int i = 0; i < GSR_STAGE_NUM; ++i) ms[i] = 0.f;
     if (g_timed_calls <= 0) return fail(GSR_ERR_INVALID_ARG, "no timed gsr_forward call on this thread");
     if (g_inflight != 0) return fail(GSR_ERR_INVALID_ARG, "a split call is still in flight on this thread");
-    const int ncalls = (int)(g_timed_calls < kTimingRing ? g_timed_calls : kTimingRing);
+    int slots[kTimingRing];
+    const int ncalls = completed_slots((int)(g_timed_calls < kTimingRing ? g_timed_calls : kTimingRing), slots);
+    if (ncalls <= 0) return fail(GSR_ERR_INVALID_ARG, "no completed timed gsr_forward call on this thread");
     double sum[GSR_STAGE_NUM] = {0};
     // per-slab intervals -> stage: binning (gather / scan / recount / expansion), tile sort, ranges, colours, blend
     static const int slab_stage[kSlabEvents] = {GSR_STAGE_DUPLICATE, GSR_STAGE_TILE_SORT, GSR_STAGE_RANGES, GSR_STAGE_COLOUR,
                                                 GSR_STAGE_BLEND};
     for (int c = 0; c < ncalls; ++c) {
-        const int slot = (int)((g_begun_calls - 1 - c) % kTimingRing);
+        const int slot = slots[c];
         const int last = kHeadEvents - 1 + kSlabEvents * g_ev_slabs[slot];
         GSR_HIP(hipEventSynchronize(g_ev[slot][last]));
         for (int i = 0; i + 1 < kHeadEvents; ++i) {  // preprocess, depth sort, scan (= the host's wait for the pair count)
@@ -203,10 +234,12 @@ int gsr_get_call_times(float* ms, int capacity) {
     if (!ms || capacity < 0) return fail(GSR_ERR_INVALID_ARG, "bad arguments");
     if (g_timed_calls <= 0) return 0;
     if (g_inflight != 0) return fail(GSR_ERR_INVALID_ARG, "a split call is still in flight on this thread");
-    int ncalls = (int)(g_timed_calls < kTimingRing ? g_timed_calls : kTimingRing);
-    if (ncalls > capacity) ncalls = capacity;
+    int want = (int)(g_timed_calls < kTimingRing ? g_timed_calls : kTimingRing);
+    if (want > capacity) want = capacity;
+    int slots[kTimingRing];
+    const int ncalls = completed_slots(want, slots);
     for (int c = 0; c < ncalls; ++c) {
-        const int slot = (int)((g_begun_calls - 1 - c) % kTimingRing);
+        const int slot = slots[c];
         const int last = kHeadEvents - 1 + kSlabEvents * g_ev_slabs[slot];
         GSR_HIP(hipEventSynchronize(g_ev[slot][last]));
         GSR_HIP(hipEventElapsedTime(&ms[c], g_ev[slot][0], g_ev[slot][last]));
@@ -469,7 +502,7 @@ struct ForwardCall {
     PinnedSlot pinned;
 
     ~ForwardCall() {
-        if (timed && g_inflight > 0) --g_inflight;  // (a call cancelled while timing is on leaves a stale slot in the ring)
+        if (timed && g_inflight > 0) --g_inflight;  // (a call that never finished leaves g_ev_slabs[slot] == 0: readers skip it)
         if (!pinned.host) return;
         if (queued) (void)hipEventSynchronize(pinned.copied);  // the copy may still be landing in the buffer
         g_pinned_free.push_back(pinned);
@@ -566,9 +599,25 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
             for (auto& e : set) GSR_HIP(hipEventCreate(&e));
         g_ev_made = true;
     }
+    if (g_epoch_seen != g_timing_epoch.load()) {  // timing was switched on or off (by any thread) since this thread's last call
+        g_epoch_seen = g_timing_epoch.load();
+        g_timed_calls = 0; g_begun_calls = 0; g_inflight = 0;
+    }
     g_slot = fc.slot = (int)(g_begun_calls % kTimingRing);  // one slot per call in flight (ring of 256: more than any driver keeps)
     g_stamp = fc.timed = g_timing;
     if (fc.timed) { ++g_begun_calls; ++g_inflight; g_ev_slabs[fc.slot] = 0; }
+    // A retired slot goes back to the free list only once its `finished` event has completed: its slab-table copy may still
+    // be in flight on ANOTHER stream (several streams fed by one thread), and a new call on this stream must neither
+    // share that host buffer nor re-record that event.
+    for (size_t i = 0; i < g_pinned_draining.size();) {
+        if (hipEventQuery(g_pinned_draining[i].finished) != hipErrorNotReady) {
+            g_pinned_free.push_back(g_pinned_draining[i]);
+            g_pinned_draining[i] = g_pinned_draining.back();
+            g_pinned_draining.pop_back();
+        } else {
+            ++i;
+        }
+    }
     if (!g_pinned_free.empty()) {
         fc.pinned = g_pinned_free.back();
         g_pinned_free.pop_back();
@@ -757,6 +806,8 @@ int forward_finish(ForwardCall& fc) {
     hg.off[3] = (uint64_t)((char*)ga.rgb - gbase);
     hg.off[4] = (uint64_t)fc.geom_off[GSR_GEOM_INTERNAL_RADII];
     hg.off[5] = (uint64_t)fc.off_slabs;
+    hg.off[6] = (uint64_t)fc.off_quad;
+    hg.off[7] = (uint64_t)fc.off_rows;
     hb.count[0] = (uint32_t)S;
     hi.count[0] = (uint32_t)fc.width; hi.count[1] = (uint32_t)fc.height; hi.count[2] = (uint32_t)T; hi.count[3] = (uint32_t)S;
     hi.off[1] = (uint64_t)((char*)n_contrib - fc.ibase);
@@ -785,6 +836,15 @@ int forward_finish(ForwardCall& fc) {
         else
             pl_sorted = own_list;
         GSR_STAGE_CHECK("tile_sort");
+        if (debug && plan.bound[k] > 1) {  // the sorts' contract, checked: (tile, depth bits, id) ascending through the list
+            GSR_HIP(gsr::launch_list_order_check(slab, plan.bound[k], tk_sorted, pl_sorted, ga.raster, ga.counters, stream));
+            uint32_t violations = 0;
+            GSR_HIP(hipMemcpyAsync(&violations, &ga.counters->order_violations, sizeof violations, hipMemcpyDeviceToHost, stream));
+            GSR_HIP(hipStreamSynchronize(stream));
+            if (violations != 0u)
+                return fail(GSR_ERR_INTERNAL, "depth slab %d: %u entries of the sorted list are out of (tile, depth, id) order "
+                                              "(radix rank %s)", k, violations, gsr::radix_rank_mode(stream, nullptr) ? "LDS adds" : "ballots");
+        }
         stamp(kHeadEvents + kSlabEvents * k + 1, stream);
         list_of[k] = pl_sorted;
         tile_keys_sorted = tk_sorted;
@@ -820,7 +880,7 @@ int forward_finish(ForwardCall& fc) {
     GSR_HIP(hipMemcpyAsync(reinterpret_cast<char*>(fc.pinned.host) + kSlabTableAt, ba.slabs, sizeof(gsr::SlabInfo) * S,
                            hipMemcpyDeviceToHost, stream));
     GSR_HIP(hipEventRecord(fc.pinned.finished, stream));
-    if (g_last_slot.host) g_pinned_free.push_back(g_last_slot);
+    if (g_last_slot.host) g_pinned_draining.push_back(g_last_slot);  // (its copy may still be pending on another stream)
     g_last_slot = fc.pinned;
     fc.pinned = PinnedSlot();
     g_last_slabs = S;

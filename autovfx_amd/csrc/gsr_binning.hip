@@ -755,7 +755,38 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const SlabInfo* __rest
     ranges[t] = (e > b) ? make_uint2(b, e) : make_uint2(0u, 0u);
 }
 
+// ------------------------------------------------------------------------------------------------
+// debug calls only: entry i of a slab's sorted list must not precede entry i - 1 in (tile, depth bits, Gaussian id)
+// order -- the order the reference's single 64-bit stable sort yields (rasterizer_impl.cu:304-309) and that the depth
+// sort + stable tile sort here must reproduce.  An unstable pass anywhere would show up as a violation.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) list_order_check_kernel(const SlabInfo* __restrict__ slab, const uint32_t* __restrict__ keys,
+                                                               const uint32_t* __restrict__ list,
+                                                               const SplatRaster* __restrict__ raster, FrameCounters* counters) {
+    const uint32_t n = slab->pairs;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x + 1u;
+    bool bad = false;
+    if (i < n) {
+        const uint32_t ta = keys[i - 1], tb = keys[i], ga = list[i - 1], gb = list[i];
+        uint32_t da = __float_as_uint(raster[ga].depth), db = __float_as_uint(raster[gb].depth);
+        if (da == kCulledKey) da = kCulledKey - 1u;   // (as the projection kernel keys a NaN depth)
+        if (db == kCulledKey) db = kCulledKey - 1u;
+        bad = ta > tb || (ta == tb && (da > db || (da == db && ga >= gb)));
+    }
+    const unsigned long long b = __ballot(bad);
+    if (b != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&counters->order_violations, (uint32_t)__popcll(b));
+}
+
 } // namespace
+
+hipError_t launch_list_order_check(const SlabInfo* slab, uint32_t pairs_bound, const uint32_t* sorted_tile_keys,
+                                   const uint32_t* point_list, const SplatRaster* raster, FrameCounters* counters,
+                                   hipStream_t stream) {
+    if (pairs_bound < 2u) return hipSuccess;
+    hipLaunchKernelGGL(list_order_check_kernel, dim3((pairs_bound + 255u) / 256u), dim3(256), 0, stream, slab, sorted_tile_keys,
+                       point_list, raster, counters);
+    return hipGetLastError();
+}
 
 hipError_t launch_bin_scan(const BinningArrays& a, const Camera& cam, int num_slabs, const uint32_t* pair_cuts, hipStream_t stream) {
     (void)cam;

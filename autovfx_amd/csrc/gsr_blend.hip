@@ -140,6 +140,10 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(BlendArgs a) {
     }
 
     uint32_t seg_base = 0u;  // list positions of earlier segments (n_contrib counts through the concatenation)
+    for (int seg = 0; seg < a.seg_begin; ++seg) {  // ... also of the segments earlier launches walked
+        const uint2 earlier = a.segs.ranges[seg][tile];
+        seg_base += earlier.y - earlier.x;
+    }
     for (int seg = a.seg_begin; seg < a.seg_end && done_mask != ~0ull; ++seg) {
         const uint2 range = a.segs.ranges[seg][tile];
         const uint32_t count = range.y - range.x;

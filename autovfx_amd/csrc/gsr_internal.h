@@ -23,7 +23,8 @@ struct FrameCounters {
     uint32_t big_rows[kRectPartials];               // tile rows of the splats too large for a mask (sizes the run pool)
     uint32_t error_flag;                            // bit 0 = prefiltered violation
     uint32_t pool_used;                             // run pool: rows handed out so far (bin_gather_kernel)
-    uint32_t pad[2];
+    uint32_t order_violations;                      // debug calls: list entries out of (tile, depth bits, id) order
+    uint32_t pad;
 };
 constexpr size_t kCounterCopyBytes = sizeof(FrameCounters);
 
@@ -144,6 +145,11 @@ hipError_t launch_slab_recount(const BinningArrays& a, int slab, hipStream_t str
 // (tile id, Gaussian id) pairs of one slab in depth order; at most pairs_bound of them (the grid is sized for it)
 hipError_t launch_expand(const BinningArrays& a, int slab, uint32_t pairs_bound, uint32_t* tile_keys, uint32_t* point_list,
                          hipStream_t stream);
+// debug calls: counts (into counters->order_violations) the entries of a slab's sorted list that are not in ascending
+// (tile, depth bits, Gaussian id) order relative to their predecessor -- what two stable sorts must have produced
+hipError_t launch_list_order_check(const SlabInfo* slab, uint32_t pairs_bound, const uint32_t* sorted_tile_keys,
+                                   const uint32_t* point_list, const SplatRaster* raster, FrameCounters* counters,
+                                   hipStream_t stream);
 struct ArenaHeader;
 // ranges[t] = [first, last) positions of tile t in the sorted keys ((0,0) when empty); the number of keys is read from
 // slab->pairs.  header_dst may be null; otherwise the three arena headers are stamped by the same launch.
@@ -229,6 +235,12 @@ hipError_t launch_pack_rgba8(const float* color, const float* alpha, uint8_t* ou
 // counts the returning LDS adds whose result was not (value before the instruction) + (lower lanes on the same counter)
 hipError_t launch_lds_atomic_order_selftest(uint32_t workgroups, uint32_t rounds, uint32_t seed, unsigned long long* mismatches,
                                             hipStream_t stream);
+// The in-wave rank of the scatter kernel: request 0 = ballots, 1 = returning LDS adds unconditionally, 2 = LDS adds on a
+// device that passed the lane-order self-test (run once per device, on `stream`, by the first caller), ballots elsewhere.
+// radix_rank_mode returns what sorts on the CURRENT device use (1 = LDS adds); *violations = what the self-test counted.
+void radix_set_rank_request(int request);
+int radix_rank_request();
+int radix_rank_mode(hipStream_t stream, unsigned long long* violations);
 size_t radix_scratch_words(uint32_t n);
 hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt,
                             uint32_t* vals, uint32_t* vals_alt, bool iota_payload, bool want_sorted_keys,

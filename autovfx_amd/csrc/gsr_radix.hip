@@ -17,24 +17,27 @@
 //
 // Scatter kernel, one workgroup = 256 lanes (4 wave64) x 16 items = 4096 pairs:
 //   1. keys are loaded wave-striped (item i of lane L at wave_base + 64 i + L: coalesced);
-//   2. stable rank inside the wave: one returning LDS add per item on the wave's counter of the item's digit.  Lanes
-//      of one instruction that hit the same counter are served in ascending lane order and a wave's instructions
-//      retire in program order, so the values returned number the wave's items of a digit in tile order.  (That
-//      order is what gfx950's LDS does, pinned by gsr_selftest_lds_atomic_order / tests/test_radix_gpu.py; the
-//      ballot-matching form -- 8 ballots per item, popcount below the lane -- is kept behind
-//      GSR_RADIX_RANK_BY_LDS_ATOMICS=0.  The atomics cut the kernel's vector instructions by about 40 %: C3 frame
-//      -30 us single-stream, +1.4 % with 3 streams, same box.)
+//   2. stable rank inside the wave, in one of two forms, BOTH compiled in (template parameter kRankAtomic):
+//        - ballots: 8 ballots per item match the lanes with the same digit, popcount below the lane.  Relies on
+//          nothing but the ISA; this is the fallback and what GSR_OPT_RADIX_RANK = 0 forces.
+//        - LDS atomics: one returning LDS add per item on the wave's counter of the item's digit.  Correct only if lanes
+//          of one instruction that hit the same counter are served in ascending lane order (a wave's instructions retire
+//          in program order), so that the values returned number the wave's items of a digit in tile order.  That order
+//          is what gfx950's LDS does, but no manual promises it, so the library CHECKS it: the first sort on a device
+//          runs the self-test below (lds_atomic_order_selftest_kernel, every conflict density) and the atomics are used
+//          on that device only if it reports zero violations (radix_rank_mode(); GSR_OPT_RADIX_RANK, default 2 = auto).
+//          The atomics cut the kernel's vector instructions by about 40 %: C3 frame -30 us single-stream, +1.4 %
+//          with 3 streams, same box.
 //   3. counters are turned into (wave, digit) offsets, a 256-wide scan gives the digit segments of the tile;
 //   4. pairs are parked in LDS at their in-tile position and written out in that order, so every digit
 //      segment is a contiguous, coalesced run in HBM.
 #include "gsr_internal.h"
 
+#include <mutex>
+
 namespace gsr {
 namespace {
 
-#ifndef GSR_RADIX_RANK_BY_LDS_ATOMICS
-#define GSR_RADIX_RANK_BY_LDS_ATOMICS 1
-#endif
 constexpr int kThreads = 256;
 constexpr int kItems = 16;
 constexpr int kTileItems = kThreads * kItems;
@@ -144,9 +147,10 @@ __global__ void __launch_bounds__(kThreads) radix_scan_kernel(uint32_t* __restri
 
 // ------------------------------------------------------------------------------------------------
 // scatter.  kIota: payloads are the item indices (first pass of the depth sort: no payload read).
-// kKeysOut: false on a last pass whose sorted keys nobody reads.
+// kKeysOut: false on a last pass whose sorted keys nobody reads.  kRankAtomic: the in-wave rank by returning LDS adds
+// (only launched on a device that passed the lane-order self-test) instead of ballots.
 // ------------------------------------------------------------------------------------------------
-template <bool kIota, bool kKeysOut>
+template <bool kIota, bool kKeysOut, bool kRankAtomic>
 __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                 const uint32_t* __restrict__ vals_in,
                                                                 uint32_t* __restrict__ keys_out,
@@ -192,17 +196,18 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t*
     // 2. stable rank inside the wave
     uint32_t rank[kItems];
     uint32_t* my_count = s_count[wave];
-#if GSR_RADIX_RANK_BY_LDS_ATOMICS
-    // One returning LDS add per item on the wave's counter of its digit: lanes that hit the same counter in one
-    // instruction are served in ascending lane order and instructions retire in program order, so the returned values
-    // number the wave's items of a digit in tile order (item i of lane L sits at 64 i + L) -- the rank the ballots compute.
+    if (kRankAtomic) {
+        // One returning LDS add per item on the wave's counter of its digit: lanes that hit the same counter in one
+        // instruction are served in ascending lane order and instructions retire in program order, so the returned values
+        // number the wave's items of a digit in tile order (item i of lane L sits at 64 i + L) -- the rank the ballots
+        // compute.  Only reached on a device where the self-test confirmed that order (radix_rank_mode).
 #pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        const bool valid = first + 64u * i < tile_n;
-        const uint32_t d = (key[i] >> shift) & digit_mask;
-        rank[i] = valid ? atomicAdd(&my_count[d], 1u) : 0u;
-    }
-#else
+        for (int i = 0; i < kItems; ++i) {
+            const bool valid = first + 64u * i < tile_n;
+            const uint32_t d = (key[i] >> shift) & digit_mask;
+            rank[i] = valid ? atomicAdd(&my_count[d], 1u) : 0u;
+        }
+    } else {
     const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
@@ -220,7 +225,7 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t*
         rank[i] = before + (uint32_t)__popcll(peers & below);
         if (valid && (peers >> lane) == 1ull) my_count[d] = before + (uint32_t)__popcll(peers);  // highest peer
     }
-#endif
+    }
     __syncthreads();
     GSR_TRACE(1);
 
@@ -327,6 +332,59 @@ hipError_t launch_lds_atomic_order_selftest(uint32_t workgroups, uint32_t rounds
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Which in-wave rank the scatter kernel uses on the current device.  g_rank_request: 0 ballots, 1 LDS atomics without
+// asking, 2 (default) LDS atomics on a device that passed the lane-order self-test, ballots elsewhere.  The self-test
+// runs ONCE per device and process, on the first sort (or the first query): 512 workgroups x 4 waves x 192 instructions
+// of every conflict density (~0.4 M instructions, 25 M lane results; well under a millisecond), on its own small
+// allocation, with the calling stream drained before and after -- a one-time cost at the first call on a device.
+// ------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_rank_mutex;
+int g_rank_request = 2;
+int g_rank_verdict[kMaxDevices];      // 0 not tested yet, 1 passed (atomics), 2 failed (ballots), 3 could not be tested (ballots)
+unsigned long long g_rank_violations[kMaxDevices];
+
+int test_device_locked(int dev, hipStream_t stream) {
+    unsigned long long* d_bad = nullptr;
+    unsigned long long h_bad = ~0ull;
+    int verdict = 3;
+    if (hipMalloc((void**)&d_bad, sizeof *d_bad) == hipSuccess) {
+        if (hipMemsetAsync(d_bad, 0, sizeof *d_bad, stream) == hipSuccess &&
+            launch_lds_atomic_order_selftest(512u, 192u, 0x6a09e667u, d_bad, stream) == hipSuccess &&
+            launch_lds_atomic_order_selftest(512u, 192u, 0xbb67ae85u, d_bad, stream) == hipSuccess &&
+            hipMemcpyAsync(&h_bad, d_bad, sizeof h_bad, hipMemcpyDeviceToHost, stream) == hipSuccess &&
+            hipStreamSynchronize(stream) == hipSuccess)
+            verdict = h_bad == 0ull ? 1 : 2;
+        (void)hipFree(d_bad);
+    }
+    g_rank_violations[dev] = h_bad;
+    return verdict;
+}
+} // namespace
+
+void radix_set_rank_request(int request) {
+    std::lock_guard<std::mutex> lock(g_rank_mutex);
+    g_rank_request = request < 0 ? 0 : request > 2 ? 2 : request;
+}
+int radix_rank_request() {
+    std::lock_guard<std::mutex> lock(g_rank_mutex);
+    return g_rank_request;
+}
+// 1 = LDS atomics, 0 = ballots, for sorts queued on the current device from now on.
+int radix_rank_mode(hipStream_t stream, unsigned long long* violations) {
+    std::lock_guard<std::mutex> lock(g_rank_mutex);
+    if (violations) *violations = 0ull;
+    if (g_rank_request == 0) return 0;
+    if (g_rank_request == 1) return 1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 0;
+    if (g_rank_verdict[dev] == 0) g_rank_verdict[dev] = test_device_locked(dev, stream);
+    if (violations) *violations = g_rank_violations[dev];
+    return g_rank_verdict[dev] == 1 ? 1 : 0;
+}
+
 size_t radix_scratch_words(uint32_t n) {
     const size_t tiles = ((size_t)n + kTileItems - 1) / kTileItems;
     return 256u * ((tiles + 3u) & ~(size_t)3u) + 256u;  // per-digit rows of tile counts, then the digit totals
@@ -340,6 +398,7 @@ hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* k
     if (n == 0 || bits <= 0) return hipSuccess;
     if (bits > 32) return hipErrorInvalidValue;
     const int passes = (bits + 7) / 8;
+    const bool atomics = radix_rank_mode(stream, nullptr) == 1;  // (the first sort on a device runs the lane-order self-test)
     const uint32_t tiles = (n + kTileItems - 1) / kTileItems;
     const uint32_t tiles_pad = (tiles + 3u) & ~3u;
     uint32_t* counts = scratch;
@@ -352,13 +411,19 @@ hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* k
         const bool keys_out = want_sorted_keys || p + 1 < passes;
         hipLaunchKernelGGL(radix_count_kernel, dim3(tiles), dim3(kThreads), 0, stream, kin, n, 8 * p, mask, counts, tiles_pad, n_device);
         hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(kThreads), 0, stream, counts, tiles, tiles_pad, totals, n_device);
-#define GSR_RADIX_LAUNCH(I, K)                                                                                    \
-    hipLaunchKernelGGL((radix_scatter_kernel<I, K>), dim3(tiles), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, \
+#define GSR_RADIX_LAUNCH(I, K, A)                                                                                      \
+    hipLaunchKernelGGL((radix_scatter_kernel<I, K, A>), dim3(tiles), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, \
                        8 * p, mask, counts, tiles_pad, totals, n_device)
-        if (iota && keys_out) GSR_RADIX_LAUNCH(true, true);
-        else if (iota) GSR_RADIX_LAUNCH(true, false);
-        else if (keys_out) GSR_RADIX_LAUNCH(false, true);
-        else GSR_RADIX_LAUNCH(false, false);
+#define GSR_RADIX_LAUNCH_IK(A)                      \
+    do {                                            \
+        if (iota && keys_out) GSR_RADIX_LAUNCH(true, true, A);   \
+        else if (iota) GSR_RADIX_LAUNCH(true, false, A);         \
+        else if (keys_out) GSR_RADIX_LAUNCH(false, true, A);     \
+        else GSR_RADIX_LAUNCH(false, false, A);                  \
+    } while (0)
+        if (atomics) GSR_RADIX_LAUNCH_IK(true);
+        else GSR_RADIX_LAUNCH_IK(false);
+#undef GSR_RADIX_LAUNCH_IK
 #undef GSR_RADIX_LAUNCH
         uint32_t* t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;

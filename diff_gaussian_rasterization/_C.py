@@ -43,6 +43,32 @@ _BINNING_CB = _lib.ALLOC_FN(_alloc_binning)
 _IMAGE_CB = _lib.ALLOC_FN(_alloc_image)
 
 
+# ---- test hook: what freshly allocated scratch / output / gradient tensors contain --------------------------------
+# Every tensor this module hands to the library is ``torch.empty``: the library must write what it later reads, whatever
+# the allocator recycled.  ``set_alloc_poison`` makes that property testable (tests/test_poison_gpu.py): None = leave the
+# memory as the allocator returned it (the default), an int 0..255 = fill with that byte (0xFF: every float a NaN, every
+# index 4 G), "random" = random bytes.  Results must not depend on it.
+_POISON = None
+
+
+def set_alloc_poison(pattern) -> None:
+    global _POISON
+    if pattern is not None and pattern != "random" and not (isinstance(pattern, int) and 0 <= pattern <= 255):
+        raise ValueError("poison pattern: None, 'random' or a byte value")
+    _POISON = pattern
+
+
+def _new(shape, dtype, device) -> torch.Tensor:
+    t = torch.empty(shape, dtype=dtype, device=device)
+    if _POISON is not None and t.numel():
+        raw = t.view(torch.uint8) if t.dim() else t.reshape(1).view(torch.uint8)
+        if _POISON == "random":
+            raw.random_(0, 256)
+        else:
+            raw.fill_(_POISON)
+    return t
+
+
 class _CallScratch:
     """The three growable byte tensors of ``rasterize_points.cu:73-80`` (resizeFunctional)."""
 
@@ -51,7 +77,7 @@ class _CallScratch:
         self.buffers = {k: torch.empty(0, dtype=torch.uint8, device=device) for k in ("geom", "binning", "image")}
 
     def alloc(self, which: str, nbytes: int) -> int:
-        t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        t = _new(int(nbytes), torch.uint8, self.device)
         self.buffers[which] = t
         return t.data_ptr()
 
@@ -175,7 +201,7 @@ def _rasterize(background, means3D, colors, opacity, scales, rotations, scale_mo
 
     # The reference zero-fills its outputs (rasterize_points.cu:68-71), which only matters for P == 0:
     # with P > 0 every pixel and every radius is written by the kernels, so the fills are skipped.
-    make = torch.zeros if P == 0 else torch.empty
+    make = (lambda shape, dtype, device: torch.zeros(shape, dtype=dtype, device=device)) if P == 0 else _new
     # colour and alpha are the first three and the fourth plane of ONE buffer, so a caller that wants RGBA
     # (render() does: gaussian_renderer/__init__.py:161) gets it without a copy (rgba_planes below)
     rgba = make((4, H, W), dtype=torch.float32, device=device)
@@ -300,7 +326,7 @@ def rasterize_gaussians_begin(background, means3D, colors, opacity, scales, rota
     P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
     if extra_colors is not None and (extra_colors.dim() != 2 or extra_colors.shape != (P, 3)):
         raise RuntimeError("extra_colors must have dimensions (num_points, 3)")
-    make = torch.zeros if P == 0 else torch.empty
+    make = (lambda shape, dtype, device: torch.zeros(shape, dtype=dtype, device=device)) if P == 0 else _new
     # colour and alpha are the first three and the fourth plane of ONE buffer, so a caller that wants RGBA
     # (render() does: gaussian_renderer/__init__.py:161) gets it without a copy (rgba_planes below)
     rgba = make((4, H, W), dtype=torch.float32, device=device)
@@ -362,7 +388,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
     M = int(sh.size(1)) if sh.numel() != 0 else 0
     # P == 0: nothing runs, the (empty) results are trivially defined; otherwise gsr_backward writes every element
-    z = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)
+    z = lambda *shape: _new(shape, torch.float32, device)
     dL_dmeans3D, dL_dmeans2D, dL_dcolors = z(P, 3), z(P, 3), z(P, 3)
     dL_ddepths, dL_dconic, dL_dopacity = z(P, 1), z(P, 2, 2), z(P, 1)   # the first two are intermediates
     dL_dcov3D, dL_dsh, dL_dscales, dL_drotations = z(P, 6), z(P, M, 3), z(P, 3), z(P, 4)
@@ -376,7 +402,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         radii_ = radii.contiguous()
         if radii_.dtype != torch.int32:
             raise RuntimeError(f"radii: expected an int32 tensor, got {radii_.dtype}")
-        accum = torch.empty((P, 16), dtype=torch.float32, device=device)   # cleared by the library
+        accum = _new((P, 16), torch.float32, device)   # cleared by the library
         with torch.cuda.device(device):
             rc = _lib.lib.gsr_backward(
                 P, int(degree), M, int(R), _ptr(bg_), W, H, _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(sc_),

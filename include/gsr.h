@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 6
+#define GSR_ABI_VERSION 7
 
 #if defined(__GNUC__)
 #define GSR_API __attribute__((visibility("default")))
@@ -56,7 +56,8 @@ typedef enum gsr_status {
     GSR_ERR_ALLOC = -2,        /* a scratch callback returned NULL                                  */
     GSR_ERR_HIP = -3,          /* a HIP runtime call or kernel failed (message has the HIP string) */
     GSR_ERR_UNSUPPORTED = -4,  /* entry point declared but not built yet                            */
-    GSR_ERR_PREFILTERED = -5   /* prefiltered=1 but a Gaussian failed the near-plane test (debug)   */
+    GSR_ERR_PREFILTERED = -5,  /* prefiltered=1 but a Gaussian failed the near-plane test (debug)   */
+    GSR_ERR_INTERNAL = -6      /* debug=1 only: a per-tile list came out of the sorts in the wrong order  */
 } gsr_status;
 
 /* Scratch provider: must return a device pointer to at least `nbytes` bytes that stays valid until
@@ -325,6 +326,16 @@ typedef enum gsr_option {
      * further slab costs a fixed dozen of small launches, what it saves grows with the pairs it can drop.  (At
      * 960x540 with 1 M Gaussians and ~2 M live pairs slabs lose 13 %; with 6 - 18 M live pairs they gain 5 - 60 %.) */
     GSR_OPT_SLAB_MIN_REST = 4,
+    /* [2] How the radix sort ranks the keys of a wave (gsr_radix.hip).  0: ballots -- relies on nothing but the ISA.
+     * 1: one returning LDS add per key, unconditionally -- correct only where lanes of one instruction that hit the same
+     * LDS counter are served in ascending lane order, which gfx950 does and no manual promises.  2 (default): the first
+     * sort on each device runs gsr_selftest_lds_atomic_order's kernel (~0.4 M instructions of every conflict density,
+     * once per device and process) and uses the LDS adds on that device only if it counted zero violations, ballots
+     * otherwise.  Both forms produce the same stable sort; the LDS adds are ~25 % faster per pass. */
+    GSR_OPT_RADIX_RANK = 5,
+    /* read-only: what sorts queued on the CURRENT device use -- 1 LDS adds, 0 ballots (runs the self-test if this
+     * device has not been tested yet and the request is 2).  gsr_set_option rejects it. */
+    GSR_OPT_RADIX_RANK_ACTIVE = 6,
     GSR_OPT_NUM
 } gsr_option;
 GSR_API int gsr_set_option(int option, int value);

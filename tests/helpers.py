@@ -121,7 +121,17 @@ def _hip_forward_raw(_C, cloud, cam, device, bg, scale_modifier, sh_degree, cov3
         st.image_width, e if c.shs is None else c.shs, st.sh_degree, st.campos, False, debug)
     torch.cuda.synchronize()
     lay = _C.last_layout() if cloud.P else {}
-    P, W, H = cloud.P, cam.image_width, cam.image_height
+    out = {"num_rendered": n, "color": color.cpu().numpy(), "depth": depth.cpu().numpy(),
+           "alpha": alpha.cpu().numpy(), "radii": radii.cpu().numpy()}
+    if cloud.P:
+        assert lay["counts"]["num_rendered"] == n
+        out.update(decode_scratch(lay, geom, binning, img, cloud.P, cam.image_width, cam.image_height))
+    return out
+
+
+def decode_scratch(lay, geom, binning, img, P, W, H):
+    """Every sub-array of the three scratch arenas of a FULL forward call (``lay`` = ``_C.last_layout()`` taken right
+    after it on the calling thread), as numpy arrays."""
     T = ((W + 15) // 16) * ((H + 15) // 16)
 
     def view(buf, off, dtype, count, shape=None):
@@ -129,31 +139,63 @@ def _hip_forward_raw(_C, cloud, cam, device, bg, scale_modifier, sh_degree, cov3
         t = buf[off:off + nbytes].view(dtype)
         return (t.reshape(shape) if shape else t).cpu().numpy()
 
-    out = {"num_rendered": n, "color": color.cpu().numpy(), "depth": depth.cpu().numpy(),
-           "alpha": alpha.cpu().numpy(), "radii": radii.cpu().numpy()}
-    if P:
-        g = lay["geom"]
-        raster = view(geom, g["raster"], torch.float32, 8 * P, (P, 8))   # x y cxx cxy cyy opacity z pad
-        out["depths"] = np.ascontiguousarray(raster[:, 6])
-        out["means2D"] = np.ascontiguousarray(raster[:, 0:2])
-        out["conic_opacity"] = np.ascontiguousarray(raster[:, 2:6])
-        out["rgb"] = view(geom, g["rgb"], torch.float32, 3 * P, (P, 3))
-        bins = view(geom, g["splat_bins"], torch.int32, 4 * P, (P, 4)).astype(np.uint32)
-        out["tight_rect"] = np.stack((bins[:, 0] & 0xFFFF, bins[:, 0] >> 16, bins[:, 1] & 0xFFFF, bins[:, 1] >> 16), 1)   # x0 y0 w h
-        out["live_mask"] = bins[:, 2].astype(np.uint64) | (bins[:, 3].astype(np.uint64) << np.uint64(32))
-        out["depth_order"] = view(geom, g["depth_order"], torch.int32, P).astype(np.uint32)
-        out["point_offsets"] = view(geom, g["point_offsets"], torch.int32, P).astype(np.uint32)
-        # live tiles = pairs each splat emits: the steps of the inclusive offsets over the depth order
-        tt = np.zeros(P, np.uint32)
-        tt[out["depth_order"]] = np.diff(out["point_offsets"].astype(np.int64), prepend=0).astype(np.uint32)
-        out["tiles_touched"] = tt
-        b = lay["binning"]
-        live = lay["counts"]["live_pairs"]
-        assert lay["counts"]["num_rendered"] == n
-        out["live_pairs"] = live
-        out["point_list"] = view(binning, b["point_list"], torch.int32, live).astype(np.uint32)
-        out["tile_keys"] = view(binning, b["tile_keys"], torch.int32, live).astype(np.uint32)
-        i = lay["image"]
-        out["ranges"] = view(img, i["ranges"], torch.int32, 2 * T, (T, 2)).astype(np.uint32)
-        out["n_contrib"] = view(img, i["n_contrib"], torch.int32, W * H, (H, W)).astype(np.uint32)
+    out = {}
+    g = lay["geom"]
+    raster = view(geom, g["raster"], torch.float32, 8 * P, (P, 8))   # x y cxx cxy cyy opacity z pad
+    out["depths"] = np.ascontiguousarray(raster[:, 6])
+    out["means2D"] = np.ascontiguousarray(raster[:, 0:2])
+    out["conic_opacity"] = np.ascontiguousarray(raster[:, 2:6])
+    out["rgb"] = view(geom, g["rgb"], torch.float32, 3 * P, (P, 3))
+    bins = view(geom, g["splat_bins"], torch.int32, 4 * P, (P, 4)).astype(np.uint32)
+    out["tight_rect"] = np.stack((bins[:, 0] & 0xFFFF, bins[:, 0] >> 16, bins[:, 1] & 0xFFFF, bins[:, 1] >> 16), 1)   # x0 y0 w h
+    out["live_mask"] = bins[:, 2].astype(np.uint64) | (bins[:, 3].astype(np.uint64) << np.uint64(32))
+    out["depth_order"] = view(geom, g["depth_order"], torch.int32, P).astype(np.uint32)
+    out["point_offsets"] = view(geom, g["point_offsets"], torch.int32, P).astype(np.uint32)
+    # live tiles = pairs each splat emits: the steps of the inclusive offsets over the depth order
+    tt = np.zeros(P, np.uint32)
+    tt[out["depth_order"]] = np.diff(out["point_offsets"].astype(np.int64), prepend=0).astype(np.uint32)
+    out["tiles_touched"] = tt
+    b = lay["binning"]
+    live = lay["counts"]["live_pairs"]
+    out["live_pairs"] = live
+    out["point_list"] = view(binning, b["point_list"], torch.int32, live).astype(np.uint32)
+    out["tile_keys"] = view(binning, b["tile_keys"], torch.int32, live).astype(np.uint32)
+    i = lay["image"]
+    out["ranges"] = view(img, i["ranges"], torch.int32, 2 * T, (T, 2)).astype(np.uint32)
+    out["n_contrib"] = view(img, i["n_contrib"], torch.int32, W * H, (H, W)).astype(np.uint32)
     return out
+
+
+class dump_on_failure:
+    """``with dump_on_failure(name, inputs=..., hip=..., ref=...)``: when the block raises, every numpy array of the given
+    dicts is saved to gpurun_out/failures/<name>.npz (merged back from the GPU box) and the failure re-raised, so a
+    red run can be localised afterwards even if it never repeats."""
+
+    def __init__(self, name, **groups):
+        self.name, self.groups = name, groups
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is None:
+            return False
+        import os
+        import traceback
+        root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "failures")
+        os.makedirs(root, exist_ok=True)
+        flat = {}
+        for gname, d in self.groups.items():
+            for k, v in (d or {}).items():
+                if torch.is_tensor(v):
+                    v = v.detach().cpu().numpy()
+                if isinstance(v, (np.ndarray, int, float, np.integer, np.floating)):
+                    flat[f"{gname}.{k}"] = np.asarray(v)
+        safe = "".join(ch if ch.isalnum() or ch in "-_." else "_" for ch in self.name)
+        try:
+            np.savez_compressed(os.path.join(root, safe + ".npz"), **flat)
+            with open(os.path.join(root, safe + ".txt"), "w") as f:
+                f.write("".join(traceback.format_exception(exc_type, exc, tb)))
+        except OSError:
+            pass
+        return False

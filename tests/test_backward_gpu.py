@@ -16,7 +16,7 @@ from autovfx_amd.cameras import orbit_cameras
 from autovfx_amd.scenes import GaussianCloud
 from oracle import cpu_oracle
 
-from helpers import oracle_kwargs, settings_for
+from helpers import decode_scratch, dump_on_failure, oracle_kwargs, settings_for
 from test_oracle_backward import GOLDEN_BW, cpu_cov3d, load_bw_case, pixel_grads
 from test_parity_gpu import report
 
@@ -48,6 +48,12 @@ def hip_backward(cloud, cam, pg, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, sh_degr
     try:
         color, depth, alpha, radii = GaussianRasterizer(st)(means3D=means3D, means2D=means2D, opacities=opac, shs=shs,
                                                             colors_precomp=colors, **kw)
+        # the forward's own scratch (what the backward is about to read), decoded BEFORE the backward runs: a wrong
+        # gradient can then be traced to a wrong list / order / last contributor instead of being one number too far off
+        from diff_gaussian_rasterization import _C
+        torch.cuda.synchronize()
+        saved = color.grad_fn.saved_tensors   # (.., radii, sh, geom, binning, image, alpha): __init__.py save_for_backward
+        fwd = decode_scratch(_C.last_layout(), saved[7], saved[8], saved[9], cloud.P, cam.image_width, cam.image_height) if cloud.P else {}
         t = lambda a: torch.from_numpy(a).to(device)
         loss = (color * t(pg["dL_dcolor"])).sum() + (depth * t(pg["dL_ddepth"])).sum() + (alpha * t(pg["dL_dalpha"])).sum()
         loss.backward()
@@ -55,9 +61,62 @@ def hip_backward(cloud, cam, pg, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, sh_degr
         _lib.set_option(_lib.OPT_TILE_CULL, 1)
     torch.cuda.synchronize()
     g = lambda x: None if x is None or x.grad is None else x.grad.cpu().numpy()
-    return {"color": color.detach().cpu().numpy(), "dL_dmeans3D": g(means3D), "dL_dmeans2D": g(means2D),
+    return {"color": color.detach().cpu().numpy(), "depth": depth.detach().cpu().numpy(), "alpha": alpha.detach().cpu().numpy(),
+            "dL_dmeans3D": g(means3D), "dL_dmeans2D": g(means2D),
             "dL_dopacity": g(opac), "dL_dsh": g(shs), "dL_dcolors": g(colors), "dL_dscales": g(scales),
-            "dL_drotations": g(rots), "dL_dcov3D": g(cov), "radii": radii.cpu().numpy()}
+            "dL_drotations": g(rots), "dL_dcov3D": g(cov), "radii": radii.cpu().numpy(), "fwd": fwd, "cull": cull}
+
+
+def assert_forward_state(name, hip, fref):
+    """The forward half of a backward case, against the oracle's forward with intermediates: integers bit-exact
+    (radii, depth order; with tile culling off also the lists, their ranges and every pixel's last contributor -- with
+    it on the lists are thinner, so they are checked for order and against the unculled run's images), images within
+    the forward tolerance.  Runs BEFORE the gradient comparison so that a failure says which stage went wrong."""
+    from test_parity_gpu import RGB_TOL, FLIP_PPM
+    f = hip["fwd"]
+    np.testing.assert_array_equal(hip["radii"], fref["radii"], err_msg=f"{name}: radii")
+    vis = fref["radii"] > 0
+    V = int(vis.sum())
+    ids = np.nonzero(vis)[0]
+    expect = ids[np.lexsort((ids, fref["depths"][ids].view(np.uint32)))]
+    if not hip["cull"]:
+        np.testing.assert_array_equal(f["depth_order"][:V], expect.astype(np.uint32), err_msg=f"{name}: depth order")
+        np.testing.assert_array_equal(f["point_list"], fref["point_list"], err_msg=f"{name}: point_list")
+        np.testing.assert_array_equal(f["ranges"], fref["ranges"], err_msg=f"{name}: ranges")
+        bad = int((f["n_contrib"] != fref["n_contrib"]).sum())
+        assert bad <= int(np.ceil(FLIP_PPM * 1e-6 * f["n_contrib"].size)), f"{name}: n_contrib differs on {bad} pixels"
+    else:
+        # culled: splats whose every tile is dead leave the depth order; what is left keeps the oracle's order, and each
+        # tile's list is ascending in (depth bits, id) -- the property the blend and the backward rely on
+        order = f["depth_order"]
+        kept = order[f["tiles_touched"][order] > 0]
+        pos = np.full(fref["radii"].shape[0], -1, np.int64)
+        pos[expect] = np.arange(V)
+        assert (pos[kept] >= 0).all() and (np.diff(pos[kept]) > 0).all(), f"{name}: culled depth order is not a subsequence"
+        pl, tk = f["point_list"], f["tile_keys"]
+        keys = (fref["depths"][pl].view(np.uint32).astype(np.uint64) << np.uint64(32)) | pl.astype(np.uint64)
+        if pl.size > 1:
+            same_tile = tk[1:] == tk[:-1]
+            assert (tk[1:] >= tk[:-1]).all(), f"{name}: tile keys not ascending"
+            out_of_order = int((same_tile & ~(keys[1:] > keys[:-1])).sum())
+            assert out_of_order == 0, f"{name}: {out_of_order} list entries out of (depth, id) order inside their tile"
+    dmax = max(1.0, float(np.abs(fref["depth"]).max()))
+    npx = fref["alpha"].size
+    for key, tol in (("color", RGB_TOL), ("alpha", RGB_TOL), ("depth", RGB_TOL * dmax)):
+        err = np.abs(hip[key].astype(np.float64) - fref[key].astype(np.float64))
+        bad = int((err > tol).sum())
+        assert bad <= int(np.ceil(FLIP_PPM * 1e-6 * npx)), f"{name}: forward {key} off on {bad} px (max {err.max():.3e})"
+
+
+def check_case(name, cloud, cam, pg, hip, ref, keys, **okw):
+    """One backward case: forward state first, then every gradient; on any failure the inputs, the HIP results (with the
+    decoded forward scratch) and the oracle's are dumped to gpurun_out/failures/."""
+    fref = cpu_oracle.forward(intermediates=True, **oracle_kwargs(cloud, cam, **okw))
+    with dump_on_failure("bw_" + name, hip={k: v for k, v in hip.items() if k != "fwd"}, fwd=hip["fwd"], ref=ref, fref=fref, pg=pg,
+                         cloud={"means3D": cloud.means3D, "opacities": cloud.opacities, "scales": cloud.scales,
+                                "rotations": cloud.rotations}):
+        assert_forward_state(name, hip, fref)
+        compare(name, hip, ref, keys)
 
 
 def compare(name, hip, ref, keys):
@@ -85,8 +144,7 @@ def test_backward_sh_scene(cull):
     kw.update(pg)
     ref = cpu_oracle.backward(**kw)
     hip = hip_backward(cloud, cam, pg, bg=(0.1, 0.2, 0.3), cull=cull)
-    np.testing.assert_array_equal(hip["radii"], ref["radii"])
-    compare(f"sh_cull{int(cull)}", hip, ref, KEYS_SH)
+    check_case(f"sh_cull{int(cull)}", cloud, cam, pg, hip, ref, KEYS_SH, bg=(0.1, 0.2, 0.3))
 
 
 def test_backward_precomputed_colours_and_orbit_camera():
@@ -94,7 +152,8 @@ def test_backward_precomputed_colours_and_orbit_camera():
     pg = pixel_grads(cam, 6)
     kw = oracle_kwargs(cloud, cam, bg=(1.0, 1.0, 1.0))
     kw.update(pg)
-    compare("precomp", hip_backward(cloud, cam, pg, bg=(1.0, 1.0, 1.0)), cpu_oracle.backward(**kw), KEYS_PRE)
+    check_case("precomp", cloud, cam, pg, hip_backward(cloud, cam, pg, bg=(1.0, 1.0, 1.0)), cpu_oracle.backward(**kw), KEYS_PRE,
+               bg=(1.0, 1.0, 1.0))
 
 
 def test_backward_cov3d_precomp_scale_modifier_low_degree():
@@ -104,11 +163,13 @@ def test_backward_cov3d_precomp_scale_modifier_low_degree():
     kw = oracle_kwargs(cloud, cam, cov3D_precomp=cov, sh_degree=1, bg=(0.5, 0.5, 0.5))
     kw.update(pg)
     hip = hip_backward(cloud, cam, pg, bg=(0.5, 0.5, 0.5), cov3D_precomp=cov, sh_degree=1)
-    compare("cov3d_deg1", hip, cpu_oracle.backward(**kw), ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dcov3D"))
+    check_case("cov3d_deg1", cloud, cam, pg, hip, cpu_oracle.backward(**kw),
+               ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dcov3D"), cov3D_precomp=cov, sh_degree=1, bg=(0.5, 0.5, 0.5))
     cloud2 = scenes.config_c1(P=2500, seed=34)
     kw = oracle_kwargs(cloud2, cam, scale_modifier=1.7)
     kw.update(pg)
-    compare("scale_mod", hip_backward(cloud2, cam, pg, scale_modifier=1.7), cpu_oracle.backward(**kw), KEYS_SH)
+    check_case("scale_mod", cloud2, cam, pg, hip_backward(cloud2, cam, pg, scale_modifier=1.7), cpu_oracle.backward(**kw), KEYS_SH,
+               scale_modifier=1.7)
 
 
 def test_backward_big_splats_and_ragged_image():
@@ -117,7 +178,7 @@ def test_backward_big_splats_and_ragged_image():
     pg = pixel_grads(cam, 8)
     kw = oracle_kwargs(cloud, cam)
     kw.update(pg)
-    compare("big_ragged", hip_backward(cloud, cam, pg), cpu_oracle.backward(**kw), KEYS_SH)
+    check_case("big_ragged", cloud, cam, pg, hip_backward(cloud, cam, pg), cpu_oracle.backward(**kw), KEYS_SH)
 
 
 @pytest.mark.parametrize("path", GOLDEN_BW, ids=[os.path.basename(p)[:-4] for p in GOLDEN_BW])
@@ -180,7 +241,7 @@ def test_backward_randomised_configurations(seed):
     kw = oracle_kwargs(cloud, cam, bg=bg, sh_degree=deg)
     kw.update(pg)
     hip = hip_backward(cloud, cam, pg, bg=bg, sh_degree=deg, cull=bool(seed % 2))
-    compare(f"rand{seed}", hip, cpu_oracle.backward(**kw), KEYS_SH)
+    check_case(f"rand{seed}", cloud, cam, pg, hip, cpu_oracle.backward(**kw), KEYS_SH, bg=bg, sh_degree=deg)
 
 
 def test_backward_c2_full_size_vs_oracle():
@@ -192,8 +253,7 @@ def test_backward_c2_full_size_vs_oracle():
     kw.update(pg)
     ref = cpu_oracle.backward(**kw)
     hip = hip_backward(cloud, cam, pg)
-    np.testing.assert_array_equal(hip["radii"], ref["radii"])
-    compare("c2_full_1M", hip, ref, KEYS_SH)
+    check_case("c2_full_1M", cloud, cam, pg, hip, ref, KEYS_SH)
 
 
 def test_backward_sh_degree_four_with_25_coefficients_leaves_higher_bands_zero():

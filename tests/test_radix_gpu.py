@@ -8,6 +8,18 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["ballots", "lds_adds"], autouse=True)
+def rank_variant(request):
+    """Both in-wave rank forms of the scatter kernel are compiled in (gsr_radix.hip); every test of this file runs with
+    each of them forced (GSR_OPT_RADIX_RANK 0 / 1), then the default (2: LDS adds where the device passed the self-test)
+    is restored."""
+    from autovfx_amd import _lib
+    _lib.set_option(_lib.OPT_RADIX_RANK, 0 if request.param == "ballots" else 1)
+    assert _lib.get_option(_lib.OPT_RADIX_RANK_ACTIVE) == (0 if request.param == "ballots" else 1)
+    yield request.param
+    _lib.set_option(_lib.OPT_RADIX_RANK, 2)
+
+
 def sort_pairs(keys, vals, bits, iota=False):
     from autovfx_amd import _lib
     n = keys.numel()
@@ -78,3 +90,40 @@ def test_lds_atomics_serve_lanes_in_order():
         assert _lib.lib.gsr_selftest_lds_atomic_order(2048, 512, seed, bad.data_ptr(), stream) == 0, _lib.last_error()
     torch.cuda.synchronize()
     assert int(bad.item()) == 0
+
+
+def test_default_mode_selftests_the_device_and_reports_what_it_uses():
+    """GSR_OPT_RADIX_RANK = 2 (the default): the first sort on a device runs the lane-order self-test; on MI355X it passes
+    and GSR_OPT_RADIX_RANK_ACTIVE says LDS adds.  (Were it to fail, ACTIVE would say ballots and the sorts would still be
+    right: that branch is the `ballots` parametrisation of every test above.)"""
+    from autovfx_amd import _lib
+    _lib.set_option(_lib.OPT_RADIX_RANK, 2)
+    assert _lib.get_option(_lib.OPT_RADIX_RANK) == 2
+    assert _lib.get_option(_lib.OPT_RADIX_RANK_ACTIVE) == 1, "the LDS lane-order self-test failed on this device"
+    with pytest.raises(RuntimeError):
+        _lib.set_option(_lib.OPT_RADIX_RANK_ACTIVE, 0)
+    keys = torch.randint(0, 2**13, (1_000_003,), device="cuda", dtype=torch.int32)
+    vals = torch.arange(keys.numel(), device="cuda", dtype=torch.int32)
+    want = torch.sort(keys.to(torch.int64), stable=True).indices.to(torch.int32)
+    _, got = sort_pairs(keys.clone(), vals, 13)
+    assert torch.equal(got, want)
+
+
+def test_c2_full_frame_is_identical_with_either_rank():
+    """BASELINE configs[1] at full size through both rank forms: every public output and the sorted lists bit for bit
+    (debug = True also runs the library's own (tile, depth, id) order check over the 3.5 M-entry list)."""
+    import numpy as np
+    from autovfx_amd import _lib, scenes
+    from autovfx_amd.cameras import orbit_cameras
+    from helpers import hip_forward_inference, hip_forward_raw
+    cloud, cam = scenes.config_c2(), orbit_cameras(200, 960, 540)[100]
+    outs = {}
+    for mode in (0, 1):
+        _lib.set_option(_lib.OPT_RADIX_RANK, mode)
+        outs[mode] = (hip_forward_raw(cloud, cam, cull=True, debug=True), hip_forward_inference(cloud, cam, slabs=0, slab_first=40, debug=True))
+    for k in ("color", "depth", "alpha", "radii", "depth_order", "point_list", "tile_keys", "ranges", "n_contrib"):
+        np.testing.assert_array_equal(outs[0][0][k], outs[1][0][k], err_msg=k)
+    for k in ("color", "depth", "alpha", "radii"):
+        np.testing.assert_array_equal(outs[0][1][k], outs[1][1][k], err_msg="inference " + k)
+        np.testing.assert_array_equal(outs[0][1][k], outs[0][0][k], err_msg="inference vs full " + k)
+    assert outs[0][1]["slab_pairs"] == outs[1][1]["slab_pairs"] and len(outs[0][1]["slab_pairs"]) > 1
