@@ -332,6 +332,10 @@ def main():
     ap.add_argument("--slabs", type=int, default=None, help="A/B knob: GSR_OPT_SLABS (1 = no depth slabs; default: as the scene calls for)")
     ap.add_argument("--slab-first", type=int, default=None, help="A/B knob: GSR_OPT_SLAB_FIRST (pairs per tile in the first slab)")
     ap.add_argument("--no-defer-colour", action="store_true", help="A/B knob: GSR_OPT_DEFER_COLOUR = 0")
+    ap.add_argument("--frames-digest", action="store_true",
+                    help="add `frames_digest` to the line: SHA-256 of the RGBA8 frames rank 0 holds after the last timed region "
+                         "(the gathered stack in frame order with N > 1 ranks / --force-distributed), so that the N > 1 code "
+                         "path can be checked byte for byte against the N = 1 path (tests/test_rccl_gpu.py)")
     ap.add_argument("--profile-run", action="store_true",
                     help="for rocprofv3: only warm-up + ONE timed region of uniform calls (no replay, statistics, baselines)")
     args = ap.parse_args()
@@ -413,7 +417,7 @@ def main():
 
     begin_fn = begin_fn_boundary if args.boundary == "render" else rasterize_begin
     render_fn = render_fn_boundary if args.boundary == "render" else rasterize
-    gather_stats, gathered_shape = {}, [None]
+    gather_stats, gathered_shape, last_frames = {}, [None], [None]
 
     timed_frames = [frame_of(Wm + j) for j in range(K)]
     for f in timed_frames:   # camera matrices resident before the clock starts
@@ -425,6 +429,7 @@ def main():
             g = render_and_gather(b.cloud, cam_list, list(range(K)), b.bg, dst=0, streams=S, chunks=args.gather_chunks,
                                   driver=driver, begin_fn=begin_fn, render_fn=render_fn, rows=K, stats=gather_stats)
             gathered_shape[0] = None if g is None else tuple(g.shape)
+            last_frames[0] = None if g is None else (g, K * world)   # (put into frame order after the clock stopped)
     elif strong:
         job_cams = [b.cam(f) for f in range(min(args.job_frames, F))]
         job_cams = [job_cams[f % len(job_cams)] for f in range(args.job_frames)]
@@ -435,11 +440,13 @@ def main():
             cloud = broadcast_cloud(src_cloud if rank == 0 else None, src=0, device=device) if distributed else src_cloud
             g = render_and_gather(cloud, job_cams, my_ids, b.bg, dst=0, streams=S, chunks=args.gather_chunks, driver=driver,
                                   begin_fn=begin_fn, render_fn=render_fn, rows=K, stats=gather_stats)
-            if g is not None:
-                gathered_shape[0] = tuple(frames_in_order(g, args.job_frames).shape) if distributed else tuple(g.shape)
+            if g is not None:   # rank-major [world, rows, 4, H, W]; frames_in_order (a copy) runs after the clock stopped
+                last_frames[0] = (g, args.job_frames)
+                gathered_shape[0] = tuple(g.shape)
     else:
         def region():
             b.run(timed_frames, rgba, S, side, composed)
+            last_frames[0] = (rgba[:K][None], K) if K <= rgba.shape[0] else None
 
     with torch.no_grad():
         b.run([frame_of(i) for i in range(Wm)], rgba, S, side, composed)
@@ -567,6 +574,12 @@ def main():
             line["reference_on_gpu"] = reference_on_gpu
         if also is not None:
             line["also"] = also
+        if args.frames_digest and last_frames[0] is not None:
+            import hashlib
+            torch.cuda.synchronize()
+            fr = frames_in_order(*last_frames[0]).contiguous().cpu().numpy()
+            line["frames_digest"] = {"sha256": hashlib.sha256(fr.tobytes()).hexdigest(), "shape": list(fr.shape),
+                                     "nonzero_bytes": int(np.count_nonzero(fr))}
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if distributed:
         dist.destroy_process_group()
