@@ -113,6 +113,51 @@ class Camera:
         return Camera.from_Rt(R, T, focal2fov(fx, width), focal2fov(fy, height), width, height, name)
 
 
+def sugar_camera(c2w_opengl: np.ndarray, fov_x: float, fov_y: float, width: int, height: int, cx_ndc: float = 0.0,
+                 cy_ndc: float = 0.0, name: str = "", znear: float = 0.01, zfar: float = 100.0) -> Camera:
+    """The matrices SuGaR's ``render_image_gaussian_rasterizer`` hands to the rasterizer
+    (``sugar/sugar_scene/sugar_model.py:2008-2032``): a nerfstudio camera-to-world matrix (OpenGL axes: y up, z back) is
+    flipped to COLMAP axes (``c2w[:3, 1:3] *= -1``), inverted, and -- unlike the vanilla 3DGS camera -- the projection
+    matrix carries the principal point of the pytorch3d camera: ``proj_transform[2, 0] = -K[0, 2]``,
+    ``proj_transform[2, 1] = -K[1, 2]`` on the TRANSPOSED matrix (``cx_ndc``, ``cy_ndc``: pytorch3d NDC units, zero for a
+    centred principal point).  ``viewmatrix`` and ``tanfov`` are unchanged, so the 2D covariance and the frustum clamp see the
+    centred camera while the pixel centres are shifted: the call shape of BASELINE configs[3]."""
+    c2w = np.array(c2w_opengl, dtype=np.float32)
+    if c2w.shape == (3, 4):
+        c2w = np.concatenate((c2w, np.array([[0, 0, 0, 1]], dtype=np.float32)), axis=0)
+    c2w = c2w.copy()
+    c2w[:3, 1:3] *= -1
+    w2c = np.linalg.inv(c2w)
+    R = np.transpose(w2c[:3, :3])
+    T = w2c[:3, 3]
+    Rt = np.zeros((4, 4), dtype=np.float32)      # getWorld2View (graphics_utils.py:39-50 without the translate / scale detour)
+    Rt[:3, :3] = R.transpose()
+    Rt[:3, 3] = T
+    Rt[3, 3] = 1.0
+    wv = torch.tensor(Rt).transpose(0, 1).contiguous()
+    pj = projection_matrix(znear, zfar, fov_x, fov_y).transpose(0, 1).contiguous()
+    pj[2, 0] = -float(cx_ndc)
+    pj[2, 1] = -float(cy_ndc)
+    full = wv.unsqueeze(0).bmm(pj.unsqueeze(0)).squeeze(0).contiguous()
+    center = torch.tensor(c2w[:3, 3].copy())      # p3d_camera.get_camera_center()
+    return Camera(int(width), int(height), float(fov_x), float(fov_y), wv, pj, full, center, name, znear, zfar,
+                  wv.inverse().contiguous())
+
+
+def sugar_orbit_cameras(num_views: int, width: int, height: int, cx_ndc: float = 0.037, cy_ndc: float = -0.021,
+                        fovx_deg: float = 60.0, radius: float = 4.0, theta_deg: float = 30.0) -> List[Camera]:
+    """The orbit of ``orbit_cameras`` as SuGaR would render it: poses converted to nerfstudio's OpenGL axes and pushed
+    through ``sugar_camera`` with an off-centre principal point (a calibrated COLMAP camera is never exactly centred)."""
+    fovx = math.radians(fovx_deg)
+    fovy = focal2fov(fov2focal(fovx, width), height)
+    out = []
+    for i, c2w in enumerate(orbit_c2w(radius, num_views, theta_deg)):
+        gl = np.array(c2w, dtype=np.float64)
+        gl[:3, 1:3] *= -1                         # OpenCV -> OpenGL: what a nerfstudio transform_matrix holds
+        out.append(sugar_camera(gl, fovx, fovy, width, height, cx_ndc, cy_ndc, "{0:05d}".format(i)))
+    return out
+
+
 def _unit(v: np.ndarray, eps: float = 1e-10) -> np.ndarray:
     return v / (np.linalg.norm(v) + eps)
 

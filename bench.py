@@ -65,8 +65,8 @@ WORKLOADS = {
                   cfg="config_heavy", width=960, height=540, frames=200),
     "heavy1080": dict(name="heavy at 1920x1080 (stress workload, not a BASELINE config)",
                       cfg="config_heavy", width=1920, height=1080, frames=200),
-    "c4": dict(name="C4: 200k flat SuGaR-style Gaussians, colors_precomp, RGB + normal + depth in one fused call, "
-                    "960x540, 50-frame orbit (BASELINE configs[3])",
+    "c4": dict(name="C4: 200k flat SuGaR-style Gaussians, colors_precomp, SuGaR's off-centre principal-point projection, "
+                    "RGB + normal + depth in one fused call, 960x540, 50-frame orbit (BASELINE configs[3])",
                cfg="config_c4", width=960, height=540, frames=50),
     "c5": dict(name="C5: C2 frames -> RGBA8 -> composite with synthetic Blender layers (object, shadow catcher, 3DGS "
                     "object, smoke + fire), 960x540, 400 frames (BASELINE configs[4])",
@@ -107,7 +107,11 @@ class Bench:
         cfg = getattr(scenes, wl["cfg"])
         self.cloud_cpu = cfg(P=gaussians) if gaussians else cfg()
         self.cloud = self.cloud_cpu.to(device)
-        self.cams_cpu = orbit_cameras(self.F, self.W, self.H)
+        if key == "c4":   # SuGaR's camera: projection matrix with the principal-point terms (sugar_model.py:2029-2030)
+            from autovfx_amd.cameras import sugar_orbit_cameras
+            self.cams_cpu = sugar_orbit_cameras(self.F, self.W, self.H)
+        else:
+            self.cams_cpu = orbit_cameras(self.F, self.W, self.H)
         self._cams = {}
         self.bg = torch.zeros(3, dtype=torch.float32, device=device)
         self.P = self.cloud.P

@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from autovfx_amd import scenes  # noqa: E402
-from autovfx_amd.cameras import orbit_cameras  # noqa: E402
+from autovfx_amd.cameras import orbit_cameras, sugar_orbit_cameras  # noqa: E402
 from oracle import ref_oracle  # noqa: E402
 from helpers import oracle_kwargs  # noqa: E402
 
@@ -52,6 +52,11 @@ def cases():
     c.means3D[:, 2] = 0.0      # one depth plane: order decided by the tie rule
     c.scales[:30] *= 25.0      # some screen-filling splats
     yield "ties_and_big_splats_64x64", oracle_kwargs(c, scenes.c1_camera(64, 64))
+    # BASELINE configs[3]: SuGaR's call shape -- flat surface-bound Gaussians, colors_precomp, and the projection matrix
+    # with the off-centre principal-point terms of sugar_model.py:2029-2030
+    c = scenes.config_c4(P=4000, seed=170)
+    yield "c4_sugar_principal_point_120x68", oracle_kwargs(c, sugar_orbit_cameras(12, 120, 68, cx_ndc=0.11, cy_ndc=-0.07)[4],
+                                                           bg=(0.0, 0.0, 0.0))
 
 
 def backward_cases():
@@ -74,10 +79,16 @@ def backward_cases():
     c.scales[:20] *= 20.0
     kw = oracle_kwargs(c, cam, scale_modifier=1.3, sh_degree=1, bg=(0.5, 0.5, 0.5)); kw.update(grads(cam, 3))
     yield "bw_sh1_big_splats_33x17", kw
+    cam = sugar_orbit_cameras(12, 60, 34, cx_ndc=0.11, cy_ndc=-0.07)[7]
+    kw = oracle_kwargs(scenes.config_c4(P=1200, seed=204), cam, bg=(0.0, 0.0, 0.0)); kw.update(grads(cam, 4))
+    yield "bw_c4_sugar_principal_point_60x34", kw
 
 
 def main():
+    only = sys.argv[1:]   # optional: regenerate just the named fixtures
     for name, kw in backward_cases():
+        if only and name not in only:
+            continue
         out = ref_oracle.backward(**kw)
         inputs = {"in_" + k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v))
                   for k, v in kw.items() if v is not None}
@@ -86,6 +97,8 @@ def main():
         np.savez_compressed(path, **inputs, **outputs)
         print(f"{name}: P={kw['means3D'].shape[0]} D={out['num_rendered']} -> {os.path.getsize(path) / 1024:.0f} KiB")
     for name, kw in cases():
+        if only and name not in only:
+            continue
         out = ref_oracle.forward(intermediates=True, **kw)
         inputs = {"in_" + k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v))
                   for k, v in kw.items() if v is not None}

@@ -13,7 +13,7 @@ import pytest
 from oracle import cpu_oracle
 
 GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz"))
-                if not os.path.basename(p).startswith("bw_"))
+                if not os.path.basename(p).startswith(("bw_", "ply_")))
 
 
 def load_case(path):

@@ -106,3 +106,39 @@ def test_slab_policy_is_host_logic():
         _lib.set_option(_lib.OPT_SLABS, 2)
         _lib.set_option(_lib.OPT_SLAB_FIRST, 400)
         _lib.set_option(_lib.OPT_SLAB_MIN_REST, 3_000_000)
+
+
+def test_sugar_camera_mirrors_the_reference_call_site():
+    """autovfx_amd.cameras.sugar_camera against a line-by-line transcription of sugar_model.py:2008-2032 with the reference's
+    own getWorld2View / getProjectionMatrix formulas (graphics_utils.py:39-72) written out in numpy."""
+    import math
+    import numpy as np
+    import torch
+    from autovfx_amd.cameras import orbit_c2w, sugar_camera, orbit_cameras, sugar_orbit_cameras
+    W, H, fovx = 320, 180, math.radians(60.0)
+    fovy = 2 * math.atan(math.tan(fovx / 2) * H / W)
+    gl = np.array(orbit_c2w(4.0, 8)[3])
+    gl[:3, 1:3] *= -1                                   # a nerfstudio pose: OpenGL axes
+    cx, cy, zn, zf = 0.09, -0.05, 0.01, 100.0
+    cam = sugar_camera(gl[:3], fovx, fovy, W, H, cx, cy)
+    # --- transcription of the call site ---
+    c2w = np.concatenate((gl[:3].astype(np.float32), np.array([[0, 0, 0, 1]], np.float32)), 0)
+    c2w[:3, 1:3] *= -1
+    w2c = np.linalg.inv(c2w)
+    R, T = np.transpose(w2c[:3, :3]), w2c[:3, 3]
+    Rt = np.zeros((4, 4)); Rt[:3, :3] = R.transpose(); Rt[:3, 3] = T; Rt[3, 3] = 1.0
+    wv = torch.Tensor(np.float32(Rt)).transpose(0, 1)
+    tH, tW = math.tan(fovy / 2), math.tan(fovx / 2)
+    top, right = tH * zn, tW * zn
+    P = torch.zeros(4, 4)
+    P[0, 0] = 2.0 * zn / (right + right); P[1, 1] = 2.0 * zn / (top + top)
+    P[0, 2] = 0.0; P[1, 2] = 0.0; P[3, 2] = 1.0; P[2, 2] = 1.0 * zf / (zf - zn); P[2, 3] = -(zf * zn) / (zf - zn)
+    proj = P.transpose(0, 1).clone()
+    proj[2, 0] = -cx; proj[2, 1] = -cy
+    full = wv.unsqueeze(0).bmm(proj.unsqueeze(0)).squeeze(0)
+    assert torch.equal(cam.world_view_transform, wv) and torch.equal(cam.full_proj_transform, full)
+    assert torch.allclose(cam.camera_center, torch.tensor(gl[:3, 3], dtype=torch.float32))
+    # a centred principal point is the vanilla GSCamera
+    a, b = sugar_orbit_cameras(8, W, H, 0.0, 0.0)[3], orbit_cameras(8, W, H)[3]
+    assert torch.allclose(a.full_proj_transform, b.full_proj_transform, atol=1e-6)
+    assert cam.tanfovx == b.tanfovx

@@ -10,7 +10,7 @@ import torch
 from hypothesis import HealthCheck, given, settings, strategies as st
 
 from autovfx_amd import scenes
-from autovfx_amd.cameras import orbit_cameras
+from autovfx_amd.cameras import orbit_cameras, sugar_orbit_cameras
 from oracle import cpu_oracle, ref_oracle
 
 from helpers import oracle_kwargs
@@ -34,6 +34,17 @@ def test_orbit_cloud_and_precomputed_colours():
     cam = orbit_cameras(16, 240, 135)[5]
     both(oracle_kwargs(scenes.config_c2(P=20_000, seed=3), cam), "c2-20k")
     both(oracle_kwargs(scenes.config_c4(P=8_000, seed=4), cam, bg=(1, 1, 1)), "c4-8k")
+
+
+def test_c4_sugar_camera_with_off_centre_principal_point():
+    """BASELINE configs[3]: the projection matrix SuGaR builds (sugar_model.py:2023-2032) through the reference's own
+    kernels and the oracle, forward and backward."""
+    from test_oracle_backward import assert_bits, pixel_grads
+    cam = sugar_orbit_cameras(12, 200, 112, cx_ndc=0.09, cy_ndc=-0.05)[5]
+    kw = oracle_kwargs(scenes.config_c4(P=12_000, seed=9), cam)
+    both(kw, "c4-sugar-pp")
+    kw.update(pixel_grads(cam, 11))
+    assert_bits(cpu_oracle.backward(**kw), ref_oracle.backward(**kw), "c4-sugar-pp-bw")
 
 
 def test_mark_visible_matches_reference():

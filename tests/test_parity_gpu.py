@@ -183,6 +183,45 @@ def test_colors_precomp_flat_gaussians():
     run_both("c4_precomp", cloud, cam, bg=(1.0, 1.0, 1.0))
 
 
+def test_c4_sugar_camera_with_off_centre_principal_point():
+    """BASELINE configs[3] as SuGaR actually calls the rasterizer (sugar_model.py:2008-2032, 2141-2183): flat
+    surface-bound Gaussians, ``colors_precomp``, and a projection matrix that carries the principal point
+    (``proj_transform[2, 0] = -K[0, 2]``, ``[2, 1] = -K[1, 2]``) while viewmatrix and tanfov stay those of the centred
+    camera.  Every stage bit-exact like the other cases; then RGB + normal in one fused call (gsr_forward_extra) against
+    SuGaR's two passes, bit for bit."""
+    from autovfx_amd.cameras import sugar_orbit_cameras
+    from diff_gaussian_rasterization import _C
+    cloud = scenes.config_c4(P=20000)
+    cam = sugar_orbit_cameras(8, 320, 180, cx_ndc=0.09, cy_ndc=-0.05)[3]
+    centred = sugar_orbit_cameras(8, 320, 180, cx_ndc=0.0, cy_ndc=0.0)[3]
+    hip, ref = run_both("c4_sugar_pp", cloud, cam, bg=(0.0, 0.0, 0.0))
+    # the principal point moves every pixel centre by (cx * W / 2, cy * H / 2) pixels and nothing else per Gaussian
+    base = cpu_oracle.forward(intermediates=True, **oracle_kwargs(cloud, centred))
+    vis = (ref["radii"] > 0) & (base["radii"] > 0)
+    shift = ref["means2D"][vis] - base["means2D"][vis]
+    assert np.abs(shift[:, 0] - (-0.09) * 160).max() < 2e-3 and np.abs(shift[:, 1] - 0.05 * 90).max() < 2e-3
+    np.testing.assert_array_equal(ref["conic_opacity"][vis], base["conic_opacity"][vis])
+    dev = "cuda:0"
+    c = cloud.to(dev)
+    st = settings_for(cam, dev, (0.0, 0.0, 0.0), 1.0, 0)
+    e = torch.Tensor([])
+    normals = torch.nn.functional.normalize(c.means3D, dim=1) * 0.5 + 0.5
+    args = lambda colors: (st.bg, c.means3D, colors, c.opacities, c.scales, c.rotations, 1.0, e, st.viewmatrix, st.projmatrix,
+                           st.tanfovx, st.tanfovy, st.image_height, st.image_width, e, 0, st.campos, False, False)
+    _C.set_geometry_cache(False)
+    try:
+        fused = _C.rasterize_gaussians_extra(*args(c.colors_precomp), normals, inference=True)
+        rgb_pass = _C.rasterize_gaussians(*args(c.colors_precomp))
+        normal_pass = _C.rasterize_gaussians(*args(normals))
+    finally:
+        _C.set_geometry_cache(True)
+    torch.cuda.synchronize()
+    for i in (1, 2, 3, 4):
+        assert torch.equal(fused[i], rgb_pass[i]), i
+    assert torch.equal(fused[8], normal_pass[1])
+    np.testing.assert_array_equal(rgb_pass[1].cpu().numpy(), hip["color"])
+
+
 def test_cov3d_precomp_matches_scale_rot_path():
     cloud = scenes.config_c1(P=4000, seed=21)
     cam = scenes.c1_camera(160, 160)

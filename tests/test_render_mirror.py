@@ -57,6 +57,45 @@ def test_ascii_ply_is_read_too(tmp_path):
     assert names == ["x", "y", "z"] and table.tolist() == [[1, 2, 3], [4, 5, 6]]
 
 
+@needs_reference
+def test_ply_written_here_is_read_by_the_reference_load_ply_and_vice_versa(tmp_path):
+    """f3 pin: the REFERENCE's own ``load_ply`` (scene/gaussian_model.py:229-266), unchanged, reads
+    a file written by ``autovfx_amd.gaussian_model.save_ply`` into the same six tensors; the reference's ``save_ply``
+    (:201-221) writes, from those, a file that is byte-identical to ours and that our ``load_ply`` reads back."""
+    import ref_plyfile_stub as stub
+    ref = stub.reference_gaussian_model()
+    m, _ = model(300, seed=5)
+    m._rotation = m._rotation + 0.01 * torch.randn(300, 4, generator=torch.Generator().manual_seed(1))   # raw, un-normalised
+    ours = str(tmp_path / "ours" / "point_cloud.ply")
+    m.save_ply(ours)
+    r = ref.GaussianModel(3)
+    with stub.on_cpu():
+        r.load_ply(ours)
+    assert r.active_sh_degree == 3
+    for k in stub.FIELDS:
+        assert torch.equal(getattr(m, k), getattr(r, k).detach()), k
+    theirs = str(tmp_path / "theirs" / "point_cloud.ply")
+    r.save_ply(theirs)
+    assert open(theirs, "rb").read() == open(ours, "rb").read()
+    back = gm.GaussianModel(3).load_ply(theirs)
+    for k in stub.FIELDS:
+        assert torch.equal(getattr(m, k), getattr(back, k)), k
+
+
+def test_ply_golden_file_written_by_the_reference(tmp_path):
+    """The same pin where the reference tree does not exist (the GPU box): tests/golden/ply_ref_point_cloud_40.ply was written
+    by the reference's save_ply and ply_ref_point_cloud_40.npz holds what its load_ply read back
+    (tests/golden/make_ply_golden.py)."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    want = np.load(os.path.join(here, "ply_ref_point_cloud_40.npz"))
+    got = gm.GaussianModel(3).load_ply(os.path.join(here, "ply_ref_point_cloud_40.ply"))
+    for k in want.files:
+        np.testing.assert_array_equal(getattr(got, k).numpy(), want[k], err_msg=k)
+    again = str(tmp_path / "again.ply")
+    got.save_ply(again)
+    assert open(again, "rb").read() == open(os.path.join(here, "ply_ref_point_cloud_40.ply"), "rb").read()
+
+
 def _import_reference(name):
     """Import a reference module with the packages it needs at import time stubbed out."""
     for missing in ("kornia", "plyfile", "simple_knn", "simple_knn._C", "trimesh", "cv2", "open3d"):
