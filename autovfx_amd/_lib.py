@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GSR_LIB", os.path.join(_HERE, "lib", "libgsr_hip.so")
 ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 
 # enum mirrors of include/gsr.h
-GEOM_SLOTS = ("raster", "rgb", "splat_bins", "internal_radii", "depth_order", "point_offsets")
+GEOM_SLOTS = ("raster", "rgb", "splat_bins", "internal_radii", "depth_order", "point_offsets", "listed")
 BIN_SLOTS = ("point_list", "tile_keys")
 IMG_SLOTS = ("ranges", "n_contrib")
 STAGES = ("preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "ranges", "blend", "colour")
@@ -28,7 +28,7 @@ SYMBOLS = ("gsr_forward", "gsr_mark_visible", "gsr_backward", "gsr_last_geom_off
            "gsr_last_image_offsets", "gsr_set_stage_timing", "gsr_get_stage_times", "gsr_last_error",
            "gsr_abi_version", "gsr_target_arch", "gsr_set_option", "gsr_get_option", "gsr_pack_rgba8", "gsr_last_pair_counts", "gsr_blend", "gsr_composite",
            "gsr_radix_scratch_bytes", "gsr_radix_sort_pairs", "gsr_selftest_exp", "gsr_view_normals", "gsr_normal_maps", "gsr_forward_extra", "gsr_get_call_times",
-           "gsr_forward_begin", "gsr_forward_finish", "gsr_forward_ready", "gsr_forward_cancel", "gsr_last_slab_pairs", "gsr_plan_slabs", "gsr_selftest_lds_atomic_order")
+           "gsr_forward_begin", "gsr_forward_finish", "gsr_forward_ready", "gsr_forward_cancel", "gsr_last_slab_pairs", "gsr_plan_slabs", "gsr_selftest_lds_atomic_order", "gsr_get_backward_times")
 OPT_TILE_CULL = 0
 OPT_SLABS = 1
 OPT_SLAB_FIRST = 2
@@ -123,6 +123,8 @@ def _load() -> ctypes.CDLL:
     lib.gsr_set_stage_timing.argtypes = [ctypes.c_int]
     lib.gsr_get_call_times.restype = ctypes.c_int
     lib.gsr_get_call_times.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int]
+    lib.gsr_get_backward_times.restype = ctypes.c_int
+    lib.gsr_get_backward_times.argtypes = [ctypes.POINTER(ctypes.c_float * 2)]
     lib.gsr_get_stage_times.restype = ctypes.c_int
     lib.gsr_get_stage_times.argtypes = [ctypes.POINTER(ctypes.c_float * len(STAGES))]
     lib.gsr_last_error.restype = ctypes.c_char_p
@@ -198,6 +200,15 @@ def call_times_ms(capacity: int = 256) -> list:
     if n < 0:
         raise RuntimeError(last_error())
     return [float(arr[i]) for i in range(n)]
+
+
+def backward_times_ms() -> dict:
+    """Mean milliseconds of gsr_backward's two kernels over the calls since ``set_stage_timing(True)`` (process-wide)."""
+    arr = (ctypes.c_float * 2)()
+    n = lib.gsr_get_backward_times(ctypes.byref(arr))
+    if n < 0:
+        raise RuntimeError(last_error())
+    return {"render_backward": float(arr[0]), "preprocess_backward": float(arr[1]), "calls": int(n)}
 
 
 def stage_times_ms() -> dict:

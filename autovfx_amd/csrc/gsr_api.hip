@@ -61,6 +61,13 @@ thread_local int g_inflight = 0;       // timed calls begun and not yet finished
 thread_local bool g_stamp = false;     // whether the call being queued records events
 thread_local int g_slot = 0;           // ring slot of the call being queued
 
+// Backward timing: process-wide (autograd calls gsr_backward from its own thread), guarded by a mutex.
+constexpr int kBackwardRing = 64;
+std::mutex g_bw_mutex;
+hipEvent_t g_bw_ev[kBackwardRing][3];
+bool g_bw_made = false;
+long g_bw_calls = 0;
+
 int fail(gsr_status code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -178,6 +185,10 @@ int gsr_get_option(int option) {
 }
 
 void gsr_set_stage_timing(int enable) {
+    {
+        std::lock_guard<std::mutex> lock(g_bw_mutex);
+        g_bw_calls = 0;
+    }
     g_timing = enable != 0;
     g_timing_epoch.fetch_add(1);   // other threads drop their records when they next begin a call
     g_epoch_seen = g_timing_epoch.load();
@@ -245,6 +256,26 @@ int gsr_get_call_times(float* ms, int capacity) {
         GSR_HIP(hipEventElapsedTime(&ms[c], g_ev[slot][0], g_ev[slot][last]));
     }
     return ncalls;
+}
+
+int gsr_get_backward_times(float ms[2]) {
+    ms[0] = ms[1] = 0.f;
+    std::lock_guard<std::mutex> lock(g_bw_mutex);
+    const int n = (int)(g_bw_calls < kBackwardRing ? g_bw_calls : kBackwardRing);
+    if (n <= 0) return 0;
+    double sum[2] = {0, 0};
+    for (int c = 0; c < n; ++c) {
+        const int slot = (int)((g_bw_calls - 1 - c) % kBackwardRing);
+        GSR_HIP(hipEventSynchronize(g_bw_ev[slot][2]));
+        for (int i = 0; i < 2; ++i) {
+            float t = 0.f;
+            GSR_HIP(hipEventElapsedTime(&t, g_bw_ev[slot][i], g_bw_ev[slot][i + 1]));
+            sum[i] += t;
+        }
+    }
+    ms[0] = (float)(sum[0] / n);
+    ms[1] = (float)(sum[1] / n);
+    return n;
 }
 
 int gsr_last_geom_offsets(size_t o[GSR_GEOM_NUM_SLOTS]) {
@@ -347,10 +378,22 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     const uint32_t* n_contrib = (const uint32_t*)(bases[2] + h[2].off[1]);
     const float* colors = colors_precomp != nullptr ? colors_precomp : rgb;  // rasterizer_impl.cu:399
 
+    int bw_slot = -1;
+    if (g_timing) {
+        std::lock_guard<std::mutex> lock(g_bw_mutex);
+        if (!g_bw_made) {
+            for (auto& set : g_bw_ev)
+                for (auto& e : set) GSR_HIP(hipEventCreate(&e));
+            g_bw_made = true;
+        }
+        bw_slot = (int)(g_bw_calls % kBackwardRing);
+        GSR_HIP(hipEventRecord(g_bw_ev[bw_slot][0], stream));
+    }
     GSR_HIP(hipMemsetAsync(accum_scratch, 0, (size_t)P * 16 * sizeof(float), stream));
     GSR_HIP(gsr::launch_render_backward(cam, ranges, point_list, background, raster, colors, accum_alphas, n_contrib,
                                         dL_dpix, dL_dpix_depth, dL_dpix_alpha, accum_scratch, stream));
     GSR_STAGE_CHECK("render_backward");
+    if (bw_slot >= 0) GSR_HIP(hipEventRecord(g_bw_ev[bw_slot][1], stream));
     gsr::BackwardInputs b;
     b.P = P; b.sh_degree = D; b.M = M; b.means3D = means3D; b.radii = radii; b.shs = shs; b.scales = scales;
     b.rotations = rotations; b.cov3D_precomp = cov3D_precomp; b.scale_modifier = scale_modifier;
@@ -359,6 +402,11 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     b.dL_dmean3D = dL_dmean3D; b.dL_dcov3D = dL_dcov3D; b.dL_dsh = dL_dsh; b.dL_dscale = dL_dscale; b.dL_drot = dL_drot;
     GSR_HIP(gsr::launch_preprocess_backward(b, cam, stream));
     GSR_STAGE_CHECK("preprocess_backward");
+    if (bw_slot >= 0) {
+        GSR_HIP(hipEventRecord(g_bw_ev[bw_slot][2], stream));
+        std::lock_guard<std::mutex> lock(g_bw_mutex);
+        ++g_bw_calls;   // (concurrent backward calls on several threads would share slots: timing is a single-caller aid)
+    }
     return GSR_OK;
 }
 
@@ -719,6 +767,7 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     GSR_STAGE_CHECK("depth_sort");
     stamp(2, stream);
     geom_off[GSR_GEOM_DEPTH_ORDER] = (size_t)((char*)fc.order - gbase);
+    geom_off[GSR_GEOM_LISTED] = fc.defer_colour ? fc.off_listed : 0;
     return 0;
 }
 
@@ -888,6 +937,7 @@ int forward_finish(ForwardCall& fc) {
 
     // what the gsr_last_* accessors report: the call that finished last on this thread
     for (int i = 0; i < GSR_GEOM_NUM_SLOTS; ++i) g_geom_off[i] = fc.geom_off[i] + fc.gshift;
+    if (!(fc.defer_colour && S > 1)) g_geom_off[GSR_GEOM_LISTED] = 0;   // (single-slab calls colour every emitting splat)
     memcpy(g_img_off, fc.img_off, sizeof g_img_off);
     g_bin_off[GSR_BIN_POINT_LIST] = (size_t)((char*)list_of[0] - braw);
     g_bin_off[GSR_BIN_TILE_KEYS] = (size_t)((char*)tile_keys_sorted - braw);

@@ -98,8 +98,10 @@ class GaussianModel:
     def invalidate_cache(self) -> None:
         self.__dict__.pop("_memo_cache", None)
 
+    memoise = True   # False: every getter recomputes on every call, as the reference's getters do (bench.py times that shape)
+
     def _memo(self, name, deps, fn):
-        if torch.is_grad_enabled() and any(t.requires_grad for t in deps):
+        if not self.memoise or (torch.is_grad_enabled() and any(t.requires_grad for t in deps)):
             return fn()
         versions = tuple((t._version, t.data_ptr(), tuple(t.shape)) for t in deps)
         cache = self.__dict__.setdefault("_memo_cache", {})

@@ -33,6 +33,12 @@ class PipelineParams:
     debug = False
 
 
+# False: render() keeps the reference's structure even without autograd -- ~40 PyTorch launches around two rasterizer calls
+# (gaussian_renderer/__init__.py:118-208) -- instead of the two fused kernels and the folded normal pass.  bench.py times
+# that shape next to the default; results are the same images.
+FUSE_ELEMENTWISE = True
+
+
 def _stream_ptr(device):
     import ctypes
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
@@ -185,7 +191,7 @@ def _render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_col
     # With autograd off and the data on the GPU, the elementwise work around the passes runs as two fused kernels
     # (gsr_view_normals / gsr_normal_maps) instead of ~40 PyTorch launches, and the normal pass is folded into the
     # first one (gsr_forward_extra); same formulas, same images (tests).
-    fused = (not torch.is_grad_enabled()) and xyz.is_cuda and xyz.dtype == torch.float32 and hasattr(pc, "get_minimum_axis")
+    fused = FUSE_ELEMENTWISE and (not torch.is_grad_enabled()) and xyz.is_cuda and xyz.dtype == torch.float32 and hasattr(pc, "get_minimum_axis")
     dir_pp_normalized = None
     if not fused or (override_color is None and pipe.convert_SHs_python):
         dir_pp = xyz - viewpoint_camera.camera_center.repeat(xyz.shape[0], 1)

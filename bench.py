@@ -92,6 +92,47 @@ def algorithmic_bytes(P, V, D, T, W, H, M=16):
     return st
 
 
+def design_bytes(u, inference=True, deferred=True):
+    """What THIS library's stages have to move per frame at the least ("design bytes"): per-unit
+    figures of its own data layout x the measured units of the frame.  u: P Gaussians, V visible (radii > 0), E emitting
+    (a non-empty tight rectangle), pairs = expanded pairs per depth slab, L = Gaussians whose colour is evaluated, T tiles,
+    W x H pixels, M SH coefficients.  Lower bounds: the re-scan of a later slab and the parking of unfinished pixels between
+    two blend launches are left out."""
+    P, V, E, L, T, W, H, M = u["P"], u["V"], u["E"], u["L"], u["T"], u["W"], u["H"], u["M"]
+    pairs, S = float(sum(u["pairs"])), max(1, len(u["pairs"]))
+    sh = (12 * M + 12) if M else 12                        # SH record (or precomputed colour) read + xyz / nothing
+    st = {
+        # xyz 12 r; radii 4, splat record 16, depth key 4, listed byte 1 w | scale 12 + quat 16 + opacity 4 r, raster record 32 w
+        "preprocess": 37 * P + 64 * V + (0 if (inference and deferred and M) else (sh + 12) * V),
+        # 4 passes: histogram reads 4; scatter reads key (+ payload past the first pass), writes payload (+ key before the last)
+        "depth_sort": 72 * P,
+        "scan": 0,
+        # gather: order 4 + record 16 r, record 16 + offset 4 w per emitter; offsets r/w 8 per Gaussian; expansion: offset 4 +
+        # record 16 + id 4 r per emitter, key 4 + id 4 w per pair
+        "duplicate": 64 * E + 8 * P + 8 * pairs,
+        "tile_sort": 40 * pairs,                           # 2 passes x (4 histogram + 8 r + 8 w)
+        "ranges": 8 * T * S,
+        # SH 12 M + xyz 12 r, colour 12 w per evaluated Gaussian; the listed bytes once per launch
+        "colour": ((12 * M + 24) * L + P * S) if (inference and deferred and M) else 0,
+        # list entry 4 r per pair; raster 32 + colour 12 r once per listed Gaussian; colour 12 + depth 4 + alpha 4 + n_contrib 4 w
+        "blend": 4 * pairs + 44 * L + 24 * W * H,
+    }
+    st["frame"] = sum(st.values())
+    return st
+
+
+# kernels of each stage (names as rocprofv3 prints them, namespaces stripped) for the counter traffic per stage
+STAGE_KERNELS = {
+    "preprocess": ("preprocess_kernel",),
+    "depth_sort": (),   # split by call index below: the first 4 passes of a frame are the depth sort
+    "duplicate": ("bin_gather_kernel", "bin_offsets_kernel", "slab_bounds_kernel", "slab_recount_kernel", "slab_compact_kernel", "expand_kernel"),
+    "tile_sort": (),
+    "ranges": ("tile_ranges_kernel",),
+    "colour": ("sh_colour_listed_kernel", "sh_colour_all_kernel"),
+    "blend": ("blend_quadrant_kernel",),
+}
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # one workload on this rank's GPU
 # ---------------------------------------------------------------------------------------------------------------------
@@ -204,23 +245,59 @@ class Bench:
             for st in side:
                 torch.cuda.current_stream(self.device).wait_stream(st)
 
-    def stats(self, frames):
-        """(mean visible, mean num_rendered) over `frames` (untimed)."""
+    def units(self, frames):
+        """Mean per-frame units of `frames` (untimed inference calls, scratch decoded): V visible (radii > 0), D the
+        reference's num_rendered, E emitting splats, L Gaussians whose colour is evaluated, pairs expanded per depth slab."""
         from diff_gaussian_rasterization import _C
-        Vs, Ds = [], []
+        acc = {"V": [], "D": [], "E": [], "L": []}
+        pairs = []
         e = torch.Tensor([])
         c = self.cloud
+        _C.set_geometry_cache(False)
+        try:
+            with torch.no_grad():
+                for f in frames:
+                    cam = self.cam(f)
+                    n, _c, _d, _a, radii, geom, *_ = _C.rasterize_gaussians(
+                        self.bg, c.means3D, e if c.colors_precomp is None else c.colors_precomp, c.opacities, c.scales,
+                        c.rotations, 1.0, e, cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy,
+                        self.H, self.W, e if c.shs is None else c.shs, c.sh_degree, cam.camera_center, False, False,
+                        inference=True)
+                    lay = _C.last_layout()
+                    g = lay["geom"]
+                    bins = geom[g["splat_bins"]:g["splat_bins"] + 16 * self.P].view(torch.int32).view(-1, 4)
+                    E = int((bins[:, 1] != 0).sum().item())
+                    L = E
+                    if g.get("listed", 0):
+                        L = int((geom[g["listed"]:g["listed"] + self.P] != 0).sum().item())
+                    acc["D"].append(int(n)); acc["V"].append(int((radii > 0).sum().item())); acc["E"].append(E); acc["L"].append(L)
+                    pairs.append(list(lay["slab_pairs"]))
+        finally:
+            _C.set_geometry_cache(True)
+        S = max(len(p) for p in pairs)
+        mean_pairs = [float(np.mean([p[k] if k < len(p) else 0 for p in pairs])) for k in range(S)]
+        out = {k: float(np.mean(v)) for k, v in acc.items()}
+        out.update(P=self.P, T=self.T, W=self.W, H=self.H, M=self.M, pairs=mean_pairs)
+        return out
+
+    def stats(self, frames):
+        u = self.units(frames)
+        return u["V"], u["D"]
+
+    def run_blocking(self, frames, rgba):
+        """The loop an unmodified caller runs (scene_representation.py:355-424): one frame at a time on the current stream,
+        each a blocking ``GaussianRasterizer.forward`` (or the whole ``render()``), nothing in flight beside it."""
+        from autovfx_amd.frame_parallel import rasterize
         with torch.no_grad():
-            for f in frames:
+            for j, f in enumerate(frames):
                 cam = self.cam(f)
-                n, _c, _d, _a, radii, *_ = _C.rasterize_gaussians(
-                    self.bg, c.means3D, e if c.colors_precomp is None else c.colors_precomp, c.opacities, c.scales,
-                    c.rotations, 1.0, e, cam.world_view_transform, cam.full_proj_transform, cam.tanfovx, cam.tanfovy,
-                    self.H, self.W, e if c.shs is None else c.shs, c.sh_degree, cam.camera_center, False, False,
-                    inference=True)
-                Ds.append(int(n))
-                Vs.append(int((radii > 0).sum().item()))
-        return float(np.mean(Vs)), float(np.mean(Ds))
+                if self.boundary == "render":
+                    from autovfx_amd import renderer
+                    out = renderer.render(cam, self.model, renderer.PipelineParams, self.bg)
+                    res = (out["render"][:3], out["depth"][None], out["render"][3:4], out["radii"])
+                else:
+                    res = rasterize(self.cloud, cam, self.bg)
+                self.consume(j % rgba.shape[0], res, rgba)
 
 
 def synthetic_blender_layers(W, H, device, seed=11):
@@ -485,38 +562,78 @@ def main():
     fps = lambda s: total_frames / s
     ms_per_step = med / K * 1e3
 
-    # ---- per-frame workload statistics (untimed): V and D of this rank's timed frames ----
-    V, D = b.stats(timed_frames[::max(1, K // 8)])
+    # ---- the caller's own loop: one blocking GaussianRasterizer.forward (or render()) per frame, one stream ----
+    serial = None
+    if world == 1 and not distributed and not strong and b.extra is None and b.layers is None:
+        Ks = min(K, 100)
+        with torch.no_grad():
+            b.run_blocking(timed_frames[:min(Ks, 8)], rgba)
+            ssecs = timed_regions(lambda: b.run_blocking(timed_frames[:Ks], rgba), min(R, 3), False, device)
+        smed = sorted(ssecs)[len(ssecs) // 2]
+        serial = {"value": round(Ks / smed, 2), "unit": "frames/s", "ms_per_step": round(smed / Ks * 1e3, 4), "steps": Ks,
+                  "regions": [round(Ks / x, 2) for x in ssecs], "streams": 1,
+                  "what": "what an unmodified caller gets (scene_representation.py:355-424): frames one at a time on the "
+                          "current stream, each a blocking " + ("render()" if args.boundary == "render" else "GaussianRasterizer.forward")
+                          + " + RGBA8 pack; host wall clock between synchronize()s, like `value`"}
+
+    # ---- per-frame workload statistics (untimed): the units of this rank's timed frames ----
+    units = b.units(timed_frames[::max(1, K // 8)])
+    V, D = units["V"], units["D"]
     alg = algorithmic_bytes(P, V, D, T, W, H, M)
+    design = design_bytes(units, inference=True, deferred=_lib.get_option(_lib.OPT_DEFER_COLOUR) != 0)
 
     calls = stage_ms.pop("calls")
-    stage_alg = {"preprocess": alg["preprocess"], "depth_sort": 0, "scan": alg["scan"], "duplicate": alg["duplicate"],
-                 "tile_sort": alg["sort"], "ranges": alg["ranges"], "blend": alg["blend"], "colour": 0}
-    stages = {k: {"ms": round(v, 4), "alg_bytes": int(stage_alg[k]),
-                  "alg_GBps": round(stage_alg[k] / (v * 1e-3) / 1e9, 1) if v > 0 else None}
-              for k, v in stage_ms.items()}
+    traffic = pmc_traffic(T_key=args.workload if not args.gaussians else None)
+    counter = stage_counter_bytes(traffic)
+    # Per stage: this library's design bytes (design_bytes above: what its own layout has to move, measured units) and the
+    # HBM bytes the counters saw (profiles/, per stage) over the stage's time.  Both are <= what the hardware can move; the
+    # reference formula's bytes are NOT credited per stage -- the stages are not the reference's -- only
+    # for the frame (`frac_equiv`) and for the dominant kernel, as the contract asks.
+    stages = {}
+    for k, v in stage_ms.items():
+        ent = {"ms": round(v, 4), "design_bytes": int(design.get(k, 0)),
+               "design_GBps": round(design.get(k, 0) / (v * 1e-3) / 1e9, 1) if v > 0 else None}
+        if counter is not None and k in counter:
+            ent["counter_bytes"] = int(counter[k])
+            ent["counter_GBps"] = round(counter[k] / (v * 1e-3) / 1e9, 1) if v > 0 else None
+            ent["frac_of_hbm_peak"] = round(counter[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if v > 0 else None
+        stages[k] = ent
     # the dominant kernel of the frame is the blend; an inference call launches it once per depth slab, so "per launch"
     # figures are the frame's blend figures divided by the launches of a frame (what rocprofv3's per-kernel average is)
+    stage_alg = {"preprocess": alg["preprocess"], "depth_sort": 0, "scan": alg["scan"], "duplicate": alg["duplicate"],
+                 "tile_sort": alg["sort"], "ranges": alg["ranges"], "blend": alg["blend"], "colour": 0}
     dom = max(stage_ms, key=stage_ms.get)
     kernel_of = {"blend": "blend_quadrant_kernel", "preprocess": "preprocess_kernel", "duplicate": "expand_kernel",
                  "ranges": "tile_ranges_kernel", "colour": "sh_colour_listed_kernel"}
     launches = max(1, len(slab_pairs)) if dom in ("blend", "duplicate", "ranges", "colour", "tile_sort") else 1
-    traffic = pmc_traffic(T_key=args.workload if not args.gaussians else None)
     dom_kernel = kernel_of.get(dom, dom)
     dom_traffic = None
     if traffic is not None and dom_kernel in traffic["kernels"]:
         dom_traffic = int(traffic["kernels"][dom_kernel]["bytes_per_launch"])
-    dom_gbps = stage_alg[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
-    frame_gbps = alg["frame"] / (ms_per_step * 1e-3) / 1e9
-    frame = {"alg_bytes": int(alg["frame"]), "achieved": round(frame_gbps, 1),
-             "frac": round(frame_gbps / HBM_PEAK_GBPS, 4), "n_pass_ref_sort": alg["n_pass"],
+    dom_bytes = stage_alg[dom] if stage_alg[dom] else design[dom]
+    dom_gbps = dom_bytes / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+    equiv_gbps = alg["frame"] / (ms_per_step * 1e-3) / 1e9
+    design_gbps = design["frame"] / (ms_per_step * 1e-3) / 1e9
+    frame = {"ms_per_step": round(ms_per_step, 4),
              # one frame alone on the GPU, first kernel to last (HIP events), over the per-stage replay
              "single_stream_ms_p50": round(call_ms[len(call_ms) // 2], 4) if call_ms else None,
-             "single_stream_ms_p95": round(call_ms[min(len(call_ms) - 1, int(0.95 * len(call_ms)))], 4) if call_ms else None}
+             "single_stream_ms_p95": round(call_ms[min(len(call_ms) - 1, int(0.95 * len(call_ms)))], 4) if call_ms else None,
+             "design_bytes": int(design["frame"]), "achieved_design": round(design_gbps, 1),
+             "frac_design": round(design_gbps / HBM_PEAK_GBPS, 4),
+             # the reference formula's bytes (SURVEY.md 8d B_alg, 6 radix passes over 64-bit keys ...) over this frame time:
+             # an EQUIVALENCE figure -- this design does not move most of those bytes
+             "alg_bytes_reference_formula": int(alg["frame"]), "achieved_equiv": round(equiv_gbps, 1),
+             "frac_equiv": round(equiv_gbps / HBM_PEAK_GBPS, 4), "n_pass_ref_sort": alg["n_pass"]}
     if traffic is not None:
         tr_gbps = traffic["frame_bytes"] / (ms_per_step * 1e-3) / 1e9
-        frame.update({"traffic": int(traffic["frame_bytes"]), "achieved_traffic": round(tr_gbps, 1),
-                      "frac_traffic": round(tr_gbps / HBM_PEAK_GBPS, 4)})
+        # THE frame figure: HBM bytes the counters measured for one frame / the frame time of the timed regions / peak
+        frame.update({"traffic": int(traffic["frame_bytes"]), "achieved": round(tr_gbps, 1),
+                      "frac": round(tr_gbps / HBM_PEAK_GBPS, 4)})
+        if serial is not None:
+            frame["frac_serial"] = round(traffic["frame_bytes"] / (serial["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+    else:
+        frame.update({"traffic": None, "achieved": round(design_gbps, 1), "frac": round(design_gbps / HBM_PEAK_GBPS, 4),
+                      "frac_is": "design bytes (no counter summary for this workload)"})
     roofline = {
         "bound": "hbm", "kernel": dom_kernel,
         "achieved": round(dom_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -524,10 +641,12 @@ def main():
         "traffic_source": None if traffic is None else traffic["source"],
         "traffic_measured_at": None if traffic is None else traffic["commit"],
         "launches_per_frame": launches, "avg_launch_ms": round(stage_ms[dom] / launches, 4),
-        "alg_bytes_per_launch": int(stage_alg[dom] / launches), "per_frame_ms": round(stage_ms[dom], 4),
-        "alg_bytes_per_frame": int(stage_alg[dom]), "stage_replay_calls": calls,
-        "note": "vector-instruction-issue bound, not HBM bound (DESIGN.md section 4): frac is algorithmic bytes over HBM peak",
+        "alg_bytes_per_launch": int(dom_bytes / launches), "per_frame_ms": round(stage_ms[dom], 4),
+        "alg_bytes_per_frame": int(dom_bytes), "design_bytes_per_frame": int(design[dom]), "stage_replay_calls": calls,
+        "note": "vector-instruction-issue bound, not HBM bound (DESIGN.md section 4): frac = SURVEY 8d's algorithmic bytes of the "
+                "kernel (44 B per reference pair + 24 B per pixel) over its time and the HBM peak",
         "frame": frame, "stages": stages, "slab_pairs_last_frame": slab_pairs,
+        "units_mean": {k: (round(v, 1) if not isinstance(v, list) else [round(x, 1) for x in v]) for k, v in units.items()},
     }
 
     cpu_baseline = None
@@ -539,7 +658,7 @@ def main():
 
     also = None
     if rank == 0 and world == 1 and not args.no_also and args.workload == "c3" and not args.gaussians and args.boundary == "op":
-        also = run_also(device, side, S)
+        also = run_also(device, side, S, parity=not args.no_cpu_baseline)
 
     if rank == 0:
         metric = ("rendered frames/sec at 1920x1080, 3M Gaussians" if args.workload == "c3" and not args.gaussians
@@ -565,7 +684,9 @@ def main():
                        "options": {"tile_cull": _lib.get_option(_lib.OPT_TILE_CULL),
                                    "slabs": _lib.get_option(_lib.OPT_SLABS), "slab_first": _lib.get_option(_lib.OPT_SLAB_FIRST),
                                    "defer_colour": _lib.get_option(_lib.OPT_DEFER_COLOUR)}},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "value_serial": None if serial is None else serial["value"],
+            "ms_per_step_serial": None if serial is None else serial["ms_per_step"],
+            "serial": serial, "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         if strong:
             line["config"]["job_frames"] = args.job_frames
@@ -589,7 +710,7 @@ def main():
         dist.destroy_process_group()
 
 
-def run_also(device, side, S):
+def run_also(device, side, S, parity=True):
     """Short runs of the other BASELINE configs and boundaries, so that their figures are on the driver-observed line."""
     also = {}
 
@@ -642,7 +763,155 @@ def run_also(device, side, S):
         return out
 
     guarded("c5_render_and_composite", c5)
+    guarded("c3_reference_shaped_render", lambda: reference_shaped_render(device))
+    guarded("backward_c3", lambda: backward_iteration("c3", device, parity=parity))
     return also
+
+
+def reference_shaped_render(device, key="c3", frames=24):
+    """The reference's per-frame ``render()`` in ITS call shape on this library (gaussian_renderer/__init__.py:83-218 as
+    scene_representation.py:424 calls it): every frame recomputes exp / sigmoid / normalize / cat(dc, rest) and the minimum
+    axis, calls the rasterizer twice through ``GaussianRasterizer`` (SH pass, then normals as colors_precomp), and
+    post-processes the normal and pseudo-normal maps in PyTorch; one frame at a time, one stream.  The only help an
+    unchanged caller gets is the drop-in's geometry reuse between the two passes (timed with it on and off).  Next to it
+    the same boundary with this repository's own ``render()`` (memoised activations, fused elementwise kernels, normal
+    pass folded into the first), serial as well."""
+    from autovfx_amd import renderer
+    from diff_gaussian_rasterization import _C
+    b = Bench(key, device, None, boundary="render")
+    fr = [(10 + 7 * j) % b.F for j in range(frames)]
+    for f in fr:
+        b.cam(f)
+
+    def run(n=frames):
+        with torch.no_grad():
+            for f in fr[:n]:
+                out = renderer.render(b.cam(f), b.model, renderer.PipelineParams, b.bg)
+        return out
+
+    def timed():
+        run(4)
+        secs = timed_regions(run, 3, False, device)
+        return sorted(secs)[1] / frames * 1e3
+
+    out = {"workload": b.name, "frames": frames, "streams": 1}
+    out["fused_ms_per_frame"] = round(timed(), 4)
+    try:
+        b.model.memoise = False
+        renderer.FUSE_ELEMENTWISE = False
+        out["ms_per_frame"] = round(timed(), 4)
+        _C.set_geometry_cache(False)
+        out["ms_per_frame_without_geometry_reuse"] = round(timed(), 4)
+    finally:
+        _C.set_geometry_cache(True)
+        b.model.memoise = True
+        renderer.FUSE_ELEMENTWISE = True
+    out["value"] = round(1e3 / out["ms_per_frame"], 2)
+    out["unit"] = "frames/s"
+    out["what"] = ("reference-shaped render(): per-frame activations in PyTorch, two GaussianRasterizer calls, PyTorch normal "
+                   "post-processing; blocking, one stream; geometry reuse between the two passes on (the drop-in's default)")
+    return out
+
+
+def backward_iteration(key, device, steps=12, parity=True):
+    """One training-style iteration (train.py:84-134 without the optimizer): forward (a FULL call: gradients are wanted),
+    L1 + depth loss, ``loss.backward()``; HIP events around the halves, the two backward kernels timed by the library's
+    own events on the launch stream.  Gradient parity against the CPU oracle's backward on one frame."""
+    from autovfx_amd import _lib, scenes
+    from autovfx_amd.cameras import orbit_cameras
+    from autovfx_amd.frame_parallel import settings_for_camera
+    from diff_gaussian_rasterization import GaussianRasterizer, _C
+    wl = WORKLOADS[key]
+    W, H = wl["width"], wl["height"]
+    cloud_cpu = getattr(scenes, wl["cfg"])()
+    cloud = cloud_cpu.to(device)
+    cams_cpu = orbit_cameras(wl["frames"], W, H)
+    bg = torch.zeros(3, device=device)
+    leaves = [t.clone().requires_grad_(True) for t in (cloud.means3D, cloud.opacities, cloud.shs, cloud.scales, cloud.rotations)]
+    target = torch.rand(3, H, W, device=device)
+
+    def it(i, timers=None):
+        m3, op, sh, sc, rot = leaves
+        for t in leaves:
+            t.grad = None
+        cam = cams_cpu[i].to(device)
+        rast = GaussianRasterizer(settings_for_camera(cam, bg, 3))
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        img, depth, alpha, radii = rast(m3, torch.zeros_like(m3, requires_grad=True), op, shs=sh, scales=sc, rotations=rot)
+        loss = (img - target).abs().mean() + 0.01 * depth.mean()
+        e[1].record()
+        loss.backward()
+        e[2].record()
+        if timers is not None:
+            timers.append(e)
+        return int((radii > 0).sum().item()) if timers is None else None
+
+    for i in range(4):
+        it(i)
+    live = _C.last_layout()["counts"]["live_pairs"]
+    torch.cuda.synchronize()
+    _lib.set_stage_timing(True)
+    timers = []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        it(5 + i, timers)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    bw_k = _lib.backward_times_ms()
+    _lib.set_stage_timing(False)
+    fw = sum(a.elapsed_time(b_) for a, b_, _ in timers) / len(timers)
+    bw = sum(b_.elapsed_time(c) for _, b_, c in timers) / len(timers)
+    P = cloud.P
+    # render_backward_kernel: per list entry it walks the forward's 48-byte reads (id 4, raster 32, colour 12) and adds
+    # one 40-byte line of partial sums per (entry, 8x8 quadrant) that contributes; per pixel 28 B in.  Algorithmic bytes
+    # as SURVEY 8d counts the forward blend (44 B per pair + per-pixel terms) plus the ten 4-byte sums per pair the
+    # reference's backward adds atomically: (44 + 40) * live pairs + 28 * W * H.
+    rb_bytes = (44 + 40) * live + 28 * W * H
+    out = {"workload": wl["name"], "P": P, "steps": steps, "iters_per_s": round(steps / el, 2), "ms_per_iter": round(el / steps * 1e3, 3),
+           "forward_plus_loss_ms": round(fw, 3), "backward_ms": round(bw, 3), "live_pairs": int(live),
+           "kernels": {"render_backward_kernel": {"ms": round(bw_k["render_backward"], 4), "alg_bytes": int(rb_bytes),
+                                                  "alg_GBps": round(rb_bytes / max(1e-9, bw_k["render_backward"] * 1e-3) / 1e9, 1),
+                                                  "frac_of_hbm_peak": round(rb_bytes / max(1e-9, bw_k["render_backward"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                                  "bound": "vector issue + LDS cross-lane reductions + one atomic line per (entry, quadrant)"},
+                       # per Gaussian: inputs 12 + 12 + 16 + 192 (SH) + its 64-byte line of sums; gradients 12+12+16+4+12+4+24+192+12+16
+                       "preprocess_backward_kernel": {"ms": round(bw_k["preprocess_backward"], 4), "alg_bytes": int(600 * P),
+                                                      "alg_GBps": round(600 * P / max(1e-9, bw_k["preprocess_backward"] * 1e-3) / 1e9, 1),
+                                                      "frac_of_hbm_peak": round(600 * P / max(1e-9, bw_k["preprocess_backward"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                                      "bound": "hbm"}},
+           "timed_calls": bw_k["calls"]}
+    if parity:
+        try:
+            from oracle import cpu_oracle
+            g = np.random.default_rng(5)
+            pg = dict(dL_dcolor=(g.standard_normal((3, H, W)) / (3 * H * W)).astype(np.float32),
+                      dL_ddepth=np.full((1, H, W), 0.01 / (H * W), np.float32), dL_dalpha=np.zeros((1, H, W), np.float32))
+            cam = cams_cpu[7]
+            kw = dict(means3D=cloud_cpu.means3D, opacities=cloud_cpu.opacities, bg=np.zeros(3, np.float32), width=W, height=H,
+                      viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, campos=cam.camera_center,
+                      tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, sh_degree=3, shs=cloud_cpu.shs, scales=cloud_cpu.scales,
+                      rotations=cloud_cpu.rotations, **pg)
+            t0 = time.perf_counter()
+            ref = cpu_oracle.backward(**kw)
+            t_ref = time.perf_counter() - t0
+            for t in leaves:
+                t.grad = None
+            camd = cam.to(device)
+            img, depth, alpha, radii = GaussianRasterizer(settings_for_camera(camd, bg, 3))(
+                leaves[0], torch.zeros_like(leaves[0], requires_grad=True), leaves[1], shs=leaves[2], scales=leaves[3], rotations=leaves[4])
+            tt = lambda a: torch.from_numpy(a).to(device)
+            ((img * tt(pg["dL_dcolor"])).sum() + (depth * tt(pg["dL_ddepth"])).sum() + (alpha * tt(pg["dL_dalpha"])).sum()).backward()
+            torch.cuda.synchronize()
+            rel = {}
+            for name, leaf in zip(("dL_dmeans3D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations"), leaves):
+                a, r = leaf.grad.cpu().numpy().astype(np.float64).reshape(-1), ref[name].astype(np.float64).reshape(-1)
+                rel[name] = float(np.abs(a - r).max() / max(1e-30, np.abs(r).max()))
+            out["parity_vs_cpu_oracle"] = {"frame": 7, "max_abs_err_over_max_abs": {k: float(f"{v:.3e}") for k, v in rel.items()},
+                                           "bar": 2e-4, "radii_equal": bool((radii.cpu().numpy() == ref["radii"]).all()),
+                                           "oracle_seconds": round(t_ref, 2)}
+        except Exception as e:
+            out["parity_vs_cpu_oracle"] = {"error": repr(e)[:200]}
+    return out
 
 
 def time_frame_files(b, n):
@@ -679,6 +948,26 @@ def time_frame_files(b, n):
                 "writer_pool": {"frames": m, "threads": workers, "ms_per_frame": round(t_pool / m * 1e3, 2)}}
     except Exception as e:
         return {"error": repr(e)[:200]}
+
+
+def stage_counter_bytes(traffic):
+    """HBM bytes per frame and stage from the committed counter summary: kernels are attributed to stages by name; the
+    three radix kernels serve both sorts, so their bytes are split by the summary's own per-sort entries when it has them
+    (pmc_reduce.py writes `stages`), else left out."""
+    if traffic is None:
+        return None
+    if "stages" in traffic:
+        return {k: float(v) for k, v in traffic["stages"].items()}
+    out = {}
+    for stage, names in STAGE_KERNELS.items():
+        tot = 0.0
+        for n in names:
+            k = traffic["kernels"].get(n)
+            if k is not None:
+                tot += k.get("bytes_per_frame", k["bytes_per_launch"] * k.get("launches_per_frame", 1))
+        if names:
+            out[stage] = tot
+    return out
 
 
 def pmc_traffic(T_key):

@@ -272,6 +272,9 @@ typedef enum gsr_geom_slot {
     GSR_GEOM_INTERNAL_RADII,    /* i32[P]   used when the caller passes radii == NULL              */
     GSR_GEOM_DEPTH_ORDER,       /* u32[P]   Gaussian ids, ascending (depth bits, id); culled last  */
     GSR_GEOM_POINT_OFFSETS,     /* u32[P]   inclusive scan of the pair counts in DEPTH_ORDER order     */
+    GSR_GEOM_LISTED,            /* u8[P]    inference calls with deferred colours that were cut into depth slabs: s + 1 when
+                                   slab s (the last one that did) put the Gaussian into a list, 0 when none did; such a call
+                                   evaluates SH colours for exactly these.  Offset 0 = the call has no such array. */
     GSR_GEOM_NUM_SLOTS
 } gsr_geom_slot;
 
@@ -366,6 +369,11 @@ GSR_API int gsr_get_stage_times(float ms[GSR_STAGE_NUM]);
 /* First-kernel-to-last-kernel device time of each of the most recent timed gsr_forward calls of this thread, newest
  * first; returns how many were written (at most `capacity` and at most the ring of 256). */
 GSR_API int gsr_get_call_times(float* ms, int capacity);
+/* While stage timing is enabled gsr_backward records HIP events on its stream as well: ms[0] = mean milliseconds of the
+ * per-pixel pass (render_backward_kernel, with the clearing of its accumulation scratch), ms[1] = of the per-Gaussian pass
+ * (preprocess_backward_kernel), over the gsr_backward calls of the whole process since timing was enabled (at most the
+ * last 64; autograd runs backward on its own thread, so this record is process-wide).  Returns the number of calls averaged. */
+GSR_API int gsr_get_backward_times(float ms[2]);
 
 GSR_API const char* gsr_last_error(void);
 GSR_API int gsr_abi_version(void);
