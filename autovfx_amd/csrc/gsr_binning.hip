@@ -21,7 +21,7 @@
 //                         tile, records re-written IN DEPTH ORDER.
 //   bin_offsets_kernel  : adds the sum of all earlier tile totals (each workgroup sums them itself: a few KB of
 //                         L2-resident words, no chain, no look-back) -> POINT_OFFSETS, global and inclusive.
-//   slab_bounds_kernel  : cuts the depth order into slabs at the given pair counts.
+//                         The workgroup whose tile a slab boundary falls into also writes the slab table.
 //   slab_recount_kernel / slab_compact_kernel (slabs > 0): drop finished tiles from the records, re-scan, and list the
 //                         positions that still have a live pair (behind an opaque front nine splats in ten have none:
 //                         the expansion walks the compacted list, not the depth order).
@@ -382,58 +382,61 @@ __global__ void __launch_bounds__(256) bin_gather_kernel(BinningArrays a) {
 
 // P - V trailing positions (culled Gaussians) repeat the total so that POINT_OFFSETS is defined over all P, as
 // the reference's inclusive scan is.
+//
+// The same launch cuts the depth order into slabs (round 2 had a kernel of its own for it): slab s takes the positions
+// whose inclusive offset lies in (cut[s-1], cut[s]]; its end is the number of positions with an offset <= cut[s], and
+// that boundary falls into exactly one 1024-position tile -- the first whose last offset exceeds the cut (the last tile
+// when no offset does) -- whose workgroup counts how many of its own positions stay below the cut and writes the slab
+// table entries.  The last slab ends at V.
+struct SlabCuts { uint32_t cut[kMaxSlabs]; };
+
 __global__ void __launch_bounds__(256) bin_offsets_kernel(int P, int V, const uint32_t* __restrict__ tile_totals,
-                                                          uint32_t* __restrict__ offsets, uint32_t* __restrict__ tile_ends) {
+                                                          uint32_t* __restrict__ offsets, uint32_t* __restrict__ tile_ends,
+                                                          int num_slabs, SlabCuts cuts, SlabInfo* __restrict__ slabs) {
     __shared__ uint32_t s_scratch[4];
     const int tiles_v = (V + kDupTile - 1) / kDupTile;
     const int upto = min((int)blockIdx.x, tiles_v);
     uint32_t part = 0;
     for (int t = threadIdx.x; t < upto; t += 256) part += tile_totals[t];
     const uint32_t before = block_sum_256(part, s_scratch);
-    if (threadIdx.x == 0 && (int)blockIdx.x < tiles_v) tile_ends[blockIdx.x] = before + tile_totals[blockIdx.x];
+    const bool has_pairs = (int)blockIdx.x < tiles_v;
+    const uint32_t tile_end = has_pairs ? before + tile_totals[blockIdx.x] : before;
+    if (threadIdx.x == 0 && has_pairs) tile_ends[blockIdx.x] = tile_end;
     // positions past V (culled Gaussians) carry the grand total: the tile that straddles V is the last one with pairs
-    const uint32_t total = (int)blockIdx.x < tiles_v ? before + tile_totals[blockIdx.x] : before;
     const int k0 = (int)blockIdx.x * kDupTile + 4 * (int)threadIdx.x;
+    uint32_t mine[4] = {0u, 0u, 0u, 0u};   // global inclusive offsets of this lane's positions below V
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int k = k0 + j;
-        if (k < V) offsets[k] += before;
-        else if (k < P) offsets[k] = total;
+        if (k < V) {
+            mine[j] = offsets[k] + before;
+            offsets[k] = mine[j];
+        } else if (k < P) {
+            offsets[k] = tile_end;
+        }
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// slab boundaries: slab s = positions whose inclusive offset lies in (cut[s-1], cut[s]]; one workgroup per slab.
-// ------------------------------------------------------------------------------------------------
-struct SlabCuts { uint32_t cut[kMaxSlabs]; };
-
-// number of positions [0, V) whose inclusive offset is <= limit (offsets ascend: they form a prefix)
-__device__ __forceinline__ uint32_t positions_upto(uint32_t limit, int V, const uint32_t* __restrict__ offsets,
-                                                   const uint32_t* __restrict__ tile_ends, uint32_t* s_scratch) {
-    const int tiles = (V + kDupTile - 1) / kDupTile;
-    uint32_t n_le = 0;
-    for (int t = threadIdx.x; t < tiles; t += 256) n_le += tile_ends[t] <= limit ? 1u : 0u;
-    const int tile0 = (int)block_sum_256(n_le, s_scratch);  // tiles that end at or before the limit
-    n_le = 0;
-    const int k0 = tile0 * kDupTile + 4 * (int)threadIdx.x;
+    if (!has_pairs) return;   // workgroup-uniform
+    const bool last_tile = (int)blockIdx.x == tiles_v - 1;
+    for (int s = 0; s < num_slabs; ++s) {
+        const bool open_end = s == num_slabs - 1;   // the last slab takes everything that is left
+        const uint32_t cut = open_end ? 0xFFFFFFFFu : cuts.cut[s];
+        const bool inside = !open_end && before <= cut && cut < tile_end;  // the boundary lies among this tile's positions
+        const bool beyond = last_tile && (open_end || cut >= tile_end);    // ... or behind the last position of all
+        if (!inside && !beyond) continue;   // workgroup-uniform
+        uint32_t n_le = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (k0 + j < V) n_le += offsets[k0 + j] <= limit ? 1u : 0u;
-    return (uint32_t)tile0 * kDupTile + block_sum_256(n_le, s_scratch);
-}
-
-__global__ void __launch_bounds__(256) slab_bounds_kernel(int V, int num_slabs, SlabCuts cuts, const uint32_t* __restrict__ offsets,
-                                                          const uint32_t* __restrict__ tile_ends, SlabInfo* __restrict__ slabs) {
-    __shared__ uint32_t s_scratch[4];
-    const int s = blockIdx.x;
-    const uint32_t first = s == 0 ? 0u : positions_upto(cuts.cut[s - 1], V, offsets, tile_ends, s_scratch);
-    const uint32_t end = s == num_slabs - 1 ? (uint32_t)V : positions_upto(cuts.cut[s], V, offsets, tile_ends, s_scratch);
-    if (threadIdx.x == 0) {
-        SlabInfo info;
-        info.first = first; info.end = end; info.emitters = end - first;
-        // slab 0 is expanded from the global offsets as they are; later slabs set their count when they re-scan
-        info.pairs = (s == 0 && end > 0u) ? offsets[end - 1] : 0u;
-        slabs[s] = info;
+        for (int j = 0; j < 4; ++j)
+            if (k0 + j < V && (beyond || mine[j] <= cut)) ++n_le;
+        const uint32_t below = block_sum_256(n_le, s_scratch);   // this tile's positions that stay in slab s (a prefix of them)
+        const uint32_t pos = (uint32_t)blockIdx.x * kDupTile + below;
+        if (threadIdx.x == 0) {
+            slabs[s].end = pos;
+            if (s + 1 < num_slabs) slabs[s + 1].first = pos;
+            if (s == 0) slabs[0].emitters = pos;
+            if (s == 0 && below == 0u) slabs[0].pairs = before;   // the slab ends with the previous tile
+        }
+        // slab 0 is expanded from the global offsets as they are: its pair count is the offset of its last position
+        if (s == 0 && below != 0u && (uint32_t)threadIdx.x == (below - 1u) / 4u) slabs[0].pairs = mine[(below - 1u) & 3u];
     }
 }
 
@@ -793,10 +796,11 @@ hipError_t launch_bin_scan(const BinningArrays& a, const Camera& cam, int num_sl
     const int tiles_p = div_up(a.P, kDupTile), tiles_v = div_up(a.V, kDupTile);
     if (tiles_v > 0) hipLaunchKernelGGL(bin_gather_kernel, dim3(tiles_v), dim3(256), 0, stream, a);
     uint32_t* tile_ends = a.tile_totals + tiles_p;
-    hipLaunchKernelGGL(bin_offsets_kernel, dim3(tiles_p), dim3(256), 0, stream, a.P, a.V, a.tile_totals, a.offsets, tile_ends);
     SlabCuts cuts = {};
     for (int s = 0; s + 1 < num_slabs; ++s) cuts.cut[s] = pair_cuts[s];
-    hipLaunchKernelGGL(slab_bounds_kernel, dim3(num_slabs), dim3(256), 0, stream, a.V, num_slabs, cuts, a.offsets, tile_ends, a.slabs);
+    // (V == 0: the slab table stays as the call's zero-filled block left it: no positions, no pairs)
+    hipLaunchKernelGGL(bin_offsets_kernel, dim3(tiles_p), dim3(256), 0, stream, a.P, a.V, a.tile_totals, a.offsets, tile_ends, num_slabs, cuts,
+                       a.slabs);
     return hipGetLastError();
 }
 
