@@ -49,10 +49,11 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
     uint32_t big_rows = 0;      // tile rows of a splat too large for a mask
     SplatBin bin = {0u, 0u, 0u, 0u};
     uint32_t key = kCulledKey;
-    // what the tile-mask phase needs of a candidate (a visible splat whose tight rectangle has <= kMaskTiles tiles)
+    // what the tile-mask phase needs of a candidate (a visible splat whose tight rectangle has <= kMaskTiles tiles and
+    // at least 2 x 2 of them)
     bool mask_candidate = false;
-    uint32_t cand_tests = 0;
-    float4 cand_conic = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t cand_rows = 0;
+    LiveRegion cand_region = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0};
     float2 cand_centre = make_float2(0.f, 0.f);
 
     if (in_range) {
@@ -144,7 +145,11 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
                 rect_area = area;
                 // exact-image tile culling, part 1: the rectangle cut down to where alpha >= 1/255 is possible at all
                 TileRect tr = rc;
-                if (in.tile_cull) tr = tight_rect(live_region(conic_o.x, conic_o.y, conic_o.z, skip_below), px, py, rc);
+                LiveRegion region = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0};
+                if (in.tile_cull) {
+                    region = live_region(conic_o.x, conic_o.y, conic_o.z, skip_below);
+                    tr = tight_rect(region, px, py, rc);
+                }
                 const uint32_t tw = (uint32_t)(tr.x1 - tr.x0), th = (uint32_t)(tr.y1 - tr.y0), tarea = tw * th;
                 if (tarea != 0u) {
                     bin.xy0 = (uint32_t)tr.x0 | ((uint32_t)tr.y0 << 16);
@@ -158,10 +163,10 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
                         // {q <= beta}, so every tile row it spans contains the ellipse's extreme point of that side, and
                         // with a single column that point lies in the row's only tile.  Only rectangles of at least
                         // 2 x 2 tiles have corners to test (a third of C3's splats).
-                        if (in.tile_cull && tw >= 2u && th >= 2u) {
+                        if (in.tile_cull && tw >= 2u && th >= 2u && region.kind == 1) {   // (kind 0: nothing can be bounded)
                             mask_candidate = true;
-                            cand_tests = tarea;
-                            cand_conic = make_float4(conic_o.x, conic_o.y, conic_o.z, skip_below);  // w: the pre-test threshold
+                            cand_rows = th;
+                            cand_region = region;
                             cand_centre = make_float2(px, py);
                         }
                     } else {  // too large for a mask: one run of live columns per tile row, worked out at gather time
@@ -179,55 +184,67 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
     GSR_KTRACE(blockIdx.x, 1);
 
     // ---- exact-image tile culling, wave-cooperative ----
-    // A lane looping over the tiles of its own rectangle makes the wave run as long as its largest rectangle.  Instead
-    // the (splat, tile) tests of the wave's 64 splats are flattened: test t belongs to the splat whose inclusive count
-    // first exceeds t (binary search over the counts parked in LDS), every lane runs one test per iteration, the
-    // ballot of the results is cut back into per-splat masks.  Iterations = total tests / 64.
+    // The region where a splat can reach alpha >= 1/255 is an ellipse; cut with the pixel rows of one tile row it is
+    // convex, so the live tiles of that row are ONE run of columns with a closed form (gsr_device.h: row_run -- what
+    // bin_gather_kernel uses for the splats too large for a mask).  The mask of a small splat is therefore built from one
+    // run per tile row instead of one test per tile (round 2: 4 - 9 tests for the usual 2x2 ... 3x3 rectangles against 2 - 3
+    // runs), and the (splat, row) items of the wave's 64 splats are flattened over its lanes: item t belongs to the splat
+    // whose inclusive row count first exceeds t (binary search over the counts parked in LDS), every lane computes one
+    // run per iteration and ORs its bits into the splat's mask in LDS.  Iterations = rows of the wave's candidates / 64:
+    // one, as a rule.
     {
-        __shared__ float4 s_conic[4][64];
-        __shared__ float4 s_place[4][64];   // centre x, y, first tile (x | y << 16), rectangle width
+        __shared__ float4 s_reg0[4][64];    // conic A, B, C, beta
+        __shared__ float4 s_reg1[4][64];    // half extents u, v, centre x, y
+        __shared__ uint2 s_place[4][64];    // first tile x | y << 16, rectangle width
         __shared__ uint32_t s_incl[4][64];
+        __shared__ uint32_t s_mask[4][64][2];
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const uint32_t n_tests = cand_tests;
-        uint32_t incl = n_tests;
+        uint32_t incl = cand_rows;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
             if (lane >= d) incl += o;
         }
-        const uint32_t excl = incl - n_tests;
         const uint32_t total = (uint32_t)__shfl((int)incl, 63);
         if (total != 0u) {  // wave-uniform
-            s_conic[wave][lane] = cand_conic;
-            s_place[wave][lane] = make_float4(cand_centre.x, cand_centre.y, __uint_as_float(bin.xy0), __uint_as_float(bin.wh & 0xFFFFu));
+            s_reg0[wave][lane] = make_float4(cand_region.A, cand_region.B, cand_region.C, cand_region.beta);
+            s_reg1[wave][lane] = make_float4(cand_region.u_ext, cand_region.v_ext, cand_centre.x, cand_centre.y);
+            s_place[wave][lane] = make_uint2(bin.xy0, bin.wh & 0xFFFFu);
             s_incl[wave][lane] = incl;
-            __builtin_amdgcn_s_waitcnt(0);       // this wave's own LDS writes have landed
+            s_mask[wave][lane][0] = 0u;
+            s_mask[wave][lane][1] = 0u;
+            GSR_WAIT_LDS();                      // this wave's own LDS writes have landed
             __builtin_amdgcn_wave_barrier();
-            unsigned long long mask = 0ull;
             for (uint32_t t0 = 0; t0 < total; t0 += 64u) {
                 const uint32_t t = t0 + (uint32_t)lane;
-                int lo = 0, hi = 63;  // first splat whose inclusive count exceeds t
+                if (t < total) {
+                    int lo = 0, hi = 63;  // first splat whose inclusive row count exceeds t
 #pragma unroll
-                for (int step = 0; step < 6; ++step) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_incl[wave][mid] > t) hi = mid; else lo = mid + 1;
-                }
-                const float4 co = s_conic[wave][lo], pl = s_place[wave][lo];
-                const uint32_t xy0 = __float_as_uint(pl.z), w = __float_as_uint(pl.w);
-                const uint32_t first = lo > 0 ? s_incl[wave][lo - 1] : 0u;
-                const uint32_t local = t - first;  // < 64, w <= 64: (local + 0.5) / w is >= 1/128 away from an integer
-                const uint32_t row = (uint32_t)(((float)local + 0.5f) * __builtin_amdgcn_rcpf((float)w));
-                const uint32_t col = local - row * w;
-                const bool live = t < total && splat_reaches_tile(co, co.w, make_float2(pl.x, pl.y), (int)((xy0 & 0xFFFFu) + col),
-                                                                  (int)((xy0 >> 16) + row));
-                const unsigned long long b = __ballot(live);
-                const uint32_t from = max(excl, t0), to = min(incl, t0 + 64u);  // my tests inside this batch
-                if (from < to) {
-                    const unsigned long long bits = (b >> (from - t0)) & (to - from >= 64u ? ~0ull : (1ull << (to - from)) - 1ull);
-                    mask |= bits << (from - excl);
+                    for (int step = 0; step < 6; ++step) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_incl[wave][mid] > t) hi = mid; else lo = mid + 1;
+                    }
+                    const uint32_t r = t - (lo > 0 ? s_incl[wave][lo - 1] : 0u);
+                    const float4 q0 = s_reg0[wave][lo], q1 = s_reg1[wave][lo];
+                    const uint2 pl = s_place[wave][lo];
+                    LiveRegion g;
+                    g.A = q0.x; g.B = q0.y; g.C = q0.z; g.beta = q0.w; g.u_ext = q1.x; g.v_ext = q1.y; g.kind = 1;
+                    const uint32_t x0 = pl.x & 0xFFFFu, y0 = pl.x >> 16, w = pl.y;   // w <= 32: at least two rows, at most 64 tiles
+                    int ca, cb;
+                    row_run<true>(g, q1.z, q1.w, (int)(y0 + r), (int)x0, (int)(x0 + w), &ca, &cb);
+                    if (cb > ca) {
+                        const uint32_t len = (uint32_t)(cb - ca);
+                        const unsigned long long bits = ((len >= 32u ? 0xFFFFFFFFull : (1ull << len) - 1ull) << ((uint32_t)ca - x0)) << (r * w);
+                        if ((uint32_t)bits != 0u) atomicOr(&s_mask[wave][lo][0], (uint32_t)bits);
+                        if ((uint32_t)(bits >> 32) != 0u) atomicOr(&s_mask[wave][lo][1], (uint32_t)(bits >> 32));
+                    }
                 }
             }
+            GSR_WAIT_LDS();
+            __builtin_amdgcn_wave_barrier();
             if (mask_candidate) {
+                const unsigned long long mask = ((unsigned long long)s_mask[wave][lane][0] | ((unsigned long long)s_mask[wave][lane][1] << 32)) &
+                                                ((unsigned long long)bin.lo | ((unsigned long long)bin.hi << 32));   // (inside the rectangle)
                 bin.lo = (uint32_t)mask; bin.hi = (uint32_t)(mask >> 32);
                 live_bound = (uint32_t)__popcll(mask);
                 if (mask == 0ull) {  // every tile is dead: the splat is listed nowhere (radii and num_rendered still count it)
