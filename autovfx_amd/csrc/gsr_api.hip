@@ -904,14 +904,21 @@ int forward_finish(ForwardCall& fc) {
         const bool last = k == S - 1;
         const gsr::ArenaHeader hs[3] = {hg, hb, hi};
         void* const dsts[3] = {gbase, bbase, fc.ibase};
-        // tile ranges (all (0,0) when nothing is live: rasterizer_impl.cu:311); the last launch also stamps the headers
-        GSR_HIP(gsr::launch_tile_ranges(slab, T, tk_sorted, ranges, last ? dsts : nullptr, hs, stream));
+        // tile ranges (all (0,0) when nothing is live: rasterizer_impl.cu:311); the call's last duty also stamps the headers.
+        // A call that evaluates deferred colours hands the duty to the first workgroups of its colour kernel (one launch
+        // less, and the search latency hides behind the colour reads); otherwise it is a launch of its own.
+        gsr::RangesDuty duty = {};
+        duty.slab = slab; duty.num_tiles = T; duty.keys = tk_sorted; duty.ranges = ranges;
+        for (int i = 0; i < 3; ++i) { duty.headers[i] = hs[i]; duty.header_dst[i] = last ? dsts[i] : nullptr; }
+        const bool colour_blocks_suffice = (S == 1 ? (P + 255) / 256 : (P + 1023) / 1024) >= gsr::ranges_duty_blocks(T);
+        const bool fused_ranges = fc.defer_colour && colour_blocks_suffice && !debug;
+        if (!fused_ranges) GSR_HIP(gsr::launch_tile_ranges(duty, stream));
         GSR_STAGE_CHECK("tile_ranges");
         stamp(kHeadEvents + kSlabEvents * k + 2, stream);
         if (fc.defer_colour && S == 1)
-            GSR_HIP(gsr::launch_sh_colour_all(fc.in, cam, ga.bins, ga.rgb, stream));
+            GSR_HIP(gsr::launch_sh_colour_all(fc.in, cam, ga.bins, ga.rgb, fused_ranges ? &duty : nullptr, stream));
         else if (fc.defer_colour)
-            GSR_HIP(gsr::launch_sh_colour_listed(fc.in, cam, ba.listed, k + 1, slab, ga.rgb, stream));
+            GSR_HIP(gsr::launch_sh_colour_listed(fc.in, cam, ba.listed, k + 1, slab, ga.rgb, fused_ranges ? &duty : nullptr, stream));
         stamp(kHeadEvents + kSlabEvents * k + 3, stream);
         GSR_HIP(gsr::launch_blend(cam, segs, k, k + 1, /*fresh=*/k == 0, /*final=*/last, ga.raster, features, fc.background,
                                   fc.out_color, fc.out_depth, fc.out_alpha, n_contrib, ba.quad_done, ba.done_rows, fc.row_words, stream,

@@ -726,36 +726,11 @@ __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5: ranges[t] = [lower_bound(t), lower_bound(t+1)) over the sorted tile keys; (0,0) when empty,
-// which is what the reference's memset + boundary scan leaves behind.
+// K5 on its own (calls without a colour kernel to carry it: full calls, precomputed colours): gsr_device.h tile_ranges_duty.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__ a, uint32_t n, uint32_t v) {
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if (a[mid] < v) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
-struct ArenaHeaders3 { ArenaHeader h[3]; void* dst[3]; };
-
-__global__ void __launch_bounds__(256) tile_ranges_kernel(const SlabInfo* __restrict__ slab, int num_tiles,
-                                                          const uint32_t* __restrict__ keys,
-                                                          uint2* __restrict__ ranges, ArenaHeaders3 headers) {
-    // the three arena headers ride along (one launch less per call)
-    if (blockIdx.x == 0 && threadIdx.x < 3 && headers.dst[threadIdx.x] != nullptr)
-        *reinterpret_cast<ArenaHeader*>(headers.dst[threadIdx.x]) = headers.h[threadIdx.x];
-    // One binary search per tile (a chain of ~22 dependent loads: the kernel is that latency): the end of a tile's
-    // list is the beginning of the next tile's, taken from the neighbouring lane through LDS.
+__global__ void __launch_bounds__(256) tile_ranges_kernel(RangesDuty duty) {
     __shared__ uint32_t s_first[256];
-    const int t = blockIdx.x * 255 + threadIdx.x;   // 256 boundaries per workgroup = 255 tiles
-    const uint32_t n = slab->pairs;
-    s_first[threadIdx.x] = lower_bound_u32(keys, n, (uint32_t)min(t, num_tiles));
-    __syncthreads();
-    if (threadIdx.x == 255 || t >= num_tiles) return;
-    const uint32_t b = s_first[threadIdx.x], e = s_first[threadIdx.x + 1];
-    ranges[t] = (e > b) ? make_uint2(b, e) : make_uint2(0u, 0u);
+    tile_ranges_duty(duty, blockIdx.x, s_first);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -821,15 +796,8 @@ hipError_t launch_expand(const BinningArrays& a, int slab, uint32_t pairs_bound,
     return hipGetLastError();
 }
 
-hipError_t launch_tile_ranges(const SlabInfo* slab, int num_tiles, const uint32_t* sorted_tile_keys, uint2* ranges,
-                              void* const header_dst[3], const ArenaHeader headers[3], hipStream_t stream) {
-    ArenaHeaders3 a = {};
-    for (int i = 0; i < 3; ++i) {
-        a.dst[i] = header_dst ? header_dst[i] : nullptr;
-        if (header_dst) a.h[i] = headers[i];
-    }
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(div_up(num_tiles, 255)), dim3(256), 0, stream, slab, num_tiles,
-                       sorted_tile_keys, ranges, a);
+hipError_t launch_tile_ranges(const RangesDuty& duty, hipStream_t stream) {
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(ranges_duty_blocks(duty.num_tiles)), dim3(256), 0, stream, duty);
     return hipGetLastError();
 }
 

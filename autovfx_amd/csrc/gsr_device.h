@@ -13,6 +13,37 @@ inline int div_up(int a, int b) { return (a + b - 1) / b; }
 // their maxima): the wave-level hand-overs through LDS below must not also wait for global stores still in flight.
 #define GSR_WAIT_LDS() __builtin_amdgcn_s_waitcnt(0xC07F)
 
+// ------------------------------------------------------------------------------------------------
+// K5 (identifyTileRanges, rasterizer_impl.cu:116-138): ranges[t] = [lower_bound(t), lower_bound(t + 1)) over the sorted
+// tile keys; (0,0) when empty, which is what the reference's memset + boundary scan leaves behind.  One binary search
+// per tile (a chain of ~22 dependent loads: that latency is all it costs); the end of a tile's list is the beginning of
+// the next tile's, taken from the neighbouring lane through LDS.  Called by every lane of a 256-lane workgroup with
+// block < ranges_duty_blocks(num_tiles): the stand-alone kernel, or the first workgroups of a colour kernel, where the
+// search latency hides behind the kernel's streaming work.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__ a, uint32_t n, uint32_t v) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ void tile_ranges_duty(const RangesDuty& d, uint32_t block, uint32_t* s_first /*256 words of LDS*/) {
+    if (block == 0 && threadIdx.x < 3 && d.header_dst[threadIdx.x] != nullptr)
+        *reinterpret_cast<ArenaHeader*>(d.header_dst[threadIdx.x]) = d.headers[threadIdx.x];
+    const int t = (int)block * 255 + (int)threadIdx.x;   // 256 boundaries per workgroup = 255 tiles
+    const uint32_t n = d.slab->pairs;
+    s_first[threadIdx.x] = lower_bound_u32(d.keys, n, (uint32_t)min(t, d.num_tiles));
+    __syncthreads();
+    if (threadIdx.x != 255 && t < d.num_tiles) {
+        const uint32_t b = s_first[threadIdx.x], e = s_first[threadIdx.x + 1];
+        d.ranges[t] = (e > b) ? make_uint2(b, e) : make_uint2(0u, 0u);
+    }
+    __syncthreads();   // (the caller may reuse the LDS)
+}
+
 // 4-byte aligned aggregates: the compiler may still fuse them into dwordx3/x4 accesses, but no
 // 16-byte alignment is assumed of caller tensors.
 struct __attribute__((aligned(4))) F3 { float x, y, z; };

@@ -95,6 +95,33 @@ struct GeometryArrays {
     uint8_t* listed;      // nullable: one byte per Gaussian, cleared here for the pair expansion's marks (deferred colours)
 };
 
+// First 256 bytes of each scratch arena: what the backward pass needs to find the forward's arrays
+// again.  The reference re-derives its layout from sizes (rasterizer_impl.cu:381-383 fromChunk);
+// ours also depends on which radix ping-pong buffer ended up holding the sorted list, so it is recorded.
+constexpr uint32_t kArenaMagic = 0x47535231u;  // "GSR1"
+struct ArenaHeader {
+    uint32_t magic;
+    uint32_t kind;      // 0 geometry, 1 binning, 2 image
+    uint32_t count[4];  // geometry: P, num_rendered (reference), slabs, inference flag; binning: slabs; image: W, H, T, slabs
+    uint32_t pad[2];
+    uint64_t off[8];    // byte offsets from the header's own address (geometry: 0 raster, 3 rgb, 4 radii, 5 slab table,
+                        // 6 quadrant bits, 7 tile bit rows; image: 1 n_contrib)
+    uint64_t slab_off[kMaxSlabs];  // binning: the sorted point list of slab s; image: its tile ranges
+};
+static_assert(sizeof(ArenaHeader) <= 256, "arena headers occupy the first 256 bytes");
+
+// The per-tile [begin, end) of one slab's sorted list (K5, identifyTileRanges): 255 tiles per 256-lane workgroup, so
+// div_up(num_tiles, 255) workgroups of whatever kernel carries the duty (gsr_device.h: tile_ranges_duty).
+struct RangesDuty {
+    const SlabInfo* slab;          // pairs = number of sorted keys
+    int num_tiles;
+    const uint32_t* keys;          // sorted tile ids
+    uint2* ranges;
+    ArenaHeader headers[3];        // stamped at header_dst[i] by workgroup 0 when non-null (the call's last ranges duty)
+    void* header_dst[3];
+};
+inline int ranges_duty_blocks(int num_tiles) { return (num_tiles + 254) / 255; }
+
 // ---- kernels (gsr_kernels.hip: per-Gaussian and per-pixel streaming kernels) ----
 hipError_t launch_preprocess(const GaussianInputs& in, const Camera& cam, const GeometryArrays& out,
                              hipStream_t stream);
@@ -102,10 +129,12 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmat
                                hipStream_t stream);
 // SH colours of the Gaussians the pair expansion of one slab marked (`listed[gid] == tag`, tag = slab + 1;
 // GaussianInputs::defer_colour), evaluated in Gaussian order; rgb[gid] is written.
+// `duty` (nullable): the slab's tile ranges are computed by the first workgroups of the same launch.
 hipError_t launch_sh_colour_listed(const GaussianInputs& in, const Camera& cam, const uint8_t* listed, int tag, const SlabInfo* slab,
-                                   float* rgb, hipStream_t stream);
+                                   float* rgb, const RangesDuty* duty, hipStream_t stream);
 // ... of every splat that emits pairs at all, in Gaussian order (a deferred-colour call that needs no depth slabs)
-hipError_t launch_sh_colour_all(const GaussianInputs& in, const Camera& cam, const SplatBin* bins, float* rgb, hipStream_t stream);
+hipError_t launch_sh_colour_all(const GaussianInputs& in, const Camera& cam, const SplatBin* bins, float* rgb, const RangesDuty* duty,
+                                hipStream_t stream);
 
 // ---- binning (gsr_binning.hip): from the depth order to per-tile lists, slab by slab ----
 // What the binning kernels share for one call.
@@ -150,11 +179,11 @@ hipError_t launch_expand(const BinningArrays& a, int slab, uint32_t pairs_bound,
 hipError_t launch_list_order_check(const SlabInfo* slab, uint32_t pairs_bound, const uint32_t* sorted_tile_keys,
                                    const uint32_t* point_list, const SplatRaster* raster, FrameCounters* counters,
                                    hipStream_t stream);
-struct ArenaHeader;
+struct RangesDuty;
 // ranges[t] = [first, last) positions of tile t in the sorted keys ((0,0) when empty); the number of keys is read from
-// slab->pairs.  header_dst may be null; otherwise the three arena headers are stamped by the same launch.
-hipError_t launch_tile_ranges(const SlabInfo* slab, int num_tiles, const uint32_t* sorted_tile_keys, uint2* ranges,
-                              void* const header_dst[3], const ArenaHeader headers[3], hipStream_t stream);
+// slab->pairs.  The three arena headers may ride along (RangesDuty::header_dst).  A stand-alone launch; calls that
+// evaluate deferred colours hand the same duty to the first workgroups of their colour kernel instead (one launch less).
+hipError_t launch_tile_ranges(const RangesDuty& duty, hipStream_t stream);
 
 // ---- blend (gsr_blend.hip) ----
 // One list segment per slab; a launch walks segments [seg_begin, seg_end).  `fresh`: pixels start from T = 1 (else
@@ -170,21 +199,6 @@ hipError_t launch_blend(const Camera& cam, const BlendSegments& segs, int seg_be
                         int row_words, hipStream_t stream, const float* extra_features = nullptr, float* out_extra = nullptr);
 // counts the floats with bit patterns first_bits .. first_bits + count - 1 on which the blend's exp differs from expf
 hipError_t launch_exp_selftest(uint32_t first_bits, uint32_t count, unsigned long long* mismatches, hipStream_t stream);
-
-// First 256 bytes of each scratch arena: what the backward pass needs to find the forward's arrays
-// again.  The reference re-derives its layout from sizes (rasterizer_impl.cu:381-383 fromChunk);
-// ours also depends on which radix ping-pong buffer ended up holding the sorted list, so it is recorded.
-constexpr uint32_t kArenaMagic = 0x47535231u;  // "GSR1"
-struct ArenaHeader {
-    uint32_t magic;
-    uint32_t kind;      // 0 geometry, 1 binning, 2 image
-    uint32_t count[4];  // geometry: P, num_rendered (reference), slabs, inference flag; binning: slabs; image: W, H, T, slabs
-    uint32_t pad[2];
-    uint64_t off[8];    // byte offsets from the header's own address (geometry: 0 raster, 3 rgb, 4 radii, 5 slab table,
-                        // 6 quadrant bits, 7 tile bit rows; image: 1 n_contrib)
-    uint64_t slab_off[kMaxSlabs];  // binning: the sorted point list of slab s; image: its tile ranges
-};
-static_assert(sizeof(ArenaHeader) <= 256, "arena headers occupy the first 256 bytes");
 
 struct BackwardInputs {
     int P, sh_degree, M;

@@ -296,12 +296,16 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) sh_colour_listed_kernel(GaussianInputs in, const float* __restrict__ cam_pos,
                                                                const uint8_t* __restrict__ listed, int tag,
-                                                               const SlabInfo* __restrict__ slab, float* __restrict__ rgb) {
+                                                               const SlabInfo* __restrict__ slab, float* __restrict__ rgb,
+                                                               RangesDuty duty, int duty_blocks) {
     // A wave looks at 256 consecutive Gaussians (4 marks per lane), packs the marked ones into a list in LDS (a scan of
     // the lanes' counts: their order is kept, so addresses still ascend) and evaluates that list with full
     // lanes.  One Gaussian per lane would run the whole evaluation for every wave that holds a single marked Gaussian:
     // at C3's 22 % that was 9.8 M vector instructions per launch for 1.5 M worth of work.
     __shared__ uint32_t s_list[4][256];
+    // The slab's tile ranges ride on the first workgroups (gsr_device.h: tile_ranges_duty): their ~8 us of dependent loads
+    // disappear behind the kernel's streaming work instead of being a launch of their own between the sort and this one.
+    if ((int)blockIdx.x < duty_blocks) tile_ranges_duty(duty, blockIdx.x, &s_list[0][0]);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int first = (blockIdx.x * 4 + wave) * 256;   // this wave's 256 Gaussians
     if (first >= in.P || slab->pairs == 0u) return;    // (a slab that found every tile finished lists nothing)
@@ -351,7 +355,10 @@ __global__ void __launch_bounds__(256) sh_colour_listed_kernel(GaussianInputs in
 // ran without colours): every splat that emits pairs at all, in GAUSSIAN order, so that the 192-byte records are read
 // as the projection kernel would have read them (lane-strided, every line used) instead of gathered in depth order.
 __global__ void __launch_bounds__(256) sh_colour_all_kernel(GaussianInputs in, const float* __restrict__ cam_pos,
-                                                            const SplatBin* __restrict__ bins, float* __restrict__ rgb) {
+                                                            const SplatBin* __restrict__ bins, float* __restrict__ rgb,
+                                                            RangesDuty duty, int duty_blocks) {
+    __shared__ uint32_t s_first[256];
+    if ((int)blockIdx.x < duty_blocks) tile_ranges_duty(duty, blockIdx.x, s_first);   // (as in sh_colour_listed_kernel)
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= in.P || bins[i].wh == 0u) return;
     int deg = in.sh_degree < 3 ? in.sh_degree : 3;
@@ -499,16 +506,24 @@ hipError_t launch_preprocess(const GaussianInputs& in, const Camera& cam, const 
     return hipGetLastError();
 }
 
+// A colour launch carries the ranges duty only when it has at least as many workgroups as the duty needs.
 hipError_t launch_sh_colour_listed(const GaussianInputs& in, const Camera& cam, const uint8_t* listed, int tag, const SlabInfo* slab,
-                                   float* rgb, hipStream_t stream) {
-    if (in.P <= 0) return hipSuccess;
-    hipLaunchKernelGGL(sh_colour_listed_kernel, dim3(div_up(in.P, 1024)), dim3(256), 0, stream, in, cam.cam_pos, listed, tag, slab, rgb);
+                                   float* rgb, const RangesDuty* duty, hipStream_t stream) {
+    const int blocks = div_up(in.P, 1024);
+    if (in.P <= 0 || (duty != nullptr && blocks < ranges_duty_blocks(duty->num_tiles))) return hipErrorInvalidValue;
+    RangesDuty none = {};
+    hipLaunchKernelGGL(sh_colour_listed_kernel, dim3(blocks), dim3(256), 0, stream, in, cam.cam_pos, listed, tag, slab, rgb,
+                       duty ? *duty : none, duty ? ranges_duty_blocks(duty->num_tiles) : 0);
     return hipGetLastError();
 }
 
-hipError_t launch_sh_colour_all(const GaussianInputs& in, const Camera& cam, const SplatBin* bins, float* rgb, hipStream_t stream) {
-    if (in.P <= 0) return hipSuccess;
-    hipLaunchKernelGGL(sh_colour_all_kernel, dim3(div_up(in.P, 256)), dim3(256), 0, stream, in, cam.cam_pos, bins, rgb);
+hipError_t launch_sh_colour_all(const GaussianInputs& in, const Camera& cam, const SplatBin* bins, float* rgb, const RangesDuty* duty,
+                                hipStream_t stream) {
+    const int blocks = div_up(in.P, 256);
+    if (in.P <= 0 || (duty != nullptr && blocks < ranges_duty_blocks(duty->num_tiles))) return hipErrorInvalidValue;
+    RangesDuty none = {};
+    hipLaunchKernelGGL(sh_colour_all_kernel, dim3(blocks), dim3(256), 0, stream, in, cam.cam_pos, bins, rgb, duty ? *duty : none,
+                       duty ? ranges_duty_blocks(duty->num_tiles) : 0);
     return hipGetLastError();
 }
 
