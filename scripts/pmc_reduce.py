@@ -5,6 +5,10 @@ from collections import defaultdict
 
 src, dst = sys.argv[1], sys.argv[2]
 acc = defaultdict(lambda: [0.0, 0])
+# the three radix kernels serve both sorts of a frame: a launch over ceil(P / 4096) tiles belongs to the depth sort
+P_GAUSSIANS = int(os.environ.get("GSR_PMC_P", "3000000"))
+DEPTH_GRID = ((P_GAUSSIANS + 4095) // 4096) * 256
+by_sort = defaultdict(lambda: [0.0, 0])   # (kernel, counter, "depth" | "tile") -> [sum, launches]
 for path in glob.glob(os.path.join(src, "*", "**", "*counter_collection.csv"), recursive=True):
     with open(path) as f:
         for r in csv.DictReader(f):
@@ -16,6 +20,9 @@ for path in glob.glob(os.path.join(src, "*", "**", "*counter_collection.csv"), r
             short = short.split("(")[0].replace("gsr::", "")
             a = acc[(short, r["Counter_Name"])]
             a[0] += float(r["Counter_Value"]); a[1] += 1
+            if short.startswith(("radix_count_kernel", "radix_scatter_kernel")):
+                b = by_sort[(short.split("<")[0], r["Counter_Name"], "depth" if int(r["Grid_Size"]) == DEPTH_GRID else "tile")]
+                b[0] += float(r["Counter_Value"]); b[1] += 1
 # a kernel dispatch is reported once per XCD / dimension by some counters: normalise by launches of the kernel
 with open(dst, "w") as f:
     f.write("# rocprofv3 --pmc passes (one counter group per run, kernel-trace only), bench.py --steps 6 --warmup 2 --streams 1, C3 workload\n")
@@ -49,8 +56,31 @@ if len(sys.argv) >= 5:
         e["launches"] += v["launches_per_frame"] or 0.0
     kernels = {k: {"bytes_per_launch": e["bytes"] / e["launches"] if e["launches"] else 0.0, "launches_per_frame": e["launches"]}
                for k, e in kernels.items()}
+    # HBM-side bytes per frame and pipeline stage (bench.py's per-stage counter figures)
+    stage_of = {"preprocess_kernel": "preprocess", "bin_gather_kernel": "duplicate", "bin_offsets_kernel": "duplicate",
+                "slab_recount_kernel": "duplicate", "slab_compact_kernel": "duplicate", "expand_kernel": "duplicate",
+                "tile_ranges_kernel": "ranges", "sh_colour_listed_kernel": "colour", "sh_colour_all_kernel": "colour",
+                "blend_quadrant_kernel": "blend"}
+    stages = defaultdict(float)
+    for k, e in kernels.items():
+        if k in stage_of:
+            stages[stage_of[k]] += e["bytes_per_launch"] * e["launches_per_frame"]
+    sort_launches = {"depth": 0.0, "tile": 0.0}
+    for kern in ("radix_count_kernel", "radix_scatter_kernel"):
+        for which in ("depth", "tile"):
+            fs, ws = by_sort.get((kern, "FETCH_SIZE", which)), by_sort.get((kern, "WRITE_SIZE", which))
+            if fs and ws and frames:
+                stages[which + "_sort"] += (2.0 * fs[0] + ws[0]) * 1024.0 / frames
+                if kern == "radix_count_kernel":
+                    sort_launches[which] = fs[1] / frames
+    scan = kernels.get("radix_scan_kernel")
+    if scan and sum(sort_launches.values()) > 0:   # the scan kernel's grid does not depend on the item count: split by launches
+        tot = scan["bytes_per_launch"] * scan["launches_per_frame"]
+        for which in ("depth", "tile"):
+            stages[which + "_sort"] += tot * sort_launches[which] / sum(sort_launches.values())
     with open(sys.argv[3], "w") as f:
         json.dump({"commit": sys.argv[4], "workload": "c3", "command": "bench.py --profile-run --steps 6 --warmup 2 --streams 1",
                    "formula": "(2 * FETCH_SIZE + WRITE_SIZE) KiB * 1024, mean per launch; frame = sum over kernels x launches per frame",
-                   "frames_profiled": frames, "frame_bytes": frame_bytes, "kernels": kernels, "variants": per_variant}, f, indent=1)
+                   "frames_profiled": frames, "frame_bytes": frame_bytes, "stages": dict(stages), "kernels": kernels,
+                   "variants": per_variant}, f, indent=1)
     print("frame traffic bytes:", int(frame_bytes))
