@@ -499,6 +499,24 @@ int gsr_normal_maps(int width, int height, const float* normal_rgb, const float*
     return GSR_OK;
 }
 
+int gsr_place_object(int n, const float* xyz, const float* rotation_raw, const float* log_scale, const float* opacity, const float* shs,
+                     int M, const float* placement, float* out_means3D, float* out_scales, float* out_rotations, float* out_opacities,
+                     float* out_shs, void* stream_) {
+    if (n < 0) return fail(GSR_ERR_INVALID_ARG, "bad size n=%d", n);
+    if (n == 0) return GSR_OK;
+    if (!xyz || !rotation_raw || !log_scale || !placement || !out_means3D || !out_scales || !out_rotations)
+        return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    if ((out_opacities != nullptr) != (opacity != nullptr) || (out_shs != nullptr) != (shs != nullptr))
+        return fail(GSR_ERR_INVALID_ARG, "opacity / shs and their outputs must be given together");
+    if (shs != nullptr && M <= 0) return fail(GSR_ERR_INVALID_ARG, "shs given with M=%d", M);
+    gsr::ObjectPlacement pl;
+    static_assert(sizeof(gsr::ObjectPlacement) == 21 * sizeof(float), "the placement block is 21 floats");
+    memcpy(&pl, placement, sizeof pl);
+    GSR_HIP(gsr::launch_place_object(n, xyz, rotation_raw, log_scale, opacity, shs, M, pl, out_means3D, out_scales, out_rotations,
+                                     out_opacities, out_shs, (hipStream_t)stream_));
+    return GSR_OK;
+}
+
 int gsr_selftest_exp(uint32_t first_bits, uint32_t count, unsigned long long* device_mismatches, void* stream_) {
     if (!device_mismatches || count > 0x7FFFFFFFu) return fail(GSR_ERR_INVALID_ARG, "bad selftest arguments");
     if (count == 0) return GSR_OK;

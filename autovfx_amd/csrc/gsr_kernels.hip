@@ -618,6 +618,74 @@ __global__ void __launch_bounds__(256) normal_maps_kernel(NormalMapArgs a) {
     *reinterpret_cast<F3*>(a.pseudo + 3 * pid) = n;
 }
 
+// ------------------------------------------------------------------------------------------------
+// gsr_place_object: the per-frame rigid-body placement of one inserted object (gaussians_utils.py:85-118
+// transform_gaussians) fused with the activations the render path applies afterwards (gaussian_model.py:95-128) and
+// written straight into the object's slice of the resident scene buffers -- what the reference does with a deep copy of
+// the scene, a PLY reload, ~10 PyTorch launches and a concatenation of everything, per frame.  One lane per Gaussian;
+// every arithmetic step is a separate fp32 rounding in the reference's order (the library is built without contraction).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) place_object_kernel(int n, const float* __restrict__ xyz, const float* __restrict__ rot,
+                                                           const float* __restrict__ log_scale, const float* __restrict__ opacity,
+                                                           const float* __restrict__ shs, int M, ObjectPlacement pl,
+                                                           float* __restrict__ out_xyz, float* __restrict__ out_scales,
+                                                           float* __restrict__ out_rot, float* __restrict__ out_opacity,
+                                                           float* __restrict__ out_shs) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        // gaussians_utils.py:94-96 (scale about the initial centre), :100-102 (rotate about it), :106-107 (translate)
+        const F3 p = ld3(xyz + 3 * (size_t)i);
+        float v[3] = {p.x, p.y, p.z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            v[k] = v[k] - pl.c0[k];
+            v[k] = v[k] * pl.s;
+            v[k] = v[k] + pl.c0[k];
+            v[k] = v[k] - pl.c0[k];
+        }
+        float w[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) w[j] = (v[0] * pl.R[3 * j + 0] + v[1] * pl.R[3 * j + 1]) + v[2] * pl.R[3 * j + 2];   // new_xyz @ R.T
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            w[k] = w[k] + pl.c0[k];
+            w[k] = w[k] + (pl.c[k] - pl.c0[k]);
+        }
+        *reinterpret_cast<F3*>(out_xyz + 3 * (size_t)i) = F3{w[0], w[1], w[2]};
+        // :97 new_scales += log(scaling), then exp (gaussian_model.py:96-97)
+        const F3 ls = ld3(log_scale + 3 * (size_t)i);
+        *reinterpret_cast<F3*>(out_scales + 3 * (size_t)i) = F3{expf(ls.x + pl.log_s), expf(ls.y + pl.log_s), expf(ls.z + pl.log_s)};
+        // :103 quaternion_multiply(matrix_to_quaternion(R), q) (rotation_utils.py:113-135), then F.normalize (gaussian_model.py:100-101)
+        const F4 b = *reinterpret_cast<const F4*>(rot + 4 * (size_t)i);
+        const float aw = pl.qR[0], ax = pl.qR[1], ay = pl.qR[2], az = pl.qR[3];
+        float ow = aw * b.x - ax * b.y - ay * b.z - az * b.w;
+        float ox = aw * b.y + ax * b.x + ay * b.w - az * b.z;
+        float oy = aw * b.z - ax * b.w + ay * b.x + az * b.y;
+        float oz = aw * b.w + ax * b.z - ay * b.y + az * b.x;
+        if (ow < 0.f) { ow = -ow; ox = -ox; oy = -oy; oz = -oz; }   // standardize_quaternion
+        const float norm = fmaxf(sqrtf(((ow * ow + ox * ox) + oy * oy) + oz * oz), 1e-12f);
+        *reinterpret_cast<F4*>(out_rot + 4 * (size_t)i) = F4{ow / norm, ox / norm, oy / norm, oz / norm};
+        if (out_opacity != nullptr) out_opacity[i] = opacity[i];
+    }
+    if (out_shs != nullptr) {   // the object's SH block copied as one contiguous run: 3 M floats per Gaussian, 16-byte pieces
+        const size_t words = (size_t)n * 3u * (size_t)M;
+        for (size_t w4 = (size_t)blockIdx.x * 256u + threadIdx.x; w4 * 4u < words; w4 += (size_t)gridDim.x * 256u) {
+            if (w4 * 4u + 3u < words && ((reinterpret_cast<uintptr_t>(shs) | reinterpret_cast<uintptr_t>(out_shs)) & 15u) == 0)
+                reinterpret_cast<float4*>(out_shs)[w4] = reinterpret_cast<const float4*>(shs)[w4];
+            else
+                for (size_t k = w4 * 4u; k < words && k < w4 * 4u + 4u; ++k) out_shs[k] = shs[k];
+        }
+    }
+}
+
+hipError_t launch_place_object(int n, const float* xyz, const float* rot, const float* log_scale, const float* opacity,
+                               const float* shs, int M, const ObjectPlacement& pl, float* out_xyz, float* out_scales, float* out_rot,
+                               float* out_opacity, float* out_shs, hipStream_t stream) {
+    hipLaunchKernelGGL(place_object_kernel, dim3(div_up(n, 256)), dim3(256), 0, stream, n, xyz, rot, log_scale, opacity, shs, M, pl, out_xyz,
+                       out_scales, out_rot, out_opacity, out_shs);
+    return hipGetLastError();
+}
+
 hipError_t launch_view_normals(int P, const float* means3D, const float* axis, const float* cam_pos, float* out,
                                hipStream_t stream) {
     hipLaunchKernelGGL(view_normals_kernel, dim3(div_up(P, 256)), dim3(256), 0, stream, P, means3D, axis, cam_pos, out);

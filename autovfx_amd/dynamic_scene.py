@@ -1,0 +1,150 @@
+"""Dynamic scenes: a static base cloud plus rigidly moving inserted objects, composed per frame without copying the scene.
+
+What the reference does for every frame of an edited scene (``scene_representation.py:357-372``): ``copy.deepcopy`` of the
+whole scene, ``load_ply`` of every inserted object from disk, ``transform_gaussians`` (``gaussians_utils.py:85-118``:
+scale, rotate and translate the object's raw parameters about its initial centre, ~10 PyTorch launches),
+``merge_two_gaussians`` (``:71-82``: six ``torch.cat`` over everything, ~0.7 GB of copies for a 3 M-Gaussian scene), and
+then ``render()`` re-activates all of it.
+
+Here the scene lives in ONE set of resident, already ACTIVATED buffers sized for the base plus every object (288 GB of
+HBM hold hundreds of such scenes): the base part is written once, each object's raw parameters are loaded to the GPU
+once, and per frame one kernel per placed object (``gsr_place_object``, include/gsr.h) transforms, activates and writes that
+object's Gaussians at its offset.  A frame's cloud is a prefix view of the buffers -- base first, then the objects placed
+in that frame, in placement order, exactly the concatenation order of the reference -- handed to the rasterizer as is.
+The arithmetic is the reference's, operation by operation (``oracle/dynamic_oracle.py`` restates it; tests compare).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .scenes import GaussianCloud
+
+
+def matrix_to_quaternion(R) -> np.ndarray:
+    """``rotation_utils.py:24-85`` for one 3x3 matrix, fp32: (w, x, y, z) of the best-conditioned candidate."""
+    f32 = np.float32
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = (f32(v) for v in np.asarray(R, dtype=f32).reshape(9))
+    one = f32(1.0)
+    pre = np.array([one + m00 + m11 + m22, one + m00 - m11 - m22, one - m00 + m11 - m22, one - m00 - m11 + m22], dtype=f32)
+    q_abs = np.where(pre > 0, np.sqrt(np.maximum(pre, f32(0))), f32(0)).astype(f32)
+    sq = (q_abs * q_abs).astype(f32)
+    cand = np.array([[sq[0], m21 - m12, m02 - m20, m10 - m01], [m21 - m12, sq[1], m10 + m01, m02 + m20],
+                     [m02 - m20, m10 + m01, sq[2], m12 + m21], [m10 - m01, m20 + m02, m21 + m12, sq[3]]], dtype=f32)
+    cand = (cand / (f32(2.0) * np.maximum(q_abs, f32(0.1)))[:, None]).astype(f32)
+    return cand[int(np.argmax(q_abs))]
+
+
+def placement_block(center, R, scaling: float, initial_center) -> np.ndarray:
+    """The 21 floats ``gsr_place_object`` takes: centre[3], R[9] row-major, scale, initial centre[3], q_R[4], log(scale)."""
+    f32 = np.float32
+    R = np.asarray(R, dtype=f32).reshape(3, 3)
+    return np.concatenate((np.asarray(center, f32).reshape(3), R.reshape(9), [f32(scaling)], np.asarray(initial_center, f32).reshape(3),
+                           matrix_to_quaternion(R), [f32(math.log(float(scaling)))])).astype(f32)
+
+
+class _ObjectCloud:
+    """One inserted object, resident: raw xyz / rotation / log-scale (what the transform acts on), and the parts a rigid
+    placement does not change, activated once (opacity = sigmoid, SH = cat(dc, rest))."""
+
+    def __init__(self, model, initial_center, device):
+        t = lambda a: a.detach().to(device=device, dtype=torch.float32).contiguous()
+        self.xyz, self.rotation, self.log_scale = t(model._xyz), t(model._rotation), t(model._scaling)
+        self.opacity = torch.sigmoid(t(model._opacity)).contiguous()
+        self.shs = torch.cat((t(model._features_dc), t(model._features_rest)), dim=1).contiguous()
+        self.initial_center = np.asarray(initial_center, dtype=np.float32).reshape(3)
+        self.P = int(self.xyz.shape[0])
+
+
+class DynamicScene:
+    """``DynamicScene(base_model, {object_id: (object_model, initial_center)})``; models carry the reference's raw parameters
+    (``autovfx_amd.gaussian_model.GaussianModel`` or anything with ``_xyz, _rotation, _scaling, _opacity, _features_dc,
+    _features_rest``).  ``compose(placements)`` returns the frame's ``GaussianCloud`` (activated tensors, views of the resident
+    buffers: valid until the next ``compose`` on the same stream)."""
+
+    def __init__(self, base, objects: Dict[str, Tuple[object, Sequence[float]]], device="cuda:0", sh_degree: Optional[int] = None):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DynamicScene places objects with a HIP kernel: it needs a GPU (there is no CPU fallback)")
+        t = lambda a: a.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        self.objects = {k: _ObjectCloud(m, c0, self.device) for k, (m, c0) in objects.items()}
+        self.P_base = int(base._xyz.shape[0])
+        cap = self.P_base + sum(o.P for o in self.objects.values())
+        M = int(base._features_dc.shape[1] + base._features_rest.shape[1])
+        for k, o in self.objects.items():
+            if int(o.shs.shape[1]) != M:
+                raise ValueError(f"object {k!r} has {int(o.shs.shape[1])} SH coefficients, the scene {M}")
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=self.device)
+        self.means3D, self.scales, self.rotations = new(cap, 3), new(cap, 3), new(cap, 4)
+        self.opacities, self.shs = new(cap, 1), new(cap, M, 3)
+        self.sh_degree = int(sh_degree if sh_degree is not None else getattr(base, "active_sh_degree", 3))
+        with torch.no_grad():   # the base part, once: the activations render() would redo every frame (gaussian_model.py:95-128)
+            n = self.P_base
+            self.means3D[:n] = t(base._xyz)
+            self.scales[:n] = torch.exp(t(base._scaling))
+            self.rotations[:n] = torch.nn.functional.normalize(t(base._rotation))
+            self.opacities[:n] = torch.sigmoid(t(base._opacity))
+            self.shs[:n] = torch.cat((t(base._features_dc), t(base._features_rest)), dim=1)
+        self.capacity, self.M = cap, M
+
+    def compose(self, placements: Iterable[Tuple[str, Sequence[float], Sequence[Sequence[float]], float]]) -> GaussianCloud:
+        """``placements``: the objects present in this frame, in merge order, each ``(object_id, center[3], rotation[3][3],
+        scaling)`` -- ``rb_transform['pos'], ['rot'], ['scale']`` of ``scene_representation.py:364-366``.  An object may be
+        placed more than once (the buffers then need room for it: ``ValueError`` otherwise)."""
+        from . import _lib
+        at = self.P_base
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        with torch.cuda.device(self.device):
+            for obj_id, center, rotation, scaling in placements:
+                o = self.objects[obj_id]
+                if at + o.P > self.capacity:
+                    raise ValueError("the scene buffers have no room for another copy of " + repr(obj_id))
+                block = (ctypes.c_float * 21)(*placement_block(center, rotation, scaling, o.initial_center).tolist())
+                rc = _lib.lib.gsr_place_object(
+                    o.P, o.xyz.data_ptr(), o.rotation.data_ptr(), o.log_scale.data_ptr(), o.opacity.data_ptr(), o.shs.data_ptr(), self.M,
+                    ctypes.byref(block), self.means3D[at:].data_ptr(), self.scales[at:].data_ptr(), self.rotations[at:].data_ptr(),
+                    self.opacities[at:].data_ptr(), self.shs[at:].data_ptr(), stream)
+                if rc != 0:
+                    raise RuntimeError(f"gsr_place_object failed ({rc}): {_lib.last_error()}")
+                at += o.P
+        return GaussianCloud(self.means3D[:at], self.opacities[:at], self.scales[:at], self.rotations[:at], self.shs[:at], None,
+                             self.sh_degree)
+
+
+def reference_shaped_compose(base, objects: Dict[str, Tuple[object, Sequence[float]]], placements, device) -> GaussianCloud:
+    """The same frame composed the reference's way with PyTorch on the GPU -- clone the base parameters, transform each
+    placed object's raw parameters with the reference's sequence of tensor operations (``gaussians_utils.py:85-118``),
+    concatenate everything (``:71-82``), activate (``gaussian_model.py:95-128``) -- minus the per-frame PLY reload.  The
+    measuring stick for ``DynamicScene`` (bench.py ``also.c5_dynamic``) and its on-GPU parity partner (tests)."""
+    t = lambda a: a.detach().to(device=device, dtype=torch.float32)
+    parts = {k: [t(getattr(base, k)).clone()] for k in ("_xyz", "_rotation", "_scaling", "_opacity", "_features_dc", "_features_rest")}
+    for obj_id, center, rotation, scaling in placements:
+        m, c0 = objects[obj_id]
+        c0 = torch.as_tensor(np.asarray(c0, np.float32), device=device)
+        center = torch.as_tensor(np.asarray(center, np.float32), device=device)
+        R = torch.as_tensor(np.asarray(rotation, np.float32).reshape(3, 3), device=device)
+        xyz, rot, ls = t(m._xyz).clone(), t(m._rotation).clone(), t(m._scaling).clone()
+        xyz -= c0.unsqueeze(0); xyz *= scaling; xyz += c0.unsqueeze(0)
+        ls += np.log(scaling)
+        xyz -= c0.unsqueeze(0)
+        xyz = torch.matmul(xyz, R.T)
+        xyz += c0.unsqueeze(0)
+        qR = torch.as_tensor(matrix_to_quaternion(R.cpu().numpy()), device=device)
+        aw, ax, ay, az = torch.unbind(qR.expand_as(rot), -1)
+        bw, bx, by, bz = torch.unbind(rot, -1)
+        q = torch.stack((aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                         aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw), -1)
+        q = torch.where(q[..., 0:1] < 0, -q, q)
+        xyz += (center - c0).unsqueeze(0)
+        for k, v in (("_xyz", xyz), ("_rotation", q), ("_scaling", ls), ("_opacity", t(m._opacity)), ("_features_dc", t(m._features_dc)),
+                     ("_features_rest", t(m._features_rest))):
+            parts[k].append(v)
+    cat = {k: torch.cat(v, dim=0) for k, v in parts.items()}
+    return GaussianCloud(cat["_xyz"].contiguous(), torch.sigmoid(cat["_opacity"]).contiguous(), torch.exp(cat["_scaling"]).contiguous(),
+                         torch.nn.functional.normalize(cat["_rotation"]).contiguous(),
+                         torch.cat((cat["_features_dc"], cat["_features_rest"]), dim=1).contiguous(), None,
+                         int(getattr(base, "active_sh_degree", 3)))

@@ -214,6 +214,29 @@ GSR_API int gsr_view_normals(int P, const float* means3D, const float* axis, con
 GSR_API int gsr_normal_maps(int width, int height, const float* normal_rgb, const float* depth, const float* c2w,
                             float fx, float fy, float cx, float cy, float* normal, float* pseudo_normal, void* stream);
 
+/*
+ * Dynamic scenes (BASELINE configs[4]; SURVEY.md: scene_representation.py:357-372): for every frame of an edited scene the
+ * reference deep-copies the whole scene, re-loads each inserted object's PLY, applies the frame's rigid-body transform in
+ * PyTorch (gaussians_utils.py:85-118 transform_gaussians) and concatenates everything (:71-82 merge_two_gaussians, ~0.7 GB
+ * of copies at 3 M Gaussians) before it calls render().  Here the scene lives in ONE resident buffer set sized for the base
+ * scene plus all objects; the base part is written once, and per frame only the objects are placed:
+ *
+ * gsr_place_object transforms n Gaussians of one object from their RAW parameters (as the PLY holds them) and writes them
+ * ACTIVATED (what the rasterizer consumes) at the given output pointers, i.e. at the object's offset in the scene buffers:
+ *   xyz        : ((x - c0) * s + c0 - c0) R^T + c0 + (c - c0), every operation a separate fp32 rounding in exactly that
+ *                order (gaussians_utils.py:94-108; the 3x3 product as (x0 r0 + x1 r1) + x2 r2)
+ *   rotation   : unit( standardize( q_R (x) q_raw ) ) with q_R = matrix_to_quaternion(R) supplied by the caller
+ *                (rotation_utils.py:24-85,113-135; F.normalize as gaussian_model.py:100-101)
+ *   scale      : exp(log_scale + log_s)          (gaussians_utils.py:97 then gaussian_model.py:96-97)
+ *   opacity, SH: copied (already activated / concatenated by the caller once per object; nullable = leave as is)
+ * placement: 21 host floats -- center c[3], rotation R[9] row-major, scale s, initial_center c0[3], q_R[4] (w,x,y,z),
+ * log_s (= (float)log((double)s)).  One streaming kernel: 40 B in + 40 B out per Gaussian (+ 196 B each way with SH).
+ */
+GSR_API int gsr_place_object(int n, const float* xyz, const float* rotation_raw, const float* log_scale,
+                             const float* opacity /*nullable*/, const float* shs /*nullable*/, int M,
+                             const float* placement /*host, 21 floats*/, float* out_means3D, float* out_scales,
+                             float* out_rotations, float* out_opacities /*nullable*/, float* out_shs /*nullable*/, void* stream);
+
 /* Self-test of the blend kernel's exp(): adds to *device_mismatches (a zeroed device u64) the number of floats
  * with bit patterns first_bits .. first_bits + count - 1 whose exp differs from the device library's expf.
  * The blend evaluates exp only for arguments <= 0; tests sweep every float of [-103, 0]. */
