@@ -17,7 +17,7 @@ from __future__ import annotations
 
 import ctypes
 import math
-from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+from typing import Dict, Iterable, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -64,9 +64,14 @@ class DynamicScene:
     """``DynamicScene(base_model, {object_id: (object_model, initial_center)})``; models carry the reference's raw parameters
     (``autovfx_amd.gaussian_model.GaussianModel`` or anything with ``_xyz, _rotation, _scaling, _opacity, _features_dc,
     _features_rest``).  ``compose(placements)`` returns the frame's ``GaussianCloud`` (activated tensors, views of the resident
-    buffers: valid until the next ``compose`` on the same stream)."""
+    buffers: valid until the next ``compose`` into the same slot).
 
-    def __init__(self, base, objects: Dict[str, Tuple[object, Sequence[float]]], device="cuda:0", sh_degree: Optional[int] = None):
+    ``slots`` > 1 keeps that many independent copies of the scene buffers (a 3 M-Gaussian scene is 0.7 GB of 288): a driver
+    that holds several frames in flight on several HIP streams composes frame ``i`` into slot ``i % slots`` on the stream
+    that renders it, so a frame's objects are never overwritten while an earlier frame on another stream still reads them."""
+
+    def __init__(self, base, objects: Dict[str, Tuple[object, Sequence[float]]], device="cuda:0", sh_degree: Optional[int] = None,
+                 slots: int = 1):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("DynamicScene places objects with a HIP kernel: it needs a GPU (there is no CPU fallback)")
@@ -79,23 +84,26 @@ class DynamicScene:
             if int(o.shs.shape[1]) != M:
                 raise ValueError(f"object {k!r} has {int(o.shs.shape[1])} SH coefficients, the scene {M}")
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=self.device)
-        self.means3D, self.scales, self.rotations = new(cap, 3), new(cap, 3), new(cap, 4)
-        self.opacities, self.shs = new(cap, 1), new(cap, M, 3)
         self.sh_degree = int(sh_degree if sh_degree is not None else getattr(base, "active_sh_degree", 3))
+        self.capacity, self.M = cap, M
+        self._slots = []
         with torch.no_grad():   # the base part, once: the activations render() would redo every frame (gaussian_model.py:95-128)
             n = self.P_base
-            self.means3D[:n] = t(base._xyz)
-            self.scales[:n] = torch.exp(t(base._scaling))
-            self.rotations[:n] = torch.nn.functional.normalize(t(base._rotation))
-            self.opacities[:n] = torch.sigmoid(t(base._opacity))
-            self.shs[:n] = torch.cat((t(base._features_dc), t(base._features_rest)), dim=1)
-        self.capacity, self.M = cap, M
+            first = (t(base._xyz), torch.exp(t(base._scaling)), torch.nn.functional.normalize(t(base._rotation)),
+                     torch.sigmoid(t(base._opacity)), torch.cat((t(base._features_dc), t(base._features_rest)), dim=1))
+            for _ in range(max(1, int(slots))):
+                bufs = (new(cap, 3), new(cap, 3), new(cap, 4), new(cap, 1), new(cap, M, 3))
+                for dst, src in zip(bufs, first):
+                    dst[:n] = src
+                self._slots.append(bufs)
+        self.means3D, self.scales, self.rotations, self.opacities, self.shs = self._slots[0]
 
-    def compose(self, placements: Iterable[Tuple[str, Sequence[float], Sequence[Sequence[float]], float]]) -> GaussianCloud:
+    def compose(self, placements: Iterable[Tuple[str, Sequence[float], Sequence[Sequence[float]], float]], slot: int = 0) -> GaussianCloud:
         """``placements``: the objects present in this frame, in merge order, each ``(object_id, center[3], rotation[3][3],
         scaling)`` -- ``rb_transform['pos'], ['rot'], ['scale']`` of ``scene_representation.py:364-366``.  An object may be
         placed more than once (the buffers then need room for it: ``ValueError`` otherwise)."""
         from . import _lib
+        means3D, scales, rotations, opacities, shs = self._slots[slot % len(self._slots)]
         at = self.P_base
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         with torch.cuda.device(self.device):
@@ -106,13 +114,12 @@ class DynamicScene:
                 block = (ctypes.c_float * 21)(*placement_block(center, rotation, scaling, o.initial_center).tolist())
                 rc = _lib.lib.gsr_place_object(
                     o.P, o.xyz.data_ptr(), o.rotation.data_ptr(), o.log_scale.data_ptr(), o.opacity.data_ptr(), o.shs.data_ptr(), self.M,
-                    ctypes.byref(block), self.means3D[at:].data_ptr(), self.scales[at:].data_ptr(), self.rotations[at:].data_ptr(),
-                    self.opacities[at:].data_ptr(), self.shs[at:].data_ptr(), stream)
+                    ctypes.byref(block), means3D[at:].data_ptr(), scales[at:].data_ptr(), rotations[at:].data_ptr(),
+                    opacities[at:].data_ptr(), shs[at:].data_ptr(), stream)
                 if rc != 0:
                     raise RuntimeError(f"gsr_place_object failed ({rc}): {_lib.last_error()}")
                 at += o.P
-        return GaussianCloud(self.means3D[:at], self.opacities[:at], self.scales[:at], self.rotations[:at], self.shs[:at], None,
-                             self.sh_degree)
+        return GaussianCloud(means3D[:at], opacities[:at], scales[:at], rotations[:at], shs[:at], None, self.sh_degree)
 
 
 def reference_shaped_compose(base, objects: Dict[str, Tuple[object, Sequence[float]]], placements, device) -> GaussianCloud:

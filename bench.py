@@ -763,9 +763,96 @@ def run_also(device, side, S, parity=True):
         return out
 
     guarded("c5_render_and_composite", c5)
+    guarded("c5_dynamic", lambda: dynamic_scene_bench(device, side, S))
     guarded("c3_reference_shaped_render", lambda: reference_shaped_render(device))
     guarded("backward_c3", lambda: backward_iteration("c3", device, parity=parity))
     return also
+
+
+def dynamic_scene_bench(device, side, S, frames=120):
+    """BASELINE configs[4] with moving objects (scene_representation.py:357-372): the C2 scene (1 M Gaussians, 960x540) plus
+    two inserted objects of 60 k Gaussians, each with its own rigid transform per frame.  Three ways: the static scene (no
+    objects move: the buffers are composed once) as the yardstick; DynamicScene (one gsr_place_object launch per object and
+    frame into resident buffers); the reference's structure in PyTorch on the GPU (clone the scene, transform with ~10
+    launches per object, six concatenations over everything, re-activate everything) -- WITHOUT its per-frame PLY reload."""
+    import math
+    from autovfx_amd import scenes
+    from autovfx_amd.cameras import orbit_cameras
+    from autovfx_amd.dynamic_scene import DynamicScene, reference_shaped_compose
+    from autovfx_amd.frame_parallel import pack_rgba8, rasterize, rasterize_begin
+    from autovfx_amd.gaussian_model import GaussianModel
+    W, H = 960, 540
+    c = scenes.config_c2()
+    base = GaussianModel.from_activated(c.means3D, c.opacities, c.scales, c.rotations, c.shs, 3)
+    objs = {}
+    for k, name in enumerate(("a", "b")):
+        o = scenes.config_c1(P=60_000, seed=70 + k)
+        objs[name] = (GaussianModel.from_activated(o.means3D * 0.25, o.opacities, o.scales * 0.25, o.rotations, o.shs, 3), (0.0, 0.0, 0.0))
+
+    def rz(deg):
+        t = math.radians(deg)
+        return np.array([[math.cos(t), -math.sin(t), 0], [math.sin(t), math.cos(t), 0], [0, 0, 1]], np.float32)
+
+    place = lambda f: [("a", (0.8 * math.cos(0.05 * f), 0.8 * math.sin(0.05 * f), 0.2), rz(3.0 * f), 1.0),
+                       ("b", (-0.5, 0.3 + 0.004 * f, 0.1 * math.sin(0.1 * f)), rz(-2.0 * f), 1.0 + 0.002 * f)]
+    cams = [cam.to(device) for cam in orbit_cameras(200, W, H)[:frames]]
+    bg = torch.zeros(3, device=device)
+    rgba = torch.empty((4, H, W), dtype=torch.uint8, device=device)
+    scene = DynamicScene(base, objs, device=device, slots=max(1, S))
+    static_cloud = scene.compose(place(0))
+
+    def serial(compose):
+        with torch.no_grad():
+            for f in range(frames):
+                color, _d, alpha, _r = rasterize(compose(f), cams[f], bg)
+                pack_rgba8(color, alpha, out=rgba)
+
+    def timed(fn):
+        fn()
+        secs = timed_regions(fn, 3, False, device)
+        return sorted(secs)[1] / frames * 1e3
+
+    out = {"workload": "C2 scene (1 M Gaussians, 960x540) + 2 inserted objects of 60 k Gaussians, each moved rigidly every frame",
+           "frames": frames, "P_frame": static_cloud.P}
+    out["static_ms_per_frame"] = round(timed(lambda: serial(lambda f: static_cloud)), 4)
+    out["ms_per_frame"] = round(timed(lambda: serial(lambda f: scene.compose(place(f)))), 4)
+    out["reference_shaped_ms_per_frame"] = round(timed(lambda: serial(lambda f: reference_shaped_compose(base, objs, place(f), device))), 4)
+    out["value"] = round(1e3 / out["ms_per_frame"], 1)
+    out["unit"] = "frames/s"
+    out["vs_static"] = round(out["static_ms_per_frame"] / out["ms_per_frame"], 3)
+    out["streams"] = 1
+    # several frames in flight: frame f composed into slot f % S on the stream that renders it
+    if S > 1:
+        from collections import deque
+
+        def pipelined():
+            with torch.no_grad():
+                q = deque()
+
+                def finish():
+                    st, p = q.popleft()
+                    with torch.cuda.stream(st):
+                        color, _d, alpha, _r = p.finish()
+                        pack_rgba8(color, alpha, out=rgba)
+
+                for f in range(frames):
+                    while len(q) == S:
+                        finish()
+                    st = side[f % S]
+                    with torch.cuda.stream(st):
+                        q.append((st, rasterize_begin(scene.compose(place(f), slot=f % S), cams[f], bg)))
+                while q:
+                    finish()
+                for st in side:
+                    torch.cuda.current_stream(device).wait_stream(st)
+
+        ms = timed(pipelined)
+        out["pipelined"] = {"streams": S, "ms_per_frame": round(ms, 4), "value": round(1e3 / ms, 1)}
+    with torch.no_grad():   # parity of one moving frame against the reference-shaped composition on the same GPU
+        a = rasterize(scene.compose(place(37)), cams[37], bg)[0].clone()
+        b = rasterize(reference_shaped_compose(base, objs, place(37), device), cams[37], bg)[0]
+    out["rgb_maxabs_vs_reference_shaped_frame37"] = float((a - b).abs().max())
+    return out
 
 
 def reference_shaped_render(device, key="c3", frames=24):
