@@ -106,30 +106,35 @@ def _require_gpu(t: torch.Tensor, what: str) -> torch.device:
     return t.device
 
 
-# ---- geometry reuse between the two passes of render() -------------------------------------------------------------
+# ---- geometry reuse between the two passes of render() (OPT-IN) ------------------------------------------------------
 # gaussian_renderer.render() calls the rasterizer twice per frame with the very same tensor objects for the
 # geometry (means3D, opacity, scales, rotations / cov3D, camera) and only the colour source changed
-# (gaussian_renderer/__init__.py:151-159 then :176-184).  When a call arrives whose geometry inputs are the SAME
-# tensor objects at the SAME autograd version as the call just before it on this thread and stream, and it brings
-# precomputed colours, everything up to the per-tile lists is reused and only the blend kernel runs.
-# Contract (also in INTEGRATION.md):
+# (gaussian_renderer/__init__.py:151-159 then :176-184).  With the reuse switched on, a call whose geometry inputs are the
+# SAME tensor objects at the SAME autograd version as the call just before it on this thread and stream, and which brings
+# precomputed colours, reuses everything up to the per-tile lists: only the blend kernel runs (bit-identical images, 12 % of
+# an unchanged render() at C3).
+#
+# It is OFF unless asked for -- ``GSR_GEOMETRY_CACHE=1`` in the environment or ``set_geometry_cache(True)`` -- because it
+# is a behaviour the reference does not have: a write that bypasses the version counter between the two calls
+# (`t.data.add_()`, a raw-pointer write from another extension, a DLPack alias) is invisible to it, and the second call
+# would composite over the first call's geometry.  The reference recomputes; by default so does this module.
+# (autovfx_amd.renderer.render does not need it: it folds the normal pass into the first call.)  Contract when on:
 #   * one follow-up per full call: the entry is dropped by the first hit (and by any miss), so a stale hit can only
 #     ever be the call immediately after the one that computed the geometry, and the previous call's scratch
 #     (~300 MB at 3 M Gaussians) is pinned no longer than that;
 #   * identity + version: the previous call's input tensors are kept alive by the entry, so an id / address cannot
-#     be recycled; any in-place operation PyTorch knows about bumps `_version` and misses;
-#   * what it cannot see: writes that bypass the version counter between the two calls (`t.data.add_()`, a raw
-#     pointer write from another extension, a DLPack alias).  Code that does that between two rasterizer calls on
-#     the same tensors must call set_geometry_cache(False) or run with GSR_GEOMETRY_CACHE=0.
+#     be recycled; any in-place operation PyTorch knows about bumps `_version` and misses.
 import os as _os
 
-_GEOMETRY_CACHE = _os.environ.get("GSR_GEOMETRY_CACHE", "1") != "0"
+_GEOMETRY_CACHE_DEFAULT = _os.environ.get("GSR_GEOMETRY_CACHE", "0") == "1"
+_GEOMETRY_CACHE = _GEOMETRY_CACHE_DEFAULT
 cache_stats = {"hits": 0, "misses": 0}
 
 
-def set_geometry_cache(enabled: bool) -> None:
+def set_geometry_cache(enabled) -> None:
+    """True / False; None restores the process default (``GSR_GEOMETRY_CACHE``, off when unset)."""
     global _GEOMETRY_CACHE
-    _GEOMETRY_CACHE = bool(enabled)
+    _GEOMETRY_CACHE = _GEOMETRY_CACHE_DEFAULT if enabled is None else bool(enabled)
     _tls.cache = None
 
 

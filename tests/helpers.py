@@ -106,7 +106,7 @@ def hip_forward_inference(cloud: GaussianCloud, cam: Camera, device="cuda:0", bg
         _lib.set_option(_lib.OPT_SLAB_FIRST, 400)
         _lib.set_option(_lib.OPT_DEFER_COLOUR, 1)
         _lib.set_option(_lib.OPT_SLAB_MIN_REST, 3000000)
-        _C.set_geometry_cache(True)
+        _C.set_geometry_cache(None)
 
 
 def _hip_forward_raw(_C, cloud, cam, device, bg, scale_modifier, sh_degree, cov3D_precomp, debug):

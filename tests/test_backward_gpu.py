@@ -302,4 +302,4 @@ def test_backward_rejects_the_scratch_of_an_inference_call():
                 torch.cuda.synchronize()
                 assert torch.isfinite(grads[3]).all() and float(grads[3].abs().sum()) > 0   # dL_dmeans3D
     finally:
-        _C.set_geometry_cache(True)
+        _C.set_geometry_cache(None)

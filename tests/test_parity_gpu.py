@@ -214,7 +214,7 @@ def test_c4_sugar_camera_with_off_centre_principal_point():
         rgb_pass = _C.rasterize_gaussians(*args(c.colors_precomp))
         normal_pass = _C.rasterize_gaussians(*args(normals))
     finally:
-        _C.set_geometry_cache(True)
+        _C.set_geometry_cache(None)
     torch.cuda.synchronize()
     for i in (1, 2, 3, 4):
         assert torch.equal(fused[i], rgb_pass[i]), i
@@ -607,7 +607,7 @@ def test_split_call_is_the_one_shot_call():
         r = empty.finish()
         assert r[0] == 0 and float(r[1].abs().max()) == 0.0
     finally:
-        _C.set_geometry_cache(True)
+        _C.set_geometry_cache(None)
 
 
 def test_second_pass_reuses_geometry_bit_for_bit():
@@ -797,7 +797,7 @@ def test_second_feature_set_equals_a_second_pass(case):
         plain = _C.rasterize_gaussians(*args(*first))
         second = _C.rasterize_gaussians(*args(extra, e))
     finally:
-        _C.set_geometry_cache(True)
+        _C.set_geometry_cache(None)
     torch.cuda.synchronize()
     assert fused[0] == plain[0]
     for i in (1, 2, 3, 4):
@@ -815,7 +815,7 @@ def test_second_feature_set_equals_a_second_pass(case):
         torch.cuda.synchronize()
         n_slabs = len(_C.last_layout()["slab_pairs"])
     finally:
-        _C.set_geometry_cache(True)
+        _C.set_geometry_cache(None)
         _lib.set_option(_lib.OPT_SLABS, 2); _lib.set_option(_lib.OPT_SLAB_FIRST, 400); _lib.set_option(_lib.OPT_SLAB_MIN_REST, 3_000_000)
     assert n_slabs > 1 or case == "ragged_precomp"
     assert slabbed[0] == plain[0]

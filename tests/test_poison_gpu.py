@@ -125,7 +125,7 @@ def test_second_blend_and_fused_second_feature(scene, inference):
             torch.cuda.synchronize()
             return outs
         finally:
-            _C.set_geometry_cache(True)
+            _C.set_geometry_cache(None)
             _lib.set_option(_lib.OPT_SLABS, 2); _lib.set_option(_lib.OPT_SLAB_FIRST, 400); _lib.set_option(_lib.OPT_SLAB_MIN_REST, 3_000_000)
 
     base = _with_poison(0, run)
