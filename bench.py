@@ -778,7 +778,8 @@ def dynamic_scene_bench(device, side, S, frames=120):
     import math
     from autovfx_amd import scenes
     from autovfx_amd.cameras import orbit_cameras
-    from autovfx_amd.dynamic_scene import DynamicScene, reference_shaped_compose
+    from autovfx_amd.dynamic_scene import DynamicScene
+    from oracle.dynamic_torch import reference_shaped_compose
     from autovfx_amd.frame_parallel import pack_rgba8, rasterize, rasterize_begin
     from autovfx_amd.gaussian_model import GaussianModel
     W, H = 960, 540

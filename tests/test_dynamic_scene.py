@@ -159,7 +159,8 @@ def test_place_object_against_the_restatement():
 @pytest.mark.gpu
 def test_frames_match_the_reference_shaped_composition_and_the_cpu_oracle():
     from autovfx_amd.cameras import orbit_cameras
-    from autovfx_amd.dynamic_scene import DynamicScene, reference_shaped_compose
+    from autovfx_amd.dynamic_scene import DynamicScene
+    from oracle.dynamic_torch import reference_shaped_compose
     from autovfx_amd.frame_parallel import rasterize
     from oracle import cpu_oracle
     from test_parity_gpu import assert_images

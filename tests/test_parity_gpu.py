@@ -823,6 +823,37 @@ def test_second_feature_set_equals_a_second_pass(case):
         assert torch.equal(slabbed[i], fused[i]), (i, n_slabs)
 
 
+def test_stage_timing_skips_a_call_that_was_begun_and_never_finished():
+    """gsr_set_stage_timing: a split call that is cancelled after its first half leaves a ring slot with unrecorded events;
+    the readers must skip it (round-2 advisor), and the backward's two kernels are timed by the same switch."""
+    from autovfx_amd import _lib
+    from autovfx_amd.frame_parallel import rasterize, rasterize_begin
+    dev = "cuda:0"
+    cloud, cam = scenes.config_c1(P=5000, seed=3).to(dev), scenes.c1_camera(128, 96).to(dev)
+    bg = torch.zeros(3, device=dev)
+    _lib.set_stage_timing(True)
+    try:
+        with torch.no_grad():
+            rasterize(cloud, cam, bg)
+            pending = rasterize_begin(cloud, cam, bg)
+            del pending                       # cancelled: its slot never gets its later events
+            rasterize(cloud, cam, bg)
+        torch.cuda.synchronize()
+        st = _lib.stage_times_ms()
+        assert st["calls"] == 2 and st["blend"] > 0 and st["preprocess"] > 0
+        assert len(_lib.call_times_ms()) == 2 and min(_lib.call_times_ms()) > 0
+        leaf = cloud.means3D.clone().requires_grad_(True)
+        from diff_gaussian_rasterization import GaussianRasterizer
+        img = GaussianRasterizer(settings_for(cam, dev))(leaf, torch.zeros_like(leaf, requires_grad=True), cloud.opacities, shs=cloud.shs,
+                                                       scales=cloud.scales, rotations=cloud.rotations)[0]
+        img.sum().backward()
+        torch.cuda.synchronize()
+        bw = _lib.backward_times_ms()
+        assert bw["calls"] == 1 and bw["render_backward"] > 0 and bw["preprocess_backward"] > 0
+    finally:
+        _lib.set_stage_timing(False)
+
+
 def test_sh_degree_above_three_is_degree_three():
     """SuGaR checkpoints reach the rasterizer with active_sh_degree = 4 and 16 coefficients
     (scene_representation.py:196,213); computeColorFromSH (forward.cu:20-71) only tests deg > 0, > 1, > 2, so the
