@@ -97,7 +97,7 @@ def _load() -> ctypes.CDLL:
     lib.gsr_normal_maps.argtypes = [ctypes.c_int, ctypes.c_int, c_f, c_f, c_f] + [ctypes.c_float] * 4 + [c_f, c_f, ctypes.c_void_p]
     lib.gsr_place_object.restype = ctypes.c_int
     lib.gsr_place_object.argtypes = [ctypes.c_int, c_f, c_f, c_f, c_f, c_f, ctypes.c_int, ctypes.POINTER(ctypes.c_float * 21),
-                                     c_f, c_f, c_f, c_f, c_f, ctypes.c_void_p]
+                                     c_f, c_f, c_f, c_f, c_f, c_f, ctypes.c_void_p]
     lib.gsr_selftest_exp.restype = ctypes.c_int
     lib.gsr_selftest_lds_atomic_order.restype = ctypes.c_int
     lib.gsr_selftest_lds_atomic_order.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]

@@ -501,7 +501,7 @@ int gsr_normal_maps(int width, int height, const float* normal_rgb, const float*
 
 int gsr_place_object(int n, const float* xyz, const float* rotation_raw, const float* log_scale, const float* opacity, const float* shs,
                      int M, const float* placement, float* out_means3D, float* out_scales, float* out_rotations, float* out_opacities,
-                     float* out_shs, void* stream_) {
+                     float* out_shs, float* out_min_axis, void* stream_) {
     if (n < 0) return fail(GSR_ERR_INVALID_ARG, "bad size n=%d", n);
     if (n == 0) return GSR_OK;
     if (!xyz || !rotation_raw || !log_scale || !placement || !out_means3D || !out_scales || !out_rotations)
@@ -513,7 +513,7 @@ int gsr_place_object(int n, const float* xyz, const float* rotation_raw, const f
     static_assert(sizeof(gsr::ObjectPlacement) == 21 * sizeof(float), "the placement block is 21 floats");
     memcpy(&pl, placement, sizeof pl);
     GSR_HIP(gsr::launch_place_object(n, xyz, rotation_raw, log_scale, opacity, shs, M, pl, out_means3D, out_scales, out_rotations,
-                                     out_opacities, out_shs, (hipStream_t)stream_));
+                                     out_opacities, out_shs, out_min_axis, (hipStream_t)stream_));
     return GSR_OK;
 }
 

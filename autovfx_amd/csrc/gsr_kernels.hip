@@ -630,7 +630,7 @@ __global__ void __launch_bounds__(256) place_object_kernel(int n, const float* _
                                                            const float* __restrict__ shs, int M, ObjectPlacement pl,
                                                            float* __restrict__ out_xyz, float* __restrict__ out_scales,
                                                            float* __restrict__ out_rot, float* __restrict__ out_opacity,
-                                                           float* __restrict__ out_shs) {
+                                                           float* __restrict__ out_shs, float* __restrict__ out_min_axis) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
         // gaussians_utils.py:94-96 (scale about the initial centre), :100-102 (rotate about it), :106-107 (translate)
@@ -654,7 +654,8 @@ __global__ void __launch_bounds__(256) place_object_kernel(int n, const float* _
         *reinterpret_cast<F3*>(out_xyz + 3 * (size_t)i) = F3{w[0], w[1], w[2]};
         // :97 new_scales += log(scaling), then exp (gaussian_model.py:96-97)
         const F3 ls = ld3(log_scale + 3 * (size_t)i);
-        *reinterpret_cast<F3*>(out_scales + 3 * (size_t)i) = F3{expf(ls.x + pl.log_s), expf(ls.y + pl.log_s), expf(ls.z + pl.log_s)};
+        const F3 sc = F3{expf(ls.x + pl.log_s), expf(ls.y + pl.log_s), expf(ls.z + pl.log_s)};
+        *reinterpret_cast<F3*>(out_scales + 3 * (size_t)i) = sc;
         // :103 quaternion_multiply(matrix_to_quaternion(R), q) (rotation_utils.py:113-135), then F.normalize (gaussian_model.py:100-101)
         const F4 b = *reinterpret_cast<const F4*>(rot + 4 * (size_t)i);
         const float aw = pl.qR[0], ax = pl.qR[1], ay = pl.qR[2], az = pl.qR[3];
@@ -664,8 +665,21 @@ __global__ void __launch_bounds__(256) place_object_kernel(int n, const float* _
         float oz = aw * b.w + ax * b.z - ay * b.y + az * b.x;
         if (ow < 0.f) { ow = -ow; ox = -ox; oy = -oy; oz = -oz; }   // standardize_quaternion
         const float norm = fmaxf(sqrtf(((ow * ow + ox * ox) + oy * oy) + oz * oz), 1e-12f);
-        *reinterpret_cast<F4*>(out_rot + 4 * (size_t)i) = F4{ow / norm, ox / norm, oy / norm, oz / norm};
+        const F4 qn = F4{ow / norm, ox / norm, oy / norm, oz / norm};
+        *reinterpret_cast<F4*>(out_rot + 4 * (size_t)i) = qn;
         if (out_opacity != nullptr) out_opacity[i] = opacity[i];
+        if (out_min_axis != nullptr) {
+            // general_utils.py:78-101 build_rotation (normalises once more) and :135-141 get_minimum_axis: the column of R that
+            // belongs to the smallest scale (first one on a tie)
+            const float n2 = sqrtf(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
+            const float w = qn.x / n2, x = qn.y / n2, y = qn.z / n2, z = qn.w / n2;
+            const int c = (sc.x <= sc.y && sc.x <= sc.z) ? 0 : (sc.y <= sc.z ? 1 : 2);
+            F3 col;
+            if (c == 0) col = F3{1.f - 2.f * (y * y + z * z), 2.f * (x * y + w * z), 2.f * (x * z - w * y)};
+            else if (c == 1) col = F3{2.f * (x * y - w * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + w * x)};
+            else col = F3{2.f * (x * z + w * y), 2.f * (y * z - w * x), 1.f - 2.f * (x * x + y * y)};
+            *reinterpret_cast<F3*>(out_min_axis + 3 * (size_t)i) = col;
+        }
     }
     if (out_shs != nullptr) {   // the object's SH block copied as one contiguous run: 3 M floats per Gaussian, 16-byte pieces
         const size_t words = (size_t)n * 3u * (size_t)M;
@@ -680,9 +694,9 @@ __global__ void __launch_bounds__(256) place_object_kernel(int n, const float* _
 
 hipError_t launch_place_object(int n, const float* xyz, const float* rot, const float* log_scale, const float* opacity,
                                const float* shs, int M, const ObjectPlacement& pl, float* out_xyz, float* out_scales, float* out_rot,
-                               float* out_opacity, float* out_shs, hipStream_t stream) {
+                               float* out_opacity, float* out_shs, float* out_min_axis, hipStream_t stream) {
     hipLaunchKernelGGL(place_object_kernel, dim3(div_up(n, 256)), dim3(256), 0, stream, n, xyz, rot, log_scale, opacity, shs, M, pl, out_xyz,
-                       out_scales, out_rot, out_opacity, out_shs);
+                       out_scales, out_rot, out_opacity, out_shs, out_min_axis);
     return hipGetLastError();
 }
 

@@ -60,6 +60,27 @@ class _ObjectCloud:
         self.P = int(self.xyz.shape[0])
 
 
+class FrameModel:
+    """One composed frame with the ``GaussianModel`` getters ``render()`` reads (``gaussian_renderer/__init__.py:118-171``):
+    already activated tensors, nothing is recomputed.  Valid as long as the ``GaussianCloud`` it wraps."""
+
+    def __init__(self, cloud: GaussianCloud, min_axis: torch.Tensor):
+        self._cloud, self._min_axis = cloud, min_axis
+        self.active_sh_degree = self.max_sh_degree = cloud.sh_degree
+
+    get_xyz = property(lambda self: self._cloud.means3D)
+    get_scaling = property(lambda self: self._cloud.scales)
+    get_rotation = property(lambda self: self._cloud.rotations)
+    get_opacity = property(lambda self: self._cloud.opacities)
+    get_features = property(lambda self: self._cloud.shs)
+    get_minimum_axis = property(lambda self: self._min_axis)
+
+    def get_normal(self, dir_pp_normalized=None):
+        from .gaussian_model import flip_align_view
+        normal_axis, _ = flip_align_view(self._min_axis, dir_pp_normalized)
+        return normal_axis / normal_axis.norm(dim=1, keepdim=True)
+
+
 class DynamicScene:
     """``DynamicScene(base_model, {object_id: (object_model, initial_center)})``; models carry the reference's raw parameters
     (``autovfx_amd.gaussian_model.GaussianModel`` or anything with ``_xyz, _rotation, _scaling, _opacity, _features_dc,
@@ -92,18 +113,22 @@ class DynamicScene:
             first = (t(base._xyz), torch.exp(t(base._scaling)), torch.nn.functional.normalize(t(base._rotation)),
                      torch.sigmoid(t(base._opacity)), torch.cat((t(base._features_dc), t(base._features_rest)), dim=1))
             for _ in range(max(1, int(slots))):
-                bufs = (new(cap, 3), new(cap, 3), new(cap, 4), new(cap, 1), new(cap, M, 3))
+                bufs = (new(cap, 3), new(cap, 3), new(cap, 4), new(cap, 1), new(cap, M, 3), new(cap, 3))
                 for dst, src in zip(bufs, first):
                     dst[:n] = src
                 self._slots.append(bufs)
-        self.means3D, self.scales, self.rotations, self.opacities, self.shs = self._slots[0]
+            from .gaussian_model import get_minimum_axis
+            base_axis = get_minimum_axis(first[1], first[2]).contiguous()   # general_utils.py:135-141, once for the base
+            for bufs in self._slots:
+                bufs[5][:n] = base_axis
+        self.means3D, self.scales, self.rotations, self.opacities, self.shs, self.min_axis = self._slots[0]
 
     def compose(self, placements: Iterable[Tuple[str, Sequence[float], Sequence[Sequence[float]], float]], slot: int = 0) -> GaussianCloud:
         """``placements``: the objects present in this frame, in merge order, each ``(object_id, center[3], rotation[3][3],
         scaling)`` -- ``rb_transform['pos'], ['rot'], ['scale']`` of ``scene_representation.py:364-366``.  An object may be
         placed more than once (the buffers then need room for it: ``ValueError`` otherwise)."""
         from . import _lib
-        means3D, scales, rotations, opacities, shs = self._slots[slot % len(self._slots)]
+        means3D, scales, rotations, opacities, shs, min_axis = self._slots[slot % len(self._slots)]
         at = self.P_base
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         with torch.cuda.device(self.device):
@@ -115,8 +140,16 @@ class DynamicScene:
                 rc = _lib.lib.gsr_place_object(
                     o.P, o.xyz.data_ptr(), o.rotation.data_ptr(), o.log_scale.data_ptr(), o.opacity.data_ptr(), o.shs.data_ptr(), self.M,
                     ctypes.byref(block), means3D[at:].data_ptr(), scales[at:].data_ptr(), rotations[at:].data_ptr(),
-                    opacities[at:].data_ptr(), shs[at:].data_ptr(), stream)
+                    opacities[at:].data_ptr(), shs[at:].data_ptr(), min_axis[at:].data_ptr(), stream)
                 if rc != 0:
                     raise RuntimeError(f"gsr_place_object failed ({rc}): {_lib.last_error()}")
                 at += o.P
+        self._last_min_axis = min_axis[:at]
         return GaussianCloud(means3D[:at], opacities[:at], scales[:at], rotations[:at], shs[:at], None, self.sh_degree)
+
+    def compose_model(self, placements, slot: int = 0) -> FrameModel:
+        """``compose`` for callers of ``render()`` (``autovfx_amd.renderer.render`` or the reference's own): the frame as an
+        object with the ``GaussianModel`` getters -- RGBA, depth, normal and pseudo-normal maps of a moving scene come out of
+        ``render(view, scene.compose_model(placements), pipe, bg)`` as they do for a static one."""
+        cloud = self.compose(placements, slot)
+        return FrameModel(cloud, self._last_min_axis)

@@ -229,13 +229,17 @@ GSR_API int gsr_normal_maps(int width, int height, const float* normal_rgb, cons
  *                (rotation_utils.py:24-85,113-135; F.normalize as gaussian_model.py:100-101)
  *   scale      : exp(log_scale + log_s)          (gaussians_utils.py:97 then gaussian_model.py:96-97)
  *   opacity, SH: copied (already activated / concatenated by the caller once per object; nullable = leave as is)
+ *   min_axis   : (nullable) the rotation-matrix column of the smallest activated scale, what render() turns into the
+ *                per-Gaussian normal (general_utils.py:78-101 build_rotation, :135-141 get_minimum_axis), from the
+ *                normalised quaternion, in that code's operation order
  * placement: 21 host floats -- center c[3], rotation R[9] row-major, scale s, initial_center c0[3], q_R[4] (w,x,y,z),
  * log_s (= (float)log((double)s)).  One streaming kernel: 40 B in + 40 B out per Gaussian (+ 196 B each way with SH).
  */
 GSR_API int gsr_place_object(int n, const float* xyz, const float* rotation_raw, const float* log_scale,
                              const float* opacity /*nullable*/, const float* shs /*nullable*/, int M,
                              const float* placement /*host, 21 floats*/, float* out_means3D, float* out_scales,
-                             float* out_rotations, float* out_opacities /*nullable*/, float* out_shs /*nullable*/, void* stream);
+                             float* out_rotations, float* out_opacities /*nullable*/, float* out_shs /*nullable*/,
+                             float* out_min_axis /*[n,3], nullable*/, void* stream);
 
 /* Self-test of the blend kernel's exp(): adds to *device_mismatches (a zeroed device u64) the number of floats
  * with bit patterns first_bits .. first_bits + count - 1 whose exp differs from the device library's expf.
