@@ -143,6 +143,11 @@ def _load() -> ctypes.CDLL:
 
 lib = _load()
 
+# A/B from the shell (scripts/gpu_r3_check.sh): GSR_RADIX_RANK=0 forces the ballot rank of the radix sort, 1 the LDS adds,
+# 2 / unset = adds where the per-device self-test passed.
+if os.environ.get("GSR_RADIX_RANK", "") in ("0", "1", "2"):
+    lib.gsr_set_option(5, int(os.environ["GSR_RADIX_RANK"]))
+
 
 def last_error() -> str:
     return lib.gsr_last_error().decode("utf-8", "replace")

@@ -934,7 +934,7 @@ int forward_finish(ForwardCall& fc) {
         GSR_STAGE_CHECK("tile_ranges");
         stamp(kHeadEvents + kSlabEvents * k + 2, stream);
         if (fc.defer_colour && S == 1)
-            GSR_HIP(gsr::launch_sh_colour_all(fc.in, cam, ga.bins, ga.rgb, fused_ranges ? &duty : nullptr, stream));
+            GSR_HIP(gsr::launch_sh_colour_all(fc.in, cam, ga.radii, ga.rgb, fused_ranges ? &duty : nullptr, stream));
         else if (fc.defer_colour)
             GSR_HIP(gsr::launch_sh_colour_listed(fc.in, cam, ba.listed, k + 1, slab, ga.rgb, fused_ranges ? &duty : nullptr, stream));
         stamp(kHeadEvents + kSlabEvents * k + 3, stream);

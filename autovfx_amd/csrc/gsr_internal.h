@@ -132,8 +132,8 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmat
 // `duty` (nullable): the slab's tile ranges are computed by the first workgroups of the same launch.
 hipError_t launch_sh_colour_listed(const GaussianInputs& in, const Camera& cam, const uint8_t* listed, int tag, const SlabInfo* slab,
                                    float* rgb, const RangesDuty* duty, hipStream_t stream);
-// ... of every splat that emits pairs at all, in Gaussian order (a deferred-colour call that needs no depth slabs)
-hipError_t launch_sh_colour_all(const GaussianInputs& in, const Camera& cam, const SplatBin* bins, float* rgb, const RangesDuty* duty,
+// ... of every splat with a radius, in Gaussian order (a deferred-colour call that needs no depth slabs)
+hipError_t launch_sh_colour_all(const GaussianInputs& in, const Camera& cam, const int* radii, float* rgb, const RangesDuty* duty,
                                 hipStream_t stream);
 
 // ---- binning (gsr_binning.hip): from the depth order to per-tile lists, slab by slab ----

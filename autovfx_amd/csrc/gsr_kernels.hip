@@ -354,13 +354,15 @@ __global__ void __launch_bounds__(256) sh_colour_listed_kernel(GaussianInputs in
 // The same for a call that turned out to need no depth slabs (the host learns that only after the projection kernel
 // ran without colours): every splat that emits pairs at all, in GAUSSIAN order, so that the 192-byte records are read
 // as the projection kernel would have read them (lane-strided, every line used) instead of gathered in depth order.
+// (Which splats: those with a radius, i.e. everything the projection kernel did not cull -- a 4-byte flag per Gaussian read
+// as a stream; the few splats whose every tile is dead get a colour nobody reads.)
 __global__ void __launch_bounds__(256) sh_colour_all_kernel(GaussianInputs in, const float* __restrict__ cam_pos,
-                                                            const SplatBin* __restrict__ bins, float* __restrict__ rgb,
+                                                            const int* __restrict__ radii, float* __restrict__ rgb,
                                                             RangesDuty duty, int duty_blocks) {
     __shared__ uint32_t s_first[256];
     if ((int)blockIdx.x < duty_blocks) tile_ranges_duty(duty, blockIdx.x, s_first);   // (as in sh_colour_listed_kernel)
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= in.P || bins[i].wh == 0u) return;
+    if (i >= in.P || radii[i] <= 0) return;
     int deg = in.sh_degree < 3 ? in.sh_degree : 3;
     if (deg > 2 && in.M < 16) deg = 2;
     if (deg > 1 && in.M < 9) deg = 1;
@@ -517,12 +519,12 @@ hipError_t launch_sh_colour_listed(const GaussianInputs& in, const Camera& cam, 
     return hipGetLastError();
 }
 
-hipError_t launch_sh_colour_all(const GaussianInputs& in, const Camera& cam, const SplatBin* bins, float* rgb, const RangesDuty* duty,
+hipError_t launch_sh_colour_all(const GaussianInputs& in, const Camera& cam, const int* radii, float* rgb, const RangesDuty* duty,
                                 hipStream_t stream) {
     const int blocks = div_up(in.P, 256);
     if (in.P <= 0 || (duty != nullptr && blocks < ranges_duty_blocks(duty->num_tiles))) return hipErrorInvalidValue;
     RangesDuty none = {};
-    hipLaunchKernelGGL(sh_colour_all_kernel, dim3(blocks), dim3(256), 0, stream, in, cam.cam_pos, bins, rgb, duty ? *duty : none,
+    hipLaunchKernelGGL(sh_colour_all_kernel, dim3(blocks), dim3(256), 0, stream, in, cam.cam_pos, radii, rgb, duty ? *duty : none,
                        duty ? ranges_duty_blocks(duty->num_tiles) : 0);
     return hipGetLastError();
 }
