@@ -9,6 +9,12 @@ Per frame it writes images/<i>.png (RGBA8, save_image rounding), depth/<i>.npy (
 files the reference's frame loop writes and `blender/blend_all.py` consumes.  Rank r renders frames r, r+N, ...; every
 rank writes its own frames (no gather is needed when the output is files).  `--synthetic P` renders the synthetic C2
 cloud with P Gaussians instead of a PLY; `--orbit N WxH` an N-view orbit instead of a trajectory file.
+
+Moving inserted objects (`scene_representation.py:357-372`): `--object ID=object_gaussians.ply@cx,cy,cz` (repeatable; the
+object's Gaussians and its initial centre, what `get_center_of_mesh_2` returns for its mesh) and `--rigid-body-json FILE` with the
+reference's `rb_transform_info` structure, `{ID: {"001": {"pos": [x, y, z], "rot": [[...], [...], [...]], "scale": s}, ...}}`
+(frame keys are 1-based, three digits; an object without an entry for a frame is absent from it).  The scene then lives in
+resident buffers and each frame places its objects with one kernel each (`autovfx_amd/dynamic_scene.py`).
 """
 import argparse
 import json
@@ -33,6 +39,9 @@ def main():
     ap.add_argument("--downscale", type=float, default=1.0)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--white-background", action="store_true")
+    ap.add_argument("--object", action="append", default=[], metavar="ID=PLY@cx,cy,cz",
+                    help="an inserted object: its Gaussians (PLY, read with --sh-degree) and its initial centre")
+    ap.add_argument("--rigid-body-json", help="per-frame rigid-body transforms of the objects (rb_transform_info)")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
 
@@ -67,11 +76,33 @@ def main():
         cams = cameras.orbit_cameras(int(n), w, h)
     bg = torch.tensor([1.0, 1.0, 1.0] if args.white_background else [0.0, 0.0, 0.0], device=dev)
 
+    scene, transforms = None, {}
+    if args.object:
+        from autovfx_amd.dynamic_scene import DynamicScene
+        objects = {}
+        for spec in args.object:
+            oid, rest = spec.split("=", 1)
+            path, centre = rest.rsplit("@", 1)
+            om = GaussianModel(args.sh_degree).load_ply(path, device=str(dev))
+            objects[oid] = (om, [float(v) for v in centre.split(",")])
+        if args.rigid_body_json:
+            with open(args.rigid_body_json) as f:
+                transforms = json.load(f)
+        scene = DynamicScene(model, objects, device=dev, sh_degree=model.active_sh_degree)
+
+    def frame_model(i):
+        if scene is None:
+            return model
+        key = "{0:03d}".format(i + 1)   # frame index starts from 001 (scene_representation.py:362)
+        placed = [(oid, t[key]["pos"], t[key]["rot"], float(t[key]["scale"])) for oid, t in transforms.items() if key in t]
+        return scene.compose_model(placed)
+
     mine = shard_frames(len(cams), rank, world)
     t0 = time.perf_counter()
     with torch.no_grad(), frame_io.FrameWriter(args.out) as writer:   # PNG / .npy encoding on a pool of host threads
         for i in mine:
-            out = renderer.render(cams[i].to(dev), model, renderer.PipelineParams, bg)
+            out = renderer.render(cams[i].to(dev), frame_model(i), renderer.PipelineParams, bg)
+            # (the maps are per-call buffers: the next frame's placement rewrites the scene buffers, not them)
             writer.submit(cams[i].image_name or f"{i:05d}", out)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0

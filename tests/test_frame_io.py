@@ -84,3 +84,43 @@ def test_render_trajectory_script_end_to_end(tmp_path):
     normal = frame_io.decode_png((out / "normal" / "00001.png").read_bytes())
     assert rgba.shape == (90, 160, 4) and depth.shape == (90, 160) and normal.shape == (90, 160, 3)
     assert rgba[..., 3].max() > 200 and depth.max() > 1.0          # something was rendered
+
+
+@pytest.mark.gpu
+def test_render_trajectory_script_with_moving_objects(tmp_path):
+    """The same script with an inserted object that moves (--object, --rigid-body-json: the reference's rb_transform_info):
+    a frame without an entry renders the base scene alone, a frame with one differs from it where the object is."""
+    import json
+    import subprocess
+    import sys
+    from autovfx_amd import cameras, scenes
+    from autovfx_amd.gaussian_model import GaussianModel
+    os_ = __import__("os")
+    c = scenes.config_c2(P=20_000, seed=3)
+    ply = str(tmp_path / "point_cloud.ply")
+    GaussianModel.from_activated(c.means3D, c.opacities, c.scales, c.rotations, c.shs, 3).save_ply(ply)
+    o = scenes.config_c1(P=3000, seed=9)
+    obj = str(tmp_path / "object_gaussians.ply")
+    GaussianModel.from_activated(o.means3D * 0.3, o.opacities.clamp(min=0.6), o.scales * 0.6, o.rotations, o.shs, 3).save_ply(obj)
+    poses = [cameras.orbit_c2w(4.0, 3)[0]] * 3      # one camera, three frames: only the object changes
+    fx = cameras.fov2focal(np.deg2rad(60.0), 160)
+    traj = str(tmp_path / "traj.json")
+    with open(traj, "w") as f:
+        json.dump(cameras.trajectory_dict("t", poses, fx, fx, 80, 45, 160, 90), f)
+    rb = {"obj1": {"002": {"pos": [0.2, 0.1, 0.0], "rot": np.eye(3).tolist(), "scale": 1.0},
+                   "003": {"pos": [-0.4, 0.3, 0.2], "rot": [[0, -1, 0], [1, 0, 0], [0, 0, 1]], "scale": 1.5}}}
+    rbj = str(tmp_path / "rb.json")
+    with open(rbj, "w") as f:
+        json.dump(rb, f)
+    root = os_.path.dirname(os_.path.dirname(os_.path.abspath(__file__)))
+    outs = {}
+    for name, extra in (("static", []), ("moving", ["--object", f"obj1={obj}@0,0,0", "--rigid-body-json", rbj])):
+        out = tmp_path / name
+        r = subprocess.run([sys.executable, os_.path.join(root, "scripts", "render_trajectory.py"), "--ply", ply, "--trajectory", traj,
+                            "--out", str(out), *extra], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = [frame_io.decode_png((out / "images" / f"{i:05d}.png").read_bytes()) for i in range(3)]
+    assert np.array_equal(outs["moving"][0], outs["static"][0]), "frame 001 has no object: the base scene alone"
+    for i in (1, 2):
+        assert int((outs["moving"][i].astype(int) - outs["static"][i].astype(int)).__abs__().max()) > 20, f"frame {i + 1}: the object is missing"
+    assert not np.array_equal(outs["moving"][1], outs["moving"][2])
