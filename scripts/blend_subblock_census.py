@@ -82,6 +82,14 @@ for t in tiles:
         T = np.where(upd, test_T, T)
         if done.all(): break
     done_at[~inside] = -1
+    # coarser work items (two or four pixels per lane): a 16x8 / 8x16 half tile or the whole tile per wave, one reach-filtered list
+    for name, rects in (("h16x8", [(0, 0, 16, 8), (0, 8, 16, 8)]), ("v8x16", [(0, 0, 8, 16), (8, 0, 8, 16)]), ("full16", [(0, 0, 16, 16)])):
+        for (ox, oy, w, h) in rects:
+            sl2 = (slice(oy, oy + h), slice(ox, ox + w))
+            if not inside[sl2].any(): continue
+            n_h = min(L, done_at[sl2].max() + 1)
+            rh = reach(A[:n_h], B[:n_h], C[:n_h], o[:n_h], cx[:n_h], cy[:n_h], tx * 16 + ox, ty * 16 + oy, w, h)
+            tot["it_" + name] = tot.get("it_" + name, 0) + int(rh.sum())
     for qy in range(2):
         for qx in range(2):
             sl = (slice(8 * qy, 8 * qy + 8), slice(8 * qx, 8 * qx + 8))
@@ -120,3 +128,5 @@ print("reference list entries / tile-culled", tot["entries"], tot["tile_reach"])
 print("quadrant iterations (processed entries):", tot["it_quad"], " with a live pixel: %.1f%%" % (100 * tot["it_quad_live"] / tot["it_quad"]), " live lanes per processed entry: %.1f" % (tot["live_lanes"] / tot["it_quad"]))
 print("4x4 sub-block streams: iterations %.1f%% of now (batched by 64), %.1f%% unbatched; (sub-block, entry) pairs per quadrant iteration %.2f" % (100 * tot["it_sub"] / tot["it_quad"], 100 * tot["it_sub_nobatch"] / tot["it_quad"], tot["pairs_sub"] / tot["it_quad"]))
 print("8x4 halves: iterations %.1f%% of now" % (100 * tot["it_half"] / tot["it_quad"]))
+for name, what in (("h16x8", "16x8 halves, 2 pixels per lane"), ("v8x16", "8x16 halves, 2 pixels per lane"), ("full16", "whole tile, 4 pixels per lane")):
+    print("%s: iterations %.1f%% of now" % (what, 100 * tot["it_" + name] / tot["it_quad"]))
