@@ -47,7 +47,8 @@ constexpr int kHeadEvents = 4, kSlabEvents = 5;
 constexpr int kEventsPerCall = kHeadEvents + kSlabEvents * gsr::kMaxSlabs;
 int g_options[GSR_OPT_NUM] = {/*GSR_OPT_TILE_CULL*/ 1, /*GSR_OPT_SLABS*/ 2, /*GSR_OPT_SLAB_FIRST*/ 400,
                               /*GSR_OPT_DEFER_COLOUR*/ 1, /*GSR_OPT_SLAB_MIN_REST*/ 3000000,
-                              /*GSR_OPT_RADIX_RANK (kept by gsr_radix.hip)*/ 2, /*GSR_OPT_RADIX_RANK_ACTIVE (read-only)*/ 0};
+                              /*GSR_OPT_RADIX_RANK (kept by gsr_radix.hip)*/ 2, /*GSR_OPT_RADIX_RANK_ACTIVE (read-only)*/ 0,
+                              /*GSR_OPT_DEPTH_DROP*/ 1};
 bool g_timing = false;
 std::atomic<long> g_timing_epoch{0};       // bumped by gsr_set_stage_timing: every thread restarts its record at its next call
 thread_local long g_epoch_seen = -1;
@@ -781,7 +782,8 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     uint32_t* keys_sorted = nullptr;
     GSR_HIP(gsr::radix_sort_pairs((uint32_t*)(gbase + fc.off_radix_tmp), (uint32_t)P, 32, ga.depth_keys, (uint32_t*)(gbase + off_keys_b),
                                   (uint32_t*)(gbase + off_ids_a), (uint32_t*)(gbase + off_ids_b),
-                                  /*iota_payload=*/true, /*want_sorted_keys=*/false, &keys_sorted, &fc.order, stream));
+                                  /*iota_payload=*/true, /*want_sorted_keys=*/false, &keys_sorted, &fc.order, stream, nullptr,
+                                  g_options[GSR_OPT_DEPTH_DROP] != 0 ? &gsr::kCulledKey : nullptr));
     GSR_STAGE_CHECK("depth_sort");
     stamp(2, stream);
     geom_off[GSR_GEOM_DEPTH_ORDER] = (size_t)((char*)fc.order - gbase);
@@ -853,6 +855,13 @@ int forward_finish(ForwardCall& fc) {
     ba.run_incl = (uint32_t*)(bbase + off_pool_incl);
     ba.counters = ga.counters;
     ba.slabs = (gsr::SlabInfo*)(gbase + fc.off_slabs);
+    // the slabs' pair counts are stored into the pinned slot by the kernels that settle them (pinned memory is device-visible
+    // at its own address; if this runtime says otherwise a copy follows the call as in rounds 1 - 2)
+    gsr::SlabInfo* const host_table = reinterpret_cast<gsr::SlabInfo*>(reinterpret_cast<char*>(fc.pinned.host) + kSlabTableAt);
+    void* host_table_dev = nullptr;
+    if (hipHostGetDevicePointer(&host_table_dev, host_table, 0) != hipSuccess) { (void)hipGetLastError(); host_table_dev = nullptr; }
+    ba.slabs_host = reinterpret_cast<gsr::SlabInfo*>(host_table_dev);
+    for (int k = 0; k < gsr::kMaxSlabs; ++k) host_table[k] = gsr::SlabInfo{0u, 0u, 0u, 0u};   // (a slab no kernel reaches has no pairs)
     ba.quad_done = (uint32_t*)(gbase + fc.off_quad);
     ba.done_rows = (uint32_t*)(gbase + fc.off_rows);
     ba.row_words = fc.row_words;
@@ -950,9 +959,10 @@ int forward_finish(ForwardCall& fc) {
     }
     if (fc.timed) { g_ev_slabs[fc.slot] = S; ++g_timed_calls; }
 
-    // the pair counts of the slabs travel to pinned memory behind everything else; whoever asks for them waits then
-    GSR_HIP(hipMemcpyAsync(reinterpret_cast<char*>(fc.pinned.host) + kSlabTableAt, ba.slabs, sizeof(gsr::SlabInfo) * S,
-                           hipMemcpyDeviceToHost, stream));
+    // the pair counts of the slabs are in pinned memory once the call's kernels are done; whoever asks for them waits then
+    if (ba.slabs_host == nullptr)
+        GSR_HIP(hipMemcpyAsync(reinterpret_cast<char*>(fc.pinned.host) + kSlabTableAt, ba.slabs, sizeof(gsr::SlabInfo) * S,
+                               hipMemcpyDeviceToHost, stream));
     GSR_HIP(hipEventRecord(fc.pinned.finished, stream));
     if (g_last_slot.host) g_pinned_draining.push_back(g_last_slot);  // (its copy may still be pending on another stream)
     g_last_slot = fc.pinned;

@@ -392,7 +392,8 @@ struct SlabCuts { uint32_t cut[kMaxSlabs]; };
 
 __global__ void __launch_bounds__(256) bin_offsets_kernel(int P, int V, const uint32_t* __restrict__ tile_totals,
                                                           uint32_t* __restrict__ offsets, uint32_t* __restrict__ tile_ends,
-                                                          int num_slabs, SlabCuts cuts, SlabInfo* __restrict__ slabs) {
+                                                          int num_slabs, SlabCuts cuts, SlabInfo* __restrict__ slabs,
+                                                          SlabInfo* __restrict__ slabs_host) {
     __shared__ uint32_t s_scratch[4];
     const int tiles_v = (V + kDupTile - 1) / kDupTile;
     const int upto = min((int)blockIdx.x, tiles_v);
@@ -433,10 +434,16 @@ __global__ void __launch_bounds__(256) bin_offsets_kernel(int P, int V, const ui
             slabs[s].end = pos;
             if (s + 1 < num_slabs) slabs[s + 1].first = pos;
             if (s == 0) slabs[0].emitters = pos;
-            if (s == 0 && below == 0u) slabs[0].pairs = before;   // the slab ends with the previous tile
+            if (s == 0 && below == 0u) {   // the slab ends with the previous tile
+                slabs[0].pairs = before;
+                if (slabs_host != nullptr) slabs_host[0].pairs = before;
+            }
         }
         // slab 0 is expanded from the global offsets as they are: its pair count is the offset of its last position
-        if (s == 0 && below != 0u && (uint32_t)threadIdx.x == (below - 1u) / 4u) slabs[0].pairs = mine[(below - 1u) & 3u];
+        if (s == 0 && below != 0u && (uint32_t)threadIdx.x == (below - 1u) / 4u) {
+            slabs[0].pairs = mine[(below - 1u) & 3u];
+            if (slabs_host != nullptr) slabs_host[0].pairs = mine[(below - 1u) & 3u];
+        }
     }
 }
 
@@ -574,7 +581,10 @@ __global__ void __launch_bounds__(256) slab_compact_kernel(BinningArrays a, int 
         for (uint32_t t = threadIdx.x; t < tiles; t += 256) { pp += pair_totals[t]; ee += emit_totals[t]; }
         const uint32_t all_pairs = block_sum_256(pp, s_scratch);
         const uint32_t all_emit = block_sum_256(ee, s_scratch);
-        if (threadIdx.x == 0) { a.slabs[slab].pairs = all_pairs; a.slabs[slab].emitters = all_emit; }
+        if (threadIdx.x == 0) {
+            a.slabs[slab].pairs = all_pairs; a.slabs[slab].emitters = all_emit;
+            if (a.slabs_host != nullptr) a.slabs_host[slab].pairs = all_pairs;
+        }
     }
     if (blockIdx.x >= tiles) return;
     uint32_t pp = 0, ee = 0;
@@ -775,7 +785,7 @@ hipError_t launch_bin_scan(const BinningArrays& a, const Camera& cam, int num_sl
     for (int s = 0; s + 1 < num_slabs; ++s) cuts.cut[s] = pair_cuts[s];
     // (V == 0: the slab table stays as the call's zero-filled block left it: no positions, no pairs)
     hipLaunchKernelGGL(bin_offsets_kernel, dim3(tiles_p), dim3(256), 0, stream, a.P, a.V, a.tile_totals, a.offsets, tile_ends, num_slabs, cuts,
-                       a.slabs);
+                       a.slabs, a.slabs_host);
     return hipGetLastError();
 }
 

@@ -160,6 +160,8 @@ struct BinningArrays {
     uint32_t pool_rows;
     FrameCounters* counters;
     SlabInfo* slabs;              // [kMaxSlabs] device
+    SlabInfo* slabs_host;         // nullable: the same table in pinned host memory (device-visible address); the kernels that
+                                  // settle a slab's pair count store it there too, so no copy has to follow the call
     uint32_t* quad_done;          // [ceil(4T / 32)] one bit per 8x8 quadrant whose 64 pixels have all stopped
     uint32_t* done_rows;          // [grid_y * row_words] the same per tile, one bit row per tile row
     int row_words;                // 32-bit words per bit row
@@ -251,6 +253,8 @@ hipError_t launch_pack_rgba8(const float* color, const float* alpha, uint8_t* ou
 // is 0..n-1 and `vals` is not read.  want_sorted_keys = false skips the key stores of the last pass.
 // n_device (nullable): the number of pairs is read from this device word by every kernel (it must not exceed n, which
 // then only sizes the launches and the scratch layout): a sort can be queued before its size is known on the host.
+// drop_key (nullable; with iota_payload, more than one pass, no n_device): items with this key leave the sort in its first
+// pass -- not ranked, not written; the sorted arrays hold the others, in order, and their tails are undefined.
 // counts the returning LDS adds whose result was not (value before the instruction) + (lower lanes on the same counter)
 hipError_t launch_lds_atomic_order_selftest(uint32_t workgroups, uint32_t rounds, uint32_t seed, unsigned long long* mismatches,
                                             hipStream_t stream);
@@ -264,6 +268,6 @@ size_t radix_scratch_words(uint32_t n);
 hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt,
                             uint32_t* vals, uint32_t* vals_alt, bool iota_payload, bool want_sorted_keys,
                             uint32_t** keys_sorted, uint32_t** vals_sorted, hipStream_t stream,
-                            const uint32_t* n_device = nullptr);
+                            const uint32_t* n_device = nullptr, const uint32_t* drop_key = nullptr);
 
 } // namespace gsr

@@ -31,6 +31,10 @@
 //   3. counters are turned into (wave, digit) offsets, a 256-wide scan gives the digit segments of the tile;
 //   4. pairs are parked in LDS at their in-tile position and written out in that order, so every digit
 //      segment is a contiguous, coalesced run in HBM.
+//
+// A sort may DROP one key value in its first pass (radix_sort_pairs' drop_key: the depth sort's culled Gaussians, a quarter
+// of C3's and most of a close-up's): the count kernel does not count those items, the scatter neither ranks nor writes them
+// and stores how many were kept; the later passes read that count (n_device) and sort the kept ones only.
 #include "gsr_internal.h"
 
 #include <mutex>
@@ -84,7 +88,8 @@ __device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t* sc
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kThreads) radix_count_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
                                                               uint32_t digit_mask, uint32_t* __restrict__ counts,
-                                                              uint32_t tiles_pad, const uint32_t* __restrict__ n_device) {
+                                                              uint32_t tiles_pad, const uint32_t* __restrict__ n_device,
+                                                              int drop, uint32_t drop_key) {
     __shared__ uint32_t s_hist[kCountCopies][256];
     const int tid = threadIdx.x;
     const uint32_t block = blockIdx.x;
@@ -100,15 +105,28 @@ __global__ void __launch_bounds__(kThreads) radix_count_kernel(const uint32_t* _
         uint4 k[kItems / 4];
 #pragma unroll
         for (int i = 0; i < kItems / 4; ++i) k[i] = k4[i * kThreads + tid];
+        if (!drop) {
 #pragma unroll
-        for (int i = 0; i < kItems / 4; ++i) {
-            atomicAdd(&mine[(k[i].x >> shift) & digit_mask], 1u);
-            atomicAdd(&mine[(k[i].y >> shift) & digit_mask], 1u);
-            atomicAdd(&mine[(k[i].z >> shift) & digit_mask], 1u);
-            atomicAdd(&mine[(k[i].w >> shift) & digit_mask], 1u);
+            for (int i = 0; i < kItems / 4; ++i) {
+                atomicAdd(&mine[(k[i].x >> shift) & digit_mask], 1u);
+                atomicAdd(&mine[(k[i].y >> shift) & digit_mask], 1u);
+                atomicAdd(&mine[(k[i].z >> shift) & digit_mask], 1u);
+                atomicAdd(&mine[(k[i].w >> shift) & digit_mask], 1u);
+            }
+        } else {   // keys equal to drop_key leave the sort with this pass: they are not counted (and not written by the scatter)
+#pragma unroll
+            for (int i = 0; i < kItems / 4; ++i) {
+                if (k[i].x != drop_key) atomicAdd(&mine[(k[i].x >> shift) & digit_mask], 1u);
+                if (k[i].y != drop_key) atomicAdd(&mine[(k[i].y >> shift) & digit_mask], 1u);
+                if (k[i].z != drop_key) atomicAdd(&mine[(k[i].z >> shift) & digit_mask], 1u);
+                if (k[i].w != drop_key) atomicAdd(&mine[(k[i].w >> shift) & digit_mask], 1u);
+            }
         }
     } else {
-        for (uint32_t t = tid; tile_base + t < n; t += kThreads) atomicAdd(&mine[(keys[tile_base + t] >> shift) & digit_mask], 1u);
+        for (uint32_t t = tid; tile_base + t < n; t += kThreads) {
+            const uint32_t kk = keys[tile_base + t];
+            if (!drop || kk != drop_key) atomicAdd(&mine[(kk >> shift) & digit_mask], 1u);
+        }
     }
     __syncthreads();
     uint32_t c = 0;
@@ -157,7 +175,8 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t*
                                                                 uint32_t* __restrict__ vals_out, uint32_t n, int shift,
                                                                 uint32_t digit_mask, const uint32_t* __restrict__ offsets,
                                                                 uint32_t tiles_pad, const uint32_t* __restrict__ totals,
-                                                                const uint32_t* __restrict__ n_device) {
+                                                                const uint32_t* __restrict__ n_device, uint32_t drop_key,
+                                                                uint32_t* __restrict__ kept_out) {
     __shared__ uint32_t s_keys[kTileItems];
     __shared__ uint32_t s_vals[kTileItems];
     __shared__ uint32_t s_count[kWaves][256];  // per-wave digit counts, then per-wave offsets inside the segment
@@ -189,6 +208,13 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t*
         if (kIota) val[i] = tile_base + t;
         else val[i] = t < tile_n ? vals_in[tile_base + t] : 0u;
     }
+    // items of this lane that take part: inside the tile, and (first pass of a sort that drops a key value, kept_out != null:
+    // the depth sort's culled Gaussians) not the dropped key -- those are neither ranked nor written, the later passes never
+    // see them
+    uint32_t ok = 0u;
+#pragma unroll
+    for (int i = 0; i < kItems; ++i)
+        if (first + 64u * i < tile_n && !(kIota && kept_out != nullptr && key[i] == drop_key)) ok |= 1u << i;
     const uint32_t tile_offset = offsets[(size_t)tid * tiles_pad + block];  // keys of digit `tid` in earlier tiles
     const uint32_t digit_total = totals[tid];
     __syncthreads();
@@ -203,7 +229,7 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t*
         // compute.  Only reached on a device where the self-test confirmed that order (radix_rank_mode).
 #pragma unroll
         for (int i = 0; i < kItems; ++i) {
-            const bool valid = first + 64u * i < tile_n;
+            const bool valid = (ok >> i) & 1u;
             const uint32_t d = (key[i] >> shift) & digit_mask;
             rank[i] = valid ? atomicAdd(&my_count[d], 1u) : 0u;
         }
@@ -211,7 +237,7 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t*
     const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
-        const bool valid = first + 64u * i < tile_n;
+        const bool valid = (ok >> i) & 1u;
         const uint32_t d = (key[i] >> shift) & digit_mask;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -237,17 +263,19 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t*
         s_count[w][tid] = total;
         total += c;
     }
-    const uint32_t seg_start = block_exclusive_sum(total, s_scan, tid);
+    uint32_t tile_kept;   // = tile_n unless keys were dropped
+    const uint32_t seg_start = block_exclusive_sum(total, s_scan, tid, &tile_kept);
     const uint32_t digit_start = block_exclusive_sum(digit_total, s_scan, tid);  // keys with a smaller digit
     s_seg_start[tid] = seg_start;
     s_dst_base[tid] = digit_start + tile_offset - seg_start;
+    if (kIota && kept_out != nullptr && block == 0u && tid == 255) *kept_out = digit_start + digit_total;  // what the later passes sort
     __syncthreads();
     GSR_TRACE(2);
 
     // 4. park in tile order, then stream out
 #pragma unroll
     for (int i = 0; i < kItems; ++i) {
-        if (first + 64u * i < tile_n) {
+        if ((ok >> i) & 1u) {
             const uint32_t d = (key[i] >> shift) & digit_mask;
             const uint32_t pos = s_seg_start[d] + s_count[wave][d] + rank[i];
             s_keys[pos] = key[i];
@@ -259,7 +287,7 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t*
 #pragma unroll
     for (int j = 0; j < kItems; ++j) {
         const uint32_t p = (uint32_t)(j * kThreads + tid);
-        if (p < tile_n) {
+        if (p < tile_kept) {
             const uint32_t k = s_keys[p];
             const uint32_t dst = s_dst_base[(k >> shift) & digit_mask] + p;
             if (kKeysOut) keys_out[dst] = k;
@@ -387,12 +415,13 @@ int radix_rank_mode(hipStream_t stream, unsigned long long* violations) {
 
 size_t radix_scratch_words(uint32_t n) {
     const size_t tiles = ((size_t)n + kTileItems - 1) / kTileItems;
-    return 256u * ((tiles + 3u) & ~(size_t)3u) + 256u;  // per-digit rows of tile counts, then the digit totals
+    return 256u * ((tiles + 3u) & ~(size_t)3u) + 256u + 4u;  // per-digit rows of tile counts, the digit totals, the kept count
 }
 
 hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt,
                             uint32_t* vals, uint32_t* vals_alt, bool iota_payload, bool want_sorted_keys,
-                            uint32_t** keys_sorted, uint32_t** vals_sorted, hipStream_t stream, const uint32_t* n_device) {
+                            uint32_t** keys_sorted, uint32_t** vals_sorted, hipStream_t stream, const uint32_t* n_device,
+                            const uint32_t* drop_key) {
     *keys_sorted = keys;
     *vals_sorted = vals;
     if (n == 0 || bits <= 0) return hipSuccess;
@@ -403,17 +432,23 @@ hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* k
     const uint32_t tiles_pad = (tiles + 3u) & ~3u;
     uint32_t* counts = scratch;
     uint32_t* totals = scratch + (size_t)256u * tiles_pad;
+    uint32_t* kept = totals + 256;   // drop_key: how many items the first pass kept = what the later passes sort
+    const bool dropping = drop_key != nullptr && iota_payload && n_device == nullptr && passes > 1;
     uint32_t *kin = keys, *kout = keys_alt, *vin = vals, *vout = vals_alt;
     for (int p = 0; p < passes; ++p) {
         const int width = bits - 8 * p < 8 ? bits - 8 * p : 8;
         const uint32_t mask = (1u << width) - 1u;
         const bool iota = iota_payload && p == 0;
         const bool keys_out = want_sorted_keys || p + 1 < passes;
-        hipLaunchKernelGGL(radix_count_kernel, dim3(tiles), dim3(kThreads), 0, stream, kin, n, 8 * p, mask, counts, tiles_pad, n_device);
+        const int drop = dropping && p == 0 ? 1 : 0;
+        const uint32_t dkey = dropping ? *drop_key : 0u;
+        uint32_t* kept_out = drop ? kept : nullptr;
+        if (dropping && p == 1) n_device = kept;   // (the launches stay sized for n: surplus workgroups leave at once)
+        hipLaunchKernelGGL(radix_count_kernel, dim3(tiles), dim3(kThreads), 0, stream, kin, n, 8 * p, mask, counts, tiles_pad, n_device, drop, dkey);
         hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(kThreads), 0, stream, counts, tiles, tiles_pad, totals, n_device);
 #define GSR_RADIX_LAUNCH(I, K, A)                                                                                      \
     hipLaunchKernelGGL((radix_scatter_kernel<I, K, A>), dim3(tiles), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, \
-                       8 * p, mask, counts, tiles_pad, totals, n_device)
+                       8 * p, mask, counts, tiles_pad, totals, n_device, dkey, kept_out)
 #define GSR_RADIX_LAUNCH_IK(A)                      \
     do {                                            \
         if (iota && keys_out) GSR_RADIX_LAUNCH(true, true, A);   \

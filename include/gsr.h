@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 7
+#define GSR_ABI_VERSION 8
 
 #if defined(__GNUC__)
 #define GSR_API __attribute__((visibility("default")))
@@ -297,7 +297,7 @@ typedef enum gsr_geom_slot {
                                    (0 = emits nothing), then the 64-bit mask of its live tiles when w * h <= 64 (all ones
                                    for a larger splat, whose live tiles are found later); GSR_OPT_TILE_CULL */
     GSR_GEOM_INTERNAL_RADII,    /* i32[P]   used when the caller passes radii == NULL              */
-    GSR_GEOM_DEPTH_ORDER,       /* u32[P]   Gaussian ids, ascending (depth bits, id); culled last  */
+    GSR_GEOM_DEPTH_ORDER,       /* u32[P]   Gaussian ids, ascending (depth bits, id): the visible ones; GSR_OPT_DEPTH_DROP */
     GSR_GEOM_POINT_OFFSETS,     /* u32[P]   inclusive scan of the pair counts in DEPTH_ORDER order     */
     GSR_GEOM_LISTED,            /* u8[P]    inference calls with deferred colours that were cut into depth slabs: s + 1 when
                                    slab s (the last one that did) put the Gaussian into a list, 0 when none did; such a call
@@ -366,6 +366,11 @@ typedef enum gsr_option {
     /* read-only: what sorts queued on the CURRENT device use -- 1 LDS adds, 0 ballots (runs the self-test if this
      * device has not been tested yet and the request is 2).  gsr_set_option rejects it. */
     GSR_OPT_RADIX_RANK_ACTIVE = 6,
+    /* [1] The depth sort drops the Gaussians that produce no pair (culled, or every tile dead) in its first pass instead of
+     * carrying them to the end of the order through all four: the later passes sort the visible ones only.  The first
+     * `visible` entries of GSR_GEOM_DEPTH_ORDER are the same either way; with 1 the entries behind them are undefined
+     * (0: the culled Gaussians, in index order, as rounds 1 - 2 left them). */
+    GSR_OPT_DEPTH_DROP = 7,
     GSR_OPT_NUM
 } gsr_option;
 GSR_API int gsr_set_option(int option, int value);

@@ -150,10 +150,17 @@ def decode_scratch(lay, geom, binning, img, P, W, H):
     out["tight_rect"] = np.stack((bins[:, 0] & 0xFFFF, bins[:, 0] >> 16, bins[:, 1] & 0xFFFF, bins[:, 1] >> 16), 1)   # x0 y0 w h
     out["live_mask"] = bins[:, 2].astype(np.uint64) | (bins[:, 3].astype(np.uint64) << np.uint64(32))
     out["depth_order"] = view(geom, g["depth_order"], torch.int32, P).astype(np.uint32)
+    # The depth sort drops the Gaussians that emit nothing in its first pass (GSR_OPT_DEPTH_DROP): the order is defined for
+    # the others (a record with a size) and whatever the buffer held behind them is blanked here, so that whole-array
+    # comparisons between two runs compare what the library defines.
+    out["sorted_count"] = int(np.count_nonzero(bins[:, 1]))
+    out["depth_order"][out["sorted_count"]:] = 0xFFFFFFFF
     out["point_offsets"] = view(geom, g["point_offsets"], torch.int32, P).astype(np.uint32)
     # live tiles = pairs each splat emits: the steps of the inclusive offsets over the depth order
     tt = np.zeros(P, np.uint32)
-    tt[out["depth_order"]] = np.diff(out["point_offsets"].astype(np.int64), prepend=0).astype(np.uint32)
+    steps = np.diff(out["point_offsets"].astype(np.int64), prepend=0).astype(np.uint32)
+    emits = steps != 0   # (positions behind the visible ones carry no pairs; the depth order there is undefined: GSR_OPT_DEPTH_DROP)
+    tt[out["depth_order"][emits]] = steps[emits]
     out["tiles_touched"] = tt
     b = lay["binning"]
     live = lay["counts"]["live_pairs"]

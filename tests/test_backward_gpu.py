@@ -88,8 +88,8 @@ def assert_forward_state(name, hip, fref):
     else:
         # culled: splats whose every tile is dead leave the depth order; what is left keeps the oracle's order, and each
         # tile's list is ascending in (depth bits, id) -- the property the blend and the backward rely on
-        order = f["depth_order"]
-        kept = order[f["tiles_touched"][order] > 0]
+        steps = np.diff(f["point_offsets"].astype(np.int64), prepend=0)
+        kept = f["depth_order"][steps > 0]   # (the order behind the visible Gaussians is undefined: GSR_OPT_DEPTH_DROP)
         pos = np.full(fref["radii"].shape[0], -1, np.int64)
         pos[expect] = np.arange(V)
         assert (pos[kept] >= 0).all() and (np.diff(pos[kept]) > 0).all(), f"{name}: culled depth order is not a subsequence"

@@ -65,7 +65,7 @@ def test_argument_errors_do_not_need_a_device():
     assert L.gsr_radix_sort_pairs(5, 0, None, None, None, None, 0, None, 0, None, None) == -1      # bits out of range
     assert L.gsr_radix_sort_pairs(0, 8, None, None, None, None, 0, None, 0, None, None) == 0       # nothing to sort
     assert L.gsr_radix_sort_pairs(5, 8, None, None, None, None, 0, None, 0, None, None) == -1
-    assert L.gsr_radix_scratch_bytes(4096, 32) == (256 * 4 + 256) * 4 and L.gsr_radix_scratch_bytes(4097, 13) == (256 * 4 + 256) * 4
+    assert L.gsr_radix_scratch_bytes(4096, 32) == (256 * 4 + 256 + 4) * 4 and L.gsr_radix_scratch_bytes(4097, 13) == (256 * 4 + 256 + 4) * 4
     assert L.gsr_selftest_exp(0, 1, None, None) == -1
     assert L.gsr_mark_visible(-1, None, None, None, None, None) == -1
     assert L.gsr_mark_visible(0, None, None, None, None, None) == 0
