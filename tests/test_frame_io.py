@@ -1,4 +1,4 @@
-"""Frame writers: dependency-free PNG against PIL's decoder, and the three per-frame files."""
+"""Frame writers: dependency-free PNG against PIL's decoder, and the four per-frame files."""
 import io
 
 import numpy as np
@@ -30,6 +30,27 @@ def test_write_frame_outputs(tmp_path):
     n = frame_io.decode_png(open(paths["normal"], "rb").read())
     np.testing.assert_array_equal(n, ((result["normal"] + 1) / 2 * 255).to(torch.uint8).numpy())
     assert paths["images"].endswith("images/00007.png") and paths["depth"].endswith("depth/00007.npy")
+    # the depth preview: depth2img(depth, scale=3.0) through the turbo table (scene_representation.py:432-433)
+    prev = frame_io.decode_png(open(paths["depth_preview"], "rb").read())
+    idx = (np.clip(result["depth"].numpy() / 3.0, 0.0, 1.0) * 255).astype(np.uint8)
+    np.testing.assert_array_equal(prev, frame_io.TURBO_LUT[idx])
+    assert paths["depth_preview"].endswith("depth/00007.png") and prev.shape == (H, W, 3)
+
+
+def test_turbo_table_is_the_published_one():
+    """TURBO_LUT against matplotlib's copy of the turbo float table (the numbers OpenCV's colormap.cpp carries), x 255,
+    rounded to nearest; end points and a mid entry typed in from cv2.applyColorMap's documented output (BGR reversed)."""
+    lut = frame_io.TURBO_LUT
+    assert lut.shape == (256, 3) and lut.dtype == np.uint8
+    np.testing.assert_array_equal(lut[0], (48, 18, 59))      # dark blue
+    np.testing.assert_array_equal(lut[255], (122, 4, 3))     # dark red
+    assert lut[128, 1] > 240 and lut[128, 0] > 120 and lut[128, 2] < 100   # the green-yellow middle
+    cm = pytest.importorskip("matplotlib._cm_listed")
+    data = np.array(cm._turbo_data, dtype=np.float32)
+    np.testing.assert_array_equal(lut, np.rint(data * np.float32(255.0)).astype(np.uint8))
+    # depth2img: scale, clip, truncation to 8 bits
+    d = np.array([-1.0, 0.0, 1.5, 2.999, 3.0, 40.0], np.float32)
+    np.testing.assert_array_equal(frame_io.depth2img(d, 3.0), lut[[0, 0, 127, 254, 255, 255]])
 
 
 def test_frame_writer_pool_writes_the_same_files(tmp_path):
@@ -47,7 +68,7 @@ def test_frame_writer_pool_writes_the_same_files(tmp_path):
             fr["render"].zero_()          # the frame was copied out: the caller may reuse its tensors at once
     for sub in ("images", "depth", "normal"):
         names = sorted(p.name for p in (a / sub).iterdir())
-        assert names == sorted(p.name for p in (b / sub).iterdir()) and len(names) == 9
+        assert names == sorted(p.name for p in (b / sub).iterdir()) and len(names) == (18 if sub == "depth" else 9)   # .npy + preview .png
         for n in names:
             assert (a / sub / n).read_bytes() == (b / sub / n).read_bytes(), (sub, n)
     w = frame_io.FrameWriter(str(tmp_path / "bad"), workers=1)
@@ -58,7 +79,7 @@ def test_frame_writer_pool_writes_the_same_files(tmp_path):
 
 @pytest.mark.gpu
 def test_render_trajectory_script_end_to_end(tmp_path):
-    """PLY + trajectory JSON in, the reference's three per-frame files out (scripts/render_trajectory.py)."""
+    """PLY + trajectory JSON in, the reference's four per-frame files out (scripts/render_trajectory.py)."""
     import json
     import subprocess
     import sys
