@@ -26,6 +26,7 @@ thread_local bool g_have_offsets = false;
 // The pair counts of a call past the first host read live on the device (one SlabInfo per depth slab); the call
 // queues a copy of that table into pinned memory at its end, and the accessors below wait for it only when asked.
 struct PinnedSlot {
+    void* dev = nullptr;          // the same memory at its device-visible address (null: this runtime does not map it)
     uint32_t* host = nullptr;     // a few KB of pinned memory, pooled per calling thread and deliberately never
     hipEvent_t copied = nullptr;  // freed: freeing at thread exit can race HIP runtime teardown
     hipEvent_t finished = nullptr;
@@ -689,7 +690,8 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
         fc.pinned = g_pinned_free.back();
         g_pinned_free.pop_back();
     } else {
-        GSR_HIP(hipHostMalloc((void**)&fc.pinned.host, kPinnedBytes, hipHostMallocPortable));
+        GSR_HIP(hipHostMalloc((void**)&fc.pinned.host, kPinnedBytes, hipHostMallocPortable | hipHostMallocMapped));
+        if (hipHostGetDevicePointer(&fc.pinned.dev, fc.pinned.host, 0) != hipSuccess) { (void)hipGetLastError(); fc.pinned.dev = nullptr; }
         GSR_HIP(hipEventCreateWithFlags(&fc.pinned.copied, hipEventDisableTiming));
         GSR_HIP(hipEventCreateWithFlags(&fc.pinned.finished, hipEventDisableTiming));
     }
@@ -713,13 +715,14 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     const size_t off_slab_offsets = gc.take<uint32_t>(fc.inference ? n : 0);
     const size_t off_slab_cpos = gc.take<uint32_t>(fc.inference ? n : 0);
     const size_t off_slab_coffs = gc.take<uint32_t>(fc.inference ? n : 0);
-    // the words of a call that must be zero before its first kernel, cleared by ONE memset: frame counters, the table of
-    // depth slabs, one bit per finished 8x8 quadrant, one bit per finished tile (a row of bits per tile row)
+    // the words of a call that must be zero before the kernels that use them, cleared by the tally kernel behind the
+    // projection: frame counters, the table of depth slabs, one bit per finished 8x8 quadrant, one bit per finished tile
     const size_t off_flag = gc.take<gsr::FrameCounters>(1);
     fc.off_slabs = gc.take<gsr::SlabInfo>(gsr::kMaxSlabs);
     fc.off_quad = gc.take<uint32_t>(quad_words);
     fc.off_rows = gc.take<uint32_t>(rows_words);
     const size_t zero_end = gc.off;
+    const size_t off_tallies = gc.take<gsr::BlockTally>((n + 255) / 256);
     fc.off_listed = gc.take<uint8_t>(fc.defer_colour ? n : 0);  // one byte per Gaussian: which slab listed it (cleared by the
                                                                 // projection kernel among its other per-Gaussian stores)
     const size_t off_tile_totals = gc.take<uint32_t>(2 * dup_blocks);  // tile totals, then global offsets at tile ends
@@ -758,6 +761,7 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     ga.ids = nullptr;  // the first radix pass generates 0..P-1 itself
     ga.listed = fc.defer_colour ? (uint8_t*)(gbase + fc.off_listed) : nullptr;
     ga.counters = (gsr::FrameCounters*)(gbase + off_flag);
+    ga.tallies = (gsr::BlockTally*)(gbase + off_tallies);
     fc.point_offsets = (uint32_t*)(gbase + geom_off[GSR_GEOM_POINT_OFFSETS]);
     fc.slab_offsets = (uint32_t*)(gbase + off_slab_offsets);
     fc.slab_cpos = (uint32_t*)(gbase + off_slab_cpos);
@@ -766,16 +770,21 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     fc.slab_tile_totals = (uint32_t*)(gbase + off_slab_totals);
     fc.sorted_bins = (uint4*)(gbase + off_sorted_bins);
 
-    GSR_HIP(hipMemsetAsync(gbase + off_flag, 0, zero_end - off_flag, stream));
     stamp(0, stream);
     GSR_HIP(gsr::launch_preprocess(in, cam, ga, stream));
     GSR_STAGE_CHECK("preprocess");
     stamp(1, stream);
 
-    // The one host round trip of the call (rasterizer_impl.cu:282 reads num_rendered back to size the
-    // binning arena).  Here the totals come out of the preprocess kernel, so the copy is queued right
-    // behind it and the host waits on an event while the GPU is already running the depth sort.
-    GSR_HIP(hipMemcpyAsync(fc.pinned.host, gbase + off_flag, kCounterBytes, hipMemcpyDeviceToHost, stream));
+    // The one host round trip of the call (rasterizer_impl.cu:282 reads num_rendered back to size the binning arena).  Here
+    // the totals are summed by one short launch behind the projection kernel, which stores them straight into the call's
+    // pinned slot (device-visible at its own address) and clears the call's zero block on the way; the host waits on an
+    // event while the GPU is already running the depth sort.
+    void* const host_dev = fc.pinned.dev;
+    memset(fc.pinned.host, 0, kCounterBytes);
+    GSR_HIP(gsr::launch_counter_tally(ga.tallies, (P + 255) / 256, ga.counters, zero_end - off_flag,
+                                      reinterpret_cast<gsr::FrameCounters*>(host_dev), stream));
+    if (host_dev == nullptr)   // (a runtime that does not map pinned memory: the totals went into the zero block's first slots)
+        GSR_HIP(hipMemcpyAsync(fc.pinned.host, gbase + off_flag, kCounterBytes, hipMemcpyDeviceToHost, stream));
     GSR_HIP(hipEventRecord(fc.pinned.copied, stream));
     fc.queued = true;
 
@@ -858,9 +867,7 @@ int forward_finish(ForwardCall& fc) {
     // the slabs' pair counts are stored into the pinned slot by the kernels that settle them (pinned memory is device-visible
     // at its own address; if this runtime says otherwise a copy follows the call as in rounds 1 - 2)
     gsr::SlabInfo* const host_table = reinterpret_cast<gsr::SlabInfo*>(reinterpret_cast<char*>(fc.pinned.host) + kSlabTableAt);
-    void* host_table_dev = nullptr;
-    if (hipHostGetDevicePointer(&host_table_dev, host_table, 0) != hipSuccess) { (void)hipGetLastError(); host_table_dev = nullptr; }
-    ba.slabs_host = reinterpret_cast<gsr::SlabInfo*>(host_table_dev);
+    ba.slabs_host = fc.pinned.dev ? reinterpret_cast<gsr::SlabInfo*>(reinterpret_cast<char*>(fc.pinned.dev) + kSlabTableAt) : nullptr;
     for (int k = 0; k < gsr::kMaxSlabs; ++k) host_table[k] = gsr::SlabInfo{0u, 0u, 0u, 0u};   // (a slab no kernel reaches has no pairs)
     ba.quad_done = (uint32_t*)(gbase + fc.off_quad);
     ba.done_rows = (uint32_t*)(gbase + fc.off_rows);

@@ -15,8 +15,9 @@ constexpr int kDupTile = 1024;               // sorted positions per workgroup o
 constexpr int kMaxSlabs = 8;                 // front-to-back depth slabs of one call (occlusion culling between slabs)
 constexpr uint32_t kMaskTiles = 64;          // tight rectangles up to this many tiles carry a bit mask of live tiles
 
-// Device words of one forward call that must be zero before its first kernel: ONE memset clears them all.
-// Only the first kCounterCopyBytes travel back to the host.
+// Device words of one forward call that must be zero before the kernel that uses them: cleared, with the slab table and
+// the bit rows that follow them in the arena, by the tally kernel that follows the projection (no memset launch).
+// The totals travel to the host in the same layout (slot 0 of each array; the other slots are zero).
 struct FrameCounters {
     unsigned long long pair_totals[kRectPartials];  // (sum of rectangle areas) << 32 | upper bound of the live pairs
     uint32_t visible[kRectPartials];                // Gaussians that emit at least the chance of a pair (key != kCulledKey)
@@ -27,6 +28,15 @@ struct FrameCounters {
     uint32_t pad;
 };
 constexpr size_t kCounterCopyBytes = sizeof(FrameCounters);
+
+// What one 256-lane workgroup of the projection kernel found.  Every workgroup stores its own entry and counter_tally_kernel
+// sums them: no atomics (rounds 1 - 2: three per wave on 64 zero-filled words), nothing to zero-fill.
+struct BlockTally {
+    unsigned long long pair_total;   // (sum of rectangle areas) << 32 | upper bound of the live pairs
+    uint32_t visible;                // Gaussians with key != kCulledKey
+    uint32_t big_rows;               // tile rows of the splats too large for a mask; bit 31 = a prefiltered violation
+};
+static_assert(sizeof(BlockTally) == 16, "one 16-byte store per workgroup");
 
 struct Camera {
     const float* viewmatrix;  // 16 floats, transposed w2c
@@ -89,6 +99,7 @@ struct GeometryArrays {
     float* rgb;
     SplatBin* bins;
     FrameCounters* counters;
+    BlockTally* tallies;  // [div_up(P, 256)] one entry per workgroup of the projection kernel
     int* radii;           // caller's radii or the internal array
     uint32_t* depth_keys; // sort keys (float bits of depth, kCulledKey if culled)
     uint32_t* ids;        // 0..P-1, the sort payload; nullptr when the sort generates it itself
@@ -127,6 +138,13 @@ hipError_t launch_preprocess(const GaussianInputs& in, const Camera& cam, const 
                              hipStream_t stream);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
                                hipStream_t stream);
+// Sums the projection kernel's per-workgroup tallies, stores the totals at `host_totals` (pinned host memory at its
+// device-visible address; slot 0 of each array, the rest of the block must have been zeroed by the host) or, when that is
+// null, into `zero_block` itself (a D2H copy then follows), and clears the `zero_bytes` at `zero_block` (frame counters,
+// slab table, quadrant and tile bits of the call) -- one short launch in place of a memset before the projection and a
+// copy after it.
+hipError_t launch_counter_tally(const BlockTally* tallies, int blocks, FrameCounters* zero_block, size_t zero_bytes,
+                                FrameCounters* host_totals, hipStream_t stream);
 // SH colours of the Gaussians the pair expansion of one slab marked (`listed[gid] == tag`, tag = slab + 1;
 // GaussianInputs::defer_colour), evaluated in Gaussian order; rgb[gid] is written.
 // `duty` (nullable): the slab's tile ranges are computed by the first workgroups of the same launch.

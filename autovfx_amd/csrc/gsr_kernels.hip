@@ -47,6 +47,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
     uint32_t rect_area = 0;     // the reference's rectangle: what num_rendered counts
     uint32_t live_bound = 0;    // upper bound of the pairs this splat will emit (exact for masked splats)
     uint32_t big_rows = 0;      // tile rows of a splat too large for a mask
+    bool violation = false;     // culled although the caller said nothing would be (prefiltered)
     SplatBin bin = {0u, 0u, 0u, 0u};
     uint32_t key = kCulledKey;
     // what the tile-mask phase needs of a candidate (a visible splat whose tight rectangle has <= kMaskTiles tiles and
@@ -71,7 +72,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
     if (vz <= 0.2f) {
         // The reference printf+traps here when prefiltered is set (auxiliary.h:156-160); we record
         // the violation and keep the context alive.
-        if (in.prefiltered) atomicOr(&out.counters->error_flag, 1u);
+        violation = in.prefiltered != 0;
     } else {
         const float pw = 1.0f / (hw + 0.0000001f);
         const float ndc_x = hx * pw, ndc_y = hy * pw;
@@ -264,8 +265,11 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
     }
     // Pair totals, needed on the host before the binning arena can be sized: an upper bound of the live pairs (what
     // gets expanded and sorted; exact but for the splats too large for a mask) in the low word and the reference's
-    // num_rendered (sum of rectangle areas, part of its return value) in the high word of one 64-bit add.  One atomic
-    // per wave, spread over kRectPartials words (same-word atomics serialise at ~12 ns each).
+    // num_rendered (sum of rectangle areas, part of its return value) in the high word of one 64-bit sum.  Summed over
+    // the wave, then over the workgroup's four waves through LDS, and stored as this workgroup's BlockTally: no atomics and
+    // no zero-filled accumulator (counter_tally_kernel adds the workgroups up).
+    __shared__ unsigned long long s_tot[4];
+    __shared__ uint32_t s_vis[4], s_big[4];
     unsigned long long wave_tot = ((unsigned long long)rect_area << 32) | (unsigned long long)live_bound;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wave_tot += __shfl_xor(wave_tot, d);
@@ -275,13 +279,65 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) big_rows += (uint32_t)__shfl_xor((int)big_rows, d);
     }
+    const unsigned long long any_violation = __ballot(violation);
     if ((threadIdx.x & 63) == 0) {
-        const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) & (kRectPartials - 1);
-        if (wave_tot != 0ull) atomicAdd(out.counters->pair_totals + slot, wave_tot);
-        if (emitting != 0ull) atomicAdd(out.counters->visible + slot, (uint32_t)__popcll(emitting));
-        if (any_big != 0ull) atomicAdd(out.counters->big_rows + slot, big_rows);
+        const int w = threadIdx.x >> 6;
+        s_tot[w] = wave_tot;
+        s_vis[w] = (uint32_t)__popcll(emitting);
+        s_big[w] = (any_big != 0ull ? big_rows : 0u) | (any_violation != 0ull ? 0x80000000u : 0u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        BlockTally t;
+        t.pair_total = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+        t.visible = s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3];
+        const uint32_t big = (s_big[0] & 0x7FFFFFFFu) + (s_big[1] & 0x7FFFFFFFu) + (s_big[2] & 0x7FFFFFFFu) + (s_big[3] & 0x7FFFFFFFu);
+        t.big_rows = big | ((s_big[0] | s_big[1] | s_big[2] | s_big[3]) & 0x80000000u);
+        *reinterpret_cast<uint4*>(out.tallies + blockIdx.x) = *reinterpret_cast<const uint4*>(&t);
     }
     GSR_KTRACE(blockIdx.x, 3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One workgroup right behind the projection kernel: adds up its per-workgroup tallies, hands the totals to the host and
+// clears the call's zero block.  Takes the place of the memset that used to precede the projection kernel and of the
+// copy kernel that followed it (rasterizer_impl.cu:282 reads num_rendered back at this point).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) counter_tally_kernel(const BlockTally* __restrict__ tallies, int blocks,
+                                                             FrameCounters* __restrict__ zero_block, int zero_words,
+                                                             FrameCounters* __restrict__ host_totals) {
+    __shared__ unsigned long long s_tot[16];
+    __shared__ uint32_t s_vis[16], s_big[16], s_flag[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long tot = 0ull;
+    uint32_t vis = 0u, big = 0u, flag = 0u;
+    for (int b = tid; b < blocks; b += 1024) {
+        const uint4 t = *reinterpret_cast<const uint4*>(tallies + b);
+        tot += (unsigned long long)t.x | ((unsigned long long)t.y << 32);
+        vis += t.z;
+        big += t.w & 0x7FFFFFFFu;
+        flag |= t.w >> 31;
+    }
+    uint32_t* z = reinterpret_cast<uint32_t*>(zero_block);
+    for (int i = tid; i < zero_words; i += 1024) z[i] = 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        tot += __shfl_xor(tot, d);
+        vis += (uint32_t)__shfl_xor((int)vis, d);
+        big += (uint32_t)__shfl_xor((int)big, d);
+        flag |= (uint32_t)__shfl_xor((int)flag, d);
+    }
+    if (lane == 0) { s_tot[wave] = tot; s_vis[wave] = vis; s_big[wave] = big; s_flag[wave] = flag; }
+    __syncthreads();   // (also: the zero block is cleared before the totals may land in it)
+    if (tid == 0) {
+        tot = 0ull; vis = 0u; big = 0u; flag = 0u;
+        for (int w = 0; w < 16; ++w) { tot += s_tot[w]; vis += s_vis[w]; big += s_big[w]; flag |= s_flag[w]; }
+        FrameCounters* dst = host_totals != nullptr ? host_totals : zero_block;
+        dst->pair_totals[0] = tot;
+        dst->visible[0] = vis;
+        dst->big_rows[0] = big;
+        dst->error_flag = flag;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -526,6 +582,13 @@ hipError_t launch_sh_colour_all(const GaussianInputs& in, const Camera& cam, con
     RangesDuty none = {};
     hipLaunchKernelGGL(sh_colour_all_kernel, dim3(blocks), dim3(256), 0, stream, in, cam.cam_pos, radii, rgb, duty ? *duty : none,
                        duty ? ranges_duty_blocks(duty->num_tiles) : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_counter_tally(const BlockTally* tallies, int blocks, FrameCounters* zero_block, size_t zero_bytes,
+                                FrameCounters* host_totals, hipStream_t stream) {
+    hipLaunchKernelGGL(counter_tally_kernel, dim3(1), dim3(1024), 0, stream, tallies, blocks, zero_block, (int)(zero_bytes / 4),
+                       host_totals);
     return hipGetLastError();
 }
 
