@@ -123,7 +123,7 @@ def design_bytes(u, inference=True, deferred=True):
 
 # kernels of each stage (names as rocprofv3 prints them, namespaces stripped) for the counter traffic per stage
 STAGE_KERNELS = {
-    "preprocess": ("preprocess_kernel",),
+    "preprocess": ("preprocess_kernel", "counter_tally_kernel"),
     "depth_sort": (),   # split by call index below: the first 4 passes of a frame are the depth sort
     "duplicate": ("bin_gather_kernel", "bin_offsets_kernel", "slab_bounds_kernel", "slab_recount_kernel", "slab_compact_kernel", "expand_kernel"),
     "tile_sort": (),
@@ -1034,7 +1034,7 @@ def time_frame_files(b, n):
                     w.submit(f"p{j:05d}", frames[j % 4])
             t_pool = time.perf_counter() - t0
         return {"frames": n, "ms_per_frame": round(t_total / n * 1e3, 2),
-                "what": "RGBA PNG + depth .npy + normal PNG per frame (D2H copies, zlib level 3, file writes), one host thread",
+                "what": "RGBA PNG + depth .npy + depth preview PNG + normal PNG per frame (D2H copies, zlib level 3, file writes), one host thread",
                 "writer_pool": {"frames": m, "threads": workers, "ms_per_frame": round(t_pool / m * 1e3, 2)}}
     except Exception as e:
         return {"error": repr(e)[:200]}

@@ -57,7 +57,7 @@ if len(sys.argv) >= 5:
     kernels = {k: {"bytes_per_launch": e["bytes"] / e["launches"] if e["launches"] else 0.0, "launches_per_frame": e["launches"]}
                for k, e in kernels.items()}
     # HBM-side bytes per frame and pipeline stage (bench.py's per-stage counter figures)
-    stage_of = {"preprocess_kernel": "preprocess", "bin_gather_kernel": "duplicate", "bin_offsets_kernel": "duplicate",
+    stage_of = {"preprocess_kernel": "preprocess", "counter_tally_kernel": "preprocess", "bin_gather_kernel": "duplicate", "bin_offsets_kernel": "duplicate",
                 "slab_recount_kernel": "duplicate", "slab_compact_kernel": "duplicate", "expand_kernel": "duplicate",
                 "tile_ranges_kernel": "ranges", "sh_colour_listed_kernel": "colour", "sh_colour_all_kernel": "colour",
                 "blend_quadrant_kernel": "blend"}
