@@ -33,12 +33,24 @@
 // upper bound and surplus workgroups leave at once.
 #include "gsr_device.h"
 
+// Profiling aid (python -m autovfx_amd.build --trace, scripts/kernel_trace.py --binning): lane 0 of a workgroup stamps the
+// 100 MHz wall clock into slot `slot` of record `id`.  Compiled out of the normal library.
+#ifdef GSR_KERNEL_TRACE
+__device__ unsigned long long* g_binning_trace = nullptr;
+extern "C" __attribute__((visibility("default"))) int gsr_debug_set_binning_trace(void* device_words) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_binning_trace), &device_words, sizeof device_words);
+}
+#define GSR_BTRACE(id, slot) do { if (threadIdx.x == 0 && g_binning_trace) g_binning_trace[(size_t)(id) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define GSR_BTRACE(id, slot) do { } while (0)
+#endif
+
 namespace gsr {
 namespace {
 
 constexpr int kPairTile = 2048;
 constexpr int kPairsPerLane = kPairTile / 256;  // consecutive pairs of one lane
-constexpr int kMaxDoneWords = 4096;             // tile bit rows held in LDS by the slab kernels (16 KB)
+constexpr int kMaxDoneWords = 4096;             // most tile bit rows the slab kernels hold in LDS (16 KB; an 8K x 8K image has 1 024)
 static_assert(kDupTile == 1024, "256 lanes x 4 consecutive positions");
 
 // Sum over the workgroup's 256 lanes, returned to every lane; scratch is 4 words of LDS.
@@ -220,6 +232,7 @@ __global__ void __launch_bounds__(256) bin_gather_kernel(BinningArrays a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int V = a.V;
     const int k0 = (int)blockIdx.x * kDupTile + 4 * tid;  // 4 consecutive positions per lane
+    GSR_BTRACE(blockIdx.x, 0);
     uint32_t gid[4] = {0u, 0u, 0u, 0u};
     if (k0 + 3 < V) {
         const uint4 g = *reinterpret_cast<const uint4*>(a.depth_order + k0);
@@ -246,6 +259,7 @@ __global__ void __launch_bounds__(256) bin_gather_kernel(BinningArrays a) {
     // wave; a splat that does not get its rows (cannot happen: the pool is sized from the projection kernel's count)
     // keeps its full rectangle, which is only less culled, never wrong.
     const unsigned long long any_big = __ballot(rows_needed != 0u);
+    GSR_BTRACE(blockIdx.x, 1);
     if (any_big != 0ull) {   // wave-uniform
         uint32_t incl = rows_needed;
 #pragma unroll
@@ -362,9 +376,11 @@ __global__ void __launch_bounds__(256) bin_gather_kernel(BinningArrays a) {
                 rec[j].w = count[j];
             }
     }
+    GSR_BTRACE(blockIdx.x, 2);
     const uint32_t mine = count[0] + count[1] + count[2] + count[3];
     uint32_t tile_total;
     const uint32_t before = block_exclusive_256(mine, s_wave, &tile_total);
+    GSR_BTRACE(blockIdx.x, 3);
     if (tid == 0) a.tile_totals[blockIdx.x] = tile_total;
     const uint32_t o0 = before + count[0], o1 = o0 + count[1], o2 = o1 + count[2], o3 = o2 + count[3];
     if (k0 + 3 < V) {
@@ -378,6 +394,7 @@ __global__ void __launch_bounds__(256) bin_gather_kernel(BinningArrays a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if (k0 + j < V) a.sorted_bins[k0 + j] = rec[j];
+    GSR_BTRACE(blockIdx.x, 4);
 }
 
 // P - V trailing positions (culled Gaussians) repeat the total so that POINT_OFFSETS is defined over all P, as
@@ -456,16 +473,18 @@ __device__ __forceinline__ void load_done_rows(uint32_t* s_done, const uint32_t*
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(256) slab_recount_kernel(BinningArrays a, int slab) {
-    __shared__ uint32_t s_done[kMaxDoneWords];
+__global__ void __launch_bounds__(256, 7) slab_recount_kernel(BinningArrays a, int slab) {
+    extern __shared__ uint32_t s_done[];   // grid_y * row_words words (sized at the launch; none for the first slab's expansion)
     __shared__ uint32_t s_wave[4];
     __shared__ uint4 s_geo[4][64];       // the large splats of one round: their records
     __shared__ uint32_t s_rows[4][64];   // inclusive row counts
     __shared__ uint32_t s_live[4][64];   // live unfinished tiles, summed over the rows
+    GSR_BTRACE(8192 + blockIdx.x, 0);
     const SlabInfo info = a.slabs[slab];
     const uint32_t first = info.first, end = min(info.end, (uint32_t)a.V);
     const uint32_t k0 = first + blockIdx.x * (uint32_t)kDupTile + 4u * threadIdx.x;
     if (first + blockIdx.x * (uint32_t)kDupTile >= end) return;  // workgroup-uniform
+    GSR_BTRACE(8192 + blockIdx.x, 1);
     load_done_rows(s_done, a.done_rows, a.grid_y * a.row_words);
     // Every tile finished already (a scene with an opaque front: the first slab is often all it takes)?  Then no splat of
     // this slab has a live pair and the records need not even be read: the counts below stay zero.
@@ -476,6 +495,7 @@ __global__ void __launch_bounds__(256) slab_recount_kernel(BinningArrays a, int 
         done_tiles += (uint32_t)__popc(s_done[i] & (cols >= 32u ? ~0u : (1u << cols) - 1u));
     }
     const bool nothing_left = block_sum_256(done_tiles, s_wave) == (uint32_t)(a.grid_x * a.grid_y);
+    GSR_BTRACE(8192 + blockIdx.x, 2);
     uint32_t count[4];
     uint4 rec[4];
 #pragma unroll
@@ -494,6 +514,7 @@ __global__ void __launch_bounds__(256) slab_recount_kernel(BinningArrays a, int 
         }
         count[j] = (uint32_t)__popcll(left);
     }
+    GSR_BTRACE(8192 + blockIdx.x, 3);
     // Large splats: the live, unfinished tiles of every tile row, the rows of the wave's splats flattened over its lanes
     // exactly as bin_gather_kernel flattens them (one of the lane's four positions at a time).
     {
@@ -549,6 +570,7 @@ __global__ void __launch_bounds__(256) slab_recount_kernel(BinningArrays a, int 
             __builtin_amdgcn_wave_barrier();
         }
     }
+    GSR_BTRACE(8192 + blockIdx.x, 4);
     const uint32_t mine = count[0] + count[1] + count[2] + count[3];
     uint32_t tile_total;
     const uint32_t before = block_exclusive_256(mine, s_wave, &tile_total);
@@ -564,6 +586,7 @@ __global__ void __launch_bounds__(256) slab_recount_kernel(BinningArrays a, int 
         run += count[j];
         if (k0 + j < end) a.slab_offsets[k0 + j] = run;
     }
+    GSR_BTRACE(8192 + blockIdx.x, 5);
 }
 
 // Second half of the re-scan: tile-local offsets become slab-wide, and the positions that kept a live pair are listed
@@ -627,8 +650,9 @@ __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, 
     constexpr int kBatch = 2048;            // items whose offsets are parked in LDS at a time
     __shared__ uint32_t s_incl[kBatch + 1]; // s_incl[0] = pairs before the batch's first item
     __shared__ uint32_t s_scratch[4];
-    __shared__ uint32_t s_done[kMaxDoneWords];
+    extern __shared__ uint32_t s_done[];   // grid_y * row_words words (sized at the launch; none for the first slab's expansion)
     const int tid = threadIdx.x;
+    GSR_BTRACE(16384 + 8192 * slab + blockIdx.x, 0);
     const SlabInfo info = a.slabs[slab];
     const uint32_t num_pairs = info.pairs;
     // The launch was sized for an upper bound of the pairs.  When far fewer are left (a slab behind an opaque front keeps a
@@ -655,6 +679,7 @@ __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, 
         done = s_done;
     }
     const uint32_t grid_x = (uint32_t)a.grid_x;
+    GSR_BTRACE(16384 + 8192 * slab + blockIdx.x, 1);
 
     // first item whose inclusive offset exceeds p_begin = number of items with offset <= p_begin: whole 1024-item
     // tiles first (their last offsets), then inside the tile that straddles p_begin
@@ -671,6 +696,7 @@ __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, 
     }
     int s0 = tile0 * kDupTile + (int)block_sum_256(n_le, s_scratch);
     auto position_of = [&](int item) -> uint32_t { return compacted ? cpos[item] : (uint32_t)item; };
+    GSR_BTRACE(16384 + 8192 * slab + blockIdx.x, 2);
 
     const uint32_t my_begin = p_begin + per_lane * (uint32_t)tid;
     const uint32_t my_end = min(p_end, my_begin + per_lane);
@@ -718,6 +744,7 @@ __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, 
         if (finished) break;
         s0 += kBatch;
     }
+    GSR_BTRACE(16384 + 8192 * slab + blockIdx.x, 3);
     if (my_begin + per_lane <= p_end) {   // (per_lane is a multiple of 4 and so is my_begin: 16-byte stores)
 #pragma unroll
         for (int q = 0; q < kPairsPerLane; q += 4) {
@@ -733,6 +760,7 @@ __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, 
                 point_list[my_begin + q] = ids[q];
             }
     }
+    GSR_BTRACE(16384 + 8192 * slab + blockIdx.x, 4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -793,7 +821,12 @@ hipError_t launch_slab_recount(const BinningArrays& a, int slab, hipStream_t str
     const int tiles_v = div_up(a.V, kDupTile), tiles_p = div_up(a.P, kDupTile);
     (void)tiles_p;
     // (an empty slab still needs its counts set: slab_compact_kernel's first workgroup does that)
-    if (tiles_v > 0) hipLaunchKernelGGL(slab_recount_kernel, dim3(tiles_v), dim3(256), 0, stream, a, slab);
+    // The bit rows are dynamic LDS, sized by what the image needs (1 KB at 1920x1080): with a fixed 16 KB the expansion's
+    // workgroups did not all fit on the GPU at once (6 per CU = 1 536 of C3's 1 594) and the few left over ran as a second,
+    // nearly empty round behind the others -- a third of the kernel's time.
+    const int done_words = a.grid_y * a.row_words;
+    if (done_words > kMaxDoneWords) return hipErrorInvalidValue;   // (gsr_api.hip does not plan slabs for such an image)
+    if (tiles_v > 0) hipLaunchKernelGGL(slab_recount_kernel, dim3(tiles_v), dim3(256), (size_t)done_words * 4, stream, a, slab);
     hipLaunchKernelGGL(slab_compact_kernel, dim3(tiles_v > 0 ? tiles_v : 1), dim3(256), 0, stream, a, slab);
     return hipGetLastError();
 }
@@ -801,8 +834,10 @@ hipError_t launch_slab_recount(const BinningArrays& a, int slab, hipStream_t str
 hipError_t launch_expand(const BinningArrays& a, int slab, uint32_t pairs_bound, uint32_t* tile_keys, uint32_t* point_list,
                          hipStream_t stream) {
     if (pairs_bound == 0) return hipSuccess;
-    hipLaunchKernelGGL(expand_kernel, dim3((pairs_bound + kPairTile - 1) / kPairTile), dim3(256), 0, stream, a, slab, tile_keys,
-                       point_list);
+    const int done_words = slab > 0 ? a.grid_y * a.row_words : 0;
+    if (done_words > kMaxDoneWords) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(expand_kernel, dim3((pairs_bound + kPairTile - 1) / kPairTile), dim3(256), (size_t)done_words * 4, stream, a, slab,
+                       tile_keys, point_list);
     return hipGetLastError();
 }
 

@@ -361,7 +361,9 @@ __global__ void __launch_bounds__(256) sh_colour_listed_kernel(GaussianInputs in
     __shared__ uint32_t s_list[4][256];
     // The slab's tile ranges ride on the first workgroups (gsr_device.h: tile_ranges_duty): their ~8 us of dependent loads
     // disappear behind the kernel's streaming work instead of being a launch of their own between the sort and this one.
+    GSR_KTRACE(16384 + 8192 * (tag - 1) + blockIdx.x, 0);
     if ((int)blockIdx.x < duty_blocks) tile_ranges_duty(duty, blockIdx.x, &s_list[0][0]);
+    GSR_KTRACE(16384 + 8192 * (tag - 1) + blockIdx.x, 1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int first = (blockIdx.x * 4 + wave) * 256;   // this wave's 256 Gaussians
     if (first >= in.P || slab->pairs == 0u) return;    // (a slab that found every tile finished lists nothing)
@@ -391,6 +393,7 @@ __global__ void __launch_bounds__(256) sh_colour_listed_kernel(GaussianInputs in
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         if (mine[j]) s_list[wave][at++] = (uint32_t)(i0 + j);
+    GSR_KTRACE(16384 + 8192 * (tag - 1) + blockIdx.x, 2);
     if (n == 0u) return;   // wave-uniform
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
@@ -405,6 +408,7 @@ __global__ void __launch_bounds__(256) sh_colour_listed_kernel(GaussianInputs in
         const F3 col = sh_to_rgb(deg, p, cp, in.shs + 3 * (size_t)in.M * i);
         *reinterpret_cast<F3*>(rgb + 3 * (size_t)i) = col;
     }
+    GSR_KTRACE(16384 + 8192 * (tag - 1) + blockIdx.x, 3);
 }
 
 // The same for a call that turned out to need no depth slabs (the host learns that only after the projection kernel

@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--slots", type=int, default=4)
     ap.add_argument("--records", type=int, default=1 << 16)
+    ap.add_argument("--binning", action="store_true",
+                    help="the binning kernels' stamps (gsr_binning.hip GSR_BTRACE): bin_gather, slab_recount, expand of slab 0 / 1")
+    ap.add_argument("--colour", action="store_true", help="sh_colour_listed_kernel's stamps (gsr_kernels.hip)")
     args = ap.parse_args()
     from autovfx_amd import _lib, scenes
     from autovfx_amd.cameras import orbit_cameras
@@ -36,12 +39,37 @@ def main():
         rasterize(cloud, cam, bg)
     torch.cuda.synchronize()
     trace = torch.zeros(args.records * 8, dtype=torch.int64, device="cuda")
-    _lib.lib.gsr_debug_set_trace.argtypes = [ctypes.c_void_p]
-    assert _lib.lib.gsr_debug_set_trace(trace.data_ptr()) == 0
+    arm = _lib.lib.gsr_debug_set_binning_trace if args.binning else _lib.lib.gsr_debug_set_trace
+    arm.argtypes = [ctypes.c_void_p]
+    assert arm(trace.data_ptr()) == 0
     rasterize(cloud, cam, bg)
     torch.cuda.synchronize()
-    _lib.lib.gsr_debug_set_trace(None)
+    arm(None)
     t = trace.cpu().numpy().reshape(-1, 8).astype(np.float64)
+    def groups(specs):
+        for name, base, slots in specs:
+            g = t[base:base + 8192]
+            started = g[g[:, 0] > 0] * 0.01
+            g = started[started[:, slots - 1] > 0][:, :slots]   # workgroups that ran to the end (the others left at once)
+            if len(g) == 0:
+                print(name, "no records"); continue
+            t0 = started[:, 0].min()
+            print(f"{name}: {len(started)} workgroups started, {len(g)} ran through; span {g.max() - t0:.1f} us; "
+                  f"starts p50 {np.median(g[:, 0]) - t0:.1f} p95 {np.percentile(g[:, 0], 95) - t0:.1f} max {g[:, 0].max() - t0:.1f} us")
+            for k in range(slots - 1):
+                d = g[:, k + 1] - g[:, k]
+                print(f"   phase {k}->{k + 1}: mean {d.mean():6.2f} us  p50 {np.median(d):6.2f}  p95 {np.percentile(d, 95):6.2f}  max {d.max():6.2f}")
+            life = g[:, slots - 1] - g[:, 0]
+            print(f"   workgroup life: mean {life.mean():.2f} us  p95 {np.percentile(life, 95):.2f}  max {life.max():.2f}")
+
+    if args.binning:
+        groups((("bin_gather_kernel", 0, 5), ("slab_recount_kernel", 8192, 6), ("expand_kernel slab 0", 16384, 5),
+                ("expand_kernel slab 1", 24576, 5)))
+        return
+    if args.colour:   # (lane 0 of the workgroup = its first wave: the other three waves are not stamped)
+        groups((("sh_colour_listed_kernel slab 0", 16384, 4), ("sh_colour_listed_kernel slab 1", 24576, 4)))
+        return
+    t[16384:] = 0   # (the projection kernel's records)
     t = t[t[:, 0] > 0][:, :args.slots] * 0.01          # 100 MHz -> microseconds
     t0 = t[:, 0].min()
     q = [0, 25, 50, 75, 100]
