@@ -30,6 +30,18 @@
 // concatenated list: same bits.
 #include "gsr_device.h"
 
+// Profiling aid (python -m autovfx_amd.build --trace, scripts/kernel_trace.py --blend): every single-wave workgroup stamps the
+// 100 MHz wall clock at its start and end.  Compiled out of the normal library.
+#ifdef GSR_KERNEL_TRACE
+__device__ unsigned long long* g_blend_trace = nullptr;
+extern "C" __attribute__((visibility("default"))) int gsr_debug_set_blend_trace(void* device_words) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_blend_trace), &device_words, sizeof device_words);
+}
+#define GSR_LTRACE(id, slot) do { if (threadIdx.x == 0 && g_blend_trace) g_blend_trace[(size_t)(id) * 2 + (slot)] = wall_clock64(); } while (0)
+#else
+#define GSR_LTRACE(id, slot) do { } while (0)
+#endif
+
 namespace gsr {
 namespace {
 
@@ -102,6 +114,7 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(BlendArgs a) {
     const int tile = item >> 2, quad = item & 3;
     const int lane = threadIdx.x;
     const bool fresh = a.fresh != 0, final = a.final != 0;
+    GSR_LTRACE(a.seg_begin * 40960 + blockIdx.x, 0);
     if (!fresh && ((a.quad_done[item >> 5] >> (item & 31)) & 1u)) return;  // finished by an earlier launch
     const int qx0 = (tile % a.grid_x) * kTile + kQ * (quad & 1);
     const int qy0 = (tile / a.grid_x) * kTile + kQ * (quad >> 1);
@@ -263,6 +276,7 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(BlendArgs a) {
             a.out_extra[2 * plane + pid] = Eb;
         }
     }
+    GSR_LTRACE(a.seg_begin * 40960 + blockIdx.x, 1);
 }
 
 } // namespace
