@@ -49,7 +49,7 @@ constexpr int kEventsPerCall = kHeadEvents + kSlabEvents * gsr::kMaxSlabs;
 int g_options[GSR_OPT_NUM] = {/*GSR_OPT_TILE_CULL*/ 1, /*GSR_OPT_SLABS*/ 2, /*GSR_OPT_SLAB_FIRST*/ 400,
                               /*GSR_OPT_DEFER_COLOUR*/ 1, /*GSR_OPT_SLAB_MIN_REST*/ 3000000,
                               /*GSR_OPT_RADIX_RANK (kept by gsr_radix.hip)*/ 2, /*GSR_OPT_RADIX_RANK_ACTIVE (read-only)*/ 0,
-                              /*GSR_OPT_DEPTH_DROP*/ 1};
+                              /*GSR_OPT_DEPTH_DROP*/ 1, /*GSR_OPT_BLEND_ORDER*/ 1};
 bool g_timing = false;
 std::atomic<long> g_timing_epoch{0};       // bumped by gsr_set_stage_timing: every thread restarts its record at its next call
 thread_local long g_epoch_seen = -1;
@@ -560,7 +560,7 @@ struct ForwardCall {
     size_t gshift = 0;
     size_t geom_off[GSR_GEOM_NUM_SLOTS] = {};
     size_t img_off[GSR_IMG_NUM_SLOTS] = {};
-    size_t off_slabs = 0, off_quad = 0, off_rows = 0, off_listed = 0, off_radix_tmp = 0;
+    size_t off_slabs = 0, off_quad = 0, off_rows = 0, off_listed = 0, off_radix_tmp = 0, off_order = 0;
     int row_words = 0;
     uint32_t *order = nullptr, *point_offsets = nullptr, *slab_offsets = nullptr, *tile_totals = nullptr, *slab_tile_totals = nullptr;
     uint32_t *slab_cpos = nullptr, *slab_coffs = nullptr;
@@ -721,6 +721,7 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     fc.off_slabs = gc.take<gsr::SlabInfo>(gsr::kMaxSlabs);
     fc.off_quad = gc.take<uint32_t>(quad_words);
     fc.off_rows = gc.take<uint32_t>(rows_words);
+    fc.off_order = gc.take<uint32_t>((size_t)gsr::kMaxSlabs * 8 * gsr::kOrderClasses);  // tiles per (slab, XCD band, list-length class)
     const size_t zero_end = gc.off;
     const size_t off_tallies = gc.take<gsr::BlockTally>((n + 255) / 256);
     fc.off_listed = gc.take<uint8_t>(fc.defer_colour ? n : 0);  // one byte per Gaussian: which slab listed it (cleared by the
@@ -850,6 +851,11 @@ int forward_finish(ForwardCall& fc) {
     const size_t off_pool = bc.take<uint32_t>((size_t)pool_rows);
     const size_t off_pool_incl = bc.take<uint32_t>((size_t)pool_rows);
     const size_t off_btmp = bc.take<char>(tsort_tmp);
+    // blend order (gsr_internal.h: BlendOrder): only where a launch has more single-wave workgroups than the GPU holds at once
+    // (256 CUs x 32 waves); smaller images are resident from the first cycle and the order is immaterial
+    const bool ordered_blend = g_options[GSR_OPT_BLEND_ORDER] != 0 && 4 * (long long)T > 8192;
+    const int order_cap = T / 8 + (T % 8 ? 1 : 0);
+    const size_t off_order_table = bc.take<uint32_t>(ordered_blend ? (size_t)S * 8 * gsr::kOrderClasses * order_cap : 0);
     char* braw = fc.binning_alloc(bc.total(), fc.binning_user);
     if (!braw) return fail(GSR_ERR_ALLOC, "binning scratch callback returned NULL for %zu bytes", bc.total());
     char* bbase = align_base(braw);
@@ -943,6 +949,16 @@ int forward_finish(ForwardCall& fc) {
         // less, and the search latency hides behind the colour reads); otherwise it is a launch of its own.
         gsr::RangesDuty duty = {};
         duty.slab = slab; duty.num_tiles = T; duty.keys = tk_sorted; duty.ranges = ranges;
+        gsr::BlendOrder order = {nullptr, nullptr, 0, 0};
+        if (ordered_blend) {
+            order.counts = (uint32_t*)(gbase + fc.off_order) + (size_t)k * 8 * gsr::kOrderClasses;
+            order.table = (uint32_t*)(bbase + off_order_table) + (size_t)k * 8 * gsr::kOrderClasses * order_cap;
+            order.cap = order_cap;
+            // classes half the slab's mean list length wide: the longest class starts at 3.5 times the mean
+            uint32_t mean = plan.bound[k] / (uint32_t)T;
+            while (mean > 3u) { mean >>= 1; ++order.shift; }
+        }
+        duty.order = order;
         for (int i = 0; i < 3; ++i) { duty.headers[i] = hs[i]; duty.header_dst[i] = last ? dsts[i] : nullptr; }
         const bool colour_blocks_suffice = (S == 1 ? (P + 255) / 256 : (P + 1023) / 1024) >= gsr::ranges_duty_blocks(T);
         const bool fused_ranges = fc.defer_colour && colour_blocks_suffice && !debug;
@@ -956,7 +972,7 @@ int forward_finish(ForwardCall& fc) {
         stamp(kHeadEvents + kSlabEvents * k + 3, stream);
         GSR_HIP(gsr::launch_blend(cam, segs, k, k + 1, /*fresh=*/k == 0, /*final=*/last, ga.raster, features, fc.background,
                                   fc.out_color, fc.out_depth, fc.out_alpha, n_contrib, ba.quad_done, ba.done_rows, fc.row_words, stream,
-                                  fc.extra_features, fc.out_extra));
+                                  fc.extra_features, fc.out_extra, &order));
         GSR_STAGE_CHECK("blend");
         stamp(kHeadEvents + kSlabEvents * k + 4, stream);
         if (last) {

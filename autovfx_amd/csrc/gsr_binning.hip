@@ -767,7 +767,7 @@ __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, 
 // K5 on its own (calls without a colour kernel to carry it: full calls, precomputed colours): gsr_device.h tile_ranges_duty.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) tile_ranges_kernel(RangesDuty duty) {
-    __shared__ uint32_t s_first[256];
+    __shared__ uint32_t s_first[kRangesDutyLdsWords];
     tile_ranges_duty(duty, blockIdx.x, s_first);
 }
 

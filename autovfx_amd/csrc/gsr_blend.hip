@@ -70,6 +70,7 @@ __global__ void exp_selftest_kernel(uint32_t first_bits, uint32_t count, unsigne
 
 struct BlendArgs {
     int W, H, grid_x, num_tiles;
+    BlendOrder order;
     BlendSegments segs;
     int seg_begin, seg_end;
     int fresh, final;
@@ -110,7 +111,28 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(BlendArgs a) {
 
     constexpr int kQ = kTile / 2;
     const int W = a.W, H = a.H;
-    const int item = xcd_band_tile(blockIdx.x, 4 * a.num_tiles);  // the 4 quadrants of a tile share an XCD
+    int item;
+    if (a.order.counts == nullptr) {
+        item = xcd_band_tile(blockIdx.x, 4 * a.num_tiles);  // the 4 quadrants of a tile share an XCD
+    } else {
+        // longest lists first inside the XCD's band (gsr_internal.h: BlendOrder): workgroup b runs on XCD b % 8 and is the
+        // (b / 8)-th of that XCD -- quadrant (b / 8) % 4 of the (b / 32)-th tile in (class, filing order)
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        const int nth = local >> 2;
+        const uint32_t* __restrict__ cnt = a.order.counts + xcd * kOrderClasses;
+        uint32_t before = 0u;
+        int cls = kOrderClasses;
+#pragma unroll
+        for (int c = 0; c < kOrderClasses; ++c) {   // (eight wave-uniform loads)
+            const uint32_t n = cnt[c];
+            if (cls == kOrderClasses) {
+                if ((uint32_t)nth < before + n) cls = c; else before += n;
+            }
+        }
+        if (cls >= kOrderClasses) return;   // past this band's tiles (the grid is padded to the largest band)
+        const uint32_t tile_of = a.order.table[(size_t)(xcd * kOrderClasses + cls) * a.order.cap + ((uint32_t)nth - before)];
+        item = 4 * (int)tile_of + (local & 3);
+    }
     const int tile = item >> 2, quad = item & 3;
     const int lane = threadIdx.x;
     const bool fresh = a.fresh != 0, final = a.final != 0;
@@ -284,17 +306,23 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(BlendArgs a) {
 hipError_t launch_blend(const Camera& cam, const BlendSegments& segs, int seg_begin, int seg_end, bool fresh, bool final,
                         const SplatRaster* raster, const float* features, const float* background, float* out_color,
                         float* out_depth, float* out_alpha, uint32_t* n_contrib, uint32_t* quad_done, uint32_t* done_rows,
-                        int row_words, hipStream_t stream, const float* extra_features, float* out_extra) {
+                        int row_words, hipStream_t stream, const float* extra_features, float* out_extra, const BlendOrder* order) {
     BlendArgs a;
     a.W = cam.width; a.H = cam.height; a.grid_x = cam.grid_x; a.num_tiles = cam.grid_x * cam.grid_y;
     a.segs = segs; a.seg_begin = seg_begin; a.seg_end = seg_end; a.fresh = fresh ? 1 : 0; a.final = final ? 1 : 0;
     a.raster = raster; a.features = features; a.extra_features = extra_features; a.background = background;
     a.out_color = out_color; a.out_depth = out_depth; a.out_alpha = out_alpha; a.out_extra = out_extra;
     a.n_contrib = n_contrib; a.quad_done = quad_done; a.done_rows = done_rows; a.row_words = row_words;
+    int blocks = 4 * a.num_tiles;
+    a.order = BlendOrder{nullptr, nullptr, 0, 0};
+    if (order != nullptr && order->counts != nullptr) {
+        a.order = *order;
+        blocks = 8 * 4 * order->cap;   // every XCD gets workgroups for the largest band; the surplus leaves at once
+    }
     if (extra_features != nullptr)
-        hipLaunchKernelGGL(blend_quadrant_kernel<true>, dim3(4 * a.num_tiles), dim3(64), 0, stream, a);
+        hipLaunchKernelGGL(blend_quadrant_kernel<true>, dim3(blocks), dim3(64), 0, stream, a);
     else
-        hipLaunchKernelGGL(blend_quadrant_kernel<false>, dim3(4 * a.num_tiles), dim3(64), 0, stream, a);
+        hipLaunchKernelGGL(blend_quadrant_kernel<false>, dim3(blocks), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
 

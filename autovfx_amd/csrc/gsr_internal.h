@@ -123,11 +123,26 @@ static_assert(sizeof(ArenaHeader) <= 256, "arena headers occupy the first 256 by
 
 // The per-tile [begin, end) of one slab's sorted list (K5, identifyTileRanges): 255 tiles per 256-lane workgroup, so
 // div_up(num_tiles, 255) workgroups of whatever kernel carries the duty (gsr_device.h: tile_ranges_duty).
+// In which order the blend's workgroups take the tiles of a slab (images with more quadrants than the GPU has wave slots):
+// every XCD keeps its contiguous band of the image (gsr_device.h: xcd_band_tile -- neighbouring tiles share splats and an
+// L2), but walks it LONGEST LIST FIRST, in 8 classes of list length, so that the waves still running when the launch runs
+// dry are short ones.  The ranges duty files every tile under (band, class) with one returning atomic on a zeroed counter;
+// the blend finds its tile from the eight counters of its band.  Placement only: results do not depend on it (nor on the
+// order the atomics happen to be served in).
+struct BlendOrder {
+    uint32_t* counts;   // [8 bands][8 classes], zero before the ranges duty (null: plain band order)
+    uint32_t* table;    // [8][8][cap] tile ids
+    int cap;            // tiles of the largest band
+    int shift;          // class = 7 - min(7, list length >> shift)
+};
+constexpr int kOrderClasses = 8;
+
 struct RangesDuty {
     const SlabInfo* slab;          // pairs = number of sorted keys
     int num_tiles;
     const uint32_t* keys;          // sorted tile ids
     uint2* ranges;
+    BlendOrder order;
     ArenaHeader headers[3];        // stamped at header_dst[i] by workgroup 0 when non-null (the call's last ranges duty)
     void* header_dst[3];
 };
@@ -216,7 +231,8 @@ struct BlendSegments {
 hipError_t launch_blend(const Camera& cam, const BlendSegments& segs, int seg_begin, int seg_end, bool fresh, bool final,
                         const SplatRaster* raster, const float* features, const float* background, float* out_color,
                         float* out_depth, float* out_alpha, uint32_t* n_contrib, uint32_t* quad_done, uint32_t* done_rows,
-                        int row_words, hipStream_t stream, const float* extra_features = nullptr, float* out_extra = nullptr);
+                        int row_words, hipStream_t stream, const float* extra_features = nullptr, float* out_extra = nullptr,
+                        const BlendOrder* order = nullptr);
 // counts the floats with bit patterns first_bits .. first_bits + count - 1 on which the blend's exp differs from expf
 hipError_t launch_exp_selftest(uint32_t first_bits, uint32_t count, unsigned long long* mismatches, hipStream_t stream);
 

@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(256) sh_colour_listed_kernel(GaussianInputs in
 __global__ void __launch_bounds__(256) sh_colour_all_kernel(GaussianInputs in, const float* __restrict__ cam_pos,
                                                             const int* __restrict__ radii, float* __restrict__ rgb,
                                                             RangesDuty duty, int duty_blocks) {
-    __shared__ uint32_t s_first[256];
+    __shared__ uint32_t s_first[kRangesDutyLdsWords];
     if ((int)blockIdx.x < duty_blocks) tile_ranges_duty(duty, blockIdx.x, s_first);   // (as in sh_colour_listed_kernel)
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= in.P || radii[i] <= 0) return;

@@ -371,6 +371,10 @@ typedef enum gsr_option {
      * `visible` entries of GSR_GEOM_DEPTH_ORDER are the same either way; with 1 the entries behind them are undefined
      * (0: the culled Gaussians, in index order, as rounds 1 - 2 left them). */
     GSR_OPT_DEPTH_DROP = 7,
+    /* [1] Images with more 8x8 quadrants than the GPU has wave slots (above ~1000x540): every XCD walks its band of the image
+     * longest tile list first (8 classes of list length) instead of in raster order, so that the waves still running when
+     * the blend launch runs dry are short ones.  Placement only: same results. */
+    GSR_OPT_BLEND_ORDER = 8,
     GSR_OPT_NUM
 } gsr_option;
 GSR_API int gsr_set_option(int option, int value);
