@@ -53,7 +53,9 @@ __device__ __forceinline__ void tile_ranges_duty(const RangesDuty& d, uint32_t b
             auto band_of = [&](int tile) { return tile < r * (q + 1) ? tile / (q + 1) : r + (tile - r * (q + 1)) / max(q, 1); };
             const int band = band_of(t), band0 = band_of((int)block * 255);   // (a block of 255 tiles meets at most two bands: q >= 256)
             const uint32_t len = e > b ? e - b : 0u;
-            const int cls = (kOrderClasses - 1) - (int)min((uint32_t)(kOrderClasses - 1), len >> d.order.shift);
+            // classes 0 .. 6 by list length, longest first; the last class is the tiles with NOTHING to blend (a later slab's
+            // finished tiles): their workgroups leave at once and are dispatched behind everybody who has work
+            const int cls = len == 0u ? kOrderClasses - 1 : (kOrderClasses - 2) - (int)min((uint32_t)(kOrderClasses - 2), len >> d.order.shift);
             cell = band * kOrderClasses + cls;
             local_cell = min(band - band0, 1) * kOrderClasses + cls;
             rank = atomicAdd(&s_cell[local_cell], 1u);   // LDS: the block's tiles of a cell take ONE place in the global counter

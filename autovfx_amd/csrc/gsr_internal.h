@@ -125,15 +125,16 @@ static_assert(sizeof(ArenaHeader) <= 256, "arena headers occupy the first 256 by
 // div_up(num_tiles, 255) workgroups of whatever kernel carries the duty (gsr_device.h: tile_ranges_duty).
 // In which order the blend's workgroups take the tiles of a slab (images with more quadrants than the GPU has wave slots):
 // every XCD keeps its contiguous band of the image (gsr_device.h: xcd_band_tile -- neighbouring tiles share splats and an
-// L2), but walks it LONGEST LIST FIRST, in 8 classes of list length, so that the waves still running when the launch runs
-// dry are short ones.  The ranges duty files every tile under (band, class) with one returning atomic on a zeroed counter;
+// L2), but walks it LONGEST LIST FIRST, in 7 classes of list length and an eighth for the tiles with nothing to blend, so
+// that the waves still running when the launch runs dry are short ones and the workgroups that leave at once (a later
+// slab's finished tiles) are dispatched behind everybody who has work.  The ranges duty files every tile under (band, class) with one returning atomic on a zeroed counter;
 // the blend finds its tile from the eight counters of its band.  Placement only: results do not depend on it (nor on the
 // order the atomics happen to be served in).
 struct BlendOrder {
     uint32_t* counts;   // [8 bands][8 classes], zero before the ranges duty (null: plain band order)
     uint32_t* table;    // [8][8][cap] tile ids
     int cap;            // tiles of the largest band
-    int shift;          // class = 7 - min(7, list length >> shift)
+    int shift;          // class = 6 - min(6, list length >> shift); class 7 = empty lists
 };
 constexpr int kOrderClasses = 8;
 
