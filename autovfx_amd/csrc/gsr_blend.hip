@@ -111,28 +111,9 @@ __global__ void __launch_bounds__(64, 8) blend_quadrant_kernel(BlendArgs a) {
 
     constexpr int kQ = kTile / 2;
     const int W = a.W, H = a.H;
-    int item;
-    if (a.order.counts == nullptr) {
-        item = xcd_band_tile(blockIdx.x, 4 * a.num_tiles);  // the 4 quadrants of a tile share an XCD
-    } else {
-        // longest lists first inside the XCD's band (gsr_internal.h: BlendOrder): workgroup b runs on XCD b % 8 and is the
-        // (b / 8)-th of that XCD -- quadrant (b / 8) % 4 of the (b / 32)-th tile in (class, filing order)
-        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-        const int nth = local >> 2;
-        const uint32_t* __restrict__ cnt = a.order.counts + xcd * kOrderClasses;
-        uint32_t before = 0u;
-        int cls = kOrderClasses;
-#pragma unroll
-        for (int c = 0; c < kOrderClasses; ++c) {   // (eight wave-uniform loads)
-            const uint32_t n = cnt[c];
-            if (cls == kOrderClasses) {
-                if ((uint32_t)nth < before + n) cls = c; else before += n;
-            }
-        }
-        if (cls >= kOrderClasses) return;   // past this band's tiles (the grid is padded to the largest band)
-        const uint32_t tile_of = a.order.table[(size_t)(xcd * kOrderClasses + cls) * a.order.cap + ((uint32_t)nth - before)];
-        item = 4 * (int)tile_of + (local & 3);
-    }
+    // the 4 quadrants of a tile share an XCD; large images: longest lists first inside the XCD's band (BlendOrder)
+    const int item = a.order.counts == nullptr ? xcd_band_tile(blockIdx.x, 4 * a.num_tiles) : ordered_item(a.order, blockIdx.x);
+    if (item < 0) return;   // (the ordered grid is padded to the largest band)
     const int tile = item >> 2, quad = item & 3;
     const int lane = threadIdx.x;
     const bool fresh = a.fresh != 0, final = a.final != 0;

@@ -337,6 +337,26 @@ __device__ __forceinline__ int xcd_band_tile(int b, int T) {
     return xcd * q + min(xcd, r) + local;
 }
 
+// The item (4 * tile + quadrant) workgroup b of a per-quadrant launch works on when its tiles are taken longest list first
+// inside each XCD's band (gsr_internal.h: BlendOrder); -1 for the surplus workgroups of the padded grid.  Workgroup b runs
+// on XCD b % 8 and is the (b / 8)-th of that XCD: quadrant (b / 8) % 4 of the (b / 32)-th tile in (class, filing order).
+__device__ __forceinline__ int ordered_item(const BlendOrder& o, int b) {
+    const int xcd = b & 7, local = b >> 3;
+    const uint32_t nth = (uint32_t)(local >> 2);
+    const uint32_t* __restrict__ cnt = o.counts + xcd * kOrderClasses;
+    uint32_t before = 0u;
+    int cls = kOrderClasses;
+#pragma unroll
+    for (int c = 0; c < kOrderClasses; ++c) {   // (eight wave-uniform loads)
+        const uint32_t n = cnt[c];
+        if (cls == kOrderClasses) {
+            if (nth < before + n) cls = c; else before += n;
+        }
+    }
+    if (cls == kOrderClasses) return -1;
+    return 4 * (int)o.table[(size_t)(xcd * kOrderClasses + cls) * o.cap + (nth - before)] + (local & 3);
+}
+
 // expf for the blend loop: the instruction sequence of the device library's expf (extended-precision
 // x * log2(e), round to nearest, v_exp_f32 of the remainder, ldexp) without its two range clamps, which only
 // act for x < -103.97 or x > 88.72.  The blend calls it with power <= 0 (or NaN); together with the
