@@ -295,7 +295,7 @@ hipError_t launch_blend(const Camera& cam, const BlendSegments& segs, int seg_be
     a.out_color = out_color; a.out_depth = out_depth; a.out_alpha = out_alpha; a.out_extra = out_extra;
     a.n_contrib = n_contrib; a.quad_done = quad_done; a.done_rows = done_rows; a.row_words = row_words;
     int blocks = 4 * a.num_tiles;
-    a.order = BlendOrder{nullptr, nullptr, 0, 0};
+    a.order = BlendOrder{nullptr, nullptr, 0, 0, 0};
     if (order != nullptr && order->counts != nullptr) {
         a.order = *order;
         blocks = 8 * 4 * order->cap;   // every XCD gets workgroups for the largest band; the surplus leaves at once

@@ -30,48 +30,40 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t* __restrict__
     return lo;
 }
 
-constexpr int kRangesDutyLdsWords = 256 + 2 * 2 * kOrderClasses;   // tile boundaries; (count, base) of the block's <= 2 x 8 order cells
+constexpr int kRangesDutyLdsWords = 256 + 2 * 8 * kOrderClasses;   // tile boundaries; (count, base) of the 8 x 8 order cells
 
 __device__ __forceinline__ void tile_ranges_duty(const RangesDuty& d, uint32_t block, uint32_t* s_first /*kRangesDutyLdsWords of LDS*/) {
     if (block == 0 && threadIdx.x < 3 && d.header_dst[threadIdx.x] != nullptr)
         *reinterpret_cast<ArenaHeader*>(d.header_dst[threadIdx.x]) = d.headers[threadIdx.x];
     const int t = (int)block * 255 + (int)threadIdx.x;   // 256 boundaries per workgroup = 255 tiles
     const uint32_t n = d.slab->pairs;
-    uint32_t* s_cell = s_first + 256;   // [16] tiles of this block per (band - first band, class), then [16] their bases in the table
+    uint32_t* s_cell = s_first + 256;   // [64] tiles of this block per (XCD, class), then [64] their bases in the table
     const bool ordering = d.order.counts != nullptr;
-    if (ordering && threadIdx.x < 4 * kOrderClasses) s_cell[threadIdx.x] = 0u;
+    if (ordering && threadIdx.x < 2 * 8 * kOrderClasses) s_cell[threadIdx.x] = 0u;
     s_first[threadIdx.x] = lower_bound_u32(d.keys, n, (uint32_t)min(t, d.num_tiles));
     __syncthreads();
     const bool mine = threadIdx.x != 255 && t < d.num_tiles;
-    int cell = 0, local_cell = 0;
+    int cell = 0;
     uint32_t rank = 0u;
     if (mine) {
         const uint32_t b = s_first[threadIdx.x], e = s_first[threadIdx.x + 1];
         d.ranges[t] = (e > b) ? make_uint2(b, e) : make_uint2(0u, 0u);
-        if (ordering) {   // file the tile under (its XCD's band, class of list length): BlendOrder
-            const int q = d.num_tiles >> 3, r = d.num_tiles & 7;
-            auto band_of = [&](int tile) { return tile < r * (q + 1) ? tile / (q + 1) : r + (tile - r * (q + 1)) / max(q, 1); };
-            const int band = band_of(t), band0 = band_of((int)block * 255);   // (a block of 255 tiles meets at most two bands: q >= 256)
+        if (ordering) {   // file the tile under (its XCD, class of list length): BlendOrder
+            const int xcd = (t / d.order.strip) & 7;
             const uint32_t len = e > b ? e - b : 0u;
             // classes 0 .. 6 by list length, longest first; the last class is the tiles with NOTHING to blend (a later slab's
             // finished tiles): their workgroups leave at once and are dispatched behind everybody who has work
             const int cls = len == 0u ? kOrderClasses - 1 : (kOrderClasses - 2) - (int)min((uint32_t)(kOrderClasses - 2), len >> d.order.shift);
-            cell = band * kOrderClasses + cls;
-            local_cell = min(band - band0, 1) * kOrderClasses + cls;
-            rank = atomicAdd(&s_cell[local_cell], 1u);   // LDS: the block's tiles of a cell take ONE place in the global counter
+            cell = xcd * kOrderClasses + cls;
+            rank = atomicAdd(&s_cell[cell], 1u);   // LDS: the block's tiles of a cell take ONE place in the global counter
         }
     }
     if (ordering) {   // (workgroup-uniform)
         __syncthreads();
-        if (threadIdx.x < 2 * kOrderClasses && s_cell[threadIdx.x] != 0u) {
-            const int q = d.num_tiles >> 3, r = d.num_tiles & 7;
-            const int first_tile = (int)block * 255;
-            const int band0 = first_tile < r * (q + 1) ? first_tile / (q + 1) : r + (first_tile - r * (q + 1)) / max(q, 1);
-            const int global_cell = (band0 + (int)threadIdx.x / kOrderClasses) * kOrderClasses + (int)threadIdx.x % kOrderClasses;
-            s_cell[2 * kOrderClasses + threadIdx.x] = atomicAdd(&d.order.counts[global_cell], s_cell[threadIdx.x]);
-        }
+        if (threadIdx.x < 8 * kOrderClasses && s_cell[threadIdx.x] != 0u)
+            s_cell[8 * kOrderClasses + threadIdx.x] = atomicAdd(&d.order.counts[threadIdx.x], s_cell[threadIdx.x]);
         __syncthreads();
-        if (mine) d.order.table[(size_t)cell * d.order.cap + s_cell[2 * kOrderClasses + local_cell] + rank] = (uint32_t)t;
+        if (mine) d.order.table[(size_t)cell * d.order.cap + s_cell[8 * kOrderClasses + cell] + rank] = (uint32_t)t;
     }
     __syncthreads();   // (the caller may reuse the LDS)
 }

@@ -124,8 +124,8 @@ static_assert(sizeof(ArenaHeader) <= 256, "arena headers occupy the first 256 by
 // The per-tile [begin, end) of one slab's sorted list (K5, identifyTileRanges): 255 tiles per 256-lane workgroup, so
 // div_up(num_tiles, 255) workgroups of whatever kernel carries the duty (gsr_device.h: tile_ranges_duty).
 // In which order the blend's workgroups take the tiles of a slab (images with more quadrants than the GPU has wave slots):
-// every XCD keeps its contiguous band of the image (gsr_device.h: xcd_band_tile -- neighbouring tiles share splats and an
-// L2), but walks it LONGEST LIST FIRST, in 7 classes of list length and an eighth for the tiles with nothing to blend, so
+// every XCD keeps contiguous strips of the image (neighbouring tiles share splats and an L2; several strips per XCD, spread over
+// the picture, so that all XCDs get a share of its busy middle), but walks them LONGEST LIST FIRST, in 7 classes of list length and an eighth for the tiles with nothing to blend, so
 // that the waves still running when the launch runs dry are short ones and the workgroups that leave at once (a later
 // slab's finished tiles) are dispatched behind everybody who has work.  The ranges duty files every tile under (band, class) with one returning atomic on a zeroed counter;
 // the blend finds its tile from the eight counters of its band.  Placement only: results do not depend on it (nor on the
@@ -133,8 +133,9 @@ static_assert(sizeof(ArenaHeader) <= 256, "arena headers occupy the first 256 by
 struct BlendOrder {
     uint32_t* counts;   // [8 bands][8 classes], zero before the ranges duty (null: plain band order)
     uint32_t* table;    // [8][8][cap] tile ids
-    int cap;            // tiles of the largest band
+    int cap;            // room per (band, class): the most tiles an XCD can get
     int shift;          // class = 6 - min(6, list length >> shift); class 7 = empty lists
+    int strip;          // an XCD's band is every 8th strip of `strip` consecutive tiles: tile t -> XCD (t / strip) % 8
 };
 constexpr int kOrderClasses = 8;
 
