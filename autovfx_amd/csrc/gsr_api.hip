@@ -851,9 +851,10 @@ int forward_finish(ForwardCall& fc) {
     const size_t off_pool = bc.take<uint32_t>((size_t)pool_rows);
     const size_t off_pool_incl = bc.take<uint32_t>((size_t)pool_rows);
     const size_t off_btmp = bc.take<char>(tsort_tmp);
-    // blend order (gsr_internal.h: BlendOrder): only where a launch has more single-wave workgroups than the GPU holds at once
-    // (256 CUs x 32 waves); smaller images are resident from the first cycle and the order is immaterial
-    const bool ordered_blend = g_options[GSR_OPT_BLEND_ORDER] != 0 && 4 * (long long)T > 8192;
+    // blend order (gsr_internal.h: BlendOrder).  Where a launch has more single-wave workgroups than the GPU holds at once (256 CUs
+    // x 32 waves: above ~1000x540) it decides which waves run last; below that it still spreads every XCD's share over the
+    // image (C2 blend 0.137 -> 0.128 ms, C4 0.210 -> 0.202, heavy unchanged, same box); a few hundred tiles are not worth the table
+    const bool ordered_blend = g_options[GSR_OPT_BLEND_ORDER] != 0 && T > 256;
     // every XCD takes four strips of consecutive tiles spread over the image (strip i -> XCD i % 8): one contiguous eighth each
     // gave the XCDs with the picture's middle up to 10 % more work than those with its edges, and the launch ends with the
     // slowest (same box, C3 blend: 1 / 2 / 4 / 8 strips 0.355 / 0.343 / 0.344 / 0.341 ms)

@@ -371,9 +371,10 @@ typedef enum gsr_option {
      * `visible` entries of GSR_GEOM_DEPTH_ORDER are the same either way; with 1 the entries behind them are undefined
      * (0: the culled Gaussians, in index order, as rounds 1 - 2 left them). */
     GSR_OPT_DEPTH_DROP = 7,
-    /* [1] Images with more 8x8 quadrants than the GPU has wave slots (above ~1000x540): every XCD walks its band of the image
-     * longest tile list first (8 classes of list length) instead of in raster order, so that the waves still running when
-     * the blend launch runs dry are short ones.  Placement only: same results. */
+    /* [1] Images of more than 256 tiles: every XCD blends four strips of tiles spread over the image (instead of one contiguous
+     * eighth: the picture's middle is busier than its edges) and walks them longest tile list first (7 classes of list
+     * length, then the tiles with nothing to blend), so that the waves still running when a launch with more workgroups than
+     * wave slots runs dry are short ones.  Placement only: same results. */
     GSR_OPT_BLEND_ORDER = 8,
     GSR_OPT_NUM
 } gsr_option;

@@ -18,7 +18,7 @@ import collections, re
 acc = collections.defaultdict(list)
 for l in open("$OUT/ab.txt"):
     m = re.match(r"(\S+) (\[.*?\]) (\S+) (\S+) (\S+) (.*)", l)
-    acc[(m.group(1), m.group(2))].append((float(m.group(3)), float(m.group(4)), float(m.group(5)), m.group(6)))
+    acc[(m.group(1), m.group(2))].append((float(m.group(3)), float(m.group(4)) if m.group(4) != 'None' else 0.0, float(m.group(5)), m.group(6)))
 for (wl, fl), v in sorted(acc.items()):
     print(f"{wl:6s} {fl:40s} fps {sorted(x[0] for x in v)}  serial fps {sorted(x[1] for x in v)}  1-stream ms {sorted(x[2] for x in v)[len(v)//2]}")
     print("        ", v[len(v) // 2][3])
