@@ -683,7 +683,9 @@ def main():
                        "stream_driver": ("pipelined" if not (distributed or strong) else driver) if S > 1 else "serial",
                        "options": {"tile_cull": _lib.get_option(_lib.OPT_TILE_CULL),
                                    "slabs": _lib.get_option(_lib.OPT_SLABS), "slab_first": _lib.get_option(_lib.OPT_SLAB_FIRST),
-                                   "defer_colour": _lib.get_option(_lib.OPT_DEFER_COLOUR)}},
+                                   "defer_colour": _lib.get_option(_lib.OPT_DEFER_COLOUR),
+                                   "depth_drop": _lib.get_option(_lib.OPT_DEPTH_DROP), "blend_order": _lib.get_option(_lib.OPT_BLEND_ORDER),
+                                   "radix_rank_active": _lib.get_option(_lib.OPT_RADIX_RANK_ACTIVE)}},
             "value_serial": None if serial is None else serial["value"],
             "ms_per_step_serial": None if serial is None else serial["ms_per_step"],
             "serial": serial, "roofline": roofline, "cpu_baseline": cpu_baseline,
