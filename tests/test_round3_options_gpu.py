@@ -1,6 +1,7 @@
-"""The depth sort drops the Gaussians that emit nothing in its first pass (``GSR_OPT_DEPTH_DROP``, gsr_radix.hip): nothing
-the library defines may change.  Compared with the plain form (drop 0) on the same inputs, with fresh allocations
-poisoned so that a later pass that read the undefined tail of the order would show."""
+"""Round-3 options that must not change a bit.  ``GSR_OPT_DEPTH_DROP``: the depth sort drops the Gaussians that emit nothing in
+its first pass (gsr_radix.hip) -- compared with the plain form on the same inputs, with fresh allocations poisoned so that a
+later pass that read the undefined tail of the order would show.  ``GSR_OPT_BLEND_ORDER``: which workgroup blends which tile
+(gsr_internal.h BlendOrder) -- placement only."""
 import numpy as np
 import pytest
 from autovfx_amd import scenes
@@ -30,6 +31,7 @@ def _defaults():
     from diff_gaussian_rasterization import _C
     yield
     _lib.set_option(_lib.OPT_DEPTH_DROP, 1)
+    _lib.set_option(_lib.OPT_BLEND_ORDER, 1)
     _C.set_alloc_poison(None)
 
 
@@ -62,4 +64,34 @@ def test_depth_drop_same_lists(scene):
     for k in ("color", "depth", "alpha"):
         np.testing.assert_array_equal(a[k].view(np.uint32), b[k].view(np.uint32), err_msg=f"{scene}: {k}")
         np.testing.assert_array_equal(outs[0][1][k].view(np.uint32), outs[1][1][k].view(np.uint32), err_msg=f"{scene} inference: {k}")
+    assert outs[0][1]["slab_pairs"] == outs[1][1]["slab_pairs"]
+
+
+@pytest.mark.parametrize("scene", ["heavy15k", "c2", "c2_behind"])
+def test_blend_order_is_placement_only(scene):
+    """GSR_OPT_BLEND_ORDER (four strips of tiles per XCD, longest tile lists first; images of more than 256 tiles) decides which
+    workgroup blends which tile, nothing else: every image, ``n_contrib`` and the lists of a full call and the images of an
+    inference call cut into slabs are the same bits with it on and off."""
+    from autovfx_amd import _lib
+    from diff_gaussian_rasterization import _C
+    from helpers import hip_forward_inference, hip_forward_raw
+    cloud, cam = _scene(scene)
+    outs = {}
+    try:
+        for order in (0, 1):
+            _lib.set_option(_lib.OPT_BLEND_ORDER, order)
+            assert _lib.get_option(_lib.OPT_BLEND_ORDER) == order
+            _C.set_alloc_poison("random")
+            full = hip_forward_raw(cloud, cam, cull=True, bg=(0.3, 0.2, 0.1))
+            inf = hip_forward_inference(cloud, cam, slabs=0, slab_first=40, bg=(0.3, 0.2, 0.1))
+            _C.set_alloc_poison(None)
+            outs[order] = (full, inf)
+    finally:
+        _lib.set_option(_lib.OPT_BLEND_ORDER, 1)
+    for k in ("radii", "point_list", "tile_keys", "ranges", "n_contrib"):
+        np.testing.assert_array_equal(outs[0][0][k], outs[1][0][k], err_msg=f"{scene}: {k}")
+    for k in ("color", "depth", "alpha"):
+        np.testing.assert_array_equal(outs[0][0][k].view(np.uint32), outs[1][0][k].view(np.uint32), err_msg=f"{scene}: {k}")
+        np.testing.assert_array_equal(outs[0][1][k].view(np.uint32), outs[1][1][k].view(np.uint32), err_msg=f"{scene} inference: {k}")
+        np.testing.assert_array_equal(outs[1][1][k].view(np.uint32), outs[1][0][k].view(np.uint32), err_msg=f"{scene} inference vs full: {k}")
     assert outs[0][1]["slab_pairs"] == outs[1][1]["slab_pairs"]
