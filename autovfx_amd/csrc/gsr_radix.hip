@@ -436,7 +436,11 @@ hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* k
     const bool dropping = drop_key != nullptr && iota_payload && n_device == nullptr && passes > 1;
     uint32_t *kin = keys, *kout = keys_alt, *vin = vals, *vout = vals_alt;
     for (int p = 0; p < passes; ++p) {
-        const int width = bits - 8 * p < 8 ? bits - 8 * p : 8;
+        // digits as even as the key allows (13 tile-key bits: 7 + 6, not 8 + 5): fewer digits per pass mean longer runs of a digit
+        // in a 4096-pair tile, i.e. fewer partially written lines in the scatter
+        const int base_w = bits / passes, wide = bits % passes;   // the first `wide` passes are one bit wider
+        const int width = base_w + (p < wide ? 1 : 0);
+        const int shift = p * base_w + (p < wide ? p : wide);
         const uint32_t mask = (1u << width) - 1u;
         const bool iota = iota_payload && p == 0;
         const bool keys_out = want_sorted_keys || p + 1 < passes;
@@ -444,11 +448,11 @@ hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* k
         const uint32_t dkey = dropping ? *drop_key : 0u;
         uint32_t* kept_out = drop ? kept : nullptr;
         if (dropping && p == 1) n_device = kept;   // (the launches stay sized for n: surplus workgroups leave at once)
-        hipLaunchKernelGGL(radix_count_kernel, dim3(tiles), dim3(kThreads), 0, stream, kin, n, 8 * p, mask, counts, tiles_pad, n_device, drop, dkey);
+        hipLaunchKernelGGL(radix_count_kernel, dim3(tiles), dim3(kThreads), 0, stream, kin, n, shift, mask, counts, tiles_pad, n_device, drop, dkey);
         hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(kThreads), 0, stream, counts, tiles, tiles_pad, totals, n_device);
 #define GSR_RADIX_LAUNCH(I, K, A)                                                                                      \
     hipLaunchKernelGGL((radix_scatter_kernel<I, K, A>), dim3(tiles), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, \
-                       8 * p, mask, counts, tiles_pad, totals, n_device, dkey, kept_out)
+                       shift, mask, counts, tiles_pad, totals, n_device, dkey, kept_out)
 #define GSR_RADIX_LAUNCH_IK(A)                      \
     do {                                            \
         if (iota && keys_out) GSR_RADIX_LAUNCH(true, true, A);   \
