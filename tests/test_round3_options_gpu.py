@@ -19,6 +19,8 @@ def _scene(name):
         return scenes.config_heavy(P=15_000), orbit_cameras(200, 960, 540)[3]
     if name == "c2":
         return scenes.config_c2(), orbit_cameras(200, 960, 540)[100]
+    if name == "odd858":     # 33 x 26 = 858 tiles: strips of 27 tiles that end in the middle of tile rows, the last one short
+        return scenes.config_c1(P=30_000, seed=5), scenes.c1_camera(517, 403)
     if name == "c2_behind":   # a camera inside the cloud: half of the Gaussians are culled, and leave the depth sort at once
         cams = orbit_cameras(200, 960, 540, radius=0.5)
         return scenes.config_c2(), cams[17]
@@ -67,7 +69,7 @@ def test_depth_drop_same_lists(scene):
     assert outs[0][1]["slab_pairs"] == outs[1][1]["slab_pairs"]
 
 
-@pytest.mark.parametrize("scene", ["heavy15k", "c2", "c2_behind"])
+@pytest.mark.parametrize("scene", ["odd858", "heavy15k", "c2", "c2_behind"])
 def test_blend_order_is_placement_only(scene):
     """GSR_OPT_BLEND_ORDER (four strips of tiles per XCD, longest tile lists first; images of more than 256 tiles) decides which
     workgroup blends which tile, nothing else: every image, ``n_contrib`` and the lists of a full call and the images of an
@@ -83,7 +85,7 @@ def test_blend_order_is_placement_only(scene):
             assert _lib.get_option(_lib.OPT_BLEND_ORDER) == order
             _C.set_alloc_poison("random")
             full = hip_forward_raw(cloud, cam, cull=True, bg=(0.3, 0.2, 0.1))
-            inf = hip_forward_inference(cloud, cam, slabs=0, slab_first=40, bg=(0.3, 0.2, 0.1))
+            inf = hip_forward_inference(cloud, cam, slabs=0, slab_first=8 if scene == "odd858" else 40, bg=(0.3, 0.2, 0.1))
             _C.set_alloc_poison(None)
             outs[order] = (full, inf)
     finally:
