@@ -49,6 +49,30 @@ def test_enum_mirrors_match_header():
     assert to_name(enum_members("gsr_stage"), "GSR_STAGE_") == _lib.STAGES
 
 
+def test_options_are_host_state_with_the_documented_defaults():
+    """gsr_option (include/gsr.h): the binding's OPT_* mirror the enum, every option reads back its documented default [n],
+    set / get round-trip without a device, the read-only and range rules hold."""
+    from autovfx_amd import _lib
+    members = [m for m in enum_members("gsr_option") if m != "GSR_OPT_NUM"]
+    for i, m in enumerate(members):
+        assert getattr(_lib, "OPT_" + m[len("GSR_OPT_"):]) == i, m
+    # the default stands in brackets at the start of each option's comment
+    body = HEADER[HEADER.index("typedef enum gsr_option"):HEADER.index("} gsr_option;")]
+    defaults = [int(x) for x in re.findall(r"/\* \[(\d+)\]", body)]
+    settable = [m for m in members if m != "GSR_OPT_RADIX_RANK_ACTIVE"]
+    assert len(defaults) == len(settable), (defaults, settable)
+    for m, want in zip(settable, defaults):
+        assert _lib.get_option(getattr(_lib, "OPT_" + m[len("GSR_OPT_"):])) == want, m
+    for opt, other in ((_lib.OPT_DEPTH_DROP, 0), (_lib.OPT_BLEND_ORDER, 0), (_lib.OPT_SLAB_FIRST, 123)):
+        was = _lib.get_option(opt)
+        _lib.set_option(opt, other)
+        assert _lib.get_option(opt) == other
+        _lib.set_option(opt, was)
+    assert _lib.lib.gsr_set_option(_lib.OPT_RADIX_RANK_ACTIVE, 1) != 0 and "read-only" in _lib.last_error()
+    assert _lib.lib.gsr_set_option(_lib.OPT_RADIX_RANK, 3) != 0
+    assert _lib.lib.gsr_set_option(len(members), 0) != 0 and _lib.lib.gsr_set_option(-1, 0) != 0
+
+
 def test_argument_errors_do_not_need_a_device():
     from autovfx_amd import _lib
     L = _lib.lib
