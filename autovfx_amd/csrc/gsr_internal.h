@@ -121,15 +121,15 @@ struct ArenaHeader {
 };
 static_assert(sizeof(ArenaHeader) <= 256, "arena headers occupy the first 256 bytes");
 
-// The per-tile [begin, end) of one slab's sorted list (K5, identifyTileRanges): 255 tiles per 256-lane workgroup, so
-// div_up(num_tiles, 255) workgroups of whatever kernel carries the duty (gsr_device.h: tile_ranges_duty).
-// In which order the blend's workgroups take the tiles of a slab (images with more quadrants than the GPU has wave slots):
-// every XCD keeps contiguous strips of the image (neighbouring tiles share splats and an L2; several strips per XCD, spread over
-// the picture, so that all XCDs get a share of its busy middle), but walks them LONGEST LIST FIRST, in 7 classes of list length and an eighth for the tiles with nothing to blend, so
-// that the waves still running when the launch runs dry are short ones and the workgroups that leave at once (a later
-// slab's finished tiles) are dispatched behind everybody who has work.  The ranges duty files every tile under (band, class) with one returning atomic on a zeroed counter;
-// the blend finds its tile from the eight counters of its band.  Placement only: results do not depend on it (nor on the
-// order the atomics happen to be served in).
+// Which workgroup of a blend launch takes which tile (images of more than 256 tiles).  Workgroup b runs on XCD b % 8.  Every
+// XCD's share of the image -- its band -- is four strips of consecutive tiles spread over the picture (strip i -> XCD i % 8:
+// neighbouring tiles share splats and an L2, and all XCDs get a share of the picture's busy middle), and the XCD walks its
+// band LONGEST LIST FIRST, in 7 classes of list length and an eighth for the tiles with nothing to blend: the waves still
+// running when a launch with more workgroups than wave slots runs dry are short ones, and the workgroups that leave at
+// once (a later slab's finished tiles) are dispatched behind everybody who has work.  The ranges duty files every tile under
+// (band, class): counts per duty workgroup in LDS, one global atomic per (workgroup, cell) on the call's zeroed counters,
+// the tile id into the cell's part of the table.  The blend finds its tile from the eight counters of its band
+// (gsr_device.h: ordered_item).  Placement only: results do not depend on it, nor on the order the atomics are served in.
 struct BlendOrder {
     uint32_t* counts;   // [8 bands][8 classes], zero before the ranges duty (null: plain band order)
     uint32_t* table;    // [8][8][cap] tile ids
@@ -139,6 +139,8 @@ struct BlendOrder {
 };
 constexpr int kOrderClasses = 8;
 
+// The per-tile [begin, end) of one slab's sorted list (K5, identifyTileRanges): 255 tiles per 256-lane workgroup, so
+// div_up(num_tiles, 255) workgroups of whatever kernel carries the duty (gsr_device.h: tile_ranges_duty).
 struct RangesDuty {
     const SlabInfo* slab;          // pairs = number of sorted keys
     int num_tiles;
