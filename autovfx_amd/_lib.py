@@ -15,11 +15,11 @@ LIB_PATH = os.environ.get("GSR_LIB", os.path.join(_HERE, "lib", "libgsr_hip.so")
 ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 
 # enum mirrors of include/gsr.h
-GEOM_SLOTS = ("raster", "rgb", "splat_bins", "internal_radii", "depth_order", "point_offsets", "listed")
+GEOM_SLOTS = ("raster", "rgb", "splat_bins", "internal_radii", "depth_order", "point_offsets", "listed", "view_normals")
 BIN_SLOTS = ("point_list", "tile_keys")
 IMG_SLOTS = ("ranges", "n_contrib")
 STAGES = ("preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "ranges", "blend", "colour")
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_SLABS = 8
 FORWARD_INFERENCE = 1
 
@@ -28,7 +28,8 @@ SYMBOLS = ("gsr_forward", "gsr_mark_visible", "gsr_backward", "gsr_last_geom_off
            "gsr_last_image_offsets", "gsr_set_stage_timing", "gsr_get_stage_times", "gsr_last_error",
            "gsr_abi_version", "gsr_target_arch", "gsr_set_option", "gsr_get_option", "gsr_pack_rgba8", "gsr_last_pair_counts", "gsr_blend", "gsr_composite",
            "gsr_radix_scratch_bytes", "gsr_radix_sort_pairs", "gsr_selftest_exp", "gsr_view_normals", "gsr_normal_maps", "gsr_forward_extra", "gsr_get_call_times",
-           "gsr_forward_begin", "gsr_forward_finish", "gsr_forward_ready", "gsr_forward_cancel", "gsr_last_slab_pairs", "gsr_plan_slabs", "gsr_selftest_lds_atomic_order", "gsr_get_backward_times", "gsr_place_object")
+           "gsr_forward_begin", "gsr_forward_finish", "gsr_forward_ready", "gsr_forward_cancel", "gsr_last_slab_pairs", "gsr_plan_slabs", "gsr_selftest_lds_atomic_order", "gsr_get_backward_times", "gsr_place_object",
+           "gsr_forward_raw", "gsr_forward_raw_begin")
 OPT_TILE_CULL = 0
 OPT_SLABS = 1
 OPT_SLAB_FIRST = 2
@@ -38,6 +39,11 @@ OPT_RADIX_RANK = 5           # 0 ballots, 1 LDS adds, 2 (default) LDS adds where
 OPT_RADIX_RANK_ACTIVE = 6    # read-only: what the current device uses (1 LDS adds, 0 ballots)
 OPT_BLEND_ORDER = 8          # 1 (default): large images are blended longest tile list first inside each XCD's band
 OPT_DEPTH_DROP = 7           # 1 (default): Gaussians that emit nothing leave the depth sort in its first pass
+
+
+class RawParams(ctypes.Structure):
+    """``gsr_raw_params`` (include/gsr.h): device pointers of a model's six raw parameter tensors."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("xyz", "log_scales", "rotations", "opacity_logits", "features_dc", "features_rest")]
 
 
 class GsrLibraryError(ImportError):
@@ -70,6 +76,16 @@ def _load() -> ctypes.CDLL:
     lib.gsr_forward_extra.argtypes = lib.gsr_forward.argtypes[:-2] + [c_f, c_f, ctypes.c_uint, ctypes.c_int, ctypes.c_void_p]
     lib.gsr_forward_begin.restype = ctypes.c_void_p
     lib.gsr_forward_begin.argtypes = lib.gsr_forward_extra.argtypes
+    lib.gsr_forward_raw.restype = ctypes.c_int
+    lib.gsr_forward_raw.argtypes = [
+        ALLOC_FN, ctypes.c_void_p, ALLOC_FN, ctypes.c_void_p, ALLOC_FN, ctypes.c_void_p,
+        ctypes.c_int, ctypes.c_int, ctypes.c_int,            # P D M
+        c_f, ctypes.c_int, ctypes.c_int,                     # background width height
+        ctypes.POINTER(RawParams), ctypes.c_float,           # raw scale_modifier
+        c_f, c_f, c_f, ctypes.c_float, ctypes.c_float, ctypes.c_int,  # view proj campos tanx tany prefiltered
+        c_f, c_f, c_f, c_f, c_f, ctypes.c_uint, ctypes.c_int, ctypes.c_void_p]   # color depth alpha radii normal flags debug stream
+    lib.gsr_forward_raw_begin.restype = ctypes.c_void_p
+    lib.gsr_forward_raw_begin.argtypes = lib.gsr_forward_raw.argtypes
     lib.gsr_forward_finish.restype = ctypes.c_int
     lib.gsr_forward_finish.argtypes = [ctypes.c_void_p]
     lib.gsr_forward_ready.restype = ctypes.c_int

@@ -567,6 +567,11 @@ struct ForwardCall {
     uint4* sorted_bins = nullptr;
     const float *colors_precomp = nullptr, *background = nullptr, *extra_features = nullptr;
     float *out_color = nullptr, *out_depth = nullptr, *out_alpha = nullptr, *out_extra = nullptr;
+    // gsr_forward_raw (set before forward_begin): the inputs are a model's raw parameter tensors; raw_rest = its
+    // _features_rest; raw_normals = the per-Gaussian view normals are worked out by the projection kernel into an array of
+    // the geometry arena and composited as the call's second feature set (into out_extra)
+    bool raw = false, raw_normals = false;
+    const float* raw_rest = nullptr;
     PinnedSlot pinned;
 
     ~ForwardCall() {
@@ -638,6 +643,10 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
         return fail(GSR_ERR_INVALID_ARG, "provide exactly one of (scales, rotations) / cov3D_precomp");
     if (shs != nullptr && M <= 0) return fail(GSR_ERR_INVALID_ARG, "shs given with M=%d", M);
     if ((flags & ~(unsigned)GSR_FORWARD_INFERENCE) != 0u) return fail(GSR_ERR_INVALID_ARG, "unknown flags 0x%x", flags);
+    if (fc.raw && (shs == nullptr || !have_sr || (M > 1 && fc.raw_rest == nullptr)))
+        return fail(GSR_ERR_INVALID_ARG, "raw parameters: xyz, log_scales, rotations, opacity_logits, features_dc (and features_rest when M > 1) are all required");
+    if (fc.raw_normals && (!fc.raw || out_extra == nullptr || extra_features != nullptr))
+        return fail(GSR_ERR_INVALID_ARG, "view normals need a raw-parameter call and an output image");
 
     gsr::Camera& cam = fc.cam;
     cam.viewmatrix = viewmatrix;
@@ -709,6 +718,7 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     geom_off[GSR_GEOM_RGB] = gc.take<float>(3 * n);
     geom_off[GSR_GEOM_SPLAT_BINS] = gc.take<gsr::SplatBin>(n);
     geom_off[GSR_GEOM_INTERNAL_RADII] = gc.take<int>(n);
+    geom_off[GSR_GEOM_VIEW_NORMALS] = gc.take<float>(fc.raw_normals ? 3 * n : 0);
     const size_t off_keys_a = gc.take<uint32_t>(n), off_keys_b = gc.take<uint32_t>(n);
     const size_t off_ids_a = gc.take<uint32_t>(n), off_ids_b = gc.take<uint32_t>(n);
     geom_off[GSR_GEOM_POINT_OFFSETS] = gc.take<uint32_t>(n);
@@ -752,6 +762,11 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     in.scale_modifier = scale_modifier; in.prefiltered = prefiltered;
     in.tile_cull = g_options[GSR_OPT_TILE_CULL] != 0;
     in.defer_colour = fc.defer_colour ? 1 : 0;
+    in.raw = fc.raw ? 1 : 0;
+    in.shs_rest = fc.raw_rest;
+    in.view_normals = fc.raw_normals ? (float*)(gbase + geom_off[GSR_GEOM_VIEW_NORMALS]) : nullptr;
+    if (fc.raw_normals) fc.extra_features = in.view_normals;
+    else geom_off[GSR_GEOM_VIEW_NORMALS] = 0;
 
     gsr::GeometryArrays& ga = fc.ga;
     ga.raster = (gsr::SplatRaster*)(gbase + geom_off[GSR_GEOM_RASTER]);
@@ -1043,6 +1058,58 @@ int gsr_forward_extra(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn bin
     ForwardCall fc;
     const int rc = forward_begin(fc, GSR_FORWARD_ARGS, extra_features, out_extra, flags);
     return rc < 0 ? rc : forward_finish(fc);
+}
+
+namespace {
+// gsr_forward_raw / gsr_forward_raw_begin: a model's tensors take the places of the activated ones in the common path
+int raw_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_alloc, void* binning_user,
+              gsr_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width, int height,
+              const gsr_raw_params* raw, float scale_modifier, const float* viewmatrix, const float* projmatrix,
+              const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth,
+              float* out_alpha, int* radii, float* out_normal, unsigned flags, int debug, void* stream) {
+    if (!raw) return fail(GSR_ERR_INVALID_ARG, "null raw parameter block");
+    if (M <= 0) return fail(GSR_ERR_INVALID_ARG, "raw parameters carry SH coefficients: M=%d", M);
+    fc.raw = true;
+    fc.raw_rest = raw->features_rest;
+    fc.raw_normals = out_normal != nullptr;
+    return forward_begin(fc, geom_alloc, geom_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background, width,
+                         height, raw->xyz, raw->features_dc, nullptr, raw->opacity_logits, raw->log_scales, scale_modifier,
+                         raw->rotations, nullptr, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color,
+                         out_depth, out_alpha, radii, debug, stream, nullptr, out_normal, flags);
+}
+} // namespace
+
+int gsr_forward_raw(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_alloc, void* binning_user,
+                    gsr_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width,
+                    int height, const gsr_raw_params* raw, float scale_modifier, const float* viewmatrix,
+                    const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+                    float* out_color, float* out_depth, float* out_alpha, int* radii, float* out_normal, unsigned flags,
+                    int debug, void* stream) {
+    ForwardCall fc;
+    const int rc = raw_begin(fc, geom_alloc, geom_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background,
+                             width, height, raw, scale_modifier, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered,
+                             out_color, out_depth, out_alpha, radii, out_normal, flags, debug, stream);
+    return rc < 0 ? rc : forward_finish(fc);
+}
+
+void* gsr_forward_raw_begin(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_alloc, void* binning_user,
+                            gsr_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background,
+                            int width, int height, const gsr_raw_params* raw, float scale_modifier, const float* viewmatrix,
+                            const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+                            float* out_color, float* out_depth, float* out_alpha, int* radii, float* out_normal,
+                            unsigned flags, int debug, void* stream) {
+    ForwardCall* fc = new (std::nothrow) ForwardCall;
+    if (!fc) {
+        fail(GSR_ERR_ALLOC, "out of host memory");
+        return nullptr;
+    }
+    if (raw_begin(*fc, geom_alloc, geom_user, binning_alloc, binning_user, image_alloc, image_user, P, D, M, background, width,
+                  height, raw, scale_modifier, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color,
+                  out_depth, out_alpha, radii, out_normal, flags, debug, stream) < 0) {
+        delete fc;
+        return nullptr;
+    }
+    return fc;
 }
 
 void* gsr_forward_begin(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_alloc, void* binning_user,

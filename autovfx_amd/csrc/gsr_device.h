@@ -136,41 +136,99 @@ __device__ __forceinline__ F3 axmy(F3 acc, float s, F3 v) {  // acc - s * v, unf
 }
 
 // forward.cu:20-71 up to (and including) the +0.5, before the clamp.  (x, y, z) is the unit view
-// direction; `sh` points at this Gaussian's [M,3] block; deg already clamped to what M holds.
-__device__ __forceinline__ F3 sh_unclamped(int deg, float x, float y, float z, const float* sh) {
-    F3 c = ld3(sh);
+// direction; coefficient 0 sits at `sh0`, coefficient k >= 1 at `shr + 3 k`; deg already clamped to what M holds.
+// One [M,3] block (the reference's `shs`): sh0 = shr = the block.  A model's two tensors (gsr_forward_raw): sh0 = its
+// _features_dc row, shr = its _features_rest row - 3 -- what torch.cat((dc, rest), dim=1) would have laid out, unread.
+__device__ __forceinline__ F3 sh_unclamped(int deg, float x, float y, float z, const float* sh0, const float* shr) {
+    F3 c = ld3(sh0);
     F3 v = F3{kSH0 * c.x, kSH0 * c.y, kSH0 * c.z};
     if (deg > 0) {
-        v = axmy(v, kSH1 * y, ld3(sh + 3));
-        v = axpy(v, kSH1 * z, ld3(sh + 6));
-        v = axmy(v, kSH1 * x, ld3(sh + 9));
+        v = axmy(v, kSH1 * y, ld3(shr + 3));
+        v = axpy(v, kSH1 * z, ld3(shr + 6));
+        v = axmy(v, kSH1 * x, ld3(shr + 9));
         if (deg > 1) {
             const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-            v = axpy(v, kSH2_0 * xy, ld3(sh + 12));
-            v = axpy(v, kSH2_1 * yz, ld3(sh + 15));
-            v = axpy(v, kSH2_2 * (2.0f * zz - xx - yy), ld3(sh + 18));
-            v = axpy(v, kSH2_3 * xz, ld3(sh + 21));
-            v = axpy(v, kSH2_4 * (xx - yy), ld3(sh + 24));
+            v = axpy(v, kSH2_0 * xy, ld3(shr + 12));
+            v = axpy(v, kSH2_1 * yz, ld3(shr + 15));
+            v = axpy(v, kSH2_2 * (2.0f * zz - xx - yy), ld3(shr + 18));
+            v = axpy(v, kSH2_3 * xz, ld3(shr + 21));
+            v = axpy(v, kSH2_4 * (xx - yy), ld3(shr + 24));
             if (deg > 2) {
-                v = axpy(v, kSH3_0 * y * (3.0f * xx - yy), ld3(sh + 27));
-                v = axpy(v, kSH3_1 * xy * z, ld3(sh + 30));
-                v = axpy(v, kSH3_2 * y * (4.0f * zz - xx - yy), ld3(sh + 33));
-                v = axpy(v, kSH3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), ld3(sh + 36));
-                v = axpy(v, kSH3_4 * x * (4.0f * zz - xx - yy), ld3(sh + 39));
-                v = axpy(v, kSH3_5 * z * (xx - yy), ld3(sh + 42));
-                v = axpy(v, kSH3_6 * x * (xx - 3.0f * yy), ld3(sh + 45));
+                v = axpy(v, kSH3_0 * y * (3.0f * xx - yy), ld3(shr + 27));
+                v = axpy(v, kSH3_1 * xy * z, ld3(shr + 30));
+                v = axpy(v, kSH3_2 * y * (4.0f * zz - xx - yy), ld3(shr + 33));
+                v = axpy(v, kSH3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), ld3(shr + 36));
+                v = axpy(v, kSH3_4 * x * (4.0f * zz - xx - yy), ld3(shr + 39));
+                v = axpy(v, kSH3_5 * z * (xx - yy), ld3(shr + 42));
+                v = axpy(v, kSH3_6 * x * (xx - 3.0f * yy), ld3(shr + 45));
             }
         }
     }
     v.x += 0.5f; v.y += 0.5f; v.z += 0.5f;
     return v;
 }
+__device__ __forceinline__ F3 sh_unclamped(int deg, float x, float y, float z, const float* sh) {
+    return sh_unclamped(deg, x, y, z, sh, sh);
+}
 
-__device__ __forceinline__ F3 sh_to_rgb(int deg, F3 pos, F3 cam, const float* sh) {
+__device__ __forceinline__ F3 sh_to_rgb(int deg, F3 pos, F3 cam, const float* sh0, const float* shr) {
     float dx = pos.x - cam.x, dy = pos.y - cam.y, dz = pos.z - cam.z;
     const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-    const F3 v = sh_unclamped(deg, dx / len, dy / len, dz / len, sh);
+    const F3 v = sh_unclamped(deg, dx / len, dy / len, dz / len, sh0, shr);
     return F3{fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f)};
+}
+__device__ __forceinline__ F3 sh_to_rgb(int deg, F3 pos, F3 cam, const float* sh) { return sh_to_rgb(deg, pos, cam, sh, sh); }
+
+// ------------------------------------------------------------------------------------------------
+// The reference's per-frame PyTorch preparation, restated per Gaussian (gsr_forward_raw, gsr_place_object,
+// gsr_view_normals).  "As PyTorch-ROCm evaluates it" is meant literally: each helper performs the roundings of the
+// framework kernels the reference's Python launches on this GPU, in their order, so the activated values -- and with
+// them radii, lists and images -- are the bits an unchanged render() hands to the rasterizer.  The orders were
+// identified on the device (scripts/experiments/torch_op_probe.py + torch_op_identify.py, profiles/r04_torch_ops.txt):
+//   * a reduction over a contiguous last dimension of 4 is split over 4 lanes and combined by shuffles:
+//     (x0 + x1) + (x2 + x3); of 3, over 2 lanes: (x0 + x2) + x1  (ATen/native/cuda/Reduce.cuh: block.x = last_pow2(n));
+//   * elementwise expressions written as separate Python operators are separate kernels: one rounding each, never fused;
+//   * torch.argsort of 3 values is the 32-wide bitonic network (unstable): ties resolve as spelled out in min_axis.
+// The library is built with -ffp-contract=off, so what is written here is what runs.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float torch_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }  // UnarySpecialOpsKernel.cu: one / (one + exp(-a))
+
+// torch.nn.functional.normalize(q[P,4]) (gaussian_model.py:100-101): q / max(||q||, 1e-12)
+__device__ __forceinline__ F4 torch_normalize4(F4 q) {
+    const float n = fmaxf(sqrtf((q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w)), 1e-12f);
+    return F4{q.x / n, q.y / n, q.z / n, q.w / n};
+}
+// v.norm(dim=1) / torch.sum(v, dim=-1) of a contiguous [P,3]
+__device__ __forceinline__ float torch_sum3(float a, float b, float c) { return (a + c) + b; }
+__device__ __forceinline__ float torch_norm3(F3 v) { return sqrtf(torch_sum3(v.x * v.x, v.y * v.y, v.z * v.z)); }
+
+// get_minimum_axis(scales, rotations) (utils/general_utils.py:135-141 with build_rotation :78-101): the column of the
+// rotation matrix that belongs to the smallest scale.  `q` is the normalised quaternion (build_rotation normalises once
+// more, with the sum written out left to right).  Which column on a tie is what the bitonic argsort leaves in front:
+//   s0 == s1 < s2 -> 1;  s0 == s2 < s1 -> 0;  s1 == s2 < s0 -> 1;  all equal -> 2.
+__device__ __forceinline__ F3 min_axis(F3 s, F4 q) {
+    const float n = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    const float w = q.x / n, x = q.y / n, y = q.z / n, z = q.w / n;
+    int c;
+    if (s.x < s.y) c = s.z < s.x ? 2 : 0;
+    else if (s.y < s.x) c = s.z < s.y ? 2 : 1;
+    else c = s.x < s.z ? 1 : 2;
+    if (c == 0) return F3{1.f - 2.f * (y * y + z * z), 2.f * (x * y + w * z), 2.f * (x * z - w * y)};
+    if (c == 1) return F3{2.f * (x * y - w * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + w * x)};
+    return F3{2.f * (x * z + w * y), 2.f * (y * z - w * x), 1.f - 2.f * (x * x + y * y)};
+}
+
+// pc.get_normal(dir_pp_normalized) * 0.5 + 0.5 (gaussian_renderer/__init__.py:118-119,169-171; gaussian_model.py
+// get_normal; general_utils.py:151-157 flip_align_view): the axis flipped towards the camera, unit length, to [0, 1].
+__device__ __forceinline__ F3 view_normal_rgb(F3 p, F3 cam, F3 axis) {
+    const F3 d = {p.x - cam.x, p.y - cam.y, p.z - cam.z};
+    const float len = torch_norm3(d);
+    const F3 dir = {d.x / len, d.y / len, d.z / len};
+    const float dot = torch_sum3(axis.x * -dir.x, axis.y * -dir.y, axis.z * -dir.z);
+    const float sg = dot >= 0.f ? 1.f : -1.f;
+    const F3 m = {axis.x * sg, axis.y * sg, axis.z * sg};
+    const float ml = torch_norm3(m);
+    return F3{m.x / ml * 0.5f + 0.5f, m.y / ml * 0.5f + 0.5f, m.z / ml * 0.5f + 0.5f};
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -59,6 +59,14 @@ struct GaussianInputs {
     int prefiltered;
     int tile_cull;  // GSR_OPT_TILE_CULL
     int defer_colour;  // SH colours are evaluated later, only for the splats that reach a list (sh_colour_kernel)
+    // gsr_forward_raw: the parameters arrive as the model stores them and are activated in the kernels, every operation
+    // as (and in the order) PyTorch-ROCm evaluates the reference's getters (gaussian_model.py:95-128):
+    //   scales = log scales (exp), rotations = unnormalised (F.normalize), opacities = logits (sigmoid),
+    //   shs = _features_dc [P,1,3] and shs_rest = _features_rest [P,M-1,3] (the torch.cat is never materialised)
+    int raw;
+    const float* shs_rest;       // raw calls with M > 1
+    float* view_normals;         // nullable, raw calls: [P,3] pc.get_normal(dir) * 0.5 + 0.5 of every splat that emits pairs
+                                 // (gaussian_renderer/__init__.py:169-171), the blend's second feature set
 };
 
 // Everything the pair expansion needs about one splat, in one 16-byte record so that walking the splats in depth

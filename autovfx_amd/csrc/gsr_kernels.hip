@@ -35,6 +35,9 @@ namespace {
 // K1: one lane per Gaussian.  Streaming, HBM-bound: 236 B in (M = 16; 44 B when the colours are deferred) and 52 B
 // out per visible Gaussian, 12 B in / 12 B out per culled one.
 // ------------------------------------------------------------------------------------------------
+// kRaw (gsr_forward_raw): scales / rotations / opacities / shs are the model's raw parameter tensors and are activated
+// here, as PyTorch-ROCm would have (gsr_device.h: torch_*): no activated copy of anything is ever written to memory.
+template <bool kRaw>
 __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Camera cam, GeometryArrays out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool in_range = i < in.P;  // every lane stays to the end: the tile-mask phase below is wave-cooperative
@@ -79,13 +82,19 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
 
         // ---- 3D covariance (forward.cu:118-152) ----
         float c3[6];
+        F3 s = {0.f, 0.f, 0.f};
+        F4 q = {0.f, 0.f, 0.f, 0.f};
         if (in.cov3D_precomp != nullptr) {
             const float* c = in.cov3D_precomp + 6 * (size_t)i;
 #pragma unroll
             for (int k = 0; k < 6; ++k) c3[k] = c[k];
         } else {
-            const F3 s = ld3(in.scales + 3 * (size_t)i);
-            const F4 q = *reinterpret_cast<const F4*>(in.rotations + 4 * (size_t)i);
+            s = ld3(in.scales + 3 * (size_t)i);
+            q = *reinterpret_cast<const F4*>(in.rotations + 4 * (size_t)i);
+            if (kRaw) {   // gaussian_model.py:96-97 exp, :100-101 F.normalize
+                s = F3{expf(s.x), expf(s.y), expf(s.z)};
+                q = torch_normalize4(q);
+            }
             const float r = q.x, x = q.y, y = q.z, z = q.w;
             Mat3 S = {{{in.scale_modifier * s.x, 0.f, 0.f}, {0.f, in.scale_modifier * s.y, 0.f},
                        {0.f, 0.f, in.scale_modifier * s.z}}};
@@ -134,10 +143,15 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
                     if (deg > 1 && in.M < 9) deg = 1;
                     if (deg > 0 && in.M < 4) deg = 0;
                     const F3 cp = ld3(cam.cam_pos);
-                    const F3 col = sh_to_rgb(deg, p, cp, in.shs + 3 * (size_t)in.M * i);
+                    const float* sh0 = kRaw ? in.shs + 3 * (size_t)i : in.shs + 3 * (size_t)in.M * i;
+                    const float* shr = (kRaw && in.M > 1) ? in.shs_rest + 3 * (size_t)(in.M - 1) * i - 3 : sh0;
+                    const F3 col = sh_to_rgb(deg, p, cp, sh0, shr);
                     *reinterpret_cast<F3*>(out.rgb + 3 * (size_t)i) = col;
                 }
-                const float4 conic_o = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, in.opacities[i]);
+                if (kRaw && in.view_normals != nullptr)   // render()'s second feature set (gaussian_renderer/__init__.py:169-171)
+                    *reinterpret_cast<F3*>(in.view_normals + 3 * (size_t)i) = view_normal_rgb(p, ld3(cam.cam_pos), min_axis(s, q));
+                const float opacity = kRaw ? torch_sigmoid(in.opacities[i]) : in.opacities[i];   // gaussian_model.py:125-126
+                const float4 conic_o = make_float4(cc * det_inv, -cb * det_inv, ca * det_inv, opacity);
                 float4* rec = reinterpret_cast<float4*>(out.raster + i);  // one 32-byte record, two 16-byte stores
                 rec[0] = make_float4(px, py, conic_o.x, conic_o.y);
                 const float skip_below = blend_skip_below(conic_o.w);
@@ -405,7 +419,9 @@ __global__ void __launch_bounds__(256) sh_colour_listed_kernel(GaussianInputs in
     for (uint32_t t = (uint32_t)lane; t < n; t += 64u) {
         const uint32_t i = s_list[wave][t];
         const F3 p = ld3(in.means3D + 3 * (size_t)i);
-        const F3 col = sh_to_rgb(deg, p, cp, in.shs + 3 * (size_t)in.M * i);
+        const float* sh0 = in.raw ? in.shs + 3 * (size_t)i : in.shs + 3 * (size_t)in.M * i;
+        const float* shr = (in.raw && in.M > 1) ? in.shs_rest + 3 * (size_t)(in.M - 1) * i - 3 : sh0;
+        const F3 col = sh_to_rgb(deg, p, cp, sh0, shr);
         *reinterpret_cast<F3*>(rgb + 3 * (size_t)i) = col;
     }
     GSR_KTRACE(16384 + 8192 * (tag - 1) + blockIdx.x, 3);
@@ -428,7 +444,9 @@ __global__ void __launch_bounds__(256) sh_colour_all_kernel(GaussianInputs in, c
     if (deg > 1 && in.M < 9) deg = 1;
     if (deg > 0 && in.M < 4) deg = 0;
     const F3 p = ld3(in.means3D + 3 * (size_t)i);
-    const F3 col = sh_to_rgb(deg, p, ld3(cam_pos), in.shs + 3 * (size_t)in.M * i);
+    const float* sh0 = in.raw ? in.shs + 3 * (size_t)i : in.shs + 3 * (size_t)in.M * i;
+    const float* shr = (in.raw && in.M > 1) ? in.shs_rest + 3 * (size_t)(in.M - 1) * i - 3 : sh0;
+    const F3 col = sh_to_rgb(deg, p, ld3(cam_pos), sh0, shr);
     *reinterpret_cast<F3*>(rgb + 3 * (size_t)i) = col;
 }
 
@@ -564,7 +582,8 @@ __global__ void __launch_bounds__(256) composite_kernel(CompositeLayers L, size_
 
 hipError_t launch_preprocess(const GaussianInputs& in, const Camera& cam, const GeometryArrays& out,
                              hipStream_t stream) {
-    hipLaunchKernelGGL(preprocess_kernel, dim3(div_up(in.P, 256)), dim3(256), 0, stream, in, cam, out);
+    if (in.raw) hipLaunchKernelGGL(preprocess_kernel<true>, dim3(div_up(in.P, 256)), dim3(256), 0, stream, in, cam, out);
+    else hipLaunchKernelGGL(preprocess_kernel<false>, dim3(div_up(in.P, 256)), dim3(256), 0, stream, in, cam, out);
     return hipGetLastError();
 }
 
@@ -632,8 +651,15 @@ hipError_t launch_composite(int width, int height, const void* bg_c, const void*
 //                         depth map: un-project the 4 neighbours (get_ray_directions :41-80, c2w rotation),
 //                         cross product of the central differences (depth_pcd2normal :22-38), zero border.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ F3 unit3(F3 v) {  // torch.nn.functional.normalize(p=2, eps=1e-12)
+// F.normalize(p=2, eps=1e-12) of a 3-vector.  The order of the three squares is the framework reduction's (gsr_device.h):
+// left to right when the vector's components are strided planes (the permuted normal image), (x + z) + y when they are
+// contiguous (the cross products).
+__device__ __forceinline__ F3 unit3_planes(F3 v) {
     const float n = fmaxf(sqrtf(v.x * v.x + v.y * v.y + v.z * v.z), 1e-12f);
+    return F3{v.x / n, v.y / n, v.z / n};
+}
+__device__ __forceinline__ F3 unit3_contiguous(F3 v) {
+    const float n = fmaxf(torch_norm3(v), 1e-12f);
     return F3{v.x / n, v.y / n, v.z / n};
 }
 
@@ -642,15 +668,7 @@ __global__ void __launch_bounds__(256) view_normals_kernel(int P, const float* _
                                                            const float* __restrict__ cam_pos, float* __restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
-    const F3 p = ld3(means3D + 3 * (size_t)i), a = ld3(axis + 3 * (size_t)i), c = ld3(cam_pos);
-    const F3 d = {p.x - c.x, p.y - c.y, p.z - c.z};
-    const float len = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
-    const F3 dir = {d.x / len, d.y / len, d.z / len};
-    const float dot = a.x * -dir.x + a.y * -dir.y + a.z * -dir.z;
-    const float s = dot >= 0.f ? 1.f : -1.f;
-    const F3 m = {a.x * s, a.y * s, a.z * s};
-    const float ml = sqrtf(m.x * m.x + m.y * m.y + m.z * m.z);
-    *reinterpret_cast<F3*>(out + 3 * (size_t)i) = F3{m.x / ml * 0.5f + 0.5f, m.y / ml * 0.5f + 0.5f, m.z / ml * 0.5f + 0.5f};
+    *reinterpret_cast<F3*>(out + 3 * (size_t)i) = view_normal_rgb(ld3(means3D + 3 * (size_t)i), ld3(cam_pos), ld3(axis + 3 * (size_t)i));
 }
 
 struct NormalMapArgs {
@@ -658,7 +676,7 @@ struct NormalMapArgs {
     const float* normal_rgb;  // [3,H,W]
     const float* depth;       // [H,W]
     const float* c2w;         // device, 16 floats row-major: the 4x4 the Python calls c2w
-    float fx, fy, cx, cy;
+    float inv_fx, inv_fy, cx, cy;   // inv = (float)(1.0 / (double)f): see the kernel
     float* normal;            // [H,W,3]
     float* pseudo;            // [H,W,3]
 };
@@ -668,21 +686,28 @@ __global__ void __launch_bounds__(256) normal_maps_kernel(NormalMapArgs a) {
     if (u >= a.W || v >= a.H) return;
     const size_t plane = (size_t)a.W * a.H, pid = (size_t)v * a.W + u;
     const F3 raw = {a.normal_rgb[pid], a.normal_rgb[plane + pid], a.normal_rgb[2 * plane + pid]};
-    *reinterpret_cast<F3*>(a.normal + 3 * pid) = unit3(F3{(raw.x - 0.5f) * 2.0f, (raw.y - 0.5f) * 2.0f, (raw.z - 0.5f) * 2.0f});
+    *reinterpret_cast<F3*>(a.normal + 3 * pid) = unit3_planes(F3{(raw.x - 0.5f) * 2.0f, (raw.y - 0.5f) * 2.0f, (raw.z - 0.5f) * 2.0f});
 
     F3 n = {0.f, 0.f, 0.f};
     if (u >= 1 && v >= 1 && u < a.W - 1 && v < a.H - 1) {
         const float* __restrict__ m = a.c2w;  // uniform: scalar loads
+        // What the framework kernels behind the Python compute, rounding for rounding: a division by a CPU scalar is a
+        // multiplication by its reciprocal, formed in double from the float32 intrinsic and rounded once
+        // (BinaryDivTrueKernel.cu: static_cast<opmath_t>(1.0 / scalar_value<double>)); `directions @ c2w[:3,:3].T` is a GEMM that
+        // accumulates k = 0, 1, 2 with fused multiply-adds (the third direction component is 1); `rays_o + rays_d * depth`
+        // is two kernels; torch.cross contracts a_i b_j - a_j b_i into fma(a_i, b_j, -(a_j b_i)).
+        const float inv_fx = a.inv_fx, inv_fy = a.inv_fy;
         auto point = [&](int x, int y) {  // rays_o + rays_d * depth
-            const float dx = ((float)x - a.cx + 0.5f) / a.fx, dy = ((float)y - a.cy + 0.5f) / a.fy;
+            const float dx = ((float)x - a.cx + 0.5f) * inv_fx, dy = ((float)y - a.cy + 0.5f) * inv_fy;
             const float z = a.depth[(size_t)y * a.W + x];
-            return F3{m[3] + (dx * m[0] + dy * m[1] + m[2]) * z, m[7] + (dx * m[4] + dy * m[5] + m[6]) * z,
-                      m[11] + (dx * m[8] + dy * m[9] + m[10]) * z};
+            return F3{m[3] + (__builtin_fmaf(dy, m[1], dx * m[0]) + m[2]) * z, m[7] + (__builtin_fmaf(dy, m[5], dx * m[4]) + m[6]) * z,
+                      m[11] + (__builtin_fmaf(dy, m[9], dx * m[8]) + m[10]) * z};
         };
         const F3 right = point(u + 1, v), left = point(u - 1, v), top = point(u, v - 1), bottom = point(u, v + 1);
         const F3 h = {right.x - left.x, right.y - left.y, right.z - left.z};
         const F3 w = {top.x - bottom.x, top.y - bottom.y, top.z - bottom.z};
-        n = unit3(F3{h.y * w.z - h.z * w.y, h.z * w.x - h.x * w.z, h.x * w.y - h.y * w.x});
+        n = unit3_contiguous(F3{__builtin_fmaf(h.y, w.z, -(h.z * w.y)), __builtin_fmaf(h.z, w.x, -(h.x * w.z)),
+                                __builtin_fmaf(h.x, w.y, -(h.y * w.x))});
     }
     *reinterpret_cast<F3*>(a.pseudo + 3 * pid) = n;
 }
@@ -733,20 +758,12 @@ __global__ void __launch_bounds__(256) place_object_kernel(int n, const float* _
         float oy = aw * b.z - ax * b.w + ay * b.x + az * b.y;
         float oz = aw * b.w + ax * b.z - ay * b.y + az * b.x;
         if (ow < 0.f) { ow = -ow; ox = -ox; oy = -oy; oz = -oz; }   // standardize_quaternion
-        const float norm = fmaxf(sqrtf(((ow * ow + ox * ox) + oy * oy) + oz * oz), 1e-12f);
-        const F4 qn = F4{ow / norm, ox / norm, oy / norm, oz / norm};
+        const F4 qn = torch_normalize4(F4{ow, ox, oy, oz});
         *reinterpret_cast<F4*>(out_rot + 4 * (size_t)i) = qn;
         if (out_opacity != nullptr) out_opacity[i] = opacity[i];
         if (out_min_axis != nullptr) {
-            // general_utils.py:78-101 build_rotation (normalises once more) and :135-141 get_minimum_axis: the column of R that
-            // belongs to the smallest scale (first one on a tie)
-            const float n2 = sqrtf(qn.x * qn.x + qn.y * qn.y + qn.z * qn.z + qn.w * qn.w);
-            const float w = qn.x / n2, x = qn.y / n2, y = qn.z / n2, z = qn.w / n2;
-            const int c = (sc.x <= sc.y && sc.x <= sc.z) ? 0 : (sc.y <= sc.z ? 1 : 2);
-            F3 col;
-            if (c == 0) col = F3{1.f - 2.f * (y * y + z * z), 2.f * (x * y + w * z), 2.f * (x * z - w * y)};
-            else if (c == 1) col = F3{2.f * (x * y - w * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + w * x)};
-            else col = F3{2.f * (x * z + w * y), 2.f * (y * z - w * x), 1.f - 2.f * (x * x + y * y)};
+            // general_utils.py:78-101 build_rotation (normalises once more) and :135-141 get_minimum_axis (gsr_device.h: min_axis)
+            const F3 col = min_axis(sc, qn);
             *reinterpret_cast<F3*>(out_min_axis + 3 * (size_t)i) = col;
         }
     }
@@ -780,7 +797,7 @@ hipError_t launch_normal_maps(int width, int height, const float* normal_rgb, co
     NormalMapArgs a;
     a.W = width; a.H = height; a.normal_rgb = normal_rgb; a.depth = depth;
     a.c2w = c2w;
-    a.fx = fx; a.fy = fy; a.cx = cx; a.cy = cy; a.normal = normal; a.pseudo = pseudo;
+    a.inv_fx = (float)(1.0 / (double)fx); a.inv_fy = (float)(1.0 / (double)fy); a.cx = cx; a.cy = cy; a.normal = normal; a.pseudo = pseudo;
     hipLaunchKernelGGL(normal_maps_kernel, dim3(div_up(width, 64), div_up(height, 4)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }

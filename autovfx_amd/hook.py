@@ -1,0 +1,134 @@
+"""``autovfx_amd.install()``: put the MI355X render path behind an UNCHANGED AutoVFX process.
+
+AutoVFX reaches the rasterizer through two imports (paths under the reference tree):
+
+* ``from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer``
+  (``sugar/gaussian_splatting/gaussian_renderer/__init__.py:16``, ``sugar/sugar_scene/sugar_model.py:9``) -- served by the
+  ``diff_gaussian_rasterization`` package at the root of this repository once that root is on ``sys.path``;
+* ``from sugar.gaussian_splatting.gaussian_renderer import render`` (``scene_representation.py:24``,
+  ``extract/extract_object.py:14``; ``from gaussian_renderer import render`` in ``sugar/gaussian_splatting/train.py:16`` /
+  ``render.py:17``; ``from gaussian_splatting.gaussian_renderer import render as gs_render`` in
+  ``sugar/sugar_scene/gs_model.py:7``) -- the per-frame function, whose PyTorch preparation costs more than the rasterizer.
+
+``install()`` makes both resolve here:
+
+1. the repository root goes to the front of ``sys.path`` (so ``diff_gaussian_rasterization`` is this one);
+2. every module named ``...gaussian_renderer`` -- already imported or imported later (a ``sys.meta_path`` hook) -- gets its
+   ``render`` replaced by ``autovfx_amd.renderer.render`` (same signature, same result dictionary; the original stays
+   reachable as ``<module>.reference_render``), and every already-imported module that holds the original function under
+   any name (``from ... import render [as gs_render]``) is rebound too.
+
+Nothing else of the reference is touched: its ``GaussianModel``, cameras, scene editing and I/O run as they are.  With
+autograd off, ``render`` reads the model's six raw parameter tensors and activates them inside the HIP kernels
+(``gsr_forward_raw``); with autograd on it keeps the reference's structure (PyTorch activations, two rasterizer calls).
+
+Opt-in without touching AutoVFX's sources: put ``<repo>/integration`` and ``<repo>`` on ``PYTHONPATH`` and set
+``AUTOVFX_AMD_INSTALL=1``; ``integration/sitecustomize.py`` then calls ``install()`` at interpreter start (the hook itself
+imports neither torch nor the HIP library until a ``gaussian_renderer`` module is actually imported).
+"""
+from __future__ import annotations
+
+import importlib.abc
+import importlib.util
+import os
+import sys
+import types
+from typing import Callable, List, Optional
+
+_REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_TARGET_LEAF = "gaussian_renderer"
+_installed: Optional["_RendererHook"] = None
+patched_modules: List[str] = []          # names of the modules whose ``render`` was replaced (introspection / tests)
+
+
+def _is_target(fullname: str) -> bool:
+    return fullname == _TARGET_LEAF or fullname.endswith("." + _TARGET_LEAF)
+
+
+def _our_render() -> Callable:
+    from .renderer import render   # imports torch and loads libgsr_hip.so: only when a renderer module really appears
+    return render
+
+
+def _patch_renderer_module(module: types.ModuleType) -> None:
+    original = module.__dict__.get("render")
+    if original is None or getattr(original, "__module__", "").startswith("autovfx_amd"):
+        return
+    ours = _our_render()
+    module.reference_render = original
+    module.render = ours
+    if module.__name__ not in patched_modules:
+        patched_modules.append(module.__name__)
+    # importers that already bound the original under some name (``from ... import render as gs_render``)
+    for other in list(sys.modules.values()):
+        d = getattr(other, "__dict__", None)
+        if not isinstance(d, dict) or other is module:
+            continue
+        for key, value in list(d.items()):
+            if value is original:
+                d[key] = ours
+
+
+class _PatchingLoader(importlib.abc.Loader):
+    def __init__(self, inner):
+        self._inner = inner
+
+    def create_module(self, spec):
+        return self._inner.create_module(spec) if hasattr(self._inner, "create_module") else None
+
+    def exec_module(self, module):
+        self._inner.exec_module(module)
+        _patch_renderer_module(module)
+
+    def __getattr__(self, name):   # get_code, get_source, is_package, ... for tools that ask the loader
+        return getattr(self._inner, name)
+
+
+class _RendererHook(importlib.abc.MetaPathFinder):
+    """Finds ``...gaussian_renderer`` with the regular finders and wraps its loader so that ``render`` is replaced right
+    after the module body ran."""
+
+    def find_spec(self, fullname, path=None, target=None):
+        if not _is_target(fullname):
+            return None
+        for finder in sys.meta_path:
+            if finder is self or not hasattr(finder, "find_spec"):
+                continue
+            spec = finder.find_spec(fullname, path, target)
+            if spec is not None and spec.loader is not None:
+                spec.loader = _PatchingLoader(spec.loader)
+                return spec
+        return None
+
+
+def install(path: bool = True) -> None:
+    """Idempotent.  ``path=False`` leaves ``sys.path`` alone (the caller arranged for ``diff_gaussian_rasterization``)."""
+    global _installed
+    if path and (not sys.path or sys.path[0] != _REPO_ROOT):
+        if _REPO_ROOT in sys.path:
+            sys.path.remove(_REPO_ROOT)
+        sys.path.insert(0, _REPO_ROOT)
+    stale = sys.modules.get("diff_gaussian_rasterization")
+    if stale is not None and not os.path.abspath(getattr(stale, "__file__", "") or "").startswith(_REPO_ROOT):
+        raise RuntimeError(f"diff_gaussian_rasterization is already imported from {getattr(stale, '__file__', '?')}: call "
+                           "autovfx_amd.install() before anything imports the rasterizer")
+    if _installed is None:
+        _installed = _RendererHook()
+        sys.meta_path.insert(0, _installed)
+    for name, module in list(sys.modules.items()):
+        if module is not None and _is_target(name):
+            _patch_renderer_module(module)
+
+
+def uninstall() -> None:
+    """Remove the import hook and put the reference's ``render`` back into the modules ``install`` patched (importers that
+    were rebound keep what they hold; meant for tests)."""
+    global _installed
+    if _installed is not None and _installed in sys.meta_path:
+        sys.meta_path.remove(_installed)
+    _installed = None
+    for name in list(patched_modules):
+        module = sys.modules.get(name)
+        if module is not None and hasattr(module, "reference_render"):
+            module.render = module.reference_render
+    patched_modules.clear()

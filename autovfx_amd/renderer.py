@@ -38,6 +38,41 @@ class PipelineParams:
 # that shape next to the default; results are the same images.
 FUSE_ELEMENTWISE = True
 
+# True: a model that exposes the reference's six raw parameter tensors with the reference's activations (any
+# ``scene.gaussian_model.GaussianModel``: ``_xyz, _scaling, _rotation, _opacity, _features_dc, _features_rest``) is rendered
+# from those tensors directly (``gsr_forward_raw``): exp / sigmoid / normalize, the SH concat and the per-Gaussian view normal
+# happen inside the projection and colour kernels instead of ~25 PyTorch launches and 2.3 GB of traffic per frame at 3 M
+# Gaussians.  No memo, nothing cached between frames: parameters may change every frame (training, dynamic scenes).
+# Bit-identical to the getters path on this GPU (tests/test_raw_gpu.py).
+RAW_PARAMETERS = True
+_RAW_ATTRS = ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")
+_RAW_ACTIVATIONS = (("scaling_activation", torch.exp), ("opacity_activation", torch.sigmoid),
+                    ("rotation_activation", torch.nn.functional.normalize))
+
+
+def raw_parameters(pc):
+    """The six raw tensors of ``pc`` when rendering from them is the same as rendering through its getters, else None:
+    all six attributes are float32 tensors on one GPU with consistent shapes, and the model's activation functions -- the
+    reference keeps them as attributes (``setup_functions``, ``scene/gaussian_model.py:25-45``) -- are the stock ones.  A
+    model can opt out with ``pc.gsr_raw_parameters = False`` (e.g. a subclass that overrides a getter)."""
+    if not getattr(pc, "gsr_raw_parameters", True):
+        return None
+    try:
+        t = tuple(getattr(pc, a) for a in _RAW_ATTRS)
+    except AttributeError:
+        return None
+    if not all(isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.device == t[0].device for x in t):
+        return None
+    for attr, fn in _RAW_ACTIVATIONS:
+        if getattr(pc, attr, fn) is not fn:
+            return None
+    xyz, ls, rot, op, dc, rest = t
+    P = xyz.shape[0]
+    if (xyz.dim() != 2 or tuple(xyz.shape) != (P, 3) or tuple(ls.shape) != (P, 3) or tuple(rot.shape) != (P, 4) or op.numel() != P
+            or tuple(dc.shape) != (P, 1, 3) or rest.dim() != 3 or rest.shape[0] != P or rest.shape[2] != 3):
+        return None
+    return t
+
 
 def _stream_ptr(device):
     import ctypes
@@ -83,10 +118,14 @@ def depth_pcd2normal(xyz: torch.Tensor) -> torch.Tensor:
 
 
 def get_ray_directions(H: int, W: int, fx: float, fy: float, cx: float, cy: float, device) -> torch.Tensor:
-    """Camera-space ray through each pixel centre, [H,W,3] (``:41-80`` with ``random=False``)."""
+    """Camera-space ray through each pixel centre, [H,W,3] (``:41-80`` with ``random=False``).  The intrinsics enter the
+    arithmetic as the 0-dim float32 CPU tensors the reference slices out of ``torch.FloatTensor([[fx, 0, cx], ...])``
+    (``:199``): on the GPU a division by such a scalar is a multiplication by ``float(1.0 / double(float32(fx)))``, which
+    a Python float in their place would not reproduce to the last bit."""
     v, u = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=device),
                           torch.arange(W, dtype=torch.float32, device=device), indexing="ij")
-    return torch.stack(((u - cx + 0.5) / fx, (v - cy + 0.5) / fy, torch.ones_like(u)), -1)
+    fx_, fy_, cx_, cy_ = (torch.tensor(float(t), dtype=torch.float32) for t in (fx, fy, cx, cy))
+    return torch.stack(((u - cx_ + 0.5) / fx_, (v - cy_ + 0.5) / fy_, torch.ones_like(u)), -1)
 
 
 def sh_basis(deg: int, dirs: torch.Tensor) -> torch.Tensor:
@@ -147,10 +186,11 @@ def render_begin(viewpoint_camera, pc, pipe=PipelineParams, bg_color: Optional[t
     (``frame_parallel.render_shard(driver="pipelined")``): the per-Gaussian normals, the projection and the depth
     sort are queued on the current stream and the call returns without waiting for the GPU; ``finish()`` (same
     thread, same current stream) queues the rest.  Needs what the fused single-pass path needs: autograd off, data on
-    the GPU, a model with ``get_minimum_axis``.  Images are those of ``render``, bit for bit."""
+    the GPU, a model with the six raw parameter tensors or with ``get_minimum_axis``.  Images are those of ``render``, bit for bit."""
     out = _render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, split=True)
     if not isinstance(out, PendingRender):
-        raise RuntimeError("render_begin needs torch.no_grad(), float32 data on the GPU and a model with get_minimum_axis")
+        raise RuntimeError("render_begin needs torch.no_grad(), float32 data on the GPU and a model with the raw parameter "
+                           "tensors or get_minimum_axis")
     return out
 
 
@@ -181,6 +221,37 @@ def _render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_col
         campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
     rasterizer = GaussianRasterizer(raster_settings=settings)
 
+    h, w = int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)
+    fx, fy = fov2focal(viewpoint_camera.FoVx, w), fov2focal(viewpoint_camera.FoVy, h)
+    c2w = getattr(viewpoint_camera, "view_world_transform", None)   # formed with the camera when it is ours
+    if c2w is None:
+        c2w = viewpoint_camera.world_view_transform.inverse()
+
+    # Straight from the model's raw parameters (gsr_forward_raw): no getter is called, nothing is activated in PyTorch.
+    raw = None
+    if (RAW_PARAMETERS and FUSE_ELEMENTWISE and not torch.is_grad_enabled() and override_color is None
+            and not pipe.convert_SHs_python and not pipe.compute_cov3D_python):
+        raw = raw_parameters(pc)
+    if raw is not None:
+        from diff_gaussian_rasterization import _C
+        s_ = settings
+        raw_args = (s_.bg, *raw, s_.scale_modifier, s_.viewmatrix, s_.projmatrix, s_.tanfovx, s_.tanfovy, s_.image_height,
+                    s_.image_width, s_.sh_degree, s_.campos, s_.prefiltered, s_.debug)
+
+        def assemble_raw(result):
+            (_n, rendered_image, depth_image, alpha_image, radii, _g, _b, _i, normal_image) = result
+            rendered_image = _C.rgba_planes(rendered_image, alpha_image)
+            depth_image = depth_image.squeeze(0)
+            normal_image, pseudo_normal = _fused_normal_maps(normal_image, depth_image, c2w, fx, fy, w / 2, h / 2)
+            return {"render": rendered_image, "depth": depth_image, "normal": normal_image,
+                    "pseudo_normal": pseudo_normal, "viewspace_points": screenspace_points,
+                    "visibility_filter": radii > 0, "radii": radii}
+
+        if split:
+            pending = _C.rasterize_gaussians_raw_begin(*raw_args, want_normal=True, inference=True)
+            return PendingRender(lambda: assemble_raw(pending.finish()), pending.ready)
+        return assemble_raw(_C.rasterize_gaussians_raw(*raw_args, want_normal=True, inference=True))
+
     means3D, means2D, opacity = xyz, screenspace_points, pc.get_opacity
     scales = rotations = cov3D_precomp = None
     if pipe.compute_cov3D_python:
@@ -206,11 +277,6 @@ def _render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_col
     else:
         colors_precomp = override_color
 
-    h, w = int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)
-    fx, fy = fov2focal(viewpoint_camera.FoVx, w), fov2focal(viewpoint_camera.FoVy, h)
-    c2w = getattr(viewpoint_camera, "view_world_transform", None)   # formed with the camera when it is ours
-    if c2w is None:
-        c2w = viewpoint_camera.world_view_transform.inverse()
     if fused:
         # One pass: the per-Gaussian normals ride through the SAME walk of the per-tile lists as a second feature
         # set (gsr_forward_extra); the normal image is what the reference's second pass (:176-184) returns, bit for bit.

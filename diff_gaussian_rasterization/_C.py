@@ -368,6 +368,91 @@ def rasterize_gaussians_begin(background, means3D, colors, opacity, scales, rota
     return PendingForward(handle, device, stream, scratch, (tensors, ext_), outputs)
 
 
+def _raw_call(begin, background, xyz, log_scales, rotations, opacity_logits, features_dc, features_rest, scale_modifier,
+              viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, degree, campos, prefiltered, debug,
+              want_normal, inference):
+    """Common part of ``rasterize_gaussians_raw`` / ``rasterize_gaussians_raw_begin``."""
+    if xyz.dim() != 2 or xyz.size(1) != 3:
+        raise RuntimeError("xyz must have dimensions (num_points, 3)")
+    device = _require_gpu(xyz, "xyz")
+    P, H, W = int(xyz.size(0)), int(image_height), int(image_width)
+    if features_dc.dim() != 3 or tuple(features_dc.shape) != (P, 1, 3):
+        raise RuntimeError("features_dc must have dimensions (num_points, 1, 3)")
+    if features_rest.dim() != 3 or features_rest.size(0) != P or features_rest.size(2) != 3:
+        raise RuntimeError("features_rest must have dimensions (num_points, M - 1, 3)")
+    if tuple(log_scales.shape) != (P, 3) or tuple(rotations.shape) != (P, 4) or opacity_logits.numel() != P:
+        raise RuntimeError("log_scales / rotations / opacity_logits must have dimensions (num_points, 3 / 4 / 1)")
+    M = 1 + int(features_rest.size(1))
+    make = (lambda shape, dtype, device: torch.zeros(shape, dtype=dtype, device=device)) if P == 0 else _new
+    rgba = make((4, H, W), dtype=torch.float32, device=device)
+    out_color, out_alpha = rgba[:3], rgba[3:4]
+    out_depth = make((1, H, W), dtype=torch.float32, device=device)
+    radii = make((P,), dtype=torch.int32, device=device)
+    out_normal = make((3, H, W), dtype=torch.float32, device=device) if want_normal else None
+    scratch = _CallScratch(device)
+    outputs = (out_color, out_depth, out_alpha, radii, out_normal)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    if P == 0:
+        return None, device, stream, scratch, None, outputs
+    tensors = [_f32c(n, t, device) for n, t in (
+        ("background", background), ("xyz", xyz), ("log_scales", log_scales), ("rotations", rotations),
+        ("opacity_logits", opacity_logits), ("features_dc", features_dc), ("features_rest", features_rest),
+        ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("campos", campos))]
+    bg_, xyz_, ls_, rot_, op_, dc_, rest_, vm_, pm_, cp_ = tensors
+    raw = _lib.RawParams(_ptr(xyz_), _ptr(ls_), _ptr(rot_), _ptr(op_), _ptr(dc_), _ptr(rest_))
+    _tls.call = scratch
+    try:
+        with torch.cuda.device(device):
+            fn = _lib.lib.gsr_forward_raw_begin if begin else _lib.lib.gsr_forward_raw
+            rc = fn(_GEOM_CB, None, _BINNING_CB, None, _IMAGE_CB, None, P, int(degree), M, _ptr(bg_), W, H, ctypes.byref(raw),
+                    float(scale_modifier), _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx), float(tan_fovy),
+                    1 if prefiltered else 0, out_color.data_ptr(), out_depth.data_ptr(), out_alpha.data_ptr(), radii.data_ptr(),
+                    None if out_normal is None else out_normal.data_ptr(), _lib.FORWARD_INFERENCE if inference else 0,
+                    1 if debug else 0, ctypes.c_void_p(stream))
+    finally:
+        _tls.call = None
+    return rc, device, stream, scratch, tensors, outputs
+
+
+def rasterize_gaussians_raw(background, xyz, log_scales, rotations, opacity_logits, features_dc, features_rest,
+                            scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, degree,
+                            campos, prefiltered, debug, *, want_normal: bool = True, inference: bool = True):
+    """The forward pass straight from a model's RAW parameter tensors (``gsr_forward_raw``): ``_xyz``, ``_scaling`` (log),
+    ``_rotation`` (unnormalised), ``_opacity`` (logit), ``_features_dc [P,1,3]``, ``_features_rest [P,M-1,3]`` as
+    ``GaussianModel`` stores them (``scene/gaussian_model.py:95-128``).  ``exp`` / ``sigmoid`` / ``F.normalize``, the
+    ``cat(dc, rest)`` and -- with ``want_normal`` -- ``get_normal(dir) * 0.5 + 0.5`` happen inside the kernels, rounded as
+    PyTorch rounds them on this GPU: the result is bit-identical to activating in PyTorch and calling
+    ``rasterize_gaussians_extra``.  Returns that function's 9-tuple (the last entry is the normal image or None).  Not
+    part of the reference surface; ``autovfx_amd.renderer.render`` uses it for any model that exposes the six tensors."""
+    rc, device, stream, scratch, tensors, outputs = _raw_call(
+        False, background, xyz, log_scales, rotations, opacity_logits, features_dc, features_rest, scale_modifier, viewmatrix,
+        projmatrix, tan_fovx, tan_fovy, image_height, image_width, degree, campos, prefiltered, debug, want_normal, inference)
+    out_color, out_depth, out_alpha, radii, out_normal = outputs
+    rendered = 0
+    if rc is not None:
+        if rc < 0:
+            raise RuntimeError(f"gsr_forward_raw failed ({rc}): {_lib.last_error()}")
+        rendered = rc
+        _tls.last_layout = {"geom": _lib.offsets("geom"), "binning": _lib.offsets("binning"), "image": _lib.offsets("image")}
+    b = scratch.buffers
+    return rendered, out_color, out_depth, out_alpha, radii, b["geom"], b["binning"], b["image"], out_normal
+
+
+def rasterize_gaussians_raw_begin(background, xyz, log_scales, rotations, opacity_logits, features_dc, features_rest,
+                                  scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width,
+                                  degree, campos, prefiltered, debug, *, want_normal: bool = True,
+                                  inference: bool = True) -> PendingForward:
+    """``rasterize_gaussians_raw`` in two halves (``gsr_forward_raw_begin``): see ``rasterize_gaussians_begin``."""
+    handle, device, stream, scratch, tensors, outputs = _raw_call(
+        True, background, xyz, log_scales, rotations, opacity_logits, features_dc, features_rest, scale_modifier, viewmatrix,
+        projmatrix, tan_fovx, tan_fovy, image_height, image_width, degree, campos, prefiltered, debug, want_normal, inference)
+    if tensors is None:   # P == 0
+        return PendingForward(None, device, stream, scratch, None, outputs)
+    if not handle:
+        raise RuntimeError(f"gsr_forward_raw_begin failed: {_lib.last_error()}")
+    return PendingForward(handle, device, stream, scratch, (tensors, None), outputs)
+
+
 def _blend_cached(hit, background, colors, device, H, W, out_color, out_depth, out_alpha):
     """Second pass over cached geometry: one blend launch over the first pass's lists (gsr_blend)."""
     geom, binning, image = hit["geom"], hit["binning"], hit["image"]

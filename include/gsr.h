@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 8
+#define GSR_ABI_VERSION 9
 
 #if defined(__GNUC__)
 #define GSR_API __attribute__((visibility("default")))
@@ -149,6 +149,59 @@ GSR_API int gsr_forward_finish(void* call);
 GSR_API int gsr_forward_ready(void* call);
 GSR_API void gsr_forward_cancel(void* call);
 
+/*
+ * The forward pass straight from a model's RAW parameter tensors (second half).
+ *
+ * The reference's render() (sugar/gaussian_splatting/gaussian_renderer/__init__.py:83-218) re-activates the whole model
+ * in PyTorch on every frame before it calls the rasterizer -- exp(_scaling), sigmoid(_opacity), normalize(_rotation),
+ * cat(_features_dc, _features_rest) (scene/gaussian_model.py:95-128), the view direction (:118-119) and
+ * get_normal(dir) * 0.5 + 0.5 via argsort / gather / build_rotation (utils/general_utils.py:78-101,135-157) -- about
+ * 2.3 GB of framework traffic per frame at 3 M Gaussians, more than the rasterizer itself moves.  gsr_forward_raw takes
+ * the six tensors as the model stores them and applies those operations inside the projection / colour kernels:
+ *
+ *   xyz            [P,3]      GaussianModel._xyz
+ *   log_scales     [P,3]      ._scaling         scale    = exp(x)                          (gaussian_model.py:96-97)
+ *   rotations      [P,4]      ._rotation        q        = x / max(||x||, 1e-12)           (:100-101, F.normalize)
+ *   opacity_logits [P] / [P,1] ._opacity        opacity  = 1 / (1 + exp(-x))               (:125-126)
+ *   features_dc    [P,1,3]    ._features_dc     SH coefficient 0
+ *   features_rest  [P,M-1,3]  ._features_rest   SH coefficients 1 .. M-1 (NULL allowed iff M == 1); no concatenation
+ *
+ * every operation rounded as, and in the order, PyTorch-ROCm evaluates it on this GPU (identified on the device:
+ * scripts/experiments/torch_op_probe.py; e.g. the norm of a quaternion is (x0^2 + x1^2) + (x2^2 + x3^2)), so radii, lists
+ * and images are bit-identical to activating in PyTorch and calling gsr_forward_extra (tests/test_raw_gpu.py).
+ *
+ * out_normal (nullable) [3,H,W]: the reference's second rasterizer pass (:169-184) -- the per-Gaussian view normal
+ * get_normal(dir) * 0.5 + 0.5 composited with the same alpha and transmittance -- worked out per Gaussian in the projection
+ * kernel (into GSR_GEOM_VIEW_NORMALS of the geometry arena) and composited in the same walk of the lists as the colour.
+ * Ties between a Gaussian's scales pick the axis torch.argsort's bitonic network would (gsr_device.h: min_axis).
+ *
+ * flags / debug / stream / scratch callbacks / return value: as gsr_forward_extra.  A full (non-inference) raw call leaves
+ * scratch that gsr_backward accepts together with the activated tensors.  gsr_forward_raw_begin is to gsr_forward_raw what
+ * gsr_forward_begin is to gsr_forward_extra; its handle goes to gsr_forward_finish / _ready / _cancel.
+ */
+typedef struct gsr_raw_params {
+    const float* xyz;
+    const float* log_scales;
+    const float* rotations;
+    const float* opacity_logits;
+    const float* features_dc;
+    const float* features_rest;
+} gsr_raw_params;
+GSR_API int gsr_forward_raw(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_alloc, void* binning_user,
+                            gsr_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background,
+                            int width, int height, const gsr_raw_params* raw, float scale_modifier,
+                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                            float tan_fovy, int prefiltered, float* out_color, float* out_depth, float* out_alpha,
+                            int* radii /*nullable*/, float* out_normal /*[3,H,W], nullable*/, unsigned flags, int debug,
+                            void* stream);
+GSR_API void* gsr_forward_raw_begin(gsr_alloc_fn geom_alloc, void* geom_user, gsr_alloc_fn binning_alloc, void* binning_user,
+                                    gsr_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background,
+                                    int width, int height, const gsr_raw_params* raw, float scale_modifier,
+                                    const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                                    float tan_fovy, int prefiltered, float* out_color, float* out_depth, float* out_alpha,
+                                    int* radii /*nullable*/, float* out_normal /*nullable*/, unsigned flags, int debug,
+                                    void* stream);
+
 /* present[i] = (view-space z of means3D[i]) > 0.2 ; present is a device array of P bytes (bool). */
 GSR_API int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                      uint8_t* present, void* stream);
@@ -231,7 +284,8 @@ GSR_API int gsr_normal_maps(int width, int height, const float* normal_rgb, cons
  *   opacity, SH: copied (already activated / concatenated by the caller once per object; nullable = leave as is)
  *   min_axis   : (nullable) the rotation-matrix column of the smallest activated scale, what render() turns into the
  *                per-Gaussian normal (general_utils.py:78-101 build_rotation, :135-141 get_minimum_axis), from the
- *                normalised quaternion, in that code's operation order
+ *                normalised quaternion, in that code's operation order; on a tie between scales the column torch.argsort
+ *                leaves in front on this GPU (its unstable 32-wide bitonic network: see gsr_forward_raw)
  * placement: 21 host floats -- center c[3], rotation R[9] row-major, scale s, initial_center c0[3], q_R[4] (w,x,y,z),
  * log_s (= (float)log((double)s)).  One streaming kernel: 40 B in + 40 B out per Gaussian (+ 196 B each way with SH).
  */
@@ -302,6 +356,8 @@ typedef enum gsr_geom_slot {
     GSR_GEOM_LISTED,            /* u8[P]    inference calls with deferred colours that were cut into depth slabs: s + 1 when
                                    slab s (the last one that did) put the Gaussian into a list, 0 when none did; such a call
                                    evaluates SH colours for exactly these.  Offset 0 = the call has no such array. */
+    GSR_GEOM_VIEW_NORMALS,      /* f32[3P]  gsr_forward_raw with out_normal: get_normal(dir) * 0.5 + 0.5 of every splat with a
+                                   rectangle (radii > 0 and a tile).  Offset 0 = the call has no such array. */
     GSR_GEOM_NUM_SLOTS
 } gsr_geom_slot;
 

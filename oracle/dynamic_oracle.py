@@ -72,7 +72,9 @@ def transform_raw(xyz, rotation, log_scale, center, R, scaling, initial_center):
 def activate(rotation, log_scale):
     """gaussian_model.py:96-101: scales = exp(raw), rotations = F.normalize(raw) (p = 2, eps = 1e-12)."""
     q = np.asarray(rotation, dtype=f32)
-    norm = np.sqrt(((q[:, 0] * q[:, 0] + q[:, 1] * q[:, 1]) + q[:, 2] * q[:, 2]) + q[:, 3] * q[:, 3]).astype(f32)
+    # the sum of the four squares in the order the framework's reduction kernel takes them on the GPU the reference runs on
+    # (four lanes, combined by shuffles: pairwise; identified on the device, scripts/experiments/torch_op_identify.py)
+    norm = np.sqrt((q[:, 0] * q[:, 0] + q[:, 1] * q[:, 1]) + (q[:, 2] * q[:, 2] + q[:, 3] * q[:, 3])).astype(f32)
     return (q / np.maximum(norm, f32(1e-12))[:, None]).astype(f32), np.exp(np.asarray(log_scale, dtype=f32)).astype(f32)
 
 

@@ -181,7 +181,7 @@ def test_frames_match_the_reference_shaped_composition_and_the_cpu_oracle():
         assert cloud.P == ref_cloud.P
         assert float((cloud.means3D - ref_cloud.means3D).abs().max()) <= 1e-6 * float(ref_cloud.means3D.abs().max()) + 1e-7
         assert torch.equal(cloud.scales, ref_cloud.scales) and torch.equal(cloud.opacities, ref_cloud.opacities)
-        assert float((cloud.rotations - ref_cloud.rotations).abs().max()) <= 2e-7
+        assert torch.equal(cloud.rotations, ref_cloud.rotations)   # F.normalize's own summation order, bit for bit (round 4)
         got = {"color": color.cpu().numpy(), "depth": depth.cpu().numpy(), "alpha": alpha.cpu().numpy()}
         assert_images(f"dynamic_f{fi}_vs_torch", got, {"color": rc.cpu().numpy(), "depth": rd.cpu().numpy(), "alpha": ra.cpu().numpy()})
         assert int((radii != rr).sum()) <= max(1, cloud.P // 20000)

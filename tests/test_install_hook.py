@@ -1,0 +1,141 @@
+"""autovfx_amd.install(): the import hook that puts this package's render() behind an unchanged AutoVFX process, and the
+gate that decides whether a model may be rendered from its raw parameter tensors.  CPU only: nothing here launches a kernel."""
+import importlib
+import os
+import subprocess
+import sys
+import textwrap
+import types
+
+import pytest
+import torch
+
+import autovfx_amd
+from autovfx_amd import hook, renderer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GS = "/root/reference/sugar/gaussian_splatting"
+
+
+@pytest.fixture
+def fake_autovfx(tmp_path, monkeypatch):
+    """A miniature of the reference's package layout: sugar/gaussian_splatting/gaussian_renderer with a render(), and the
+    three import spellings the reference uses for it."""
+    mine = lambda n: n.split(".")[0] in ("sugar", "gaussian_renderer", "scene_representation_like", "gs_model_like")
+    parked = {n: sys.modules.pop(n) for n in [n for n in sys.modules if mine(n)]}   # (other tests stub or import these names)
+    pkg = tmp_path / "sugar" / "gaussian_splatting" / "gaussian_renderer"
+    pkg.mkdir(parents=True)
+    (tmp_path / "sugar" / "__init__.py").write_text("")
+    (tmp_path / "sugar" / "gaussian_splatting" / "__init__.py").write_text("")
+    (pkg / "__init__.py").write_text("def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):\n"
+                                     "    return 'reference'\n\ndef get_ray_directions():\n    return 'kept'\n")
+    (tmp_path / "scene_representation_like.py").write_text("from sugar.gaussian_splatting.gaussian_renderer import render\n")
+    (tmp_path / "gs_model_like.py").write_text("from sugar.gaussian_splatting.gaussian_renderer import render as gs_render\n")
+    monkeypatch.syspath_prepend(str(tmp_path))
+    monkeypatch.syspath_prepend(str(tmp_path / "sugar" / "gaussian_splatting"))   # `from gaussian_renderer import render`
+    yield tmp_path
+    autovfx_amd.uninstall()
+    for name in [n for n in sys.modules if mine(n)]:
+        del sys.modules[name]
+    sys.modules.update(parked)
+
+
+def test_install_before_import_patches_the_renderer(fake_autovfx):
+    autovfx_amd.install()
+    assert sys.path[0] == ROOT
+    caller = importlib.import_module("scene_representation_like")
+    assert caller.render is renderer.render
+    module = sys.modules["sugar.gaussian_splatting.gaussian_renderer"]
+    assert module.render is renderer.render and module.reference_render(None, None, None, None) == "reference"
+    assert module.get_ray_directions() == "kept"
+    short = importlib.import_module("gaussian_renderer")          # the spelling of sugar/gaussian_splatting/train.py:16
+    assert short.render is renderer.render
+    assert hook.patched_modules == ["sugar.gaussian_splatting.gaussian_renderer", "gaussian_renderer"]
+
+
+def test_install_after_import_rebinds_existing_importers(fake_autovfx):
+    a = importlib.import_module("scene_representation_like")
+    b = importlib.import_module("gs_model_like")
+    assert a.render(None, None, None, None) == "reference"
+    autovfx_amd.install()
+    autovfx_amd.install()   # idempotent
+    assert a.render is renderer.render and b.gs_render is renderer.render
+    assert sum(1 for f in sys.meta_path if isinstance(f, hook._RendererHook)) == 1
+    autovfx_amd.uninstall()
+    assert sys.modules["sugar.gaussian_splatting.gaussian_renderer"].render(None, None, None, None) == "reference"
+    assert not any(isinstance(f, hook._RendererHook) for f in sys.meta_path)
+
+
+def test_install_refuses_a_foreign_rasterizer_already_imported(fake_autovfx, monkeypatch):
+    foreign = types.ModuleType("diff_gaussian_rasterization")
+    foreign.__file__ = "/somewhere/site-packages/diff_gaussian_rasterization/__init__.py"
+    monkeypatch.setitem(sys.modules, "diff_gaussian_rasterization", foreign)
+    with pytest.raises(RuntimeError, match="already imported"):
+        autovfx_amd.install()
+
+
+def test_sitecustomize_opt_in(fake_autovfx):
+    """AUTOVFX_AMD_INSTALL=1 with integration/ on PYTHONPATH installs the hook at interpreter start without importing torch;
+    without the variable nothing happens."""
+    code = textwrap.dedent("""
+        import sys
+        early = 'torch' in sys.modules
+        from sugar.gaussian_splatting.gaussian_renderer import render
+        print(render.__module__, early)
+    """)
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "integration"), ROOT, str(fake_autovfx)]))
+    env.pop("AUTOVFX_AMD_INSTALL", None)
+    off = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert off.returncode == 0 and off.stdout.split() == ["sugar.gaussian_splatting.gaussian_renderer", "False"], off.stderr
+    on = subprocess.run([sys.executable, "-c", code], env=dict(env, AUTOVFX_AMD_INSTALL="1"), capture_output=True, text=True, timeout=300)
+    assert on.returncode == 0 and on.stdout.split() == ["autovfx_amd.renderer", "False"], on.stderr
+
+
+class _Model:
+    def __init__(self, P=5, M=16, device="cpu"):
+        self._xyz = torch.zeros(P, 3, device=device)
+        self._scaling = torch.zeros(P, 3, device=device)
+        self._rotation = torch.ones(P, 4, device=device)
+        self._opacity = torch.zeros(P, 1, device=device)
+        self._features_dc = torch.zeros(P, 1, 3, device=device)
+        self._features_rest = torch.zeros(P, M - 1, 3, device=device)
+
+
+def test_raw_parameter_gate(monkeypatch):
+    m = _Model()
+    assert renderer.raw_parameters(m) is None                      # CPU tensors: there is no CPU path
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))   # pretend: only the gate's logic runs
+    assert renderer.raw_parameters(m) is not None and len(renderer.raw_parameters(m)) == 6
+    for attr, fn in renderer._RAW_ACTIVATIONS:                     # the reference keeps its activations as attributes
+        setattr(m, attr, fn)
+    assert renderer.raw_parameters(m) is not None
+    m.opacity_activation = torch.tanh
+    assert renderer.raw_parameters(m) is None
+    m.opacity_activation = torch.sigmoid
+    m.gsr_raw_parameters = False
+    assert renderer.raw_parameters(m) is None
+    del m.gsr_raw_parameters
+    m._features_dc = m._features_dc.reshape(-1, 3)
+    assert renderer.raw_parameters(m) is None
+    m = _Model()
+    m._scaling = m._scaling.double()
+    assert renderer.raw_parameters(m) is None
+    m = _Model()
+    del m._features_rest
+    assert renderer.raw_parameters(m) is None
+    assert renderer.raw_parameters(_Model(M=1)) is not None        # degree 0 only: an empty [P,0,3] rest tensor
+
+
+@pytest.mark.skipif(not os.path.isdir(GS), reason="reference tree not mounted")
+def test_the_references_own_gaussian_model_passes_the_gate(monkeypatch):
+    """The class AutoVFX instantiates (scene/gaussian_model.py), imported unchanged: its attribute names, shapes and
+    activation functions are what raw_parameters() looks for."""
+    from test_render_mirror import _import_reference
+    ref = _import_reference("scene.gaussian_model")
+    r = ref.GaussianModel(3)
+    src = _Model(P=7)
+    for k, v in vars(src).items():
+        setattr(r, k, v)
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))
+    got = renderer.raw_parameters(r)
+    assert got is not None and got[0] is r._xyz and got[5] is r._features_rest
