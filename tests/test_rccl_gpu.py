@@ -51,3 +51,18 @@ def test_one_rank_rccl_job_with_cloud_broadcast_and_uneven_pieces():
     assert dist["config"]["gather"]["gathered_shape"] == [1, 33, 4, 540, 960]
     assert dist["frames_digest"] == plain["frames_digest"]
     assert dist["frames_digest"]["shape"] == [33, 4, 540, 960]
+
+
+def test_gpus_2_as_typed_without_a_launcher():
+    """``python bench.py --gpus 2`` with nothing around it: bench.py starts its own two ranks (one per GPU) over RCCL and rank 0
+    prints the line.  Needs two GPUs; on a one-GPU box the same chain is covered with gloo by tests/test_bench_launch.py."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU here: the self-launch chain is covered on CPU (tests/test_bench_launch.py)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", *COMMON], capture_output=True,
+                       text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and len(line["per_rank_frames_per_s"]) == 2
+    assert line["config"]["gather"]["gathered_shape"] == [2, 8, 4, 540, 960]
