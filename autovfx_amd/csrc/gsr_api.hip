@@ -48,9 +48,9 @@ constexpr int kHeadEvents = 4, kSlabEvents = 5;
 constexpr int kEventsPerCall = kHeadEvents + kSlabEvents * gsr::kMaxSlabs;
 int g_options[GSR_OPT_NUM] = {/*GSR_OPT_TILE_CULL*/ 1, /*GSR_OPT_SLABS*/ 2, /*GSR_OPT_SLAB_FIRST*/ 400,
                               /*GSR_OPT_DEFER_COLOUR*/ 1, /*GSR_OPT_SLAB_MIN_REST*/ 3000000,
-                              /*GSR_OPT_RADIX_RANK (kept by gsr_radix.hip)*/ 2, /*GSR_OPT_RADIX_RANK_ACTIVE (read-only)*/ 0,
+                              /*GSR_OPT_RADIX_RANK (kept by gsr_radix.hip)*/ 0, /*GSR_OPT_RADIX_RANK_ACTIVE (read-only)*/ 0,
                               /*GSR_OPT_DEPTH_DROP*/ 1, /*GSR_OPT_BLEND_ORDER*/ 1};
-bool g_timing = false;
+std::atomic<bool> g_timing{false};
 std::atomic<long> g_timing_epoch{0};       // bumped by gsr_set_stage_timing: every thread restarts its record at its next call
 thread_local long g_epoch_seen = -1;
 thread_local hipEvent_t g_ev[kTimingRing][kEventsPerCall];
@@ -68,7 +68,9 @@ constexpr int kBackwardRing = 64;
 std::mutex g_bw_mutex;
 hipEvent_t g_bw_ev[kBackwardRing][3];
 bool g_bw_made = false;
-long g_bw_calls = 0;
+bool g_bw_done[kBackwardRing];   // the slot's three events have all been recorded
+long g_bw_begun = 0;             // timed backward calls begun since timing was (re)enabled: each reserves its own slot
+long g_bw_calls = 0;             // ... and completed
 
 int fail(gsr_status code, const char* fmt, ...) {
     va_list ap;
@@ -190,6 +192,8 @@ void gsr_set_stage_timing(int enable) {
     {
         std::lock_guard<std::mutex> lock(g_bw_mutex);
         g_bw_calls = 0;
+        g_bw_begun = 0;
+        for (bool& d : g_bw_done) d = false;
     }
     g_timing = enable != 0;
     g_timing_epoch.fetch_add(1);   // other threads drop their records when they next begin a call
@@ -263,18 +267,22 @@ int gsr_get_call_times(float* ms, int capacity) {
 int gsr_get_backward_times(float ms[2]) {
     ms[0] = ms[1] = 0.f;
     std::lock_guard<std::mutex> lock(g_bw_mutex);
-    const int n = (int)(g_bw_calls < kBackwardRing ? g_bw_calls : kBackwardRing);
-    if (n <= 0) return 0;
+    const long span = g_bw_begun < kBackwardRing ? g_bw_begun : kBackwardRing;
+    if (g_bw_calls <= 0 || span <= 0) return 0;
     double sum[2] = {0, 0};
-    for (int c = 0; c < n; ++c) {
-        const int slot = (int)((g_bw_calls - 1 - c) % kBackwardRing);
+    int n = 0;
+    for (long c = 0; c < span; ++c) {   // slots are reserved per call: one begun on another thread and not yet complete is skipped
+        const int slot = (int)((g_bw_begun - 1 - c) % kBackwardRing);
+        if (!g_bw_done[slot]) continue;
         GSR_HIP(hipEventSynchronize(g_bw_ev[slot][2]));
         for (int i = 0; i < 2; ++i) {
             float t = 0.f;
             GSR_HIP(hipEventElapsedTime(&t, g_bw_ev[slot][i], g_bw_ev[slot][i + 1]));
             sum[i] += t;
         }
+        ++n;
     }
+    if (n == 0) return 0;
     ms[0] = (float)(sum[0] / n);
     ms[1] = (float)(sum[1] / n);
     return n;
@@ -388,7 +396,8 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
                 for (auto& e : set) GSR_HIP(hipEventCreate(&e));
             g_bw_made = true;
         }
-        bw_slot = (int)(g_bw_calls % kBackwardRing);
+        bw_slot = (int)(g_bw_begun++ % kBackwardRing);   // reserved here, under the lock: concurrent calls never share events
+        g_bw_done[bw_slot] = false;
         GSR_HIP(hipEventRecord(g_bw_ev[bw_slot][0], stream));
     }
     GSR_HIP(hipMemsetAsync(accum_scratch, 0, (size_t)P * 16 * sizeof(float), stream));
@@ -407,7 +416,8 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     if (bw_slot >= 0) {
         GSR_HIP(hipEventRecord(g_bw_ev[bw_slot][2], stream));
         std::lock_guard<std::mutex> lock(g_bw_mutex);
-        ++g_bw_calls;   // (concurrent backward calls on several threads would share slots: timing is a single-caller aid)
+        g_bw_done[bw_slot] = true;
+        ++g_bw_calls;
     }
     return GSR_OK;
 }
@@ -550,7 +560,7 @@ namespace {
 struct ForwardCall {
     hipStream_t stream = nullptr;
     int debug = 0, prefiltered = 0, P = 0, T = 0, width = 0, height = 0, slot = 0;
-    bool queued = false, timed = false, inference = false, defer_colour = false;
+    bool queued = false, device_work = false, timed = false, inference = false, defer_colour = false;
     gsr::Camera cam;
     gsr::GaussianInputs in;
     gsr::GeometryArrays ga;
@@ -577,8 +587,12 @@ struct ForwardCall {
     ~ForwardCall() {
         if (timed && g_inflight > 0) --g_inflight;  // (a call that never finished leaves g_ev_slabs[slot] == 0: readers skip it)
         if (!pinned.host) return;
-        if (queued) (void)hipEventSynchronize(pinned.copied);  // the copy may still be landing in the buffer
-        g_pinned_free.push_back(pinned);
+        // Only reached with a slot when the call did not complete (cancelled, or failed part way).  Kernels already queued
+        // on the stream may still store into the slot (the totals; the slab table written by bin_offsets / slab_compact):
+        // it goes back to the free list only after an event behind everything queued so far has completed -- no host wait.
+        if ((queued || device_work) && hipEventRecord(pinned.finished, stream) == hipSuccess) g_pinned_draining.push_back(pinned);
+        else if (!(queued || device_work)) g_pinned_free.push_back(pinned);
+        // (an event that cannot be recorded means the device is gone: the few KB of pinned memory are abandoned)
     }
 };
 
@@ -687,7 +701,7 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     // be in flight on ANOTHER stream (several streams fed by one thread), and a new call on this stream must neither
     // share that host buffer nor re-record that event.
     for (size_t i = 0; i < g_pinned_draining.size();) {
-        if (hipEventQuery(g_pinned_draining[i].finished) != hipErrorNotReady) {
+        if (hipEventQuery(g_pinned_draining[i].finished) == hipSuccess) {   // (an error is not "complete": the slot stays parked)
             g_pinned_free.push_back(g_pinned_draining[i]);
             g_pinned_draining[i] = g_pinned_draining.back();
             g_pinned_draining.pop_back();
@@ -828,6 +842,7 @@ int forward_finish(ForwardCall& fc) {
 
     GSR_HIP(hipEventSynchronize(fc.pinned.copied));
     fc.queued = false;
+    fc.device_work = true;   // from here on kernels that store into the pinned slot may be in flight until `finished`
     const gsr::FrameCounters* hc = reinterpret_cast<const gsr::FrameCounters*>(fc.pinned.host);  // first kCounterBytes only
     const uint32_t flag = hc->error_flag;
     unsigned long long rect_total = 0, live_total = 0, emitting = 0, pool_rows = 0;

@@ -10,6 +10,21 @@
 // (2.90 vs 2.62 ms on MI355X).
 #include "gsr_device.h"
 
+// Census of render_backward_kernel's inner loop (python -m autovfx_amd.build --trace, scripts/backward_census.py): how many
+// (quadrant, list entry) iterations reach each stage and how many of the 64 lanes contribute.  Compiled out of the normal
+// library.  Words: 0 waves that walk a list, 1 staged batches, 2 entries past the quadrant reach test, 3 with a live pixel,
+// 4 with a contributing pixel, 5 sum of contributing lanes, 6..11 entries by contributing lanes (1-2, 3-4, 5-8, 9-16, 17-32,
+// 33-64), 12 sum of live lanes.
+#ifdef GSR_KERNEL_TRACE
+__device__ unsigned long long* g_backward_census = nullptr;
+extern "C" __attribute__((visibility("default"))) int gsr_debug_set_backward_census(void* device_words) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_backward_census), &device_words, sizeof device_words);
+}
+#define GSR_BCENSUS(stmt) do { stmt; } while (0)
+#else
+#define GSR_BCENSUS(stmt) do { } while (0)
+#endif
+
 namespace gsr {
 namespace {
 
@@ -56,7 +71,8 @@ __device__ __forceinline__ float row_sum_all_lanes(float v) {  // every lane of 
     return v;
 }
 constexpr int kAccumStride = 16;  // floats per Gaussian in the accumulation scratch: one 64-byte line
-// slots: 0 r, 1 g, 2 b, 3 depth, 4 mean x, 5 mean y, 6 conic xx, 7 conic xy, 8 conic yy, 9 opacity
+// slots: 0 r, 1 g, 2 b, 3 depth, 4 S_u, 5 S_v, 6 S_{u dx}, 7 S_{u dy}, 8 S_{v dy} (u = dL_dG G dx, v = dL_dG G dy: the factored
+// sums behind dL_dmean2D and dL_dconic, finished per Gaussian by preprocess_backward_lane), 9 opacity
 
 __global__ void __launch_bounds__(64, 4) render_backward_kernel(
     int W, int H, int grid_x, int num_tiles, const uint2* __restrict__ ranges,
@@ -108,10 +124,11 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
     if (walk == 0) return;
 
     const unsigned long long inside_mask = __ballot(inside);
-    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_a = 0.f;  // accum_rec / accum_red / accum_rea
-    float last_alpha = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f, last_depth = 0.f;
+#ifdef GSR_KERNEL_TRACE
+    unsigned long long cz[13] = {1ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+#endif
+    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_a = 0.f;  // accum_rec / accum_red / accum_rea, updated eagerly
     const float bg_dot = (background[0] * dLr + background[1] * dLg) + background[2] * dLb;  // left to right
-    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
 
     // back to front: batches of 64 positions, highest first
     for (uint32_t top = walk; top > 0; top = top > 64 ? top - 64 : 0) {
@@ -135,6 +152,7 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
         }
         unsigned long long todo = __ballot(mine && splat_reaches_rect(g_co, g_skip, g_xy, qx0, qy0, kQ, kQ));
         if (todo == 0ull) continue;
+        GSR_BCENSUS(cz[1] += 1ull; cz[2] += (unsigned long long)__popcll(todo));
         __syncthreads();
         {
             float4* rec = reinterpret_cast<float4*>(&s_entry[lane]);
@@ -160,63 +178,71 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
             const unsigned long long live = __ballot(pos < last_contributor) & __ballot(!(power > 0.0f)) &
                                             __ballot(!(power < b.skip_below)) & inside_mask;
             if (live == 0ull) continue;
+            GSR_BCENSUS(cz[3] += 1ull; cz[12] += (unsigned long long)__popcll(live));
             const float G = exp_nonpositive(power);  // == expf on the contributing lanes' domain (power <= 0)
             const float alpha = fminf(0.99f, b.opacity * G);
             const unsigned long long contrib = live & __ballot(!(alpha < 1.0f / 255.0f));
             if (contrib == 0ull) continue;
-            const float4 cz = rec[2];  // r g b depth
-            struct { float r, g, b, opacity; } c = {cz.x, cz.y, cz.z, b.opacity};
-            const float z = cz.w;
-            float g_cr = 0.f, g_cg = 0.f, g_cb = 0.f, g_dep = 0.f, g_mx = 0.f, g_my = 0.f, g_kx = 0.f, g_ky = 0.f,
-                  g_kw = 0.f, g_op = 0.f;
-            if (__builtin_amdgcn_inverse_ballot_w64(contrib)) {
+            GSR_BCENSUS(const int n_ = __popcll(contrib); cz[4] += 1ull; cz[5] += (unsigned long long)n_;
+                        cz[n_ <= 2 ? 6 : n_ <= 4 ? 7 : n_ <= 8 ? 8 : n_ <= 16 ? 9 : n_ <= 32 ? 10 : 11] += 1ull);
+            const float4 cd = rec[2];  // r g b depth
+            struct { float r, g, b, opacity; } c = {cd.x, cd.y, cd.z, b.opacity};
+            const float z = cd.w;
+            // The gradient block runs on ALL 64 lanes with alpha = G = 0 on the lanes that do not contribute to this entry:
+            // with the accumulators updated eagerly (acc <- alpha c + (1 - alpha) acc right after use: the value the reference's
+            // lazy `last_alpha * last_color + (1 - last_alpha) * accum_rec` (backward.cu:516-522) takes at the next contributing
+            // entry, same operands, same roundings) every state update is the identity for alpha = 0 -- T * rcp(1) = T,
+            // 0 c + 1 acc = acc -- and all ten partial sums come out as exact zeros.  No exec mask, no zero-fill of the sums,
+            // no last_* registers (round 3: 10 + 5 moves per entry of a 68-instruction block).
+            const bool contributes = __builtin_amdgcn_inverse_ballot_w64(contrib);
+            const float alpha_m = contributes ? alpha : 0.f, G_m = contributes ? G : 0.f;
+            float g_cr, g_cg, g_cb, g_dep, g_sx, g_sy, g_kxx, g_kxy, g_kyy, g_op;
+            {
                 // Products feeding sums are fused in this block (as nvcc does for the reference): it only forms
                 // gradients, which are stated with a tolerance; alpha, T and the contributor tests above are not in it.
 #pragma clang fp contract(fast)
                 // One reciprocal serves the two divisions by (1 - alpha) (backward.cu:506,548).  Gradients are sums
                 // over atomics whose order is not the reference's anyway; the tolerance of the parity tests covers
                 // the 1-ulp difference between x * rcp(y) and x / y.
-                const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                const float one_m = 1.f - alpha_m;
+                const float inv_1ma = __builtin_amdgcn_rcpf(one_m);
                 T = T * inv_1ma;
-                const float dchannel_dcolor = alpha * T;
-                float dL_dalpha = 0.0f;
-                acc_r = last_alpha * last_r + (1.f - last_alpha) * acc_r;
-                last_r = c.r;
-                dL_dalpha += (c.r - acc_r) * dLr;
-                g_cr = dchannel_dcolor * dLr;
-                acc_g = last_alpha * last_g + (1.f - last_alpha) * acc_g;
-                last_g = c.g;
+                const float dchannel_dcolor = alpha_m * T;
+                float dL_dalpha = (c.r - acc_r) * dLr;
                 dL_dalpha += (c.g - acc_g) * dLg;
-                g_cg = dchannel_dcolor * dLg;
-                acc_b = last_alpha * last_b + (1.f - last_alpha) * acc_b;
-                last_b = c.b;
                 dL_dalpha += (c.b - acc_b) * dLb;
-                g_cb = dchannel_dcolor * dLb;
-                acc_d = last_alpha * last_depth + (1.f - last_alpha) * acc_d;
-                last_depth = z;
                 dL_dalpha += (z - acc_d) * dLd;
-                g_dep = dchannel_dcolor * dLd;
-                acc_a = last_alpha + (1.f - last_alpha) * acc_a;
                 dL_dalpha += (1.f - acc_a) * dLa;
+                g_cr = dchannel_dcolor * dLr;
+                g_cg = dchannel_dcolor * dLg;
+                g_cb = dchannel_dcolor * dLb;
+                g_dep = dchannel_dcolor * dLd;
+                acc_r = alpha_m * c.r + one_m * acc_r;
+                acc_g = alpha_m * c.g + one_m * acc_g;
+                acc_b = alpha_m * c.b + one_m * acc_b;
+                acc_d = alpha_m * z + one_m * acc_d;
+                acc_a = alpha_m + one_m * acc_a;
                 dL_dalpha *= T;
-                last_alpha = alpha;
                 dL_dalpha += (-T_final * inv_1ma) * bg_dot;
                 const float dL_dG = c.opacity * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * a.cxx - gdy * a.cxy;
-                const float dG_ddely = -gdy * b.cyy - gdx * a.cxy;
-                g_mx = dL_dG * dG_ddelx * ddelx_dx;
-                g_my = dL_dG * dG_ddely * ddely_dy;
-                g_kx = -0.5f * gdx * dx * dL_dG;
-                g_ky = -0.5f * gdx * dy * dL_dG;
-                g_kw = -0.5f * gdy * dy * dL_dG;
-                g_op = G * dL_dalpha;
+                // The conic is the same for every pixel of the entry, so the sums over pixels of the mean2D and conic gradients
+                // (backward.cu:563-581) factor: with u = dL_dG G dx, v = dL_dG G dy,
+                //   dL_dmean2D = -(W/2) (cxx S_u + cxy S_v), -(H/2) (cyy S_v + cxy S_u);  dL_dconic = -1/2 (S_{u dx}, S_{u dy}, S_{v dy}).
+                // The five sums are formed here (5 multiplies instead of 17 instructions per lane); the per-Gaussian pass, which
+                // recomputes the forward's conic anyway, finishes them.
+                const float u = dL_dG * (G_m * dx), v = dL_dG * (G_m * dy);
+                g_sx = u;
+                g_sy = v;
+                g_kxx = u * dx;
+                g_kxy = u * dy;
+                g_kyy = v * dy;
+                g_op = G_m * dL_dalpha;
             }
-            // r|g, b|depth, mx|my, kxx|kxy, kyy|opacity -> rows [r b g depth], [mx kxx my kxy], [kyy - opacity -]
+            // r|g, b|depth, su|sv, kxx|kxy, kyy|opacity -> rows [r b g depth], [su kxx sv kxy], [kyy - opacity -]
             float x0 = row_sum_all_lanes(fold16(fold32(g_cr, g_cg), fold32(g_cb, g_dep)));
-            float x1 = row_sum_all_lanes(fold16(fold32(g_mx, g_my), fold32(g_kx, g_ky)));
+            float x1 = row_sum_all_lanes(fold16(fold32(g_sx, g_sy), fold32(g_kxx, g_kxy)));
             asm volatile("" : "+v"(x0), "+v"(x1));
-            float x2 = row_sum_all_lanes(fold16(fold32(g_kw, g_op), 0.f));
+            float x2 = row_sum_all_lanes(fold16(fold32(g_kyy, g_op), 0.f));
             // keep the last row-rotate add out here, where it is one DPP instruction per value (sunk into the branch
             // below it becomes a zero-fill, a DPP move and an add)
             asm volatile("" : "+v"(x2));
@@ -226,6 +252,11 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
             }
         }
     }
+#ifdef GSR_KERNEL_TRACE
+    if (lane == 0 && g_backward_census != nullptr)
+        for (int i = 0; i < 13; ++i)
+            if (cz[i] != 0ull) atomicAdd(g_backward_census + i, cz[i]);
+#endif
 }
 
 // auxiliary.h:103-114
@@ -353,11 +384,10 @@ __device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, 
     const float4 s0 = line[0], s1 = line[1];
     const float2 s2 = *reinterpret_cast<const float2*>(line + 2);
     const float dLc_r = s0.x, dLc_g = s0.y, dLc_b = s0.z, gdep = s0.w;
-    const float g2x = s1.x, g2y = s1.y;
-    const float dLcx = s1.z, dLcy = s1.w, dLcz = s2.x;
+    const float S_u = s1.x, S_v = s1.y;
+    const float dLcx = -0.5f * s1.z, dLcy = -0.5f * s1.w, dLcz = -0.5f * s2.x;   // backward.cu:577-581, the -1/2 taken out of the sums
     *reinterpret_cast<F3*>(g.dL_dcolor + 3 * (size_t)idx) = F3{dLc_r, dLc_g, dLc_b};
     g.dL_ddepth[idx] = gdep;
-    *reinterpret_cast<F3*>(g.dL_dmean2D + 3 * (size_t)idx) = F3{g2x, g2y, 0.f};            // z is never used (backward.cu)
     *reinterpret_cast<F4*>(g.dL_dconic + 4 * (size_t)idx) = F4{dLcx, dLcy, 0.f, dLcz};   // 2x2 with one unused slot
     g.dL_dopacity[idx] = s2.y;
 
@@ -410,6 +440,16 @@ __device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, 
 #define WG(c, r) Wm.m[r][c]
     const float a = cov.m[0][0] + 0.3f, b = cov.m[1][0], c_ = cov.m[1][1] + 0.3f;
     const float denom = a * c_ - b * b;
+    // dL_dmean2D from the factored sums and the forward's conic (forward.cu:219-223, recomputed with its arithmetic):
+    // dG/d(delx) = -G dx cxx - G dy cxy, d(delx)/dx = W / 2 (backward.cu:563-571)
+    float g2x, g2y;
+    {
+        const float det_inv = 1.f / denom;
+        const float cxx = c_ * det_inv, cxy = -b * det_inv, cyy = a * det_inv;
+        g2x = -(float)(0.5 * cam.width) * (cxx * S_u + cxy * S_v);
+        g2y = -(float)(0.5 * cam.height) * (cyy * S_v + cxy * S_u);
+    }
+    *reinterpret_cast<F3*>(g.dL_dmean2D + 3 * (size_t)idx) = F3{g2x, g2y, 0.f};            // z is never used (backward.cu)
     float dL_da = 0, dL_db = 0, dL_dc = 0;
     const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
     float dcov[6];

@@ -361,16 +361,22 @@ hipError_t launch_lds_atomic_order_selftest(uint32_t workgroups, uint32_t rounds
 }
 
 // ------------------------------------------------------------------------------------------------
-// Which in-wave rank the scatter kernel uses on the current device.  g_rank_request: 0 ballots, 1 LDS atomics without
-// asking, 2 (default) LDS atomics on a device that passed the lane-order self-test, ballots elsewhere.  The self-test
-// runs ONCE per device and process, on the first sort (or the first query): 512 workgroups x 4 waves x 192 instructions
-// of every conflict density (~0.4 M instructions, 25 M lane results; well under a millisecond), on its own small
-// allocation, with the calling stream drained before and after -- a one-time cost at the first call on a device.
+// Which in-wave rank the scatter kernel uses on the current device.  g_rank_request: 0 (DEFAULT since round 4) ballots --
+// correct by the ISA alone; 1 LDS atomics without asking; 2 LDS atomics on a device that passed the lane-order self-test,
+// ballots elsewhere.  The atomics are ~25 % faster per pass (1.4 % of a C3 frame) but lean on a hardware behaviour no manual
+// promises (lanes of one instruction that hit the same LDS counter are served in ascending lane order); a statistical
+// self-test on an idle device cannot prove it under contention, so it is an opt-in, not the default.
+// With request 2 the self-test runs once per device and process, on the first sort (or the first query) after the request:
+// 512 workgroups x 4 waves x 192 instructions of every conflict density (~0.4 M instructions, 25 M lane results; well under a
+// millisecond), on its own small allocation, and SYNCHRONISES the calling stream once (hipMalloc / hipFree /
+// hipStreamSynchronize under a process-wide mutex: not legal during stream capture -- make the first call outside one, or
+// query GSR_OPT_RADIX_RANK_ACTIVE at start-up).  A test that could not run (e.g. out of memory) is not remembered: the sort
+// uses ballots this time and the next sort tries again.
 // ------------------------------------------------------------------------------------------------
 namespace {
 constexpr int kMaxDevices = 64;
 std::mutex g_rank_mutex;
-int g_rank_request = 2;
+int g_rank_request = 0;
 int g_rank_verdict[kMaxDevices];      // 0 not tested yet, 1 passed (atomics), 2 failed (ballots), 3 could not be tested (ballots)
 unsigned long long g_rank_violations[kMaxDevices];
 
@@ -408,9 +414,13 @@ int radix_rank_mode(hipStream_t stream, unsigned long long* violations) {
     if (g_rank_request == 1) return 1;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 0;
-    if (g_rank_verdict[dev] == 0) g_rank_verdict[dev] = test_device_locked(dev, stream);
+    int verdict = g_rank_verdict[dev];
+    if (verdict == 0) {
+        verdict = test_device_locked(dev, stream);
+        if (verdict != 3) g_rank_verdict[dev] = verdict;   // (3 = could not be tested: ballots now, another try at the next sort)
+    }
     if (violations) *violations = g_rank_violations[dev];
-    return g_rank_verdict[dev] == 1 ? 1 : 0;
+    return verdict == 1 ? 1 : 0;
 }
 
 size_t radix_scratch_words(uint32_t n) {

@@ -12,6 +12,14 @@ once, and per frame one kernel per placed object (``gsr_place_object``, include/
 object's Gaussians at its offset.  A frame's cloud is a prefix view of the buffers -- base first, then the objects placed
 in that frame, in placement order, exactly the concatenation order of the reference -- handed to the rasterizer as is.
 The arithmetic is the reference's, operation by operation (``oracle/dynamic_oracle.py`` restates it; tests compare).
+
+SH degree of a composed frame.  The reference renders every frame that has at least one placed object with DC-only colour:
+``merge_two_gaussians`` returns a FRESH ``GaussianModel`` (``gaussians_utils.py:75``) whose ``active_sh_degree`` is the
+constructor's 0 (``scene/gaussian_model.py:49``) -- nothing ever raises it -- and ``render()`` hands ``pc.active_sh_degree`` to
+the rasterizer (``gaussian_renderer/__init__.py:111``); a frame without placements renders the deep-copied scene at its full
+degree.  ``DynamicScene`` reproduces that by default (``placed_sh_degree=0``: the reference's frames, colour pop included);
+``placed_sh_degree=None`` renders every frame at the base model's degree -- what one would expect, and a deliberate deviation
+from upstream.
 """
 from __future__ import annotations
 
@@ -92,7 +100,7 @@ class DynamicScene:
     that renders it, so a frame's objects are never overwritten while an earlier frame on another stream still reads them."""
 
     def __init__(self, base, objects: Dict[str, Tuple[object, Sequence[float]]], device="cuda:0", sh_degree: Optional[int] = None,
-                 slots: int = 1):
+                 slots: int = 1, placed_sh_degree: Optional[int] = 0):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("DynamicScene places objects with a HIP kernel: it needs a GPU (there is no CPU fallback)")
@@ -106,6 +114,8 @@ class DynamicScene:
                 raise ValueError(f"object {k!r} has {int(o.shs.shape[1])} SH coefficients, the scene {M}")
         new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=self.device)
         self.sh_degree = int(sh_degree if sh_degree is not None else getattr(base, "active_sh_degree", 3))
+        # degree of a frame WITH placed objects: 0 = what the reference's merged model carries (module docstring); None = as the base
+        self.placed_sh_degree = None if placed_sh_degree is None else int(placed_sh_degree)
         self.capacity, self.M = cap, M
         self._slots = []
         with torch.no_grad():   # the base part, once: the activations render() would redo every frame (gaussian_model.py:95-128)
@@ -130,6 +140,7 @@ class DynamicScene:
         from . import _lib
         means3D, scales, rotations, opacities, shs, min_axis = self._slots[slot % len(self._slots)]
         at = self.P_base
+        placements = list(placements)
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         with torch.cuda.device(self.device):
             for obj_id, center, rotation, scaling in placements:
@@ -145,7 +156,8 @@ class DynamicScene:
                     raise RuntimeError(f"gsr_place_object failed ({rc}): {_lib.last_error()}")
                 at += o.P
         self._last_min_axis = min_axis[:at]
-        return GaussianCloud(means3D[:at], opacities[:at], scales[:at], rotations[:at], shs[:at], None, self.sh_degree)
+        degree = self.sh_degree if (not placements or self.placed_sh_degree is None) else self.placed_sh_degree
+        return GaussianCloud(means3D[:at], opacities[:at], scales[:at], rotations[:at], shs[:at], None, degree)
 
     def compose_model(self, placements, slot: int = 0) -> FrameModel:
         """``compose`` for callers of ``render()`` (``autovfx_amd.renderer.render`` or the reference's own): the frame as an

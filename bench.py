@@ -901,7 +901,9 @@ def dynamic_scene_bench(device, side, S, frames=120):
         return sorted(secs)[1] / frames * 1e3
 
     out = {"workload": "C2 scene (1 M Gaussians, 960x540) + 2 inserted objects of 60 k Gaussians, each moved rigidly every frame",
-           "frames": frames, "P_frame": static_cloud.P}
+           "frames": frames, "P_frame": static_cloud.P,
+           "sh_degree_of_frames_with_objects": static_cloud.sh_degree,   # 0: what the reference's merged model renders at (round 4)
+           }
     out["static_ms_per_frame"] = round(timed(lambda: serial(lambda f: static_cloud)), 4)
     out["ms_per_frame"] = round(timed(lambda: serial(lambda f: scene.compose(place(f)))), 4)
     out["reference_shaped_ms_per_frame"] = round(timed(lambda: serial(lambda f: reference_shaped_compose(base, objs, place(f), device))), 4)

@@ -412,12 +412,15 @@ typedef enum gsr_option {
      * further slab costs a fixed dozen of small launches, what it saves grows with the pairs it can drop.  (At
      * 960x540 with 1 M Gaussians and ~2 M live pairs slabs lose 13 %; with 6 - 18 M live pairs they gain 5 - 60 %.) */
     GSR_OPT_SLAB_MIN_REST = 4,
-    /* [2] How the radix sort ranks the keys of a wave (gsr_radix.hip).  0: ballots -- relies on nothing but the ISA.
-     * 1: one returning LDS add per key, unconditionally -- correct only where lanes of one instruction that hit the same
-     * LDS counter are served in ascending lane order, which gfx950 does and no manual promises.  2 (default): the first
-     * sort on each device runs gsr_selftest_lds_atomic_order's kernel (~0.4 M instructions of every conflict density,
-     * once per device and process) and uses the LDS adds on that device only if it counted zero violations, ballots
-     * otherwise.  Both forms produce the same stable sort; the LDS adds are ~25 % faster per pass. */
+    /* [0] How the radix sort ranks the keys of a wave (gsr_radix.hip).  0 (default since ABI 9): ballots -- relies on nothing
+     * but the ISA.  1: one returning LDS add per key, unconditionally -- correct only where lanes of one instruction that hit
+     * the same LDS counter are served in ascending lane order, which gfx950 is observed to do and no manual promises.  2: the
+     * first sort on each device after the request runs gsr_selftest_lds_atomic_order's kernel (~0.4 M instructions of every
+     * conflict density) and uses the LDS adds on that device only if it counted zero violations, ballots otherwise; that first
+     * sort allocates, frees and synchronises its stream once under a process-wide lock (do it outside stream capture; a test
+     * that could not run is retried by the next sort).  All forms produce the same stable sort; the LDS adds are ~25 % faster
+     * per pass, ~1.4 % of a 3 M-Gaussian frame: an opt-in, because an idle-device self-test cannot prove lane order under
+     * contention. */
     GSR_OPT_RADIX_RANK = 5,
     /* read-only: what sorts queued on the CURRENT device use -- 1 LDS adds, 0 ballots (runs the self-test if this
      * device has not been tested yet and the request is 2).  gsr_set_option rejects it. */

@@ -85,7 +85,7 @@ def placement_block(center, R, scaling, initial_center) -> np.ndarray:
                            matrix_to_quaternion(R), [f32(np.log(np.float64(scaling)))])).astype(f32)
 
 
-def compose(base, placements):
+def compose(base, placements, base_sh_degree=3):
     """``base`` and every placed object: dicts of RAW arrays ``xyz, rotation, log_scale, opacity_raw, features_dc,
     features_rest``; ``placements``: list of ``(object, center, R, scaling, initial_center)`` in merge order.  Returns the
     ACTIVATED arrays the rasterizer receives from the merged model: means3D, scales, rotations, opacities [P,1], shs [P,M,3]."""
@@ -98,5 +98,9 @@ def compose(base, placements):
     cat = {k: np.concatenate(v, axis=0) for k, v in parts.items()}
     rot, scales = activate(cat["rotation"], cat["log_scale"])
     opac = (f32(1.0) / (f32(1.0) + np.exp(-cat["opacity_raw"]))).astype(f32)
+    # The degree the reference renders this frame at: merge_two_gaussians builds a fresh GaussianModel (gaussians_utils.py:75)
+    # whose active_sh_degree stays the constructor's 0 (scene/gaussian_model.py:49), and render() passes pc.active_sh_degree
+    # (gaussian_renderer/__init__.py:111); without a placement the deep-copied scene keeps `base_sh_degree`.
     return {"means3D": cat["xyz"], "scales": scales, "rotations": rot, "opacities": opac.reshape(-1, 1),
-            "shs": np.concatenate((cat["features_dc"], cat["features_rest"]), axis=1)}
+            "shs": np.concatenate((cat["features_dc"], cat["features_rest"]), axis=1),
+            "active_sh_degree": 0 if len(placements) else int(base_sh_degree)}

@@ -19,7 +19,8 @@ from autovfx_amd.dynamic_scene import matrix_to_quaternion
 from autovfx_amd.scenes import GaussianCloud
 
 
-def reference_shaped_compose(base, objects: Dict[str, Tuple[object, Sequence[float]]], placements, device) -> GaussianCloud:
+def reference_shaped_compose(base, objects: Dict[str, Tuple[object, Sequence[float]]], placements, device,
+                             reference_sh_degree: bool = True) -> GaussianCloud:
     """The same frame composed the reference's way with PyTorch on the GPU -- clone the base parameters, transform each
     placed object's raw parameters with the reference's sequence of tensor operations (``gaussians_utils.py:85-118``),
     concatenate everything (``:71-82``), activate (``gaussian_model.py:95-128``) -- minus the per-frame PLY reload.  The
@@ -51,4 +52,5 @@ def reference_shaped_compose(base, objects: Dict[str, Tuple[object, Sequence[flo
     return GaussianCloud(cat["_xyz"].contiguous(), torch.sigmoid(cat["_opacity"]).contiguous(), torch.exp(cat["_scaling"]).contiguous(),
                          torch.nn.functional.normalize(cat["_rotation"]).contiguous(),
                          torch.cat((cat["_features_dc"], cat["_features_rest"]), dim=1).contiguous(), None,
-                         int(getattr(base, "active_sh_degree", 3)))
+                         # a merged model is a fresh GaussianModel: active_sh_degree 0 (gaussians_utils.py:75, gaussian_model.py:49)
+                         (0 if reference_sh_degree and len(placements) else int(getattr(base, "active_sh_degree", 3))))

@@ -42,6 +42,10 @@ def main():
     ap.add_argument("--object", action="append", default=[], metavar="ID=PLY@cx,cy,cz",
                     help="an inserted object: its Gaussians (PLY, read with --sh-degree) and its initial centre")
     ap.add_argument("--rigid-body-json", help="per-frame rigid-body transforms of the objects (rb_transform_info)")
+    ap.add_argument("--full-sh-on-placed-frames", action="store_true",
+                    help="render frames with placed objects at the scene's SH degree.  Default: degree 0 on such frames, as the "
+                         "reference does (its merged model is a fresh GaussianModel whose active_sh_degree is never raised: "
+                         "gaussians_utils.py:71-82)")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
 
@@ -88,7 +92,8 @@ def main():
         if args.rigid_body_json:
             with open(args.rigid_body_json) as f:
                 transforms = json.load(f)
-        scene = DynamicScene(model, objects, device=dev, sh_degree=model.active_sh_degree)
+        scene = DynamicScene(model, objects, device=dev, sh_degree=model.active_sh_degree,
+                             placed_sh_degree=None if args.full_sh_on_placed_frames else 0)
 
     def frame_model(i):
         if scene is None:

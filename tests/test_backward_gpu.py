@@ -256,6 +256,19 @@ def test_backward_c2_full_size_vs_oracle():
     check_case("c2_full_1M", cloud, cam, pg, hip, ref, KEYS_SH)
 
 
+def test_backward_c4_full_size_vs_oracle():
+    """BASELINE configs[3] at bench size (200 k flat SuGaR-style Gaussians, colors_precomp, 960x540, SuGaR's off-centre
+    principal-point camera, orbit frame 25): every gradient against the CPU oracle's backward."""
+    from autovfx_amd.cameras import sugar_orbit_cameras
+    cloud, cam = scenes.config_c4(), sugar_orbit_cameras(50, 960, 540)[25]
+    assert cloud.P == 200_000
+    pg = pixel_grads(cam, 8)
+    kw = oracle_kwargs(cloud, cam, bg=(1.0, 1.0, 1.0))
+    kw.update(pg)
+    check_case("c4_full_200k", cloud, cam, pg, hip_backward(cloud, cam, pg, bg=(1.0, 1.0, 1.0)), cpu_oracle.backward(**kw), KEYS_PRE,
+               bg=(1.0, 1.0, 1.0))
+
+
 def test_backward_sh_degree_four_with_25_coefficients_leaves_higher_bands_zero():
     """A vanilla GaussianModel(sh_degree=4) carries M = 25 coefficients; computeColorFromSH (forward.cu:20-71 and its
     backward, backward.cu:20-138) only knows bands 0..3, so coefficients 16..24 receive exactly zero gradient (the

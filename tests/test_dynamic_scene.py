@@ -95,6 +95,7 @@ def test_restatement_against_the_reference_functions_on_the_host():
         r = refgm.GaussianModel(3)
         for k in ("_xyz", "_rotation", "_scaling", "_opacity", "_features_dc", "_features_rest"):
             setattr(r, k, getattr(m, k).clone())
+        r.active_sh_degree = r.max_sh_degree   # as load_ply leaves it (gaussian_model.py:266)
         return r
 
     for fi, frame in enumerate(FRAMES):
@@ -111,8 +112,10 @@ def test_restatement_against_the_reference_functions_on_the_host():
             err = np.abs(tr._xyz.numpy().astype(np.float64) - x).max()
             assert err <= 4 * np.spacing(np.float32(np.abs(x).max())), (fi, name, err)
             allg = gu.merge_two_gaussians(allg, tr, 3)
-        got = dyn.compose(raw(base), [(raw(objs[n][0]), c, R, s, objs[n][1]) for n, c, R, s in frame])
+        got = dyn.compose(raw(base), [(raw(objs[n][0]), c, R, s, objs[n][1]) for n, c, R, s in frame], base_sh_degree=3)
         assert got["means3D"].shape[0] == allg._xyz.shape[0]
+        # the degree render() will use: the merged model is a fresh GaussianModel (0); an untouched deep copy keeps the scene's
+        assert allg.active_sh_degree == (0 if frame else 3) == got["active_sh_degree"]
         np.testing.assert_array_equal(got["shs"], torch.cat((allg._features_dc, allg._features_rest), 1).numpy())
         assert ulps(got["opacities"], torch.sigmoid(allg._opacity).numpy()) <= 2
         assert ulps(got["scales"], torch.exp(allg._scaling).numpy()) <= 2   # (numpy and torch use different vectorised exp)
@@ -173,8 +176,11 @@ def test_frames_match_the_reference_shaped_composition_and_the_cpu_oracle():
         cam = cams[fi].to(dev)
         with torch.no_grad():
             cloud = scene.compose(frame)
+            assert cloud.sh_degree == (0 if frame else 3)   # the reference's merged model renders DC-only (module docstring)
+            assert DynamicScene(base, objs, placed_sh_degree=None).compose(frame).sh_degree == 3
             color, depth, alpha, radii = [t.clone() for t in rasterize(cloud, cam, bg)]
             ref_cloud = reference_shaped_compose(base, objs, frame, dev)
+            assert ref_cloud.sh_degree == cloud.sh_degree
             rc, rd, ra, rr = rasterize(ref_cloud, cam, bg)
         torch.cuda.synchronize()
         # same device, same torch kernels for exp / sigmoid / normalize; positions differ by the matmul's summation order
@@ -190,7 +196,7 @@ def test_frames_match_the_reference_shaped_composition_and_the_cpu_oracle():
         c_ = cams[fi]
         ref = cpu_oracle.forward(means3D=w["means3D"], opacities=w["opacities"], bg=np.array([0.1, 0.2, 0.3], np.float32), width=320,
                                  height=180, viewmatrix=c_.world_view_transform, projmatrix=c_.full_proj_transform,
-                                 campos=c_.camera_center, tanfovx=c_.tanfovx, tanfovy=c_.tanfovy, sh_degree=3, shs=w["shs"],
+                                 campos=c_.camera_center, tanfovx=c_.tanfovx, tanfovy=c_.tanfovy, sh_degree=w["active_sh_degree"], shs=w["shs"],
                                  scales=w["scales"], rotations=w["rotations"])
         assert_images(f"dynamic_f{fi}_vs_oracle", got, ref)
         assert int((radii.cpu().numpy() != ref["radii"]).sum()) <= max(1, cloud.P // 20000)

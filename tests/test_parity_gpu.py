@@ -889,6 +889,45 @@ def test_c3_full_frames_vs_oracle(frame):
     report(f"c3_full_f{frame}:size", P=cloud.P, V=int((ref["radii"] > 0).sum()), D=int(ref["num_rendered"]))
 
 
+@pytest.mark.parametrize("frame", [0, 25, 49])
+def test_c4_full_size_vs_oracle(frame):
+    """BASELINE configs[3] at the size bench.py runs it (``also.c4_fused_rgb_normal_depth``): 200 k flat SuGaR-style
+    Gaussians, ``colors_precomp``, 960x540, SuGaR's off-centre principal-point camera, orbit frames 0 / 25 / 49.  Every stage
+    against the oracle with the bars of the other full-size cases; then the fused RGB + normal + depth call bench.py times
+    (``gsr_forward_extra``, inference) against SuGaR's two passes, bit for bit."""
+    from autovfx_amd.cameras import sugar_orbit_cameras
+    from diff_gaussian_rasterization import _C
+    cloud = scenes.config_c4()
+    assert cloud.P == 200_000
+    cam = sugar_orbit_cameras(50, 960, 540)[frame]
+    hip, ref = run_both(f"c4_full_f{frame}", cloud, cam)
+    report(f"c4_full_f{frame}:size", P=cloud.P, V=int((ref["radii"] > 0).sum()), D=int(ref["num_rendered"]))
+    dev = "cuda:0"
+    c = cloud.to(dev)
+    st = settings_for(cam, dev, (0.0, 0.0, 0.0), 1.0, 0)
+    e = torch.Tensor([])
+    normals = (c.means3D / c.means3D.norm(dim=1, keepdim=True) * 0.5 + 0.5).contiguous()   # what bench.py composites beside the colours
+    args = lambda colors: (st.bg, c.means3D, colors, c.opacities, c.scales, c.rotations, 1.0, e, st.viewmatrix, st.projmatrix,
+                           st.tanfovx, st.tanfovy, st.image_height, st.image_width, e, 0, st.campos, False, False)
+    _C.set_geometry_cache(False)
+    try:
+        fused = _C.rasterize_gaussians_extra(*args(c.colors_precomp), normals, inference=True)
+        rgb_pass = _C.rasterize_gaussians(*args(c.colors_precomp))
+        normal_pass = _C.rasterize_gaussians(*args(normals))
+    finally:
+        _C.set_geometry_cache(None)
+    torch.cuda.synchronize()
+    for i in (1, 2, 3, 4):
+        assert torch.equal(fused[i], rgb_pass[i]), i
+    assert torch.equal(fused[8], normal_pass[1])
+    np.testing.assert_array_equal(rgb_pass[1].cpu().numpy(), hip["color"])
+    # the normal pass against the oracle too (colors_precomp = normals)
+    ref_n = cpu_oracle.forward(**oracle_kwargs(GaussianCloud(cloud.means3D, cloud.opacities, cloud.scales, cloud.rotations, None,
+                                                             normals.cpu(), 0), cam))
+    assert_images(f"c4_full_f{frame}_normal_pass", {"color": fused[8].cpu().numpy(), "depth": fused[2].cpu().numpy(),
+                                                      "alpha": fused[3].cpu().numpy()}, ref_n)
+
+
 # ---- a trained-scene-like cloud: heavy-tailed sizes, needles and discs, bimodal opacity (scenes.config_heavy) ---------
 
 @pytest.mark.parametrize("P,wh,frame", [(15_000, (960, 540), 3), (1_000_000, (960, 540), 0), (1_000_000, (960, 540), 100)])

@@ -11,13 +11,12 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(params=["ballots", "lds_adds"], autouse=True)
 def rank_variant(request):
     """Both in-wave rank forms of the scatter kernel are compiled in (gsr_radix.hip); every test of this file runs with
-    each of them forced (GSR_OPT_RADIX_RANK 0 / 1), then the default (2: LDS adds where the device passed the self-test)
-    is restored."""
+    each of them forced (GSR_OPT_RADIX_RANK 0 / 1), then the default (0: ballots) is restored."""
     from autovfx_amd import _lib
     _lib.set_option(_lib.OPT_RADIX_RANK, 0 if request.param == "ballots" else 1)
     assert _lib.get_option(_lib.OPT_RADIX_RANK_ACTIVE) == (0 if request.param == "ballots" else 1)
     yield request.param
-    _lib.set_option(_lib.OPT_RADIX_RANK, 2)
+    _lib.set_option(_lib.OPT_RADIX_RANK, 0)
 
 
 def sort_pairs(keys, vals, bits, iota=False):
@@ -92,11 +91,13 @@ def test_lds_atomics_serve_lanes_in_order():
     assert int(bad.item()) == 0
 
 
-def test_default_mode_selftests_the_device_and_reports_what_it_uses():
-    """GSR_OPT_RADIX_RANK = 2 (the default): the first sort on a device runs the lane-order self-test; on MI355X it passes
-    and GSR_OPT_RADIX_RANK_ACTIVE says LDS adds.  (Were it to fail, ACTIVE would say ballots and the sorts would still be
-    right: that branch is the `ballots` parametrisation of every test above.)"""
+def test_selftested_mode_tests_the_device_and_reports_what_it_uses():
+    """GSR_OPT_RADIX_RANK = 2 (an opt-in since round 4; the default is 0, ballots): the first sort on a device runs the
+    lane-order self-test; on MI355X it passes and GSR_OPT_RADIX_RANK_ACTIVE says LDS adds.  (Were it to fail, ACTIVE would say
+    ballots and the sorts would still be right: that branch is the `ballots` parametrisation of every test above.)"""
     from autovfx_amd import _lib
+    _lib.set_option(_lib.OPT_RADIX_RANK, 0)
+    assert _lib.get_option(_lib.OPT_RADIX_RANK_ACTIVE) == 0    # the shipped default relies on the ISA alone
     _lib.set_option(_lib.OPT_RADIX_RANK, 2)
     assert _lib.get_option(_lib.OPT_RADIX_RANK) == 2
     assert _lib.get_option(_lib.OPT_RADIX_RANK_ACTIVE) == 1, "the LDS lane-order self-test failed on this device"
