@@ -29,7 +29,7 @@ SYMBOLS = ("gsr_forward", "gsr_mark_visible", "gsr_backward", "gsr_last_geom_off
            "gsr_abi_version", "gsr_target_arch", "gsr_set_option", "gsr_get_option", "gsr_pack_rgba8", "gsr_last_pair_counts", "gsr_blend", "gsr_composite",
            "gsr_radix_scratch_bytes", "gsr_radix_sort_pairs", "gsr_selftest_exp", "gsr_view_normals", "gsr_normal_maps", "gsr_forward_extra", "gsr_get_call_times",
            "gsr_forward_begin", "gsr_forward_finish", "gsr_forward_ready", "gsr_forward_cancel", "gsr_last_slab_pairs", "gsr_plan_slabs", "gsr_selftest_lds_atomic_order", "gsr_get_backward_times", "gsr_place_object",
-           "gsr_forward_raw", "gsr_forward_raw_begin")
+           "gsr_forward_raw", "gsr_forward_raw_begin", "gsr_backward_raw")
 OPT_TILE_CULL = 0
 OPT_SLABS = 1
 OPT_SLAB_FIRST = 2
@@ -130,6 +130,15 @@ def _load() -> ctypes.CDLL:
         c_f, c_f, c_f, c_f,                                    # radii geom binning image
         c_f, c_f, c_f, c_f,                                    # accum_alphas dL_dpix dL_dpix_depth dL_dpix_alpha
         c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f,      # dL_dmean2D conic opacity color depth mean3D cov3D sh scale rot
+        c_f, ctypes.c_int, ctypes.c_void_p]                    # accum_scratch debug stream
+    lib.gsr_backward_raw.restype = ctypes.c_int
+    lib.gsr_backward_raw.argtypes = [
+        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f, ctypes.c_int, ctypes.c_int,  # P D M R bg W H
+        ctypes.POINTER(RawParams), ctypes.c_float,             # raw scale_modifier
+        c_f, c_f, c_f, ctypes.c_float, ctypes.c_float,         # view proj campos tanx tany
+        c_f, c_f, c_f, c_f,                                    # radii geom binning image
+        c_f, c_f, c_f, c_f, c_f,                               # accum_alphas dL_dpix dL_dpix_depth dL_dpix_alpha dL_dpix_normal
+        c_f, c_f, c_f, c_f, c_f, c_f, c_f,                     # dL_dmean2D xyz log_scales rotations opacity dc rest
         c_f, ctypes.c_int, ctypes.c_void_p]                    # accum_scratch debug stream
     for name, n in (("gsr_last_geom_offsets", len(GEOM_SLOTS)), ("gsr_last_binning_offsets", len(BIN_SLOTS)),
                     ("gsr_last_image_offsets", len(IMG_SLOTS))):

@@ -332,25 +332,34 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
     return GSR_OK;
 }
 
-int gsr_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
-                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
-                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
-                 const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii, const char* geom_buffer,
-                 const char* binning_buffer, const char* image_buffer, const float* accum_alphas, const float* dL_dpix,
-                 const float* dL_dpix_depth, const float* dL_dpix_alpha, float* dL_dmean2D, float* dL_dconic,
-                 float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D,
-                 float* dL_dsh, float* dL_dscale, float* dL_drot, float* accum_scratch, int debug, void* stream_) {
+} // extern "C"
+
+namespace {
+// gsr_backward and gsr_backward_raw: `raw` != nullptr -> the parameter pointers are the model's raw tensors (raw->xyz in
+// means3D's place, and so on), dL_dsh_rest / dL_dpix_normal belong to that form.
+int backward_impl(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                  const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii, const char* geom_buffer,
+                  const char* binning_buffer, const char* image_buffer, const float* accum_alphas, const float* dL_dpix,
+                  const float* dL_dpix_depth, const float* dL_dpix_alpha, float* dL_dmean2D, float* dL_dconic,
+                  float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D,
+                  float* dL_dsh, float* dL_dscale, float* dL_drot, float* accum_scratch, int debug, void* stream_,
+                  const gsr_raw_params* raw, const float* dL_dpix_normal, float* dL_dsh_rest) {
     hipStream_t stream = (hipStream_t)stream_;
     if (P < 0 || width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARG, "bad sizes P=%d W=%d H=%d", P, width, height);
     if (P == 0) return GSR_OK;  // rasterize_points.cu:169: gradients stay as the binding zero-filled them
     if (!geom_buffer || !binning_buffer || !image_buffer) return fail(GSR_ERR_INVALID_ARG, "null scratch buffer");
+    if ((dL_dpix_depth != nullptr) != (dL_dpix_alpha != nullptr))
+        return fail(GSR_ERR_INVALID_ARG, "dL_dpix_depth and dL_dpix_alpha must be given together (both NULL = both all zeros)");
     if (!means3D || !background || !viewmatrix || !projmatrix || !cam_pos || !accum_alphas || !dL_dpix ||
-        !dL_dpix_depth || !dL_dpix_alpha || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_ddepth ||
-        !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot || !accum_scratch)
+        !dL_dmean2D || !dL_dopacity || !dL_dmean3D || !dL_dscale || !dL_drot || !accum_scratch)
         return fail(GSR_ERR_INVALID_ARG, "null required pointer");
     if (shs != nullptr && (M <= 0 || !dL_dsh)) return fail(GSR_ERR_INVALID_ARG, "shs given with M=%d or no dL_dsh", M);
     if ((scales != nullptr) != (rotations != nullptr) || (scales != nullptr) == (cov3D_precomp != nullptr))
         return fail(GSR_ERR_INVALID_ARG, "provide exactly one of (scales, rotations) / cov3D_precomp");
+    if (raw != nullptr && (!shs || !scales || !raw->opacity_logits || (M > 1 && (!raw->features_rest || !dL_dsh_rest))))
+        return fail(GSR_ERR_INVALID_ARG, "raw parameters: all six tensors and dL_dfeatures_rest (M > 1) are required");
 
     const char* bases[3] = {align_base(const_cast<char*>(geom_buffer)), align_base(const_cast<char*>(binning_buffer)),
                             align_base(const_cast<char*>(image_buffer))};
@@ -370,6 +379,8 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
         h[2].count[1] != (uint32_t)height)
         return fail(GSR_ERR_INVALID_ARG, "scratch buffers belong to a different call (P %u/%d, R %u/%d, %ux%u/%dx%d)",
                     h[0].count[0], P, h[0].count[1], R, h[2].count[0], h[2].count[1], width, height);
+    if (dL_dpix_normal != nullptr && (raw == nullptr || h[0].off[1] == 0))
+        return fail(GSR_ERR_INVALID_ARG, "dL_dpix_normal needs the scratch of a gsr_forward_raw call that composited the normal image");
 
     gsr::Camera cam;
     cam.viewmatrix = viewmatrix; cam.projmatrix = projmatrix; cam.cam_pos = cam_pos;
@@ -403,6 +414,9 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     GSR_HIP(hipMemsetAsync(accum_scratch, 0, (size_t)P * 16 * sizeof(float), stream));
     GSR_HIP(gsr::launch_render_backward(cam, ranges, point_list, background, raster, colors, accum_alphas, n_contrib,
                                         dL_dpix, dL_dpix_depth, dL_dpix_alpha, accum_scratch, stream));
+    if (dL_dpix_normal != nullptr)   // the second feature set's pass: colour sums to slots 10 - 12, geometry sums add to 4 - 9
+        GSR_HIP(gsr::launch_render_backward(cam, ranges, point_list, background, raster, (const float*)(bases[0] + h[0].off[1]),
+                                            accum_alphas, n_contrib, dL_dpix_normal, nullptr, nullptr, accum_scratch, stream, 10));
     GSR_STAGE_CHECK("render_backward");
     if (bw_slot >= 0) GSR_HIP(hipEventRecord(g_bw_ev[bw_slot][1], stream));
     gsr::BackwardInputs b;
@@ -411,6 +425,10 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     b.accum = accum_scratch; b.dL_dmean2D = dL_dmean2D; b.dL_dconic = dL_dconic; b.dL_dopacity = dL_dopacity;
     b.dL_dcolor = dL_dcolor; b.dL_ddepth = dL_ddepth;
     b.dL_dmean3D = dL_dmean3D; b.dL_dcov3D = dL_dcov3D; b.dL_dsh = dL_dsh; b.dL_dscale = dL_dscale; b.dL_drot = dL_drot;
+    if (raw != nullptr) {
+        b.raw = 1; b.shs_rest = raw->features_rest; b.opacity_logits = raw->opacity_logits; b.dL_dsh_rest = dL_dsh_rest;
+        b.normal_grads = dL_dpix_normal != nullptr ? 1 : 0;
+    }
     GSR_HIP(gsr::launch_preprocess_backward(b, cam, stream));
     GSR_STAGE_CHECK("preprocess_backward");
     if (bw_slot >= 0) {
@@ -420,6 +438,41 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
         ++g_bw_calls;
     }
     return GSR_OK;
+}
+} // namespace
+
+extern "C" {
+
+int gsr_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii, const char* geom_buffer,
+                 const char* binning_buffer, const char* image_buffer, const float* accum_alphas, const float* dL_dpix,
+                 const float* dL_dpix_depth, const float* dL_dpix_alpha, float* dL_dmean2D, float* dL_dconic,
+                 float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D,
+                 float* dL_dsh, float* dL_dscale, float* dL_drot, float* accum_scratch, int debug, void* stream_) {
+    return backward_impl(P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier, rotations,
+                         cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer,
+                         image_buffer, accum_alphas, dL_dpix, dL_dpix_depth, dL_dpix_alpha, dL_dmean2D, dL_dconic, dL_dopacity,
+                         dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, accum_scratch, debug, stream_,
+                         nullptr, nullptr, nullptr);
+}
+
+int gsr_backward_raw(int P, int D, int M, int R, const float* background, int width, int height, const gsr_raw_params* raw,
+                     float scale_modifier, const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                     float tan_fovy, const int* radii, const char* geom_buffer, const char* binning_buffer,
+                     const char* image_buffer, const float* accum_alphas, const float* dL_dpix, const float* dL_dpix_depth,
+                     const float* dL_dpix_alpha, const float* dL_dpix_normal, float* dL_dmean2D, float* dL_dxyz,
+                     float* dL_dlog_scales, float* dL_drotations, float* dL_dopacity_logits, float* dL_dfeatures_dc,
+                     float* dL_dfeatures_rest, float* accum_scratch, int debug, void* stream_) {
+    if (!raw) return fail(GSR_ERR_INVALID_ARG, "null raw parameter block");
+    if (M <= 0) return fail(GSR_ERR_INVALID_ARG, "raw parameters carry SH coefficients: M=%d", M);
+    return backward_impl(P, D, M, R, background, width, height, raw->xyz, raw->features_dc, nullptr, raw->log_scales, scale_modifier,
+                         raw->rotations, nullptr, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, radii, geom_buffer,
+                         binning_buffer, image_buffer, accum_alphas, dL_dpix, dL_dpix_depth, dL_dpix_alpha, dL_dmean2D,
+                         /*dL_dconic=*/nullptr, dL_dopacity_logits, /*dL_dcolor=*/nullptr, /*dL_ddepth=*/nullptr, dL_dxyz,
+                         /*dL_dcov3D=*/nullptr, dL_dfeatures_dc, dL_dlog_scales, dL_drotations, accum_scratch, debug, stream_, raw,
+                         dL_dpix_normal, dL_dfeatures_rest);
 }
 
 int gsr_blend(const char* geom_buffer, const char* binning_buffer, const char* image_buffer, int width, int height,
@@ -928,6 +981,7 @@ int forward_finish(ForwardCall& fc) {
     hg.kind = 0; hb.kind = 1; hi.kind = 2;
     hg.count[0] = (uint32_t)P; hg.count[1] = num_rendered; hg.count[2] = (uint32_t)S; hg.count[3] = fc.inference ? 1u : 0u;
     hg.off[0] = (uint64_t)((char*)ga.raster - gbase);
+    hg.off[1] = (uint64_t)(fc.raw_normals ? fc.geom_off[GSR_GEOM_VIEW_NORMALS] : 0);   // 0 = the call composited no view normals
     hg.off[3] = (uint64_t)((char*)ga.rgb - gbase);
     hg.off[4] = (uint64_t)fc.geom_off[GSR_GEOM_INTERNAL_RADII];
     hg.off[5] = (uint64_t)fc.off_slabs;

@@ -72,15 +72,20 @@ __device__ __forceinline__ float row_sum_all_lanes(float v) {  // every lane of 
 }
 constexpr int kAccumStride = 16;  // floats per Gaussian in the accumulation scratch: one 64-byte line
 // slots: 0 r, 1 g, 2 b, 3 depth, 4 S_u, 5 S_v, 6 S_{u dx}, 7 S_{u dy}, 8 S_{v dy} (u = dL_dG G dx, v = dL_dG G dy: the factored
-// sums behind dL_dmean2D and dL_dconic, finished per Gaussian by preprocess_backward_lane), 9 opacity
+// sums behind dL_dmean2D and dL_dconic, finished per Gaussian by preprocess_backward_lane), 9 opacity; 10 - 12 the colour sums
+// of a pass over the call's SECOND feature set (gsr_backward_raw with dL_dpix_normal: its geometry sums add to 4 - 9), 13 unused
 
+// kDepthAlpha = false: the caller has no gradient for the depth and alpha images (dL_dpixel_depths / dL_dpixel_alphas are not
+// read): their terms of dL_dalpha, the two accumulators behind them and the depth sum drop out of the loop -- the usual
+// training loss (train.py:84-134, scene_representation.py:495-520) only looks at the colour image.
+template <bool kDepthAlpha>
 __global__ void __launch_bounds__(64, 4) render_backward_kernel(
     int W, int H, int grid_x, int num_tiles, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const float* __restrict__ background,
     const SplatRaster* __restrict__ raster, const float* __restrict__ colors, const float* __restrict__ accum_alphas,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dpixel_alphas,
-    float* __restrict__ accum /*[P,16], zero on entry*/) {
+    float* __restrict__ accum /*[P,16], zero on entry*/, int colour_slot /*0; 10: a pass over the second feature set*/) {
     __shared__ BlendEntry s_entry[64];  // the forward's 48-byte record; the Gaussian id rides in its pad word
 
     constexpr int kQ = kTile / 2;
@@ -101,7 +106,7 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
     // forward results for this pixel (backward.cu:459-479)
     // which slot of a Gaussian's accumulation line this lane adds to after the reduce-scatter (see below)
     const int red_k = lane & 15, red_row = lane >> 4;
-    const int my_slot = red_k == 0 ? ((red_row & 1) << 1 | (red_row >> 1))
+    const int my_slot = red_k == 0 ? colour_slot + ((red_row & 1) << 1 | (red_row >> 1))
                       : red_k == 1 ? 4 + ((red_row & 1) << 1 | (red_row >> 1))
                       : (red_k == 2 && (red_row & 1) == 0) ? 8 + (red_row >> 1) : -1;
 
@@ -113,8 +118,10 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
         dLr = dL_dpixels[pid];
         dLg = dL_dpixels[plane + pid];
         dLb = dL_dpixels[2 * plane + pid];
-        dLd = dL_dpixel_depths[pid];
-        dLa = dL_dpixel_alphas[pid];
+        if (kDepthAlpha) {
+            dLd = dL_dpixel_depths[pid];
+            dLa = dL_dpixel_alphas[pid];
+        }
     }
     // entries at list positions >= every pixel's last contributor are skipped by every pixel
     uint32_t walk = last_contributor;
@@ -211,17 +218,21 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
                 float dL_dalpha = (c.r - acc_r) * dLr;
                 dL_dalpha += (c.g - acc_g) * dLg;
                 dL_dalpha += (c.b - acc_b) * dLb;
-                dL_dalpha += (z - acc_d) * dLd;
-                dL_dalpha += (1.f - acc_a) * dLa;
+                if (kDepthAlpha) {
+                    dL_dalpha += (z - acc_d) * dLd;
+                    dL_dalpha += (1.f - acc_a) * dLa;
+                }
                 g_cr = dchannel_dcolor * dLr;
                 g_cg = dchannel_dcolor * dLg;
                 g_cb = dchannel_dcolor * dLb;
-                g_dep = dchannel_dcolor * dLd;
+                g_dep = kDepthAlpha ? dchannel_dcolor * dLd : 0.f;
                 acc_r = alpha_m * c.r + one_m * acc_r;
                 acc_g = alpha_m * c.g + one_m * acc_g;
                 acc_b = alpha_m * c.b + one_m * acc_b;
-                acc_d = alpha_m * z + one_m * acc_d;
-                acc_a = alpha_m + one_m * acc_a;
+                if (kDepthAlpha) {
+                    acc_d = alpha_m * z + one_m * acc_d;
+                    acc_a = alpha_m + one_m * acc_a;
+                }
                 dL_dalpha *= T;
                 dL_dalpha += (-T_final * inv_1ma) * bg_dot;
                 const float dL_dG = c.opacity * dL_dalpha;
@@ -347,29 +358,93 @@ struct BackwardArgs {
     float* dL_dsh;               // [P,M,3] nullable
     float* dL_dscale;            // [P,3]
     float* dL_drot;              // [P,4]
+    // gsr_backward_raw: scales / rotations / shs are the model's RAW tensors (log scales, unnormalised quaternions, _features_dc)
+    // and the gradients leave with the activations' chain rule applied: dL_dscale -> d/d(log scale), dL_drot -> d/d(raw
+    // quaternion), dL_dopacity -> d/d(logit), dL_dsh -> d/d(_features_dc) [P,1,3], dL_dsh_rest -> d/d(_features_rest) [P,M-1,3]
+    int raw;
+    const float* shs_rest;       // _features_rest [P,M-1,3] (raw, M > 1)
+    const float* opacity_logits; // _opacity [P] (raw)
+    float* dL_dsh_rest;          // [P,M-1,3] (raw, M > 1)
+    int normal_grads;            // raw: accum slots 10 - 12 hold dL/d(view normal colour): chained through get_normal to the quaternion
+    const float* cam_pos_normals;
 };
+
+// d/d(x) of x / max(||x||, 1e-12) against an upstream gradient g (what autograd makes of F.normalize: the clamp passes no
+// gradient): (g - n (n . g)) / ||x|| with n the normalised vector; g / 1e-12 below the clamp.
+__device__ __forceinline__ F4 normalize4_backward(F4 x, F4 n, F4 g) {
+    const float len = sqrtf((x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w));
+    if (!(len > 1e-12f)) return F4{g.x / 1e-12f, g.y / 1e-12f, g.z / 1e-12f, g.w / 1e-12f};
+    const float d = n.x * g.x + n.y * g.y + n.z * g.z + n.w * g.w;
+    return F4{(g.x - n.x * d) / len, (g.y - n.y * d) / len, (g.z - n.z * d) / len, (g.w - n.w * d) / len};
+}
+
+// Backward of gsr_device.h: view_normal_rgb(p, cam, min_axis(s, q)) with respect to the (normalised) quaternion q: through
+// * 0.5 + 0.5, the unit normalisation, the flip (a constant sign), the selected column of build_rotation(q) and that
+// function's own renormalisation of q (general_utils.py:78-101,135-157; gaussian_model.py get_normal).  The position and the
+// scales only enter through a sign and an argmin: no gradient, as in autograd.
+__device__ __forceinline__ F4 view_normal_backward(F3 p, F3 cam, F3 s, F4 q, F3 g_rgb) {
+    const float n2 = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    const float w = q.x / n2, x = q.y / n2, y = q.z / n2, z = q.w / n2;
+    int c;
+    if (s.x < s.y) c = s.z < s.x ? 2 : 0;
+    else if (s.y < s.x) c = s.z < s.y ? 2 : 1;
+    else c = s.x < s.z ? 1 : 2;
+    F3 a, dw, dx, dy, dz;   // the column and its derivatives with respect to w, x, y, z
+    if (c == 0) {
+        a = F3{1.f - 2.f * (y * y + z * z), 2.f * (x * y + w * z), 2.f * (x * z - w * y)};
+        dw = F3{0.f, 2.f * z, -2.f * y}; dx = F3{0.f, 2.f * y, 2.f * z}; dy = F3{-4.f * y, 2.f * x, -2.f * w}; dz = F3{-4.f * z, 2.f * w, 2.f * x};
+    } else if (c == 1) {
+        a = F3{2.f * (x * y - w * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z + w * x)};
+        dw = F3{-2.f * z, 0.f, 2.f * x}; dx = F3{2.f * y, -4.f * x, 2.f * w}; dy = F3{2.f * x, 0.f, 2.f * z}; dz = F3{-2.f * w, -4.f * z, 2.f * y};
+    } else {
+        a = F3{2.f * (x * z + w * y), 2.f * (y * z - w * x), 1.f - 2.f * (x * x + y * y)};
+        dw = F3{2.f * y, -2.f * x, 0.f}; dx = F3{2.f * z, -2.f * w, -4.f * x}; dy = F3{2.f * w, 2.f * z, -4.f * y}; dz = F3{2.f * x, 2.f * y, 0.f};
+    }
+    const F3 d = {p.x - cam.x, p.y - cam.y, p.z - cam.z};
+    const float len = torch_norm3(d);
+    const float dot = torch_sum3(a.x * -(d.x / len), a.y * -(d.y / len), a.z * -(d.z / len));
+    const float sg = dot >= 0.f ? 1.f : -1.f;
+    const F3 m = {a.x * sg, a.y * sg, a.z * sg};
+    const float ml = torch_norm3(m);
+    const F3 n = {m.x / ml, m.y / ml, m.z / ml};
+    const F3 gn = {0.5f * g_rgb.x, 0.5f * g_rgb.y, 0.5f * g_rgb.z};
+    const float nd = n.x * gn.x + n.y * gn.y + n.z * gn.z;
+    const F3 ga = {sg * (gn.x - n.x * nd) / ml, sg * (gn.y - n.y * nd) / ml, sg * (gn.z - n.z * nd) / ml};   // d/d(axis)
+    const F4 gq = {ga.x * dw.x + ga.y * dw.y + ga.z * dw.z, ga.x * dx.x + ga.y * dx.y + ga.z * dx.z,
+                   ga.x * dy.x + ga.y * dy.y + ga.z * dy.z, ga.x * dz.x + ga.y * dz.y + ga.z * dz.z};        // d/d(w, x, y, z)
+    const float qd = w * gq.x + x * gq.y + y * gq.z + z * gq.w;
+    return F4{(gq.x - w * qd) / n2, (gq.y - x * qd) / n2, (gq.z - y * qd) / n2, (gq.w - z * qd) / n2};    // through q / ||q||
+}
 
 constexpr int kShStagePitch = 65;  // words between consecutive floats of one lane's record in the LDS stage
 
 // One lane = one Gaussian.  `stage` (nullable) is this lane's column of the wave's LDS stage for dL_dsh: float f of
 // the record goes to stage[f * kShStagePitch]; with stage == nullptr the record is stored straight to HBM.
+template <bool kRaw>
 __device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, const Camera& cam, int idx, float* stage) {
     if (!(g.radii[idx] > 0)) {
         // Not rendered: every gradient of this Gaussian is zero.  The kernel defines ALL output elements, so the
         // caller does not have to zero-fill a gigabyte of gradient tensors first (dL_dsh alone is 576 MB at 3 M).
         const F3 z3 = {0.f, 0.f, 0.f};
         *reinterpret_cast<F3*>(g.dL_dmean2D + 3 * (size_t)idx) = z3;
-        *reinterpret_cast<F4*>(g.dL_dconic + 4 * (size_t)idx) = F4{0.f, 0.f, 0.f, 0.f};
+        if (g.dL_dconic != nullptr) *reinterpret_cast<F4*>(g.dL_dconic + 4 * (size_t)idx) = F4{0.f, 0.f, 0.f, 0.f};
         g.dL_dopacity[idx] = 0.f;
-        *reinterpret_cast<F3*>(g.dL_dcolor + 3 * (size_t)idx) = z3;
-        g.dL_ddepth[idx] = 0.f;
+        if (g.dL_dcolor != nullptr) *reinterpret_cast<F3*>(g.dL_dcolor + 3 * (size_t)idx) = z3;
+        if (g.dL_ddepth != nullptr) g.dL_ddepth[idx] = 0.f;
         *reinterpret_cast<F3*>(g.dL_dmean3D + 3 * (size_t)idx) = z3;
-        *reinterpret_cast<F3*>(g.dL_dcov3D + 6 * (size_t)idx) = z3;
-        *reinterpret_cast<F3*>(g.dL_dcov3D + 6 * (size_t)idx + 3) = z3;
+        if (g.dL_dcov3D != nullptr) {
+            *reinterpret_cast<F3*>(g.dL_dcov3D + 6 * (size_t)idx) = z3;
+            *reinterpret_cast<F3*>(g.dL_dcov3D + 6 * (size_t)idx + 3) = z3;
+        }
         if (stage != nullptr) {
             for (int f = 0; f < 3 * g.M; ++f) stage[f * kShStagePitch] = 0.f;
         } else if (g.dL_dsh != nullptr) {
-            for (int k = 0; k < g.M; ++k) *reinterpret_cast<F3*>(g.dL_dsh + 3 * ((size_t)g.M * idx + k)) = z3;
+            if (kRaw) {
+                *reinterpret_cast<F3*>(g.dL_dsh + 3 * (size_t)idx) = z3;
+                for (int k = 1; k < g.M; ++k) *reinterpret_cast<F3*>(g.dL_dsh_rest + 3 * ((size_t)(g.M - 1) * idx + k - 1)) = z3;
+            } else {
+                for (int k = 0; k < g.M; ++k) *reinterpret_cast<F3*>(g.dL_dsh + 3 * ((size_t)g.M * idx + k)) = z3;
+            }
         }
         *reinterpret_cast<F3*>(g.dL_dscale + 3 * (size_t)idx) = z3;
         *reinterpret_cast<F4*>(g.dL_drot + 4 * (size_t)idx) = F4{0.f, 0.f, 0.f, 0.f};
@@ -386,22 +461,37 @@ __device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, 
     const float dLc_r = s0.x, dLc_g = s0.y, dLc_b = s0.z, gdep = s0.w;
     const float S_u = s1.x, S_v = s1.y;
     const float dLcx = -0.5f * s1.z, dLcy = -0.5f * s1.w, dLcz = -0.5f * s2.x;   // backward.cu:577-581, the -1/2 taken out of the sums
-    *reinterpret_cast<F3*>(g.dL_dcolor + 3 * (size_t)idx) = F3{dLc_r, dLc_g, dLc_b};
-    g.dL_ddepth[idx] = gdep;
-    *reinterpret_cast<F4*>(g.dL_dconic + 4 * (size_t)idx) = F4{dLcx, dLcy, 0.f, dLcz};   // 2x2 with one unused slot
-    g.dL_dopacity[idx] = s2.y;
+    // (intermediates the caller does not want -- dL_dconic / dL_ddepth always, dL_dcolor with SH colours, dL_dcov3D with scales and
+    // rotations -- may be NULL: 56 bytes per Gaussian less to write)
+    if (g.dL_dcolor != nullptr) *reinterpret_cast<F3*>(g.dL_dcolor + 3 * (size_t)idx) = F3{dLc_r, dLc_g, dLc_b};
+    if (g.dL_ddepth != nullptr) g.dL_ddepth[idx] = gdep;
+    if (g.dL_dconic != nullptr) *reinterpret_cast<F4*>(g.dL_dconic + 4 * (size_t)idx) = F4{dLcx, dLcy, 0.f, dLcz};   // 2x2 with one unused slot
+    if (kRaw) {   // through sigmoid (gaussian_model.py:125-126): dL/d(logit) = dL/d(opacity) o (1 - o)
+        const float o = torch_sigmoid(g.opacity_logits[idx]);
+        g.dL_dopacity[idx] = s2.y * ((1.f - o) * o);
+    } else {
+        g.dL_dopacity[idx] = s2.y;
+    }
 
     // 3D covariance as the forward computed it
     float c3[6];
     Mat3 R = {}, S = {};
     float sx = 0.f, sy = 0.f, sz = 0.f, qr = 0.f, qx = 0.f, qy = 0.f, qz = 0.f;
+    F4 q_raw = {0.f, 0.f, 0.f, 0.f};
+    F3 s_act = {0.f, 0.f, 0.f};
     if (g.cov3D_precomp != nullptr) {
         const float* c = g.cov3D_precomp + 6 * (size_t)idx;
 #pragma unroll
         for (int k = 0; k < 6; ++k) c3[k] = c[k];
     } else {
-        const F3 s = ld3(g.scales + 3 * (size_t)idx);
-        const F4 q = *reinterpret_cast<const F4*>(g.rotations + 4 * (size_t)idx);
+        F3 s = ld3(g.scales + 3 * (size_t)idx);
+        F4 q = *reinterpret_cast<const F4*>(g.rotations + 4 * (size_t)idx);
+        if (kRaw) {   // the forward's activations (gsr_device.h: torch_*)
+            q_raw = q;
+            s = F3{expf(s.x), expf(s.y), expf(s.z)};
+            q = torch_normalize4(q);
+            s_act = s;
+        }
         qr = q.x; qx = q.y; qy = q.z; qz = q.w;
         sx = g.scale_modifier * s.x; sy = g.scale_modifier * s.y; sz = g.scale_modifier * s.z;
         S.m[0][0] = sx; S.m[1][1] = sy; S.m[2][2] = sz;
@@ -467,8 +557,10 @@ __device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, 
 #pragma unroll
         for (int i = 0; i < 6; ++i) dcov[i] = 0;
     }
+    if (g.dL_dcov3D != nullptr) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) g.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+        for (int i = 0; i < 6; ++i) g.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+    }
     const float dL_dT00 = 2 * (TG(0, 0) * VG(0, 0) + TG(0, 1) * VG(0, 1) + TG(0, 2) * VG(0, 2)) * dL_da + (TG(1, 0) * VG(0, 0) + TG(1, 1) * VG(0, 1) + TG(1, 2) * VG(0, 2)) * dL_db;
     const float dL_dT01 = 2 * (TG(0, 0) * VG(1, 0) + TG(0, 1) * VG(1, 1) + TG(0, 2) * VG(1, 2)) * dL_da + (TG(1, 0) * VG(1, 0) + TG(1, 1) * VG(1, 1) + TG(1, 2) * VG(1, 2)) * dL_db;
     const float dL_dT02 = 2 * (TG(0, 0) * VG(2, 0) + TG(0, 1) * VG(2, 1) + TG(0, 2) * VG(2, 2)) * dL_da + (TG(1, 0) * VG(2, 0) + TG(1, 1) * VG(2, 1) + TG(1, 2) * VG(2, 2)) * dL_db;
@@ -508,14 +600,16 @@ __device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, 
         if (deg > 2 && g.M < 16) deg = 2;
         if (deg > 1 && g.M < 9) deg = 1;
         if (deg > 0 && g.M < 4) deg = 0;
-        const float* sh = g.shs + 3 * (size_t)g.M * idx;
-        float* dsh = g.dL_dsh + 3 * (size_t)g.M * idx;
+        const float* sh = kRaw ? g.shs + 3 * (size_t)idx : g.shs + 3 * (size_t)g.M * idx;   // coefficient 0
+        const float* shr = (kRaw && g.M > 1) ? g.shs_rest + 3 * (size_t)(g.M - 1) * idx - 3 : sh;   // coefficient k >= 1 at shr + 3 k
+        float* dsh = kRaw ? g.dL_dsh + 3 * (size_t)idx : g.dL_dsh + 3 * (size_t)g.M * idx;
+        float* dshr = (kRaw && g.M > 1) ? g.dL_dsh_rest + 3 * (size_t)(g.M - 1) * idx - 3 : dsh;
         const F3 cp = ld3(cam.cam_pos);
         const F3 o = F3{mean.x - cp.x, mean.y - cp.y, mean.z - cp.z};
         const float len = sqrtf(o.x * o.x + o.y * o.y + o.z * o.z);
         const float x = o.x / len, y = o.y / len, z = o.z / len;
         // the forward's clamp decision, recomputed with the forward's own arithmetic
-        F3 pre = sh_unclamped(deg, x, y, z, sh);
+        F3 pre = sh_unclamped(deg, x, y, z, sh, shr);
         const float dL0 = dLc_r * (pre.x < 0 ? 0.f : 1.f), dL1 = dLc_g * (pre.y < 0 ? 0.f : 1.f),
                     dL2 = dLc_b * (pre.z < 0 ? 0.f : 1.f);
         float kk[16];
@@ -532,12 +626,12 @@ __device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, 
         } else {
 #pragma unroll
             for (int k = 0; k < 16; ++k)
-                if (k < ncoef) *reinterpret_cast<F3*>(dsh + 3 * k) = F3{kk[k] * dL0, kk[k] * dL1, kk[k] * dL2};
-            for (int k = ncoef; k < g.M; ++k) *reinterpret_cast<F3*>(dsh + 3 * k) = F3{0.f, 0.f, 0.f};  // bands above the degree
+                if (k < ncoef) *reinterpret_cast<F3*>((k == 0 ? dsh : dshr) + 3 * k) = F3{kk[k] * dL0, kk[k] * dL1, kk[k] * dL2};
+            for (int k = ncoef; k < g.M; ++k) *reinterpret_cast<F3*>((k == 0 ? dsh : dshr) + 3 * k) = F3{0.f, 0.f, 0.f};  // bands above the degree
         }
-        const F3 d0 = sh_dir_grads_channel(deg, x, y, z, sh, 0);
-        const F3 d1 = sh_dir_grads_channel(deg, x, y, z, sh, 1);
-        const F3 d2 = sh_dir_grads_channel(deg, x, y, z, sh, 2);
+        const F3 d0 = sh_dir_grads_channel(deg, x, y, z, shr, 0);   // (reads coefficients k >= 1 only)
+        const F3 d1 = sh_dir_grads_channel(deg, x, y, z, shr, 1);
+        const F3 d2 = sh_dir_grads_channel(deg, x, y, z, shr, 2);
         const F3 ddir = F3{d0.x * dL0 + d1.x * dL1 + d2.x * dL2, d0.y * dL0 + d1.y * dL1 + d2.y * dL2,
                            d0.z * dL0 + d1.z * dL1 + d2.z * dL2};
         const F3 dm = dnormvdv3(o, ddir);
@@ -562,20 +656,35 @@ __device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, 
         Mat3 dMt = transpose3(dM);
 #define COL(Mx, c, r) Mx.m[r][c]
         const float sv[3] = {sx, sy, sz};
+        const float act[3] = {s_act.x, s_act.y, s_act.z};
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-            g.dL_dscale[3 * (size_t)idx + c] = COL(Rt, c, 0) * COL(dMt, c, 0) + COL(Rt, c, 1) * COL(dMt, c, 1) + COL(Rt, c, 2) * COL(dMt, c, 2);
+        for (int c = 0; c < 3; ++c) {
+            const float ds = COL(Rt, c, 0) * COL(dMt, c, 0) + COL(Rt, c, 1) * COL(dMt, c, 1) + COL(Rt, c, 2) * COL(dMt, c, 2);
+            g.dL_dscale[3 * (size_t)idx + c] = kRaw ? ds * act[c] : ds;   // raw: through exp (gaussian_model.py:96-97)
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int rr = 0; rr < 3; ++rr) COL(dMt, c, rr) *= sv[c];
 #define D(c, rr) COL(dMt, c, rr)
         const float r = qr, x = qx, y = qy, z = qz;
-        float* dq = g.dL_drot + 4 * (size_t)idx;
+        float dq[4];
         dq[0] = 2 * z * (D(0, 1) - D(1, 0)) + 2 * y * (D(2, 0) - D(0, 2)) + 2 * x * (D(1, 2) - D(2, 1));
         dq[1] = 2 * y * (D(1, 0) + D(0, 1)) + 2 * z * (D(2, 0) + D(0, 2)) + 2 * r * (D(1, 2) - D(2, 1)) - 4 * x * (D(2, 2) + D(1, 1));
         dq[2] = 2 * x * (D(1, 0) + D(0, 1)) + 2 * r * (D(2, 0) - D(0, 2)) + 2 * z * (D(1, 2) + D(2, 1)) - 4 * y * (D(2, 2) + D(0, 0));
         dq[3] = 2 * r * (D(0, 1) - D(1, 0)) + 2 * x * (D(2, 0) + D(0, 2)) + 2 * y * (D(1, 2) + D(2, 1)) - 4 * z * (D(1, 1) + D(0, 0));
+        F4 gq = {dq[0], dq[1], dq[2], dq[3]};
+        if (kRaw) {
+            const F4 qn = {r, x, y, z};
+            if (g.normal_grads) {   // the normal map's share (accum slots 10 - 12 = dL/d(view normal colour))
+                const float4 nl = *reinterpret_cast<const float4*>(g.accum + (size_t)kAccumStride * idx + 8);   // slots 8..11
+                const float nb = g.accum[(size_t)kAccumStride * idx + 12];
+                const F4 gn = view_normal_backward(mean, ld3(g.cam_pos_normals), s_act, qn, F3{nl.z, nl.w, nb});
+                gq = F4{gq.x + gn.x, gq.y + gn.y, gq.z + gn.z, gq.w + gn.w};
+            }
+            gq = normalize4_backward(q_raw, qn, gq);   // through F.normalize (gaussian_model.py:100-101)
+        }
+        *reinterpret_cast<F4*>(g.dL_drot + 4 * (size_t)idx) = gq;
 #undef D
 #undef COL
     } else {
@@ -587,27 +696,61 @@ __device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, 
 // dL_dsh is 192 bytes per Gaussian: written lane by lane it goes out as 12-byte pieces 192 bytes apart (measured
 // 2.8 TB/s, scripts/ubench/sh_store.hip); staged through LDS ([float][lane], pitch 65: conflict-free both ways) the
 // wave writes its 12 KB as contiguous 16-byte stores (5.9 TB/s).  Taken when M == 16 and the tensor is 16-byte aligned.
+template <bool kRaw>
 __global__ void __launch_bounds__(256) preprocess_backward_kernel(BackwardArgs g, Camera cam) {
     __shared__ float s_stage[4][48 * kShStagePitch];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool staged = g.dL_dsh != nullptr && g.M == 16 && (reinterpret_cast<uintptr_t>(g.dL_dsh) & 15u) == 0;  // uniform
-    if (idx < g.P) preprocess_backward_lane(g, cam, idx, staged ? s_stage[wave] + lane : nullptr);
+    // (raw: the record leaves as _features_dc's 12 bytes and _features_rest's 180: both dense arrays, 16-byte aligned starts)
+    const bool staged = g.dL_dsh != nullptr && g.M == 16 &&
+                        (reinterpret_cast<uintptr_t>(kRaw ? g.dL_dsh_rest : g.dL_dsh) & 15u) == 0;  // uniform
+    if (idx < g.P) preprocess_backward_lane<kRaw>(g, cam, idx, staged ? s_stage[wave] + lane : nullptr);
     if (!staged) return;
     const int g0 = blockIdx.x * 256 + wave * 64;  // first Gaussian of this wave
     if (g0 >= g.P) return;
     __builtin_amdgcn_s_waitcnt(0);       // this wave's own LDS writes have landed
     __builtin_amdgcn_wave_barrier();
     const float* mine = s_stage[wave];
-    float4* dst = reinterpret_cast<float4*>(g.dL_dsh + 48 * (size_t)g0);
-    const int chunks = min(64, g.P - g0) * 12;
+    const int count = min(64, g.P - g0);
+    if (!kRaw) {
+        float4* dst = reinterpret_cast<float4*>(g.dL_dsh + 48 * (size_t)g0);
+        const int chunks = count * 12;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) {
-        const int c = k * 64 + lane;  // 16-byte chunk of the wave's 12 KB
-        if (c < chunks) {
-            const int gi = c / 12, f = (c - gi * 12) * 4;
-            dst[c] = make_float4(mine[(f + 0) * kShStagePitch + gi], mine[(f + 1) * kShStagePitch + gi],
-                                 mine[(f + 2) * kShStagePitch + gi], mine[(f + 3) * kShStagePitch + gi]);
+        for (int k = 0; k < 12; ++k) {
+            const int c = k * 64 + lane;  // 16-byte chunk of the wave's 12 KB
+            if (c < chunks) {
+                const int gi = c / 12, f = (c - gi * 12) * 4;
+                dst[c] = make_float4(mine[(f + 0) * kShStagePitch + gi], mine[(f + 1) * kShStagePitch + gi],
+                                     mine[(f + 2) * kShStagePitch + gi], mine[(f + 3) * kShStagePitch + gi]);
+            }
+        }
+    } else {
+        // coefficient 0 -> _features_dc's gradient: 12 bytes per Gaussian, neighbouring lanes neighbouring addresses
+        if (lane < count)
+            *reinterpret_cast<F3*>(g.dL_dsh + 3 * (size_t)(g0 + lane)) =
+                F3{mine[0 * kShStagePitch + lane], mine[1 * kShStagePitch + lane], mine[2 * kShStagePitch + lane]};
+        // coefficients 1..15 -> _features_rest's: the wave's 64 x 45 floats are one contiguous run (64 x 180 bytes, a multiple
+        // of 16), written as 16-byte chunks; float F of the run belongs to Gaussian F / 45, record float 3 + F % 45
+        float4* dst = reinterpret_cast<float4*>(g.dL_dsh_rest + 45 * (size_t)g0);
+        const int floats = count * 45;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int c = k * 64 + lane;
+            const int F = 4 * c;
+            if (F + 3 < floats) {
+                float v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int gi = (F + t) / 45, r = (F + t) - 45 * gi;
+                    v[t] = mine[(3 + r) * kShStagePitch + gi];
+                }
+                dst[c] = make_float4(v[0], v[1], v[2], v[3]);
+            } else if (F < floats) {   // (the last chunk of a ragged last wave)
+                for (int t = 0; F + t < floats; ++t) {
+                    const int gi = (F + t) / 45, r = (F + t) - 45 * gi;
+                    g.dL_dsh_rest[45 * (size_t)g0 + F + t] = mine[(3 + r) * kShStagePitch + gi];
+                }
+            }
         }
     }
 }
@@ -618,11 +761,16 @@ hipError_t launch_render_backward(const Camera& cam, const uint2* ranges, const 
                                   const float* background, const SplatRaster* raster, const float* colors,
                                   const float* accum_alphas,
                                   const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
-                                  const float* dL_dpix_alpha, float* accum, hipStream_t stream) {
+                                  const float* dL_dpix_alpha, float* accum, hipStream_t stream, int colour_slot) {
     const int T = cam.grid_x * cam.grid_y;
-    hipLaunchKernelGGL(render_backward_kernel, dim3(4 * T), dim3(64), 0, stream, cam.width, cam.height, cam.grid_x, T,
-                       ranges, point_list, background, raster, colors, accum_alphas, n_contrib,
-                       dL_dpix, dL_dpix_depth, dL_dpix_alpha, accum);
+    if (dL_dpix_depth != nullptr && dL_dpix_alpha != nullptr)
+        hipLaunchKernelGGL(render_backward_kernel<true>, dim3(4 * T), dim3(64), 0, stream, cam.width, cam.height, cam.grid_x, T,
+                           ranges, point_list, background, raster, colors, accum_alphas, n_contrib,
+                           dL_dpix, dL_dpix_depth, dL_dpix_alpha, accum, colour_slot);
+    else
+        hipLaunchKernelGGL(render_backward_kernel<false>, dim3(4 * T), dim3(64), 0, stream, cam.width, cam.height, cam.grid_x, T,
+                           ranges, point_list, background, raster, colors, accum_alphas, n_contrib,
+                           dL_dpix, nullptr, nullptr, accum, colour_slot);
     return hipGetLastError();
 }
 
@@ -635,7 +783,10 @@ hipError_t launch_preprocess_backward(const BackwardInputs& b, const Camera& cam
     g.dL_dcolor = b.dL_dcolor; g.dL_ddepth = b.dL_ddepth;
     g.dL_dmean3D = b.dL_dmean3D; g.dL_dcov3D = b.dL_dcov3D; g.dL_dsh = b.dL_dsh; g.dL_dscale = b.dL_dscale;
     g.dL_drot = b.dL_drot;
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3(div_up(b.P, 256)), dim3(256), 0, stream, g, cam);
+    g.raw = b.raw; g.shs_rest = b.shs_rest; g.opacity_logits = b.opacity_logits; g.dL_dsh_rest = b.dL_dsh_rest;
+    g.normal_grads = b.normal_grads; g.cam_pos_normals = cam.cam_pos;
+    if (b.raw) hipLaunchKernelGGL(preprocess_backward_kernel<true>, dim3(div_up(b.P, 256)), dim3(256), 0, stream, g, cam);
+    else hipLaunchKernelGGL(preprocess_backward_kernel<false>, dim3(div_up(b.P, 256)), dim3(256), 0, stream, g, cam);
     return hipGetLastError();
 }
 

@@ -268,13 +268,19 @@ struct BackwardInputs {
     float* dL_dsh;
     float* dL_dscale;
     float* dL_drot;
+    // gsr_backward_raw (gsr_backward.hip: BackwardArgs): raw inputs, gradients with respect to the raw parameters
+    int raw = 0;
+    const float* shs_rest = nullptr;
+    const float* opacity_logits = nullptr;
+    float* dL_dsh_rest = nullptr;
+    int normal_grads = 0;
 };
 hipError_t launch_render_backward(const Camera& cam, const uint2* ranges, const uint32_t* point_list,
                                   const float* background, const SplatRaster* raster, const float* colors,
                                   const float* accum_alphas,
                                   const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
                                   const float* dL_dpix_alpha, float* accum /*[P,16] floats, zero on entry*/,
-                                  hipStream_t stream);
+                                  hipStream_t stream, int colour_slot = 0 /*10: the pass over a call's second feature set*/);
 hipError_t launch_preprocess_backward(const BackwardInputs& b, const Camera& cam, hipStream_t stream);
 hipError_t launch_composite(int width, int height, const void* bg_c, const void* o_c, const float* o_d,
                             const void* s_c, const float* s_d, const void* o_s_c, const void* o_gs_c,

@@ -50,6 +50,47 @@ _RAW_ACTIVATIONS = (("scaling_activation", torch.exp), ("opacity_activation", to
                     ("rotation_activation", torch.nn.functional.normalize))
 
 
+# True: with autograd ON such a model is rendered by ONE full rasterizer call from the raw tensors as well (colour + normal
+# image in the same walk of the lists) and differentiated by gsr_backward_raw, which applies the activations' chain rule inside
+# the per-Gaussian kernel: a training iteration (scene_representation.py:495-520, train.py:84-134) runs one forward and one
+# backward pass of the rasterizer instead of ~25 PyTorch activation kernels, two forward passes and their autograd graph.
+# Same values forward (bit-identical images), gradients within the tolerance of sums formed with atomics
+# (tests/test_raw_autograd_gpu.py).  False: the reference's structure (PyTorch activations, two rasterizer calls).
+RAW_AUTOGRAD = True
+
+
+class _RasterizeRaw(torch.autograd.Function):
+    """``gsr_forward_raw`` (a full call) / ``gsr_backward_raw`` as one autograd node over the model's six raw tensors."""
+
+    @staticmethod
+    def forward(ctx, xyz, log_scales, rotations, opacity_logits, features_dc, features_rest, means2D, settings):
+        from diff_gaussian_rasterization import _C
+        s = settings
+        inference = not any(ctx.needs_input_grad)
+        (n, color, depth, alpha, radii, geom, binning, image, normal) = _C.rasterize_gaussians_raw(
+            s.bg, xyz, log_scales, rotations, opacity_logits, features_dc, features_rest, s.scale_modifier, s.viewmatrix, s.projmatrix,
+            s.tanfovx, s.tanfovy, s.image_height, s.image_width, s.sh_degree, s.campos, s.prefiltered, s.debug, want_normal=True,
+            inference=inference)
+        ctx.settings, ctx.num_rendered = s, n
+        ctx.save_for_backward(xyz, log_scales, rotations, opacity_logits, features_dc, features_rest, radii, geom, binning, image, alpha)
+        ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)   # an image the loss never read arrives as None: its pass / terms are skipped
+        return color, depth, alpha, radii, normal
+
+    @staticmethod
+    def backward(ctx, g_color, g_depth, g_alpha, _g_radii, g_normal):
+        from diff_gaussian_rasterization import _C
+        if g_color is None and g_depth is None and g_alpha is None and g_normal is None:
+            return (None,) * 8
+        s = ctx.settings
+        xyz, log_scales, rotations, opacity_logits, features_dc, features_rest, radii, geom, binning, image, alpha = ctx.saved_tensors
+        g2d, gxyz, gls, grot, gop, gdc, grest = _C.rasterize_gaussians_raw_backward(
+            s.bg, xyz, log_scales, rotations, opacity_logits, features_dc, features_rest, radii, s.scale_modifier, s.viewmatrix,
+            s.projmatrix, s.tanfovx, s.tanfovy, g_color, g_depth, g_alpha, g_normal, s.sh_degree, s.campos, geom, ctx.num_rendered,
+            binning, image, alpha, s.debug)
+        return gxyz, gls, grot, gop, gdc, grest, g2d, None
+
+
 def raw_parameters(pc):
     """The six raw tensors of ``pc`` when rendering from them is the same as rendering through its getters, else None:
     all six attributes are float32 tensors on one GPU with consistent shapes, and the model's activation functions -- the
@@ -229,9 +270,23 @@ def _render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_col
 
     # Straight from the model's raw parameters (gsr_forward_raw): no getter is called, nothing is activated in PyTorch.
     raw = None
-    if (RAW_PARAMETERS and FUSE_ELEMENTWISE and not torch.is_grad_enabled() and override_color is None
-            and not pipe.convert_SHs_python and not pipe.compute_cov3D_python):
+    if (RAW_PARAMETERS and FUSE_ELEMENTWISE and override_color is None and not pipe.convert_SHs_python
+            and not pipe.compute_cov3D_python and (RAW_AUTOGRAD or not torch.is_grad_enabled())):
         raw = raw_parameters(pc)
+    if raw is not None and torch.is_grad_enabled():
+        # one differentiable rasterizer call from the raw tensors; the per-pixel post-processing stays in PyTorch (:186-208),
+        # so whatever the loss reads -- RGBA, depth, normal map, pseudo normals -- carries its gradient back
+        rendered, depth_image, alpha_image, radii, normal_image = _RasterizeRaw.apply(*raw, screenspace_points, settings)
+        rendered_image = torch.cat((rendered, alpha_image), dim=0)
+        depth_image = depth_image.squeeze(0)
+        normal_image = (normal_image - 0.5) * 2.0
+        normal_image = torch.nn.functional.normalize(normal_image.permute(1, 2, 0), p=2, dim=-1)
+        directions = get_ray_directions(h, w, fx, fy, w / 2, h / 2, depth_image.device)
+        rays_d = directions @ c2w[:3, :3].T
+        rays_o = c2w[:3, 3].expand_as(rays_d)
+        pseudo_normal = depth_pcd2normal(rays_o + rays_d * depth_image.unsqueeze(-1))
+        return {"render": rendered_image, "depth": depth_image, "normal": normal_image, "pseudo_normal": pseudo_normal,
+                "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
     if raw is not None:
         from diff_gaussian_rasterization import _C
         s_ = settings

@@ -785,6 +785,9 @@ def main():
             rf["backward_kernel_ms"] = (bw.get("kernels") or {}).get("render_backward_kernel", {}).get("ms")
             rf["training_iteration_ms"] = bw.get("ms_per_iter")
             rf["training_iteration_reference_on_gpu_ms"] = (bw.get("reference_on_gpu") or {}).get("ms_per_iter")
+            tr = also.get("training_render_c3") or {}
+            rf["training_render_iteration_ms"] = tr.get("ms_per_iter")
+            rf["training_render_iteration_reference_structure_ms"] = tr.get("reference_structure_ms_per_iter")
             line["config"]["unchanged_render_frames_per_s"] = ur.get("value")
         if args.frames_digest and last_frames[0] is not None:
             import hashlib
@@ -853,6 +856,7 @@ def run_also(device, side, S, parity=True):
     guarded("c5_dynamic", lambda: dynamic_scene_bench(device, side, S))
     guarded("c3_reference_shaped_render", lambda: reference_shaped_render(device))
     guarded("backward_c3", lambda: backward_iteration("c3", device, parity=parity))
+    guarded("training_render_c3", lambda: training_render_iteration(device))
     return also
 
 
@@ -1048,6 +1052,51 @@ def reference_shaped_render(device, key="c3", frames=24):
     return out
 
 
+def training_render_iteration(device, key="c3", steps=10):
+    """One iteration of the reference's training loops AS THEY CALL IT (scene_representation.py:495-520: ``render()`` with
+    autograd on, an L1 loss on ``result["render"]``, ``loss.backward()``; no optimizer step) on the reference's model class
+    shape (``ReferenceGetters``, leaves = the six raw tensors).  Two ways on this library:
+
+    ms_per_iter                 render() differentiable from the raw tensors: one full rasterizer call (colour + normal image in
+                                one walk), gsr_backward_raw with the activations' chain rule in the per-Gaussian kernel
+    reference_structure_ms      renderer.RAW_AUTOGRAD = False: PyTorch activations + get_normal with their autograd graph, two
+                                complete GaussianRasterizer calls, gsr_backward, autograd through the activations
+    Same forward images bit for bit, gradients within the atomics tolerance (tests/test_raw_autograd_gpu.py)."""
+    from autovfx_amd import renderer
+    b = Bench(key, device, None, boundary="op")
+    m = ReferenceGetters(b.cloud, b.cloud.sh_degree)
+    params = ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")
+    for k in params:
+        setattr(m, k, getattr(m, k).detach().clone().requires_grad_(True))
+    target = torch.rand(4, b.H, b.W, device=device)
+    fr = [(10 + 7 * j) % b.F for j in range(steps)]
+    for f in fr:
+        b.cam(f)
+
+    def run(n=steps):
+        for f in fr[:n]:
+            for k in params:
+                getattr(m, k).grad = None
+            out = renderer.render(b.cam(f), m, renderer.PipelineParams, b.bg)
+            (out["render"] - target).abs().mean().backward()
+
+    def timed():
+        run(3)
+        secs = timed_regions(run, 3, False, device)
+        return sorted(secs)[1] / steps * 1e3
+
+    out = {"workload": b.name, "steps": steps, "loss": "L1 on render() RGBA (scene_representation.py:507-510 without SSIM / LPIPS)"}
+    out["ms_per_iter"] = round(timed(), 3)
+    try:
+        renderer.RAW_AUTOGRAD = False
+        out["reference_structure_ms_per_iter"] = round(timed(), 3)
+    finally:
+        renderer.RAW_AUTOGRAD = True
+    out["iters_per_s"] = round(1e3 / out["ms_per_iter"], 1)
+    out["speedup_vs_reference_structure"] = round(out["reference_structure_ms_per_iter"] / out["ms_per_iter"], 2)
+    return out
+
+
 def backward_iteration(key, device, steps=12, parity=True):
     """One training-style iteration (train.py:84-134 without the optimizer): forward (a FULL call: gradients are wanted),
     L1 + depth loss, ``loss.backward()``; HIP events around the halves, the two backward kernels timed by the library's
@@ -1061,6 +1110,7 @@ def backward_iteration(key, device, steps=12, parity=True):
     cloud_cpu = getattr(scenes, wl["cfg"])()
     cloud = cloud_cpu.to(device)
     cams_cpu = orbit_cameras(wl["frames"], W, H)
+    cams_dev = {i: cams_cpu[i].to(device) for i in range(0, 5 + steps + 1)}   # resident before any clock starts
     bg = torch.zeros(3, device=device)
     leaves = [t.clone().requires_grad_(True) for t in (cloud.means3D, cloud.opacities, cloud.shs, cloud.scales, cloud.rotations)]
     target = torch.rand(3, H, W, device=device)
@@ -1069,7 +1119,7 @@ def backward_iteration(key, device, steps=12, parity=True):
         m3, op, sh, sc, rot = leaves
         for t in leaves:
             t.grad = None
-        cam = cams_cpu[i].to(device)
+        cam = cams_dev[i]
         rast = GaussianRasterizer(settings_for_camera(cam, bg, 3))
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         e[0].record()
@@ -1115,7 +1165,7 @@ def backward_iteration(key, device, steps=12, parity=True):
                                                       "frac_of_hbm_peak": round(600 * P / max(1e-9, bw_k["preprocess_backward"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                                       "bound": "hbm"}},
            "timed_calls": bw_k["calls"]}
-    out["reference_on_gpu"] = reference_training_iteration(cloud, cams_cpu, bg, target, device, steps)
+    out["reference_on_gpu"] = reference_training_iteration(cloud, cams_cpu, bg, target, device, steps, cams_dev)
     if isinstance(out["reference_on_gpu"], dict) and "ms_per_iter" in out["reference_on_gpu"]:
         out["vs_reference_kernels"] = round(out["reference_on_gpu"]["ms_per_iter"] / out["ms_per_iter"], 2)
     if parity:
@@ -1152,7 +1202,7 @@ def backward_iteration(key, device, steps=12, parity=True):
     return out
 
 
-def reference_training_iteration(cloud, cams_cpu, bg, target, device, steps):
+def reference_training_iteration(cloud, cams_cpu, bg, target, device, steps, cams_dev=None):
     """The same training-style iteration through the REFERENCE's own kernels compiled for gfx950 (oracle/ref_hip.py:
     forward.cu + backward.cu + rasterizer_impl.cu, hipCUB for its CUB calls): forward, the same loss gradients formed in
     PyTorch, backward.  A measuring stick: what "matching the reference" means for an iteration on this GPU.  The reference
@@ -1167,7 +1217,7 @@ def reference_training_iteration(cloud, cams_cpu, bg, target, device, steps):
         dalpha = torch.zeros((1, H, W), device=device)
 
         def it(i, t):
-            cam = cams_cpu[i].to(device)
+            cam = cams_dev[i] if cams_dev is not None and i in cams_dev else cams_cpu[i].to(device)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             n, color, depth, alpha, radii = ref_hip.forward(cloud, cam, bg, outs)

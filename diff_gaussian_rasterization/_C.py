@@ -453,6 +453,51 @@ def rasterize_gaussians_raw_begin(background, xyz, log_scales, rotations, opacit
     return PendingForward(handle, device, stream, scratch, (tensors, None), outputs)
 
 
+def rasterize_gaussians_raw_backward(background, xyz, log_scales, rotations, opacity_logits, features_dc, features_rest, radii,
+                                     scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
+                                     dL_dout_alpha, dL_dout_normal, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
+                                     out_alpha, debug):
+    """Gradients of a full ``rasterize_gaussians_raw`` call with respect to the model's raw tensors (``gsr_backward_raw``):
+    returns ``(dL_dmeans2D, dL_dxyz, dL_dlog_scales, dL_drotations, dL_dopacity_logits, dL_dfeatures_dc, dL_dfeatures_rest)``.
+    ``dL_dout_depth`` / ``dL_dout_alpha`` / ``dL_dout_normal`` may be None (no gradient for that image)."""
+    device = _require_gpu(xyz, "xyz")
+    P = int(xyz.size(0))
+    H, W = int(out_alpha.size(-2)), int(out_alpha.size(-1))
+    M = 1 + int(features_rest.size(1))
+    z = lambda *shape: _new(shape, torch.float32, device)
+    g2d, gxyz, gls, grot, gop = z(P, 3), z(P, 3), z(P, 3), z(P, 4), z(*opacity_logits.shape)
+    gdc, grest = z(P, 1, 3), z(P, M - 1, 3)
+    if P != 0:
+        f = lambda n, t: _f32c(n, t, device)
+        fn_ = lambda n, t: None if t is None else f(n, t)
+        if dL_dout_color is None:
+            dL_dout_color = torch.zeros((3, H, W), dtype=torch.float32, device=device)
+        if (dL_dout_depth is None) != (dL_dout_alpha is None):
+            dL_dout_depth = torch.zeros((1, H, W), dtype=torch.float32, device=device) if dL_dout_depth is None else dL_dout_depth
+            dL_dout_alpha = torch.zeros((1, H, W), dtype=torch.float32, device=device) if dL_dout_alpha is None else dL_dout_alpha
+        tensors = [f(n, t) for n, t in (("background", background), ("xyz", xyz), ("log_scales", log_scales), ("rotations", rotations),
+                                        ("opacity_logits", opacity_logits), ("features_dc", features_dc), ("features_rest", features_rest),
+                                        ("viewmatrix", viewmatrix), ("projmatrix", projmatrix), ("campos", campos),
+                                        ("out_alpha", out_alpha), ("dL_dout_color", dL_dout_color))]
+        bg_, xyz_, ls_, rot_, op_, dc_, rest_, vm_, pm_, cp_, oa_, gc_ = tensors
+        gd_, ga_, gn_ = fn_("dL_dout_depth", dL_dout_depth), fn_("dL_dout_alpha", dL_dout_alpha), fn_("dL_dout_normal", dL_dout_normal)
+        radii_ = radii.contiguous()
+        if radii_.dtype != torch.int32:
+            raise RuntimeError(f"radii: expected an int32 tensor, got {radii_.dtype}")
+        raw = _lib.RawParams(_ptr(xyz_), _ptr(ls_), _ptr(rot_), _ptr(op_), _ptr(dc_), _ptr(rest_))
+        accum = _new((P, 16), torch.float32, device)   # cleared by the library
+        with torch.cuda.device(device):
+            rc = _lib.lib.gsr_backward_raw(
+                P, int(degree), M, int(R), _ptr(bg_), W, H, ctypes.byref(raw), float(scale_modifier), _ptr(vm_), _ptr(pm_), _ptr(cp_),
+                float(tan_fovx), float(tan_fovy), _ptr(radii_), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(oa_),
+                _ptr(gc_), _ptr(gd_), _ptr(ga_), _ptr(gn_), g2d.data_ptr(), gxyz.data_ptr(), gls.data_ptr(), grot.data_ptr(),
+                gop.data_ptr(), gdc.data_ptr(), grest.data_ptr() if M > 1 else None, accum.data_ptr(), 1 if debug else 0,
+                ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"gsr_backward_raw failed ({rc}): {_lib.last_error()}")
+    return g2d, gxyz, gls, grot, gop, gdc, grest
+
+
 def _blend_cached(hit, background, colors, device, H, W, out_color, out_depth, out_alpha):
     """Second pass over cached geometry: one blend launch over the first pass's lists (gsr_blend)."""
     geom, binning, image = hit["geom"], hit["binning"], hit["image"]
@@ -469,26 +514,41 @@ def _blend_cached(hit, background, colors, device, H, W, out_color, out_depth, o
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
                                  dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, out_alpha,
-                                 debug):
+                                 debug, *, skip_unused: bool = False):
     """Gradients of one forward call: the 24-argument backward of the reference
     (``DGR/rasterize_points.h:40-65``, ``DGR/rasterize_points.cu:121-209``), same order in, same 8-tuple out
-    ``(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)``."""
+    ``(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)``.
+    ``skip_unused`` (keyword only, not in the reference): gradients of inputs that were not given -- ``dL_dcolors`` with SH
+    colours, ``dL_dcov3D`` with scales and rotations -- and the two intermediates the reference computes but never returns
+    (conic, depth) are not written at all (56 bytes per Gaussian less); the skipped entries of the tuple are None."""
     device = _require_gpu(means3D, "means3D")
     P = int(means3D.size(0))
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
     M = int(sh.size(1)) if sh.numel() != 0 else 0
     # P == 0: nothing runs, the (empty) results are trivially defined; otherwise gsr_backward writes every element
     z = lambda *shape: _new(shape, torch.float32, device)
-    dL_dmeans3D, dL_dmeans2D, dL_dcolors = z(P, 3), z(P, 3), z(P, 3)
-    dL_ddepths, dL_dconic, dL_dopacity = z(P, 1), z(P, 2, 2), z(P, 1)   # the first two are intermediates
-    dL_dcov3D, dL_dsh, dL_dscales, dL_drotations = z(P, 6), z(P, M, 3), z(P, 3), z(P, 4)
+    want_colors = not (skip_unused and colors.numel() == 0)
+    want_cov = not (skip_unused and cov3D_precomp.numel() == 0)
+    dL_dmeans3D, dL_dmeans2D = z(P, 3), z(P, 3)
+    dL_dcolors = z(P, 3) if want_colors else None
+    dL_ddepths, dL_dconic = (None, None) if skip_unused else (z(P, 1), z(P, 2, 2))   # intermediates
+    dL_dopacity = z(P, 1)
+    dL_dcov3D = z(P, 6) if want_cov else None
+    dL_dsh, dL_dscales, dL_drotations = z(P, M, 3), z(P, 3), z(P, 4)
     if P != 0:
         f = lambda n, t: _f32c(n, t, device)
+        # (beyond the reference: dL_dout_depth / dL_dout_alpha may be None = all zeros -- a loss that only reads the colour image;
+        # the per-pixel pass then skips their terms.  One of them alone is completed with zeros.)
+        if (dL_dout_depth is None) != (dL_dout_alpha is None):
+            like = (H, W)
+            dL_dout_depth = torch.zeros((1, *like), dtype=torch.float32, device=device) if dL_dout_depth is None else dL_dout_depth
+            dL_dout_alpha = torch.zeros((1, *like), dtype=torch.float32, device=device) if dL_dout_alpha is None else dL_dout_alpha
+        fn_ = lambda n, t: None if t is None else f(n, t)
         bg_, m3_, sh_, col_, sc_, rot_, cov_, vm_, pm_, cp_, oa_, gc_, gd_, ga_ = (
             f("background", background), f("means3D", means3D), f("sh", sh), f("colors", colors), f("scales", scales),
             f("rotations", rotations), f("cov3D_precomp", cov3D_precomp), f("viewmatrix", viewmatrix),
             f("projmatrix", projmatrix), f("campos", campos), f("out_alpha", out_alpha),
-            f("dL_dout_color", dL_dout_color), f("dL_dout_depth", dL_dout_depth), f("dL_dout_alpha", dL_dout_alpha))
+            f("dL_dout_color", dL_dout_color), fn_("dL_dout_depth", dL_dout_depth), fn_("dL_dout_alpha", dL_dout_alpha))
         radii_ = radii.contiguous()
         if radii_.dtype != torch.int32:
             raise RuntimeError(f"radii: expected an int32 tensor, got {radii_.dtype}")
@@ -498,8 +558,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 P, int(degree), M, int(R), _ptr(bg_), W, H, _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(sc_),
                 float(scale_modifier), _ptr(rot_), _ptr(cov_), _ptr(vm_), _ptr(pm_), _ptr(cp_), float(tan_fovx),
                 float(tan_fovy), _ptr(radii_), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(oa_),
-                _ptr(gc_), _ptr(gd_), _ptr(ga_), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(),
-                dL_dcolors.data_ptr(), dL_ddepths.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
+                _ptr(gc_), _ptr(gd_), _ptr(ga_), dL_dmeans2D.data_ptr(), _ptr(dL_dconic), dL_dopacity.data_ptr(),
+                _ptr(dL_dcolors), _ptr(dL_ddepths), dL_dmeans3D.data_ptr(), _ptr(dL_dcov3D),
                 dL_dsh.data_ptr() if M else None, dL_dscales.data_ptr(), dL_drotations.data_ptr(), accum.data_ptr(),
                 1 if debug else 0,
                 ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))

@@ -84,6 +84,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buffer,
                               binning_buffer, img_buffer, alpha)
         ctx.mark_non_differentiable(radii)
+        # an output the loss never touched arrives in backward as None instead of a zero-filled image: the native backward
+        # then skips the depth / alpha terms altogether (include/gsr.h: gsr_backward)
+        ctx.set_materialize_grads(False)
         return color, depth, alpha, radii
 
     @staticmethod
@@ -91,14 +94,18 @@ class _RasterizeGaussians(torch.autograd.Function):
         s = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buffer, binning_buffer,
          img_buffer, alpha) = ctx.saved_tensors
+        if grad_out_color is None and grad_out_depth is None and grad_out_alpha is None:
+            return (None,) * 9
+        if grad_out_color is None:
+            grad_out_color = torch.zeros((3, alpha.shape[1], alpha.shape[2]), dtype=alpha.dtype, device=alpha.device)
         # positional order of DGR/rasterize_points.h:40-65
         native_args = (s.bg, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier, cov3Ds_precomp,
                        s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, grad_out_color, grad_out_depth,
                        grad_out_alpha, sh, s.sh_degree, s.campos, geom_buffer, ctx.num_rendered, binning_buffer,
                        img_buffer, alpha, s.debug)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
-         grad_rotations) = _call_with_snapshot(_C.rasterize_gaussians_backward, native_args, s.debug, _SNAPSHOT_BW,
-                                               "backward")
+         grad_rotations) = _call_with_snapshot(functools.partial(_C.rasterize_gaussians_backward, skip_unused=True), native_args,
+                                               s.debug, _SNAPSHOT_BW, "backward")
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
                 grad_rotations, grad_cov3Ds_precomp, None)
 

@@ -315,8 +315,12 @@ GSR_API int gsr_selftest_lds_atomic_order(uint32_t workgroups, uint32_t rounds, 
  *   geom/binning/image_buffer   the three scratch arenas of that call, untouched since (the pointers the
  *                     scratch callbacks returned); they are self-describing and are validated
  *   accum_alphas      the forward's out_alpha;  dL_dpix[3,H,W], dL_dpix_depth[H,W], dL_dpix_alpha[H,W]
+ *                     (the last two may both be NULL = all zeros: a loss that only looks at the colour image -- train.py:84-134,
+ *                     scene_representation.py:495-520 -- has no gradient for them, and the per-pixel pass then skips their terms;
+ *                     same gradients as with zero-filled arrays, ~10 % fewer instructions)
  *   outputs (every element is written: unlike the reference, whose binding zero-fills them first, :158-168,
- *   they may arrive with any content): dL_dmean2D[P,3],
+ *   they may arrive with any content; dL_dconic, dL_dcolor, dL_ddepth and dL_dcov3D may be NULL when the caller has no use
+ *   for them -- the first and third are intermediates the reference's binding never returns): dL_dmean2D[P,3],
  *   dL_dconic[P,4] (xx, xy, unused, yy), dL_dopacity[P], dL_dcolor[P,3], dL_ddepth[P], dL_dmean3D[P,3],
  *   dL_dcov3D[P,6], dL_dsh[P,M,3] (NULL allowed without shs), dL_dscale[P,3], dL_drot[P,4]
  *   accum_scratch     16*P floats of device memory, any content: the per-pixel pass sums each Gaussian's ten
@@ -334,10 +338,35 @@ GSR_API int gsr_backward(int P, int D, int M, int R, const float* background, in
                          const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
                          const int* radii /*nullable*/, const char* geom_buffer, const char* binning_buffer,
                          const char* image_buffer, const float* accum_alphas, const float* dL_dpix,
-                         const float* dL_dpix_depth, const float* dL_dpix_alpha, float* dL_dmean2D,
+                         const float* dL_dpix_depth /*nullable*/, const float* dL_dpix_alpha /*nullable*/, float* dL_dmean2D,
                          float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepth,
                          float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh /*nullable*/, float* dL_dscale,
                          float* dL_drot, float* accum_scratch /* 16*P floats, any content */, int debug, void* stream);
+
+/*
+ * Gradients of a gsr_forward_raw call (a FULL call: flags without GSR_FORWARD_INFERENCE) with respect to the model's RAW
+ * parameter tensors: gsr_backward with the activations' chain rule applied inside the per-Gaussian pass, i.e. what autograd
+ * produces for the reference's render() (gaussian_renderer/__init__.py:83-218 over scene/gaussian_model.py:95-128) --
+ *   dL_dlog_scales      = dL/d(scale) * scale                       (through exp)
+ *   dL_drotations       = (g - q (q . g)) / ||raw||                 (through F.normalize; g / 1e-12 below its clamp)
+ *   dL_dopacity_logits  = dL/d(opacity) * o (1 - o)                 (through sigmoid)
+ *   dL_dfeatures_dc [P,1,3], dL_dfeatures_rest [P,M-1,3]            (the two halves of dL_dsh: torch.cat's backward)
+ *   dL_dxyz [P,3], dL_dmean2D [P,3]                                 (as gsr_backward's dL_dmean3D / dL_dmean2D)
+ * -- without the ~1 GB of activated tensors and their gradients ever existing.  dL_dpix_normal (nullable) [3,H,W] is the
+ * gradient of the normal image the forward composited (out_normal): one more per-pixel pass over the same lists, its
+ * per-Gaussian colour gradient chained through get_normal / build_rotation to the quaternion (positions and scales enter the
+ * normal only through a sign and an argmin: no gradient, as in autograd).  dL_dpix_depth / dL_dpix_alpha: nullable as in
+ * gsr_backward.  radii / scratch buffers / accum_scratch / return value: as gsr_backward.  Every output element is written.
+ */
+GSR_API int gsr_backward_raw(int P, int D, int M, int R, const float* background, int width, int height,
+                             const gsr_raw_params* raw, float scale_modifier, const float* viewmatrix, const float* projmatrix,
+                             const float* cam_pos, float tan_fovx, float tan_fovy, const int* radii /*nullable*/,
+                             const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+                             const float* accum_alphas, const float* dL_dpix, const float* dL_dpix_depth /*nullable*/,
+                             const float* dL_dpix_alpha /*nullable*/, const float* dL_dpix_normal /*nullable*/,
+                             float* dL_dmean2D, float* dL_dxyz, float* dL_dlog_scales, float* dL_drotations,
+                             float* dL_dopacity_logits, float* dL_dfeatures_dc, float* dL_dfeatures_rest /*NULL iff M == 1*/,
+                             float* accum_scratch /* 16*P floats, any content */, int debug, void* stream);
 
 /* ---- introspection (used by the parity tests and bench.py; not part of the reference API) ---- */
 

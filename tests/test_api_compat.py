@@ -81,7 +81,11 @@ def test_native_module_surface():
         "prefiltered", "debug"]
     assert [n for n in params if n not in positional] == ["inference"] and params["inference"].default is False
     assert list(inspect.signature(_C.mark_visible).parameters) == ["means3D", "viewmatrix", "projmatrix"]
-    assert list(inspect.signature(_C.rasterize_gaussians_backward).parameters) == [
+    bw_params = inspect.signature(_C.rasterize_gaussians_backward).parameters
+    # (one keyword-only addition that defaults to the reference's behaviour: every gradient tensor is written and returned)
+    assert [n for n, p in bw_params.items() if p.kind is inspect.Parameter.KEYWORD_ONLY] == ["skip_unused"]
+    assert bw_params["skip_unused"].default is False
+    assert [n for n, p in bw_params.items() if p.kind is not inspect.Parameter.KEYWORD_ONLY] == [
         "background", "means3D", "radii", "colors", "scales", "rotations", "scale_modifier", "cov3D_precomp",
         "viewmatrix", "projmatrix", "tan_fovx", "tan_fovy", "dL_dout_color", "dL_dout_depth", "dL_dout_alpha", "sh",
         "degree", "campos", "geomBuffer", "R", "binningBuffer", "imageBuffer", "out_alpha", "debug"]

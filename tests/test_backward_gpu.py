@@ -256,6 +256,45 @@ def test_backward_c2_full_size_vs_oracle():
     check_case("c2_full_1M", cloud, cam, pg, hip, ref, KEYS_SH)
 
 
+def test_colour_only_loss_skips_the_depth_and_alpha_terms_with_the_same_gradients():
+    """A loss that reads only the colour image (the reference's training loops: train.py:84-134,
+    scene_representation.py:495-520) leaves depth and alpha without a gradient: autograd then hands None to the backward
+    (set_materialize_grads(False)), gsr_backward gets NULL for both images and the per-pixel pass runs without their terms.
+    Gradients must equal those of the same loss with explicit zero weights on depth and alpha (which takes the full kernel)
+    -- to the tolerance of sums formed with atomics -- and the oracle's."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = "cuda:0"
+    cloud, cam = scenes.config_c1(P=20_000, seed=61), orbit_cameras(8, 320, 200)[5]
+    pg = pixel_grads(cam, 12)
+    pg["dL_ddepth"] = np.zeros_like(pg["dL_ddepth"])
+    pg["dL_dalpha"] = np.zeros_like(pg["dL_dalpha"])
+    kw = oracle_kwargs(cloud, cam, bg=(0.2, 0.1, 0.3))
+    kw.update(pg)
+    ref = cpu_oracle.backward(**kw)
+    full = hip_backward(cloud, cam, pg, bg=(0.2, 0.1, 0.3))            # zero-filled depth / alpha gradients: every term runs
+    c = cloud.to(dev)
+    st = settings_for(cam, dev, (0.2, 0.1, 0.3), 1.0, cloud.sh_degree)
+    leaves = [t.clone().requires_grad_(True) for t in (c.means3D, c.opacities, c.shs, c.scales, c.rotations)]
+    means2D = torch.zeros_like(c.means3D, requires_grad=True)
+    color, depth, alpha, radii = GaussianRasterizer(st)(means3D=leaves[0], means2D=means2D, opacities=leaves[1], shs=leaves[2],
+                                                        scales=leaves[3], rotations=leaves[4])
+    (color * torch.from_numpy(pg["dL_dcolor"]).to(dev)).sum().backward()   # depth and alpha never enter the loss
+    torch.cuda.synchronize()
+    lean = {"dL_dmeans3D": leaves[0].grad, "dL_dmeans2D": means2D.grad, "dL_dopacity": leaves[1].grad, "dL_dsh": leaves[2].grad,
+            "dL_dscales": leaves[3].grad, "dL_drotations": leaves[4].grad}
+    lean = {k: v.cpu().numpy() for k, v in lean.items()}
+    compare("colour_only_vs_oracle", lean, ref, KEYS_SH)
+    compare("colour_only_vs_full_kernel", lean, full, KEYS_SH)
+    # a loss that touches nothing of the rasterizer's outputs but its depth: colour arrives as None and is zero-filled
+    for t in leaves:
+        t.grad = None
+    color, depth, alpha, radii = GaussianRasterizer(st)(means3D=leaves[0], means2D=torch.zeros_like(c.means3D), opacities=leaves[1],
+                                                        shs=leaves[2], scales=leaves[3], rotations=leaves[4])
+    depth.sum().backward()
+    assert leaves[0].grad is not None and torch.isfinite(leaves[0].grad).all() and float(leaves[0].grad.abs().sum()) > 0
+    assert float(leaves[2].grad.abs().sum()) == 0.0   # no colour gradient -> none for the SH coefficients
+
+
 def test_backward_c4_full_size_vs_oracle():
     """BASELINE configs[3] at bench size (200 k flat SuGaR-style Gaussians, colors_precomp, 960x540, SuGaR's off-centre
     principal-point camera, orbit frame 25): every gradient against the CPU oracle's backward."""
