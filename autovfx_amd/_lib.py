@@ -29,7 +29,7 @@ SYMBOLS = ("gsr_forward", "gsr_mark_visible", "gsr_backward", "gsr_last_geom_off
            "gsr_abi_version", "gsr_target_arch", "gsr_set_option", "gsr_get_option", "gsr_pack_rgba8", "gsr_last_pair_counts", "gsr_blend", "gsr_composite",
            "gsr_radix_scratch_bytes", "gsr_radix_sort_pairs", "gsr_selftest_exp", "gsr_view_normals", "gsr_normal_maps", "gsr_forward_extra", "gsr_get_call_times",
            "gsr_forward_begin", "gsr_forward_finish", "gsr_forward_ready", "gsr_forward_cancel", "gsr_last_slab_pairs", "gsr_plan_slabs", "gsr_selftest_lds_atomic_order", "gsr_get_backward_times", "gsr_place_object",
-           "gsr_forward_raw", "gsr_forward_raw_begin", "gsr_backward_raw")
+           "gsr_forward_raw", "gsr_forward_raw_begin", "gsr_backward_raw", "gsr_place_object_subset")
 OPT_TILE_CULL = 0
 OPT_SLABS = 1
 OPT_SLAB_FIRST = 2
@@ -116,6 +116,9 @@ def _load() -> ctypes.CDLL:
     lib.gsr_place_object.restype = ctypes.c_int
     lib.gsr_place_object.argtypes = [ctypes.c_int, c_f, c_f, c_f, c_f, c_f, ctypes.c_int, ctypes.POINTER(ctypes.c_float * 21),
                                      c_f, c_f, c_f, c_f, c_f, c_f, ctypes.c_void_p]
+    lib.gsr_place_object_subset.restype = ctypes.c_int
+    lib.gsr_place_object_subset.argtypes = [ctypes.c_int, c_f, c_f, c_f, c_f, c_f, c_f, ctypes.c_int, ctypes.POINTER(ctypes.c_float * 21),
+                                            c_f, c_f, c_f, c_f, c_f, c_f, ctypes.c_void_p]
     lib.gsr_selftest_exp.restype = ctypes.c_int
     lib.gsr_selftest_lds_atomic_order.restype = ctypes.c_int
     lib.gsr_selftest_lds_atomic_order.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]

@@ -564,22 +564,40 @@ int gsr_normal_maps(int width, int height, const float* normal_rgb, const float*
     return GSR_OK;
 }
 
-int gsr_place_object(int n, const float* xyz, const float* rotation_raw, const float* log_scale, const float* opacity, const float* shs,
-                     int M, const float* placement, float* out_means3D, float* out_scales, float* out_rotations, float* out_opacities,
-                     float* out_shs, float* out_min_axis, void* stream_) {
+namespace {
+int place_impl(int n, const uint32_t* subset, const float* xyz, const float* rotation_raw, const float* log_scale, const float* opacity,
+               const float* shs, int M, const float* placement, float* out_means3D, float* out_scales, float* out_rotations,
+               float* out_opacities, float* out_shs, float* out_min_axis, void* stream_, bool placement_required) {
     if (n < 0) return fail(GSR_ERR_INVALID_ARG, "bad size n=%d", n);
     if (n == 0) return GSR_OK;
-    if (!xyz || !rotation_raw || !log_scale || !placement || !out_means3D || !out_scales || !out_rotations)
+    if (!xyz || !rotation_raw || !log_scale || !out_means3D || !out_scales || !out_rotations || (placement_required && !placement))
         return fail(GSR_ERR_INVALID_ARG, "null pointer");
     if ((out_opacities != nullptr) != (opacity != nullptr) || (out_shs != nullptr) != (shs != nullptr))
         return fail(GSR_ERR_INVALID_ARG, "opacity / shs and their outputs must be given together");
     if (shs != nullptr && M <= 0) return fail(GSR_ERR_INVALID_ARG, "shs given with M=%d", M);
-    gsr::ObjectPlacement pl;
+    gsr::ObjectPlacement pl = {};
     static_assert(sizeof(gsr::ObjectPlacement) == 21 * sizeof(float), "the placement block is 21 floats");
-    memcpy(&pl, placement, sizeof pl);
-    GSR_HIP(gsr::launch_place_object(n, xyz, rotation_raw, log_scale, opacity, shs, M, pl, out_means3D, out_scales, out_rotations,
-                                     out_opacities, out_shs, out_min_axis, (hipStream_t)stream_));
+    if (placement != nullptr) memcpy(&pl, placement, sizeof pl);
+    GSR_HIP(gsr::launch_place_object(n, subset, placement != nullptr, xyz, rotation_raw, log_scale, opacity, shs, M, pl, out_means3D,
+                                     out_scales, out_rotations, out_opacities, out_shs, out_min_axis, (hipStream_t)stream_));
     return GSR_OK;
+}
+} // namespace
+
+int gsr_place_object(int n, const float* xyz, const float* rotation_raw, const float* log_scale, const float* opacity, const float* shs,
+                     int M, const float* placement, float* out_means3D, float* out_scales, float* out_rotations, float* out_opacities,
+                     float* out_shs, float* out_min_axis, void* stream_) {
+    return place_impl(n, nullptr, xyz, rotation_raw, log_scale, opacity, shs, M, placement, out_means3D, out_scales, out_rotations,
+                      out_opacities, out_shs, out_min_axis, stream_, true);
+}
+
+int gsr_place_object_subset(int m, const uint32_t* subset, const float* xyz, const float* rotation_raw, const float* log_scale,
+                            const float* opacity, const float* shs, int M, const float* placement, float* out_means3D,
+                            float* out_scales, float* out_rotations, float* out_opacities, float* out_shs, float* out_min_axis,
+                            void* stream_) {
+    if (m > 0 && !subset) return fail(GSR_ERR_INVALID_ARG, "null subset");
+    return place_impl(m, subset, xyz, rotation_raw, log_scale, opacity, shs, M, placement, out_means3D, out_scales, out_rotations,
+                      out_opacities, out_shs, out_min_axis, stream_, false);
 }
 
 int gsr_selftest_exp(uint32_t first_bits, uint32_t count, unsigned long long* device_mismatches, void* stream_) {

@@ -293,9 +293,10 @@ hipError_t launch_normal_maps(int width, int height, const float* normal_rgb, co
                               float fx, float fy, float cx, float cy, float* normal, float* pseudo, hipStream_t stream);
 // gsr_place_object (include/gsr.h): one object of a dynamic scene, raw parameters -> activated, at its place in the scene buffers
 struct ObjectPlacement { float c[3], R[9], s, c0[3], qR[4], log_s; };
-hipError_t launch_place_object(int n, const float* xyz, const float* rot, const float* log_scale, const float* opacity,
-                               const float* shs, int M, const ObjectPlacement& pl, float* out_xyz, float* out_scales, float* out_rot,
-                               float* out_opacity, float* out_shs, float* out_min_axis, hipStream_t stream);
+hipError_t launch_place_object(int n, const uint32_t* subset /*nullable: output j <- input subset[j]*/, bool transform,
+                               const float* xyz, const float* rot, const float* log_scale, const float* opacity, const float* shs, int M,
+                               const ObjectPlacement& pl, float* out_xyz, float* out_scales, float* out_rot, float* out_opacity,
+                               float* out_shs, float* out_min_axis, hipStream_t stream);
 hipError_t launch_pack_rgba8(const float* color, const float* alpha, uint8_t* out, size_t n_pixels,
                              hipStream_t stream);
 

@@ -719,7 +719,12 @@ __global__ void __launch_bounds__(256) normal_maps_kernel(NormalMapArgs a) {
 // the scene, a PLY reload, ~10 PyTorch launches and a concatenation of everything, per frame.  One lane per Gaussian;
 // every arithmetic step is a separate fp32 rounding in the reference's order (the library is built without contraction).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) place_object_kernel(int n, const float* __restrict__ xyz, const float* __restrict__ rot,
+// `subset` (nullable): ascending indices of the object's Gaussians to take -- output j comes from input subset[j] (the melting
+// branch of the frame loop, scene_representation.py:409-418: `orig_gaussians._xyz[mask]` ... merged as they are).
+// `transform` = 0: no rigid transform at all -- positions are copied, the raw quaternion is only normalised (that branch never
+// calls transform_gaussians, so not even the identity's roundings may be applied).
+__global__ void __launch_bounds__(256) place_object_kernel(int n, const uint32_t* __restrict__ subset, int transform,
+                                                           const float* __restrict__ xyz, const float* __restrict__ rot,
                                                            const float* __restrict__ log_scale, const float* __restrict__ opacity,
                                                            const float* __restrict__ shs, int M, ObjectPlacement pl,
                                                            float* __restrict__ out_xyz, float* __restrict__ out_scales,
@@ -727,62 +732,86 @@ __global__ void __launch_bounds__(256) place_object_kernel(int n, const float* _
                                                            float* __restrict__ out_shs, float* __restrict__ out_min_axis) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) {
-        // gaussians_utils.py:94-96 (scale about the initial centre), :100-102 (rotate about it), :106-107 (translate)
-        const F3 p = ld3(xyz + 3 * (size_t)i);
-        float v[3] = {p.x, p.y, p.z};
+        const size_t src = subset != nullptr ? (size_t)subset[i] : (size_t)i;
+        const F3 p = ld3(xyz + 3 * src);
+        const F3 ls = ld3(log_scale + 3 * src);
+        const F4 b = *reinterpret_cast<const F4*>(rot + 4 * src);
+        F3 sc;
+        F4 qn;
+        if (transform) {
+            // gaussians_utils.py:94-96 (scale about the initial centre), :100-102 (rotate about it), :106-107 (translate)
+            float v[3] = {p.x, p.y, p.z};
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            v[k] = v[k] - pl.c0[k];
-            v[k] = v[k] * pl.s;
-            v[k] = v[k] + pl.c0[k];
-            v[k] = v[k] - pl.c0[k];
+            for (int k = 0; k < 3; ++k) {
+                v[k] = v[k] - pl.c0[k];
+                v[k] = v[k] * pl.s;
+                v[k] = v[k] + pl.c0[k];
+                v[k] = v[k] - pl.c0[k];
+            }
+            float w[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) w[j] = (v[0] * pl.R[3 * j + 0] + v[1] * pl.R[3 * j + 1]) + v[2] * pl.R[3 * j + 2];   // new_xyz @ R.T
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                w[k] = w[k] + pl.c0[k];
+                w[k] = w[k] + (pl.c[k] - pl.c0[k]);
+            }
+            *reinterpret_cast<F3*>(out_xyz + 3 * (size_t)i) = F3{w[0], w[1], w[2]};
+            // :97 new_scales += log(scaling), then exp (gaussian_model.py:96-97)
+            sc = F3{expf(ls.x + pl.log_s), expf(ls.y + pl.log_s), expf(ls.z + pl.log_s)};
+            // :103 quaternion_multiply(matrix_to_quaternion(R), q) (rotation_utils.py:113-135), then F.normalize (gaussian_model.py:100-101)
+            const float aw = pl.qR[0], ax = pl.qR[1], ay = pl.qR[2], az = pl.qR[3];
+            float ow = aw * b.x - ax * b.y - ay * b.z - az * b.w;
+            float ox = aw * b.y + ax * b.x + ay * b.w - az * b.z;
+            float oy = aw * b.z - ax * b.w + ay * b.x + az * b.y;
+            float oz = aw * b.w + ax * b.z - ay * b.y + az * b.x;
+            if (ow < 0.f) { ow = -ow; ox = -ox; oy = -oy; oz = -oz; }   // standardize_quaternion
+            qn = torch_normalize4(F4{ow, ox, oy, oz});
+        } else {
+            *reinterpret_cast<F3*>(out_xyz + 3 * (size_t)i) = p;
+            sc = F3{expf(ls.x), expf(ls.y), expf(ls.z)};
+            qn = torch_normalize4(b);
         }
-        float w[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) w[j] = (v[0] * pl.R[3 * j + 0] + v[1] * pl.R[3 * j + 1]) + v[2] * pl.R[3 * j + 2];   // new_xyz @ R.T
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            w[k] = w[k] + pl.c0[k];
-            w[k] = w[k] + (pl.c[k] - pl.c0[k]);
-        }
-        *reinterpret_cast<F3*>(out_xyz + 3 * (size_t)i) = F3{w[0], w[1], w[2]};
-        // :97 new_scales += log(scaling), then exp (gaussian_model.py:96-97)
-        const F3 ls = ld3(log_scale + 3 * (size_t)i);
-        const F3 sc = F3{expf(ls.x + pl.log_s), expf(ls.y + pl.log_s), expf(ls.z + pl.log_s)};
         *reinterpret_cast<F3*>(out_scales + 3 * (size_t)i) = sc;
-        // :103 quaternion_multiply(matrix_to_quaternion(R), q) (rotation_utils.py:113-135), then F.normalize (gaussian_model.py:100-101)
-        const F4 b = *reinterpret_cast<const F4*>(rot + 4 * (size_t)i);
-        const float aw = pl.qR[0], ax = pl.qR[1], ay = pl.qR[2], az = pl.qR[3];
-        float ow = aw * b.x - ax * b.y - ay * b.z - az * b.w;
-        float ox = aw * b.y + ax * b.x + ay * b.w - az * b.z;
-        float oy = aw * b.z - ax * b.w + ay * b.x + az * b.y;
-        float oz = aw * b.w + ax * b.z - ay * b.y + az * b.x;
-        if (ow < 0.f) { ow = -ow; ox = -ox; oy = -oy; oz = -oz; }   // standardize_quaternion
-        const F4 qn = torch_normalize4(F4{ow, ox, oy, oz});
         *reinterpret_cast<F4*>(out_rot + 4 * (size_t)i) = qn;
-        if (out_opacity != nullptr) out_opacity[i] = opacity[i];
+        if (out_opacity != nullptr) out_opacity[i] = opacity[src];
         if (out_min_axis != nullptr) {
             // general_utils.py:78-101 build_rotation (normalises once more) and :135-141 get_minimum_axis (gsr_device.h: min_axis)
             const F3 col = min_axis(sc, qn);
             *reinterpret_cast<F3*>(out_min_axis + 3 * (size_t)i) = col;
         }
     }
-    if (out_shs != nullptr) {   // the object's SH block copied as one contiguous run: 3 M floats per Gaussian, 16-byte pieces
-        const size_t words = (size_t)n * 3u * (size_t)M;
-        for (size_t w4 = (size_t)blockIdx.x * 256u + threadIdx.x; w4 * 4u < words; w4 += (size_t)gridDim.x * 256u) {
-            if (w4 * 4u + 3u < words && ((reinterpret_cast<uintptr_t>(shs) | reinterpret_cast<uintptr_t>(out_shs)) & 15u) == 0)
-                reinterpret_cast<float4*>(out_shs)[w4] = reinterpret_cast<const float4*>(shs)[w4];
-            else
-                for (size_t k = w4 * 4u; k < words && k < w4 * 4u + 4u; ++k) out_shs[k] = shs[k];
+    if (out_shs != nullptr) {
+        const bool vec = ((reinterpret_cast<uintptr_t>(shs) | reinterpret_cast<uintptr_t>(out_shs)) & 15u) == 0;
+        if (subset == nullptr) {   // the object's SH block copied as one contiguous run: 3 M floats per Gaussian, 16-byte pieces
+            const size_t words = (size_t)n * 3u * (size_t)M;
+            for (size_t w4 = (size_t)blockIdx.x * 256u + threadIdx.x; w4 * 4u < words; w4 += (size_t)gridDim.x * 256u) {
+                if (w4 * 4u + 3u < words && vec)
+                    reinterpret_cast<float4*>(out_shs)[w4] = reinterpret_cast<const float4*>(shs)[w4];
+                else
+                    for (size_t k = w4 * 4u; k < words && k < w4 * 4u + 4u; ++k) out_shs[k] = shs[k];
+            }
+        } else if (vec && (3 * M) % 4 == 0) {   // row j <- row subset[j], 16-byte pieces of a row
+            const size_t per_row = (size_t)(3 * M / 4), chunks = (size_t)n * per_row;
+            for (size_t c = (size_t)blockIdx.x * 256u + threadIdx.x; c < chunks; c += (size_t)gridDim.x * 256u) {
+                const size_t row = c / per_row, q = c - row * per_row;
+                reinterpret_cast<float4*>(out_shs)[c] = reinterpret_cast<const float4*>(shs)[(size_t)subset[row] * per_row + q];
+            }
+        } else {
+            const size_t per_row = (size_t)(3 * M), words = (size_t)n * per_row;
+            for (size_t k = (size_t)blockIdx.x * 256u + threadIdx.x; k < words; k += (size_t)gridDim.x * 256u) {
+                const size_t row = k / per_row;
+                out_shs[k] = shs[(size_t)subset[row] * per_row + (k - row * per_row)];
+            }
         }
     }
 }
 
-hipError_t launch_place_object(int n, const float* xyz, const float* rot, const float* log_scale, const float* opacity,
-                               const float* shs, int M, const ObjectPlacement& pl, float* out_xyz, float* out_scales, float* out_rot,
-                               float* out_opacity, float* out_shs, float* out_min_axis, hipStream_t stream) {
-    hipLaunchKernelGGL(place_object_kernel, dim3(div_up(n, 256)), dim3(256), 0, stream, n, xyz, rot, log_scale, opacity, shs, M, pl, out_xyz,
-                       out_scales, out_rot, out_opacity, out_shs, out_min_axis);
+hipError_t launch_place_object(int n, const uint32_t* subset, bool transform, const float* xyz, const float* rot, const float* log_scale,
+                               const float* opacity, const float* shs, int M, const ObjectPlacement& pl, float* out_xyz, float* out_scales,
+                               float* out_rot, float* out_opacity, float* out_shs, float* out_min_axis, hipStream_t stream) {
+    hipLaunchKernelGGL(place_object_kernel, dim3(div_up(n, 256)), dim3(256), 0, stream, n, subset, transform ? 1 : 0, xyz, rot, log_scale,
+                       opacity, shs, M, pl, out_xyz, out_scales, out_rot, out_opacity, out_shs, out_min_axis);
     return hipGetLastError();
 }
 

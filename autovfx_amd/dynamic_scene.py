@@ -136,28 +136,61 @@ class DynamicScene:
     def compose(self, placements: Iterable[Tuple[str, Sequence[float], Sequence[Sequence[float]], float]], slot: int = 0) -> GaussianCloud:
         """``placements``: the objects present in this frame, in merge order, each ``(object_id, center[3], rotation[3][3],
         scaling)`` -- ``rb_transform['pos'], ['rot'], ['scale']`` of ``scene_representation.py:364-366``.  An object may be
-        placed more than once (the buffers then need room for it: ``ValueError`` otherwise)."""
+        placed more than once (the buffers then need room for it: ``ValueError`` otherwise).
+
+        A fifth entry selects a SUBSET of the object's Gaussians: a boolean mask of length n (numpy / torch, host or GPU) or
+        an int tensor of ascending indices -- the melting branch of the frame loop (``scene_representation.py:373-421``: the
+        Gaussians whose closest mesh triangle survives in the frame's melting mesh, ``orig_gaussians._xyz[mask]`` ... merged
+        as they are).  That branch applies no transform: pass ``center = rotation = scaling = None`` and the subset is merged
+        untouched (positions bit for bit), exactly as the reference merges it; with a transform the subset is moved like a
+        whole object would be."""
         from . import _lib
         means3D, scales, rotations, opacities, shs, min_axis = self._slots[slot % len(self._slots)]
         at = self.P_base
         placements = list(placements)
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         with torch.cuda.device(self.device):
-            for obj_id, center, rotation, scaling in placements:
+            for entry in placements:
+                obj_id, center, rotation, scaling = entry[:4]
+                subset = self._subset_indices(entry[4], self.objects[obj_id].P) if len(entry) > 4 and entry[4] is not None else None
                 o = self.objects[obj_id]
-                if at + o.P > self.capacity:
+                count = o.P if subset is None else int(subset.numel())
+                if at + count > self.capacity:
                     raise ValueError("the scene buffers have no room for another copy of " + repr(obj_id))
-                block = (ctypes.c_float * 21)(*placement_block(center, rotation, scaling, o.initial_center).tolist())
-                rc = _lib.lib.gsr_place_object(
-                    o.P, o.xyz.data_ptr(), o.rotation.data_ptr(), o.log_scale.data_ptr(), o.opacity.data_ptr(), o.shs.data_ptr(), self.M,
-                    ctypes.byref(block), means3D[at:].data_ptr(), scales[at:].data_ptr(), rotations[at:].data_ptr(),
-                    opacities[at:].data_ptr(), shs[at:].data_ptr(), min_axis[at:].data_ptr(), stream)
+                if center is None and (rotation is not None or scaling is not None):
+                    raise ValueError("an untransformed placement has center = rotation = scaling = None")
+                block = None if center is None else (ctypes.c_float * 21)(*placement_block(center, rotation, scaling, o.initial_center).tolist())
+                outs = (means3D[at:].data_ptr(), scales[at:].data_ptr(), rotations[at:].data_ptr(), opacities[at:].data_ptr(),
+                        shs[at:].data_ptr(), min_axis[at:].data_ptr(), stream)
+                if count == 0:
+                    continue
+                if subset is None and block is not None:
+                    rc = _lib.lib.gsr_place_object(o.P, o.xyz.data_ptr(), o.rotation.data_ptr(), o.log_scale.data_ptr(), o.opacity.data_ptr(),
+                                                   o.shs.data_ptr(), self.M, ctypes.byref(block), *outs)
+                else:
+                    if subset is None:   # the whole object, untransformed
+                        subset = torch.arange(o.P, dtype=torch.int32, device=self.device)
+                    self._keep_alive = getattr(self, "_keep_alive", [])[-8:] + [subset]   # (the kernel reads it after this call returns)
+                    rc = _lib.lib.gsr_place_object_subset(count, subset.data_ptr(), o.xyz.data_ptr(), o.rotation.data_ptr(),
+                                                          o.log_scale.data_ptr(), o.opacity.data_ptr(), o.shs.data_ptr(), self.M,
+                                                          None if block is None else ctypes.byref(block), *outs)
                 if rc != 0:
                     raise RuntimeError(f"gsr_place_object failed ({rc}): {_lib.last_error()}")
-                at += o.P
+                at += count
         self._last_min_axis = min_axis[:at]
         degree = self.sh_degree if (not placements or self.placed_sh_degree is None) else self.placed_sh_degree
         return GaussianCloud(means3D[:at], opacities[:at], scales[:at], rotations[:at], shs[:at], None, degree)
+
+    def _subset_indices(self, sel, n: int) -> torch.Tensor:
+        """A mask or index list -> ascending int32 indices on the scene's device."""
+        t = torch.as_tensor(sel)
+        if t.dtype == torch.bool:
+            if t.numel() != n:
+                raise ValueError(f"subset mask has {t.numel()} entries, the object {n} Gaussians")
+            t = torch.nonzero(t.reshape(-1), as_tuple=False).reshape(-1)
+        elif t.numel() and (int(t.min()) < 0 or int(t.max()) >= n):
+            raise ValueError("subset indices out of range")
+        return t.to(device=self.device, dtype=torch.int32).contiguous()
 
     def compose_model(self, placements, slot: int = 0) -> FrameModel:
         """``compose`` for callers of ``render()`` (``autovfx_amd.renderer.render`` or the reference's own): the frame as an

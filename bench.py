@@ -911,6 +911,17 @@ def dynamic_scene_bench(device, side, S, frames=120):
     out["static_ms_per_frame"] = round(timed(lambda: serial(lambda f: static_cloud)), 4)
     out["ms_per_frame"] = round(timed(lambda: serial(lambda f: scene.compose(place(f)))), 4)
     out["reference_shaped_ms_per_frame"] = round(timed(lambda: serial(lambda f: reference_shaped_compose(base, objs, place(f), device))), 4)
+    # the melting branch (scene_representation.py:373-421): per frame a different masked subset of each object is merged
+    # untransformed (gsr_place_object_subset); the masks are resident index lists, as a caller that matched meshes once would hold
+    g = torch.Generator(device="cpu").manual_seed(3)
+    n_obj = {k: int(m._xyz.shape[0]) for k, (m, _c) in objs.items()}
+    subsets = [{k: torch.nonzero(torch.rand(n, generator=g) < (0.25 + 0.5 * ((f * 7 + j) % 5) / 4)).reshape(-1).to(torch.int32).to(device)
+                for j, (k, n) in enumerate(n_obj.items())} for f in range(8)]
+    masked = lambda f: [(k, None, None, None, subsets[f % 8][k]) for k in n_obj]
+    static_masked = scene.compose(masked(0))
+    out["masked_static_ms_per_frame"] = round(timed(lambda: serial(lambda f: static_masked)), 4)
+    out["masked_ms_per_frame"] = round(timed(lambda: serial(lambda f: scene.compose(masked(f)))), 4)
+    out["masked_vs_static"] = round(out["masked_static_ms_per_frame"] / out["masked_ms_per_frame"], 3)
     out["value"] = round(1e3 / out["ms_per_frame"], 1)
     out["unit"] = "frames/s"
     out["vs_static"] = round(out["static_ms_per_frame"] / out["ms_per_frame"], 3)

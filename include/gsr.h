@@ -295,6 +295,18 @@ GSR_API int gsr_place_object(int n, const float* xyz, const float* rotation_raw,
                              float* out_rotations, float* out_opacities /*nullable*/, float* out_shs /*nullable*/,
                              float* out_min_axis /*[n,3], nullable*/, void* stream);
 
+/* gsr_place_object for a SUBSET of an object's Gaussians: output j is built from input subset[j] (m ascending indices into the
+ * object's arrays, device memory) -- the melting branch of the reference's frame loop (scene_representation.py:373-421), which
+ * merges `orig_gaussians._xyz[mask]`, `._rotation[mask]`, ... of every melting mesh into the scene for one frame.  That branch
+ * applies NO rigid transform: with placement == NULL positions are copied bit for bit, the raw quaternion is only normalised,
+ * scale = exp(log_scale) (passing an identity placement instead would apply the identity's roundings, which the reference
+ * does not).  With a placement the subset is transformed like gsr_place_object transforms the whole object. */
+GSR_API int gsr_place_object_subset(int m, const uint32_t* subset, const float* xyz, const float* rotation_raw,
+                                    const float* log_scale, const float* opacity /*nullable*/, const float* shs /*nullable*/, int M,
+                                    const float* placement /*host, 21 floats; NULL = untransformed*/, float* out_means3D,
+                                    float* out_scales, float* out_rotations, float* out_opacities /*nullable*/,
+                                    float* out_shs /*nullable*/, float* out_min_axis /*[m,3], nullable*/, void* stream);
+
 /* Self-test of the blend kernel's exp(): adds to *device_mismatches (a zeroed device u64) the number of floats
  * with bit patterns first_bits .. first_bits + count - 1 whose exp differs from the device library's expf.
  * The blend evaluates exp only for arguments <= 0; tests sweep every float of [-103, 0]. */

@@ -87,11 +87,19 @@ def placement_block(center, R, scaling, initial_center) -> np.ndarray:
 
 def compose(base, placements, base_sh_degree=3):
     """``base`` and every placed object: dicts of RAW arrays ``xyz, rotation, log_scale, opacity_raw, features_dc,
-    features_rest``; ``placements``: list of ``(object, center, R, scaling, initial_center)`` in merge order.  Returns the
+    features_rest``; ``placements``: list of ``(object, center, R, scaling, initial_center[, mask])`` in merge order; a mask selects a subset of
+    the object, ``center = None`` merges it untransformed (the melting branch).  Returns the
     ACTIVATED arrays the rasterizer receives from the merged model: means3D, scales, rotations, opacities [P,1], shs [P,M,3]."""
     parts = {k: [np.asarray(base[k], dtype=f32)] for k in ("xyz", "rotation", "log_scale", "opacity_raw", "features_dc", "features_rest")}
-    for obj, center, R, scaling, c0 in placements:
-        x, q, ls = transform_raw(obj["xyz"], obj["rotation"], obj["log_scale"], center, R, scaling, c0)
+    for entry in placements:
+        obj, center, R, scaling, c0 = entry[:5]
+        if len(entry) > 5 and entry[5] is not None:   # a subset of the object (scene_representation.py:409-416: `orig._xyz[mask]` ...)
+            mask = np.asarray(entry[5])
+            obj = {k: np.asarray(v)[mask] for k, v in obj.items()}
+        if center is None:   # the melting branch merges the subset as it is: no transform_gaussians call (:417)
+            x, q, ls = obj["xyz"], obj["rotation"], obj["log_scale"]
+        else:
+            x, q, ls = transform_raw(obj["xyz"], obj["rotation"], obj["log_scale"], center, R, scaling, c0)
         for k, v in (("xyz", x), ("rotation", q), ("log_scale", ls), ("opacity_raw", obj["opacity_raw"]),
                      ("features_dc", obj["features_dc"]), ("features_rest", obj["features_rest"])):
             parts[k].append(np.asarray(v, dtype=f32))

@@ -27,8 +27,17 @@ def reference_shaped_compose(base, objects: Dict[str, Tuple[object, Sequence[flo
     measuring stick for ``DynamicScene`` (bench.py ``also.c5_dynamic``) and its on-GPU parity partner (tests)."""
     t = lambda a: a.detach().to(device=device, dtype=torch.float32)
     parts = {k: [t(getattr(base, k)).clone()] for k in ("_xyz", "_rotation", "_scaling", "_opacity", "_features_dc", "_features_rest")}
-    for obj_id, center, rotation, scaling in placements:
+    for entry in placements:
+        obj_id, center, rotation, scaling = entry[:4]
         m, c0 = objects[obj_id]
+        if len(entry) > 4 and entry[4] is not None:   # the melting branch (scene_representation.py:409-417): boolean-mask indexing
+            mask = torch.as_tensor(np.asarray(entry[4]), device=device)
+            sub = {k: t(getattr(m, k))[mask] for k in ("_xyz", "_rotation", "_scaling", "_opacity", "_features_dc", "_features_rest")}
+            if center is None:   # merged as it is
+                for k, v in sub.items():
+                    parts[k].append(v)
+                continue
+            m = type("Subset", (), sub)
         c0 = torch.as_tensor(np.asarray(c0, np.float32), device=device)
         center = torch.as_tensor(np.asarray(center, np.float32), device=device)
         R = torch.as_tensor(np.asarray(rotation, np.float32).reshape(3, 3), device=device)

@@ -244,3 +244,82 @@ def test_an_object_placed_twice_needs_room_and_says_so():
     with pytest.raises(ValueError, match="no room"):
         scene.compose(two + [("chair", (0, 1, 0), np.eye(3), 1.0)])
     assert scene.compose(two[:1]).P == 1000 + 400
+
+
+# ---------------------------------------------------------------- masked subsets: the melting branch ----------------------------------------------------------------
+def melting_frames(objs, seed=0):
+    """Frames as the melting branch builds them (scene_representation.py:373-421): per object up to two melting meshes, each
+    keeping the Gaussians whose closest mesh triangle survives -- here random masks of different densities, one empty, one full."""
+    g = np.random.default_rng(seed)
+    n = {k: int(m._xyz.shape[0]) for k, (m, _c) in objs.items()}
+    mask = lambda k, p: g.random(n[k]) < p
+    return [
+        [("chair", None, None, None, mask("chair", 0.6))],
+        [("chair", None, None, None, mask("chair", 0.3)), ("chair", None, None, None, mask("chair", 0.1)), ("ball", None, None, None, mask("ball", 0.9))],
+        [("ball", None, None, None, np.zeros(n["ball"], bool)), ("chair", None, None, None, np.ones(n["chair"], bool))],
+        [("ball", (0.2, 0.1, 0.0), rot((0, 1, 0), 30), 1.2, mask("ball", 0.5))],   # a subset that IS transformed
+    ]
+
+
+def test_masked_merge_restatement_matches_boolean_indexing():
+    base, objs = models()
+    for frame in melting_frames(objs):
+        got = dyn.compose(raw(base), [(raw(objs[e[0]][0]), e[1], e[2], e[3], objs[e[0]][1], e[4]) for e in frame])
+        want_xyz = [base._xyz.numpy()]
+        for name, center, R, s, mask in frame:
+            if center is None:
+                want_xyz.append(objs[name][0]._xyz.numpy()[mask])
+        if all(e[1] is None for e in frame):
+            np.testing.assert_array_equal(got["means3D"], np.concatenate(want_xyz))
+        assert got["means3D"].shape[0] == base._xyz.shape[0] + sum(int(np.asarray(e[4]).sum()) for e in frame)
+        assert got["active_sh_degree"] == 0
+
+
+@pytest.mark.gpu
+def test_masked_subsets_are_merged_bit_for_bit_and_render_like_subset_then_merge():
+    """``DynamicScene.compose`` with masks against the reference's sequence in PyTorch on the same GPU -- boolean-mask indexing
+    of the six raw tensors, merge_two_gaussians, activation -- every composed tensor ``torch.equal`` (untransformed subsets are
+    copied, never touched), and the rendered frame bit-identical."""
+    from autovfx_amd.cameras import orbit_cameras
+    from autovfx_amd.dynamic_scene import DynamicScene
+    from autovfx_amd.frame_parallel import rasterize
+    from oracle.dynamic_torch import reference_shaped_compose
+    base, objs = models(P_base=30_000, P_obj=5000, seed=7)
+    frames = melting_frames(objs, seed=3)
+    cap_objs = {k: v for k, v in objs.items()}
+    scene = DynamicScene(base, {**cap_objs, "chair2": objs["chair"]})   # room for the frame that merges two chair subsets
+    frames = [[("chair2" if (i > 0 and e[0] == "chair" and any(p[0] == "chair" for p in fr[:i])) else e[0],) + tuple(e[1:])
+               for i, e in enumerate(fr)] for fr in frames]
+    objs_t = {**objs, "chair2": objs["chair"]}
+    dev = torch.device("cuda:0")
+    bg = torch.tensor([0.1, 0.0, 0.2], device=dev)
+    cams = orbit_cameras(len(frames), 320, 180)
+    for fi, frame in enumerate(frames):
+        cam = cams[fi].to(dev)
+        with torch.no_grad():
+            cloud = scene.compose(frame)
+            got = [t.clone() for t in rasterize(cloud, cam, bg)]
+            ref_cloud = reference_shaped_compose(base, objs_t, frame, dev)
+            want = rasterize(ref_cloud, cam, bg)
+        torch.cuda.synchronize()
+        assert cloud.P == ref_cloud.P == scene.P_base + sum(int(np.asarray(e[4]).sum()) for e in frame)
+        assert cloud.sh_degree == ref_cloud.sh_degree == 0
+        untransformed = all(e[1] is None for e in frame)
+        for name in ("opacities", "scales", "rotations", "shs") + (("means3D",) if untransformed else ()):
+            assert torch.equal(getattr(cloud, name), getattr(ref_cloud, name)), (fi, name)
+        if untransformed:
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), fi
+        else:   # (positions of a transformed subset differ by the matmul's summation order, as for whole objects)
+            assert float((cloud.means3D - ref_cloud.means3D).abs().max()) <= 1e-6 * float(ref_cloud.means3D.abs().max()) + 1e-7
+            assert float((got[0] - want[0]).abs().max()) <= 1e-4
+    # index lists and GPU masks are accepted too, and say so when they do not fit
+    m = torch.zeros(objs["ball"][0]._xyz.shape[0], dtype=torch.bool, device=dev)
+    m[::3] = True
+    a = scene.compose([("ball", None, None, None, m)])
+    b = scene.compose([("ball", None, None, None, torch.nonzero(m).reshape(-1).to(torch.int32))], slot=0)
+    assert a.P == b.P == scene.P_base + int(m.sum())
+    with pytest.raises(ValueError, match="entries"):
+        scene.compose([("ball", None, None, None, np.ones(5, bool))])
+    with pytest.raises(ValueError, match="untransformed"):
+        scene.compose([("ball", None, np.eye(3), 1.0, None)])
