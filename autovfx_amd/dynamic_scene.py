@@ -187,9 +187,11 @@ class DynamicScene:
         if t.dtype == torch.bool:
             if t.numel() != n:
                 raise ValueError(f"subset mask has {t.numel()} entries, the object {n} Gaussians")
-            t = torch.nonzero(t.reshape(-1), as_tuple=False).reshape(-1)
-        elif t.numel() and (int(t.min()) < 0 or int(t.max()) >= n):
+            t = torch.nonzero(t.reshape(-1), as_tuple=False).reshape(-1)   # (a GPU mask costs one host read here: its count sizes the frame)
+        elif not t.is_cuda and t.numel() and (int(t.min()) < 0 or int(t.max()) >= n):
             raise ValueError("subset indices out of range")
+        # (an index list that already lives on the GPU is taken as is -- checking it would read it back every frame; the fast
+        # path for a caller that matched meshes once and keeps the per-frame lists resident)
         return t.to(device=self.device, dtype=torch.int32).contiguous()
 
     def compose_model(self, placements, slot: int = 0) -> FrameModel:
