@@ -139,3 +139,28 @@ def test_the_references_own_gaussian_model_passes_the_gate(monkeypatch):
     monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))
     got = renderer.raw_parameters(r)
     assert got is not None and got[0] is r._xyz and got[5] is r._features_rest
+
+
+@pytest.mark.skipif(not os.path.isdir(GS), reason="reference tree not mounted")
+def test_install_patches_the_real_reference_renderer_module():
+    """The REFERENCE's own ``sugar/gaussian_splatting/gaussian_renderer/__init__.py``, imported unchanged from where it lies
+    (its heavy imports stubbed as tests/test_render_mirror.py does) in a fresh interpreter after ``autovfx_amd.install()``:
+    its ``diff_gaussian_rasterization`` is this repository's, its ``render`` is replaced, the original is kept, and the
+    signatures agree (a caller's positional / keyword use keeps working)."""
+    code = textwrap.dedent(f"""
+        import inspect, sys, types
+        sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+        import autovfx_amd
+        autovfx_amd.install()
+        from test_render_mirror import _import_reference
+        gr = _import_reference("gaussian_renderer")          # `from gaussian_renderer import render` (train.py:16)
+        import diff_gaussian_rasterization as dgr
+        ours, theirs = inspect.signature(gr.render), inspect.signature(gr.reference_render)
+        print(gr.render.__module__, gr.reference_render.__module__, dgr.__file__.startswith({ROOT!r}),
+              list(ours.parameters) == list(theirs.parameters),
+              [p.default for p in ours.parameters.values()][4:] == [p.default for p in theirs.parameters.values()][4:])
+    """)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.split() == ["autovfx_amd.renderer", "gaussian_renderer", "True", "True", "True"], r.stdout
