@@ -22,6 +22,8 @@ import os
 import sys
 import time
 
+import os as _os
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # before the HIP runtime starts: RCCL's peer set-up needs dmabuf IPC here
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
