@@ -1170,10 +1170,12 @@ def backward_iteration(key, device, steps=12, parity=True):
                                                   "alg_GBps": round(rb_bytes / max(1e-9, bw_k["render_backward"] * 1e-3) / 1e9, 1),
                                                   "frac_of_hbm_peak": round(rb_bytes / max(1e-9, bw_k["render_backward"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                                   "bound": "vector issue + LDS cross-lane reductions + one atomic line per (entry, quadrant)"},
-                       # per Gaussian: inputs 12 + 12 + 16 + 192 (SH) + its 64-byte line of sums; gradients 12+12+16+4+12+4+24+192+12+16
-                       "preprocess_backward_kernel": {"ms": round(bw_k["preprocess_backward"], 4), "alg_bytes": int(600 * P),
-                                                      "alg_GBps": round(600 * P / max(1e-9, bw_k["preprocess_backward"] * 1e-3) / 1e9, 1),
-                                                      "frac_of_hbm_peak": round(600 * P / max(1e-9, bw_k["preprocess_backward"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                       # per Gaussian: inputs 12 + 12 + 16 + 192 (SH) + its 64-byte line of sums; gradients 12 (mean2D) + 4 (opacity) +
+                       # 12 (mean3D) + 192 (SH) + 12 + 16 (scale, rotation) = 248 (round 4: conic 16, colour 12, depth 4 and cov3D 24 are
+                       # not written when nobody reads them) -> 544 B
+                       "preprocess_backward_kernel": {"ms": round(bw_k["preprocess_backward"], 4), "alg_bytes": int(544 * P),
+                                                      "alg_GBps": round(544 * P / max(1e-9, bw_k["preprocess_backward"] * 1e-3) / 1e9, 1),
+                                                      "frac_of_hbm_peak": round(544 * P / max(1e-9, bw_k["preprocess_backward"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                                       "bound": "hbm"}},
            "timed_calls": bw_k["calls"]}
     out["reference_on_gpu"] = reference_training_iteration(cloud, cams_cpu, bg, target, device, steps, cams_dev)
