@@ -31,7 +31,7 @@ FILE_FLAGS = {}   # per-file additions, if a unit ever needs its own
 
 
 EXAMPLES_DIR = os.path.join(HERE, "..", "examples")
-EXAMPLES = ("render_raw", "render_stream")
+EXAMPLES = ("render_raw", "render_stream", "train_step_raw")
 
 
 def build_examples(force: bool = False, verbose: bool = False):

@@ -41,7 +41,7 @@ def read_out(path, P, W, H):
 STREAM_BIN = os.path.join(ROOT, "examples", "bin", "render_stream")
 
 
-@pytest.mark.parametrize("name", ["render_raw", "render_stream"])
+@pytest.mark.parametrize("name", ["render_raw", "render_stream", "train_step_raw"])
 def test_example_source_uses_only_the_public_header(name):
     src = open(os.path.join(ROOT, "examples", name + ".cpp")).read()
     includes = [l.split()[1] for l in src.splitlines() if l.startswith("#include")]
@@ -93,3 +93,64 @@ def test_native_program_matches_python_binding(tmp_path, P, W, H):
     assert n == int(_C.last_layout()["counts"]["num_rendered"]) > 0      # num_rendered, the reference's return value
     for k in ("color", "depth", "alpha", "radii"):
         np.testing.assert_array_equal(got[k], np.asarray(want[k]).reshape(-1), err_msg=k)
+
+
+TRAIN_BIN = os.path.join(ROOT, "examples", "bin", "train_step_raw")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [16, 4])
+def test_native_raw_forward_and_backward_match_the_python_binding(tmp_path, M):
+    """examples/train_step_raw.cpp: gsr_forward_raw (a full call with the normal image) + gsr_backward_raw (colour and normal
+    gradients given, depth / alpha NULL) from plain C++ against the Python binding on the same raw tensors: the four images
+    and radii bit for bit, the seven gradient tensors within the tolerance of sums formed with atomics.  The program fills
+    every output with 0xFF first: an element the library did not write would come back as NaN."""
+    assert os.path.exists(TRAIN_BIN), "examples/bin/train_step_raw is not built: run __graft_entry__.build()"
+    from diff_gaussian_rasterization import _C
+    dev = "cuda:0"
+    P, W, H, D = 15_000, 288, 176, {16: 3, 4: 1}[M]
+    c = scenes.config_c1(P=P, seed=23)
+    cam = orbit_cameras(7, W, H)[2]
+    g = torch.Generator().manual_seed(4)
+    raw = dict(xyz=c.means3D, ls=torch.log(c.scales), rot=c.rotations * (0.5 + 2 * torch.rand(P, 1, generator=g)),
+               op=torch.logit(c.opacities.reshape(-1).clamp(1e-6, 1 - 1e-6)), dc=c.shs[:, :1].contiguous(), rest=c.shs[:, 1:M].contiguous())
+    bg = torch.tensor([0.2, 0.1, 0.3])
+    g_color = torch.randn(3, H, W, generator=g) / (H * W)
+    g_normal = torch.randn(3, H, W, generator=g) / (H * W)
+    model, out = str(tmp_path / "model.bin"), str(tmp_path / "out.bin")
+    f32 = lambda t: np.ascontiguousarray(t.detach().cpu().numpy(), dtype="<f4").tobytes()
+    with open(model, "wb") as f:
+        f.write(struct.pack("<5i", P, M, D, W, H))
+        f.write(struct.pack("<2f", cam.tanfovx, cam.tanfovy))
+        for t in (bg, raw["xyz"], raw["ls"], raw["rot"], raw["op"], raw["dc"], raw["rest"], cam.world_view_transform,
+                  cam.full_proj_transform, cam.camera_center, g_color, g_normal):
+            f.write(f32(t))
+    r = subprocess.run([TRAIN_BIN, model, out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    blob = open(out, "rb").read()
+    n = struct.unpack_from("<i", blob, 0)[0]
+    at, got = 4, {}
+    for k, count, dt in (("color", 3 * H * W, "<f4"), ("depth", H * W, "<f4"), ("alpha", H * W, "<f4"), ("normal", 3 * H * W, "<f4"),
+                         ("radii", P, "<i4"), ("g_xyz", 3 * P, "<f4"), ("g_ls", 3 * P, "<f4"), ("g_rot", 4 * P, "<f4"), ("g_op", P, "<f4"),
+                         ("g_dc", 3 * P, "<f4"), ("g_rest", 3 * P * (M - 1), "<f4"), ("g_2d", 3 * P, "<f4")):
+        got[k] = np.frombuffer(blob, dtype=dt, count=count, offset=at)
+        at += 4 * count
+    assert at == len(blob)
+    t = lambda a: a.to(dev).contiguous()
+    camd = cam.to(dev)
+    args = (t(bg), t(raw["xyz"]), t(raw["ls"]), t(raw["rot"]), t(raw["op"]), t(raw["dc"]), t(raw["rest"]))
+    with torch.no_grad():
+        fw = _C.rasterize_gaussians_raw(*args, 1.0, camd.world_view_transform, camd.full_proj_transform, camd.tanfovx, camd.tanfovy, H, W,
+                                        D, camd.camera_center, False, False, want_normal=True, inference=False)
+        bw = _C.rasterize_gaussians_raw_backward(*args, fw[4], 1.0, camd.world_view_transform, camd.full_proj_transform, camd.tanfovx,
+                                                 camd.tanfovy, t(g_color), None, None, t(g_normal), D, camd.camera_center, fw[5], fw[0],
+                                                 fw[6], fw[7], fw[3], False)
+    torch.cuda.synchronize()
+    assert n == fw[0] > 0
+    for k, want in (("color", fw[1]), ("depth", fw[2]), ("alpha", fw[3]), ("normal", fw[8]), ("radii", fw[4])):
+        np.testing.assert_array_equal(got[k], want.cpu().numpy().reshape(-1), err_msg=k)
+    for k, want in zip(("g_2d", "g_xyz", "g_ls", "g_rot", "g_op", "g_dc", "g_rest"), bw):
+        a, b = got[k].astype(np.float64), want.cpu().numpy().reshape(-1).astype(np.float64)
+        assert np.isfinite(a).all(), f"{k}: an element was not written"
+        assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max() + 1e-6, k
+    assert np.abs(got["g_rest"]).sum() > 0 if M > 1 else got["g_rest"].size == 0
