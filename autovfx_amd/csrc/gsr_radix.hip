@@ -19,15 +19,14 @@
 //   1. keys are loaded wave-striped (item i of lane L at wave_base + 64 i + L: coalesced);
 //   2. stable rank inside the wave, in one of two forms, BOTH compiled in (template parameter kRankAtomic):
 //        - ballots: 8 ballots per item match the lanes with the same digit, popcount below the lane.  Relies on
-//          nothing but the ISA; this is the fallback and what GSR_OPT_RADIX_RANK = 0 forces.
+//          nothing but the ISA; the DEFAULT since round 4 (GSR_OPT_RADIX_RANK = 0).
 //        - LDS atomics: one returning LDS add per item on the wave's counter of the item's digit.  Correct only if lanes
 //          of one instruction that hit the same counter are served in ascending lane order (a wave's instructions retire
 //          in program order), so that the values returned number the wave's items of a digit in tile order.  That order
-//          is what gfx950's LDS does, but no manual promises it, so the library CHECKS it: the first sort on a device
-//          runs the self-test below (lds_atomic_order_selftest_kernel, every conflict density) and the atomics are used
-//          on that device only if it reports zero violations (radix_rank_mode(); GSR_OPT_RADIX_RANK, default 2 = auto).
-//          The atomics cut the kernel's vector instructions by about 40 %: C3 frame -30 us single-stream, +1.4 %
-//          with 3 streams, same box.
+//          is what gfx950's LDS is observed to do, but no manual promises it: an opt-in (GSR_OPT_RADIX_RANK = 1, or 2 = only
+//          on a device that passed the self-test below, lds_atomic_order_selftest_kernel, every conflict density, run by
+//          the first sort after the request: radix_rank_mode()).  The atomics cut the kernel's vector instructions by about
+//          40 %: C3 frame -30 us single-stream, +1.4 % with several streams, same box.
 //   3. counters are turned into (wave, digit) offsets, a 256-wide scan gives the digit segments of the tile;
 //   4. pairs are parked in LDS at their in-tile position and written out in that order, so every digit
 //      segment is a contiguous, coalesced run in HBM.
