@@ -35,10 +35,11 @@ OPT_SLABS = 1
 OPT_SLAB_FIRST = 2
 OPT_DEFER_COLOUR = 3
 OPT_SLAB_MIN_REST = 4
-OPT_RADIX_RANK = 5           # 0 (default) ballots, 1 LDS adds, 2 LDS adds where the per-device self-test passed
-OPT_RADIX_RANK_ACTIVE = 6    # read-only: what the current device uses (1 LDS adds, 0 ballots)
+OPT_RADIX_RANK = 5           # 0 ballots, 1 verified LDS adds, 2 (default) those where the per-device self-test passed, 3 test hook
+OPT_RADIX_RANK_ACTIVE = 6    # read-only: what the current device uses (1 verified LDS adds, 0 ballots)
 OPT_BLEND_ORDER = 8          # 1 (default): large images are blended longest tile list first inside each XCD's band
 OPT_DEPTH_DROP = 7           # 1 (default): Gaussians that emit nothing leave the depth sort in its first pass
+OPT_RADIX_RANK_FALLBACKS = 9 # read-only: tiles on the current device whose LDS-add ranks failed the order check (re-ranked with ballots)
 
 
 class RawParams(ctypes.Structure):
@@ -173,9 +174,9 @@ def _load() -> ctypes.CDLL:
 
 lib = _load()
 
-# A/B from the shell (scripts/gpu_r3_check.sh): GSR_RADIX_RANK=0 forces the ballot rank of the radix sort, 1 the LDS adds,
-# 2 = adds where the per-device self-test passed; unset = the library default (0, ballots).
-if os.environ.get("GSR_RADIX_RANK", "") in ("0", "1", "2"):
+# A/B from the shell: GSR_RADIX_RANK=0 forces the ballot rank of the radix sort, 1 the verified LDS adds, 2 = those where the
+# per-device self-test passed, 3 = with an injected inversion (test hook); unset = the library default (2).
+if os.environ.get("GSR_RADIX_RANK", "") in ("0", "1", "2", "3"):
     lib.gsr_set_option(5, int(os.environ["GSR_RADIX_RANK"]))
 if os.environ.get("GSR_BLEND_ORDER", "") in ("0", "1"):
     lib.gsr_set_option(OPT_BLEND_ORDER, int(os.environ["GSR_BLEND_ORDER"]))

@@ -48,8 +48,8 @@ constexpr int kHeadEvents = 4, kSlabEvents = 5;
 constexpr int kEventsPerCall = kHeadEvents + kSlabEvents * gsr::kMaxSlabs;
 int g_options[GSR_OPT_NUM] = {/*GSR_OPT_TILE_CULL*/ 1, /*GSR_OPT_SLABS*/ 2, /*GSR_OPT_SLAB_FIRST*/ 400,
                               /*GSR_OPT_DEFER_COLOUR*/ 1, /*GSR_OPT_SLAB_MIN_REST*/ 3000000,
-                              /*GSR_OPT_RADIX_RANK (kept by gsr_radix.hip)*/ 0, /*GSR_OPT_RADIX_RANK_ACTIVE (read-only)*/ 0,
-                              /*GSR_OPT_DEPTH_DROP*/ 1, /*GSR_OPT_BLEND_ORDER*/ 1};
+                              /*GSR_OPT_RADIX_RANK (kept by gsr_radix.hip)*/ 2, /*GSR_OPT_RADIX_RANK_ACTIVE (read-only)*/ 0,
+                              /*GSR_OPT_DEPTH_DROP*/ 1, /*GSR_OPT_BLEND_ORDER*/ 1, /*GSR_OPT_RADIX_RANK_FALLBACKS (read-only)*/ 0};
 std::atomic<bool> g_timing{false};
 std::atomic<long> g_timing_epoch{0};       // bumped by gsr_set_stage_timing: every thread restarts its record at its next call
 thread_local long g_epoch_seen = -1;
@@ -174,8 +174,9 @@ const char* gsr_target_arch(void) { return "gfx950"; }
 int gsr_set_option(int option, int value) {
     if (option < 0 || option >= GSR_OPT_NUM) return fail(GSR_ERR_INVALID_ARG, "unknown option %d", option);
     if (option == GSR_OPT_RADIX_RANK_ACTIVE) return fail(GSR_ERR_INVALID_ARG, "GSR_OPT_RADIX_RANK_ACTIVE is read-only");
+    if (option == GSR_OPT_RADIX_RANK_FALLBACKS) return fail(GSR_ERR_INVALID_ARG, "GSR_OPT_RADIX_RANK_FALLBACKS is read-only");
     if (option == GSR_OPT_RADIX_RANK) {
-        if (value < 0 || value > 2) return fail(GSR_ERR_INVALID_ARG, "GSR_OPT_RADIX_RANK must be 0, 1 or 2");
+        if (value < 0 || value > 3) return fail(GSR_ERR_INVALID_ARG, "GSR_OPT_RADIX_RANK must be 0, 1, 2 or 3");
         gsr::radix_set_rank_request(value);
     }
     g_options[option] = value;
@@ -185,6 +186,11 @@ int gsr_get_option(int option) {
     if (option < 0 || option >= GSR_OPT_NUM) return fail(GSR_ERR_INVALID_ARG, "unknown option %d", option);
     if (option == GSR_OPT_RADIX_RANK) return gsr::radix_rank_request();
     if (option == GSR_OPT_RADIX_RANK_ACTIVE) return gsr::radix_rank_mode(nullptr, nullptr);  // (self-test on the null stream if due)
+    if (option == GSR_OPT_RADIX_RANK_FALLBACKS) {
+        unsigned long long tiles = 0ull;
+        if (gsr::radix_rank_fallbacks(&tiles) != hipSuccess) return -1;
+        return tiles > 0x7fffffffull ? 0x7fffffff : (int)tiles;
+    }
     return g_options[option];
 }
 
@@ -893,7 +899,8 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     GSR_HIP(gsr::radix_sort_pairs((uint32_t*)(gbase + fc.off_radix_tmp), (uint32_t)P, 32, ga.depth_keys, (uint32_t*)(gbase + off_keys_b),
                                   (uint32_t*)(gbase + off_ids_a), (uint32_t*)(gbase + off_ids_b),
                                   /*iota_payload=*/true, /*want_sorted_keys=*/false, &keys_sorted, &fc.order, stream, nullptr,
-                                  g_options[GSR_OPT_DEPTH_DROP] != 0 ? &gsr::kCulledKey : nullptr));
+                                  g_options[GSR_OPT_DEPTH_DROP] != 0 ? &gsr::kCulledKey : nullptr,
+                                  /*few_top_digits=*/true));   // the keys are positive floats: their top byte is sign + 7 exponent bits
     GSR_STAGE_CHECK("depth_sort");
     stamp(2, stream);
     geom_off[GSR_GEOM_DEPTH_ORDER] = (size_t)((char*)fc.order - gbase);

@@ -308,19 +308,24 @@ hipError_t launch_pack_rgba8(const float* color, const float* alpha, uint8_t* ou
 // then only sizes the launches and the scratch layout): a sort can be queued before its size is known on the host.
 // drop_key (nullable; with iota_payload, more than one pass, no n_device): items with this key leave the sort in its first
 // pass -- not ranked, not written; the sorted arrays hold the others, in order, and their tails are undefined.
+// few_top_digits: a hint that the most significant digit takes only a handful of values (the top byte of a positive float: sign
+// and seven exponent bits) -- that pass then ranks with ballots, whose cost does not grow with lanes hitting one counter.
 // counts the returning LDS adds whose result was not (value before the instruction) + (lower lanes on the same counter)
 hipError_t launch_lds_atomic_order_selftest(uint32_t workgroups, uint32_t rounds, uint32_t seed, unsigned long long* mismatches,
                                             hipStream_t stream);
-// The in-wave rank of the scatter kernel: request 0 = ballots, 1 = returning LDS adds unconditionally, 2 = LDS adds on a
-// device that passed the lane-order self-test (run once per device, on `stream`, by the first caller), ballots elsewhere.
-// radix_rank_mode returns what sorts on the CURRENT device use (1 = LDS adds); *violations = what the self-test counted.
+// The in-wave rank of the scatter kernel: request 0 = ballots, 1 = returning LDS adds verified per tile (ballot repair in place),
+// 2 = those on a device that passed the lane-order self-test (run once per device, on `stream`, by the first caller), ballots
+// elsewhere, 3 = 1 with an injected inversion (test hook).  radix_rank_mode returns what sorts on the CURRENT device use
+// (0 ballots, 1 verified LDS adds, 2 with the inversion); *violations = what the self-test counted.
 void radix_set_rank_request(int request);
 int radix_rank_request();
 int radix_rank_mode(hipStream_t stream, unsigned long long* violations);
+hipError_t radix_rank_fallbacks(unsigned long long* tiles);   // tiles re-ranked with ballots after a failed order check
 size_t radix_scratch_words(uint32_t n);
 hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt,
                             uint32_t* vals, uint32_t* vals_alt, bool iota_payload, bool want_sorted_keys,
                             uint32_t** keys_sorted, uint32_t** vals_sorted, hipStream_t stream,
-                            const uint32_t* n_device = nullptr, const uint32_t* drop_key = nullptr);
+                            const uint32_t* n_device = nullptr, const uint32_t* drop_key = nullptr,
+                            bool few_top_digits = false);
 
 } // namespace gsr

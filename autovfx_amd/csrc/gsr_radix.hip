@@ -17,16 +17,19 @@
 //
 // Scatter kernel, one workgroup = 256 lanes (4 wave64) x 16 items = 4096 pairs:
 //   1. keys are loaded wave-striped (item i of lane L at wave_base + 64 i + L: coalesced);
-//   2. stable rank inside the wave, in one of two forms, BOTH compiled in (template parameter kRankAtomic):
+//   2. stable rank inside the wave, in one of two forms, BOTH compiled in (template parameter kRank):
 //        - ballots: 8 ballots per item match the lanes with the same digit, popcount below the lane.  Relies on
-//          nothing but the ISA; the DEFAULT since round 4 (GSR_OPT_RADIX_RANK = 0).
-//        - LDS atomics: one returning LDS add per item on the wave's counter of the item's digit.  Correct only if lanes
-//          of one instruction that hit the same counter are served in ascending lane order (a wave's instructions retire
-//          in program order), so that the values returned number the wave's items of a digit in tile order.  That order
-//          is what gfx950's LDS is observed to do, but no manual promises it: an opt-in (GSR_OPT_RADIX_RANK = 1, or 2 = only
-//          on a device that passed the self-test below, lds_atomic_order_selftest_kernel, every conflict density, run by
-//          the first sort after the request: radix_rank_mode()).  The atomics cut the kernel's vector instructions by about
-//          40 %: C3 frame -30 us single-stream, +1.4 % with several streams, same box.
+//          nothing but the ISA (GSR_OPT_RADIX_RANK = 0).
+//        - VERIFIED LDS atomics (the default, GSR_OPT_RADIX_RANK = 2): one returning LDS add per item on the wave's counter
+//          of the item's digit.  The values returned are the right rank if lanes of one instruction that hit the same counter
+//          are served in ascending lane order -- what gfx950's LDS is observed to do, but no manual promises it.  So the
+//          kernel does not rely on it: before a tile writes anything, it parks (digit, index-in-tile) at the positions the
+//          ranks give and checks that the word rises strictly from position to position (one compare per item; the digit
+//          counts, hence the segments, are right whatever the order because the adds are atomic).  A tile that fails the
+//          check is ranked again with ballots, in place, and counted (GSR_OPT_RADIX_RANK_FALLBACKS); the output is the stable
+//          sort either way.  The check costs ~8 of the ~35 vector instructions per item the ballots cost.
+//          Request 2 additionally runs the lane-order self-test (lds_atomic_order_selftest_kernel) on the first sort and
+//          uses plain ballots on a device that fails it -- there every tile would pay the atomics AND the ballots.
 //   3. counters are turned into (wave, digit) offsets, a 256-wide scan gives the digit segments of the tile;
 //   4. pairs are parked in LDS at their in-tile position and written out in that order, so every digit
 //      segment is a contiguous, coalesced run in HBM.
@@ -164,10 +167,13 @@ __global__ void __launch_bounds__(kThreads) radix_scan_kernel(uint32_t* __restri
 
 // ------------------------------------------------------------------------------------------------
 // scatter.  kIota: payloads are the item indices (first pass of the depth sort: no payload read).
-// kKeysOut: false on a last pass whose sorted keys nobody reads.  kRankAtomic: the in-wave rank by returning LDS adds
-// (only launched on a device that passed the lane-order self-test) instead of ballots.
+// kKeysOut: false on a last pass whose sorted keys nobody reads.  kRank: how the in-wave rank is found -- 0 ballots, 1 returning
+// LDS adds whose result every workgroup VERIFIES before it writes anything (and redoes with ballots if the check fails),
+// 2 = 1 with an inversion injected into every wave (test hook: the check must catch it and the ballots repair it).
 // ------------------------------------------------------------------------------------------------
-template <bool kIota, bool kKeysOut, bool kRankAtomic>
+__device__ unsigned long long g_rank_fallbacks = 0ull;   // tiles whose LDS-add ranks failed the order check (this device, since load)
+
+template <bool kIota, bool kKeysOut, int kRank>
 __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                 const uint32_t* __restrict__ vals_in,
                                                                 uint32_t* __restrict__ keys_out,
@@ -220,36 +226,53 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t*
 
     // 2. stable rank inside the wave
     uint32_t rank[kItems];
-    uint32_t* my_count = s_count[wave];
-    if (kRankAtomic) {
-        // One returning LDS add per item on the wave's counter of its digit: lanes that hit the same counter in one
-        // instruction are served in ascending lane order and instructions retire in program order, so the returned values
-        // number the wave's items of a digit in tile order (item i of lane L sits at 64 i + L) -- the rank the ballots
-        // compute.  Only reached on a device where the self-test confirmed that order (radix_rank_mode).
+    // by ballots: 8 ballots per item match the lanes with the same digit; `counters` = 256 zeroed words of this wave
+    auto rank_by_ballots = [&](uint32_t* counters) {
+        const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
         for (int i = 0; i < kItems; ++i) {
             const bool valid = (ok >> i) & 1u;
             const uint32_t d = (key[i] >> shift) & digit_mask;
-            rank[i] = valid ? atomicAdd(&my_count[d], 1u) : 0u;
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                if ((digit_mask >> b) == 0u) break;  // wave-uniform: a narrow last digit needs fewer ballots
+                const bool set = (d >> b) & 1u;
+                const unsigned long long with_bit = __ballot(set);
+                peers &= set ? with_bit : ~with_bit;
+            }
+            const uint32_t before = counters[d];  // every peer reads the same word before the bump below
+            rank[i] = before + (uint32_t)__popcll(peers & below);
+            if (valid && (peers >> lane) == 1ull) counters[d] = before + (uint32_t)__popcll(peers);  // highest peer
+        }
+    };
+    if (kRank != 0) {
+        // One returning LDS add per item on the wave's counter of its digit.  On gfx950 lanes of one instruction that hit the
+        // same counter are observed to be served in ascending lane order (and a wave's instructions retire in program order),
+        // in which case the returned values number the wave's items of a digit in tile order (item i of lane L sits at
+        // 64 i + L) -- the rank the ballots compute.  No manual promises that order, so nothing rests on it: the counts are
+        // right whatever the order (the adds are atomic), and step 4 checks the order itself before anything leaves the tile.
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) {
+            const bool valid = (ok >> i) & 1u;
+            const uint32_t d = (key[i] >> shift) & digit_mask;
+            rank[i] = valid ? atomicAdd(&s_count[wave][d], 1u) : 0u;
+        }
+        if (kRank == 2) {   // test hook: the two lowest lanes that share lane 0's digit in item 0 trade ranks
+            const uint32_t d = (key[0] >> shift) & digit_mask;
+            const uint32_t d_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+            unsigned long long peers = __ballot((ok & 1u) && d == d_first);
+            if (__popcll(peers) >= 2) {
+                const int l0 = __ffsll((long long)peers) - 1;
+                peers &= peers - 1ull;
+                const int l1 = __ffsll((long long)peers) - 1;
+                const uint32_t r0 = (uint32_t)__shfl((int)rank[0], l0), r1 = (uint32_t)__shfl((int)rank[0], l1);
+                if (lane == l0) rank[0] = r1;
+                if (lane == l1) rank[0] = r0;
+            }
         }
     } else {
-    const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        const bool valid = (ok >> i) & 1u;
-        const uint32_t d = (key[i] >> shift) & digit_mask;
-        unsigned long long peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            if ((digit_mask >> b) == 0u) break;  // wave-uniform: a narrow last digit needs fewer ballots
-            const bool set = (d >> b) & 1u;
-            const unsigned long long with_bit = __ballot(set);
-            peers &= set ? with_bit : ~with_bit;
-        }
-        const uint32_t before = my_count[d];  // every peer reads the same word before the bump below
-        rank[i] = before + (uint32_t)__popcll(peers & below);
-        if (valid && (peers >> lane) == 1ull) my_count[d] = before + (uint32_t)__popcll(peers);  // highest peer
-    }
+        rank_by_ballots(s_count[wave]);
     }
     __syncthreads();
     GSR_TRACE(1);
@@ -272,14 +295,61 @@ __global__ void __launch_bounds__(kThreads) radix_scatter_kernel(const uint32_t*
     GSR_TRACE(2);
 
     // 4. park in tile order, then stream out
+    if (kRank == 0) {
 #pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-        if ((ok >> i) & 1u) {
-            const uint32_t d = (key[i] >> shift) & digit_mask;
-            const uint32_t pos = s_seg_start[d] + s_count[wave][d] + rank[i];
-            s_keys[pos] = key[i];
-            s_vals[pos] = val[i];
+        for (int i = 0; i < kItems; ++i) {
+            if ((ok >> i) & 1u) {
+                const uint32_t d = (key[i] >> shift) & digit_mask;
+                const uint32_t pos = s_seg_start[d] + s_count[wave][d] + rank[i];
+                s_keys[pos] = key[i];
+                s_vals[pos] = val[i];
+            }
         }
+    } else {
+        // 4a. park the keys, and in the payload's place (digit, index in the tile): the sort of this tile is right if and only
+        //     if that word rises strictly along the parked positions -- digits ascend from segment to segment by construction
+        //     (step 3 only used the COUNTS, which the atomicity of the adds guarantees), so the only thing that can be wrong
+        //     is the order inside a (wave, digit) run, and a run out of tile order has a descent
+#pragma unroll
+        for (int i = 0; i < kItems; ++i) {
+            if ((ok >> i) & 1u) {
+                const uint32_t d = (key[i] >> shift) & digit_mask;
+                const uint32_t pos = s_seg_start[d] + s_count[wave][d] + rank[i];
+                s_keys[pos] = key[i];
+                s_vals[pos] = (d << 12) | (first + 64u * i);
+                rank[i] = pos;
+            }
+        }
+        __syncthreads();
+        // 4b. the check: 4096 comparisons of neighbours
+        int descent = 0;
+#pragma unroll
+        for (int j = 0; j < kItems; ++j) {
+            const uint32_t p = (uint32_t)(j * kThreads + tid);
+            if (p != 0u && p < tile_kept) descent |= (int)(s_vals[p] <= s_vals[p - 1u]);
+        }
+        if (__syncthreads_or(descent)) {
+            // 4c. (never taken on the hardware this was measured on) rank again with ballots, on counters carved from the
+            //     payload area, and park the keys where they belong
+            for (int w = 0; w < kWaves; ++w) s_vals[w * 256 + tid] = 0u;
+            __syncthreads();
+            rank_by_ballots(s_vals + wave * 256);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < kItems; ++i) {
+                if ((ok >> i) & 1u) {
+                    const uint32_t d = (key[i] >> shift) & digit_mask;
+                    const uint32_t pos = s_seg_start[d] + s_count[wave][d] + rank[i];
+                    s_keys[pos] = key[i];
+                    rank[i] = pos;
+                }
+            }
+            if (tid == 0) atomicAdd(&g_rank_fallbacks, 1ull);
+        }
+        // 4d. the payloads
+#pragma unroll
+        for (int i = 0; i < kItems; ++i)
+            if ((ok >> i) & 1u) s_vals[rank[i]] = val[i];
     }
     __syncthreads();
     GSR_TRACE(3);
@@ -360,11 +430,12 @@ hipError_t launch_lds_atomic_order_selftest(uint32_t workgroups, uint32_t rounds
 }
 
 // ------------------------------------------------------------------------------------------------
-// Which in-wave rank the scatter kernel uses on the current device.  g_rank_request: 0 (DEFAULT since round 4) ballots --
-// correct by the ISA alone; 1 LDS atomics without asking; 2 LDS atomics on a device that passed the lane-order self-test,
-// ballots elsewhere.  The atomics are ~25 % faster per pass (1.4 % of a C3 frame) but lean on a hardware behaviour no manual
-// promises (lanes of one instruction that hit the same LDS counter are served in ascending lane order); a statistical
-// self-test on an idle device cannot prove it under contention, so it is an opt-in, not the default.
+// Which in-wave rank the scatter kernel uses on the current device.  g_rank_request: 0 ballots; 1 verified LDS atomics
+// without asking; 2 (DEFAULT) verified LDS atomics on a device that passed the lane-order self-test, ballots elsewhere; 3 =
+// 1 with an inversion injected into every wave (test hook for the check and the in-place repair).
+// Since round 4 the sort's correctness does not depend on the lane order in any of these: the atomics' ranks are checked per
+// tile inside the scatter kernel and repaired with ballots when they fail (see the kernel); the self-test only decides
+// whether the atomics are worth trying on this device.
 // With request 2 the self-test runs once per device and process, on the first sort (or the first query) after the request:
 // 512 workgroups x 4 waves x 192 instructions of every conflict density (~0.4 M instructions, 25 M lane results; well under a
 // millisecond), on its own small allocation, and SYNCHRONISES the calling stream once (hipMalloc / hipFree /
@@ -375,7 +446,7 @@ hipError_t launch_lds_atomic_order_selftest(uint32_t workgroups, uint32_t rounds
 namespace {
 constexpr int kMaxDevices = 64;
 std::mutex g_rank_mutex;
-int g_rank_request = 0;
+int g_rank_request = 2;
 int g_rank_verdict[kMaxDevices];      // 0 not tested yet, 1 passed (atomics), 2 failed (ballots), 3 could not be tested (ballots)
 unsigned long long g_rank_violations[kMaxDevices];
 
@@ -399,18 +470,24 @@ int test_device_locked(int dev, hipStream_t stream) {
 
 void radix_set_rank_request(int request) {
     std::lock_guard<std::mutex> lock(g_rank_mutex);
-    g_rank_request = request < 0 ? 0 : request > 2 ? 2 : request;
+    g_rank_request = request < 0 ? 0 : request > 3 ? 2 : request;
 }
 int radix_rank_request() {
     std::lock_guard<std::mutex> lock(g_rank_mutex);
     return g_rank_request;
 }
-// 1 = LDS atomics, 0 = ballots, for sorts queued on the current device from now on.
+// Tiles (this device, since the library was loaded) whose LDS-add ranks failed the in-kernel order check and were ranked
+// again with ballots.  Reads a device word: synchronises with the null stream only -- synchronise the sorting stream first.
+hipError_t radix_rank_fallbacks(unsigned long long* count) {
+    return hipMemcpyFromSymbol(count, HIP_SYMBOL(g_rank_fallbacks), sizeof *count, 0, hipMemcpyDeviceToHost);
+}
+// 1 = verified LDS atomics (2 = with the injected inversion), 0 = ballots, for sorts queued on the current device from now on.
 int radix_rank_mode(hipStream_t stream, unsigned long long* violations) {
     std::lock_guard<std::mutex> lock(g_rank_mutex);
     if (violations) *violations = 0ull;
     if (g_rank_request == 0) return 0;
     if (g_rank_request == 1) return 1;
+    if (g_rank_request == 3) return 2;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 0;
     int verdict = g_rank_verdict[dev];
@@ -430,13 +507,13 @@ size_t radix_scratch_words(uint32_t n) {
 hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt,
                             uint32_t* vals, uint32_t* vals_alt, bool iota_payload, bool want_sorted_keys,
                             uint32_t** keys_sorted, uint32_t** vals_sorted, hipStream_t stream, const uint32_t* n_device,
-                            const uint32_t* drop_key) {
+                            const uint32_t* drop_key, bool few_top_digits) {
     *keys_sorted = keys;
     *vals_sorted = vals;
     if (n == 0 || bits <= 0) return hipSuccess;
     if (bits > 32) return hipErrorInvalidValue;
     const int passes = (bits + 7) / 8;
-    const bool atomics = radix_rank_mode(stream, nullptr) == 1;  // (the first sort on a device runs the lane-order self-test)
+    const int rank_form = radix_rank_mode(stream, nullptr);  // (the first sort on a device runs the lane-order self-test)
     const uint32_t tiles = (n + kTileItems - 1) / kTileItems;
     const uint32_t tiles_pad = (tiles + 3u) & ~3u;
     uint32_t* counts = scratch;
@@ -469,8 +546,12 @@ hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* k
         else if (keys_out) GSR_RADIX_LAUNCH(false, true, A);     \
         else GSR_RADIX_LAUNCH(false, false, A);                  \
     } while (0)
-        if (atomics) GSR_RADIX_LAUNCH_IK(true);
-        else GSR_RADIX_LAUNCH_IK(false);
+        // (64 lanes on a handful of LDS counters serialise the adds: measured 19.8 us against 16.1 us with ballots on the top
+        // byte of C3's depth keys, while on evenly spread digits the adds win 13.5 : 18.4)
+        const int form = few_top_digits && p + 1 == passes && rank_form == 1 ? 0 : rank_form;
+        if (form == 1) GSR_RADIX_LAUNCH_IK(1);
+        else if (form == 2) GSR_RADIX_LAUNCH_IK(2);
+        else GSR_RADIX_LAUNCH_IK(0);
 #undef GSR_RADIX_LAUNCH_IK
 #undef GSR_RADIX_LAUNCH
         uint32_t* t = kin; kin = kout; kout = t;

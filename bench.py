@@ -748,7 +748,9 @@ def main():
                                    "slabs": _lib.get_option(_lib.OPT_SLABS), "slab_first": _lib.get_option(_lib.OPT_SLAB_FIRST),
                                    "defer_colour": _lib.get_option(_lib.OPT_DEFER_COLOUR),
                                    "depth_drop": _lib.get_option(_lib.OPT_DEPTH_DROP), "blend_order": _lib.get_option(_lib.OPT_BLEND_ORDER),
-                                   "radix_rank_active": _lib.get_option(_lib.OPT_RADIX_RANK_ACTIVE)}},
+                                   "radix_rank_active": _lib.get_option(_lib.OPT_RADIX_RANK_ACTIVE),
+                                   # 4096-key tiles of this whole run whose LDS-add ranks failed the sort's own order check
+                                   "radix_rank_fallbacks": _lib.get_option(_lib.OPT_RADIX_RANK_FALLBACKS)}},
             "n_ranks_seen": n_ranks_seen, "per_rank_frames_per_s": per_rank_fps,
             "value_serial": None if serial is None else serial["value"],
             "ms_per_step_serial": None if serial is None else serial["ms_per_step"],

@@ -453,18 +453,20 @@ typedef enum gsr_option {
      * further slab costs a fixed dozen of small launches, what it saves grows with the pairs it can drop.  (At
      * 960x540 with 1 M Gaussians and ~2 M live pairs slabs lose 13 %; with 6 - 18 M live pairs they gain 5 - 60 %.) */
     GSR_OPT_SLAB_MIN_REST = 4,
-    /* [0] How the radix sort ranks the keys of a wave (gsr_radix.hip).  0 (default since ABI 9): ballots -- relies on nothing
-     * but the ISA.  1: one returning LDS add per key, unconditionally -- correct only where lanes of one instruction that hit
-     * the same LDS counter are served in ascending lane order, which gfx950 is observed to do and no manual promises.  2: the
-     * first sort on each device after the request runs gsr_selftest_lds_atomic_order's kernel (~0.4 M instructions of every
-     * conflict density) and uses the LDS adds on that device only if it counted zero violations, ballots otherwise; that first
-     * sort allocates, frees and synchronises its stream once under a process-wide lock (do it outside stream capture; a test
-     * that could not run is retried by the next sort).  All forms produce the same stable sort; the LDS adds are ~25 % faster
-     * per pass, ~1.4 % of a 3 M-Gaussian frame: an opt-in, because an idle-device self-test cannot prove lane order under
-     * contention. */
+    /* [2] How the radix sort ranks the keys of a wave (gsr_radix.hip).  All forms produce the same stable sort, and none of
+     * them relies on anything the ISA does not promise.  0: ballots.  1: one returning LDS add per key, VERIFIED -- the values
+     * returned are the stable rank if lanes of one instruction that hit the same LDS counter are served in ascending lane
+     * order, which gfx950 is observed to do and no manual promises; so every 4096-key tile checks the order its ranks produce
+     * (one compare per key) before it writes anything, and a tile that fails is ranked again with ballots in place and counted
+     * in GSR_OPT_RADIX_RANK_FALLBACKS.  2 (default): as 1 on a device that passed gsr_selftest_lds_atomic_order's kernel
+     * (~0.4 M instructions of every conflict density, run by the first sort on each device after the request), plain ballots
+     * on a device that failed it (there every tile would pay for both); that first sort allocates, frees and synchronises
+     * its stream once under a process-wide lock (do it outside stream capture; a test that could not run is retried by the
+     * next sort).  3: as 1 with an inversion injected into every wave -- a test hook for the check and the repair.
+     * Verified LDS adds are ~20 % faster per pass than ballots: ~3 % of a single-stream 3 M-Gaussian frame. */
     GSR_OPT_RADIX_RANK = 5,
-    /* read-only: what sorts queued on the CURRENT device use -- 1 LDS adds, 0 ballots (runs the self-test if this
-     * device has not been tested yet and the request is 2).  gsr_set_option rejects it. */
+    /* read-only: what sorts queued on the CURRENT device use -- 1 verified LDS adds (2: with the injected inversion), 0 ballots
+     * (runs the self-test if this device has not been tested yet and the request is 2).  gsr_set_option rejects it. */
     GSR_OPT_RADIX_RANK_ACTIVE = 6,
     /* [1] The depth sort drops the Gaussians that produce no pair (culled, or every tile dead) in its first pass instead of
      * carrying them to the end of the order through all four: the later passes sort the visible ones only.  The first
@@ -476,6 +478,11 @@ typedef enum gsr_option {
      * length, then the tiles with nothing to blend), so that the waves still running when a launch with more workgroups than
      * wave slots runs dry are short ones.  Placement only: same results. */
     GSR_OPT_BLEND_ORDER = 8,
+    /* read-only: 4096-key tiles, on the CURRENT device since the library was loaded, whose LDS-add ranks failed the order check
+     * and were ranked again with ballots (saturates at INT_MAX; -1 if the device word could not be read).  0 on every MI355X
+     * this has run on; non-zero only costs time.  Reads a device word through the null stream: synchronise the streams that
+     * sorted first.  gsr_set_option rejects it. */
+    GSR_OPT_RADIX_RANK_FALLBACKS = 9,
     GSR_OPT_NUM
 } gsr_option;
 GSR_API int gsr_set_option(int option, int value);

@@ -59,7 +59,7 @@ def test_options_are_host_state_with_the_documented_defaults():
     # the default stands in brackets at the start of each option's comment
     body = HEADER[HEADER.index("typedef enum gsr_option"):HEADER.index("} gsr_option;")]
     defaults = [int(x) for x in re.findall(r"/\* \[(\d+)\]", body)]
-    settable = [m for m in members if m != "GSR_OPT_RADIX_RANK_ACTIVE"]
+    settable = [m for m in members if m not in ("GSR_OPT_RADIX_RANK_ACTIVE", "GSR_OPT_RADIX_RANK_FALLBACKS")]
     assert len(defaults) == len(settable), (defaults, settable)
     for m, want in zip(settable, defaults):
         assert _lib.get_option(getattr(_lib, "OPT_" + m[len("GSR_OPT_"):])) == want, m
@@ -69,7 +69,8 @@ def test_options_are_host_state_with_the_documented_defaults():
         assert _lib.get_option(opt) == other
         _lib.set_option(opt, was)
     assert _lib.lib.gsr_set_option(_lib.OPT_RADIX_RANK_ACTIVE, 1) != 0 and "read-only" in _lib.last_error()
-    assert _lib.lib.gsr_set_option(_lib.OPT_RADIX_RANK, 3) != 0
+    assert _lib.lib.gsr_set_option(_lib.OPT_RADIX_RANK_FALLBACKS, 0) != 0 and "read-only" in _lib.last_error()
+    assert _lib.lib.gsr_set_option(_lib.OPT_RADIX_RANK, 4) != 0
     assert _lib.lib.gsr_set_option(len(members), 0) != 0 and _lib.lib.gsr_set_option(-1, 0) != 0
 
 

@@ -8,15 +8,29 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["ballots", "lds_adds"], autouse=True)
+RANK_FORMS = {"ballots": (0, 0), "verified_lds_adds": (1, 1), "lds_adds_with_injected_inversions": (3, 2)}   # request, ACTIVE
+
+
+@pytest.fixture(params=list(RANK_FORMS), autouse=True)
 def rank_variant(request):
-    """Both in-wave rank forms of the scatter kernel are compiled in (gsr_radix.hip); every test of this file runs with
-    each of them forced (GSR_OPT_RADIX_RANK 0 / 1), then the default (0: ballots) is restored."""
+    """All in-wave rank forms of the scatter kernel are compiled in (gsr_radix.hip); every test of this file runs with each of
+    them forced (GSR_OPT_RADIX_RANK 0 / 1 / 3), then the default (2: verified LDS adds where the self-test passed) is restored.
+    Form 3 swaps two ranks in every wave: the kernel's order check has to catch it and the ballots repair it, so the same
+    assertions hold."""
     from autovfx_amd import _lib
-    _lib.set_option(_lib.OPT_RADIX_RANK, 0 if request.param == "ballots" else 1)
-    assert _lib.get_option(_lib.OPT_RADIX_RANK_ACTIVE) == (0 if request.param == "ballots" else 1)
+    req, active = RANK_FORMS[request.param]
+    _lib.set_option(_lib.OPT_RADIX_RANK, req)
+    assert _lib.get_option(_lib.OPT_RADIX_RANK_ACTIVE) == active
     yield request.param
-    _lib.set_option(_lib.OPT_RADIX_RANK, 0)
+    _lib.set_option(_lib.OPT_RADIX_RANK, 2)
+
+
+def fallbacks():
+    from autovfx_amd import _lib
+    torch.cuda.synchronize()
+    n = _lib.get_option(_lib.OPT_RADIX_RANK_FALLBACKS)
+    assert n >= 0, "the fallback counter could not be read"
+    return n
 
 
 def sort_pairs(keys, vals, bits, iota=False):
@@ -92,22 +106,43 @@ def test_lds_atomics_serve_lanes_in_order():
 
 
 def test_selftested_mode_tests_the_device_and_reports_what_it_uses():
-    """GSR_OPT_RADIX_RANK = 2 (an opt-in since round 4; the default is 0, ballots): the first sort on a device runs the
-    lane-order self-test; on MI355X it passes and GSR_OPT_RADIX_RANK_ACTIVE says LDS adds.  (Were it to fail, ACTIVE would say
-    ballots and the sorts would still be right: that branch is the `ballots` parametrisation of every test above.)"""
+    """GSR_OPT_RADIX_RANK = 2 (the default): the first sort on a device runs the lane-order self-test; on MI355X it passes and
+    GSR_OPT_RADIX_RANK_ACTIVE says verified LDS adds.  (Were it to fail, ACTIVE would say ballots and the sorts would still be
+    right: that branch is the `ballots` parametrisation of every test above.)"""
     from autovfx_amd import _lib
     _lib.set_option(_lib.OPT_RADIX_RANK, 0)
-    assert _lib.get_option(_lib.OPT_RADIX_RANK_ACTIVE) == 0    # the shipped default relies on the ISA alone
+    assert _lib.get_option(_lib.OPT_RADIX_RANK_ACTIVE) == 0
     _lib.set_option(_lib.OPT_RADIX_RANK, 2)
     assert _lib.get_option(_lib.OPT_RADIX_RANK) == 2
     assert _lib.get_option(_lib.OPT_RADIX_RANK_ACTIVE) == 1, "the LDS lane-order self-test failed on this device"
     with pytest.raises(RuntimeError):
         _lib.set_option(_lib.OPT_RADIX_RANK_ACTIVE, 0)
+    with pytest.raises(RuntimeError):
+        _lib.set_option(_lib.OPT_RADIX_RANK_FALLBACKS, 0)
     keys = torch.randint(0, 2**13, (1_000_003,), device="cuda", dtype=torch.int32)
     vals = torch.arange(keys.numel(), device="cuda", dtype=torch.int32)
     want = torch.sort(keys.to(torch.int64), stable=True).indices.to(torch.int32)
     _, got = sort_pairs(keys.clone(), vals, 13)
     assert torch.equal(got, want)
+
+
+def test_the_order_check_catches_inversions_and_stays_silent_otherwise(rank_variant):
+    """The scatter kernel's own check of the LDS adds' ranks (gsr_radix.hip step 4b): with an inversion injected into every wave
+    every tile must notice and repair it (GSR_OPT_RADIX_RANK_FALLBACKS counts tiles x passes); with the plain adds on this
+    hardware, and with ballots, no tile may."""
+    n = 4096 * 50
+    # 13 key bits = a 7-bit and a 6-bit pass; four values per digit, so that in every wave some lane shares lane 0's digit
+    keys = (torch.randint(0, 4, (n,), device="cuda") + 128 * torch.randint(0, 4, (n,), device="cuda")).to(torch.int32)
+    vals = torch.arange(n, device="cuda", dtype=torch.int32)
+    want = torch.sort(keys.to(torch.int64), stable=True).indices.to(torch.int32)
+    before = fallbacks()
+    _, got = sort_pairs(keys.clone(), vals, 13)
+    assert torch.equal(got, want)
+    grew = fallbacks() - before
+    if rank_variant == "lds_adds_with_injected_inversions":
+        assert grew == 50 * 2, grew      # two passes of 50 tiles, every one of them repaired
+    else:
+        assert grew == 0, grew
 
 
 def test_c2_full_frame_is_identical_with_either_rank():
@@ -119,6 +154,7 @@ def test_c2_full_frame_is_identical_with_either_rank():
     from helpers import hip_forward_inference, hip_forward_raw
     cloud, cam = scenes.config_c2(), orbit_cameras(200, 960, 540)[100]
     outs = {}
+    start = fallbacks()
     for mode in (0, 1):
         _lib.set_option(_lib.OPT_RADIX_RANK, mode)
         outs[mode] = (hip_forward_raw(cloud, cam, cull=True, debug=True), hip_forward_inference(cloud, cam, slabs=0, slab_first=40, debug=True))
@@ -128,3 +164,4 @@ def test_c2_full_frame_is_identical_with_either_rank():
         np.testing.assert_array_equal(outs[0][1][k], outs[1][1][k], err_msg="inference " + k)
         np.testing.assert_array_equal(outs[0][1][k], outs[0][0][k], err_msg="inference vs full " + k)
     assert outs[0][1]["slab_pairs"] == outs[1][1]["slab_pairs"] and len(outs[0][1]["slab_pairs"]) > 1
+    assert fallbacks() == start, "a tile's LDS-add ranks failed the order check on this device"
