@@ -883,24 +883,26 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     stamp(1, stream);
 
     // The one host round trip of the call (rasterizer_impl.cu:282 reads num_rendered back to size the binning arena).  Here
-    // the totals are summed by one short launch behind the projection kernel, which stores them straight into the call's
+    // the totals are summed by one extra workgroup of the depth sort's first kernel, which stores them straight into the call's
     // pinned slot (device-visible at its own address) and clears the call's zero block on the way; the host waits on an
     // event while the GPU is already running the depth sort.
     void* const host_dev = fc.pinned.dev;
     memset(fc.pinned.host, 0, kCounterBytes);
-    GSR_HIP(gsr::launch_counter_tally(ga.tallies, (P + 255) / 256, ga.counters, zero_end - off_flag,
-                                      reinterpret_cast<gsr::FrameCounters*>(host_dev), stream));
-    if (host_dev == nullptr)   // (a runtime that does not map pinned memory: the totals went into the zero block's first slots)
-        GSR_HIP(hipMemcpyAsync(fc.pinned.host, gbase + off_flag, kCounterBytes, hipMemcpyDeviceToHost, stream));
-    GSR_HIP(hipEventRecord(fc.pinned.copied, stream));
-    fc.queued = true;
-
+    const gsr::TallyDuty tally = {ga.tallies, (P + 255) / 256, ga.counters, (int)((zero_end - off_flag) / 4),
+                                  reinterpret_cast<gsr::FrameCounters*>(host_dev), host_dev != nullptr ? 16 : 1};
+    // (a runtime that does not map pinned memory: the totals go into the zero block's first slots and are copied behind the sort)
     uint32_t* keys_sorted = nullptr;
+    fc.queued = true;   // from the first launch below on a kernel may store into the pinned slot (what ~ForwardCall looks at)
     GSR_HIP(gsr::radix_sort_pairs((uint32_t*)(gbase + fc.off_radix_tmp), (uint32_t)P, 32, ga.depth_keys, (uint32_t*)(gbase + off_keys_b),
                                   (uint32_t*)(gbase + off_ids_a), (uint32_t*)(gbase + off_ids_b),
                                   /*iota_payload=*/true, /*want_sorted_keys=*/false, &keys_sorted, &fc.order, stream, nullptr,
                                   g_options[GSR_OPT_DEPTH_DROP] != 0 ? &gsr::kCulledKey : nullptr,
-                                  /*few_top_digits=*/true));   // the keys are positive floats: their top byte is sign + 7 exponent bits
+                                  /*few_top_digits=*/true,   // the keys are positive floats: their top byte is sign + 7 exponent bits
+                                  &tally, host_dev != nullptr ? fc.pinned.copied : nullptr));
+    if (host_dev == nullptr) {
+        GSR_HIP(hipMemcpyAsync(fc.pinned.host, gbase + off_flag, kCounterBytes, hipMemcpyDeviceToHost, stream));
+        GSR_HIP(hipEventRecord(fc.pinned.copied, stream));
+    }
     GSR_STAGE_CHECK("depth_sort");
     stamp(2, stream);
     geom_off[GSR_GEOM_DEPTH_ORDER] = (size_t)((char*)fc.order - gbase);
@@ -922,13 +924,14 @@ int forward_finish(ForwardCall& fc) {
     fc.queued = false;
     fc.device_work = true;   // from here on kernels that store into the pinned slot may be in flight until `finished`
     const gsr::FrameCounters* hc = reinterpret_cast<const gsr::FrameCounters*>(fc.pinned.host);  // first kCounterBytes only
-    const uint32_t flag = hc->error_flag;
+    uint32_t flag = 0u;
     unsigned long long rect_total = 0, live_total = 0, emitting = 0, pool_rows = 0;
     for (int i = 0; i < gsr::kRectPartials; ++i) {
         rect_total += hc->pair_totals[i] >> 32;
         live_total += hc->pair_totals[i] & 0xFFFFFFFFull;
         emitting += hc->visible[i];
-        pool_rows += hc->big_rows[i];
+        pool_rows += hc->big_rows[i] & 0x7FFFFFFFu;
+        flag |= hc->big_rows[i] >> 31;
     }
     if (debug && fc.prefiltered && (flag & 1u))
         return fail(GSR_ERR_PREFILTERED, "a Gaussian was culled although prefiltered is set (auxiliary.h:156-160)");

@@ -17,12 +17,13 @@ constexpr uint32_t kMaskTiles = 64;          // tight rectangles up to this many
 
 // Device words of one forward call that must be zero before the kernel that uses them: cleared, with the slab table and
 // the bit rows that follow them in the arena, by the tally kernel that follows the projection (no memset launch).
-// The totals travel to the host in the same layout (slot 0 of each array; the other slots are zero).
+// The totals travel to the host in the same layout (one slot of each array per tally group, the others zero; bit 31 of a
+// big_rows slot = a prefiltered violation).
 struct FrameCounters {
     unsigned long long pair_totals[kRectPartials];  // (sum of rectangle areas) << 32 | upper bound of the live pairs
     uint32_t visible[kRectPartials];                // Gaussians that emit at least the chance of a pair (key != kCulledKey)
     uint32_t big_rows[kRectPartials];               // tile rows of the splats too large for a mask (sizes the run pool)
-    uint32_t error_flag;                            // bit 0 = prefiltered violation
+    uint32_t error_flag;                            // (unused: a prefiltered violation travels as bit 31 of a big_rows slot)
     uint32_t pool_used;                             // run pool: rows handed out so far (bin_gather_kernel)
     uint32_t order_violations;                      // debug calls: list entries out of (tile, depth bits, id) order
     uint32_t pad;
@@ -166,12 +167,18 @@ hipError_t launch_preprocess(const GaussianInputs& in, const Camera& cam, const 
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
                                hipStream_t stream);
 // Sums the projection kernel's per-workgroup tallies, stores the totals at `host_totals` (pinned host memory at its
-// device-visible address; slot 0 of each array, the rest of the block must have been zeroed by the host) or, when that is
-// null, into `zero_block` itself (a D2H copy then follows), and clears the `zero_bytes` at `zero_block` (frame counters,
-// slab table, quadrant and tile bits of the call) -- one short launch in place of a memset before the projection and a
-// copy after it.
-hipError_t launch_counter_tally(const BlockTally* tallies, int blocks, FrameCounters* zero_block, size_t zero_bytes,
-                                FrameCounters* host_totals, hipStream_t stream);
+// device-visible address; slot 0 of each array, the rest of the block must have been zeroed by the host) or, if that is
+// null, into `zero_block` itself (a D2H copy then follows), and clears the `zero_words` words at `zero_block` (frame counters,
+// slab table, quadrant and tile bits of the call).  Not a launch of its own: one extra workgroup of the depth sort's first
+// count kernel does it (radix_sort_pairs' `first_count_duty`) -- nothing in the depth sort needs its result.
+struct TallyDuty {
+    const BlockTally* tallies;
+    int blocks;
+    FrameCounters* zero_block;
+    int zero_words;
+    FrameCounters* host_totals;
+    int groups;   // workgroups that share the duty (<= kRectPartials; 1 if host_totals is null): group j fills slot j of the totals
+};
 // SH colours of the Gaussians the pair expansion of one slab marked (`listed[gid] == tag`, tag = slab + 1;
 // GaussianInputs::defer_colour), evaluated in Gaussian order; rgb[gid] is written.
 // `duty` (nullable): the slab's tile ranges are computed by the first workgroups of the same launch.
@@ -310,6 +317,8 @@ hipError_t launch_pack_rgba8(const float* color, const float* alpha, uint8_t* ou
 // pass -- not ranked, not written; the sorted arrays hold the others, in order, and their tails are undefined.
 // few_top_digits: a hint that the most significant digit takes only a handful of values (the top byte of a positive float: sign
 // and seven exponent bits) -- that pass then ranks with ballots, whose cost does not grow with lanes hitting one counter.
+// first_count_duty (nullable): work one extra workgroup of the first pass's count kernel does (the projection's tallies);
+// after_first_count (nullable) is recorded right behind that launch.  With n == 0 or bits <= 0 neither happens.
 // counts the returning LDS adds whose result was not (value before the instruction) + (lower lanes on the same counter)
 hipError_t launch_lds_atomic_order_selftest(uint32_t workgroups, uint32_t rounds, uint32_t seed, unsigned long long* mismatches,
                                             hipStream_t stream);
@@ -326,6 +335,7 @@ hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* k
                             uint32_t* vals, uint32_t* vals_alt, bool iota_payload, bool want_sorted_keys,
                             uint32_t** keys_sorted, uint32_t** vals_sorted, hipStream_t stream,
                             const uint32_t* n_device = nullptr, const uint32_t* drop_key = nullptr,
-                            bool few_top_digits = false);
+                            bool few_top_digits = false, const TallyDuty* first_count_duty = nullptr,
+                            hipEvent_t after_first_count = nullptr);
 
 } // namespace gsr

@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
     // gets expanded and sorted; exact but for the splats too large for a mask) in the low word and the reference's
     // num_rendered (sum of rectangle areas, part of its return value) in the high word of one 64-bit sum.  Summed over
     // the wave, then over the workgroup's four waves through LDS, and stored as this workgroup's BlockTally: no atomics and
-    // no zero-filled accumulator (counter_tally_kernel adds the workgroups up).
+    // no zero-filled accumulator (the tally duty of the depth sort's first count kernel adds the workgroups up).
     __shared__ unsigned long long s_tot[4];
     __shared__ uint32_t s_vis[4], s_big[4];
     unsigned long long wave_tot = ((unsigned long long)rect_area << 32) | (unsigned long long)live_bound;
@@ -310,48 +310,6 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
         *reinterpret_cast<uint4*>(out.tallies + blockIdx.x) = *reinterpret_cast<const uint4*>(&t);
     }
     GSR_KTRACE(blockIdx.x, 3);
-}
-
-// ------------------------------------------------------------------------------------------------
-// One workgroup right behind the projection kernel: adds up its per-workgroup tallies, hands the totals to the host and
-// clears the call's zero block.  Takes the place of the memset that used to precede the projection kernel and of the
-// copy kernel that followed it (rasterizer_impl.cu:282 reads num_rendered back at this point).
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) counter_tally_kernel(const BlockTally* __restrict__ tallies, int blocks,
-                                                             FrameCounters* __restrict__ zero_block, int zero_words,
-                                                             FrameCounters* __restrict__ host_totals) {
-    __shared__ unsigned long long s_tot[16];
-    __shared__ uint32_t s_vis[16], s_big[16], s_flag[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned long long tot = 0ull;
-    uint32_t vis = 0u, big = 0u, flag = 0u;
-    for (int b = tid; b < blocks; b += 1024) {
-        const uint4 t = *reinterpret_cast<const uint4*>(tallies + b);
-        tot += (unsigned long long)t.x | ((unsigned long long)t.y << 32);
-        vis += t.z;
-        big += t.w & 0x7FFFFFFFu;
-        flag |= t.w >> 31;
-    }
-    uint32_t* z = reinterpret_cast<uint32_t*>(zero_block);
-    for (int i = tid; i < zero_words; i += 1024) z[i] = 0u;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        tot += __shfl_xor(tot, d);
-        vis += (uint32_t)__shfl_xor((int)vis, d);
-        big += (uint32_t)__shfl_xor((int)big, d);
-        flag |= (uint32_t)__shfl_xor((int)flag, d);
-    }
-    if (lane == 0) { s_tot[wave] = tot; s_vis[wave] = vis; s_big[wave] = big; s_flag[wave] = flag; }
-    __syncthreads();   // (also: the zero block is cleared before the totals may land in it)
-    if (tid == 0) {
-        tot = 0ull; vis = 0u; big = 0u; flag = 0u;
-        for (int w = 0; w < 16; ++w) { tot += s_tot[w]; vis += s_vis[w]; big += s_big[w]; flag |= s_flag[w]; }
-        FrameCounters* dst = host_totals != nullptr ? host_totals : zero_block;
-        dst->pair_totals[0] = tot;
-        dst->visible[0] = vis;
-        dst->big_rows[0] = big;
-        dst->error_flag = flag;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -605,13 +563,6 @@ hipError_t launch_sh_colour_all(const GaussianInputs& in, const Camera& cam, con
     RangesDuty none = {};
     hipLaunchKernelGGL(sh_colour_all_kernel, dim3(blocks), dim3(256), 0, stream, in, cam.cam_pos, radii, rgb, duty ? *duty : none,
                        duty ? ranges_duty_blocks(duty->num_tiles) : 0);
-    return hipGetLastError();
-}
-
-hipError_t launch_counter_tally(const BlockTally* tallies, int blocks, FrameCounters* zero_block, size_t zero_bytes,
-                                FrameCounters* host_totals, hipStream_t stream) {
-    hipLaunchKernelGGL(counter_tally_kernel, dim3(1), dim3(1024), 0, stream, tallies, blocks, zero_block, (int)(zero_bytes / 4),
-                       host_totals);
     return hipGetLastError();
 }
 

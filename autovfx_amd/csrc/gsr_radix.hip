@@ -86,15 +86,72 @@ __device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t* sc
 }
 
 // ------------------------------------------------------------------------------------------------
-// count: counts[digit * tiles_pad + tile] = number of keys of the tile with that digit.
+// The projection kernel's tallies, summed by ONE workgroup (gsr_internal.h: TallyDuty): the totals go straight into the call's
+// pinned slot (rasterizer_impl.cu:282 reads num_rendered back at this point) and the call's zero block is cleared with plain
+// stores.  Rounds 1 - 2 had a memset in front of the projection and a copy kernel behind it, round 3 one short launch of its
+// own (7 us between the projection and the depth sort); now it rides on the depth sort's first count kernel: `groups` extra
+// workgroups (one when the totals land in the zero block itself), each filling its own slot of the totals, which the host adds.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void counter_tally_duty(const TallyDuty& d, int group, uint32_t* lds /* >= 6 * kWaves words */) {
+    unsigned long long* s_tot = reinterpret_cast<unsigned long long*>(lds);
+    uint32_t *s_vis = lds + 2 * kWaves, *s_big = s_vis + kWaves, *s_flag = s_big + kWaves;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int first = group * kThreads + tid, stride = d.groups * kThreads;
+    unsigned long long tot = 0ull;
+    uint32_t vis = 0u, big = 0u, flag = 0u;
+    // four independent loads in flight per lane: at 3 M Gaussians and 16 groups that is the whole share of a lane, one memory
+    // round trip (one group walking all 11 719 tallies a load at a time outlasted the count kernel it rides on)
+    for (int b0 = first; b0 < d.blocks; b0 += 4 * stride) {
+        uint4 t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int b = b0 + j * stride;
+            t[j] = b < d.blocks ? *reinterpret_cast<const uint4*>(d.tallies + b) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tot += (unsigned long long)t[j].x | ((unsigned long long)t[j].y << 32);
+            vis += t[j].z;
+            big += t[j].w & 0x7FFFFFFFu;
+            flag |= t[j].w >> 31;
+        }
+    }
+    uint32_t* z = reinterpret_cast<uint32_t*>(d.zero_block);
+    for (int i = first; i < d.zero_words; i += stride) z[i] = 0u;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        tot += __shfl_xor(tot, s);
+        vis += (uint32_t)__shfl_xor((int)vis, s);
+        big += (uint32_t)__shfl_xor((int)big, s);
+        flag |= (uint32_t)__shfl_xor((int)flag, s);
+    }
+    if (lane == 0) { s_tot[wave] = tot; s_vis[wave] = vis; s_big[wave] = big; s_flag[wave] = flag; }
+    __syncthreads();   // (one group, totals into the zero block itself: it is cleared before they land in it)
+    if (tid == 0) {
+        tot = 0ull; vis = 0u; big = 0u; flag = 0u;
+        for (int w = 0; w < kWaves; ++w) { tot += s_tot[w]; vis += s_vis[w]; big += s_big[w]; flag |= s_flag[w]; }
+        FrameCounters* dst = d.host_totals != nullptr ? d.host_totals : d.zero_block;
+        dst->pair_totals[group] = tot;                     // the host adds the slots up
+        dst->visible[group] = vis;
+        dst->big_rows[group] = big | (flag << 31);         // (bit 31, as in a BlockTally: a prefiltered violation)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// count: counts[digit * tiles_pad + tile] = number of keys of the tile with that digit.  With a duty (duty.tallies != null)
+// the launch has duty.groups workgroups more and the first ones do the duty instead.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kThreads) radix_count_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
                                                               uint32_t digit_mask, uint32_t* __restrict__ counts,
                                                               uint32_t tiles_pad, const uint32_t* __restrict__ n_device,
-                                                              int drop, uint32_t drop_key) {
+                                                              int drop, uint32_t drop_key, TallyDuty duty) {
     __shared__ uint32_t s_hist[kCountCopies][256];
     const int tid = threadIdx.x;
-    const uint32_t block = blockIdx.x;
+    uint32_t block = blockIdx.x;
+    if (duty.tallies != nullptr) {   // (workgroup-uniform)
+        if (block < (uint32_t)duty.groups) { counter_tally_duty(duty, (int)block, &s_hist[0][0]); return; }
+        block -= (uint32_t)duty.groups;
+    }
     if (n_device != nullptr) n = *n_device;  // the launch was sized for an upper bound
     if (block * (uint32_t)kTileItems >= n) return;
 #pragma unroll
@@ -507,7 +564,8 @@ size_t radix_scratch_words(uint32_t n) {
 hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt,
                             uint32_t* vals, uint32_t* vals_alt, bool iota_payload, bool want_sorted_keys,
                             uint32_t** keys_sorted, uint32_t** vals_sorted, hipStream_t stream, const uint32_t* n_device,
-                            const uint32_t* drop_key, bool few_top_digits) {
+                            const uint32_t* drop_key, bool few_top_digits, const TallyDuty* first_count_duty,
+                            hipEvent_t after_first_count) {
     *keys_sorted = keys;
     *vals_sorted = vals;
     if (n == 0 || bits <= 0) return hipSuccess;
@@ -534,7 +592,13 @@ hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* k
         const uint32_t dkey = dropping ? *drop_key : 0u;
         uint32_t* kept_out = drop ? kept : nullptr;
         if (dropping && p == 1) n_device = kept;   // (the launches stay sized for n: surplus workgroups leave at once)
-        hipLaunchKernelGGL(radix_count_kernel, dim3(tiles), dim3(kThreads), 0, stream, kin, n, shift, mask, counts, tiles_pad, n_device, drop, dkey);
+        const bool with_duty = p == 0 && first_count_duty != nullptr;
+        hipLaunchKernelGGL(radix_count_kernel, dim3(tiles + (with_duty ? (uint32_t)first_count_duty->groups : 0u)), dim3(kThreads), 0, stream, kin, n, shift, mask, counts,
+                           tiles_pad, n_device, drop, dkey, with_duty ? *first_count_duty : TallyDuty{});
+        if (p == 0 && after_first_count != nullptr) {
+            const hipError_t e = hipEventRecord(after_first_count, stream);
+            if (e != hipSuccess) return e;
+        }
         hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(kThreads), 0, stream, counts, tiles, tiles_pad, totals, n_device);
 #define GSR_RADIX_LAUNCH(I, K, A)                                                                                      \
     hipLaunchKernelGGL((radix_scatter_kernel<I, K, A>), dim3(tiles), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, \
