@@ -949,7 +949,7 @@ int forward_finish(ForwardCall& fc) {
     for (int k = 0; k < S; ++k) max_bound = plan.bound[k] > max_bound ? plan.bound[k] : max_bound;
     const int tile_bits = tile_key_bits((uint32_t)T);
     const int passes = (tile_bits + 7) / 8;
-    const size_t tsort_tmp = gsr::radix_scratch_words(max_bound) * sizeof(uint32_t);
+    const size_t tsort_tmp = gsr::radix_scratch_words(max_bound, gsr::expand_blocks(max_bound)) * sizeof(uint32_t);
     Carver bc;
     bc.take<gsr::ArenaHeader>(1);
     // tile keys ping-pong: shared by the slabs (nobody reads a slab's keys once its ranges are known)
@@ -1032,14 +1032,17 @@ int forward_finish(ForwardCall& fc) {
         uint32_t* list_alt = (passes % 2 == 0) ? shared_list : own_list;
         uint32_t *keys_in = (uint32_t*)(bbase + off_tk_a), *keys_alt = (uint32_t*)(bbase + off_tk_b);
         if (k > 0) GSR_HIP(gsr::launch_slab_recount(ba, k, stream));
-        GSR_HIP(gsr::launch_expand(ba, k, plan.bound[k], keys_in, list_in, stream));
+        // the expansion's workgroups count the low digits of the tile keys they write: the tile sort starts at its first scan
+        const uint32_t precount = gsr::expand_blocks(plan.bound[k]);
+        GSR_HIP(gsr::launch_expand(ba, k, plan.bound[k], keys_in, list_in, (uint32_t*)(bbase + off_btmp),
+                                   gsr::radix_count_stride(plan.bound[k], precount), gsr::radix_first_digit_mask(tile_bits), stream));
         GSR_STAGE_CHECK("expand");
         stamp(kHeadEvents + kSlabEvents * k + 0, stream);
         uint32_t *tk_sorted = keys_in, *pl_sorted = list_in;
         if (plan.bound[k] > 0)
             GSR_HIP(gsr::radix_sort_pairs((uint32_t*)(bbase + off_btmp), plan.bound[k], tile_bits, keys_in, keys_alt, list_in, list_alt,
                                           /*iota_payload=*/false, /*want_sorted_keys=*/true, &tk_sorted, &pl_sorted, stream,
-                                          &slab->pairs));
+                                          &slab->pairs, nullptr, false, nullptr, nullptr, precount));
         else
             pl_sorted = own_list;
         GSR_STAGE_CHECK("tile_sort");

@@ -48,7 +48,7 @@ extern "C" __attribute__((visibility("default"))) int gsr_debug_set_binning_trac
 namespace gsr {
 namespace {
 
-constexpr int kPairTile = 2048;
+constexpr int kPairTile = kExpandTile;
 constexpr int kPairsPerLane = kPairTile / 256;  // consecutive pairs of one lane
 constexpr int kMaxDoneWords = 4096;             // most tile bit rows the slab kernels hold in LDS (16 KB; an 8K x 8K image has 1 024)
 static_assert(kDupTile == 1024, "256 lanes x 4 consecutive positions");
@@ -646,7 +646,8 @@ __global__ void __launch_bounds__(256) slab_compact_kernel(BinningArrays a, int 
 // a later slab the compacted list of the positions that still have a live pair (slab_compact_kernel).
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, uint32_t* __restrict__ tile_keys,
-                                                     uint32_t* __restrict__ point_list) {
+                                                     uint32_t* __restrict__ point_list, uint32_t* __restrict__ first_counts,
+                                                     uint32_t count_stride, uint32_t digit_mask) {
     constexpr int kBatch = 2048;            // items whose offsets are parked in LDS at a time
     __shared__ uint32_t s_incl[kBatch + 1]; // s_incl[0] = pairs before the batch's first item
     __shared__ uint32_t s_scratch[4];
@@ -659,8 +660,7 @@ __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, 
     // few per cent), 2048 pairs per workgroup would leave most of the GPU idle behind a handful of long serial walks:
     // the pairs of a lane shrink (8 or 4) until the workgroups of the launch are all needed.  (2048 / 1024 / 4096 pairs
     // per workgroup at C3: 181 / 180 / 187 us of binning per frame.)
-    uint32_t per_lane = (uint32_t)kPairsPerLane;
-    while (per_lane > 4u && (unsigned long long)gridDim.x * 256ull * (per_lane >> 1) >= (unsigned long long)num_pairs) per_lane >>= 1;
+    const uint32_t per_lane = expand_pairs_per_lane(gridDim.x, num_pairs);
     const uint32_t pair_tile = 256u * per_lane;
     const uint32_t p_begin = blockIdx.x * pair_tile;
     if (p_begin >= num_pairs) return;
@@ -745,6 +745,21 @@ __global__ void __launch_bounds__(256) expand_kernel(BinningArrays a, int slab, 
         s0 += kBatch;
     }
     GSR_BTRACE(16384 + 8192 * slab + blockIdx.x, 3);
+    if (first_counts != nullptr) {
+        // The tile sort's first pass would read these keys back only to count their low digits per 4096-pair tile: the
+        // workgroup that made them counts them itself (one launch less per slab), and the sort's first scan folds the two or
+        // four workgroups of a tile.  Every one of the 256 digit rows is written (zeros above the mask): the scan reads all.
+        uint32_t* s_hist = s_incl;   // 4 x 256 words of the offsets' parking place (every lane is past its last read of it)
+        __syncthreads();
+        for (int i = tid; i < 4 * 256; i += 256) s_hist[i] = 0u;
+        __syncthreads();
+        uint32_t* mine = s_hist + 256 * (tid & 3);
+#pragma unroll
+        for (int q = 0; q < kPairsPerLane; ++q)
+            if ((uint32_t)q < per_lane && my_begin + q < p_end) atomicAdd(&mine[keys[q] & digit_mask], 1u);
+        __syncthreads();
+        first_counts[(size_t)tid * count_stride + blockIdx.x] = s_hist[tid] + s_hist[256 + tid] + s_hist[512 + tid] + s_hist[768 + tid];
+    }
     if (my_begin + per_lane <= p_end) {   // (per_lane is a multiple of 4 and so is my_begin: 16-byte stores)
 #pragma unroll
         for (int q = 0; q < kPairsPerLane; q += 4) {
@@ -831,13 +846,15 @@ hipError_t launch_slab_recount(const BinningArrays& a, int slab, hipStream_t str
     return hipGetLastError();
 }
 
+uint32_t expand_blocks(uint32_t pairs_bound) { return (pairs_bound + kPairTile - 1) / kPairTile; }
+
 hipError_t launch_expand(const BinningArrays& a, int slab, uint32_t pairs_bound, uint32_t* tile_keys, uint32_t* point_list,
-                         hipStream_t stream) {
+                         uint32_t* first_counts, uint32_t count_stride, uint32_t digit_mask, hipStream_t stream) {
     if (pairs_bound == 0) return hipSuccess;
     const int done_words = slab > 0 ? a.grid_y * a.row_words : 0;
     if (done_words > kMaxDoneWords) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(expand_kernel, dim3((pairs_bound + kPairTile - 1) / kPairTile), dim3(256), (size_t)done_words * 4, stream, a, slab,
-                       tile_keys, point_list);
+    hipLaunchKernelGGL(expand_kernel, dim3(expand_blocks(pairs_bound)), dim3(256), (size_t)done_words * 4, stream, a, slab,
+                       tile_keys, point_list, first_counts, count_stride, digit_mask);
     return hipGetLastError();
 }
 

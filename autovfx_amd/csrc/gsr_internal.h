@@ -12,6 +12,7 @@ constexpr uint32_t kCulledKey = 0xFFFFFFFFu; // depth key of a Gaussian that pro
 constexpr int kRectPartials = 256;           // partial sums of rectangle areas (power of two)
 constexpr int kRadixTile = 4096;             // pairs per workgroup of a radix pass (gsr_radix.hip)
 constexpr int kDupTile = 1024;               // sorted positions per workgroup of the record gather + scan
+constexpr int kExpandTile = 2048;            // most pairs one workgroup of the pair expansion writes (256 lanes x 8; gsr_binning.hip)
 constexpr int kMaxSlabs = 8;                 // front-to-back depth slabs of one call (occlusion culling between slabs)
 constexpr uint32_t kMaskTiles = 64;          // tight rectangles up to this many tiles carry a bit mask of live tiles
 
@@ -226,7 +227,11 @@ hipError_t launch_bin_scan(const BinningArrays& a, const Camera& cam, int num_sl
 // slabs > 0: drop the tiles finished by the slabs before (done_rows), re-scan inside the slab, set slabs[s].pairs
 hipError_t launch_slab_recount(const BinningArrays& a, int slab, hipStream_t stream);
 // (tile id, Gaussian id) pairs of one slab in depth order; at most pairs_bound of them (the grid is sized for it)
+// first_counts (nullable): the workgroups also leave the digit histogram of their keys for the tile sort's first pass
+// (radix_sort_pairs' precount_blocks = expand_blocks(pairs_bound)): first_counts[digit * count_stride + workgroup].
+uint32_t expand_blocks(uint32_t pairs_bound);
 hipError_t launch_expand(const BinningArrays& a, int slab, uint32_t pairs_bound, uint32_t* tile_keys, uint32_t* point_list,
+                         uint32_t* first_counts, uint32_t count_stride, uint32_t digit_mask,
                          hipStream_t stream);
 // debug calls: counts (into counters->order_violations) the entries of a slab's sorted list that are not in ascending
 // (tile, depth bits, Gaussian id) order relative to their predecessor -- what two stable sorts must have produced
@@ -319,6 +324,10 @@ hipError_t launch_pack_rgba8(const float* color, const float* alpha, uint8_t* ou
 // and seven exponent bits) -- that pass then ranks with ballots, whose cost does not grow with lanes hitting one counter.
 // first_count_duty (nullable): work one extra workgroup of the first pass's count kernel does (the projection's tallies);
 // after_first_count (nullable) is recorded right behind that launch.  With n == 0 or bits <= 0 neither happens.
+// precount_blocks != 0 (with n_device): the first pass has no count kernel -- the kernel that wrote the keys, a launch of
+// `precount_blocks` workgroups each covering 256 * expand_pairs_per_lane(precount_blocks, *n_device) consecutive keys, left
+// counts[digit * radix_count_stride(n, precount_blocks) + workgroup] for all 256 digits in `scratch`; the first scan folds them
+// into 4096-key tiles.  The scratch must then be radix_scratch_words(n, precount_blocks) words.
 // counts the returning LDS adds whose result was not (value before the instruction) + (lower lanes on the same counter)
 hipError_t launch_lds_atomic_order_selftest(uint32_t workgroups, uint32_t rounds, uint32_t seed, unsigned long long* mismatches,
                                             hipStream_t stream);
@@ -330,12 +339,24 @@ void radix_set_rank_request(int request);
 int radix_rank_request();
 int radix_rank_mode(hipStream_t stream, unsigned long long* violations);
 hipError_t radix_rank_fallbacks(unsigned long long* tiles);   // tiles re-ranked with ballots after a failed order check
-size_t radix_scratch_words(uint32_t n);
+size_t radix_scratch_words(uint32_t n, uint32_t precount_blocks = 0);
+// Pairs per lane of the pair expansion (expand_kernel): its launch of `grid` workgroups was sized for an upper bound of the
+// `n` pairs; when far fewer are left the share of a lane halves (8 -> 4) so that the workgroups of the launch are all needed.
+// Shared with the tile sort's first scan, which folds the expansion's per-workgroup digit counts into 4096-pair tiles.
+__host__ __device__ inline uint32_t expand_pairs_per_lane(uint32_t grid, uint32_t n) {
+    uint32_t per_lane = (uint32_t)kExpandTile / 256u;
+    while (per_lane > 4u && (unsigned long long)grid * 256ull * (per_lane >> 1) >= (unsigned long long)n) per_lane >>= 1;
+    return per_lane;
+}
+// Digit of the first pass of a `bits`-wide sort (shift 0): its mask.
+uint32_t radix_first_digit_mask(int bits);
+// Row stride (words) of the per-digit count rows in a sort's scratch: counts[digit * stride + tile].
+uint32_t radix_count_stride(uint32_t n, uint32_t precount_blocks = 0);
 hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt,
                             uint32_t* vals, uint32_t* vals_alt, bool iota_payload, bool want_sorted_keys,
                             uint32_t** keys_sorted, uint32_t** vals_sorted, hipStream_t stream,
                             const uint32_t* n_device = nullptr, const uint32_t* drop_key = nullptr,
                             bool few_top_digits = false, const TallyDuty* first_count_duty = nullptr,
-                            hipEvent_t after_first_count = nullptr);
+                            hipEvent_t after_first_count = nullptr, uint32_t precount_blocks = 0);
 
 } // namespace gsr

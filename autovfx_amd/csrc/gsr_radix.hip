@@ -198,18 +198,49 @@ __global__ void __launch_bounds__(kThreads) radix_count_kernel(const uint32_t* _
 // scan: one workgroup per digit turns its row of tile counts into exclusive prefixes, in place;
 // totals[digit] = number of keys with that digit.
 // ------------------------------------------------------------------------------------------------
+// kFold (the first pass of a sort whose keys were counted by the kernel that wrote them, radix_sort_pairs' precount_blocks): the
+// row holds one count per WORKGROUP of that kernel, two or four of them to a 4096-key tile (expand_pairs_per_lane); a lane adds
+// up the workgroups of its four tiles first.  In place: a tile's prefix lands on a word that only this round's lanes read, before
+// the barrier inside the block sum (tile t's workgroups start at word t * g >= t).
+template <bool kFold>
 __global__ void __launch_bounds__(kThreads) radix_scan_kernel(uint32_t* __restrict__ counts, uint32_t tiles,
                                                              uint32_t tiles_pad, uint32_t* __restrict__ totals,
-                                                             const uint32_t* __restrict__ n_device) {
+                                                             const uint32_t* __restrict__ n_device, uint32_t precount_blocks) {
     __shared__ uint32_t s_scan[kWaves];
     const int tid = threadIdx.x;
-    if (n_device != nullptr) tiles = (*n_device + (uint32_t)kTileItems - 1u) / (uint32_t)kTileItems;
-    uint4* row = reinterpret_cast<uint4*>(counts + (size_t)blockIdx.x * tiles_pad);  // tiles_pad is a multiple of 4
+    uint32_t group = 1u, live_blocks = 0u;
+    if (n_device != nullptr) {
+        const uint32_t n = *n_device;
+        tiles = (n + (uint32_t)kTileItems - 1u) / (uint32_t)kTileItems;
+        if (kFold) {
+            const uint32_t per_block = 256u * expand_pairs_per_lane(precount_blocks, n);
+            group = (uint32_t)kTileItems / per_block;
+            live_blocks = (n + per_block - 1u) / per_block;   // the workgroups behind them wrote nothing
+        }
+    }
+    uint32_t* row_words = counts + (size_t)blockIdx.x * tiles_pad;
+    uint4* row = reinterpret_cast<uint4*>(row_words);  // tiles_pad is a multiple of 4
     uint32_t carry = 0;
     for (uint32_t t0 = 0; t0 < tiles; t0 += 4u * kThreads) {
         const uint32_t t = t0 + 4u * tid;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (t < tiles_pad) v = row[t / 4u];
+        if (kFold) {
+            uint32_t c[4] = {0u, 0u, 0u, 0u};
+            if (t < tiles) {
+                for (uint32_t j = 0; j < 4u * group; j += 4u) {   // 16-byte loads: t * group is a multiple of 4
+                    const uint32_t b = t * group + j;
+                    if (b >= live_blocks) break;
+                    const uint4 w = *reinterpret_cast<const uint4*>(row_words + b);
+                    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (b + k < live_blocks) c[(j + k) / group] += ww[k];
+                }
+            }
+            v = make_uint4(c[0], c[1], c[2], c[3]);
+        } else {
+            if (t < tiles_pad) v = row[t / 4u];
+        }
         if (t + 0 >= tiles) v.x = 0u;
         if (t + 1 >= tiles) v.y = 0u;
         if (t + 2 >= tiles) v.z = 0u;
@@ -556,16 +587,24 @@ int radix_rank_mode(hipStream_t stream, unsigned long long* violations) {
     return verdict == 1 ? 1 : 0;
 }
 
-size_t radix_scratch_words(uint32_t n) {
-    const size_t tiles = ((size_t)n + kTileItems - 1) / kTileItems;
-    return 256u * ((tiles + 3u) & ~(size_t)3u) + 256u + 4u;  // per-digit rows of tile counts, the digit totals, the kept count
+uint32_t radix_count_stride(uint32_t n, uint32_t precount_blocks) {
+    const uint32_t tiles = (n + kTileItems - 1) / kTileItems;
+    return (max(tiles, precount_blocks) + 3u) & ~3u;
+}
+size_t radix_scratch_words(uint32_t n, uint32_t precount_blocks) {
+    return (size_t)256u * radix_count_stride(n, precount_blocks) + 256u + 4u;  // per-digit rows of tile counts, the digit totals, the kept count
+}
+uint32_t radix_first_digit_mask(int bits) {
+    if (bits <= 0) return 0u;
+    const int passes = (bits + 7) / 8;
+    return (1u << (bits / passes + (bits % passes != 0 ? 1 : 0))) - 1u;
 }
 
 hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt,
                             uint32_t* vals, uint32_t* vals_alt, bool iota_payload, bool want_sorted_keys,
                             uint32_t** keys_sorted, uint32_t** vals_sorted, hipStream_t stream, const uint32_t* n_device,
                             const uint32_t* drop_key, bool few_top_digits, const TallyDuty* first_count_duty,
-                            hipEvent_t after_first_count) {
+                            hipEvent_t after_first_count, uint32_t precount_blocks) {
     *keys_sorted = keys;
     *vals_sorted = vals;
     if (n == 0 || bits <= 0) return hipSuccess;
@@ -573,7 +612,8 @@ hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* k
     const int passes = (bits + 7) / 8;
     const int rank_form = radix_rank_mode(stream, nullptr);  // (the first sort on a device runs the lane-order self-test)
     const uint32_t tiles = (n + kTileItems - 1) / kTileItems;
-    const uint32_t tiles_pad = (tiles + 3u) & ~3u;
+    if (precount_blocks != 0u && n_device == nullptr) return hipErrorInvalidValue;
+    const uint32_t tiles_pad = radix_count_stride(n, precount_blocks);
     uint32_t* counts = scratch;
     uint32_t* totals = scratch + (size_t)256u * tiles_pad;
     uint32_t* kept = totals + 256;   // drop_key: how many items the first pass kept = what the later passes sort
@@ -593,13 +633,18 @@ hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* k
         uint32_t* kept_out = drop ? kept : nullptr;
         if (dropping && p == 1) n_device = kept;   // (the launches stay sized for n: surplus workgroups leave at once)
         const bool with_duty = p == 0 && first_count_duty != nullptr;
-        hipLaunchKernelGGL(radix_count_kernel, dim3(tiles + (with_duty ? (uint32_t)first_count_duty->groups : 0u)), dim3(kThreads), 0, stream, kin, n, shift, mask, counts,
-                           tiles_pad, n_device, drop, dkey, with_duty ? *first_count_duty : TallyDuty{});
+        const bool precounted = p == 0 && precount_blocks != 0u;   // (the keys' writer left the counts: no count kernel, a folding scan)
+        if (!precounted)
+            hipLaunchKernelGGL(radix_count_kernel, dim3(tiles + (with_duty ? (uint32_t)first_count_duty->groups : 0u)), dim3(kThreads), 0, stream, kin, n, shift, mask, counts,
+                               tiles_pad, n_device, drop, dkey, with_duty ? *first_count_duty : TallyDuty{});
         if (p == 0 && after_first_count != nullptr) {
             const hipError_t e = hipEventRecord(after_first_count, stream);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(radix_scan_kernel, dim3(256), dim3(kThreads), 0, stream, counts, tiles, tiles_pad, totals, n_device);
+        if (precounted)
+            hipLaunchKernelGGL(radix_scan_kernel<true>, dim3(256), dim3(kThreads), 0, stream, counts, tiles, tiles_pad, totals, n_device, precount_blocks);
+        else
+            hipLaunchKernelGGL(radix_scan_kernel<false>, dim3(256), dim3(kThreads), 0, stream, counts, tiles, tiles_pad, totals, n_device, 0u);
 #define GSR_RADIX_LAUNCH(I, K, A)                                                                                      \
     hipLaunchKernelGGL((radix_scatter_kernel<I, K, A>), dim3(tiles), dim3(kThreads), 0, stream, kin, vin, kout, vout, n, \
                        shift, mask, counts, tiles_pad, totals, n_device, dkey, kept_out)
