@@ -422,9 +422,24 @@ constexpr int kShStagePitch = 65;  // words between consecutive floats of one la
 // the record goes to stage[f * kShStagePitch]; with stage == nullptr the record is stored straight to HBM.
 template <bool kRaw>
 __device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, const Camera& cam, int idx, float* stage) {
-    if (!(g.radii[idx] > 0)) {
-        // Not rendered: every gradient of this Gaussian is zero.  The kernel defines ALL output elements, so the
-        // caller does not have to zero-fill a gigabyte of gradient tensors first (dL_dsh alone is 576 MB at 3 M).
+    // the sums of this Gaussian, one 64-byte line (ten slots; 10 - 12: a second feature set's colour sums; the rest stay zero)
+    const float4* line = reinterpret_cast<const float4*>(g.accum + (size_t)kAccumStride * idx);
+    bool idle = !(g.radii[idx] > 0);
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2q = s0, s3q = s0;
+    if (!idle) {
+        s0 = line[0]; s1 = line[1]; s2q = line[2]; s3q = line[3];
+        // Rendered, but no pixel composited it (behind an opaque front, or alpha < 1/255 everywhere: 80 % of C3's rendered
+        // Gaussians, 99 % of the trained-scene stand-in's): every sum is an exact zero and every gradient below is a product
+        // with one of them, so the 250 bytes of parameters and coefficients need not be read to write zeros.  (A NaN sum
+        // compares unequal and takes the full path; what differs from the full path is 0 x Inf for a parameter that
+        // overflowed, which would have stored NaN.)
+        idle = s0.x == 0.f && s0.y == 0.f && s0.z == 0.f && s0.w == 0.f && s1.x == 0.f && s1.y == 0.f && s1.z == 0.f && s1.w == 0.f &&
+               s2q.x == 0.f && s2q.y == 0.f && s2q.z == 0.f && s2q.w == 0.f && s3q.x == 0.f && s3q.y == 0.f && s3q.z == 0.f && s3q.w == 0.f;
+    }
+    if (idle) {
+        // Not rendered, or rendered without a contribution: every gradient of this Gaussian is zero.  The kernel defines ALL
+        // output elements, so the caller does not have to zero-fill a gigabyte of gradient tensors first (dL_dsh alone is
+        // 576 MB at 3 M).
         const F3 z3 = {0.f, 0.f, 0.f};
         *reinterpret_cast<F3*>(g.dL_dmean2D + 3 * (size_t)idx) = z3;
         if (g.dL_dconic != nullptr) *reinterpret_cast<F4*>(g.dL_dconic + 4 * (size_t)idx) = F4{0.f, 0.f, 0.f, 0.f};
@@ -454,10 +469,8 @@ __device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, 
     const float* __restrict__ proj = cam.projmatrix;
     const F3 mean = ld3(g.means3D + 3 * (size_t)idx);
 
-    // the ten sums of this Gaussian, one 64-byte line; spread into the reference's gradient arrays
-    const float4* line = reinterpret_cast<const float4*>(g.accum + (size_t)kAccumStride * idx);
-    const float4 s0 = line[0], s1 = line[1];
-    const float2 s2 = *reinterpret_cast<const float2*>(line + 2);
+    // the ten sums, spread into the reference's gradient arrays
+    const float2 s2 = make_float2(s2q.x, s2q.y);
     const float dLc_r = s0.x, dLc_g = s0.y, dLc_b = s0.z, gdep = s0.w;
     const float S_u = s1.x, S_v = s1.y;
     const float dLcx = -0.5f * s1.z, dLcy = -0.5f * s1.w, dLcz = -0.5f * s2.x;   // backward.cu:577-581, the -1/2 taken out of the sums
@@ -677,9 +690,7 @@ __device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, 
         if (kRaw) {
             const F4 qn = {r, x, y, z};
             if (g.normal_grads) {   // the normal map's share (accum slots 10 - 12 = dL/d(view normal colour))
-                const float4 nl = *reinterpret_cast<const float4*>(g.accum + (size_t)kAccumStride * idx + 8);   // slots 8..11
-                const float nb = g.accum[(size_t)kAccumStride * idx + 12];
-                const F4 gn = view_normal_backward(mean, ld3(g.cam_pos_normals), s_act, qn, F3{nl.z, nl.w, nb});
+                const F4 gn = view_normal_backward(mean, ld3(g.cam_pos_normals), s_act, qn, F3{s2q.z, s2q.w, s3q.x});   // slots 10 - 12
                 gq = F4{gq.x + gn.x, gq.y + gn.y, gq.z + gn.z, gq.w + gn.w};
             }
             gq = normalize4_backward(q_raw, qn, gq);   // through F.normalize (gaussian_model.py:100-101)

@@ -1143,6 +1143,7 @@ def backward_iteration(key, device, steps=12, parity=True):
         e[2].record()
         if timers is not None:
             timers.append(e)
+        it.last_radii = radii
         return int((radii > 0).sum().item()) if timers is None else None
 
     for i in range(4):
@@ -1161,6 +1162,13 @@ def backward_iteration(key, device, steps=12, parity=True):
     fw = sum(a.elapsed_time(b_) for a, b_, _ in timers) / len(timers)
     bw = sum(b_.elapsed_time(c) for _, b_, c in timers) / len(timers)
     P = cloud.P
+    # who the per-Gaussian kernel has work for (last iteration): rendered = reads its 64-byte line of sums; with a gradient = also
+    # reads its parameters and coefficients (round 4: a rendered Gaussian whose sums are all zero only gets its zeros written)
+    with torch.no_grad():
+        m3, op, sh, sc, rot = leaves
+        n_rendered = int((it.last_radii > 0).sum().item())
+        n_active = int(((op.grad.reshape(P, -1) != 0).any(1) | (m3.grad != 0).any(1) | (sh.grad.reshape(P, -1) != 0).any(1)).sum().item())
+    pb_moved = 252 * P + 64 * n_rendered + 232 * n_active   # 248 B of gradients + 4 B radius each; the line of sums; the inputs
     # render_backward_kernel: per list entry it walks the forward's 48-byte reads (id 4, raster 32, colour 12) and adds
     # one 40-byte line of partial sums per (entry, 8x8 quadrant) that contributes; per pixel 28 B in.  Algorithmic bytes
     # as SURVEY 8d counts the forward blend (44 B per pair + per-pixel terms) plus the ten 4-byte sums per pair the
@@ -1178,6 +1186,12 @@ def backward_iteration(key, device, steps=12, parity=True):
                        "preprocess_backward_kernel": {"ms": round(bw_k["preprocess_backward"], 4), "alg_bytes": int(544 * P),
                                                       "alg_GBps": round(544 * P / max(1e-9, bw_k["preprocess_backward"] * 1e-3) / 1e9, 1),
                                                       "frac_of_hbm_peak": round(544 * P / max(1e-9, bw_k["preprocess_backward"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                                      "alg_bytes_note": "544 B per Gaussian = what the reference's kernel moves for these gradients (an equivalence figure since "
+                                                                        "round 4: Gaussians without a gradient are not read)",
+                                                      "gaussians": {"rendered": n_rendered, "with_gradient": n_active},
+                                                      "moved_bytes": int(pb_moved),
+                                                      "moved_GBps": round(pb_moved / max(1e-9, bw_k["preprocess_backward"] * 1e-3) / 1e9, 1),
+                                                      "frac_of_hbm_peak_moved": round(pb_moved / max(1e-9, bw_k["preprocess_backward"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                                       "bound": "hbm"}},
            "timed_calls": bw_k["calls"]}
     out["reference_on_gpu"] = reference_training_iteration(cloud, cams_cpu, bg, target, device, steps, cams_dev)

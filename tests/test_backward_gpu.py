@@ -256,6 +256,35 @@ def test_backward_c2_full_size_vs_oracle():
     check_case("c2_full_1M", cloud, cam, pg, hip, ref, KEYS_SH)
 
 
+def test_rendered_gaussians_behind_an_opaque_front_get_exact_zeros_like_the_oracle():
+    """The per-Gaussian backward kernel does not read the parameters of a RENDERED Gaussian (radii > 0) whose ten sums are all
+    zero -- nobody composited it -- and writes zeros (gsr_backward.hip: preprocess_backward_lane).  A wall of opaque splats in
+    front of the cloud leaves most of the cloud rendered but untouched: the set of all-zero gradient rows must be the oracle's
+    (backward.cu multiplies by the zero sums), and the touched rows keep the usual bar."""
+    g = torch.Generator().manual_seed(12)
+    cloud, cam = scenes.config_c1(P=5000, seed=41), scenes.c1_camera(160, 128)   # camera at (0, 0, -4) looking down +z
+    # a 12 x 10 wall of big, opaque, isotropic splats one unit in front of the camera, covering the whole image
+    xs, ys = torch.meshgrid(torch.linspace(-0.8, 0.8, 12), torch.linspace(-0.7, 0.7, 10), indexing="xy")
+    wall = torch.stack([xs.reshape(-1), ys.reshape(-1), torch.full((xs.numel(),), -3.0)], 1)
+    W = wall.shape[0]
+    rot = torch.zeros(W, 4); rot[:, 0] = 1.0
+    both = GaussianCloud(means3D=torch.cat([wall, cloud.means3D]), opacities=torch.cat([torch.full((W, 1), 0.999), cloud.opacities.reshape(-1, 1)]),
+                         scales=torch.cat([torch.full((W, 3), 0.15), cloud.scales]), rotations=torch.cat([rot, cloud.rotations]),
+                         shs=torch.cat([torch.randn((W,) + tuple(cloud.shs.shape[1:]), generator=g) * 0.3, cloud.shs]))
+    pg = pixel_grads(cam, 9)
+    kw = oracle_kwargs(both, cam)
+    kw.update(pg)
+    ref = cpu_oracle.backward(**kw)
+    hip = hip_backward(both, cam, pg)
+    check_case("opaque_wall", both, cam, pg, hip, ref, KEYS_SH)
+    rendered = hip["radii"] > 0
+    rows = lambda d: np.concatenate([np.asarray(d[k]).reshape(both.P, -1) for k in KEYS_SH], 1)
+    idle_ref, idle_hip = (rows(ref) == 0).all(1), (rows(hip) == 0).all(1)
+    assert int((rendered & idle_ref).sum()) > both.P // 2, "the wall does not hide the cloud: the case tests nothing"
+    # (a composited-or-not decision at the 1/255 and 1e-4 thresholds may flip between the two for a pixel or two)
+    assert int((idle_hip != idle_ref).sum()) <= 3, np.nonzero(idle_hip != idle_ref)[0][:10]
+
+
 def test_colour_only_loss_skips_the_depth_and_alpha_terms_with_the_same_gradients():
     """A loss that reads only the colour image (the reference's training loops: train.py:84-134,
     scene_representation.py:495-520) leaves depth and alpha without a gradient: autograd then hands None to the backward
