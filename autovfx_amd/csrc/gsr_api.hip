@@ -893,12 +893,14 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     // (a runtime that does not map pinned memory: the totals go into the zero block's first slots and are copied behind the sort)
     uint32_t* keys_sorted = nullptr;
     fc.queued = true;   // from the first launch below on a kernel may store into the pinned slot (what ~ForwardCall looks at)
+    gsr::RadixSortExtras depth_extras;
+    depth_extras.drop_key = g_options[GSR_OPT_DEPTH_DROP] != 0 ? &gsr::kCulledKey : nullptr;
+    depth_extras.few_top_digits = true;   // the keys are positive floats: their top byte is sign + 7 exponent bits
+    depth_extras.first_count_duty = &tally;
+    depth_extras.after_first_count = host_dev != nullptr ? fc.pinned.copied : nullptr;
     GSR_HIP(gsr::radix_sort_pairs((uint32_t*)(gbase + fc.off_radix_tmp), (uint32_t)P, 32, ga.depth_keys, (uint32_t*)(gbase + off_keys_b),
                                   (uint32_t*)(gbase + off_ids_a), (uint32_t*)(gbase + off_ids_b),
-                                  /*iota_payload=*/true, /*want_sorted_keys=*/false, &keys_sorted, &fc.order, stream, nullptr,
-                                  g_options[GSR_OPT_DEPTH_DROP] != 0 ? &gsr::kCulledKey : nullptr,
-                                  /*few_top_digits=*/true,   // the keys are positive floats: their top byte is sign + 7 exponent bits
-                                  &tally, host_dev != nullptr ? fc.pinned.copied : nullptr));
+                                  /*iota_payload=*/true, /*want_sorted_keys=*/false, &keys_sorted, &fc.order, stream, depth_extras));
     if (host_dev == nullptr) {
         GSR_HIP(hipMemcpyAsync(fc.pinned.host, gbase + off_flag, kCounterBytes, hipMemcpyDeviceToHost, stream));
         GSR_HIP(hipEventRecord(fc.pinned.copied, stream));
@@ -1039,11 +1041,13 @@ int forward_finish(ForwardCall& fc) {
         GSR_STAGE_CHECK("expand");
         stamp(kHeadEvents + kSlabEvents * k + 0, stream);
         uint32_t *tk_sorted = keys_in, *pl_sorted = list_in;
-        if (plan.bound[k] > 0)
+        if (plan.bound[k] > 0) {
+            gsr::RadixSortExtras tile_extras;
+            tile_extras.n_device = &slab->pairs;
+            tile_extras.precount_blocks = precount;
             GSR_HIP(gsr::radix_sort_pairs((uint32_t*)(bbase + off_btmp), plan.bound[k], tile_bits, keys_in, keys_alt, list_in, list_alt,
-                                          /*iota_payload=*/false, /*want_sorted_keys=*/true, &tk_sorted, &pl_sorted, stream,
-                                          &slab->pairs, nullptr, false, nullptr, nullptr, precount));
-        else
+                                          /*iota_payload=*/false, /*want_sorted_keys=*/true, &tk_sorted, &pl_sorted, stream, tile_extras));
+        } else
             pl_sorted = own_list;
         GSR_STAGE_CHECK("tile_sort");
         if (debug && plan.bound[k] > 1) {  // the sorts' contract, checked: (tile, depth bits, id) ascending through the list

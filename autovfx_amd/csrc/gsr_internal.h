@@ -316,18 +316,7 @@ hipError_t launch_pack_rgba8(const float* color, const float* alpha, uint8_t* ou
 // Stable ascending LSD sort on the low `bits` key bits, 8 per pass (count / scan / scatter kernels, no spinning,
 // nothing to zero-fill).  scratch: radix_scratch_words(n) u32 words of any content.  iota_payload: the payload
 // is 0..n-1 and `vals` is not read.  want_sorted_keys = false skips the key stores of the last pass.
-// n_device (nullable): the number of pairs is read from this device word by every kernel (it must not exceed n, which
-// then only sizes the launches and the scratch layout): a sort can be queued before its size is known on the host.
-// drop_key (nullable; with iota_payload, more than one pass, no n_device): items with this key leave the sort in its first
-// pass -- not ranked, not written; the sorted arrays hold the others, in order, and their tails are undefined.
-// few_top_digits: a hint that the most significant digit takes only a handful of values (the top byte of a positive float: sign
-// and seven exponent bits) -- that pass then ranks with ballots, whose cost does not grow with lanes hitting one counter.
-// first_count_duty (nullable): work one extra workgroup of the first pass's count kernel does (the projection's tallies);
-// after_first_count (nullable) is recorded right behind that launch.  With n == 0 or bits <= 0 neither happens.
-// precount_blocks != 0 (with n_device): the first pass has no count kernel -- the kernel that wrote the keys, a launch of
-// `precount_blocks` workgroups each covering 256 * expand_pairs_per_lane(precount_blocks, *n_device) consecutive keys, left
-// counts[digit * radix_count_stride(n, precount_blocks) + workgroup] for all 256 digits in `scratch`; the first scan folds them
-// into 4096-key tiles.  The scratch must then be radix_scratch_words(n, precount_blocks) words.
+// `extras`: RadixSortExtras below.
 // counts the returning LDS adds whose result was not (value before the instruction) + (lower lanes on the same counter)
 hipError_t launch_lds_atomic_order_selftest(uint32_t workgroups, uint32_t rounds, uint32_t seed, unsigned long long* mismatches,
                                             hipStream_t stream);
@@ -352,11 +341,30 @@ __host__ __device__ inline uint32_t expand_pairs_per_lane(uint32_t grid, uint32_
 uint32_t radix_first_digit_mask(int bits);
 // Row stride (words) of the per-digit count rows in a sort's scratch: counts[digit * stride + tile].
 uint32_t radix_count_stride(uint32_t n, uint32_t precount_blocks = 0);
+// What a sort may be told beyond its keys (all optional).
+struct RadixSortExtras {
+    // The number of pairs is read from this device word by every kernel (it must not exceed n, which then only sizes the
+    // launches and the scratch layout): a sort can be queued before its size is known on the host.
+    const uint32_t* n_device = nullptr;
+    // (with iota_payload, more than one pass, no n_device) items with this key leave the sort in its first pass -- not ranked,
+    // not written; the sorted arrays hold the others, in order, and their tails are undefined.
+    const uint32_t* drop_key = nullptr;
+    // A hint that the most significant digit takes only a handful of values (the top byte of a positive float: sign and seven
+    // exponent bits): that pass ranks with ballots, whose cost does not grow with lanes hitting one LDS counter.
+    bool few_top_digits = false;
+    // Work some extra workgroups of the first pass's count kernel do (the projection's tallies); after_first_count is recorded
+    // right behind that launch.  With n == 0 or bits <= 0 neither happens.
+    const TallyDuty* first_count_duty = nullptr;
+    hipEvent_t after_first_count = nullptr;
+    // != 0 (needs n_device): the first pass has no count kernel -- the kernel that wrote the keys, a launch of `precount_blocks`
+    // workgroups each covering 256 * expand_pairs_per_lane(precount_blocks, *n_device) consecutive keys, left
+    // counts[digit * radix_count_stride(n, precount_blocks) + workgroup] for all 256 digits in `scratch`; the first scan folds
+    // them into 4096-key tiles.  The scratch must then be radix_scratch_words(n, precount_blocks) words.
+    uint32_t precount_blocks = 0;
+};
 hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt,
                             uint32_t* vals, uint32_t* vals_alt, bool iota_payload, bool want_sorted_keys,
                             uint32_t** keys_sorted, uint32_t** vals_sorted, hipStream_t stream,
-                            const uint32_t* n_device = nullptr, const uint32_t* drop_key = nullptr,
-                            bool few_top_digits = false, const TallyDuty* first_count_duty = nullptr,
-                            hipEvent_t after_first_count = nullptr, uint32_t precount_blocks = 0);
+                            const RadixSortExtras& extras = RadixSortExtras());
 
 } // namespace gsr

@@ -602,9 +602,13 @@ uint32_t radix_first_digit_mask(int bits) {
 
 hipError_t radix_sort_pairs(uint32_t* scratch, uint32_t n, int bits, uint32_t* keys, uint32_t* keys_alt,
                             uint32_t* vals, uint32_t* vals_alt, bool iota_payload, bool want_sorted_keys,
-                            uint32_t** keys_sorted, uint32_t** vals_sorted, hipStream_t stream, const uint32_t* n_device,
-                            const uint32_t* drop_key, bool few_top_digits, const TallyDuty* first_count_duty,
-                            hipEvent_t after_first_count, uint32_t precount_blocks) {
+                            uint32_t** keys_sorted, uint32_t** vals_sorted, hipStream_t stream, const RadixSortExtras& extras) {
+    const uint32_t* n_device = extras.n_device;
+    const uint32_t* const drop_key = extras.drop_key;
+    const bool few_top_digits = extras.few_top_digits;
+    const TallyDuty* const first_count_duty = extras.first_count_duty;
+    const hipEvent_t after_first_count = extras.after_first_count;
+    const uint32_t precount_blocks = extras.precount_blocks;
     *keys_sorted = keys;
     *vals_sorted = vals;
     if (n == 0 || bits <= 0) return hipSuccess;
