@@ -524,12 +524,13 @@ hipError_t launch_lds_atomic_order_selftest(uint32_t workgroups, uint32_t rounds
 // Since round 4 the sort's correctness does not depend on the lane order in any of these: the atomics' ranks are checked per
 // tile inside the scatter kernel and repaired with ballots when they fail (see the kernel); the self-test only decides
 // whether the atomics are worth trying on this device.
-// With request 2 the self-test runs once per device and process, on the first sort (or the first query) after the request:
-// 512 workgroups x 4 waves x 192 instructions of every conflict density (~0.4 M instructions, 25 M lane results; well under a
-// millisecond), on its own small allocation, and SYNCHRONISES the calling stream once (hipMalloc / hipFree /
-// hipStreamSynchronize under a process-wide mutex: not legal during stream capture -- make the first call outside one, or
-// query GSR_OPT_RADIX_RANK_ACTIVE at start-up).  A test that could not run (e.g. out of memory) is not remembered: the sort
-// uses ballots this time and the next sort tries again.
+// With request 2 the self-test runs once per device and process, in the first sort (or the first query) after the request:
+// 512 workgroups x 4 waves x 192 instructions of every conflict density (~0.4 M instructions, 25 M lane results; a quarter of
+// a millisecond), on its OWN stream and its own small allocation, waited for by the host (hipMalloc / hipFree /
+// hipStreamSynchronize of that stream under a process-wide mutex); the caller's stream is neither drained nor used.  While the
+// caller's stream is capturing a graph the test does not run (allocations are not legal then): that sort ranks with ballots and
+// the next one tries again, as after a test that could not run for any other reason (e.g. out of memory) -- only verdicts are
+// remembered.  Query GSR_OPT_RADIX_RANK_ACTIVE at start-up to have it out of the way.
 // ------------------------------------------------------------------------------------------------
 namespace {
 constexpr int kMaxDevices = 64;
@@ -538,19 +539,30 @@ int g_rank_request = 2;
 int g_rank_verdict[kMaxDevices];      // 0 not tested yet, 1 passed (atomics), 2 failed (ballots), 3 could not be tested (ballots)
 unsigned long long g_rank_violations[kMaxDevices];
 
-int test_device_locked(int dev, hipStream_t stream) {
+int test_device_locked(int dev, hipStream_t caller) {
+    // Never on the caller's stream: the test has its own, so the caller's queue is not drained and nothing is queued on a stream
+    // that may be recording a graph.  While the caller's stream IS capturing the test does not run at all (an allocation is not
+    // legal then): verdict 3, ballots for this sort, another try at the next one.
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (caller != nullptr && (hipStreamIsCapturing(caller, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone)) {
+        (void)hipGetLastError();
+        return 3;
+    }
     unsigned long long* d_bad = nullptr;
     unsigned long long h_bad = ~0ull;
     int verdict = 3;
+    hipStream_t own = nullptr;
+    if (hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) return 3;
     if (hipMalloc((void**)&d_bad, sizeof *d_bad) == hipSuccess) {
-        if (hipMemsetAsync(d_bad, 0, sizeof *d_bad, stream) == hipSuccess &&
-            launch_lds_atomic_order_selftest(512u, 192u, 0x6a09e667u, d_bad, stream) == hipSuccess &&
-            launch_lds_atomic_order_selftest(512u, 192u, 0xbb67ae85u, d_bad, stream) == hipSuccess &&
-            hipMemcpyAsync(&h_bad, d_bad, sizeof h_bad, hipMemcpyDeviceToHost, stream) == hipSuccess &&
-            hipStreamSynchronize(stream) == hipSuccess)
+        if (hipMemsetAsync(d_bad, 0, sizeof *d_bad, own) == hipSuccess &&
+            launch_lds_atomic_order_selftest(512u, 192u, 0x6a09e667u, d_bad, own) == hipSuccess &&
+            launch_lds_atomic_order_selftest(512u, 192u, 0xbb67ae85u, d_bad, own) == hipSuccess &&
+            hipMemcpyAsync(&h_bad, d_bad, sizeof h_bad, hipMemcpyDeviceToHost, own) == hipSuccess &&
+            hipStreamSynchronize(own) == hipSuccess)
             verdict = h_bad == 0ull ? 1 : 2;
         (void)hipFree(d_bad);
     }
+    (void)hipStreamDestroy(own);
     g_rank_violations[dev] = h_bad;
     return verdict;
 }

@@ -145,6 +145,47 @@ def test_the_order_check_catches_inversions_and_stays_silent_otherwise(rank_vari
         assert grew == 0, grew
 
 
+def test_first_sort_inside_a_graph_capture_does_not_run_the_selftest(rank_variant):
+    """A fresh process whose FIRST sort is recorded into a hipGraph (default rank request 2, device not tested yet): the lane-order
+    self-test allocates and synchronises, neither of which is legal during capture -- the library must skip it, capture the ballot
+    form, and test the device later, outside the capture.  (Run once: the parametrisation does not reach the child process.)"""
+    if rank_variant != "ballots":
+        pytest.skip("one run is enough: the child process uses the library default")
+    import os, subprocess, sys
+    code = r"""
+import ctypes, torch
+from autovfx_amd import _lib
+assert _lib.get_option(_lib.OPT_RADIX_RANK) == 2
+n, bits = 200_003, 13
+keys = torch.randint(0, 2**bits, (n,), device="cuda", dtype=torch.int32)
+vals = torch.arange(n, device="cuda", dtype=torch.int32)
+want = torch.sort(keys.to(torch.int64), stable=True).indices.to(torch.int32)
+k_in, v_in = keys.clone(), vals.clone()
+k_alt, v_alt = torch.empty_like(keys), torch.empty_like(vals)
+nbytes = int(_lib.lib.gsr_radix_scratch_bytes(n, bits))
+scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+where = ctypes.c_int(0)
+torch.cuda.synchronize()
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph):
+    rc = _lib.lib.gsr_radix_sort_pairs(n, bits, k_in.data_ptr(), k_alt.data_ptr(), v_in.data_ptr(), v_alt.data_ptr(), 0,
+                                       scratch.data_ptr(), nbytes, ctypes.byref(where),
+                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, _lib.last_error()
+k_in.copy_(keys); v_in.copy_(vals)
+graph.replay()
+torch.cuda.synchronize()
+got = v_alt if where.value else v_in
+assert torch.equal(got, want), "the captured sort is wrong"
+assert _lib.get_option(_lib.OPT_RADIX_RANK_ACTIVE) == 1, "outside the capture the device is tested and passes"
+print("captured-ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "GSR_RADIX_RANK"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0 and "captured-ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
 def test_c2_full_frame_is_identical_with_either_rank():
     """BASELINE configs[1] at full size through both rank forms: every public output and the sorted lists bit for bit
     (debug = True also runs the library's own (tile, depth, id) order check over the 3.5 M-entry list)."""
