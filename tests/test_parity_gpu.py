@@ -274,6 +274,66 @@ def test_empty_and_all_culled():
     assert not hip["alpha"].any() and not hip["depth"].any()
 
 
+def test_more_than_int_max_pairs_is_an_error_not_a_crash():
+    """70 000 splats that each cover all 32 400 tiles of a 3840x2160 image: the reference's num_rendered (an int,
+    rasterizer_impl.cu:282) would be 2.27e9 and its arena sizes wrap; here the call fails with a message before anything is
+    allocated for the pairs, and the next call on the same thread works."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = "cuda:0"
+    cam = scenes.c1_camera(3840, 2160)   # at (0, 0, -4) looking down +z
+    P = 70_000
+    g = torch.Generator().manual_seed(1)
+    means = torch.zeros(P, 3)
+    means[:, :2] = (torch.rand(P, 2, generator=g) - 0.5) * 0.5
+    means[:, 2] = torch.rand(P, generator=g) * 0.5
+    rot = torch.zeros(P, 4); rot[:, 0] = 1.0
+    big = GaussianCloud(means, torch.full((P, 1), 0.5), torch.full((P, 3), 40.0), rot, None, torch.rand(P, 3, generator=g), 0).to(dev)
+    st = settings_for(cam, dev, (0.0, 0.0, 0.0), 1.0, 0)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="overflows"):
+        GaussianRasterizer(st)(means3D=big.means3D, means2D=torch.zeros_like(big.means3D), opacities=big.opacities,
+                               colors_precomp=big.colors_precomp, scales=big.scales, rotations=big.rotations)
+    torch.cuda.synchronize()
+    small = scenes.config_c1(P=2000, seed=4)
+    hip, ref = run_both("after_overflow", small, scenes.c1_camera(96, 64))
+    np.testing.assert_array_equal(hip["radii"], ref["radii"])
+
+
+def test_one_and_a_half_billion_pairs_full_and_inference_calls_agree():
+    """Near the top of what the reference's int pair count allows: 45 000 splats that each cover all 32 400 tiles of a 3840x2160
+    image = 1.458e9 pairs (24 GB of binning arena).  The full call expands and sorts every one of them (356 000 radix tiles,
+    offsets past 2^30); the inference call stops after the first depth slab (13 M pairs).  Same image, depth, alpha and radii."""
+    from diff_gaussian_rasterization import GaussianRasterizer, _C
+    dev = "cuda:0"
+    if torch.cuda.get_device_properties(0).total_memory < 120e9:
+        pytest.skip("needs ~50 GB of device memory")
+    cam = scenes.c1_camera(3840, 2160)
+    P = 45_000
+    g = torch.Generator().manual_seed(1)
+    means = torch.zeros(P, 3)
+    means[:, :2] = (torch.rand(P, 2, generator=g) - 0.5) * 0.5
+    means[:, 2] = torch.rand(P, generator=g) * 0.5
+    rot = torch.zeros(P, 4); rot[:, 0] = 1.0
+    big = GaussianCloud(means, torch.full((P, 1), 0.5), torch.full((P, 3), 40.0), rot, None, torch.rand(P, 3, generator=g), 0).to(dev)
+    st = settings_for(cam, dev, (0.0, 0.0, 0.0), 1.0, 0)
+    kw = dict(opacities=big.opacities, colors_precomp=big.colors_precomp, scales=big.scales, rotations=big.rotations)
+    try:
+        m = big.means3D.clone().requires_grad_(True)          # a full call: everything is kept for a backward
+        full = [t.detach() for t in GaussianRasterizer(st)(means3D=m, means2D=torch.zeros_like(m), **kw)]
+        counts_full = dict(_C.last_layout()["counts"])
+        with torch.no_grad():
+            inf = list(GaussianRasterizer(st)(means3D=big.means3D, means2D=torch.zeros_like(big.means3D), **kw))
+        counts_inf = dict(_C.last_layout()["counts"])
+        torch.cuda.synchronize()
+        assert counts_full["num_rendered"] == counts_inf["num_rendered"] == P * 32400 == counts_full["live_pairs"]
+        assert counts_inf["live_pairs"] < counts_full["live_pairs"] // 50
+        for a, b, name in zip(full, inf, ("color", "depth", "alpha", "radii")):
+            assert torch.equal(a, b), name
+        assert float(full[2].min()) > 0.999 and bool((full[3] > 0).all())
+    finally:
+        del big
+        torch.cuda.empty_cache()
+
+
 def test_near_plane_threshold():
     """view z == 0.2 is culled, the next float above is kept (auxiliary.h:154)."""
     import math
