@@ -175,7 +175,8 @@ __device__ __forceinline__ F3 sh_to_rgb(int deg, F3 pos, F3 cam, const float* sh
     float dx = pos.x - cam.x, dy = pos.y - cam.y, dz = pos.z - cam.z;
     const float len = sqrtf(dx * dx + dy * dy + dz * dz);
     const F3 v = sh_unclamped(deg, dx / len, dy / len, dz / len, sh0, shr);
-    return F3{fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f)};
+    // glm::max(result, 0.0f) (forward.cu:70) is `(x < y) ? y : x`: a NaN colour stays a NaN (fmaxf would turn it into 0)
+    return F3{v.x < 0.0f ? 0.0f : v.x, v.y < 0.0f ? 0.0f : v.y, v.z < 0.0f ? 0.0f : v.z};
 }
 __device__ __forceinline__ F3 sh_to_rgb(int deg, F3 pos, F3 cam, const float* sh) { return sh_to_rgb(deg, pos, cam, sh, sh); }
 
@@ -195,7 +196,8 @@ __device__ __forceinline__ float torch_sigmoid(float x) { return 1.0f / (1.0f + 
 
 // torch.nn.functional.normalize(q[P,4]) (gaussian_model.py:100-101): q / max(||q||, 1e-12)
 __device__ __forceinline__ F4 torch_normalize4(F4 q) {
-    const float n = fmaxf(sqrtf((q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w)), 1e-12f);
+    float n = sqrtf((q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w));
+    n = n < 1e-12f ? 1e-12f : n;   // clamp_min(norm, eps): a NaN norm stays NaN, as in PyTorch (fmaxf would return eps)
     return F4{q.x / n, q.y / n, q.z / n, q.w / n};
 }
 // v.norm(dim=1) / torch.sum(v, dim=-1) of a contiguous [P,3]

@@ -166,7 +166,11 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
                     tr = tight_rect(region, px, py, rc);
                 }
                 const uint32_t tw = (uint32_t)(tr.x1 - tr.x0), th = (uint32_t)(tr.y1 - tr.y0), tarea = tw * th;
-                if (tarea != 0u) {
+                // (irad > 0: duplicateWithKeys emits pairs only `if (radii[idx] > 0)`, rasterizer_impl.cu:84.  Every finite
+                // Gaussian that gets here has a radius of at least one; a NaN covariance gives ceil(3 sqrt(NaN)) -> 0 with a
+                // one-tile rectangle: counted in num_rendered by the reference's scan, never emitted -- its slot in the
+                // reference's key array keeps whatever the allocation held.  Here it emits nothing.)
+                if (tarea != 0u && irad > 0) {
                     bin.xy0 = (uint32_t)tr.x0 | ((uint32_t)tr.y0 << 16);
                     bin.wh = tw | (th << 16);
                     if (tarea <= kMaskTiles) {
@@ -606,11 +610,13 @@ hipError_t launch_composite(int width, int height, const void* bg_c, const void*
 // left to right when the vector's components are strided planes (the permuted normal image), (x + z) + y when they are
 // contiguous (the cross products).
 __device__ __forceinline__ F3 unit3_planes(F3 v) {
-    const float n = fmaxf(sqrtf(v.x * v.x + v.y * v.y + v.z * v.z), 1e-12f);
+    float n = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    n = n < 1e-12f ? 1e-12f : n;   // clamp_min: a NaN norm stays NaN
     return F3{v.x / n, v.y / n, v.z / n};
 }
 __device__ __forceinline__ F3 unit3_contiguous(F3 v) {
-    const float n = fmaxf(torch_norm3(v), 1e-12f);
+    float n = torch_norm3(v);
+    n = n < 1e-12f ? 1e-12f : n;   // clamp_min: a NaN norm stays NaN
     return F3{v.x / n, v.y / n, v.z / n};
 }
 

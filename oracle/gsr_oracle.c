@@ -173,7 +173,7 @@ static void sh_to_rgb(int deg, const float p[3], const float cam[3], const float
 #undef SH
         v += 0.5f;
         clamped[c] = (uint8_t)(v < 0);
-        rgb[c] = fmaxf(v, 0.0f);
+        rgb[c] = v < 0.0f ? 0.0f : v;   /* glm::max(result, 0.0f) = (x < y) ? y : x: a NaN colour stays a NaN */
     }
 }
 
