@@ -9,6 +9,12 @@ from __future__ import annotations
 import ctypes
 import os
 
+# PyTorch first, always: its wheel carries its own libamdhip64 / libhsa-runtime64, and the library below asks the loader for
+# "libamdhip64.so.7" by name.  Loaded after torch it binds to the runtime torch already brought in -- one HIP runtime in the
+# process, so torch's stream handles and allocations mean the same thing on both sides.  Loaded BEFORE torch it would pull in the
+# system's runtime, torch's own would follow, and the mixture fails at the first call ("no ROCm-capable device is detected").
+import torch  # noqa: F401  (import order matters, see above)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GSR_LIB", os.path.join(_HERE, "lib", "libgsr_hip.so"))
 

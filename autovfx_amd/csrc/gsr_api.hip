@@ -188,7 +188,12 @@ int gsr_get_option(int option) {
     if (option == GSR_OPT_RADIX_RANK_ACTIVE) return gsr::radix_rank_mode(nullptr, nullptr);  // (self-test on the null stream if due)
     if (option == GSR_OPT_RADIX_RANK_FALLBACKS) {
         unsigned long long tiles = 0ull;
-        if (gsr::radix_rank_fallbacks(&tiles) != hipSuccess) return -1;
+        const hipError_t e = gsr::radix_rank_fallbacks(&tiles);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)fail(GSR_ERR_HIP, "GSR_OPT_RADIX_RANK_FALLBACKS: the device word could not be read: %s", hipGetErrorString(e));
+            return -1;
+        }
         return tiles > 0x7fffffffull ? 0x7fffffff : (int)tiles;
     }
     return g_options[option];
