@@ -187,7 +187,7 @@ print("captured-ok")
 
 
 def test_c2_full_frame_is_identical_with_either_rank():
-    """BASELINE configs[1] at full size through both rank forms: every public output and the sorted lists bit for bit
+    """BASELINE configs[1] at full size through every rank form: every public output and the sorted lists bit for bit
     (debug = True also runs the library's own (tile, depth, id) order check over the 3.5 M-entry list)."""
     import numpy as np
     from autovfx_amd import _lib, scenes
@@ -206,3 +206,13 @@ def test_c2_full_frame_is_identical_with_either_rank():
         np.testing.assert_array_equal(outs[0][1][k], outs[0][0][k], err_msg="inference vs full " + k)
     assert outs[0][1]["slab_pairs"] == outs[1][1]["slab_pairs"] and len(outs[0][1]["slab_pairs"]) > 1
     assert fallbacks() == start, "a tile's LDS-add ranks failed the order check on this device"
+    # ... and with an inversion injected into every wave of every sort of the frame (depth sort with dropped keys, tile sorts
+    # that start at a folding scan, device-side pair counts): the order check has to catch them all and the repair to restore
+    # the same lists
+    _lib.set_option(_lib.OPT_RADIX_RANK, 3)
+    hurt = (hip_forward_raw(cloud, cam, cull=True, debug=True), hip_forward_inference(cloud, cam, slabs=0, slab_first=40, debug=True))
+    assert fallbacks() > start + 1000, "the injected inversions went unnoticed"
+    for k in ("color", "depth", "alpha", "radii", "depth_order", "point_list", "tile_keys", "ranges", "n_contrib"):
+        np.testing.assert_array_equal(hurt[0][k], outs[0][0][k], err_msg="repaired: " + k)
+    for k in ("color", "depth", "alpha", "radii"):
+        np.testing.assert_array_equal(hurt[1][k], outs[0][1][k], err_msg="repaired, inference: " + k)
