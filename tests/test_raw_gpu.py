@@ -252,6 +252,47 @@ def test_render_from_raw_parameters_is_the_reference_shaped_render_bit_for_bit(s
             raise AssertionError(f"{k}: {int((d > 0).sum())} of {d.numel()} elements differ, max {float(d.max()):.3e}")
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_wild_raw_parameters_render_like_the_pytorch_path(seed):
+    """Raw tensors no optimiser would leave behind -- log-scales from -16 to 9 (exp from 1e-7 to 8 000), logits from -100 to 100
+    (sigmoid exactly 0 and exactly 1), quaternions with norms from 1e-14 (below F.normalize's eps) to 1e3 and exact zeros, SH
+    coefficients up to +-50, a sprinkle of NaN and inf in each -- through the fused raw path and through PyTorch's activations and
+    post-processing: the same bits wherever the result is a number, NaN where it is NaN (payloads aside)."""
+    g = torch.Generator().manual_seed(4000 + seed)
+    P = 6000
+    r = lambda *shape: torch.rand(*shape, generator=g)
+    n = lambda *shape: torch.randn(*shape, generator=g)
+    xyz = n(P, 3) * torch.tensor([2.0, 2.0, 2.0])
+    ls = r(P, 3) * 25 - 16
+    rot = n(P, 4) * 10 ** (r(P, 1) * 17 - 14)
+    rot[r(P) < 0.02] = 0.0
+    op = r(P, 1) * 200 - 100
+    dc, rest = n(P, 1, 3) * 10 ** (r(P, 1, 1) * 3 - 1.3), n(P, 15, 3) * 10 ** (r(P, 1, 1) * 3 - 1.3)
+    if seed >= 4:   # ... and non-finite entries, 0.5 % of the Gaussians in one array each
+        for t in (xyz, ls, rot, op, dc, rest):
+            rows = torch.randperm(P, generator=g)[:5]
+            flat = t.reshape(P, -1)
+            flat[rows, torch.randint(0, flat.shape[1], (5,), generator=g)] = torch.tensor([float("nan"), float("inf"), -float("inf"), float("nan"), float("inf")])
+    m = ReferenceShapedModel(3, *(t.to(DEV).contiguous() for t in (xyz, ls, rot, op, dc, rest)))
+    assert renderer.raw_parameters(m) is not None
+    cam = orbit_cameras(12, 233, 141)[seed].to(DEV)
+    bg = torch.tensor([0.3, 0.1, 0.2], device=DEV)
+    with torch.no_grad():
+        got = renderer.render(cam, m, renderer.PipelineParams, bg)
+    want = reference_shaped_render(cam, m, bg)
+    torch.cuda.synchronize()
+    for k in RENDER_KEYS:
+        a, b = got[k], want[k]
+        assert a.shape == b.shape and a.dtype == b.dtype, k
+        if a.dtype != torch.float32:
+            assert torch.equal(a, b), k
+            continue
+        nan_a, nan_b = torch.isnan(a), torch.isnan(b)
+        assert torch.equal(nan_a, nan_b), f"{k}: NaN in {int((nan_a != nan_b).sum())} different places"
+        assert bits_equal(torch.where(nan_a, torch.zeros_like(a), a), torch.where(nan_b, torch.zeros_like(b), b)), \
+            f"{k}: {int(((a != b) & ~nan_a).sum())} elements differ"
+
+
 def test_render_raw_with_the_sugar_camera_and_inverse_on_the_fly():
     """A camera without the precomputed inverse (the reference's GSCamera has none): c2w comes from
     ``world_view_transform.inverse()`` on the GPU in both paths; off-centre principal point as SuGaR's cameras have."""
