@@ -49,7 +49,8 @@ constexpr int kEventsPerCall = kHeadEvents + kSlabEvents * gsr::kMaxSlabs;
 int g_options[GSR_OPT_NUM] = {/*GSR_OPT_TILE_CULL*/ 1, /*GSR_OPT_SLABS*/ 2, /*GSR_OPT_SLAB_FIRST*/ 400,
                               /*GSR_OPT_DEFER_COLOUR*/ 1, /*GSR_OPT_SLAB_MIN_REST*/ 3000000,
                               /*GSR_OPT_RADIX_RANK (kept by gsr_radix.hip)*/ 2, /*GSR_OPT_RADIX_RANK_ACTIVE (read-only)*/ 0,
-                              /*GSR_OPT_DEPTH_DROP*/ 1, /*GSR_OPT_BLEND_ORDER*/ 1, /*GSR_OPT_RADIX_RANK_FALLBACKS (read-only)*/ 0};
+                              /*GSR_OPT_DEPTH_DROP*/ 1, /*GSR_OPT_BLEND_ORDER*/ 1, /*GSR_OPT_RADIX_RANK_FALLBACKS (read-only)*/ 0,
+                              /*GSR_OPT_BACKWARD_DETERMINISTIC*/ 0};
 std::atomic<bool> g_timing{false};
 std::atomic<long> g_timing_epoch{0};       // bumped by gsr_set_stage_timing: every thread restarts its record at its next call
 thread_local long g_epoch_seen = -1;
@@ -422,12 +423,71 @@ int backward_impl(int P, int D, int M, int R, const float* background, int width
         g_bw_done[bw_slot] = false;
         GSR_HIP(hipEventRecord(g_bw_ev[bw_slot][0], stream));
     }
+    const float* normal_colours = dL_dpix_normal != nullptr ? (const float*)(bases[0] + h[0].off[1]) : nullptr;
+    if (g_options[GSR_OPT_BACKWARD_DETERMINISTIC] != 0) {
+        // Per-Gaussian sums in a fixed order (gsr_backward.hip: kDet): the per-pixel passes store one record per (list position,
+        // quadrant), the point list is sorted by Gaussian id (stable: a Gaussian's positions ascend) and one lane per Gaussian
+        // adds its records in that order.  Buffers come from the stream's pool for the duration of the call.
+        const uint32_t bound = h[1].count[1];
+        const uint32_t* n_device = &reinterpret_cast<const gsr::SlabInfo*>(bases[0] + h[0].off[5])->pairs;
+        const int passes = dL_dpix_normal != nullptr ? 2 : 1;
+        int id_bits = 1;
+        while (id_bits < 32 && (1ull << id_bits) < (unsigned long long)P) ++id_bits;
+        Carver dc;
+        const size_t bit_words = ((size_t)bound + 7) / 8;
+        const size_t off_first = dc.take<uint32_t>((size_t)P), off_end = dc.take<uint32_t>((size_t)P);
+        const size_t off_bits = dc.take<uint32_t>(bit_words * passes);
+        const size_t zero_bytes = (dc.off + 255) & ~size_t(255);   // everything up to here must be zero
+        const size_t off_keys = dc.take<uint32_t>(bound), off_keys_alt = dc.take<uint32_t>(bound);
+        const size_t off_pos = dc.take<uint32_t>(bound), off_pos_alt = dc.take<uint32_t>(bound);
+        const size_t off_tmp = dc.take<uint32_t>(gsr::radix_scratch_words(bound));
+        const size_t off_part = dc.take<float>((size_t)bound * 40 * passes);
+        char* draw = nullptr;
+        GSR_HIP(hipMallocAsync((void**)&draw, dc.total() + 256, stream));
+        char* dbase = align_base(draw);
+        int rc = GSR_OK;
+        do {
+#define GSR_DET(expr) do { const hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); \
+            rc = fail(GSR_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
+            GSR_DET(hipMemsetAsync(dbase, 0, zero_bytes, stream));
+            if (rc != GSR_OK) break;
+            uint32_t* bits1 = (uint32_t*)(dbase + off_bits);
+            float* part1 = (float*)(dbase + off_part);
+            uint32_t* bits2 = passes == 2 ? bits1 + bit_words : nullptr;
+            float* part2 = passes == 2 ? part1 + (size_t)bound * 40 : nullptr;
+            GSR_DET(gsr::launch_render_backward(cam, ranges, point_list, background, raster, colors, accum_alphas, n_contrib, dL_dpix,
+                                                dL_dpix_depth, dL_dpix_alpha, accum_scratch, stream, 0, part1, bits1));
+            if (rc == GSR_OK && passes == 2)
+                GSR_DET(gsr::launch_render_backward(cam, ranges, point_list, background, raster, normal_colours, accum_alphas, n_contrib,
+                                                    dL_dpix_normal, nullptr, nullptr, accum_scratch, stream, 10, part2, bits2));
+            if (rc != GSR_OK) break;
+            uint32_t *ids_sorted = nullptr, *pos_sorted = nullptr;
+            if (bound > 0u) {
+                GSR_DET(hipMemcpyAsync(dbase + off_keys, point_list, (size_t)bound * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+                gsr::RadixSortExtras ex;
+                ex.n_device = n_device;
+                if (rc == GSR_OK)
+                    GSR_DET(gsr::radix_sort_pairs((uint32_t*)(dbase + off_tmp), bound, id_bits, (uint32_t*)(dbase + off_keys),
+                                                  (uint32_t*)(dbase + off_keys_alt), (uint32_t*)(dbase + off_pos), (uint32_t*)(dbase + off_pos_alt),
+                                                  /*iota_payload=*/true, /*want_sorted_keys=*/true, &ids_sorted, &pos_sorted, stream, ex));
+                if (rc == GSR_OK)
+                    GSR_DET(gsr::launch_det_segments(n_device, ids_sorted, bound, (uint32_t*)(dbase + off_first), (uint32_t*)(dbase + off_end), stream));
+            }
+            if (rc == GSR_OK)
+                GSR_DET(gsr::launch_det_reduce(P, (const uint32_t*)(dbase + off_first), (const uint32_t*)(dbase + off_end), pos_sorted, bits1, part1,
+                                               bits2, part2, accum_scratch, stream));
+#undef GSR_DET
+        } while (0);
+        (void)hipFreeAsync(draw, stream);
+        if (rc != GSR_OK) return rc;
+    } else {
     GSR_HIP(hipMemsetAsync(accum_scratch, 0, (size_t)P * 16 * sizeof(float), stream));
     GSR_HIP(gsr::launch_render_backward(cam, ranges, point_list, background, raster, colors, accum_alphas, n_contrib,
                                         dL_dpix, dL_dpix_depth, dL_dpix_alpha, accum_scratch, stream));
     if (dL_dpix_normal != nullptr)   // the second feature set's pass: colour sums to slots 10 - 12, geometry sums add to 4 - 9
-        GSR_HIP(gsr::launch_render_backward(cam, ranges, point_list, background, raster, (const float*)(bases[0] + h[0].off[1]),
+        GSR_HIP(gsr::launch_render_backward(cam, ranges, point_list, background, raster, normal_colours,
                                             accum_alphas, n_contrib, dL_dpix_normal, nullptr, nullptr, accum_scratch, stream, 10));
+    }
     GSR_STAGE_CHECK("render_backward");
     if (bw_slot >= 0) GSR_HIP(hipEventRecord(g_bw_ev[bw_slot][1], stream));
     gsr::BackwardInputs b;
@@ -1023,6 +1083,7 @@ int forward_finish(ForwardCall& fc) {
     hg.off[6] = (uint64_t)fc.off_quad;
     hg.off[7] = (uint64_t)fc.off_rows;
     hb.count[0] = (uint32_t)S;
+    hb.count[1] = plan.bound[0];   // room of slab 0's list (>= its pairs): sizes the deterministic backward's buffers
     hi.count[0] = (uint32_t)fc.width; hi.count[1] = (uint32_t)fc.height; hi.count[2] = (uint32_t)T; hi.count[3] = (uint32_t)S;
     hi.off[1] = (uint64_t)((char*)n_contrib - fc.ibase);
 

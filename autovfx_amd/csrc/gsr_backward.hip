@@ -78,14 +78,21 @@ constexpr int kAccumStride = 16;  // floats per Gaussian in the accumulation scr
 // kDepthAlpha = false: the caller has no gradient for the depth and alpha images (dL_dpixel_depths / dL_dpixel_alphas are not
 // read): their terms of dL_dalpha, the two accumulators behind them and the depth sum drop out of the loop -- the usual
 // training loss (train.py:84-134, scene_representation.py:495-520) only looks at the colour image.
-template <bool kDepthAlpha>
+//
+// kDet (GSR_OPT_BACKWARD_DETERMINISTIC): no atomics on floats.  The ten sums of a (quadrant, list entry) go, as plain stores, into
+// the record of that (sorted list position, quadrant) in `det_partial` -- 10 floats, record index 4 * position + quadrant --
+// and the quadrant's bit of the position is set in `det_bits` (4 bits per position, an integer atomicOr: its result does not
+// depend on the order it is served in).  det_reduce_kernel then adds every Gaussian's records in ascending (position, quadrant)
+// order: the same bits on every run, on every box.
+template <bool kDepthAlpha, bool kDet>
 __global__ void __launch_bounds__(64, 4) render_backward_kernel(
     int W, int H, int grid_x, int num_tiles, const uint2* __restrict__ ranges,
     const uint32_t* __restrict__ point_list, const float* __restrict__ background,
     const SplatRaster* __restrict__ raster, const float* __restrict__ colors, const float* __restrict__ accum_alphas,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dpixel_alphas,
-    float* __restrict__ accum /*[P,16], zero on entry*/, int colour_slot /*0; 10: a pass over the second feature set*/) {
+    float* __restrict__ accum /*[P,16], zero on entry*/, int colour_slot /*0; 10: a pass over the second feature set*/,
+    float* __restrict__ det_partial, uint32_t* __restrict__ det_bits) {
     __shared__ BlendEntry s_entry[64];  // the forward's 48-byte record; the Gaussian id rides in its pad word
 
     constexpr int kQ = kTile / 2;
@@ -259,7 +266,13 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
             asm volatile("" : "+v"(x2));
             if (my_slot >= 0) {  // ten lanes, one 64-byte line: a single atomic instruction per (quadrant, entry)
                 const float v = red_k == 0 ? x0 : red_k == 1 ? x1 : x2;
-                atomicAdd(accum + (size_t)kAccumStride * __float_as_uint(rb.w) + my_slot, v);
+                if (kDet) {
+                    const size_t s = (size_t)range.x + pos;   // position in the sorted list
+                    det_partial[(4 * s + (size_t)quad) * 10 + (size_t)(my_slot >= 10 ? my_slot - 10 : my_slot)] = v;
+                    if (lane == 0) atomicOr(det_bits + (s >> 3), 1u << (4u * (uint32_t)(s & 7) + (uint32_t)quad));   // (lane 0 has a slot)
+                } else {
+                    atomicAdd(accum + (size_t)kAccumStride * __float_as_uint(rb.w) + my_slot, v);
+                }
             }
         }
     }
@@ -268,6 +281,87 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
         for (int i = 0; i < 13; ++i)
             if (cz[i] != 0ull) atomicAdd(g_backward_census + i, cz[i]);
 #endif
+}
+
+// ---- GSR_OPT_BACKWARD_DETERMINISTIC: the per-Gaussian sums in a fixed order ----
+// sorted_ids: the call's point list sorted (stable) by Gaussian id; a Gaussian's entries are positions [first, end) of it.
+__global__ void __launch_bounds__(256) det_segments_kernel(const uint32_t* __restrict__ n_device, const uint32_t* __restrict__ sorted_ids,
+                                                          uint32_t* __restrict__ seg_first, uint32_t* __restrict__ seg_end /*both zero on entry*/) {
+    const uint32_t n = *n_device;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = sorted_ids[i];
+    if (i == 0u || sorted_ids[i - 1u] != g) seg_first[g] = i;
+    if (i + 1u == n || sorted_ids[i + 1u] != g) seg_end[g] = i + 1u;
+}
+
+// One record set: the (position, quadrant) records of one per-pixel pass and their presence bits.
+struct DetRecords { const uint32_t* bits; const float* partial; };
+__device__ __forceinline__ void det_add_position(const DetRecords& r, uint32_t s, float acc[10]) {
+    const uint32_t b = (r.bits[s >> 3] >> (4u * (s & 7u))) & 15u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (b >> q & 1u) {
+            const float* rec = r.partial + (4 * (size_t)s + (size_t)q) * 10;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) acc[k] += rec[k];
+        }
+}
+
+// One lane = one Gaussian: its records are added in ascending (list position, quadrant) order -- the list positions of a Gaussian
+// ascend with the tile, so the order is (tile, quadrant).  A Gaussian with more than 64 entries (a splat of hundreds of tiles) is
+// summed by the whole wave instead: lane l takes its entries l, l + 64, ... in that order and the 64 partial sums meet in a
+// fixed butterfly.  Which of the two forms a Gaussian takes depends on its entry count only: same inputs, same bits.
+// accum gets ALL sixteen slots of every Gaussian (zeros where nothing contributed): no memset in front.
+__global__ void __launch_bounds__(64) det_reduce_kernel(int P, const uint32_t* __restrict__ seg_first, const uint32_t* __restrict__ seg_end,
+                                                       const uint32_t* __restrict__ sorted_pos, const uint32_t* __restrict__ bits1,
+                                                       const float* __restrict__ partial1, const uint32_t* __restrict__ bits2,
+                                                       const float* __restrict__ partial2, float* __restrict__ accum) {
+    const int lane = threadIdx.x;
+    const int g = blockIdx.x * 64 + lane;
+    const DetRecords r1 = {bits1, partial1}, r2 = {bits2, partial2};
+    uint32_t first = 0u, end = 0u;
+    if (g < P) { first = seg_first[g]; end = seg_end[g]; }
+    float a1[10], a2[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) a1[k] = a2[k] = 0.f;
+    const bool long_one = end - first > 64u;
+    if (!long_one)
+        for (uint32_t i = first; i < end; ++i) {
+            const uint32_t s = sorted_pos[i];
+            det_add_position(r1, s, a1);
+            if (partial2 != nullptr) det_add_position(r2, s, a2);
+        }
+    unsigned long long todo = __ballot(long_one);
+    while (todo != 0ull) {
+        const int owner = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint32_t f = (uint32_t)__shfl((int)first, owner), e = (uint32_t)__shfl((int)end, owner);
+        float b1[10], b2[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) b1[k] = b2[k] = 0.f;
+        for (uint32_t i = f + (uint32_t)lane; i < e; i += 64u) {
+            const uint32_t s = sorted_pos[i];
+            det_add_position(r1, s, b1);
+            if (partial2 != nullptr) det_add_position(r2, s, b2);
+        }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                b1[k] += __shfl_xor(b1[k], d);
+                b2[k] += __shfl_xor(b2[k], d);
+            }
+            if (lane == owner) { a1[k] = b1[k]; a2[k] = b2[k]; }
+        }
+    }
+    if (g >= P) return;
+    float4* line = reinterpret_cast<float4*>(accum + (size_t)kAccumStride * g);
+    // slots 0 - 3 colour + depth of the first pass; 4 - 9 geometry of both; 10 - 12 colour of the second; the rest zero
+    line[0] = make_float4(a1[0], a1[1], a1[2], a1[3]);
+    line[1] = make_float4(a1[4] + a2[4], a1[5] + a2[5], a1[6] + a2[6], a1[7] + a2[7]);
+    line[2] = make_float4(a1[8] + a2[8], a1[9] + a2[9], a2[0], a2[1]);
+    line[3] = make_float4(a2[2], 0.f, 0.f, 0.f);
 }
 
 // auxiliary.h:103-114
@@ -772,16 +866,33 @@ hipError_t launch_render_backward(const Camera& cam, const uint2* ranges, const 
                                   const float* background, const SplatRaster* raster, const float* colors,
                                   const float* accum_alphas,
                                   const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
-                                  const float* dL_dpix_alpha, float* accum, hipStream_t stream, int colour_slot) {
+                                  const float* dL_dpix_alpha, float* accum, hipStream_t stream, int colour_slot,
+                                  float* det_partial, uint32_t* det_bits) {
     const int T = cam.grid_x * cam.grid_y;
-    if (dL_dpix_depth != nullptr && dL_dpix_alpha != nullptr)
-        hipLaunchKernelGGL(render_backward_kernel<true>, dim3(4 * T), dim3(64), 0, stream, cam.width, cam.height, cam.grid_x, T,
-                           ranges, point_list, background, raster, colors, accum_alphas, n_contrib,
-                           dL_dpix, dL_dpix_depth, dL_dpix_alpha, accum, colour_slot);
-    else
-        hipLaunchKernelGGL(render_backward_kernel<false>, dim3(4 * T), dim3(64), 0, stream, cam.width, cam.height, cam.grid_x, T,
-                           ranges, point_list, background, raster, colors, accum_alphas, n_contrib,
-                           dL_dpix, nullptr, nullptr, accum, colour_slot);
+    const bool full = dL_dpix_depth != nullptr && dL_dpix_alpha != nullptr, det = det_partial != nullptr;
+#define GSR_RB_LAUNCH(A, B)                                                                                                       \
+    hipLaunchKernelGGL((render_backward_kernel<A, B>), dim3(4 * T), dim3(64), 0, stream, cam.width, cam.height, cam.grid_x, T, ranges, \
+                       point_list, background, raster, colors, accum_alphas, n_contrib, dL_dpix, full ? dL_dpix_depth : nullptr,      \
+                       full ? dL_dpix_alpha : nullptr, accum, colour_slot, det_partial, det_bits)
+    if (full && det) GSR_RB_LAUNCH(true, true);
+    else if (full) GSR_RB_LAUNCH(true, false);
+    else if (det) GSR_RB_LAUNCH(false, true);
+    else GSR_RB_LAUNCH(false, false);
+#undef GSR_RB_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_det_segments(const uint32_t* n_device, const uint32_t* sorted_ids, uint32_t bound, uint32_t* seg_first, uint32_t* seg_end,
+                               hipStream_t stream) {
+    if (bound == 0u) return hipSuccess;
+    hipLaunchKernelGGL(det_segments_kernel, dim3((bound + 255u) / 256u), dim3(256), 0, stream, n_device, sorted_ids, seg_first, seg_end);
+    return hipGetLastError();
+}
+
+hipError_t launch_det_reduce(int P, const uint32_t* seg_first, const uint32_t* seg_end, const uint32_t* sorted_pos, const uint32_t* bits1,
+                             const float* partial1, const uint32_t* bits2, const float* partial2, float* accum, hipStream_t stream) {
+    hipLaunchKernelGGL(det_reduce_kernel, dim3(div_up(P, 64)), dim3(64), 0, stream, P, seg_first, seg_end, sorted_pos, bits1, partial1, bits2,
+                       partial2, accum);
     return hipGetLastError();
 }
 

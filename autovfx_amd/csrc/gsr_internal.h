@@ -292,7 +292,16 @@ hipError_t launch_render_backward(const Camera& cam, const uint2* ranges, const 
                                   const float* accum_alphas,
                                   const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
                                   const float* dL_dpix_alpha, float* accum /*[P,16] floats, zero on entry*/,
-                                  hipStream_t stream, int colour_slot = 0 /*10: the pass over a call's second feature set*/);
+                                  hipStream_t stream, int colour_slot = 0 /*10: the pass over a call's second feature set*/,
+                                  float* det_partial = nullptr, uint32_t* det_bits = nullptr /*GSR_OPT_BACKWARD_DETERMINISTIC*/);
+// GSR_OPT_BACKWARD_DETERMINISTIC (gsr_backward.hip): sorted_ids = the point list sorted by Gaussian id (n = *n_device entries);
+// seg_first / seg_end [P] (zero on entry) get every Gaussian's range in it.
+hipError_t launch_det_segments(const uint32_t* n_device, const uint32_t* sorted_ids, uint32_t bound, uint32_t* seg_first, uint32_t* seg_end,
+                               hipStream_t stream);
+// ... and accum[P,16] is written from the (position, quadrant) records of the one or two per-pixel passes, in fixed order.
+hipError_t launch_det_reduce(int P, const uint32_t* seg_first, const uint32_t* seg_end, const uint32_t* sorted_pos, const uint32_t* bits1,
+                             const float* partial1, const uint32_t* bits2 /*nullable*/, const float* partial2 /*nullable*/, float* accum,
+                             hipStream_t stream);
 hipError_t launch_preprocess_backward(const BackwardInputs& b, const Camera& cam, hipStream_t stream);
 hipError_t launch_composite(int width, int height, const void* bg_c, const void* o_c, const float* o_d,
                             const void* s_c, const float* s_d, const void* o_s_c, const void* o_gs_c,

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 9
+#define GSR_ABI_VERSION 10
 
 #if defined(__GNUC__)
 #define GSR_API __attribute__((visibility("default")))
@@ -484,6 +484,15 @@ typedef enum gsr_option {
      * this has run on; non-zero only costs time.  Reads a device word through the null stream: synchronise the streams that
      * sorted first.  gsr_set_option rejects it. */
     GSR_OPT_RADIX_RANK_FALLBACKS = 9,
+    /* [0] gsr_backward / gsr_backward_raw form every per-Gaussian sum in a FIXED order: same inputs, same bits, on every run and
+     * every box.  By default the sums of a Gaussian's (tile quadrant, list entry) contributions meet in HBM through float atomics,
+     * in the order the waves arrive (the reference's own backward does the same per pixel, backward.cu:553-596), so the last
+     * bits of a gradient -- and, for an ill-conditioned Gaussian, much more than the last bits -- differ between two runs.
+     * With 1 the per-pixel passes store one 40-byte record per contributing (sorted list position, quadrant), the point list
+     * is sorted by Gaussian id with the library's own (stable) radix sort, and one lane per Gaussian adds its records in
+     * ascending (tile, quadrant) order.  Costs 160 bytes of pool memory per live pair for the duration of the call (taken
+     * with hipMallocAsync on the call's stream: not capturable into a graph) and ~25 % of a training iteration at C3. */
+    GSR_OPT_BACKWARD_DETERMINISTIC = 10,
     GSR_OPT_NUM
 } gsr_option;
 GSR_API int gsr_set_option(int option, int value);

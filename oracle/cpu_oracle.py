@@ -189,3 +189,44 @@ def backward(**kw) -> Dict[str, np.ndarray]:
         L.gsro_forward_backward.argtypes = _backward_argtypes()
         L._bw_ready = True
     return run_backward(L.gsro_forward_backward, **kw)
+
+
+_D = ctypes.POINTER(ctypes.c_double)
+
+
+def backward_f64(*, means3D, opacities, bg, width, height, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
+                 dL_dcolor, dL_ddepth, dL_dalpha, sh_degree=0, scale_modifier=1.0, shs=None, colors_precomp=None,
+                 scales=None, rotations=None, cov3D_precomp=None) -> Dict[str, np.ndarray]:
+    """The gradient TRUTH (gsr_oracle.c: gsro_backward_f64): the reference's backward formulas evaluated in double on
+    the fp32 forward state.  Same keys as ``backward`` for the gradients, all float64."""
+    L = lib()
+    if not getattr(L, "_bw64_ready", False):
+        L.gsro_backward_f64.restype = ctypes.c_int64
+        L.gsro_backward_f64.argtypes = _backward_argtypes()[:22] + [_D] * 10
+        L._bw64_ready = True
+    m = _f32(means3D)
+    P = 0 if m is None else int(m.shape[0])
+    H, W = int(height), int(width)
+    sh, col, sc, rot, cov = _f32(shs), _f32(colors_precomp), _f32(scales), _f32(rotations), _f32(cov3D_precomp)
+    M = 0 if sh is None else int(sh.shape[1])
+    z = lambda *s: np.zeros(s, np.float64)
+    out = {"dL_dmeans2D": z(P, 3), "dL_dcolors": z(P, 3), "dL_dopacity": z(P, 1), "dL_dmeans3D": z(P, 3), "dL_dcov3D": z(P, 6),
+           "dL_dsh": z(P, M, 3), "dL_dscales": z(P, 3), "dL_drotations": z(P, 4), "dL_dconic": z(P, 4), "dL_ddepths": z(P, 1)}
+    if P == 0:
+        return out
+    op, bgv, vm, pm, cp = _f32(opacities), _f32(bg), _f32(viewmatrix), _f32(projmatrix), _f32(campos)
+    gc, gd, ga = _f32(dL_dcolor), _f32(dL_ddepth), _f32(dL_dalpha)
+    if gc is None:
+        gc = np.zeros((3, H, W), np.float32)
+    if gd is None:
+        gd = np.zeros((1, H, W), np.float32)
+    if ga is None:
+        ga = np.zeros((1, H, W), np.float32)
+    L.gsro_backward_f64(P, int(sh_degree), M, _ptr(bgv, _F), W, H, _ptr(m, _F), _ptr(sh, _F), _ptr(col, _F), _ptr(op, _F),
+                        _ptr(sc, _F), float(scale_modifier), _ptr(rot, _F), _ptr(cov, _F), _ptr(vm, _F), _ptr(pm, _F),
+                        _ptr(cp, _F), float(tanfovx), float(tanfovy), _ptr(gc, _F), _ptr(gd, _F), _ptr(ga, _F),
+                        _ptr(out["dL_dmeans2D"], _D), _ptr(out["dL_dcolors"], _D), _ptr(out["dL_dopacity"], _D),
+                        _ptr(out["dL_dmeans3D"], _D), _ptr(out["dL_dcov3D"], _D), _ptr(out["dL_dsh"], _D),
+                        _ptr(out["dL_dscales"], _D), _ptr(out["dL_drotations"], _D), _ptr(out["dL_dconic"], _D),
+                        _ptr(out["dL_ddepths"], _D))
+    return out

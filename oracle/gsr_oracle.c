@@ -786,3 +786,372 @@ int64_t gsro_forward_backward(int P, int deg, int M, const float* bg, int W, int
     free(keys); free(vals); free(ranges);
     return (int64_t)D;
 }
+
+/* =====================================================================================================
+ * FP64 GRADIENT TRUTH (test infrastructure, like the rest of this file).
+ *
+ * gsro_forward_backward (above) is ONE fp32 sample of the reference's backward: backward.cu's formulas, fp32, one
+ * particular summation order.  The reference on a GPU is another sample (atomicAdd in arrival order), this library's
+ * kernels a third.  Comparing two samples says nothing about which is closer to the gradient when a Gaussian is
+ * ill-conditioned (a needle's 1 / (denom^2 + 1e-7), backward.cu:188-201).  This section evaluates the SAME formulas
+ * (backward.cu:415-599 per pixel, :144-413 per Gaussian) in double on the SAME fp32 forward state:
+ *   - taken from the fp32 forward as data: every discrete decision (radii, lists and their order, each pixel's last
+ *     contributor, the skip tests power > 0 and alpha < 1/255 evaluated in fp32 exactly as forward.cu:338-345 does,
+ *     the SH clamp flags, the frustum-clamp flags) and the arrays the reference's backward reads from the forward's
+ *     scratch (means2D, conic_opacity, colours, depths, cov3D -- all fp32);
+ *   - evaluated in double from those: the per-pixel Gaussian weight, alpha, transmittance (as the forward PRODUCT
+ *     prod (1 - alpha), not the backward's T_final / prod recovery), the back-to-front accumulators, all per-Gaussian
+ *     sums (double accumulators: their order is immaterial at 1e-16) and the whole per-Gaussian chain.
+ * The result is "the reference's backward without rounding"; tests state gradient parity as
+ *   |hip - truth| <= max(2e-4 scale, 4 |reference_fp32 - truth|).
+ * ===================================================================================================== */
+typedef struct { double m[3][3]; } d3;
+static d3 d3_mul(const d3* a, const d3* b) {
+    d3 r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) r.m[i][j] = a->m[i][0] * b->m[0][j] + a->m[i][1] * b->m[1][j] + a->m[i][2] * b->m[2][j];
+    return r;
+}
+static d3 d3_t(const d3* a) {
+    d3 r;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) r.m[i][j] = a->m[j][i];
+    return r;
+}
+
+/* backward.cu:415-599 in double.  sums: [P,10] = colour r g b, depth, mean2D x y (before the W/2, H/2 factors are applied:
+ * they ARE applied here), conic xx xy yy, opacity -- laid out as the ten outputs below. */
+static void f64_render_backward(int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* bg,
+                                const float* means2D, const float* conic_opacity, const float* colors, const float* depths,
+                                const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
+                                const float* dL_dpix_alpha, double* dL_dmean2D /*[P,3]*/, double* dL_dconic /*[P,4]*/,
+                                double* dL_dopacity, double* dL_dcolors /*[P,3]*/, double* dL_ddepths) {
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const double ddelx_dx = 0.5 * W, ddely_dy = 0.5 * H;
+#pragma omp parallel
+    {
+        size_t cap = 1024;
+        uint32_t* ids = (uint32_t*)malloc(cap * sizeof(uint32_t));
+        double* al = (double*)malloc(cap * sizeof(double));
+        double* Tb = (double*)malloc(cap * sizeof(double));
+#pragma omp for schedule(dynamic, 1) collapse(2)
+        for (int ty = 0; ty < gy; ++ty)
+            for (int tx = 0; tx < gx; ++tx) {
+                const uint32_t lo = ranges[2 * (ty * gx + tx)];
+                for (int t = 0; t < TILE * TILE; ++t) {
+                    const int px = tx * TILE + t % TILE, py = ty * TILE + t / TILE;
+                    if (!(px < W && py < H)) continue;
+                    const size_t pid = (size_t)W * py + px;
+                    const uint32_t last = n_contrib[pid];
+                    if (last == 0) continue;
+                    if (last > cap) {
+                        cap = 2 * (size_t)last;
+                        ids = (uint32_t*)realloc(ids, cap * sizeof(uint32_t));
+                        al = (double*)realloc(al, cap * sizeof(double));
+                        Tb = (double*)realloc(Tb, cap * sizeof(double));
+                    }
+                    const float pxf = (float)px, pyf = (float)py;
+                    /* front to back over list positions [0, last): which entries contribute (fp32 decisions), their
+                     * alpha and the transmittance in front of each (double) */
+                    size_t n = 0;
+                    double T = 1.0;
+                    for (uint32_t j = 0; j < last; ++j) {
+                        const uint32_t g = point_list[lo + j];
+                        const float dxf = means2D[2 * (size_t)g] - pxf, dyf = means2D[2 * (size_t)g + 1] - pyf;
+                        const float* co = conic_opacity + 4 * (size_t)g;
+                        const float powerf = -0.5f * (co[0] * dxf * dxf + co[2] * dyf * dyf) - co[1] * dxf * dyf;
+                        if (powerf > 0.0f) continue;
+                        const float alphaf = fminf(0.99f, co[3] * expf(powerf));
+                        if (alphaf < 1.0f / 255.0f) continue;
+                        const double dx = (double)means2D[2 * (size_t)g] - px, dy = (double)means2D[2 * (size_t)g + 1] - py;
+                        const double power = -0.5 * ((double)co[0] * dx * dx + (double)co[2] * dy * dy) - (double)co[1] * dx * dy;
+                        const double a = fmin((double)0.99f, (double)co[3] * exp(power));
+                        ids[n] = g; al[n] = a; Tb[n] = T; ++n;
+                        T *= 1.0 - a;
+                    }
+                    const double T_final = T;
+                    const double dLp[3] = {dL_dpix[pid], dL_dpix[(size_t)H * W + pid], dL_dpix[2 * (size_t)H * W + pid]};
+                    const double dLd = dL_dpix_depth[pid], dLa = dL_dpix_alpha[pid];
+                    const double bg_dot = (double)bg[0] * dLp[0] + (double)bg[1] * dLp[1] + (double)bg[2] * dLp[2];
+                    double rec[3] = {0, 0, 0}, red = 0, rea = 0, last_alpha = 0, last_color[3] = {0, 0, 0}, last_depth = 0;
+                    for (size_t k = n; k-- > 0;) {
+                        const uint32_t g = ids[k];
+                        const double alpha = al[k], Tk = Tb[k];
+                        const float* co = conic_opacity + 4 * (size_t)g;
+                        const double dx = (double)means2D[2 * (size_t)g] - px, dy = (double)means2D[2 * (size_t)g + 1] - py;
+                        const double power = -0.5 * ((double)co[0] * dx * dx + (double)co[2] * dy * dy) - (double)co[1] * dx * dy;
+                        const double G = exp(power);
+                        const double dchannel_dcolor = alpha * Tk;
+                        double dL_dalpha = 0;
+                        for (int ch = 0; ch < 3; ++ch) {
+                            const double c = colors[3 * (size_t)g + ch];
+                            rec[ch] = last_alpha * last_color[ch] + (1.0 - last_alpha) * rec[ch];
+                            last_color[ch] = c;
+                            dL_dalpha += (c - rec[ch]) * dLp[ch];
+                            const double v = dchannel_dcolor * dLp[ch];
+#pragma omp atomic
+                            dL_dcolors[3 * (size_t)g + ch] += v;
+                        }
+                        const double dep = depths[g];
+                        red = last_alpha * last_depth + (1.0 - last_alpha) * red;
+                        last_depth = dep;
+                        dL_dalpha += (dep - red) * dLd;
+                        rea = last_alpha + (1.0 - last_alpha) * rea;
+                        dL_dalpha += (1.0 - rea) * dLa;
+                        dL_dalpha *= Tk;
+                        last_alpha = alpha;
+                        dL_dalpha += (-T_final / (1.0 - alpha)) * bg_dot;
+                        /* min(0.99, o G) passes its gradient through unconditionally in backward.cu (no clamp test) */
+                        const double dL_dG = (double)co[3] * dL_dalpha;
+                        const double gdx = G * dx, gdy = G * dy;
+                        const double dG_ddelx = -gdx * (double)co[0] - gdy * (double)co[1];
+                        const double dG_ddely = -gdy * (double)co[2] - gdx * (double)co[1];
+                        const double v0 = dL_dG * dG_ddelx * ddelx_dx, v1 = dL_dG * dG_ddely * ddely_dy;
+                        const double k0 = -0.5 * gdx * dx * dL_dG, k1 = -0.5 * gdx * dy * dL_dG, k3 = -0.5 * gdy * dy * dL_dG;
+                        const double vo = G * dL_dalpha, vd = dchannel_dcolor * dLd;
+#pragma omp atomic
+                        dL_ddepths[g] += vd;
+#pragma omp atomic
+                        dL_dmean2D[3 * (size_t)g + 0] += v0;
+#pragma omp atomic
+                        dL_dmean2D[3 * (size_t)g + 1] += v1;
+#pragma omp atomic
+                        dL_dconic[4 * (size_t)g + 0] += k0;
+#pragma omp atomic
+                        dL_dconic[4 * (size_t)g + 1] += k1;
+#pragma omp atomic
+                        dL_dconic[4 * (size_t)g + 3] += k3;
+#pragma omp atomic
+                        dL_dopacity[g] += vo;
+                    }
+                }
+            }
+        free(ids); free(al); free(Tb);
+    }
+}
+
+/* backward.cu:20-138 in double; the clamp flags are the fp32 forward's. */
+static void f64_sh_backward(int deg, const float p[3], const float cam[3], const float* sh, const uint8_t clamped[3],
+                            const double dL_dcolor[3], double dL_dmean[3], double* dL_dsh) {
+    const double o[3] = {(double)p[0] - cam[0], (double)p[1] - cam[1], (double)p[2] - cam[2]};
+    const double len = sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+    const double x = o[0] / len, y = o[1] / len, z = o[2] / len;
+    const double C0 = kC0, C1 = kC1;
+    double ddir[3] = {0, 0, 0};
+    for (int c = 0; c < 3; ++c) {
+        const double dL = clamped[c] ? 0.0 : dL_dcolor[c];
+#define SH(k) ((double)sh[3 * (k) + c])
+#define DSH(k) dL_dsh[3 * (k) + c]
+        double dx = 0, dy = 0, dz = 0;
+        DSH(0) = C0 * dL;
+        if (deg > 0) {
+            DSH(1) = (-C1 * y) * dL; DSH(2) = (C1 * z) * dL; DSH(3) = (-C1 * x) * dL;
+            dx = -C1 * SH(3); dy = -C1 * SH(1); dz = C1 * SH(2);
+            if (deg > 1) {
+                const double xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                const double a0 = kC2[0], a1 = kC2[1], a2 = kC2[2], a3 = kC2[3], a4 = kC2[4];
+                DSH(4) = (a0 * xy) * dL; DSH(5) = (a1 * yz) * dL; DSH(6) = (a2 * (2. * zz - xx - yy)) * dL;
+                DSH(7) = (a3 * xz) * dL; DSH(8) = (a4 * (xx - yy)) * dL;
+                dx += a0 * y * SH(4) + a2 * 2. * -x * SH(6) + a3 * z * SH(7) + a4 * 2. * x * SH(8);
+                dy += a0 * x * SH(4) + a1 * z * SH(5) + a2 * 2. * -y * SH(6) + a4 * 2. * -y * SH(8);
+                dz += a1 * y * SH(5) + a2 * 2. * 2. * z * SH(6) + a3 * x * SH(7);
+                if (deg > 2) {
+                    const double b0 = kC3[0], b1 = kC3[1], b2 = kC3[2], b3 = kC3[3], b4 = kC3[4], b5 = kC3[5], b6 = kC3[6];
+                    DSH(9) = (b0 * y * (3. * xx - yy)) * dL; DSH(10) = (b1 * xy * z) * dL;
+                    DSH(11) = (b2 * y * (4. * zz - xx - yy)) * dL; DSH(12) = (b3 * z * (2. * zz - 3. * xx - 3. * yy)) * dL;
+                    DSH(13) = (b4 * x * (4. * zz - xx - yy)) * dL; DSH(14) = (b5 * z * (xx - yy)) * dL;
+                    DSH(15) = (b6 * x * (xx - 3. * yy)) * dL;
+                    dx += b0 * SH(9) * 3. * 2. * xy + b1 * SH(10) * yz + b2 * SH(11) * -2. * xy + b3 * SH(12) * -3. * 2. * xz +
+                          b4 * SH(13) * (-3. * xx + 4. * zz - yy) + b5 * SH(14) * 2. * xz + b6 * SH(15) * 3. * (xx - yy);
+                    dy += b0 * SH(9) * 3. * (xx - yy) + b1 * SH(10) * xz + b2 * SH(11) * (-3. * yy + 4. * zz - xx) +
+                          b3 * SH(12) * -3. * 2. * yz + b4 * SH(13) * -2. * xy + b5 * SH(14) * -2. * yz + b6 * SH(15) * -3. * 2. * xy;
+                    dz += b1 * SH(10) * xy + b2 * SH(11) * 4. * 2. * yz + b3 * SH(12) * 3. * (2. * zz - xx - yy) +
+                          b4 * SH(13) * 4. * 2. * xz + b5 * SH(14) * (xx - yy);
+                }
+            }
+        }
+#undef SH
+#undef DSH
+        ddir[0] += dx * dL; ddir[1] += dy * dL; ddir[2] += dz * dL;
+    }
+    /* dnormvdv (auxiliary.h:103-114) */
+    const double sum2 = o[0] * o[0] + o[1] * o[1] + o[2] * o[2];
+    const double inv = 1.0 / sqrt(sum2 * sum2 * sum2);
+    dL_dmean[0] += ((+sum2 - o[0] * o[0]) * ddir[0] - o[1] * o[0] * ddir[1] - o[2] * o[0] * ddir[2]) * inv;
+    dL_dmean[1] += (-o[0] * o[1] * ddir[0] + (sum2 - o[1] * o[1]) * ddir[1] - o[2] * o[1] * ddir[2]) * inv;
+    dL_dmean[2] += (-o[0] * o[2] * ddir[0] - o[1] * o[2] * ddir[1] + (sum2 - o[2] * o[2]) * ddir[2]) * inv;
+}
+
+/* backward.cu:144-413 in double, one Gaussian at a time; cov3D (fp32) and clamped are the fp32 forward's. */
+static void f64_preprocess_backward(int P, int deg, int M, const float* means3D, const int* radii, const float* shs,
+                                    const uint8_t* clamped, const float* scales, const float* rots, float mod,
+                                    const float* cov3D, const float* view, const float* proj, const float* cam, int W, int H,
+                                    float tanx, float tany, const double* dL_dmean2D, const double* dL_dconic,
+                                    const double* dL_dcolor, const double* dL_ddepth, double* dL_dmean3D, double* dL_dcov3D,
+                                    double* dL_dsh, double* dL_dscale, double* dL_drot) {
+    const double h_y = H / (2.0 * (double)tany), h_x = W / (2.0 * (double)tanx);
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < P; ++idx) {
+        if (!(radii[idx] > 0)) continue;
+        const float* mean = means3D + 3 * (size_t)idx;
+        const float* c3 = cov3D + 6 * (size_t)idx;
+        const double dLc[3] = {dL_dconic[4 * (size_t)idx], dL_dconic[4 * (size_t)idx + 1], dL_dconic[4 * (size_t)idx + 3]};
+        /* the clamp decisions as the fp32 code takes them (backward.cu:160-169) */
+        float tf[3];
+        xform43(view, mean, tf);
+        const float limxf = 1.3f * tanx, limyf = 1.3f * tany;
+        const float txtzf = tf[0] / tf[2], tytzf = tf[1] / tf[2];
+        const double x_grad_mul = (txtzf < -limxf || txtzf > limxf) ? 0 : 1, y_grad_mul = (tytzf < -limyf || tytzf > limyf) ? 0 : 1;
+        double t[3];
+        for (int k = 0; k < 3; ++k)
+            t[k] = (double)view[k] * mean[0] + (double)view[4 + k] * mean[1] + (double)view[8 + k] * mean[2] + (double)view[12 + k];
+        const double limx = (double)limxf, limy = (double)limyf;
+        if (x_grad_mul == 0) t[0] = (txtzf < 0 ? -limx : limx) * t[2];
+        if (y_grad_mul == 0) t[1] = (tytzf < 0 ? -limy : limy) * t[2];
+        d3 J = {{{0}}}, Wm, T, V, Tt, Vt, A, C;
+        J.m[0][0] = h_x / t[2]; J.m[2][0] = -(h_x * t[0]) / (t[2] * t[2]);
+        J.m[1][1] = h_y / t[2]; J.m[2][1] = -(h_y * t[1]) / (t[2] * t[2]);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Wm.m[r][c] = view[4 * r + c];
+        V.m[0][0] = c3[0]; V.m[1][0] = c3[1]; V.m[2][0] = c3[2];
+        V.m[0][1] = c3[1]; V.m[1][1] = c3[3]; V.m[2][1] = c3[4];
+        V.m[0][2] = c3[2]; V.m[1][2] = c3[4]; V.m[2][2] = c3[5];
+        T = d3_mul(&Wm, &J);
+        Tt = d3_t(&T); Vt = d3_t(&V);
+        A = d3_mul(&Tt, &Vt);
+        C = d3_mul(&A, &T);
+#define TG(c, r) T.m[r][c]
+#define VG(c, r) V.m[r][c]
+#define WG(c, r) Wm.m[r][c]
+        const double a = C.m[0][0] + (double)0.3f, b = C.m[1][0], c_ = C.m[1][1] + (double)0.3f;
+        const double denom = a * c_ - b * b;
+        double dL_da = 0, dL_db = 0, dL_dc = 0;
+        const double denom2inv = 1.0 / ((denom * denom) + (double)0.0000001f);
+        double* dcov = dL_dcov3D + 6 * (size_t)idx;
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-c_ * c_ * dLc[0] + 2 * b * c_ * dLc[1] + (denom - a * c_) * dLc[2]);
+            dL_dc = denom2inv * (-a * a * dLc[2] + 2 * a * b * dLc[1] + (denom - a * c_) * dLc[0]);
+            dL_db = denom2inv * 2 * (b * c_ * dLc[0] - (denom + 2 * b * b) * dLc[1] + a * b * dLc[2]);
+            dcov[0] = (TG(0, 0) * TG(0, 0) * dL_da + TG(0, 0) * TG(1, 0) * dL_db + TG(1, 0) * TG(1, 0) * dL_dc);
+            dcov[3] = (TG(0, 1) * TG(0, 1) * dL_da + TG(0, 1) * TG(1, 1) * dL_db + TG(1, 1) * TG(1, 1) * dL_dc);
+            dcov[5] = (TG(0, 2) * TG(0, 2) * dL_da + TG(0, 2) * TG(1, 2) * dL_db + TG(1, 2) * TG(1, 2) * dL_dc);
+            dcov[1] = 2 * TG(0, 0) * TG(0, 1) * dL_da + (TG(0, 0) * TG(1, 1) + TG(0, 1) * TG(1, 0)) * dL_db + 2 * TG(1, 0) * TG(1, 1) * dL_dc;
+            dcov[2] = 2 * TG(0, 0) * TG(0, 2) * dL_da + (TG(0, 0) * TG(1, 2) + TG(0, 2) * TG(1, 0)) * dL_db + 2 * TG(1, 0) * TG(1, 2) * dL_dc;
+            dcov[4] = 2 * TG(0, 2) * TG(0, 1) * dL_da + (TG(0, 1) * TG(1, 2) + TG(0, 2) * TG(1, 1)) * dL_db + 2 * TG(1, 1) * TG(1, 2) * dL_dc;
+        } else {
+            for (int i = 0; i < 6; ++i) dcov[i] = 0;
+        }
+        const double dL_dT00 = 2 * (TG(0, 0) * VG(0, 0) + TG(0, 1) * VG(0, 1) + TG(0, 2) * VG(0, 2)) * dL_da + (TG(1, 0) * VG(0, 0) + TG(1, 1) * VG(0, 1) + TG(1, 2) * VG(0, 2)) * dL_db;
+        const double dL_dT01 = 2 * (TG(0, 0) * VG(1, 0) + TG(0, 1) * VG(1, 1) + TG(0, 2) * VG(1, 2)) * dL_da + (TG(1, 0) * VG(1, 0) + TG(1, 1) * VG(1, 1) + TG(1, 2) * VG(1, 2)) * dL_db;
+        const double dL_dT02 = 2 * (TG(0, 0) * VG(2, 0) + TG(0, 1) * VG(2, 1) + TG(0, 2) * VG(2, 2)) * dL_da + (TG(1, 0) * VG(2, 0) + TG(1, 1) * VG(2, 1) + TG(1, 2) * VG(2, 2)) * dL_db;
+        const double dL_dT10 = 2 * (TG(1, 0) * VG(0, 0) + TG(1, 1) * VG(0, 1) + TG(1, 2) * VG(0, 2)) * dL_dc + (TG(0, 0) * VG(0, 0) + TG(0, 1) * VG(0, 1) + TG(0, 2) * VG(0, 2)) * dL_db;
+        const double dL_dT11 = 2 * (TG(1, 0) * VG(1, 0) + TG(1, 1) * VG(1, 1) + TG(1, 2) * VG(1, 2)) * dL_dc + (TG(0, 0) * VG(1, 0) + TG(0, 1) * VG(1, 1) + TG(0, 2) * VG(1, 2)) * dL_db;
+        const double dL_dT12 = 2 * (TG(1, 0) * VG(2, 0) + TG(1, 1) * VG(2, 1) + TG(1, 2) * VG(2, 2)) * dL_dc + (TG(0, 0) * VG(2, 0) + TG(0, 1) * VG(2, 1) + TG(0, 2) * VG(2, 2)) * dL_db;
+        const double dL_dJ00 = WG(0, 0) * dL_dT00 + WG(0, 1) * dL_dT01 + WG(0, 2) * dL_dT02;
+        const double dL_dJ02 = WG(2, 0) * dL_dT00 + WG(2, 1) * dL_dT01 + WG(2, 2) * dL_dT02;
+        const double dL_dJ11 = WG(1, 0) * dL_dT10 + WG(1, 1) * dL_dT11 + WG(1, 2) * dL_dT12;
+        const double dL_dJ12 = WG(2, 0) * dL_dT10 + WG(2, 1) * dL_dT11 + WG(2, 2) * dL_dT12;
+#undef TG
+#undef VG
+#undef WG
+        const double tz = 1.0 / t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+        const double dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+        const double dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+        const double dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t[0]) * tz3 * dL_dJ02 + (2 * h_y * t[1]) * tz3 * dL_dJ12;
+        double dmean[3] = {(double)view[0] * dL_dtx + (double)view[1] * dL_dty + (double)view[2] * dL_dtz,
+                           (double)view[4] * dL_dtx + (double)view[5] * dL_dty + (double)view[6] * dL_dtz,
+                           (double)view[8] * dL_dtx + (double)view[9] * dL_dty + (double)view[10] * dL_dtz};
+        const double mx = mean[0], my = mean[1], mz = mean[2];
+        const double mhw = (double)proj[3] * mx + (double)proj[7] * my + (double)proj[11] * mz + (double)proj[15];
+        const double m_w = 1.0 / (mhw + (double)0.0000001f);
+        const double mul1 = ((double)proj[0] * mx + (double)proj[4] * my + (double)proj[8] * mz + (double)proj[12]) * m_w * m_w;
+        const double mul2 = ((double)proj[1] * mx + (double)proj[5] * my + (double)proj[9] * mz + (double)proj[13]) * m_w * m_w;
+        const double* g2 = dL_dmean2D + 3 * (size_t)idx;
+        dmean[0] += ((double)proj[0] * m_w - (double)proj[3] * mul1) * g2[0] + ((double)proj[1] * m_w - (double)proj[3] * mul2) * g2[1];
+        dmean[1] += ((double)proj[4] * m_w - (double)proj[7] * mul1) * g2[0] + ((double)proj[5] * m_w - (double)proj[7] * mul2) * g2[1];
+        dmean[2] += ((double)proj[8] * m_w - (double)proj[11] * mul1) * g2[0] + ((double)proj[9] * m_w - (double)proj[11] * mul2) * g2[1];
+        const double mul3 = (double)view[2] * mx + (double)view[6] * my + (double)view[10] * mz + (double)view[14];
+        dmean[0] += ((double)view[2] - (double)view[3] * mul3) * dL_ddepth[idx];
+        dmean[1] += ((double)view[6] - (double)view[7] * mul3) * dL_ddepth[idx];
+        dmean[2] += ((double)view[10] - (double)view[11] * mul3) * dL_ddepth[idx];
+        if (shs) f64_sh_backward(deg, mean, cam, shs + 3 * (size_t)M * idx, clamped + 3 * (size_t)idx, dL_dcolor + 3 * (size_t)idx, dmean,
+                                 dL_dsh + 3 * (size_t)M * idx);
+        for (int k = 0; k < 3; ++k) dL_dmean3D[3 * (size_t)idx + k] = dmean[k];
+        if (scales) {
+            const float* q = rots + 4 * (size_t)idx;
+            const double r = q[0], x = q[1], y = q[2], z = q[3];
+            d3 R, S = {{{0}}}, M3, dSig, dM, Rt, dMt;
+            R.m[0][0] = 1. - 2. * (y * y + z * z); R.m[1][0] = 2. * (x * y - r * z);       R.m[2][0] = 2. * (x * z + r * y);
+            R.m[0][1] = 2. * (x * y + r * z);       R.m[1][1] = 1. - 2. * (x * x + z * z); R.m[2][1] = 2. * (y * z - r * x);
+            R.m[0][2] = 2. * (x * z - r * y);       R.m[1][2] = 2. * (y * z + r * x);       R.m[2][2] = 1. - 2. * (x * x + y * y);
+            const double s[3] = {(double)mod * scales[3 * (size_t)idx], (double)mod * scales[3 * (size_t)idx + 1], (double)mod * scales[3 * (size_t)idx + 2]};
+            S.m[0][0] = s[0]; S.m[1][1] = s[1]; S.m[2][2] = s[2];
+            M3 = d3_mul(&S, &R);
+            dSig.m[0][0] = dcov[0];       dSig.m[1][0] = 0.5 * dcov[1]; dSig.m[2][0] = 0.5 * dcov[2];
+            dSig.m[0][1] = 0.5 * dcov[1]; dSig.m[1][1] = dcov[3];       dSig.m[2][1] = 0.5 * dcov[4];
+            dSig.m[0][2] = 0.5 * dcov[2]; dSig.m[1][2] = 0.5 * dcov[4]; dSig.m[2][2] = dcov[5];
+            d3 M2 = M3;
+            for (int a2 = 0; a2 < 3; ++a2) for (int b2 = 0; b2 < 3; ++b2) M2.m[a2][b2] = 2.0 * M3.m[a2][b2];
+            dM = d3_mul(&M2, &dSig);
+            Rt = d3_t(&R);
+            dMt = d3_t(&dM);
+#define COL(Mx, c, r) Mx.m[r][c]
+            double* ds = dL_dscale + 3 * (size_t)idx;
+            for (int c = 0; c < 3; ++c)
+                ds[c] = COL(Rt, c, 0) * COL(dMt, c, 0) + COL(Rt, c, 1) * COL(dMt, c, 1) + COL(Rt, c, 2) * COL(dMt, c, 2);
+            for (int c = 0; c < 3; ++c) for (int rr = 0; rr < 3; ++rr) COL(dMt, c, rr) *= s[c];
+#define D(c, rr) COL(dMt, c, rr)
+            double* dq = dL_drot + 4 * (size_t)idx;
+            dq[0] = 2 * z * (D(0, 1) - D(1, 0)) + 2 * y * (D(2, 0) - D(0, 2)) + 2 * x * (D(1, 2) - D(2, 1));
+            dq[1] = 2 * y * (D(1, 0) + D(0, 1)) + 2 * z * (D(2, 0) + D(0, 2)) + 2 * r * (D(1, 2) - D(2, 1)) - 4 * x * (D(2, 2) + D(1, 1));
+            dq[2] = 2 * x * (D(1, 0) + D(0, 1)) + 2 * r * (D(2, 0) - D(0, 2)) + 2 * z * (D(1, 2) + D(2, 1)) - 4 * y * (D(2, 2) + D(0, 0));
+            dq[3] = 2 * r * (D(0, 1) - D(1, 0)) + 2 * x * (D(2, 0) + D(0, 2)) + 2 * y * (D(1, 2) + D(2, 1)) - 4 * z * (D(1, 1) + D(0, 0));
+#undef D
+#undef COL
+        }
+    }
+}
+
+/*
+ * fp32 forward (identical to gsro_forward_backward's) + the double backward above.  All gradient outputs are double and must
+ * arrive zero-filled; shapes as in gsro_forward_backward.  Forward images / radii are not returned (call gsro_forward).
+ */
+int64_t gsro_backward_f64(int P, int deg, int M, const float* bg, int W, int H, const float* means3D, const float* shs,
+                          const float* colors_pre, const float* opac, const float* scales, float mod, const float* rots,
+                          const float* cov3D_pre, const float* view, const float* proj, const float* cam, float tanx, float tany,
+                          const float* dL_dout_color, const float* dL_dout_depth, const float* dL_dout_alpha,
+                          double* dL_dmeans2D, double* dL_dcolors, double* dL_dopacity, double* dL_dmeans3D, double* dL_dcov3D,
+                          double* dL_dsh, double* dL_dscales, double* dL_drots, double* dL_dconic, double* dL_ddepths) {
+    if (P == 0) return 0;
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, T = gx * gy;
+    const size_t n = (size_t)P, npx = (size_t)W * H;
+    float* means2D = (float*)calloc(2 * n, 4);
+    float* depths = (float*)calloc(n, 4);
+    float* conop = (float*)calloc(4 * n, 4);
+    float* rgb = (float*)calloc(3 * n, 4);
+    float* cov3D = (float*)calloc(6 * n, 4);
+    uint8_t* clamped = (uint8_t*)calloc(3 * n, 1);
+    int* radii = (int*)calloc(n, 4);
+    uint32_t* tiles = (uint32_t*)calloc(n, 4);
+    uint32_t* offs = (uint32_t*)calloc(n, 4);
+    uint32_t* ncontrib = (uint32_t*)calloc(npx, 4);
+    float* img = (float*)calloc(5 * npx, 4);
+    gsro_preprocess(P, deg, M, means3D, scales, mod, rots, opac, shs, cov3D_pre, colors_pre, view, proj, cam, W, H,
+                    tanx, tany, radii, means2D, depths, cov3D, rgb, conop, tiles, clamped);
+    const uint32_t D = gsro_inclusive_sum(P, tiles, offs);
+    uint64_t* keys = (uint64_t*)malloc((D ? D : 1) * sizeof(uint64_t));
+    uint32_t* vals = (uint32_t*)malloc((D ? D : 1) * sizeof(uint32_t));
+    uint32_t* ranges = (uint32_t*)malloc((size_t)T * 2 * sizeof(uint32_t));
+    gsro_duplicate(P, W, H, means2D, depths, offs, radii, keys, vals);
+    gsro_sort_pairs(D, keys, vals, 32 + gsro_key_bits((uint32_t)T));
+    gsro_tile_ranges(D, keys, T, ranges);
+    const float* feat = colors_pre ? colors_pre : rgb;
+    gsro_blend(W, H, ranges, vals, means2D, feat, depths, conop, bg, img, img + 3 * npx, img + 4 * npx, ncontrib);
+    f64_render_backward(W, H, ranges, vals, bg, means2D, conop, feat, depths, ncontrib, dL_dout_color, dL_dout_depth,
+                        dL_dout_alpha, dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors, dL_ddepths);
+    f64_preprocess_backward(P, deg, M, means3D, radii, shs, clamped, scales, rots, mod, cov3D_pre ? cov3D_pre : cov3D, view, proj,
+                            cam, W, H, tanx, tany, dL_dmeans2D, dL_dconic, dL_dcolors, dL_ddepths, dL_dmeans3D, dL_dcov3D, dL_dsh,
+                            dL_dscales, dL_drots);
+    free(means2D); free(depths); free(conop); free(rgb); free(cov3D); free(clamped); free(radii); free(tiles); free(offs);
+    free(ncontrib); free(img); free(keys); free(vals); free(ranges);
+    return (int64_t)D;
+}

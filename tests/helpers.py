@@ -206,3 +206,55 @@ class dump_on_failure:
         except OSError:
             pass
         return False
+
+
+# ---- gradient parity against the fp64 truth (oracle/gsr_oracle.c: gsro_backward_f64) ----
+GRAD_REL, GRAD_ABS, GRAD_REF_FACTOR = 2e-4, 1e-6, 4.0
+
+
+def report_row(name, **kv):
+    """One line of gpurun_out/parity_report.jsonl (copied to profiles/ at the end of a round)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "parity_report.jsonl"), "a") as f:
+        f.write(json.dumps({"test": name, **{k: (v.item() if hasattr(v, "item") else v) for k, v in kv.items()}}) + "\n")
+
+
+def gradient_errors(got, ref32, truth):
+    """max-norm distances of one gradient array: (|got - truth|, |ref32 - truth|, |got - ref32|, scale = max|truth|), over the
+    elements where the truth and the reference are finite (fp32 overflow in a wild scene is compared separately)."""
+    g, r, t = (np.asarray(a, np.float64).reshape(-1) for a in (got, ref32, truth))
+    ok = np.isfinite(t) & np.isfinite(r)
+    if not ok.any():
+        return 0.0, 0.0, 0.0, 0.0
+    g, r, t = g[ok], r[ok], t[ok]
+    return float(np.abs(g - t).max()), float(np.abs(r - t).max()), float(np.abs(g - r).max()), float(np.abs(t).max())
+
+
+def assert_gradients_vs_truth(name, got, ref32, truth, keys, rel=GRAD_REL, abs_tol=GRAD_ABS, ref_factor=GRAD_REF_FACTOR):
+    """THE gradient bar.  Per gradient array, in the max norm:
+
+        |got - truth|  <=  max(rel * max|truth| + abs_tol,  ref_factor * |ref32 - truth|)
+
+    ``truth`` = the reference's backward formulas evaluated in double on the fp32 forward state (cpu_oracle.backward_f64);
+    ``ref32`` = the reference's own fp32 backward (the CPU oracle, bit-identical to backward.cu compiled for the host, or the
+    reference's kernels on this GPU).  The first term is the bar a well-conditioned gradient has always been held to; the
+    second says an ill-conditioned one (a needle's 1 / (denom^2 + 1e-7)) may be as far from the truth as the reference
+    itself is, times ``ref_factor`` -- two fp32 samples of such a gradient differ from each other by more than 2e-4 of the
+    scale even with exact per-Gaussian sums (profiles/r05_gradient_truth.md).  No stragglers, no noise multipliers.
+    Writes one report row with, per array: err (|got - truth| / scale), ref_err, vs_ref and frac = err / bar."""
+    row, failures = {}, []
+    for k in keys:
+        if got.get(k) is None:
+            continue
+        e_got, e_ref, e_pair, scale = gradient_errors(got[k], ref32[k], truth[k])
+        bar = max(rel * scale + abs_tol, ref_factor * e_ref)
+        s = max(scale, 1e-30)
+        row[k] = {"err": e_got / s, "ref_err": e_ref / s, "vs_ref": e_pair / s, "frac": e_got / bar}
+        if not e_got <= bar:
+            failures.append(f"{k}: |got - truth| {e_got:.3e} > bar {bar:.3e} (scale {scale:.3e}, |ref32 - truth| {e_ref:.3e})")
+    report_row("grad:" + name, **{f"{k}.{m}": v for k, d in row.items() for m, v in d.items()})
+    assert not failures, f"{name}: " + "; ".join(failures)
+    return row

@@ -1,9 +1,14 @@
 """GPU parity of the backward pass: ``loss.backward()`` through the drop-in API (-> gsr_backward -> gfx950
-kernels) against the CPU oracle's backward and against golden vectors from the reference's backward.cu.
+kernels) against the fp64 gradient truth, the CPU oracle's fp32 backward and golden vectors from the reference's backward.cu.
 
-Bar: per gradient array, max |hip - ref| <= 2e-4 * max|ref| + 1e-6.  Exact bit equality is not attainable
-for sums formed with atomics (neither here nor in the reference); the forward images feeding the backward
-already agree to ~1e-6 and the per-Gaussian arithmetic is the reference's op for op.
+Bar (tests/helpers.py: assert_gradients_vs_truth): per gradient array, in the max norm,
+    |hip - truth| <= max(2e-4 * max|truth| + 1e-6, 4 * |reference_fp32 - truth|)
+with truth = backward.cu's formulas evaluated in double on the fp32 forward state (oracle/gsr_oracle.c:
+gsro_backward_f64) and reference_fp32 = the CPU oracle, which is backward.cu bit for bit.  Exact bit equality with the
+reference is not attainable for sums formed with atomics (neither here nor in the reference), and for an ill-conditioned
+Gaussian two fp32 samples differ by far more than the last bits -- the truth says how far either is allowed to be.
+Every case runs in both modes of the library: float atomics (default) and GSR_OPT_BACKWARD_DETERMINISTIC, whose results
+are a pure function of the inputs (asserted: same bits twice).
 """
 import os
 
@@ -16,16 +21,18 @@ from autovfx_amd.cameras import orbit_cameras
 from autovfx_amd.scenes import GaussianCloud
 from oracle import cpu_oracle
 
-from helpers import decode_scratch, dump_on_failure, oracle_kwargs, settings_for
+from helpers import assert_gradients_vs_truth, decode_scratch, dump_on_failure, oracle_kwargs, settings_for
 from test_oracle_backward import GOLDEN_BW, cpu_cov3d, load_bw_case, pixel_grads
 from test_parity_gpu import report
 
 pytestmark = pytest.mark.gpu
-REL, ABS = 2e-4, 1e-6
+
+
+MODES = ("atomic", "deterministic")
 
 
 def hip_backward(cloud, cam, pg, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, sh_degree=None, cov3D_precomp=None,
-                 device="cuda:0", cull=True, tanfov=None):
+                 device="cuda:0", cull=True, tanfov=None, mode="atomic"):
     from autovfx_amd import _lib
     from diff_gaussian_rasterization import GaussianRasterizer
     c = cloud.to(device)
@@ -45,6 +52,7 @@ def hip_backward(cloud, cam, pg, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, sh_degr
         scales, rots = leaf(c.scales), leaf(c.rotations)
         kw["scales"], kw["rotations"] = scales, rots
     _lib.set_option(_lib.OPT_TILE_CULL, 1 if cull else 0)
+    _lib.set_option(_lib.OPT_BACKWARD_DETERMINISTIC, 1 if mode == "deterministic" else 0)
     try:
         color, depth, alpha, radii = GaussianRasterizer(st)(means3D=means3D, means2D=means2D, opacities=opac, shs=shs,
                                                             colors_precomp=colors, **kw)
@@ -57,9 +65,10 @@ def hip_backward(cloud, cam, pg, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, sh_degr
         t = lambda a: torch.from_numpy(a).to(device)
         loss = (color * t(pg["dL_dcolor"])).sum() + (depth * t(pg["dL_ddepth"])).sum() + (alpha * t(pg["dL_dalpha"])).sum()
         loss.backward()
+        torch.cuda.synchronize()
     finally:
         _lib.set_option(_lib.OPT_TILE_CULL, 1)
-    torch.cuda.synchronize()
+        _lib.set_option(_lib.OPT_BACKWARD_DETERMINISTIC, 0)
     g = lambda x: None if x is None or x.grad is None else x.grad.cpu().numpy()
     return {"color": color.detach().cpu().numpy(), "depth": depth.detach().cpu().numpy(), "alpha": alpha.detach().cpu().numpy(),
             "dL_dmeans3D": g(means3D), "dL_dmeans2D": g(means2D),
@@ -108,81 +117,88 @@ def assert_forward_state(name, hip, fref):
         assert bad <= int(np.ceil(FLIP_PPM * 1e-6 * npx)), f"{name}: forward {key} off on {bad} px (max {err.max():.3e})"
 
 
-def check_case(name, cloud, cam, pg, hip, ref, keys, **okw):
-    """One backward case: forward state first, then every gradient; on any failure the inputs, the HIP results (with the
-    decoded forward scratch) and the oracle's are dumped to gpurun_out/failures/."""
+_ORACLE_CACHE = {}
+
+
+def oracles(name, kw):
+    """(reference fp32 backward, fp64 truth) of one case, computed once for both modes of the library."""
+    if name not in _ORACLE_CACHE:
+        _ORACLE_CACHE.clear()   # one case at a time: a full-size case holds a gigabyte
+        _ORACLE_CACHE[name] = (cpu_oracle.backward(**kw), cpu_oracle.backward_f64(**kw))
+    return _ORACLE_CACHE[name]
+
+
+def check_case(name, cloud, cam, pg, keys, mode, hip_kw=None, **okw):
+    """One backward case in one mode of the library: forward state first (integers bit-exact against the oracle), then every
+    gradient against the truth; on any failure the inputs, the HIP results (with the decoded forward scratch) and the
+    oracle's are dumped to gpurun_out/failures/.  In deterministic mode a second run must give the same bits."""
+    kw = oracle_kwargs(cloud, cam, **okw)
+    kw.update(pg)
+    ref, truth = oracles(name, kw)
+    hkw = dict(bg=tuple(float(v) for v in okw.get("bg", (0.0, 0.0, 0.0))), scale_modifier=okw.get("scale_modifier", 1.0),
+               sh_degree=okw.get("sh_degree"), cov3D_precomp=okw.get("cov3D_precomp"))
+    hkw.update(hip_kw or {})
+    hip = hip_backward(cloud, cam, pg, mode=mode, **hkw)
     fref = cpu_oracle.forward(intermediates=True, **oracle_kwargs(cloud, cam, **okw))
-    with dump_on_failure("bw_" + name, hip={k: v for k, v in hip.items() if k != "fwd"}, fwd=hip["fwd"], ref=ref, fref=fref, pg=pg,
+    with dump_on_failure(f"bw_{name}_{mode}", hip={k: v for k, v in hip.items() if k != "fwd"}, fwd=hip["fwd"], ref=ref, fref=fref, pg=pg,
                          cloud={"means3D": cloud.means3D, "opacities": cloud.opacities, "scales": cloud.scales,
                                 "rotations": cloud.rotations}):
         assert_forward_state(name, hip, fref)
-        compare(name, hip, ref, keys)
+        assert_gradients_vs_truth(f"{name}:{mode}", hip, ref, truth, keys)
+        if mode == "deterministic":
+            again = hip_backward(cloud, cam, pg, mode=mode, **hkw)
+            assert_same_bits(name, hip, again, keys)
+    return hip, ref
 
 
-def compare(name, hip, ref, keys):
-    worst = {}
+def assert_same_bits(name, a, b, keys):
     for k in keys:
-        if hip.get(k) is None:
+        if a.get(k) is None:
             continue
-        a, b = hip[k].astype(np.float64).reshape(-1), ref[k].astype(np.float64).reshape(-1)
-        scale = float(np.abs(b).max()) if b.size else 0.0
-        err = float(np.abs(a - b).max()) if b.size else 0.0
-        worst[k] = err / max(scale, 1e-30)
-        assert err <= REL * scale + ABS, f"{name}: {k} max abs err {err:.3e} vs scale {scale:.3e}"
-    report("bw:" + name, **{k: float(v) for k, v in worst.items()})
+        x, y = np.ascontiguousarray(a[k]).view(np.uint32), np.ascontiguousarray(b[k]).view(np.uint32)
+        assert np.array_equal(x, y), f"{name}: {k} differs between two deterministic runs in {int((x != y).sum())} elements"
 
 
 KEYS_SH = ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dscales", "dL_drotations")
 KEYS_PRE = ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dscales", "dL_drotations")
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("cull", [True, False])
-def test_backward_sh_scene(cull):
+def test_backward_sh_scene(cull, mode):
     cloud, cam = scenes.config_c1(P=6000, seed=31), scenes.c1_camera(192, 128)
-    pg = pixel_grads(cam, 5)
-    kw = oracle_kwargs(cloud, cam, bg=(0.1, 0.2, 0.3))
-    kw.update(pg)
-    ref = cpu_oracle.backward(**kw)
-    hip = hip_backward(cloud, cam, pg, bg=(0.1, 0.2, 0.3), cull=cull)
-    check_case(f"sh_cull{int(cull)}", cloud, cam, pg, hip, ref, KEYS_SH, bg=(0.1, 0.2, 0.3))
+    check_case("sh", cloud, cam, pixel_grads(cam, 5), KEYS_SH, mode, hip_kw={"cull": cull}, bg=(0.1, 0.2, 0.3))
 
 
-def test_backward_precomputed_colours_and_orbit_camera():
+@pytest.mark.parametrize("mode", MODES)
+def test_backward_precomputed_colours_and_orbit_camera(mode):
     cloud, cam = scenes.config_c4(P=15000, seed=32), orbit_cameras(8, 240, 135)[3]
-    pg = pixel_grads(cam, 6)
-    kw = oracle_kwargs(cloud, cam, bg=(1.0, 1.0, 1.0))
-    kw.update(pg)
-    check_case("precomp", cloud, cam, pg, hip_backward(cloud, cam, pg, bg=(1.0, 1.0, 1.0)), cpu_oracle.backward(**kw), KEYS_PRE,
-               bg=(1.0, 1.0, 1.0))
+    check_case("precomp", cloud, cam, pixel_grads(cam, 6), KEYS_PRE, mode, bg=(1.0, 1.0, 1.0))
 
 
-def test_backward_cov3d_precomp_scale_modifier_low_degree():
+@pytest.mark.parametrize("mode", MODES)
+def test_backward_cov3d_precomp_scale_modifier_low_degree(mode):
     cloud, cam = scenes.config_c1(P=2500, seed=33), scenes.c1_camera(100, 70)
     pg = pixel_grads(cam, 7)
     cov = cpu_cov3d(cloud)
-    kw = oracle_kwargs(cloud, cam, cov3D_precomp=cov, sh_degree=1, bg=(0.5, 0.5, 0.5))
-    kw.update(pg)
-    hip = hip_backward(cloud, cam, pg, bg=(0.5, 0.5, 0.5), cov3D_precomp=cov, sh_degree=1)
-    check_case("cov3d_deg1", cloud, cam, pg, hip, cpu_oracle.backward(**kw),
-               ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dcov3D"), cov3D_precomp=cov, sh_degree=1, bg=(0.5, 0.5, 0.5))
+    check_case("cov3d_deg1", cloud, cam, pg, ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh", "dL_dcov3D"), mode,
+               cov3D_precomp=cov, sh_degree=1, bg=(0.5, 0.5, 0.5))
     cloud2 = scenes.config_c1(P=2500, seed=34)
-    kw = oracle_kwargs(cloud2, cam, scale_modifier=1.7)
-    kw.update(pg)
-    check_case("scale_mod", cloud2, cam, pg, hip_backward(cloud2, cam, pg, scale_modifier=1.7), cpu_oracle.backward(**kw), KEYS_SH,
-               scale_modifier=1.7)
+    check_case("scale_mod", cloud2, cam, pg, KEYS_SH, mode, scale_modifier=1.7)
 
 
-def test_backward_big_splats_and_ragged_image():
+@pytest.mark.parametrize("mode", MODES)
+def test_backward_big_splats_and_ragged_image(mode):
     cloud, cam = scenes.config_c1(P=500, seed=35), scenes.c1_camera(131, 77)
     cloud.scales[:40] *= 20.0
-    pg = pixel_grads(cam, 8)
-    kw = oracle_kwargs(cloud, cam)
-    kw.update(pg)
-    check_case("big_ragged", cloud, cam, pg, hip_backward(cloud, cam, pg), cpu_oracle.backward(**kw), KEYS_SH)
+    check_case("big_ragged", cloud, cam, pixel_grads(cam, 8), KEYS_SH, mode)
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("path", GOLDEN_BW, ids=[os.path.basename(p)[:-4] for p in GOLDEN_BW])
-def test_backward_matches_reference_golden_vectors(path):
+def test_backward_matches_reference_golden_vectors(path, mode):
+    """The committed golden vectors are backward.cu's own fp32 results (tests/golden/make_golden.py from oracle/_ref): they are
+    the ``ref32`` of the bar, the truth is computed from the same inputs."""
     from autovfx_amd.cameras import Camera
     kw, ref = load_bw_case(path)
     t = lambda k: None if k not in kw else torch.from_numpy(np.asarray(kw[k]))
@@ -192,8 +208,9 @@ def test_backward_matches_reference_golden_vectors(path):
                  t("viewmatrix"), t("projmatrix"), t("projmatrix"), t("campos"))
     pg = {k: kw[k] for k in ("dL_dcolor", "dL_ddepth", "dL_dalpha")}
     hip = hip_backward(cloud, cam, pg, bg=tuple(float(v) for v in kw["bg"]), scale_modifier=kw["scale_modifier"],
-                       tanfov=(kw["tanfovx"], kw["tanfovy"]))
-    compare("golden:" + os.path.basename(path)[:-4], hip, ref, KEYS_SH if cloud.shs is not None else KEYS_PRE)
+                       tanfov=(kw["tanfovx"], kw["tanfovy"]), mode=mode)
+    truth = cpu_oracle.backward_f64(**kw)
+    assert_gradients_vs_truth(f"golden:{os.path.basename(path)[:-4]}:{mode}", hip, ref, truth, KEYS_SH if cloud.shs is not None else KEYS_PRE)
 
 
 def test_training_step_reduces_loss():
@@ -226,6 +243,7 @@ def test_training_step_reduces_loss():
 
 @pytest.mark.parametrize("seed", range(10))
 def test_backward_randomised_configurations(seed):
+    mode = MODES[(seed // 2) % 2]   # seeds 0 1 4 5 8 9 atomic, 2 3 6 7 deterministic (culling alternates with the seed)
     rng = np.random.default_rng(500 + seed)
     P = int(rng.choice([1, 3, 64, 65, 400, 2000]))
     W, H = int(rng.integers(1, 200)), int(rng.integers(1, 150))
@@ -238,22 +256,15 @@ def test_backward_randomised_configurations(seed):
     bg = tuple(float(v) for v in rng.uniform(0, 1, 3))
     cam = scenes.c1_camera(W, H, fovx_deg=float(rng.uniform(35, 95)))
     pg = pixel_grads(cam, seed)
-    kw = oracle_kwargs(cloud, cam, bg=bg, sh_degree=deg)
-    kw.update(pg)
-    hip = hip_backward(cloud, cam, pg, bg=bg, sh_degree=deg, cull=bool(seed % 2))
-    check_case(f"rand{seed}", cloud, cam, pg, hip, cpu_oracle.backward(**kw), KEYS_SH, bg=bg, sh_degree=deg)
+    check_case(f"rand{seed}", cloud, cam, pg, KEYS_SH, mode, hip_kw={"cull": bool(seed % 2)}, bg=bg, sh_degree=deg)
 
 
-def test_backward_c2_full_size_vs_oracle():
+@pytest.mark.parametrize("mode", MODES)
+def test_backward_c2_full_size_vs_oracle(mode):
     """BASELINE configs[1] stand-in at full size (1 M Gaussians, 960x540, orbit frame 100): every gradient against the
-    CPU oracle's backward, same bar as the small cases."""
+    truth and the CPU oracle's backward, same bar as the small cases."""
     cloud, cam = scenes.config_c2(), orbit_cameras(200, 960, 540)[100]
-    pg = pixel_grads(cam, 5)
-    kw = oracle_kwargs(cloud, cam)
-    kw.update(pg)
-    ref = cpu_oracle.backward(**kw)
-    hip = hip_backward(cloud, cam, pg)
-    check_case("c2_full_1M", cloud, cam, pg, hip, ref, KEYS_SH)
+    check_case("c2_full_1M", cloud, cam, pixel_grads(cam, 5), KEYS_SH, mode)
 
 
 def test_rendered_gaussians_behind_an_opaque_front_get_exact_zeros_like_the_oracle():
@@ -271,12 +282,7 @@ def test_rendered_gaussians_behind_an_opaque_front_get_exact_zeros_like_the_orac
     both = GaussianCloud(means3D=torch.cat([wall, cloud.means3D]), opacities=torch.cat([torch.full((W, 1), 0.999), cloud.opacities.reshape(-1, 1)]),
                          scales=torch.cat([torch.full((W, 3), 0.15), cloud.scales]), rotations=torch.cat([rot, cloud.rotations]),
                          shs=torch.cat([torch.randn((W,) + tuple(cloud.shs.shape[1:]), generator=g) * 0.3, cloud.shs]))
-    pg = pixel_grads(cam, 9)
-    kw = oracle_kwargs(both, cam)
-    kw.update(pg)
-    ref = cpu_oracle.backward(**kw)
-    hip = hip_backward(both, cam, pg)
-    check_case("opaque_wall", both, cam, pg, hip, ref, KEYS_SH)
+    hip, ref = check_case("opaque_wall", both, cam, pixel_grads(cam, 9), KEYS_SH, "atomic")
     rendered = hip["radii"] > 0
     rows = lambda d: np.concatenate([np.asarray(d[k]).reshape(both.P, -1) for k in KEYS_SH], 1)
     idle_ref, idle_hip = (rows(ref) == 0).all(1), (rows(hip) == 0).all(1)
@@ -299,7 +305,7 @@ def test_colour_only_loss_skips_the_depth_and_alpha_terms_with_the_same_gradient
     pg["dL_dalpha"] = np.zeros_like(pg["dL_dalpha"])
     kw = oracle_kwargs(cloud, cam, bg=(0.2, 0.1, 0.3))
     kw.update(pg)
-    ref = cpu_oracle.backward(**kw)
+    ref, truth = cpu_oracle.backward(**kw), cpu_oracle.backward_f64(**kw)
     full = hip_backward(cloud, cam, pg, bg=(0.2, 0.1, 0.3))            # zero-filled depth / alpha gradients: every term runs
     c = cloud.to(dev)
     st = settings_for(cam, dev, (0.2, 0.1, 0.3), 1.0, cloud.sh_degree)
@@ -312,8 +318,8 @@ def test_colour_only_loss_skips_the_depth_and_alpha_terms_with_the_same_gradient
     lean = {"dL_dmeans3D": leaves[0].grad, "dL_dmeans2D": means2D.grad, "dL_dopacity": leaves[1].grad, "dL_dsh": leaves[2].grad,
             "dL_dscales": leaves[3].grad, "dL_drotations": leaves[4].grad}
     lean = {k: v.cpu().numpy() for k, v in lean.items()}
-    compare("colour_only_vs_oracle", lean, ref, KEYS_SH)
-    compare("colour_only_vs_full_kernel", lean, full, KEYS_SH)
+    assert_gradients_vs_truth("colour_only", lean, ref, truth, KEYS_SH)
+    assert_gradients_vs_truth("colour_only_full_kernel", full, ref, truth, KEYS_SH)
     # a loss that touches nothing of the rasterizer's outputs but its depth: colour arrives as None and is zero-filled
     for t in leaves:
         t.grad = None
@@ -324,17 +330,17 @@ def test_colour_only_loss_skips_the_depth_and_alpha_terms_with_the_same_gradient
     assert float(leaves[2].grad.abs().sum()) == 0.0   # no colour gradient -> none for the SH coefficients
 
 
-def test_backward_c4_full_size_vs_oracle():
+@pytest.mark.parametrize("mode", MODES)
+def test_backward_c4_full_size_vs_oracle(mode):
     """BASELINE configs[3] at bench size (200 k flat SuGaR-style Gaussians, colors_precomp, 960x540, SuGaR's off-centre
-    principal-point camera, orbit frame 25): every gradient against the CPU oracle's backward."""
+    principal-point camera, orbit frame 25): every gradient against the truth.  These are the ill-conditioned ones (thin axis
+    3e-4 against 2e-2 in plane): the reference's own fp32 backward is 1.7e-3 of the scale away from the truth in dL_dscales,
+    and exact per-Gaussian sums rounded to fp32 move its result by 1e-3 (profiles/r05_gradient_truth.md) -- the round-4 bar
+    of 2e-4 between two fp32 samples was inside that noise."""
     from autovfx_amd.cameras import sugar_orbit_cameras
     cloud, cam = scenes.config_c4(), sugar_orbit_cameras(50, 960, 540)[25]
     assert cloud.P == 200_000
-    pg = pixel_grads(cam, 8)
-    kw = oracle_kwargs(cloud, cam, bg=(1.0, 1.0, 1.0))
-    kw.update(pg)
-    check_case("c4_full_200k", cloud, cam, pg, hip_backward(cloud, cam, pg, bg=(1.0, 1.0, 1.0)), cpu_oracle.backward(**kw), KEYS_PRE,
-               bg=(1.0, 1.0, 1.0))
+    check_case("c4_full_200k", cloud, cam, pixel_grads(cam, 8), KEYS_PRE, mode, bg=(1.0, 1.0, 1.0))
 
 
 def test_backward_sh_degree_four_with_25_coefficients_leaves_higher_bands_zero():
@@ -346,12 +352,12 @@ def test_backward_sh_degree_four_with_25_coefficients_leaves_higher_bands_zero()
     wide = GaussianCloud(cloud.means3D, cloud.opacities, cloud.scales, cloud.rotations,
                          torch.cat((cloud.shs, torch.randn(cloud.P, 9, 3, generator=g)), 1).contiguous(), None, 4)
     pg = pixel_grads(cam, 9)
-    a = hip_backward(cloud, cam, pg, sh_degree=3)
-    b = hip_backward(wide, cam, pg, sh_degree=4)
+    a = hip_backward(cloud, cam, pg, sh_degree=3, mode="deterministic")   # fixed summation order: the two runs can be compared bit for bit
+    b = hip_backward(wide, cam, pg, sh_degree=4, mode="deterministic")
     assert b["dL_dsh"].shape == (cloud.P, 25, 3)
     assert not b["dL_dsh"][:, 16:].any(), "bands above degree 3 must get zero gradient"
     np.testing.assert_array_equal(np.isfinite(b["dL_dsh"]), True)
-    np.testing.assert_allclose(b["dL_dsh"][:, :16], a["dL_dsh"], rtol=0, atol=REL * float(np.abs(a["dL_dsh"]).max()) + ABS)
+    np.testing.assert_array_equal(b["dL_dsh"][:, :16], a["dL_dsh"])
     np.testing.assert_array_equal(a["color"], b["color"])
 
 
