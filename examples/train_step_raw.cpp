@@ -19,6 +19,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../include/gsr.h"
@@ -93,6 +94,12 @@ int main(int argc, char** argv) {
     const int P = head[0], M = head[1], D = head[2], W = head[3], H = head[4];
     const size_t n = (size_t)P, px = (size_t)W * H;
     if (gsr_abi_version() != GSR_ABI_VERSION) { fprintf(stderr, "ABI mismatch\n"); return 1; }
+    // an optional third argument "deterministic": gradient sums in a fixed order (GSR_OPT_BACKWARD_DETERMINISTIC) -- two runs, or this
+    // program and any other caller of the library on the same tensors, then produce the same bits
+    if (argc > 3 && strcmp(argv[3], "deterministic") == 0 && gsr_set_option(GSR_OPT_BACKWARD_DETERMINISTIC, 1) != GSR_OK) {
+        fprintf(stderr, "gsr_set_option: %s\n", gsr_last_error());
+        return 1;
+    }
     DeviceArray bg, xyz, ls, rot, op, dc, rest, view, proj, campos, g_color, g_normal;
     if (!load(f, bg, 3) || !load(f, xyz, 3 * n) || !load(f, ls, 3 * n) || !load(f, rot, 4 * n) || !load(f, op, n) || !load(f, dc, 3 * n) ||
         !load(f, rest, 3 * n * (size_t)(M - 1)) || !load(f, view, 16) || !load(f, proj, 16) || !load(f, campos, 3) ||

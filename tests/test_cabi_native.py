@@ -99,12 +99,15 @@ TRAIN_BIN = os.path.join(ROOT, "examples", "bin", "train_step_raw")
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["atomic", "deterministic"])
 @pytest.mark.parametrize("M", [16, 4])
-def test_native_raw_forward_and_backward_match_the_python_binding(tmp_path, M):
+def test_native_raw_forward_and_backward_match_the_python_binding(tmp_path, M, mode):
     """examples/train_step_raw.cpp: gsr_forward_raw (a full call with the normal image) + gsr_backward_raw (colour and normal
     gradients given, depth / alpha NULL) from plain C++ against the Python binding on the same raw tensors: the four images
-    and radii bit for bit, the seven gradient tensors within the tolerance of sums formed with atomics.  The program fills
-    every output with 0xFF first: an element the library did not write would come back as NaN."""
+    and radii bit for bit; the seven gradient tensors bit for bit with GSR_OPT_BACKWARD_DETERMINISTIC on both sides (two
+    processes, two allocators, same bits), and within 2e-4 of the array's scale in the default mode (sums of float atomics;
+    a well-conditioned scene).  The program fills every output with 0xFF first: an element the library did not write would
+    come back as NaN."""
     assert os.path.exists(TRAIN_BIN), "examples/bin/train_step_raw is not built: run __graft_entry__.build()"
     from diff_gaussian_rasterization import _C
     dev = "cuda:0"
@@ -125,7 +128,7 @@ def test_native_raw_forward_and_backward_match_the_python_binding(tmp_path, M):
         for t in (bg, raw["xyz"], raw["ls"], raw["rot"], raw["op"], raw["dc"], raw["rest"], cam.world_view_transform,
                   cam.full_proj_transform, cam.camera_center, g_color, g_normal):
             f.write(f32(t))
-    r = subprocess.run([TRAIN_BIN, model, out], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([TRAIN_BIN, model, out] + (["deterministic"] if mode == "deterministic" else []), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     blob = open(out, "rb").read()
     n = struct.unpack_from("<i", blob, 0)[0]
@@ -139,6 +142,8 @@ def test_native_raw_forward_and_backward_match_the_python_binding(tmp_path, M):
     t = lambda a: a.to(dev).contiguous()
     camd = cam.to(dev)
     args = (t(bg), t(raw["xyz"]), t(raw["ls"]), t(raw["rot"]), t(raw["op"]), t(raw["dc"]), t(raw["rest"]))
+    from autovfx_amd import _lib
+    _lib.set_option(_lib.OPT_BACKWARD_DETERMINISTIC, 1 if mode == "deterministic" else 0)
     with torch.no_grad():
         fw = _C.rasterize_gaussians_raw(*args, 1.0, camd.world_view_transform, camd.full_proj_transform, camd.tanfovx, camd.tanfovy, H, W,
                                         D, camd.camera_center, False, False, want_normal=True, inference=False)
@@ -146,11 +151,15 @@ def test_native_raw_forward_and_backward_match_the_python_binding(tmp_path, M):
                                                  camd.tanfovy, t(g_color), None, None, t(g_normal), D, camd.camera_center, fw[5], fw[0],
                                                  fw[6], fw[7], fw[3], False)
     torch.cuda.synchronize()
+    _lib.set_option(_lib.OPT_BACKWARD_DETERMINISTIC, 0)
     assert n == fw[0] > 0
     for k, want in (("color", fw[1]), ("depth", fw[2]), ("alpha", fw[3]), ("normal", fw[8]), ("radii", fw[4])):
         np.testing.assert_array_equal(got[k], want.cpu().numpy().reshape(-1), err_msg=k)
     for k, want in zip(("g_2d", "g_xyz", "g_ls", "g_rot", "g_op", "g_dc", "g_rest"), bw):
         a, b = got[k].astype(np.float64), want.cpu().numpy().reshape(-1).astype(np.float64)
         assert np.isfinite(a).all(), f"{k}: an element was not written"
-        assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max() + 1e-6, k
+        if mode == "deterministic":
+            np.testing.assert_array_equal(got[k].view(np.uint32), want.cpu().numpy().reshape(-1).view(np.uint32), err_msg=k)
+        else:
+            assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max() + 1e-6, k
     assert np.abs(got["g_rest"]).sum() > 0 if M > 1 else got["g_rest"].size == 0

@@ -7,7 +7,20 @@ import torch
 
 from autovfx_amd import scenes
 from autovfx_amd.cameras import orbit_cameras
-from oracle import ref_hip
+from oracle import cpu_oracle, ref_hip
+
+from helpers import assert_gradients_vs_truth, oracle_kwargs
+
+TRUTH_KEY = {"means3D": "dL_dmeans3D", "opacity": "dL_dopacity", "sh": "dL_dsh", "scales": "dL_dscales", "rotations": "dL_drotations",
+             "means2D": "dL_dmeans2D"}
+
+
+def truth_for(cloud, cam, bg, w_c, w_d, w_a, also_fp32=False):
+    """The fp64 gradient truth (and, on request, the CPU oracle's fp32 backward) for a scene that lives on the GPU."""
+    kw = oracle_kwargs(cloud.to("cpu"), cam.to("cpu"), bg=bg.cpu().numpy())
+    kw.update(dL_dcolor=w_c.cpu().numpy(), dL_ddepth=w_d.cpu().numpy(), dL_dalpha=w_a.cpu().numpy())
+    truth = cpu_oracle.backward_f64(**kw)
+    return (truth, cpu_oracle.backward(**kw)) if also_fp32 else truth
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref_hip.available(), reason="oracle/_ref/libgsr_ref_hip.so not built")]
 
@@ -66,12 +79,12 @@ def test_gradients_match_the_reference_on_this_gpu(case):
         leaves["means3D"], m2d, leaves["opacities"], shs=leaves["shs"], scales=leaves["scales"], rotations=leaves["rotations"])
     ((color * w_c).sum() + (depth * w_d).sum() + (alpha * w_a).sum()).backward()
     torch.cuda.synchronize()
-    pairs = {"means3D": leaves["means3D"].grad, "opacity": leaves["opacities"].grad, "sh": leaves["shs"].grad,
-             "scales": leaves["scales"].grad, "rotations": leaves["rotations"].grad, "means2D": m2d.grad}
-    for k, got in pairs.items():
-        want = ref[k].reshape(got.shape)
-        tol = 2e-4 * max(1e-6, float(want.abs().max()))
-        assert float((got - want).abs().max()) <= tol, (k, float((got - want).abs().max()), tol)
+    got = {"dL_dmeans3D": leaves["means3D"].grad, "dL_dopacity": leaves["opacities"].grad, "dL_dsh": leaves["shs"].grad,
+           "dL_dscales": leaves["scales"].grad, "dL_drotations": leaves["rotations"].grad, "dL_dmeans2D": m2d.grad}
+    got = {k: v.cpu().numpy() for k, v in got.items()}
+    ref32 = {TRUTH_KEY[k]: v.cpu().numpy().reshape(got[TRUTH_KEY[k]].shape) for k, v in ref.items() if k in TRUTH_KEY}
+    truth = truth_for(cloud, cam, bg, w_c, w_d, w_a)
+    assert_gradients_vs_truth("refhip:" + case, got, ref32, truth, tuple(got))
 
 
 @pytest.mark.parametrize("field", ["means3D", "scales", "rotations", "opacities", "shs"])
@@ -226,22 +239,15 @@ def test_wild_but_finite_gradients_match_the_reference_kernels(seed):
     P = cloud.P
     n_ref, c_ref, d_ref, a_ref, r_ref = ref_hip.forward(cloud, cam, bg)
     ref = ref_hip.backward(cloud, cam, bg, n_ref, r_ref, a_ref, w_c, w_d, w_a)
-    # How well conditioned is each Gaussian's gradient IN THE REFERENCE?  A needle 300 : 1 a quarter of a unit from the camera, or
-    # a splat with a radius of 1e5 pixels, has gradients that are differences of terms 1e3 - 1e8 times their size: fp32 returns
-    # noise there, and the reference's noise and this library's (whose per-pixel sums are factored differently,
-    # profiles/r04_backward_census.md section 2) are two different samples of it.  The yardstick: the reference's own answer
-    # after every position moved by ONE ulp (up, and down), plus a plain second run (its atomics add in arrival order); the bar
-    # of tests/test_backward_gpu.py widens by 32 times the largest of those, per Gaussian.  (scripts/experiments/wild_gradient_probe.py)
+    # How far may a gradient be from the reference's?  A needle 300 : 1 a quarter of a unit from the camera, or a splat with a
+    # radius of 1e5 pixels, has gradients that are differences of terms 1e3 - 1e8 times their size: fp32 returns noise there --
+    # the reference's own answer is up to TEN TIMES the scale of the array away from the gradient in these scenes (measured
+    # against the truth: dL_drotations of seed 2) -- and its noise and this library's are two samples of it.  The yardstick is the
+    # fp64 truth (oracle/gsr_oracle.c: gsro_backward_f64), with two fp32 samples of the reference next to it: its kernels on
+    # this GPU, twice (atomics in arrival order), and the CPU oracle (the same arithmetic in a fixed order).
     again = ref_hip.backward(cloud, cam, bg, n_ref, r_ref, a_ref, w_c, w_d, w_a)
-    from autovfx_amd.scenes import GaussianCloud
-    nudged = GaussianCloud(torch.nextafter(cloud.means3D, torch.full_like(cloud.means3D, float("inf"))), cloud.opacities, cloud.scales,
-                           cloud.rotations, cloud.shs, None, 3)
-    n_n, _c, _d, a_n, r_n = ref_hip.forward(nudged, cam, bg)
-    moved = ref_hip.backward(nudged, cam, bg, n_n, r_n, a_n, w_c, w_d, w_a)
-    nudged = GaussianCloud(torch.nextafter(cloud.means3D, torch.full_like(cloud.means3D, -float("inf"))), cloud.opacities, cloud.scales,
-                           cloud.rotations, cloud.shs, None, 3)
-    n_n, _c, _d, a_n, r_n = ref_hip.forward(nudged, cam, bg)
-    moved_down = ref_hip.backward(nudged, cam, bg, n_n, r_n, a_n, w_c, w_d, w_a)
+    truth, cpu32 = truth_for(cloud, cam, bg, w_c, w_d, w_a, also_fp32=True)
+    assert np.array_equal(cpu32["radii"], r_ref.cpu().numpy()), "the CPU oracle renders a different set of Gaussians: its truth is not this scene's"
     leaves = {k: getattr(cloud, k).clone().requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
     m2d = torch.zeros_like(leaves["means3D"], requires_grad=True)
     color, depth, alpha, radii = GaussianRasterizer(settings_for_camera(cam, bg, 3))(
@@ -253,15 +259,23 @@ def test_wild_but_finite_gradients_match_the_reference_kernels(seed):
              "scales": leaves["scales"].grad, "rotations": leaves["rotations"].grad, "means2D": m2d.grad}
     for k, got in pairs.items():
         want = ref[k].reshape(got.shape)
-        ok = torch.isfinite(want)
-        assert bool((torch.isfinite(got) == ok).all()), k + ": non-finite gradients in different places"
-        if bool(ok.any()):
-            spread = lambda other: torch.nan_to_num((other[k].reshape(got.shape) - want).abs(), nan=0.0, posinf=0.0, neginf=0.0).reshape(P, -1).amax(1)
-            noise = torch.maximum(torch.maximum(spread(again), spread(moved)), spread(moved_down))   # per Gaussian
-            tol = 2e-4 * max(1e-6, float(want[ok].abs().max())) + 32.0 * noise
-            err = torch.where(ok, (got - want).abs(), torch.zeros_like(got)).reshape(P, -1).amax(1)
-            over = err > tol
-            worst = int(torch.argmax(err - tol))
-            # (three samples of a noise do not bound a fourth: a straggler or two among the ill-conditioned ones is let through;
-            #  anything systematic shows up in hundreds of Gaussians)
-            assert int(over.sum()) <= 2, (k, int(over.sum()), worst, float(err[worst]), float(tol[worst]))
+        assert bool((torch.isfinite(got) == torch.isfinite(want)).all()), k + ": non-finite gradients in different places"
+    got = {TRUTH_KEY[k]: v.cpu().numpy() for k, v in pairs.items()}
+    ref32 = {TRUTH_KEY[k]: ref[k].cpu().numpy().reshape(got[TRUTH_KEY[k]].shape) for k in pairs}
+    # (i) every array, max norm, against the truth: the bar of tests/test_backward_gpu.py, no multipliers, no stragglers
+    assert_gradients_vs_truth(f"wild{seed}", got, ref32, truth, tuple(got))
+    # (ii) Gaussian by Gaussian: where the reference's three fp32 samples are all close to the truth this library must be too --
+    # the max norm of (i) is set by the scene's worst needle and would let a defect in the well-conditioned ones through.  A
+    # Gaussian's bar is 2e-4 of the array's scale + 4 x the furthest of the three samples from the truth; three samples do not
+    # bound a fourth, so up to 1 % of the Gaussians may exceed it -- (i) still bounds those.
+    for k, g in got.items():
+        t = truth[k].reshape(P, -1)
+        finite = np.isfinite(t).all(1) & np.isfinite(ref32[k].reshape(P, -1)).all(1) & np.isfinite(g.reshape(P, -1)).all(1)
+        if not finite.any():
+            continue
+        dist = lambda a: np.abs(np.nan_to_num(np.asarray(a, np.float64).reshape(P, -1) - t, nan=0.0, posinf=0.0, neginf=0.0)).max(1)
+        name = [r for r, tk in TRUTH_KEY.items() if tk == k][0]
+        noise = np.maximum(np.maximum(dist(ref32[k]), dist(again[name].cpu().numpy())), dist(cpu32[k]))
+        scale = float(np.abs(t[finite]).max())
+        over = finite & (dist(g) > 2e-4 * scale + 1e-6 + 4.0 * noise)
+        assert int(over.sum()) <= max(2, P // 100), (k, int(over.sum()), int(np.argmax(dist(g) - 4.0 * noise)))
