@@ -347,6 +347,45 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 } // extern "C"
 
 namespace {
+// GSR_OPT_BACKWARD_DETERMINISTIC takes 160 bytes per live pair for the duration of a call (1.4 GB at C3).  From the device's
+// default pool that memory goes back to the driver at every synchronisation (release threshold 0) and the next call maps it
+// again: 30 ms per call at C3, against 1.2 ms for the whole backward.  A pool of the library's own, one per device, that keeps
+// what it has been given (threshold = everything) makes the second call as cheap as a cached allocator's.
+constexpr int kMaxPoolDevices = 64;
+std::mutex g_det_pool_mutex;
+hipMemPool_t g_det_pool[kMaxPoolDevices] = {};
+bool g_det_pool_tried[kMaxPoolDevices] = {};
+
+hipError_t det_alloc(void** ptr, size_t bytes, hipStream_t stream) {
+    int dev = 0;
+    hipMemPool_t pool = nullptr;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxPoolDevices) {
+        std::lock_guard<std::mutex> lock(g_det_pool_mutex);
+        if (!g_det_pool_tried[dev]) {
+            g_det_pool_tried[dev] = true;
+            hipMemPoolProps props = {};
+            props.allocType = hipMemAllocationTypePinned;
+            props.handleTypes = hipMemHandleTypeNone;
+            props.location.type = hipMemLocationTypeDevice;
+            props.location.id = dev;
+            hipMemPool_t made = nullptr;
+            if (hipMemPoolCreate(&made, &props) == hipSuccess) {
+                uint64_t keep = UINT64_MAX;
+                if (hipMemPoolSetAttribute(made, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess) g_det_pool[dev] = made;
+                else (void)hipMemPoolDestroy(made);
+            }
+            (void)hipGetLastError();
+        }
+        pool = g_det_pool[dev];
+    }
+    if (pool != nullptr) {
+        const hipError_t e = hipMallocFromPoolAsync(ptr, bytes, pool, stream);
+        if (e == hipSuccess) return e;
+        (void)hipGetLastError();
+    }
+    return hipMallocAsync(ptr, bytes, stream);   // (a runtime without pools of one's own: the device's default pool)
+}
+
 // gsr_backward and gsr_backward_raw: `raw` != nullptr -> the parameter pointers are the model's raw tensors (raw->xyz in
 // means3D's place, and so on), dL_dsh_rest / dL_dpix_normal belong to that form.
 int backward_impl(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
@@ -443,7 +482,7 @@ int backward_impl(int P, int D, int M, int R, const float* background, int width
         const size_t off_tmp = dc.take<uint32_t>(gsr::radix_scratch_words(bound));
         const size_t off_part = dc.take<float>((size_t)bound * 40 * passes);
         char* draw = nullptr;
-        GSR_HIP(hipMallocAsync((void**)&draw, dc.total() + 256, stream));
+        GSR_HIP(det_alloc((void**)&draw, dc.total() + 256, stream));
         char* dbase = align_base(draw);
         int rc = GSR_OK;
         do {

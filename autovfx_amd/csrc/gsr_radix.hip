@@ -539,30 +539,40 @@ int g_rank_request = 2;
 int g_rank_verdict[kMaxDevices];      // 0 not tested yet, 1 passed (atomics), 2 failed (ballots), 3 could not be tested (ballots)
 unsigned long long g_rank_violations[kMaxDevices];
 
+int g_rank_attempts[kMaxDevices];      // self-tests that could not run (verdict 3) on this device so far
+constexpr int kMaxSelftestAttempts = 4;
+__device__ unsigned long long g_selftest_word;   // the self-test's mismatch counter: a device symbol, so the test allocates nothing
+
 int test_device_locked(int dev, hipStream_t caller) {
     // Never on the caller's stream: the test has its own, so the caller's queue is not drained and nothing is queued on a stream
-    // that may be recording a graph.  While the caller's stream IS capturing the test does not run at all (an allocation is not
-    // legal then): verdict 3, ballots for this sort, another try at the next one.
+    // that may be recording a graph.  While the caller's stream IS capturing the test does not run at all: verdict 3, ballots for
+    // this sort, another try at the next one.  No hipMalloc / hipFree (both synchronise the whole device; round 4 did both here):
+    // the counter is a device symbol.  What remains under the process-wide lock, once per device: a stream created and destroyed
+    // and a wait of a quarter of a millisecond on it.  A test that keeps failing to RUN (stream creation, a launch error) is given
+    // up after kMaxSelftestAttempts sorts -- ballots from then on -- instead of being repeated in front of every sort of every frame.
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
     if (caller != nullptr && (hipStreamIsCapturing(caller, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone)) {
         (void)hipGetLastError();
-        return 3;
+        return 3;   // (not counted as an attempt: capture ends)
     }
     unsigned long long* d_bad = nullptr;
     unsigned long long h_bad = ~0ull;
     int verdict = 3;
     hipStream_t own = nullptr;
-    if (hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) return 3;
-    if (hipMalloc((void**)&d_bad, sizeof *d_bad) == hipSuccess) {
+    if (hipGetSymbolAddress((void**)&d_bad, HIP_SYMBOL(g_selftest_word)) == hipSuccess &&
+        hipStreamCreateWithFlags(&own, hipStreamNonBlocking) == hipSuccess) {
         if (hipMemsetAsync(d_bad, 0, sizeof *d_bad, own) == hipSuccess &&
             launch_lds_atomic_order_selftest(512u, 192u, 0x6a09e667u, d_bad, own) == hipSuccess &&
             launch_lds_atomic_order_selftest(512u, 192u, 0xbb67ae85u, d_bad, own) == hipSuccess &&
             hipMemcpyAsync(&h_bad, d_bad, sizeof h_bad, hipMemcpyDeviceToHost, own) == hipSuccess &&
             hipStreamSynchronize(own) == hipSuccess)
             verdict = h_bad == 0ull ? 1 : 2;
-        (void)hipFree(d_bad);
+        (void)hipStreamDestroy(own);
     }
-    (void)hipStreamDestroy(own);
+    if (verdict == 3) {
+        (void)hipGetLastError();
+        if (++g_rank_attempts[dev] >= kMaxSelftestAttempts) verdict = 2;   // give up: ballots on this device for good
+    }
     g_rank_violations[dev] = h_bad;
     return verdict;
 }

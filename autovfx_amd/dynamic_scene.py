@@ -170,7 +170,9 @@ class DynamicScene:
                 else:
                     if subset is None:   # the whole object, untransformed
                         subset = torch.arange(o.P, dtype=torch.int32, device=self.device)
-                    self._keep_alive = getattr(self, "_keep_alive", [])[-8:] + [subset]   # (the kernel reads it after this call returns)
+                    # the kernel reads the list after this call returns, on THIS stream: tell the caching allocator, so that a list
+                    # built on another stream (or dropped by the caller right away) is not recycled under the pending kernel
+                    subset.record_stream(torch.cuda.current_stream(self.device))
                     rc = _lib.lib.gsr_place_object_subset(count, subset.data_ptr(), o.xyz.data_ptr(), o.rotation.data_ptr(),
                                                           o.log_scale.data_ptr(), o.opacity.data_ptr(), o.shs.data_ptr(), self.M,
                                                           None if block is None else ctypes.byref(block), *outs)
@@ -188,10 +190,21 @@ class DynamicScene:
             if t.numel() != n:
                 raise ValueError(f"subset mask has {t.numel()} entries, the object {n} Gaussians")
             t = torch.nonzero(t.reshape(-1), as_tuple=False).reshape(-1)   # (a GPU mask costs one host read here: its count sizes the frame)
-        elif not t.is_cuda and t.numel() and (int(t.min()) < 0 or int(t.max()) >= n):
-            raise ValueError("subset indices out of range")
-        # (an index list that already lives on the GPU is taken as is -- checking it would read it back every frame; the fast
-        # path for a caller that matched meshes once and keeps the per-frame lists resident)
+        elif t.numel():
+            # An index >= n (or a negative one, a huge offset once cast to uint32) would be an out-of-bounds device read in
+            # gsr_place_object_subset.  Host lists are checked here every time; a list that already lives on the GPU -- the fast path
+            # of a caller that matched meshes once and keeps the per-frame lists resident -- is checked ONCE (one host read of its
+            # min and max) and remembered by (storage address, length, version counter): the frames after the first pay nothing,
+            # and an in-place edit or a new tensor is checked again.
+            key = (t.data_ptr(), t.numel(), t._version, int(n)) if t.is_cuda else None
+            seen = self.__dict__.setdefault("_checked_subsets", {})
+            if key is None or key not in seen:
+                if int(t.min()) < 0 or int(t.max()) >= n:
+                    raise ValueError("subset indices out of range")
+                if key is not None:
+                    if len(seen) >= 4096:
+                        seen.clear()
+                    seen[key] = True
         return t.to(device=self.device, dtype=torch.int32).contiguous()
 
     def compose_model(self, placements, slot: int = 0) -> FrameModel:

@@ -39,6 +39,8 @@ _REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _TARGET_LEAF = "gaussian_renderer"
 _installed: Optional["_RendererHook"] = None
 patched_modules: List[str] = []          # names of the modules whose ``render`` was replaced (introspection / tests)
+_strict = True                           # install(strict=...): may a failure to load the render path break the importing process?
+_gave_up = False                         # lenient mode: the render path could not be loaded once; do not try again
 
 
 def _is_target(fullname: str) -> bool:
@@ -51,10 +53,25 @@ def _our_render() -> Callable:
 
 
 def _patch_renderer_module(module: types.ModuleType) -> None:
+    global _gave_up
     original = module.__dict__.get("render")
-    if original is None or getattr(original, "__module__", "").startswith("autovfx_amd"):
+    if original is None or (getattr(original, "__module__", None) or "").startswith("autovfx_amd"):
         return
-    ours = _our_render()
+    if _gave_up:
+        return
+    try:
+        ours = _our_render()
+    except Exception as e:   # torch absent, libgsr_hip.so not built / stale ABI, a GPU-less helper that inherited the environment
+        if _strict:
+            raise
+        # The start-up hook (integration/sitecustomize.py) promised never to break the process: the reference's own render() stays
+        # in place.  That is not a quiet fallback for rendering -- the reference's render() imports ``diff_gaussian_rasterization``,
+        # which is this repository's package and raises when the HIP library cannot be loaded -- it only lets a process that imports
+        # the renderer module without ever rendering (a data-preparation helper on a machine without a GPU) live.
+        _gave_up = True
+        sys.stderr.write(f"[autovfx_amd] {module.__name__}.render left as the reference's: the MI355X render path could not be loaded "
+                         f"({e!r}); not retried in this process\n")
+        return
     module.reference_render = original
     module.render = ours
     if module.__name__ not in patched_modules:
@@ -101,9 +118,16 @@ class _RendererHook(importlib.abc.MetaPathFinder):
         return None
 
 
-def install(path: bool = True) -> None:
-    """Idempotent.  ``path=False`` leaves ``sys.path`` alone (the caller arranged for ``diff_gaussian_rasterization``)."""
-    global _installed
+def install(path: bool = True, strict: bool = True) -> None:
+    """Idempotent.  ``path=False`` leaves ``sys.path`` alone (the caller arranged for ``diff_gaussian_rasterization``).
+    ``strict`` (default): a render path that cannot be loaded -- no torch, libgsr_hip.so missing or of another ABI -- raises from
+    the import of the renderer module, loudly, where it happens.  ``strict=False`` is for the interpreter start-up hook
+    (integration/sitecustomize.py: every Python process of the machine runs it): one line on stderr, the module keeps the
+    reference's ``render``, no second attempt in that process."""
+    global _installed, _strict, _gave_up
+    _strict = bool(strict)
+    if strict:
+        _gave_up = False
     if path and (not sys.path or sys.path[0] != _REPO_ROOT):
         if _REPO_ROOT in sys.path:
             sys.path.remove(_REPO_ROOT)
@@ -123,10 +147,11 @@ def install(path: bool = True) -> None:
 def uninstall() -> None:
     """Remove the import hook and put the reference's ``render`` back into the modules ``install`` patched (importers that
     were rebound keep what they hold; meant for tests)."""
-    global _installed
+    global _installed, _strict, _gave_up
     if _installed is not None and _installed in sys.meta_path:
         sys.meta_path.remove(_installed)
     _installed = None
+    _strict, _gave_up = True, False
     for name in list(patched_modules):
         module = sys.modules.get(name)
         if module is not None and hasattr(module, "reference_render"):

@@ -48,6 +48,28 @@ RAW_PARAMETERS = True
 _RAW_ATTRS = ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest")
 _RAW_ACTIVATIONS = (("scaling_activation", torch.exp), ("opacity_activation", torch.sigmoid),
                     ("rotation_activation", torch.nn.functional.normalize))
+_GETTERS = ("get_xyz", "get_scaling", "get_rotation", "get_opacity", "get_features", "get_normal")
+_getters_verdict: dict = {}   # type -> bool
+
+
+def _getters_are_one_class_s(cls) -> bool:
+    """A subclass or wrapper that overrides ONE of the getters ``render()`` would otherwise call (a masked opacity, a transformed
+    xyz, its own get_normal) while keeping the raw attributes must not be rendered from the raw tensors: that would bypass the
+    override without a word.  The raw path is taken only when all six getters come from ONE class of the model's MRO -- the class
+    that defines the model (the reference's GaussianModel, this package's, a test double) -- i.e. none of them was overridden
+    further down.  A model that overrides them all and still wants the raw path says so with ``gsr_raw_parameters = True`` on its
+    class; one that wants out says ``False``.  (Cached per type.)"""
+    v = _getters_verdict.get(cls)
+    if v is None:
+        owners = set()
+        for name in _GETTERS:
+            owner = next((c for c in cls.__mro__ if name in c.__dict__), None)
+            if owner is None:
+                continue          # (a model without get_normal renders no normals anyway: the getter is simply never called)
+            owners.add(owner)
+        v = len(owners) <= 1
+        _getters_verdict[cls] = v
+    return v
 
 
 # True: with autograd ON such a model is rendered by ONE full rasterizer call from the raw tensors as well (colour + normal
@@ -94,9 +116,12 @@ class _RasterizeRaw(torch.autograd.Function):
 def raw_parameters(pc):
     """The six raw tensors of ``pc`` when rendering from them is the same as rendering through its getters, else None:
     all six attributes are float32 tensors on one GPU with consistent shapes, and the model's activation functions -- the
-    reference keeps them as attributes (``setup_functions``, ``scene/gaussian_model.py:25-45``) -- are the stock ones.  A
-    model can opt out with ``pc.gsr_raw_parameters = False`` (e.g. a subclass that overrides a getter)."""
+    reference keeps them as attributes (``setup_functions``, ``scene/gaussian_model.py:25-45``) -- are the stock ones, and no
+    subclass overrode one of the getters the raw path would bypass (``_getters_are_one_class_s``).  A model can opt out with
+    ``pc.gsr_raw_parameters = False``."""
     if not getattr(pc, "gsr_raw_parameters", True):
+        return None
+    if "gsr_raw_parameters" not in type(pc).__dict__ and not _getters_are_one_class_s(type(pc)):
         return None
     try:
         t = tuple(getattr(pc, a) for a in _RAW_ATTRS)

@@ -461,8 +461,8 @@ typedef enum gsr_option {
      * in GSR_OPT_RADIX_RANK_FALLBACKS.  2 (default): as 1 on a device that passed gsr_selftest_lds_atomic_order's kernel
      * (~0.4 M instructions of every conflict density, run by the first sort on each device after the request), plain ballots
      * on a device that failed it (there every tile would pay for both); the test runs on a stream of its own (the caller's is
-     * neither drained nor used) and the host waits a quarter of a millisecond for it, once per device, under a process-wide
-     * lock; while the caller's stream is capturing a graph it does not run and that sort uses ballots (a test that could not
+     * neither drained nor used; nothing is allocated or freed) and the host waits a quarter of a millisecond for it, once per
+     * device, under a process-wide lock; a test that cannot run at all is given up after four sorts (ballots from then on); while the caller's stream is capturing a graph it does not run and that sort uses ballots (a test that could not
      * run is retried by the next sort; gsr_get_option(GSR_OPT_RADIX_RANK_ACTIVE) at start-up gets it out of the way).  3: as 1 with an inversion injected into every wave -- a test hook for the check and the repair.
      * Verified LDS adds are ~20 % faster per pass than ballots: ~3 % of a single-stream 3 M-Gaussian frame. */
     GSR_OPT_RADIX_RANK = 5,

@@ -25,6 +25,6 @@ _chain()
 if os.environ.get("AUTOVFX_AMD_INSTALL", "") == "1":
     try:
         import autovfx_amd.hook as _install
-        _install.install()
+        _install.install(strict=False)   # a render path that cannot be loaded later costs one stderr line, not the process
     except Exception as e:   # never break interpreter start-up; the process then runs the reference's own path
         sys.stderr.write(f"[autovfx_amd] AUTOVFX_AMD_INSTALL=1 but install() failed: {e!r}\n")

@@ -198,11 +198,12 @@ def backward_f64(*, means3D, opacities, bg, width, height, viewmatrix, projmatri
                  dL_dcolor, dL_ddepth, dL_dalpha, sh_degree=0, scale_modifier=1.0, shs=None, colors_precomp=None,
                  scales=None, rotations=None, cov3D_precomp=None) -> Dict[str, np.ndarray]:
     """The gradient TRUTH (gsr_oracle.c: gsro_backward_f64): the reference's backward formulas evaluated in double on
-    the fp32 forward state.  Same keys as ``backward`` for the gradients, all float64."""
+    the fp32 forward state.  Same keys as ``backward`` for the gradients, all float64; plus ``abs_sums`` [P,10] (the sums of
+    |term| behind the ten per-Gaussian sums of the per-pixel pass, see ``fp32_noise``) and ``radii``."""
     L = lib()
     if not getattr(L, "_bw64_ready", False):
         L.gsro_backward_f64.restype = ctypes.c_int64
-        L.gsro_backward_f64.argtypes = _backward_argtypes()[:22] + [_D] * 10
+        L.gsro_backward_f64.argtypes = _backward_argtypes()[:22] + [_D] * 11 + [_I32]
         L._bw64_ready = True
     m = _f32(means3D)
     P = 0 if m is None else int(m.shape[0])
@@ -211,7 +212,8 @@ def backward_f64(*, means3D, opacities, bg, width, height, viewmatrix, projmatri
     M = 0 if sh is None else int(sh.shape[1])
     z = lambda *s: np.zeros(s, np.float64)
     out = {"dL_dmeans2D": z(P, 3), "dL_dcolors": z(P, 3), "dL_dopacity": z(P, 1), "dL_dmeans3D": z(P, 3), "dL_dcov3D": z(P, 6),
-           "dL_dsh": z(P, M, 3), "dL_dscales": z(P, 3), "dL_drotations": z(P, 4), "dL_dconic": z(P, 4), "dL_ddepths": z(P, 1)}
+           "dL_dsh": z(P, M, 3), "dL_dscales": z(P, 3), "dL_drotations": z(P, 4), "dL_dconic": z(P, 4), "dL_ddepths": z(P, 1),
+           "abs_sums": z(P, 10), "radii": np.zeros(P, np.int32)}
     if P == 0:
         return out
     op, bgv, vm, pm, cp = _f32(opacities), _f32(bg), _f32(viewmatrix), _f32(projmatrix), _f32(campos)
@@ -228,5 +230,60 @@ def backward_f64(*, means3D, opacities, bg, width, height, viewmatrix, projmatri
                         _ptr(out["dL_dmeans2D"], _D), _ptr(out["dL_dcolors"], _D), _ptr(out["dL_dopacity"], _D),
                         _ptr(out["dL_dmeans3D"], _D), _ptr(out["dL_dcov3D"], _D), _ptr(out["dL_dsh"], _D),
                         _ptr(out["dL_dscales"], _D), _ptr(out["dL_drotations"], _D), _ptr(out["dL_dconic"], _D),
-                        _ptr(out["dL_ddepths"], _D))
+                        _ptr(out["dL_ddepths"], _D), _ptr(out["abs_sums"], _D), _ptr(out["radii"], _I32))
     return out
+
+
+def fp32_noise(truth: Dict[str, np.ndarray], *, means3D, width, height, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
+               sh_degree=0, scale_modifier=1.0, shs=None, scales=None, rotations=None, cov3D_precomp=None, samples: int = 8,
+               ulps: float = 2.0, seed: int = 0, **_unused) -> Dict[str, np.ndarray]:
+    """How far may an fp32 evaluation of a gradient be from the truth?  A conditioning-aware yardstick, per element.
+
+    Every fp32 backward forms the ten per-Gaussian sums of the per-pixel pass with rounding errors: each term carries a few
+    relative roundings and the additions round again, so a sum S = sum t_i comes out as S + e with |e| of the order of
+    2^-24 * sum |t_i| -- NOT 2^-24 * |S| when the terms cancel.  The per-Gaussian chain (backward.cu:144-413) then maps the sums
+    to the parameter gradients, and for a needle or a splat at the near plane it amplifies e by 1e3 .. 1e8.  This function
+    draws ``samples`` such error vectors (e = +-ulps * 2^-24 * sum |t_i| with random signs, fixed seed; ``abs_sums`` from
+    ``backward_f64``), rounds the perturbed sums to fp32, runs the REFERENCE's fp32 chain on them (gsro_preprocess_backward,
+    backward.cu's arithmetic op for op) and returns, per gradient array, the largest |result - truth| seen per element.  It is a
+    pure function of the scene: the same yardstick on every box."""
+    L = lib()
+    if not getattr(L, "_pb_ready", False):
+        L.gsro_preprocess_backward.restype = None
+        L.gsro_preprocess_backward.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, _F, _I32, _F, _F, _F, ctypes.c_float, _F, _F, _F, _F,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, _F, _F, _F, _F, _F, _F, _F, _F, _F]
+        L._pb_ready = True
+    m = _f32(means3D)
+    P = 0 if m is None else int(m.shape[0])
+    sh, sc, rot, cov = _f32(shs), _f32(scales), _f32(rotations), _f32(cov3D_precomp)
+    M = 0 if sh is None else int(sh.shape[1])
+    vm, pm, cp = _f32(viewmatrix), _f32(projmatrix), _f32(campos)
+    keys = ("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
+    worst = {k: np.zeros(truth[k].shape, np.float64) for k in keys}
+    if P == 0:
+        return worst
+    A = truth["abs_sums"]
+    rng = np.random.default_rng(seed)
+    eps = ulps * 2.0 ** -24
+    radii = np.ascontiguousarray(truth["radii"], np.int32)
+    for _ in range(samples):
+        sign = rng.integers(0, 2, size=(P, 10)).astype(np.float64) * 2.0 - 1.0
+        e = sign * eps * A
+        g2 = np.zeros((P, 3), np.float32); g2[:, :2] = truth["dL_dmeans2D"][:, :2] + e[:, 0:2]
+        gcn = np.zeros((P, 4), np.float32); gcn[:, (0, 1, 3)] = truth["dL_dconic"][:, (0, 1, 3)] + e[:, 2:5]
+        gop = np.ascontiguousarray(truth["dL_dopacity"].reshape(P) + e[:, 5], np.float32)
+        gcol = np.ascontiguousarray(truth["dL_dcolors"] + e[:, 6:9], np.float32)
+        gdep = np.ascontiguousarray(truth["dL_ddepths"].reshape(P) + e[:, 9], np.float32)
+        o = {"dL_dmeans3D": np.zeros((P, 3), np.float32), "dL_dcov3D": np.zeros((P, 6), np.float32),
+             "dL_dsh": np.zeros((P, M, 3), np.float32), "dL_dscales": np.zeros((P, 3), np.float32), "dL_drotations": np.zeros((P, 4), np.float32)}
+        L.gsro_preprocess_backward(P, int(sh_degree), M, _ptr(m, _F), _ptr(radii, _I32), _ptr(sh, _F), _ptr(sc, _F), _ptr(rot, _F),
+                                   float(scale_modifier), _ptr(cov, _F), _ptr(vm, _F), _ptr(pm, _F), _ptr(cp, _F), int(width), int(height),
+                                   float(tanfovx), float(tanfovy), _ptr(g2, _F), _ptr(gcn, _F), _ptr(gcol, _F), _ptr(gdep, _F),
+                                   _ptr(o["dL_dmeans3D"], _F), _ptr(o["dL_dcov3D"], _F), _ptr(o["dL_dsh"] if M else None, _F),
+                                   _ptr(o["dL_dscales"], _F), _ptr(o["dL_drotations"], _F))
+        o["dL_dmeans2D"], o["dL_dopacity"], o["dL_dcolors"] = g2, gop.reshape(P, 1), gcol
+        for k in keys:
+            with np.errstate(invalid="ignore", over="ignore"):
+                d = np.abs(o[k].astype(np.float64).reshape(truth[k].shape) - truth[k])
+            worst[k] = np.fmax(worst[k], np.nan_to_num(d, nan=0.0, posinf=0.0))
+    return worst

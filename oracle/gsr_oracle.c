@@ -825,7 +825,8 @@ static void f64_render_backward(int W, int H, const uint32_t* ranges, const uint
                                 const float* means2D, const float* conic_opacity, const float* colors, const float* depths,
                                 const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
                                 const float* dL_dpix_alpha, double* dL_dmean2D /*[P,3]*/, double* dL_dconic /*[P,4]*/,
-                                double* dL_dopacity, double* dL_dcolors /*[P,3]*/, double* dL_ddepths) {
+                                double* dL_dopacity, double* dL_dcolors /*[P,3]*/, double* dL_ddepths,
+                                double* abs_sums /*nullable [P,10]: sum of |term| behind mean2D x y, conic xx xy yy, opacity, r g b, depth*/) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const double ddelx_dx = 0.5 * W, ddely_dy = 0.5 * H;
 #pragma omp parallel
@@ -923,6 +924,15 @@ static void f64_render_backward(int W, int H, const uint32_t* ranges, const uint
                         dL_dconic[4 * (size_t)g + 3] += k3;
 #pragma omp atomic
                         dL_dopacity[g] += vo;
+                        if (abs_sums) {
+                            const double av[10] = {fabs(v0), fabs(v1), fabs(k0), fabs(k1), fabs(k3), fabs(vo),
+                                                   fabs(dchannel_dcolor * dLp[0]), fabs(dchannel_dcolor * dLp[1]),
+                                                   fabs(dchannel_dcolor * dLp[2]), fabs(vd)};
+                            for (int q = 0; q < 10; ++q) {
+#pragma omp atomic
+                                abs_sums[10 * (size_t)g + q] += av[q];
+                            }
+                        }
                     }
                 }
             }
@@ -1120,7 +1130,8 @@ int64_t gsro_backward_f64(int P, int deg, int M, const float* bg, int W, int H, 
                           const float* cov3D_pre, const float* view, const float* proj, const float* cam, float tanx, float tany,
                           const float* dL_dout_color, const float* dL_dout_depth, const float* dL_dout_alpha,
                           double* dL_dmeans2D, double* dL_dcolors, double* dL_dopacity, double* dL_dmeans3D, double* dL_dcov3D,
-                          double* dL_dsh, double* dL_dscales, double* dL_drots, double* dL_dconic, double* dL_ddepths) {
+                          double* dL_dsh, double* dL_dscales, double* dL_drots, double* dL_dconic, double* dL_ddepths,
+                          double* abs_sums /*nullable [P,10], zero-filled: see f64_render_backward*/, int* radii_out /*nullable [P]*/) {
     if (P == 0) return 0;
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, T = gx * gy;
     const size_t n = (size_t)P, npx = (size_t)W * H;
@@ -1147,7 +1158,8 @@ int64_t gsro_backward_f64(int P, int deg, int M, const float* bg, int W, int H, 
     const float* feat = colors_pre ? colors_pre : rgb;
     gsro_blend(W, H, ranges, vals, means2D, feat, depths, conop, bg, img, img + 3 * npx, img + 4 * npx, ncontrib);
     f64_render_backward(W, H, ranges, vals, bg, means2D, conop, feat, depths, ncontrib, dL_dout_color, dL_dout_depth,
-                        dL_dout_alpha, dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors, dL_ddepths);
+                        dL_dout_alpha, dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors, dL_ddepths, abs_sums);
+    if (radii_out) memcpy(radii_out, radii, n * sizeof(int));
     f64_preprocess_backward(P, deg, M, means3D, radii, shs, clamped, scales, rots, mod, cov3D_pre ? cov3D_pre : cov3D, view, proj,
                             cam, W, H, tanx, tany, dL_dmeans2D, dL_dconic, dL_dcolors, dL_ddepths, dL_dmeans3D, dL_dcov3D, dL_dsh,
                             dL_dscales, dL_drots);

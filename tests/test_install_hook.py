@@ -91,6 +91,41 @@ def test_sitecustomize_opt_in(fake_autovfx):
     assert on.returncode == 0 and on.stdout.split() == ["autovfx_amd.renderer", "False"], on.stderr
 
 
+def test_start_up_hook_survives_a_render_path_that_cannot_be_loaded(fake_autovfx):
+    """under AUTOVFX_AMD_INSTALL=1 every Python process of the machine runs the hook; one in which this package's
+    render path cannot be imported (here: no torch -- the HIP library itself is only opened at the first render call, which then
+    fails loudly) must still be able to IMPORT the reference's renderer module -- one stderr line, ``render`` stays the
+    reference's, no retry at the next import.  An explicit ``autovfx_amd.install()`` stays strict: the same situation raises at
+    the import."""
+    code = textwrap.dedent("""
+        import sys
+        sys.modules['torch'] = None          # "import torch" raises from here on
+        from sugar.gaussian_splatting.gaussian_renderer import render
+        import gaussian_renderer
+        print(render.__module__, gaussian_renderer.render.__module__)
+    """)
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "integration"), ROOT, str(fake_autovfx),
+                                                       str(fake_autovfx / "sugar" / "gaussian_splatting")]),
+               GSR_LIB="/nonexistent/libgsr_hip.so", AUTOVFX_AMD_INSTALL="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split() == ["sugar.gaussian_splatting.gaussian_renderer", "gaussian_renderer"]
+    assert r.stderr.count("could not be loaded") == 1, r.stderr       # said once, not per module
+    strict = textwrap.dedent("""
+        import sys
+        import autovfx_amd
+        autovfx_amd.install()
+        sys.modules['torch'] = None
+        try:
+            from sugar.gaussian_splatting.gaussian_renderer import render
+        except Exception as e:
+            print("raised", type(e).__name__)
+    """)
+    env.pop("AUTOVFX_AMD_INSTALL")
+    r = subprocess.run([sys.executable, "-c", strict], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.split()[0] == "raised", (r.stdout, r.stderr)
+
+
 class _Model:
     def __init__(self, P=5, M=16, device="cpu"):
         self._xyz = torch.zeros(P, 3, device=device)
@@ -127,6 +162,35 @@ def test_raw_parameter_gate(monkeypatch):
 
 
 @pytest.mark.skipif(not os.path.isdir(GS), reason="reference tree not mounted")
+def test_a_subclass_that_overrides_one_getter_is_not_rendered_from_its_raw_tensors(monkeypatch):
+    """render() on the raw path calls no getter; a subclass with, say, a masked ``get_opacity`` would be rendered
+    (and differentiated) from ``_opacity`` as if the override were not there.  The gate sends such a model down the getters path."""
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))   # (the gate wants GPU tensors; none is touched)
+    from test_raw_gpu import ReferenceShapedModel
+    z = lambda *s: torch.zeros(*s)
+    args = (3, z(5, 3), z(5, 3), torch.ones(5, 4), z(5, 1), z(5, 1, 3), z(5, 15, 3))
+    stock = ReferenceShapedModel(*args)
+    assert renderer.raw_parameters(stock) is not None
+
+    class Masked(ReferenceShapedModel):
+        @property
+        def get_opacity(self):
+            return torch.sigmoid(self._opacity) * 0.5
+
+    assert renderer.raw_parameters(Masked(*args)) is None
+
+    class Plain(ReferenceShapedModel):       # a subclass that adds things but leaves the getters alone keeps the raw path
+        def extra(self):
+            return 1
+
+    assert renderer.raw_parameters(Plain(*args)) is not None
+
+    class Insists(Masked):
+        gsr_raw_parameters = True
+
+    assert renderer.raw_parameters(Insists(*args)) is not None
+
+
 def test_the_references_own_gaussian_model_passes_the_gate(monkeypatch):
     """The class AutoVFX instantiates (scene/gaussian_model.py), imported unchanged: its attribute names, shapes and
     activation functions are what raw_parameters() looks for."""
