@@ -66,17 +66,21 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, trace: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, trace: bool = False, unfused: bool = False) -> str:
     """``trace=True`` builds libgsr_hip_trace.so: the same library with per-workgroup phase timestamps compiled
-    into selected kernels (GSR_KERNEL_TRACE; see scripts/kernel_trace.py).  A profiling aid, never the default."""
+    into selected kernels (GSR_KERNEL_TRACE; see scripts/kernel_trace.py).  A profiling aid, never the default.
+    ``unfused=True`` builds libgsr_hip_unfused.so: the blend's one fused multiply-add written as the reference's sources say it
+    (GSR_UNFUSED_BLEND, gsr_blend.hip) -- a TEST build whose images must equal the reference kernels' bit for bit."""
     os.makedirs(OUT_DIR, exist_ok=True)
     cc = hipcc()
     objs, jobs = [], []
-    lib = LIB.replace(".so", "_trace.so") if trace else LIB
-    flags = FLAGS + (["-DGSR_KERNEL_TRACE=1"] if trace else [])
+    tag = "_trace" if trace else "_unfused" if unfused else ""
+    lib = LIB.replace(".so", tag + ".so")
+    flags = FLAGS + (["-DGSR_KERNEL_TRACE=1"] if trace else []) + (["-DGSR_UNFUSED_BLEND=1"] if unfused else [])
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
-        obj = os.path.join(OUT_DIR, src.replace(".hip", "_trace.o" if trace else ".o"))
+        # (only the blend differs in the unfused build: the other units' objects are shared with the product's)
+        obj = os.path.join(OUT_DIR, src.replace(".hip", (tag if trace or src == "gsr_blend.hip" else "") + ".o"))
         objs.append(obj)
         if force or _stale(obj, [sp] + HEADERS + [__file__]):
             jobs.append([cc, "-x", "hip", *flags, *FILE_FLAGS.get(src, []), "-c", sp, "-o", obj])
@@ -96,4 +100,4 @@ def build(force: bool = False, verbose: bool = False, trace: bool = False) -> st
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, trace="--trace" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose=True, trace="--trace" in sys.argv, unfused="--unfused" in sys.argv))

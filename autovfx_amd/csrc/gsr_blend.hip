@@ -50,14 +50,28 @@ namespace {
 // full-rate fused instruction in place of a multiply and an add.  This library is otherwise built without
 // contraction; this is the one place it is written out, because it is on the per-pair-per-pixel path and touches
 // only the float images (transmittance, the stopping rule and every integer output do not depend on it).
+//
+// GSR_UNFUSED_BLEND (python -m autovfx_amd.build --unfused -> lib/libgsr_hip_unfused.so, a TEST build): the same line as the
+// reference's sources say it when compiled without contraction -- multiply, multiply, add.  The reference's own kernels
+// compiled for gfx950 with -ffp-contract=off (oracle/_ref/libgsr_ref_hip.so) then produce the SAME BITS in every image, which
+// turns the image tolerance of the parity tests into an equality once per suite run (tests/test_parity_gpu.py:
+// test_unfused_blend_build_equals_the_reference_kernels_bit_for_bit).
 __device__ __forceinline__ float composite(float C, float feature, float alpha, float T) {
+#ifdef GSR_UNFUSED_BLEND
+    return C + (feature * alpha) * T;
+#else
     return __builtin_fmaf(feature * alpha, T, C);
+#endif
 }
 // Two channels at once: v_pk_mul_f32 + v_pk_fma_f32, written with a vector type so that the pairing does not depend
 // on what the SLP vectorizer decides.  Same roundings as two calls of composite().
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f composite2(v2f C, v2f feature, float alpha, float T) {
+#ifdef GSR_UNFUSED_BLEND
+    return C + (feature * alpha) * (v2f){T, T};
+#else
     return __builtin_elementwise_fma(feature * alpha, (v2f){T, T}, C);
+#endif
 }
 
 __global__ void exp_selftest_kernel(uint32_t first_bits, uint32_t count, unsigned long long* mismatches) {

@@ -10,7 +10,9 @@ Bars (stated once, used everywhere below):
   * images -- RGB and alpha: max-abs <= 1e-4; depth: <= 1e-4 * max(1, max depth).  The blend uses
     the device expf, which may differ from glibc's by an ulp; at the two discontinuities
     (alpha < 1/255, T(1-alpha) < 1e-4) that can flip a contribution, so a flip census is reported
-    and bounded instead of hidden: at most FLIP_PPM pixels per million may exceed the tolerance.
+    and bounded instead of hidden: at most FLIP_PPM pixels per million may exceed the tolerance in the adversarial scenes; the
+    BASELINE configurations C1 - C3 allow NONE (C4: two pixels, one seen), and the unfused test build is compared with the
+    reference's kernels on this GPU for equality.
 Every test appends its numbers to gpurun_out/parity_report.jsonl.
 """
 import json
@@ -58,10 +60,12 @@ def image_census(name, got, ref):
     return stats
 
 
-def assert_images(name, got, ref, allow_flips=True):
+def assert_images(name, got, ref, allow_flips=True, budget_px=None):
+    """``budget_px``: how many pixels may exceed 1e-4 (None: FLIP_PPM per million, the allowance of the adversarial scenes; the
+    BASELINE configurations pass 0 -- north_star's "within 1e-4 max-abs" without a census)."""
     st = image_census(name, got, ref)
     npx = st["pixels"]
-    budget = int(np.ceil(FLIP_PPM * 1e-6 * npx)) if allow_flips else 0
+    budget = budget_px if budget_px is not None else int(np.ceil(FLIP_PPM * 1e-6 * npx)) if allow_flips else 0
     for key in ("color", "alpha", "depth"):
         assert st[key + "_bad_px"] <= budget, f"{name}: {key} exceeds tolerance on {st[key + '_bad_px']} px (budget {budget}): {st}"
     return st
@@ -130,18 +134,20 @@ def assert_culled_lists(name, on, ref, W, H):
     return kept, dropped
 
 
-def run_both(name, cloud, cam, stage=True, **kw):
+def run_both(name, cloud, cam, stage=True, budget_px=None, **kw):
     ref = cpu_oracle.forward(intermediates=True, **oracle_kwargs(cloud, cam, **kw))
     if cloud.colors_precomp is None:
         ref["rgb_used"] = True
     hip = hip_forward_raw(cloud, cam, cull=False, **kw)        # the reference's lists, exactly
     if stage:
         assert_stage_parity(name, hip, ref)
-    st = assert_images(name, hip, ref)
-    # n_contrib may differ only where a threshold flip happened
+    st = assert_images(name, hip, ref, budget_px=budget_px)
+    # n_contrib may differ only where a threshold flip happened (a pixel whose alpha sits on 1/255 or whose T sits on 1e-4 under the
+    # CPU's expf and not under the GPU's; with a zero image budget at most a handful of such pixels, all inside 1e-4 in the images)
     nc_bad = int((hip["n_contrib"] != ref["n_contrib"]).sum())
     report(name + ":n_contrib", mismatched=nc_bad)
-    assert nc_bad <= int(np.ceil(FLIP_PPM * 1e-6 * ref["n_contrib"].size)) + st["color_bad_px"]
+    nc_budget = int(np.ceil(FLIP_PPM * 1e-6 * ref["n_contrib"].size)) if budget_px is None else max(4, 4 * budget_px)
+    assert nc_bad <= nc_budget + st["color_bad_px"]
     # default mode (exact-image tile culling): same images bit for bit, same public outputs, thinner lists
     on = hip_forward_raw(cloud, cam, cull=True, **kw)
     for k in ("color", "depth", "alpha", "radii"):
@@ -165,7 +171,7 @@ def run_both(name, cloud, cam, stage=True, **kw):
 
 def test_c1_every_stage():
     """BASELINE config C1: 10k Gaussians, 256x256, SH degree 3."""
-    run_both("c1", scenes.config_c1(), scenes.c1_camera(), bg=(0.1, 0.2, 0.3))
+    run_both("c1", scenes.config_c1(), scenes.c1_camera(), budget_px=0, bg=(0.1, 0.2, 0.3))
 
 
 @pytest.mark.parametrize("deg", [0, 1, 2, 3, 4])
@@ -935,7 +941,7 @@ def test_c2_full_frames_vs_oracle(frame):
     bit-exact against the oracle, images within 1e-4 with the flip census; tile culling on/off bit-identical."""
     cloud = scenes.config_c2()
     cam = orbit_cameras(200, 960, 540)[frame]
-    hip, ref = run_both(f"c2_full_f{frame}", cloud, cam)
+    hip, ref = run_both(f"c2_full_f{frame}", cloud, cam, budget_px=0)   # north_star: RGB within 1e-4 max-abs, every pixel
     report(f"c2_full_f{frame}:size", P=cloud.P, V=int((ref["radii"] > 0).sum()), D=int(ref["num_rendered"]))
 
 
@@ -945,7 +951,7 @@ def test_c3_full_frames_vs_oracle(frame):
     same bars as above (the radix sorts run with 3 M keys and ~13.5 M pairs, expand with ~3 300 pair tiles)."""
     cloud = scenes.config_c3()
     cam = orbit_cameras(800, 1920, 1080)[frame]
-    hip, ref = run_both(f"c3_full_f{frame}", cloud, cam)
+    hip, ref = run_both(f"c3_full_f{frame}", cloud, cam, budget_px=0)   # the headline workload: every pixel within 1e-4
     report(f"c3_full_f{frame}:size", P=cloud.P, V=int((ref["radii"] > 0).sum()), D=int(ref["num_rendered"]))
 
 
@@ -960,7 +966,10 @@ def test_c4_full_size_vs_oracle(frame):
     cloud = scenes.config_c4()
     assert cloud.P == 200_000
     cam = sugar_orbit_cameras(50, 960, 540)[frame]
-    hip, ref = run_both(f"c4_full_f{frame}", cloud, cam)
+    # every pixel within 1e-4 but ONE of frame 49 (3.3e-4: a contributor at alpha = 1/255 under glibc's expf and not under the device
+    # library's -- the same frame through the unfused test build equals the reference's kernels on this GPU bit for bit, see
+    # test_unfused_blend_build_equals_the_reference_kernels_bit_for_bit); the budget is two pixels, not twenty per million
+    hip, ref = run_both(f"c4_full_f{frame}", cloud, cam, budget_px=2)
     report(f"c4_full_f{frame}:size", P=cloud.P, V=int((ref["radii"] > 0).sum()), D=int(ref["num_rendered"]))
     dev = "cuda:0"
     c = cloud.to(dev)
@@ -985,7 +994,32 @@ def test_c4_full_size_vs_oracle(frame):
     ref_n = cpu_oracle.forward(**oracle_kwargs(GaussianCloud(cloud.means3D, cloud.opacities, cloud.scales, cloud.rotations, None,
                                                              normals.cpu(), 0), cam))
     assert_images(f"c4_full_f{frame}_normal_pass", {"color": fused[8].cpu().numpy(), "depth": fused[2].cpu().numpy(),
-                                                      "alpha": fused[3].cpu().numpy()}, ref_n)
+                                                      "alpha": fused[3].cpu().numpy()}, ref_n, budget_px=2)
+
+
+def test_unfused_blend_build_equals_the_reference_kernels_bit_for_bit():
+    """The image tolerance as an equality, once per suite run.  The product fuses ONE multiply-add, in the blend's compositing
+    line (gsr_blend.hip: composite -- what nvcc makes of forward.cu:357-360 on the reference's own hardware); everything else is
+    built without contraction.  The same sources built with -DGSR_UNFUSED_BLEND (lib/libgsr_hip_unfused.so, __graft_entry__
+    builds it) therefore have to produce the SAME BITS as the reference's kernels compiled for gfx950 without contraction
+    (oracle/_ref/libgsr_ref_hip.so) -- every pixel of colour, depth and alpha, every radius -- at BASELINE configs[0], [1] and
+    [3] (full size) through the inference call bench.py times.  (The CPU oracle cannot serve here: its expf is glibc's, the
+    GPU's is the device library's; the two differ in the last bit on a few inputs, which is where the 1e-4 bar's rare
+    threshold flips come from.)  Runs in a process of its own: a process holds one build of the library."""
+    import subprocess
+    import sys
+    from oracle import ref_hip
+    lib = os.path.join(ROOT, "autovfx_amd", "lib", "libgsr_hip_unfused.so")
+    if not ref_hip.available():
+        pytest.skip("oracle/_ref/libgsr_ref_hip.so not built")
+    assert os.path.exists(lib), "lib/libgsr_hip_unfused.so is not built: run __graft_entry__.build()"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "unfused_blend_check.py")], env=dict(os.environ, GSR_LIB=lib),
+                       capture_output=True, text=True, timeout=600)
+    rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    for row in rows:
+        report("unfused:" + row["case"], **{k: v for k, v in row.items() if k != "case"})
+    assert r.returncode == 0 and len(rows) == 3, (r.stdout[-2000:], r.stderr[-2000:])
+    assert all(row[k] == 0 for row in rows for k in row if k.endswith("_words_differ")), rows
 
 
 # ---- a trained-scene-like cloud: heavy-tailed sizes, needles and discs, bimodal opacity (scenes.config_heavy) ---------
