@@ -321,6 +321,13 @@ hipError_t launch_place_object(int n, const uint32_t* subset /*nullable: output 
 hipError_t launch_pack_rgba8(const float* color, const float* alpha, uint8_t* out, size_t n_pixels,
                              hipStream_t stream);
 
+// ---- frame outputs / compositor inputs (gsr_frameio.hip) ----
+// Bytes of the PNG file launch_png_encode writes for a W x H image with C (3 or 4) 8-bit channels; 0 if the size is not encodable.
+size_t png_file_bytes(int W, int H, int C);
+// pixels: u8, interleaved [H,W,C] or (planar != 0) [C,H,W]; out: png_file_bytes bytes, 16-byte aligned; scratch: 32 bytes.
+hipError_t launch_png_encode(const uint8_t* pixels, int W, int H, int C, int planar, uint8_t* out, unsigned long long* scratch,
+                             hipStream_t stream);
+
 // ---- hand-written radix sort (gsr_radix.hip) ----
 // Stable ascending LSD sort on the low `bits` key bits, 8 per pass (count / scan / scatter kernels, no spinning,
 // nothing to zero-fill).  scratch: radix_scratch_words(n) u32 words of any content.  iota_payload: the payload

@@ -1336,9 +1336,29 @@ def time_frame_files(b, n):
                 for j in range(m):
                     w.submit(f"p{j:05d}", frames[j % 4])
             t_pool = time.perf_counter() - t0
+            # ... and with the file images built on the GPU (gsr_png_encode: stored deflate, Adler-32 / CRC-32 in the kernel; the
+            # .npy header in front of the depth plane), one D2H copy per frame, four host threads that only write()
+            from autovfx_amd.frame_io import GpuFrameWriter
+            mg = 16 * n
+            with GpuFrameWriter(d, workers=4) as w:
+                for j in range(8):
+                    w.submit(f"w{j:05d}", frames[j % 4])     # slots, pinned buffers, the first writes
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with GpuFrameWriter(d, workers=4) as w:
+                for j in range(mg):
+                    w.submit(f"g{j:05d}", frames[j % 4])
+            t_gpu = time.perf_counter() - t0
+            file_bytes = sum(os.path.getsize(os.path.join(d, sub, "g00000" + ext)) for sub, ext in
+                             (("images", ".png"), ("depth", ".npy"), ("depth", ".png"), ("normal", ".png")))
         return {"frames": n, "ms_per_frame": round(t_total / n * 1e3, 2),
                 "what": "RGBA PNG + depth .npy + depth preview PNG + normal PNG per frame (D2H copies, zlib level 3, file writes), one host thread",
-                "writer_pool": {"frames": m, "threads": workers, "ms_per_frame": round(t_pool / m * 1e3, 2)}}
+                "writer_pool": {"frames": m, "threads": workers, "ms_per_frame": round(t_pool / m * 1e3, 2)},
+                "gpu_file_images": {"frames": mg, "threads": 4, "ms_per_frame": round(t_gpu / mg * 1e3, 3),
+                                    "bytes_per_frame": int(file_bytes), "GBps_to_files": round(file_bytes * mg / t_gpu / 1e9, 2),
+                                    "what": "the same four files, their bytes built on the GPU (stored-deflate PNGs with Adler-32 / CRC-32 "
+                                            "computed in the kernel; .npy header + fp32 plane), one D2H copy per frame into pinned memory, "
+                                            "four host threads write() to a temporary directory"}}
     except Exception as e:
         return {"error": repr(e)[:200]}
 

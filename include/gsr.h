@@ -243,6 +243,17 @@ GSR_API int gsr_composite(int width, int height, const uint8_t* bg_c, const uint
 GSR_API int gsr_pack_rgba8(const float* color, const float* alpha, uint8_t* rgba8, int width, int height,
                            void* stream);
 
+/* Frame files at render rate (the reference writes four files per frame, scene_representation.py:425-438: an RGBA PNG through
+ * torchvision.utils.save_image, the depth map as .npy, and two PNGs through cv2.imwrite).  gsr_png_encode turns an 8-bit image
+ * that lives on the GPU -- interleaved [H,W,C] or, planar != 0, [C,H,W] as gsr_pack_rgba8 leaves it; C = 3 or 4 -- into the
+ * bytes of its PNG FILE, on the GPU: 8-bit truecolour (with alpha), one IDAT chunk holding a zlib stream of stored deflate
+ * blocks (filter-0 scanlines, no compression), Adler-32 and CRC-32 computed in the kernel.  Any PNG reader decodes it to the
+ * same pixels as the reference's compressed file; the caller copies gsr_png_size(...) bytes to the host and writes them out.
+ * `out` must hold gsr_png_size(width, height, channels) + 32 bytes (the last 32, from the next 16-byte boundary on, are the
+ * kernel's scratch) and be 16-byte aligned.  gsr_png_size returns 0 for sizes that cannot be encoded. */
+GSR_API size_t gsr_png_size(int width, int height, int channels);
+GSR_API int gsr_png_encode(const uint8_t* pixels, int width, int height, int channels, int planar, uint8_t* out, void* stream);
+
 /* The sort stage on its own (what gsr_forward runs twice per call; replaces the reference's
  * cub::DeviceRadixSort::SortPairs, rasterizer_impl.cu:304-309): stable ascending sort of n (u32 key, u32
  * payload) pairs on the low `bits` key bits.  *_alt are ping-pong partners of the same length; on return

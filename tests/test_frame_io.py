@@ -145,3 +145,101 @@ def test_render_trajectory_script_with_moving_objects(tmp_path):
     for i in (1, 2):
         assert int((outs["moving"][i].astype(int) - outs["static"][i].astype(int)).__abs__().max()) > 20, f"frame {i + 1}: the object is missing"
     assert not np.array_equal(outs["moving"][1], outs["moving"][2])
+
+
+# ---- file images built on the GPU (gsr_png_encode, GpuFrameWriter) -----------------------------------------------------
+
+def _check_png_file(data: bytes, img: np.ndarray):
+    """A strict reader: every chunk's CRC against zlib's, the IDAT payload through zlib (which verifies the Adler-32), the
+    scanlines against the image, and PIL's decoder on the whole file."""
+    import struct
+    import zlib
+    h, w, c = img.shape
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, tags, idat = 8, [], b""
+    while pos < len(data):
+        n, tag = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        (crc,) = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
+        assert crc == zlib.crc32(tag + body) & 0xFFFFFFFF, f"CRC of chunk {tag!r}"
+        tags.append(tag)
+        if tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    assert pos == len(data) and tags == [b"IHDR", b"IDAT", b"IEND"]
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + w * c)
+    assert not rows[:, 0].any()
+    np.testing.assert_array_equal(rows[:, 1:].reshape(h, w, c), img)
+    PIL = pytest.importorskip("PIL.Image")
+    im = PIL.open(io.BytesIO(data))
+    im.load()
+    assert im.mode == ("RGBA" if c == 4 else "RGB")
+    np.testing.assert_array_equal(np.asarray(im), img)
+    np.testing.assert_array_equal(frame_io.decode_png(data), img)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 1, 4), (1, 1, 3), (7, 5, 4), (64, 33, 3), (3, 5461, 4), (3, 5462, 4), (300, 100, 4), (540, 960, 4),
+                                   (540, 960, 3), (1080, 1920, 4), (2, 21845, 3), (17, 1285, 3)])
+@pytest.mark.parametrize("planar", [False, True])
+def test_gpu_png_files_are_valid_and_decode_to_the_image(shape, planar):
+    """gsr_png_encode: the file bytes come off the GPU finished -- signature, IHDR, one IDAT of stored deflate blocks with its
+    Adler-32, the chunk CRC, IEND.  Sizes around the 65535-byte block boundary (a scanline stream of exactly one block, one byte
+    more, rows that straddle blocks), one pixel, the bench sizes; interleaved and planar sources."""
+    h, w, c = shape
+    img = np.random.default_rng(h * 131 + w + c).integers(0, 256, shape).astype(np.uint8)
+    src = torch.from_numpy(img).cuda()
+    if planar:
+        src = src.permute(2, 0, 1).contiguous()
+    out = frame_io.encode_png_gpu(src, planar=planar)
+    torch.cuda.synchronize()
+    assert out.numel() == frame_io.png_size(w, h, c)
+    _check_png_file(out.cpu().numpy().tobytes(), img)
+
+
+@pytest.mark.gpu
+def test_gpu_png_of_constant_images_and_rejects_what_it_cannot_encode():
+    """All-zero and all-255 images (Adler-32 sums at their extremes: s2 of a 1080p RGBA frame of 255s passes 1e15 before the
+    modulus), and the argument errors."""
+    for value in (0, 255):
+        img = np.full((1080, 1920, 4), value, np.uint8)
+        out = frame_io.encode_png_gpu(torch.from_numpy(img).cuda())
+        _check_png_file(out.cpu().numpy().tobytes(), img)
+    with pytest.raises(ValueError):
+        frame_io.encode_png_gpu(torch.zeros(4, 4, 2, dtype=torch.uint8, device="cuda"))
+    with pytest.raises(ValueError):
+        frame_io.encode_png_gpu(torch.zeros(4, 4, 4, dtype=torch.float32, device="cuda"))
+    with pytest.raises(ValueError):
+        frame_io.encode_png_gpu(torch.zeros(4, 4, 4, dtype=torch.uint8))
+
+
+@pytest.mark.gpu
+def test_gpu_frame_writer_leaves_the_same_pixels_and_the_same_npy_bytes(tmp_path):
+    """GpuFrameWriter against write_frame_outputs (the host path, itself checked against the reference's formulas above) on real
+    render() results: the three PNGs decode to the same pixels, the depth .npy is byte-identical to np.save's, frames in
+    flight do not overwrite each other (12 frames through 3 slots), a second image size re-sizes the slots."""
+    from autovfx_amd import renderer, scenes
+    from autovfx_amd.cameras import orbit_cameras
+    from autovfx_amd.gaussian_model import GaussianModel
+    dev = "cuda:0"
+    c = scenes.config_c2(P=30_000, seed=5).to(dev)
+    model = GaussianModel.from_activated(c.means3D, c.opacities, c.scales, c.rotations, c.shs, 3)
+    bg = torch.zeros(3, device=dev)
+    a, b = tmp_path / "host", tmp_path / "gpu"
+    names = []
+    with torch.no_grad(), frame_io.GpuFrameWriter(str(b), workers=2, slots=3) as w:
+        for size in ((208, 120), (96, 64)):
+            cams = orbit_cameras(12, *size)
+            for i in range(12 if size[0] == 208 else 3):
+                res = renderer.render(cams[i].to(dev), model, renderer.PipelineParams, bg)
+                name = f"{size[0]}_{i:05d}"
+                w.submit(name, res)
+                frame_io.write_frame_outputs(str(a), name, res)
+                names.append(name)
+    for name in names:
+        for sub, ext in (("images", ".png"), ("normal", ".png"), ("depth", ".png")):
+            got = frame_io.decode_png((b / sub / (name + ext)).read_bytes())
+            np.testing.assert_array_equal(got, frame_io.decode_png((a / sub / (name + ext)).read_bytes()), err_msg=f"{sub}/{name}")
+        assert (b / "depth" / (name + ".npy")).read_bytes() == (a / "depth" / (name + ".npy")).read_bytes(), name
+    img = frame_io.decode_png((b / "images" / (names[5] + ".png")).read_bytes())
+    assert img.shape == (120, 208, 4) and img[..., 3].max() > 200
