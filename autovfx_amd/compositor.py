@@ -1,9 +1,12 @@
 """GPU compositor for AutoVFX's final blend (``blender/blend_all.py::blend_frames``).
 
 ``composite_frame`` takes the layers of one frame as GPU tensors -- RGBA8 ``[H,W,4]`` colour layers and fp32
-``[H,W]`` depth maps, already resized to the background's resolution -- and returns the composited RGBA8
-frame, bit-identical to the reference's numpy arithmetic (``blend_all.py:236-300,341-343``).  File discovery,
-PNG / EXR decoding and the PIL resizes of the reference (``:124-234``) stay with the caller.
+``[H,W]`` depth maps -- and returns the composited RGBA8 frame, bit-identical to the reference's numpy arithmetic
+(``blend_all.py:236-300,341-343``).  Layers that arrive at Blender's render resolution (the reference renders them at 2x
+for anti-aliasing) are brought to the background's size first, as ``blend_all.py:217-234`` does with PIL --
+``downsample_image``: ``Image.resize(new_size, BILINEAR)`` for the colour layers, ``NEAREST`` for the depth maps -- by
+``resize_rgba8`` / ``resize_depth``, which reproduce Pillow's results bit for bit on the GPU (``gsr_resize_rgba8_bilinear``,
+``gsr_resize_f32_nearest``).  File discovery and PNG / EXR decoding (``:124-205``) stay with the caller (host libraries).
 ``smoke_depth_fill`` is the one non-pointwise step (``:207-215``): where the smoke layer has alpha its depth
 becomes the layer's 0.001-th percentile, computed here with numpy's "linear" rule.
 """
@@ -40,11 +43,50 @@ def smoke_depth_fill(s_f_c: torch.Tensor, s_f_d: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def resize_rgba8(image: torch.Tensor, size_wh, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``np.array(Image.fromarray(image).resize(size_wh, resample=Image.BILINEAR))`` for an RGBA8 ``[H,W,4]`` GPU tensor
+    (``downsample_image`` of blend_all.py:21-28): same bytes as Pillow."""
+    if not (image.is_cuda and image.dtype == torch.uint8 and image.dim() == 3 and image.shape[2] == 4):
+        raise RuntimeError("resize_rgba8 expects a uint8 GPU tensor [H,W,4]")
+    W, H = int(size_wh[0]), int(size_wh[1])
+    src = image.contiguous()
+    Hs, Ws = int(src.shape[0]), int(src.shape[1])
+    if out is None:
+        out = torch.empty((H, W, 4), dtype=torch.uint8, device=src.device)
+    tmp = torch.empty((Hs, W, 4), dtype=torch.uint8, device=src.device) if (Ws != W and Hs != H) else None
+    with torch.cuda.device(src.device):
+        rc = _lib.lib.gsr_resize_rgba8_bilinear(src.data_ptr(), Ws, Hs, out.data_ptr(), W, H, None if tmp is None else tmp.data_ptr(),
+                                                ctypes.c_void_p(torch.cuda.current_stream(src.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"gsr_resize_rgba8_bilinear failed ({rc}): {_lib.last_error()}")
+    return out
+
+
+def resize_depth(depth: torch.Tensor, size_wh, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``np.array(Image.fromarray(depth).resize(size_wh, Image.NEAREST))`` for an fp32 ``[H,W]`` GPU tensor: same values as Pillow."""
+    if not (depth.is_cuda and depth.dtype == torch.float32 and depth.dim() == 2):
+        raise RuntimeError("resize_depth expects a float32 GPU tensor [H,W]")
+    W, H = int(size_wh[0]), int(size_wh[1])
+    src = depth.contiguous()
+    if out is None:
+        out = torch.empty((H, W), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        rc = _lib.lib.gsr_resize_f32_nearest(src.data_ptr(), int(src.shape[1]), int(src.shape[0]), out.data_ptr(), W, H,
+                                             ctypes.c_void_p(torch.cuda.current_stream(src.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"gsr_resize_f32_nearest failed ({rc}): {_lib.last_error()}")
+    return out
+
+
 def _layer(t: Optional[torch.Tensor], dtype, shape, device, name):
+    """A layer at the frame's size: as it is; at another size (Blender's render resolution): resized as the reference does."""
     if t is None:
         return None
-    if t.dtype != dtype or tuple(t.shape) != shape or t.device != device:
+    if t.dtype != dtype or t.device != device or t.dim() != len(shape) or (len(shape) == 3 and t.shape[2] != 4):
         raise RuntimeError(f"{name}: expected {dtype} {shape} on {device}, got {t.dtype} {tuple(t.shape)} on {t.device}")
+    if tuple(t.shape) != shape:
+        size_wh = (shape[1], shape[0])
+        return resize_rgba8(t, size_wh) if dtype == torch.uint8 else resize_depth(t, size_wh)
     return t.contiguous()
 
 

@@ -723,6 +723,20 @@ int gsr_selftest_lds_atomic_order(uint32_t workgroups, uint32_t rounds, uint32_t
     return GSR_OK;
 }
 
+int gsr_resize_rgba8_bilinear(const uint8_t* src, int src_w, int src_h, uint8_t* dst, int dst_w, int dst_h, uint8_t* tmp, void* stream_) {
+    if (src_w <= 0 || src_h <= 0 || dst_w <= 0 || dst_h <= 0) return fail(GSR_ERR_INVALID_ARG, "bad image size %dx%d -> %dx%d", src_w, src_h, dst_w, dst_h);
+    if (!src || !dst || (!tmp && src_w != dst_w && src_h != dst_h)) return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    GSR_HIP(gsr::launch_resize_rgba8_bilinear(src, src_w, src_h, dst, dst_w, dst_h, tmp, (hipStream_t)stream_));
+    return GSR_OK;
+}
+
+int gsr_resize_f32_nearest(const float* src, int src_w, int src_h, float* dst, int dst_w, int dst_h, void* stream_) {
+    if (src_w <= 0 || src_h <= 0 || dst_w <= 0 || dst_h <= 0) return fail(GSR_ERR_INVALID_ARG, "bad image size %dx%d -> %dx%d", src_w, src_h, dst_w, dst_h);
+    if (!src || !dst) return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    GSR_HIP(gsr::launch_resize_f32_nearest(src, src_w, src_h, dst, dst_w, dst_h, (hipStream_t)stream_));
+    return GSR_OK;
+}
+
 size_t gsr_png_size(int width, int height, int channels) { return gsr::png_file_bytes(width, height, channels); }
 
 int gsr_png_encode(const uint8_t* pixels, int width, int height, int channels, int planar, uint8_t* out, void* stream_) {

@@ -20,6 +20,10 @@
 //     conditioning is one more term, 0xFFFFFFFF x^(8 N) ^ 0xFFFFFFFF.
 #include "gsr_internal.h"
 
+#include <cmath>
+#include <mutex>
+#include <vector>
+
 namespace gsr {
 namespace {
 
@@ -221,7 +225,189 @@ bool png_layout(int W, int H, int C, int planar, PngLayout* L) {
     return true;
 }
 
+// ================================================================================================
+// PIL's Image.resize, bit for bit (blender/blend_all.py:21-28: downsample_image = Image.fromarray(a).resize(new_size, BILINEAR) for
+// the RGBA8 layers, resize(new_size, NEAREST) for the float depth maps; called on every Blender layer of every frame, :217-234).
+//
+// BILINEAR on an RGBA image is three steps in Pillow (src/PIL/Image.py resize; src/libImaging/Convert.c, Resample.c):
+//   1. RGBA -> RGBa: colour channels premultiplied, MULDIV255(c, a) = (t = c a + 128, ((t >> 8) + t) >> 8);
+//   2. a separable resample in 8-bit fixed point, horizontal pass first, each pass rounding to 8 bits: the triangle filter's
+//      support is stretched by the down-scale factor (an area-weighted average, not a 2 x 2 lookup), the weights of an output
+//      pixel are normalised to sum 1 in double and converted to integers with 22 fraction bits ((int)(0.5 + w 2^22)), a pixel is
+//      clip8((2^21 + sum k_i p_i) >> 22);
+//   3. RGBa -> RGBA: c = min(255, 255 c / a) (integer division) unless a is 0 or 255.
+// An image that already has the target size is copied (no premultiply round trip); a pass whose size does not change is skipped.
+// The weight tables depend only on (input size, output size): computed on the host in the doubles Pillow uses, cached per device.
+//
+// NEAREST on a mode "F" image is an affine scale with the source coordinate ACCUMULATED in double (Geometry.c
+// ImagingScaleAffine: xo = a / 2, then xo += a per output pixel, index = (int)xo): the index tables are built on the host the same way.
+// ================================================================================================
+constexpr int kResampleBits = 32 - 8 - 2;
+
+struct ResampleTable {
+    int dev, in, out, kind;   // kind 0: bilinear weights, 1: nearest indices
+    int ksize;
+    int* bounds;              // [out][2] (first input index, count); nearest: [out] indices
+    int* coef;                // [out][ksize]
+};
+std::mutex g_table_mutex;
+std::vector<ResampleTable> g_tables;
+
+double triangle(double x) {
+    if (x < 0.0) x = -x;
+    return x < 1.0 ? 1.0 - x : 0.0;
+}
+
+// Resample.c: precompute_coeffs + normalize_coeffs_8bpc for the bilinear filter (support 1.0) over the whole input (box = image)
+void bilinear_weights(int in_size, int out_size, std::vector<int>* bounds, std::vector<int>* coef, int* ksize_out) {
+    double scale = (double)in_size / out_size, filterscale = scale;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = 1.0 * filterscale;
+    const int ksize = (int)std::ceil(support) * 2 + 1;
+    bounds->assign((size_t)out_size * 2, 0);
+    coef->assign((size_t)out_size * ksize, 0);
+    std::vector<double> k((size_t)ksize);
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = 0.0 + (xx + 0.5) * scale;
+        const double ss = 1.0 / filterscale;
+        double ww = 0.0;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        for (int x = 0; x < xmax; ++x) {
+            const double w = triangle((x + xmin - center + 0.5) * ss);
+            k[x] = w;
+            ww += w;
+        }
+        for (int x = 0; x < xmax; ++x) {
+            if (ww != 0.0) k[x] /= ww;
+            (*coef)[(size_t)xx * ksize + x] = k[x] < 0 ? (int)(-0.5 + k[x] * (1 << kResampleBits)) : (int)(0.5 + k[x] * (1 << kResampleBits));
+        }
+        (*bounds)[2 * (size_t)xx] = xmin;
+        (*bounds)[2 * (size_t)xx + 1] = xmax;
+    }
+    *ksize_out = ksize;
+}
+
+// Geometry.c ImagingScaleAffine, nearest: the source index of every output pixel (-1: outside)
+void nearest_indices(int in_size, int out_size, std::vector<int>* index) {
+    const double a = (double)in_size / out_size;
+    double xo = a * 0.5;
+    index->assign((size_t)out_size, -1);
+    for (int x = 0; x < out_size; ++x) {
+        const int xin = xo < 0.0 ? -1 : (int)xo;
+        (*index)[x] = (xin >= 0 && xin < in_size) ? xin : -1;
+        xo += a;
+    }
+}
+
+hipError_t resample_table(int in_size, int out_size, int kind, ResampleTable* out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(g_table_mutex);
+    for (const ResampleTable& t : g_tables)
+        if (t.dev == dev && t.in == in_size && t.out == out_size && t.kind == kind) { *out = t; return hipSuccess; }
+    std::vector<int> bounds, coef;
+    ResampleTable t = {dev, in_size, out_size, kind, 0, nullptr, nullptr};
+    if (kind == 0) bilinear_weights(in_size, out_size, &bounds, &coef, &t.ksize);
+    else nearest_indices(in_size, out_size, &bounds);
+    if ((e = hipMalloc((void**)&t.bounds, bounds.size() * sizeof(int))) != hipSuccess) return e;
+    if ((e = hipMemcpy(t.bounds, bounds.data(), bounds.size() * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    if (!coef.empty()) {
+        if ((e = hipMalloc((void**)&t.coef, coef.size() * sizeof(int))) != hipSuccess) return e;
+        if ((e = hipMemcpy(t.coef, coef.data(), coef.size() * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    }
+    g_tables.push_back(t);   // (a handful of sizes per process; never freed)
+    *out = t;
+    return hipSuccess;
+}
+
+__device__ __forceinline__ uint32_t muldiv255(uint32_t c, uint32_t a) {
+    const uint32_t t = c * a + 128u;
+    return ((t >> 8) + t) >> 8;
+}
+__device__ __forceinline__ int clip8(int v) {
+    v >>= kResampleBits;   // arithmetic shift: floor, as the reference's lookup table is indexed
+    return v < 0 ? 0 : v > 255 ? 255 : v;
+}
+
+// One lane = one output pixel of one pass.  kHorizontal: out[row][xx] from in[row][xmin .. xmin + n); else out[yy][x] from
+// in[ymin .. ymin + n)[x].  kPremultiply: the input is straight RGBA (the first pass of a call); kUnpremultiply: the output is
+// converted back (the last pass).
+template <bool kHorizontal, bool kPremultiply, bool kUnpremultiply>
+__global__ void __launch_bounds__(256) resample_rgba8_kernel(const uchar4* __restrict__ in, int in_w, uchar4* __restrict__ out, int out_w, int out_h,
+                                                            const int* __restrict__ bounds, const int* __restrict__ coef, int ksize) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= out_w || y >= out_h) return;
+    const int o = kHorizontal ? x : y;
+    const int first = bounds[2 * o], n = bounds[2 * o + 1];
+    const int* k = coef + (size_t)o * ksize;
+    int s0 = 1 << (kResampleBits - 1), s1 = s0, s2 = s0, s3 = s0;
+    for (int i = 0; i < n; ++i) {
+        const uchar4 p = kHorizontal ? in[(size_t)y * in_w + first + i] : in[(size_t)(first + i) * in_w + x];
+        uint32_t r = p.x, g = p.y, b = p.z;
+        const uint32_t a = p.w;
+        if (kPremultiply) { r = muldiv255(r, a); g = muldiv255(g, a); b = muldiv255(b, a); }
+        const int w = k[i];
+        s0 += (int)r * w; s1 += (int)g * w; s2 += (int)b * w; s3 += (int)a * w;
+    }
+    int r = clip8(s0), g = clip8(s1), b = clip8(s2);
+    const int a = clip8(s3);
+    if (kUnpremultiply && a != 255 && a != 0) {
+        r = min(255, 255 * r / a); g = min(255, 255 * g / a); b = min(255, 255 * b / a);
+    }
+    out[(size_t)y * out_w + x] = make_uchar4((unsigned char)r, (unsigned char)g, (unsigned char)b, (unsigned char)a);
+}
+
+__global__ void __launch_bounds__(256) nearest_f32_kernel(const float* __restrict__ in, int in_w, float* __restrict__ out, int out_w, int out_h,
+                                                         const int* __restrict__ xi, const int* __restrict__ yi) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= out_w || y >= out_h) return;
+    const int sx = xi[x], sy = yi[y];
+    if (sx >= 0 && sy >= 0) out[(size_t)y * out_w + x] = in[(size_t)sy * in_w + sx];   // (never outside for a whole-image resize)
+}
+
 } // namespace
+
+hipError_t launch_resize_rgba8_bilinear(const uint8_t* src, int src_w, int src_h, uint8_t* dst, int dst_w, int dst_h, uint8_t* tmp,
+                                        hipStream_t stream) {
+    const uchar4* in = reinterpret_cast<const uchar4*>(src);
+    uchar4* out = reinterpret_cast<uchar4*>(dst);
+    if (src_w == dst_w && src_h == dst_h)   // Image.resize returns a copy: no premultiply round trip
+        return hipMemcpyAsync(dst, src, (size_t)src_w * src_h * 4, hipMemcpyDeviceToDevice, stream);
+    const bool horizontal = src_w != dst_w, vertical = src_h != dst_h;
+    ResampleTable tx = {}, ty = {};
+    hipError_t e;
+    if (horizontal && (e = resample_table(src_w, dst_w, 0, &tx)) != hipSuccess) return e;
+    if (vertical && (e = resample_table(src_h, dst_h, 0, &ty)) != hipSuccess) return e;
+    if (horizontal && vertical) {
+        uchar4* mid = reinterpret_cast<uchar4*>(tmp);   // [src_h, dst_w]
+        hipLaunchKernelGGL((resample_rgba8_kernel<true, true, false>), dim3((dst_w + 255) / 256, src_h), dim3(256), 0, stream, in, src_w, mid, dst_w,
+                           src_h, tx.bounds, tx.coef, tx.ksize);
+        hipLaunchKernelGGL((resample_rgba8_kernel<false, false, true>), dim3((dst_w + 255) / 256, dst_h), dim3(256), 0, stream, mid, dst_w, out, dst_w,
+                           dst_h, ty.bounds, ty.coef, ty.ksize);
+    } else if (horizontal) {
+        hipLaunchKernelGGL((resample_rgba8_kernel<true, true, true>), dim3((dst_w + 255) / 256, src_h), dim3(256), 0, stream, in, src_w, out, dst_w,
+                           src_h, tx.bounds, tx.coef, tx.ksize);
+    } else {
+        hipLaunchKernelGGL((resample_rgba8_kernel<false, true, true>), dim3((dst_w + 255) / 256, dst_h), dim3(256), 0, stream, in, src_w, out, dst_w,
+                           dst_h, ty.bounds, ty.coef, ty.ksize);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_resize_f32_nearest(const float* src, int src_w, int src_h, float* dst, int dst_w, int dst_h, hipStream_t stream) {
+    if (src_w == dst_w && src_h == dst_h) return hipMemcpyAsync(dst, src, (size_t)src_w * src_h * 4, hipMemcpyDeviceToDevice, stream);
+    ResampleTable tx = {}, ty = {};
+    hipError_t e;
+    if ((e = resample_table(src_w, dst_w, 1, &tx)) != hipSuccess) return e;
+    if ((e = resample_table(src_h, dst_h, 1, &ty)) != hipSuccess) return e;
+    hipLaunchKernelGGL(nearest_f32_kernel, dim3((dst_w + 255) / 256, dst_h), dim3(256), 0, stream, src, src_w, dst, dst_w, dst_h, tx.bounds, ty.bounds);
+    return hipGetLastError();
+}
 
 size_t png_file_bytes(int W, int H, int C) {
     PngLayout L;

@@ -328,6 +328,12 @@ size_t png_file_bytes(int W, int H, int C);
 hipError_t launch_png_encode(const uint8_t* pixels, int W, int H, int C, int planar, uint8_t* out, unsigned long long* scratch,
                              hipStream_t stream);
 
+// PIL's Image.resize(BILINEAR) on an RGBA8 image [H,W,4] and Image.resize(NEAREST) on an fp32 image, bit for bit
+// (blend_all.py:21-28).  tmp: src_h * dst_w * 4 bytes (needed when both sizes change).
+hipError_t launch_resize_rgba8_bilinear(const uint8_t* src, int src_w, int src_h, uint8_t* dst, int dst_w, int dst_h, uint8_t* tmp,
+                                        hipStream_t stream);
+hipError_t launch_resize_f32_nearest(const float* src, int src_w, int src_h, float* dst, int dst_w, int dst_h, hipStream_t stream);
+
 // ---- hand-written radix sort (gsr_radix.hip) ----
 // Stable ascending LSD sort on the low `bits` key bits, 8 per pass (count / scan / scatter kernels, no spinning,
 // nothing to zero-fill).  scratch: radix_scratch_words(n) u32 words of any content.  iota_payload: the payload

@@ -851,6 +851,25 @@ def run_also(device, side, S, parity=True):
         out["compositor"] = {"avg_launch_ms": round(ms, 5), "alg_bytes_per_launch": nbytes,
                              "achieved_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1),
                              "frac_of_hbm_peak": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+        # the same composite from layers as Blender renders them -- 2x the frame, the reference's anti-aliasing set-up -- resized on
+        # the GPU exactly as blend_all.py:217-234 does with PIL (gsr_resize_rgba8_bilinear / gsr_resize_f32_nearest: Pillow's bytes)
+        g2 = torch.Generator(device=device).manual_seed(9)
+        big_c = lambda: torch.randint(0, 256, (2 * b.H, 2 * b.W, 4), dtype=torch.uint8, device=device, generator=g2)
+        big_d = lambda: torch.rand((2 * b.H, 2 * b.W), device=device, generator=g2) * 5 + 1
+        args2 = (bg_c, big_c(), big_d(), big_c(), big_d(), big_c(), big_c(), big_d(), big_c(), big_d(), big_c())
+        for _ in range(5):
+            composite_frame(*args2, out=dst)
+        e0.record()
+        for _ in range(100):
+            composite_frame(*args2, out=dst)
+        e1.record()
+        torch.cuda.synchronize()
+        ms2 = e0.elapsed_time(e1) / 100
+        in_bytes = (6 * 4 + 4 * 4) * 4 * b.W * b.H + 8 * b.W * b.H     # ten layers at 2x in (6 RGBA8, 4 fp32), the frame's background in, the frame out
+        out["compositor_from_2x_layers"] = {"avg_ms": round(ms2, 5), "alg_bytes": int(in_bytes), "achieved_GBps": round(in_bytes / (ms2 * 1e-3) / 1e9, 1),
+                                            "frac_of_hbm_peak": round(in_bytes / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                            "what": "ten Blender layers at 2x the frame resized like PIL (bilinear RGBA8 with the premultiply round trip, "
+                                                    "nearest fp32), then the composite: 11 resize launches + 1"}
         out["disk_io"] = time_frame_files(b, 8)
         return out
 

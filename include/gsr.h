@@ -254,6 +254,17 @@ GSR_API int gsr_pack_rgba8(const float* color, const float* alpha, uint8_t* rgba
 GSR_API size_t gsr_png_size(int width, int height, int channels);
 GSR_API int gsr_png_encode(const uint8_t* pixels, int width, int height, int channels, int planar, uint8_t* out, void* stream);
 
+/* The compositor's input side (blender/blend_all.py:21-28,217-234: every Blender layer of every frame is brought to the size of
+ * the rendered frame with PIL -- Image.resize(new_size, BILINEAR) for the RGBA8 layers, Image.resize(new_size, NEAREST) for the
+ * fp32 depth maps).  Both on the GPU, BIT-IDENTICAL to Pillow (12.x): the RGBA resize premultiplies, resamples in two 8-bit
+ * fixed-point passes with the triangle filter stretched by the scale factor, and un-premultiplies, exactly as Image.resize does;
+ * the nearest resize picks Pillow's source indices (accumulated in double).  src / dst: [H,W,4] u8 or [H,W] f32, contiguous.
+ * tmp: src_h * dst_w * 4 bytes of device memory (used when width AND height change; may be NULL otherwise). */
+GSR_API int gsr_resize_rgba8_bilinear(const uint8_t* src, int src_width, int src_height, uint8_t* dst, int dst_width, int dst_height,
+                                      uint8_t* tmp, void* stream);
+GSR_API int gsr_resize_f32_nearest(const float* src, int src_width, int src_height, float* dst, int dst_width, int dst_height,
+                                   void* stream);
+
 /* The sort stage on its own (what gsr_forward runs twice per call; replaces the reference's
  * cub::DeviceRadixSort::SortPairs, rasterizer_impl.cu:304-309): stable ascending sort of n (u32 key, u32
  * payload) pairs on the low `bits` key bits.  *_alt are ping-pong partners of the same length; on return

@@ -152,3 +152,82 @@ def test_compositor_throughput_report():
     alg = H * W * (7 * 4 + 4 * 4 + 4)     # 7 RGBA8 layers + 4 depth maps in, RGBA8 out
     report("compositor_1080p_all_layers", ms_per_frame=ms, alg_bytes=alg, alg_GBps=alg / (ms * 1e-3) / 1e9)
     assert ms < 5.0
+
+
+# ---- the input side: Blender layers at render resolution, brought to the frame's size as blend_all.py:217-234 does ------------
+
+def pil_downsample(image, new_size):
+    """blend_all.py:21-28, verbatim semantics (PIL is the oracle here)."""
+    from PIL import Image
+    img = Image.fromarray(image)
+    return np.array(img.resize(new_size, resample=Image.BILINEAR) if image.ndim == 3 else img.resize(new_size, Image.NEAREST))
+
+
+def oracle_from_blender_layers(L, hw):
+    """The reference's order of operations on layers that arrive at Blender's resolution: smoke depth fill on the full-size
+    layers (:207-215), then every layer through downsample_image (:217-234), then the per-pixel composite (:236-343)."""
+    args = dict(L)
+    if "s_f_c" in args:
+        args["s_f_d"], _ = co.smoke_depth_fill(args["s_f_c"], args["s_f_d"], None)
+    new_size = (hw[1], hw[0])
+    for k in args:
+        if k != "bg_c":
+            args[k] = pil_downsample(args[k], new_size)
+    return co.composite_frame(**args)
+
+
+def blender_layers(hw, scale_hw, seed, **kw):
+    """Background at the frame's size, every Blender layer at ``scale_hw`` times it."""
+    big = synthetic_layers(int(hw[0] * scale_hw[0]), int(hw[1] * scale_hw[1]), seed, **kw)
+    big["bg_c"] = synthetic_layers(hw[0], hw[1], seed + 1)["bg_c"]
+    return big
+
+
+@needs_reference
+@pytest.mark.parametrize("variant,scale", [("plain", (2, 2)), ("all", (2, 2)), ("fire", (1.5, 1.25))])
+def test_oracle_with_pil_resizes_matches_reference_blend_frames(tmp_path, variant, scale):
+    """The reference's own blend_frames on Blender layers at 2x (its anti-aliasing setup) and at an odd ratio: PIL resizes
+    inside it; the oracle path above must give the same frame."""
+    hw = (36, 52)
+    L = blender_layers(hw, scale, seed=11, with_3dgs=variant == "all", with_smoke=variant in ("fire", "all"), with_fire=variant in ("fire", "all"))
+    want = run_reference_blend_frames(L, tmp_path)
+    np.testing.assert_array_equal(oracle_from_blender_layers(L, hw), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src_hw,dst_hw", [((1080, 1920), (540, 960)), ((216, 384), (108, 192)), ((100, 150), (33, 77)), ((37, 53), (37, 20)),
+                                           ((50, 60), (57, 60)), ((64, 64), (128, 100)), ((31, 17), (31, 17)), ((5, 7), (1, 1)), ((1, 1), (4, 6)),
+                                           ((270, 481), (135, 240))])
+def test_gpu_resizes_equal_pillow_bit_for_bit(src_hw, dst_hw):
+    """gsr_resize_rgba8_bilinear / gsr_resize_f32_nearest against Pillow itself: 2x down (the reference's case), odd ratios,
+    one dimension only (the other pass is skipped but the premultiply round trip stays), up-scaling, the identity (a copy), to
+    and from one pixel.  Alpha is 0 / 255 on a third of the pixels each (the un-premultiply's special cases)."""
+    from autovfx_amd import compositor
+    g = np.random.default_rng(src_hw[0] * 7 + dst_hw[1])
+    img = g.integers(0, 256, src_hw + (4,), dtype=np.uint8)
+    img[g.random(src_hw) < 0.33, 3] = 0
+    img[g.random(src_hw) < 0.33, 3] = 255
+    depth = g.uniform(0.5, 30.0, src_hw).astype(np.float32)
+    new_size = (dst_hw[1], dst_hw[0])
+    got_c = compositor.resize_rgba8(torch.from_numpy(img).cuda(), new_size)
+    got_d = compositor.resize_depth(torch.from_numpy(depth).cuda(), new_size)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(got_c.cpu().numpy(), pil_downsample(img, new_size))
+    np.testing.assert_array_equal(got_d.cpu().numpy(), pil_downsample(depth, new_size))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["plain", "3dgs", "all"])
+@pytest.mark.parametrize("hw,scale", [((540, 960), (2, 2)), ((90, 160), (1.5, 1.25))])
+def test_hip_compositor_takes_blender_resolution_layers(variant, hw, scale):
+    """composite_frame fed the Blender layers as Blender renders them (2x the frame, or any other size): resized on the GPU
+    like blend_all.py:217-234, composited, and equal to the oracle (PIL resizes + numpy composite) byte for byte."""
+    from autovfx_amd import compositor
+    L = blender_layers(hw, scale, seed=21 + len(variant), with_3dgs=variant in ("3dgs", "all"), with_smoke=variant == "all", with_fire=variant == "all")
+    want = oracle_from_blender_layers(L, hw)
+    t = {k: torch.from_numpy(v).cuda() for k, v in L.items()}
+    if "s_f_c" in t:
+        t["s_f_d"] = compositor.smoke_depth_fill(t["s_f_c"], t["s_f_d"])     # on the full-size layers, before the resize (:207-215)
+    got = compositor.composite_frame(**t)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
