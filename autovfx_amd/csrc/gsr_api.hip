@@ -737,6 +737,20 @@ int gsr_resize_f32_nearest(const float* src, int src_w, int src_h, float* dst, i
     return GSR_OK;
 }
 
+int gsr_frame_files(const float* color, const float* alpha, const float* depth, const float* normal, float depth_scale, const uint8_t* turbo_lut,
+                    int width, int height, uint8_t* png_rgba, uint8_t* png_depth_preview, uint8_t* png_normal, float* npy_plane, uint8_t* work,
+                    void* stream_) {
+    if (width <= 0 || height <= 0 || gsr::png_file_bytes(width, height, 4) == 0) return fail(GSR_ERR_INVALID_ARG, "bad image size %dx%d", width, height);
+    if (!color || !alpha || !depth || !normal || !turbo_lut || !png_rgba || !png_depth_preview || !png_normal || !npy_plane || !work)
+        return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    if (((reinterpret_cast<uintptr_t>(png_rgba) | reinterpret_cast<uintptr_t>(png_depth_preview) | reinterpret_cast<uintptr_t>(png_normal)) & 15u) != 0)
+        return fail(GSR_ERR_INVALID_ARG, "gsr_frame_files: the PNG buffers must be 16-byte aligned");
+    if (!(depth_scale > 0.0f)) return fail(GSR_ERR_INVALID_ARG, "gsr_frame_files: depth_scale must be positive");
+    GSR_HIP(gsr::launch_frame_files(color, alpha, depth, normal, depth_scale, turbo_lut, width, height, png_rgba, png_depth_preview, png_normal,
+                                    npy_plane, work, (hipStream_t)stream_));
+    return GSR_OK;
+}
+
 size_t gsr_png_size(int width, int height, int channels) { return gsr::png_file_bytes(width, height, channels); }
 
 int gsr_png_encode(const uint8_t* pixels, int width, int height, int channels, int planar, uint8_t* out, void* stream_) {

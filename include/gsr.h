@@ -252,6 +252,14 @@ GSR_API int gsr_pack_rgba8(const float* color, const float* alpha, uint8_t* rgba
  * `out` must hold gsr_png_size(width, height, channels) + 32 bytes (the last 32, from the next 16-byte boundary on, are the
  * kernel's scratch) and be 16-byte aligned.  gsr_png_size returns 0 for sizes that cannot be encoded. */
 GSR_API size_t gsr_png_size(int width, int height, int channels);
+/* ... and one frame's four files in one call (ten launches on `stream`): color [3,H,W] + alpha [H,W] -> the RGBA PNG (save_image's
+ * rounding, gsr_pack_rgba8); depth [H,W] -> the turbo-coloured preview PNG (depth2img(depth, depth_scale): uint8(clip(d / scale,
+ * 0, 1) * 255) through turbo_lut, 256 RGB triples on the device) and, copied behind the caller's .npy header, the fp32 plane;
+ * normal [H,W,3] -> uint8((n + 1) / 2 * 255), truncated.  png_* as `out` of gsr_png_encode (sizes gsr_png_size(w, h, 4 / 3 / 3)
+ * + 32, 16-byte aligned); npy_plane: W * H floats; work: 10 * W * H bytes of device scratch. */
+GSR_API int gsr_frame_files(const float* color, const float* alpha, const float* depth, const float* normal, float depth_scale,
+                            const uint8_t* turbo_lut, int width, int height, uint8_t* png_rgba, uint8_t* png_depth_preview,
+                            uint8_t* png_normal, float* npy_plane, uint8_t* work, void* stream);
 GSR_API int gsr_png_encode(const uint8_t* pixels, int width, int height, int channels, int planar, uint8_t* out, void* stream);
 
 /* The compositor's input side (blender/blend_all.py:21-28,217-234: every Blender layer of every frame is brought to the size of

@@ -108,13 +108,14 @@ def main():
         return scene.compose_model(placed)
 
     mine = shard_frames(len(cams), rank, world)
+    cams_dev = dict(zip(mine, cameras.Camera.batch_to([cams[i] for i in mine], dev)))   # this rank's cameras, uploaded in five copies
     t0 = time.perf_counter()
     # file images built on the GPU (stored-deflate PNGs, checksums in the kernel), host threads only write(); --deflate: the frame
     # crosses as pixels and a pool of host threads compresses it (zlib level 3: files a third of the size, ~30x the host time)
     make_writer = (lambda: frame_io.FrameWriter(args.out)) if args.deflate else (lambda: frame_io.GpuFrameWriter(args.out, workers=args.writer_threads))
     with torch.no_grad(), make_writer() as writer:
         for i in mine:
-            out = renderer.render(cams[i].to(dev), frame_model(i), renderer.PipelineParams, bg)
+            out = renderer.render(cams_dev[i], frame_model(i), renderer.PipelineParams, bg)
             # (the maps are per-call buffers: the next frame's placement rewrites the scene buffers, not them)
             writer.submit(cams[i].image_name or f"{i:05d}", out)
     torch.cuda.synchronize()
