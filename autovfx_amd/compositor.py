@@ -111,3 +111,95 @@ def composite_frame(bg_c, o_c, o_d, s_c, s_d, o_s_c, o_gs_c=None, o_gs_d=None, s
     if rc != 0:
         raise RuntimeError(f"gsr_composite failed ({rc}): {_lib.last_error()}")
     return out
+
+
+# ---- blend_all.blend_frames, the function scene_representation.py:232 calls ---------------------------------------------------
+
+def load_rgb(path):
+    """``blend_all.load_rgb`` (:56-60): RGBA8 ``[H,W,4]`` or None when the layer does not exist.  PNG decoding is a host library's job
+    (Pillow, as in the reference)."""
+    import os
+    if not os.path.exists(path):
+        return None
+    import numpy as np
+    from PIL import Image
+    return np.array(Image.open(path).convert("RGBA"))
+
+
+def load_depth_exr(path):
+    """``blend_all.load_depth_exr`` (:70-75): the first channel of Blender's OpenEXR depth pass, through OpenCV as in the reference
+    (``OPENCV_IO_ENABLE_OPENEXR=1``).  OpenCV is an optional dependency of this function only."""
+    import os
+    if not os.path.exists(path):
+        return None
+    os.environ.setdefault("OPENCV_IO_ENABLE_OPENEXR", "1")
+    try:
+        import cv2
+    except ImportError as e:
+        raise RuntimeError(f"{path}: reading Blender's EXR depth passes needs OpenCV (cv2), as blender/blend_all.py does") from e
+    d = cv2.imread(path, cv2.IMREAD_ANYCOLOR | cv2.IMREAD_ANYDEPTH)
+    return d[:, :, 0]
+
+
+def blend_frames(blend_results_dir, input_config_path=None, device=None, write_video=True):
+    """Drop-in for ``blender/blend_all.py::blend_frames`` (:95-346; called at ``scene_representation.py:232``): same arguments, same
+    files found the same way (the 3DGS frames under ``<root>/images/*.png``, Blender's layers under
+    ``<blender_cache_dir>/<output_dir_name>/{rgb,depth}_*``, the frame count from ``rgb_all/*.png``), same outputs
+    (``<blend_results_dir>/frames/%04d.png`` and, when ``imageio`` / ``skimage`` are importable, ``blended.mp4``).  What happens
+    between loading and saving runs on the GPU: the smoke-depth fill, PIL's resizes of every Blender layer to the frame's size
+    (``resize_rgba8`` / ``resize_depth``), the per-pixel composite (``gsr_composite``) and the PNG encoding of the result
+    (``gsr_png_encode``: stored-deflate files holding the same pixels as ``Image.fromarray(frame).save``).  Decoding PNG / EXR
+    stays on the host, in the libraries the reference uses.  Returns the list of frame paths."""
+    import glob
+    import json
+    import os
+    import numpy as np
+    from . import frame_io
+    root_dir = os.path.dirname(os.path.normpath(os.path.dirname(os.path.normpath(blend_results_dir))))   # up two levels (:97)
+    assert input_config_path is not None, "input_config is required for blending frames"
+    with open(input_config_path, "r") as f:
+        input_config = json.load(f)
+    cache = os.path.join(input_config["blender_cache_dir"], input_config["output_dir_name"])
+    bg_rgb = sorted(glob.glob(os.path.join(root_dir, "images", "*.png")))
+    n_frame = len(glob.glob(os.path.join(cache, "rgb_all", "*.png")))     # "ensure an output video even if Blender crashes" (:126)
+    out_img_dir = os.path.join(blend_results_dir, "frames")
+    os.makedirs(out_img_dir, exist_ok=True)
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    up = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rgb = lambda kind, i: load_rgb(os.path.join(cache, kind, "{:0>3d}.png".format(i + 1)))
+    exr = lambda kind, i: load_depth_exr(os.path.join(cache, kind, "{:0>3d}".format(i + 1), "Image{:0>4d}.exr".format(i + 1)))
+    paths, host_frames = [], []
+    for i in range(n_frame):
+        bg_c = up(load_rgb(bg_rgb[i]))
+        o_c, o_d = up(rgb("rgb_obj", i)), up(exr("depth_obj", i))
+        s_c, s_d = up(rgb("rgb_shadow", i)), up(exr("depth_shadow", i))
+        o_s_c = up(rgb("rgb_all", i))
+        o_gs_c, o_gs_d = up(rgb("rgb_obj_3dgs", i)), up(exr("depth_obj_3dgs", i))
+        s_f_c, s_f_d = up(rgb("rgb_smoke_fire", i)), up(exr("depth_smoke_fire", i))
+        s_f_c_pre = up(rgb("rgb_smoke_fire_pre", i))
+        if o_gs_c is None:
+            o_gs_d = None
+        if s_f_c is not None:
+            s_f_d = smoke_depth_fill(s_f_c, s_f_d.to(torch.float32))       # on the full-size layers, before the resizes (:207-215)
+        else:
+            s_f_d = s_f_c_pre = None
+        f32 = lambda t: None if t is None else t.to(torch.float32)
+        frame = composite_frame(bg_c, o_c, f32(o_d), s_c, f32(s_d), o_s_c, o_gs_c, f32(o_gs_d), s_f_c, f32(s_f_d), s_f_c_pre)
+        data = frame_io.encode_png_gpu(frame)
+        path = os.path.join(out_img_dir, "{:0>4d}.png".format(i))
+        with open(path, "wb") as f:
+            f.write(data.cpu().numpy().tobytes())
+        paths.append(path)
+        if write_video:
+            host_frames.append(frame.cpu().numpy())
+    if write_video and host_frames:
+        try:   # generate_video_from_frames (:31-54): the reference's own host libraries, when they are there
+            import imageio.v2 as imageio
+            import skimage.transform
+            h, w = host_frames[0].shape[:2]
+            new_h, new_w = h - h % 2, w - w % 2
+            series = [(skimage.transform.resize(fr, (new_h, new_w)) * 255.0).astype(np.uint8) for fr in host_frames]
+            imageio.mimsave(os.path.join(blend_results_dir, "blended.mp4"), series, fps=15, macro_block_size=1)
+        except ImportError:
+            print("[autovfx_amd] blended.mp4 not written: imageio / skimage are not installed (the frames are under " + out_img_dir + ")")
+    return paths

@@ -13,7 +13,10 @@ AutoVFX reaches the rasterizer through two imports (paths under the reference tr
 ``install()`` makes both resolve here:
 
 1. the repository root goes to the front of ``sys.path`` (so ``diff_gaussian_rasterization`` is this one);
-2. every module named ``...gaussian_renderer`` -- already imported or imported later (a ``sys.meta_path`` hook) -- gets its
+2. a module named ``...blend_all`` (``blender/blend_all.py``, imported at ``scene_representation.py:13``) gets its ``blend_frames``
+   replaced by ``autovfx_amd.compositor.blend_frames`` (same arguments, same files in and out; PIL's resizes and the per-pixel
+   composite run on the GPU);
+3. every module named ``...gaussian_renderer`` -- already imported or imported later (a ``sys.meta_path`` hook) -- gets its
    ``render`` replaced by ``autovfx_amd.renderer.render`` (same signature, same result dictionary; the original stays
    reachable as ``<module>.reference_render``), and every already-imported module that holds the original function under
    any name (``from ... import render [as gs_render]``) is rebound too.
@@ -37,6 +40,7 @@ from typing import Callable, List, Optional
 
 _REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _TARGET_LEAF = "gaussian_renderer"
+_BLEND_LEAF = "blend_all"                # blender/blend_all.py: its blend_frames() is called at scene_representation.py:232
 _installed: Optional["_RendererHook"] = None
 patched_modules: List[str] = []          # names of the modules whose ``render`` was replaced (introspection / tests)
 _strict = True                           # install(strict=...): may a failure to load the render path break the importing process?
@@ -44,7 +48,11 @@ _gave_up = False                         # lenient mode: the render path could n
 
 
 def _is_target(fullname: str) -> bool:
-    return fullname == _TARGET_LEAF or fullname.endswith("." + _TARGET_LEAF)
+    return any(fullname == leaf or fullname.endswith("." + leaf) for leaf in (_TARGET_LEAF, _BLEND_LEAF))
+
+
+def _is_blend_module(name: str) -> bool:
+    return name == _BLEND_LEAF or name.endswith("." + _BLEND_LEAF)
 
 
 def _our_render() -> Callable:
@@ -52,8 +60,32 @@ def _our_render() -> Callable:
     return render
 
 
+def _our_blend_frames() -> Callable:
+    from .compositor import blend_frames
+    return blend_frames
+
+
 def _patch_renderer_module(module: types.ModuleType) -> None:
     global _gave_up
+    if _is_blend_module(module.__name__):
+        # the compositing step of the edit loop: ``blend_all.blend_frames(results_dir, cfg_path)`` (scene_representation.py:232) becomes
+        # autovfx_amd.compositor.blend_frames -- same arguments, same files in and out, the resizes and the per-pixel composite on the GPU
+        original = module.__dict__.get("blend_frames")
+        if original is None or (getattr(original, "__module__", None) or "").startswith("autovfx_amd") or _gave_up:
+            return
+        try:
+            ours = _our_blend_frames()
+        except Exception as e:
+            if _strict:
+                raise
+            _gave_up = True
+            sys.stderr.write(f"[autovfx_amd] {module.__name__}.blend_frames left as the reference's: the GPU compositor could not be loaded ({e!r})\n")
+            return
+        module.reference_blend_frames = original
+        module.blend_frames = ours
+        if module.__name__ not in patched_modules:
+            patched_modules.append(module.__name__)
+        return
     original = module.__dict__.get("render")
     if original is None or (getattr(original, "__module__", None) or "").startswith("autovfx_amd"):
         return
@@ -156,4 +188,6 @@ def uninstall() -> None:
         module = sys.modules.get(name)
         if module is not None and hasattr(module, "reference_render"):
             module.render = module.reference_render
+        if module is not None and hasattr(module, "reference_blend_frames"):
+            module.blend_frames = module.reference_blend_frames
     patched_modules.clear()

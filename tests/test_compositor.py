@@ -231,3 +231,80 @@ def test_hip_compositor_takes_blender_resolution_layers(variant, hw, scale):
     got = compositor.composite_frame(**t)
     torch.cuda.synchronize()
     np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def write_blender_tree(root, L, hw, frames=2):
+    """The directory layout blend_frames expects (blend_all.py:118-182), filled with synthetic layers: the 3DGS frames under
+    <scene>/custom_camera_path/images, Blender's passes under <cache>/out/{rgb,depth}_*; EXR depth passes are stood in for by .npy
+    files of the same name stem (the test patches the EXR loader: OpenCV is not part of this image)."""
+    from PIL import Image
+    results = root / "scene" / "custom_camera_path" / "traj" / "exp"
+    results.mkdir(parents=True)
+    images = root / "scene" / "custom_camera_path" / "images"
+    images.mkdir(parents=True)
+    cache = root / "cache" / "out"
+    cfg = root / "cfg.json"
+    cfg.write_text('{"blender_cache_dir": "%s", "output_dir_name": "out"}' % str(root / "cache"))
+    kinds = {"rgb_obj": "o_c", "rgb_shadow": "s_c", "rgb_all": "o_s_c", "rgb_obj_3dgs": "o_gs_c", "rgb_smoke_fire": "s_f_c", "rgb_smoke_fire_pre": "s_f_c_pre"}
+    depths = {"depth_obj": "o_d", "depth_shadow": "s_d", "depth_all": "s_d", "depth_obj_3dgs": "o_gs_d", "depth_smoke_fire": "s_f_d"}   # (depth_all is loaded and resized by the reference, then never used)
+    per_frame = []
+    for i in range(frames):
+        Li = {k: (np.roll(v, 3 * i, axis=1) if isinstance(v, np.ndarray) else v) for k, v in L.items()}
+        Image.fromarray(Li["bg_c"]).save(images / f"{i:05d}.png")
+        for kind, key in kinds.items():
+            if key in Li:
+                (cache / kind).mkdir(parents=True, exist_ok=True)
+                Image.fromarray(Li[key]).save(cache / kind / f"{i + 1:03d}.png")
+        for kind, key in list(depths.items()) + ([("depth_smoke_fire_pre", "s_f_d")] if "s_f_c_pre" in Li else []):   # (resized by the reference with the fire layer, never used)
+            if key in Li:
+                d = cache / kind / f"{i + 1:03d}"
+                d.mkdir(parents=True, exist_ok=True)
+                np.save(d / f"Image{i + 1:04d}.npy", Li[key])
+        per_frame.append(Li)
+    return results, cfg, per_frame
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["plain", "all"])
+def test_blend_frames_drop_in_on_a_directory_tree(tmp_path, monkeypatch, variant):
+    """autovfx_amd.compositor.blend_frames -- what ``blend_all.blend_frames`` becomes after ``autovfx_amd.install()`` -- on a
+    directory tree shaped like the reference's (blend_all.py:118-182), Blender layers at 2x the frame: the frames it writes decode
+    (PIL) to the oracle's composite of the same layers, byte for byte; the frame count follows rgb_all/*.png."""
+    from PIL import Image
+    from autovfx_amd import compositor
+    hw = (54, 96)
+    L = blender_layers(hw, (2, 2), seed=5, with_3dgs=variant == "all", with_smoke=variant == "all", with_fire=variant == "all")
+    results, cfg, per_frame = write_blender_tree(tmp_path, L, hw)
+    monkeypatch.setattr(compositor, "load_depth_exr", lambda p: np.load(p[:-4] + ".npy") if os.path.exists(p[:-4] + ".npy") else None)
+    paths = compositor.blend_frames(str(results), str(cfg), write_video=False)
+    assert [os.path.basename(p) for p in paths] == ["0000.png", "0001.png"]
+    for path, Li in zip(paths, per_frame):
+        got = np.array(Image.open(path))
+        np.testing.assert_array_equal(got, oracle_from_blender_layers(Li, hw), err_msg=path)
+
+
+@needs_reference
+def test_reference_blend_frames_on_the_same_directory_tree(tmp_path):
+    """The reference's own blend_frames (its file discovery, PIL loaders and resizes; only the EXR loader and the video writer
+    patched) on the tree ``write_blender_tree`` writes: its frames equal the oracle path frame by frame -- which is what the GPU
+    drop-in is compared with on the GPU box, where the reference tree does not exist."""
+    from PIL import Image
+    for missing in ("cv2", "imageio", "imageio.v2", "skimage", "skimage.transform"):
+        sys.modules.setdefault(missing, types.ModuleType(missing))
+    sys.modules["imageio"].v2 = sys.modules["imageio.v2"]
+    if BLENDER not in sys.path:
+        sys.path.insert(0, BLENDER)
+    ba = importlib.import_module("blend_all")
+    ba = importlib.reload(ba)     # (another test may have patched its loaders)
+    hw = (54, 96)
+    L = blender_layers(hw, (2, 2), seed=5, with_3dgs=True, with_smoke=True, with_fire=True)
+    results, cfg, per_frame = write_blender_tree(tmp_path, L, hw)
+    (tmp_path / "scene" / "custom_camera_path" / "depth").mkdir()
+    for i in range(len(per_frame)):
+        np.save(tmp_path / "scene" / "custom_camera_path" / "depth" / f"{i:05d}.npy", np.zeros(hw, np.float32))
+    ba.load_depth_exr = lambda p: np.load(p[:-4] + ".npy") if os.path.exists(p[:-4] + ".npy") else None
+    ba.generate_video_from_frames = lambda *a, **k: None
+    ba.blend_frames(str(results), str(cfg))
+    for i, Li in enumerate(per_frame):
+        got = np.array(Image.open(results / "frames" / f"{i:04d}.png"))
+        np.testing.assert_array_equal(got, oracle_from_blender_layers(Li, hw), err_msg=f"frame {i}")

@@ -66,6 +66,26 @@ def test_install_after_import_rebinds_existing_importers(fake_autovfx):
     assert not any(isinstance(f, hook._RendererHook) for f in sys.meta_path)
 
 
+def test_install_patches_blend_all_blend_frames(fake_autovfx, monkeypatch):
+    """``from blender import blend_all`` (scene_representation.py:13) ... ``blend_all.blend_frames(dir, cfg)`` (:232): after install()
+    the attribute is this package's drop-in, the reference's stays reachable, uninstall() puts it back."""
+    pkg = fake_autovfx / "blender"
+    pkg.mkdir()
+    (pkg / "__init__.py").write_text("")
+    (pkg / "blend_all.py").write_text("def blend_frames(blend_results_dir, input_config_path=None):\n    return 'reference'\n")
+    for n in [n for n in sys.modules if n.split(".")[0] == "blender"]:
+        monkeypatch.delitem(sys.modules, n)
+    autovfx_amd.install()
+    from autovfx_amd import compositor
+    mod = importlib.import_module("blender.blend_all")
+    assert mod.blend_frames is compositor.blend_frames and mod.reference_blend_frames("x") == "reference"
+    assert "blender.blend_all" in hook.patched_modules
+    autovfx_amd.uninstall()
+    assert mod.blend_frames("x") == "reference"
+    for n in [n for n in sys.modules if n.split(".")[0] == "blender"]:
+        del sys.modules[n]
+
+
 def test_install_refuses_a_foreign_rasterizer_already_imported(fake_autovfx, monkeypatch):
     foreign = types.ModuleType("diff_gaussian_rasterization")
     foreign.__file__ = "/somewhere/site-packages/diff_gaussian_rasterization/__init__.py"
