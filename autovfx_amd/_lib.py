@@ -25,7 +25,7 @@ GEOM_SLOTS = ("raster", "rgb", "splat_bins", "internal_radii", "depth_order", "p
 BIN_SLOTS = ("point_list", "tile_keys")
 IMG_SLOTS = ("ranges", "n_contrib")
 STAGES = ("preprocess", "depth_sort", "scan", "duplicate", "tile_sort", "ranges", "blend", "colour")
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_SLABS = 8
 FORWARD_INFERENCE = 1
 
@@ -46,6 +46,7 @@ OPT_RADIX_RANK_ACTIVE = 6    # read-only: what the current device uses (1 verifi
 OPT_BLEND_ORDER = 8          # 1 (default): large images are blended longest tile list first inside each XCD's band
 OPT_DEPTH_DROP = 7           # 1 (default): Gaussians that emit nothing leave the depth sort in its first pass
 OPT_BACKWARD_DETERMINISTIC = 10  # 1: per-Gaussian gradient sums in a fixed order (same bits on every run); default 0: float atomics
+OPT_GRAD_SLABS = 11              # 1 (default): a grad-mode forward may be an inference call (depth slabs, deferred colours); the backward walks the slabs
 OPT_RADIX_RANK_FALLBACKS = 9 # read-only: tiles on the current device whose LDS-add ranks failed the order check (re-ranked with ballots)
 
 
@@ -199,6 +200,8 @@ if os.environ.get("GSR_BLEND_ORDER", "") in ("0", "1"):
     lib.gsr_set_option(OPT_BLEND_ORDER, int(os.environ["GSR_BLEND_ORDER"]))
 if os.environ.get("GSR_DEPTH_DROP", "") in ("0", "1"):
     lib.gsr_set_option(OPT_DEPTH_DROP, int(os.environ["GSR_DEPTH_DROP"]))
+if os.environ.get("GSR_GRAD_SLABS", "") in ("0", "1"):
+    lib.gsr_set_option(OPT_GRAD_SLABS, int(os.environ["GSR_GRAD_SLABS"]))
 if os.environ.get("GSR_BACKWARD_DETERMINISTIC", "") in ("0", "1"):   # same gradient bits on every run (include/gsr.h)
     lib.gsr_set_option(OPT_BACKWARD_DETERMINISTIC, int(os.environ["GSR_BACKWARD_DETERMINISTIC"]))
 

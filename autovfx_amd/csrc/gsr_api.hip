@@ -50,7 +50,7 @@ int g_options[GSR_OPT_NUM] = {/*GSR_OPT_TILE_CULL*/ 1, /*GSR_OPT_SLABS*/ 2, /*GS
                               /*GSR_OPT_DEFER_COLOUR*/ 1, /*GSR_OPT_SLAB_MIN_REST*/ 3000000,
                               /*GSR_OPT_RADIX_RANK (kept by gsr_radix.hip)*/ 2, /*GSR_OPT_RADIX_RANK_ACTIVE (read-only)*/ 0,
                               /*GSR_OPT_DEPTH_DROP*/ 1, /*GSR_OPT_BLEND_ORDER*/ 1, /*GSR_OPT_RADIX_RANK_FALLBACKS (read-only)*/ 0,
-                              /*GSR_OPT_BACKWARD_DETERMINISTIC*/ 0};
+                              /*GSR_OPT_BACKWARD_DETERMINISTIC*/ 0, /*GSR_OPT_GRAD_SLABS*/ 1};
 std::atomic<bool> g_timing{false};
 std::atomic<long> g_timing_epoch{0};       // bumped by gsr_set_stage_timing: every thread restarts its record at its next call
 thread_local long g_epoch_seen = -1;
@@ -422,10 +422,15 @@ int backward_impl(int P, int D, int M, int R, const float* background, int width
     for (int i = 0; i < 3; ++i)
         if (h[i].magic != gsr::kArenaMagic || h[i].kind != (uint32_t)i)
             return fail(GSR_ERR_INVALID_ARG, "scratch buffer %d was not produced by gsr_forward", i);
-    if (h[0].count[2] != 1u || h[0].count[3] != 0u)
-        return fail(GSR_ERR_INVALID_ARG, "the forward call was an inference call (GSR_FORWARD_INFERENCE): its lists are cut into "
-                                         "%u depth slabs without the tiles finished early; run the forward without that flag "
-                                         "to differentiate it", h[0].count[2]);
+    // The forward call may have been cut into depth slabs (GSR_FORWARD_INFERENCE: what the binding also makes in grad mode under
+    // GSR_OPT_GRAD_SLABS): the per-pixel pass walks the slabs' list segments back to front.  Pairs a later slab dropped belong to
+    // tiles whose 256 pixels had all stopped: no pixel's last contributor lies behind them, the backward never wanted them.
+    const int S = (int)h[0].count[2];
+    if (S < 1 || S > gsr::kMaxSlabs || h[2].count[3] != (uint32_t)S)
+        return fail(GSR_ERR_INVALID_ARG, "scratch buffers describe %d depth slabs (image arena: %u)", S, h[2].count[3]);
+    if (S > 1 && g_options[GSR_OPT_BACKWARD_DETERMINISTIC] != 0)
+        return fail(GSR_ERR_INVALID_ARG, "GSR_OPT_BACKWARD_DETERMINISTIC needs the scratch of a forward call with ONE list per tile (this one "
+                                         "has %d depth slabs): set the option before the forward call, or make a full call", S);
     if (h[0].count[0] != (uint32_t)P || h[0].count[1] != (uint32_t)R || h[2].count[0] != (uint32_t)width ||
         h[2].count[1] != (uint32_t)height)
         return fail(GSR_ERR_INVALID_ARG, "scratch buffers belong to a different call (P %u/%d, R %u/%d, %ux%u/%dx%d)",
@@ -445,8 +450,12 @@ int backward_impl(int P, int D, int M, int R, const float* background, int width
     const gsr::SplatRaster* raster = (const gsr::SplatRaster*)(bases[0] + h[0].off[0]);
     const float* rgb = (const float*)(bases[0] + h[0].off[3]);
     if (radii == nullptr) radii = (const int*)(bases[0] + h[0].off[4]);
-    const uint32_t* point_list = (const uint32_t*)(bases[1] + h[1].slab_off[0]);
-    const uint2* ranges = (const uint2*)(bases[2] + h[2].slab_off[0]);
+    gsr::BlendSegments segs = {};
+    for (int k = 0; k < S; ++k) {
+        segs.point_list[k] = (const uint32_t*)(bases[1] + h[1].slab_off[k]);
+        segs.ranges[k] = (const uint2*)(bases[2] + h[2].slab_off[k]);
+    }
+    const uint32_t* point_list = segs.point_list[0];   // (the deterministic mode's id sort: one segment)
     const uint32_t* n_contrib = (const uint32_t*)(bases[2] + h[2].off[1]);
     const float* colors = colors_precomp != nullptr ? colors_precomp : rgb;  // rasterizer_impl.cu:399
 
@@ -494,10 +503,10 @@ int backward_impl(int P, int D, int M, int R, const float* background, int width
             float* part1 = (float*)(dbase + off_part);
             uint32_t* bits2 = passes == 2 ? bits1 + bit_words : nullptr;
             float* part2 = passes == 2 ? part1 + (size_t)bound * 40 : nullptr;
-            GSR_DET(gsr::launch_render_backward(cam, ranges, point_list, background, raster, colors, accum_alphas, n_contrib, dL_dpix,
+            GSR_DET(gsr::launch_render_backward(cam, segs, S, background, raster, colors, accum_alphas, n_contrib, dL_dpix,
                                                 dL_dpix_depth, dL_dpix_alpha, accum_scratch, stream, 0, part1, bits1));
             if (rc == GSR_OK && passes == 2)
-                GSR_DET(gsr::launch_render_backward(cam, ranges, point_list, background, raster, normal_colours, accum_alphas, n_contrib,
+                GSR_DET(gsr::launch_render_backward(cam, segs, S, background, raster, normal_colours, accum_alphas, n_contrib,
                                                     dL_dpix_normal, nullptr, nullptr, accum_scratch, stream, 10, part2, bits2));
             if (rc != GSR_OK) break;
             uint32_t *ids_sorted = nullptr, *pos_sorted = nullptr;
@@ -521,10 +530,10 @@ int backward_impl(int P, int D, int M, int R, const float* background, int width
         if (rc != GSR_OK) return rc;
     } else {
     GSR_HIP(hipMemsetAsync(accum_scratch, 0, (size_t)P * 16 * sizeof(float), stream));
-    GSR_HIP(gsr::launch_render_backward(cam, ranges, point_list, background, raster, colors, accum_alphas, n_contrib,
+    GSR_HIP(gsr::launch_render_backward(cam, segs, S, background, raster, colors, accum_alphas, n_contrib,
                                         dL_dpix, dL_dpix_depth, dL_dpix_alpha, accum_scratch, stream));
     if (dL_dpix_normal != nullptr)   // the second feature set's pass: colour sums to slots 10 - 12, geometry sums add to 4 - 9
-        GSR_HIP(gsr::launch_render_backward(cam, ranges, point_list, background, raster, normal_colours,
+        GSR_HIP(gsr::launch_render_backward(cam, segs, S, background, raster, normal_colours,
                                             accum_alphas, n_contrib, dL_dpix_normal, nullptr, nullptr, accum_scratch, stream, 10));
     }
     GSR_STAGE_CHECK("render_backward");

@@ -86,8 +86,7 @@ constexpr int kAccumStride = 16;  // floats per Gaussian in the accumulation scr
 // order: the same bits on every run, on every box.
 template <bool kDepthAlpha, bool kDet>
 __global__ void __launch_bounds__(64, 4) render_backward_kernel(
-    int W, int H, int grid_x, int num_tiles, const uint2* __restrict__ ranges,
-    const uint32_t* __restrict__ point_list, const float* __restrict__ background,
+    int W, int H, int grid_x, int num_tiles, BlendSegments segs, int num_segs, const float* __restrict__ background,
     const SplatRaster* __restrict__ raster, const float* __restrict__ colors, const float* __restrict__ accum_alphas,
     const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_dpixel_depths, const float* __restrict__ dL_dpixel_alphas,
@@ -107,8 +106,13 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
     const size_t pid = (size_t)W * (size_t)py + (size_t)px;
     const size_t plane = (size_t)W * (size_t)H;
 
-    const uint2 range = ranges[tile];
-    const uint32_t count = range.y - range.x;
+    // The tile's list arrives in num_segs front-to-back segments (one per depth slab of the forward call; a full call has one).
+    // A pixel's positions -- n_contrib among them -- count through their concatenation, as the forward blend counted them.
+    uint32_t count = 0u;
+    for (int k = 0; k < num_segs; ++k) {
+        const uint2 r = segs.ranges[k][tile];
+        count += r.y - r.x;
+    }
 
     // forward results for this pixel (backward.cu:459-479)
     // which slot of a Gaussian's accumulation line this lane adds to after the reduce-scatter (see below)
@@ -144,9 +148,16 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
     float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_a = 0.f;  // accum_rec / accum_red / accum_rea, updated eagerly
     const float bg_dot = (background[0] * dLr + background[1] * dLg) + background[2] * dLb;  // left to right
 
-    // back to front: batches of 64 positions, highest first
-    for (uint32_t top = walk; top > 0; top = top > 64 ? top - 64 : 0) {
-        const uint32_t first = top > 64 ? top - 64 : 0;  // batch covers positions [first, top)
+    // back to front: the segments last to first, inside a segment batches of 64 positions, highest first
+    uint32_t seg_end = count;   // concatenated position just behind the segment being walked
+    for (int k = num_segs - 1; k >= 0; --k) {
+    const uint2 range = segs.ranges[k][tile];
+    const uint32_t* __restrict__ point_list = segs.point_list[k];
+    const uint32_t seg_base = seg_end - (range.y - range.x);   // concatenated position of the segment's first entry
+    seg_end = seg_base;
+    if (walk <= seg_base) continue;                            // nobody's last contributor reaches into this segment
+    for (uint32_t top = walk - seg_base < range.y - range.x ? walk - seg_base : range.y - range.x; top > 0; top = top > 64 ? top - 64 : 0) {
+        const uint32_t first = top > 64 ? top - 64 : 0;  // batch covers the segment's positions [first, top)
         const uint32_t e = first + (uint32_t)lane;
         float2 g_xy = make_float2(0.f, 0.f);
         float4 g_co = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -179,7 +190,7 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
         while (todo != 0ull) {
             const int j = 63 - __builtin_clzll(todo);  // highest position first
             todo &= ~(1ull << j);
-            const uint32_t pos = first + (uint32_t)j;
+            const uint32_t pos = seg_base + first + (uint32_t)j;   // concatenated position: what n_contrib counts
             uint32_t entry_offset;  // as in the forward blend: one vector register for the record's three reads
             asm("v_mov_b32 %0, %1" : "=v"(entry_offset) : "s"(j * (int)sizeof(BlendEntry)));
             const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_entry) + entry_offset);
@@ -267,7 +278,7 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
             if (my_slot >= 0) {  // ten lanes, one 64-byte line: a single atomic instruction per (quadrant, entry)
                 const float v = red_k == 0 ? x0 : red_k == 1 ? x1 : x2;
                 if (kDet) {
-                    const size_t s = (size_t)range.x + pos;   // position in the sorted list
+                    const size_t s = (size_t)range.x + (pos - seg_base);   // position in the sorted list (deterministic calls have ONE segment)
                     det_partial[(4 * s + (size_t)quad) * 10 + (size_t)(my_slot >= 10 ? my_slot - 10 : my_slot)] = v;
                     if (lane == 0) atomicOr(det_bits + (s >> 3), 1u << (4u * (uint32_t)(s & 7) + (uint32_t)quad));   // (lane 0 has a slot)
                 } else {
@@ -275,6 +286,7 @@ __global__ void __launch_bounds__(64, 4) render_backward_kernel(
                 }
             }
         }
+    }
     }
 #ifdef GSR_KERNEL_TRACE
     if (lane == 0 && g_backward_census != nullptr)
@@ -862,7 +874,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(BackwardArgs g
 
 } // namespace
 
-hipError_t launch_render_backward(const Camera& cam, const uint2* ranges, const uint32_t* point_list,
+hipError_t launch_render_backward(const Camera& cam, const BlendSegments& segs, int num_segs,
                                   const float* background, const SplatRaster* raster, const float* colors,
                                   const float* accum_alphas,
                                   const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,
@@ -871,8 +883,8 @@ hipError_t launch_render_backward(const Camera& cam, const uint2* ranges, const 
     const int T = cam.grid_x * cam.grid_y;
     const bool full = dL_dpix_depth != nullptr && dL_dpix_alpha != nullptr, det = det_partial != nullptr;
 #define GSR_RB_LAUNCH(A, B)                                                                                                       \
-    hipLaunchKernelGGL((render_backward_kernel<A, B>), dim3(4 * T), dim3(64), 0, stream, cam.width, cam.height, cam.grid_x, T, ranges, \
-                       point_list, background, raster, colors, accum_alphas, n_contrib, dL_dpix, full ? dL_dpix_depth : nullptr,      \
+    hipLaunchKernelGGL((render_backward_kernel<A, B>), dim3(4 * T), dim3(64), 0, stream, cam.width, cam.height, cam.grid_x, T, segs, \
+                       num_segs, background, raster, colors, accum_alphas, n_contrib, dL_dpix, full ? dL_dpix_depth : nullptr,      \
                        full ? dL_dpix_alpha : nullptr, accum, colour_slot, det_partial, det_bits)
     if (full && det) GSR_RB_LAUNCH(true, true);
     else if (full) GSR_RB_LAUNCH(true, false);

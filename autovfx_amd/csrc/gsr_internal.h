@@ -287,7 +287,8 @@ struct BackwardInputs {
     float* dL_dsh_rest = nullptr;
     int normal_grads = 0;
 };
-hipError_t launch_render_backward(const Camera& cam, const uint2* ranges, const uint32_t* point_list,
+// segs / num_segs: the per-tile lists of the forward call, one segment per depth slab, front to back (a full call: one)
+hipError_t launch_render_backward(const Camera& cam, const BlendSegments& segs, int num_segs,
                                   const float* background, const SplatRaster* raster, const float* colors,
                                   const float* accum_alphas,
                                   const uint32_t* n_contrib, const float* dL_dpix, const float* dL_dpix_depth,

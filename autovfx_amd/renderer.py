@@ -88,7 +88,7 @@ class _RasterizeRaw(torch.autograd.Function):
     def forward(ctx, xyz, log_scales, rotations, opacity_logits, features_dc, features_rest, means2D, settings):
         from diff_gaussian_rasterization import _C
         s = settings
-        inference = not any(ctx.needs_input_grad)
+        inference = not any(ctx.needs_input_grad) or _C.grad_slabs()   # (GSR_OPT_GRAD_SLABS: the backward walks the slabs' segments)
         (n, color, depth, alpha, radii, geom, binning, image, normal) = _C.rasterize_gaussians_raw(
             s.bg, xyz, log_scales, rotations, opacity_logits, features_dc, features_rest, s.scale_modifier, s.viewmatrix, s.projmatrix,
             s.tanfovx, s.tanfovy, s.image_height, s.image_width, s.sh_degree, s.campos, s.prefiltered, s.debug, want_normal=True,

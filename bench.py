@@ -1213,6 +1213,28 @@ def backward_iteration(key, device, steps=12, parity=True):
                                                       "frac_of_hbm_peak_moved": round(pb_moved / max(1e-9, bw_k["preprocess_backward"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                                       "bound": "hbm"}},
            "timed_calls": bw_k["calls"]}
+    out["forward_call"] = "inference call (GSR_OPT_GRAD_SLABS: depth slabs, SH colours only for listed splats; the backward walks the slabs)" \
+        if _lib.get_option(_lib.OPT_GRAD_SLABS) else "full call"
+    out["forward_slab_pairs"] = _C.last_layout()["slab_pairs"]
+    # the same iteration with the forward as a FULL call (GSR_OPT_GRAD_SLABS = 0: every live pair sorted, SH for every visible splat)
+    try:
+        _lib.set_option(_lib.OPT_GRAD_SLABS, 0)
+        for i in range(3):
+            it(i)
+        torch.cuda.synchronize()
+        timers = []
+        t0 = time.perf_counter()
+        for i in range(steps):
+            it(5 + i, timers)
+        torch.cuda.synchronize()
+        el_f = time.perf_counter() - t0
+        out["with_full_call_forward"] = {"ms_per_iter": round(el_f / steps * 1e3, 3),
+                                         "forward_plus_loss_ms": round(sum(a.elapsed_time(b_) for a, b_, _ in timers) / len(timers), 3),
+                                         "backward_ms": round(sum(b_.elapsed_time(c) for _, b_, c in timers) / len(timers), 3)}
+    except Exception as e:
+        out["with_full_call_forward"] = {"error": repr(e)[:200]}
+    finally:
+        _lib.set_option(_lib.OPT_GRAD_SLABS, 1)
     # GSR_OPT_BACKWARD_DETERMINISTIC: what a fixed summation order costs, and that it is one (the same frame twice: same bits)
     try:
         _lib.set_option(_lib.OPT_BACKWARD_DETERMINISTIC, 1)

@@ -166,6 +166,12 @@ def last_layout() -> dict:
     return lay
 
 
+def grad_slabs() -> bool:
+    """May a forward call that will be differentiated be an inference call (include/gsr.h: GSR_OPT_GRAD_SLABS)?  Not while the
+    deterministic backward is requested: that mode sorts one list per tile."""
+    return _lib.get_option(_lib.OPT_GRAD_SLABS) != 0 and _lib.get_option(_lib.OPT_BACKWARD_DETERMINISTIC) == 0
+
+
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
                         prefiltered, debug, *, inference: bool = False

@@ -75,7 +75,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                        s.sh_degree, s.campos, s.prefiltered, s.debug)
         # Nothing upstream wants a gradient (torch.no_grad(), or plain tensors): the binding may say so, and the library
         # then builds its lists the cheaper way (include/gsr.h: GSR_FORWARD_INFERENCE); same images, same radii.
-        inference = not any(ctx.needs_input_grad)
+        # ... and a call that WILL be differentiated may be built that way too (GSR_OPT_GRAD_SLABS): the backward walks the depth
+        # slabs' list segments; only the deterministic backward needs one list per tile, i.e. a full call.
+        inference = not any(ctx.needs_input_grad) or _C.grad_slabs()
         forward_fn = functools.partial(_C.rasterize_gaussians, inference=inference)
         (num_rendered, color, depth, alpha, radii, geom_buffer, binning_buffer, img_buffer) = _call_with_snapshot(
             forward_fn, native_args, s.debug, _SNAPSHOT_FW, "forward")

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 10
+#define GSR_ABI_VERSION 11
 
 #if defined(__GNUC__)
 #define GSR_API __attribute__((visibility("default")))
@@ -523,6 +523,14 @@ typedef enum gsr_option {
      * ascending (tile, quadrant) order.  Costs 160 bytes of pool memory per live pair for the duration of the call (taken
      * with hipMallocAsync on the call's stream: not capturable into a graph) and ~25 % of a training iteration at C3. */
     GSR_OPT_BACKWARD_DETERMINISTIC = 10,
+    /* [1] A hint for BINDINGS (the library itself only stores it): a forward call whose result WILL be differentiated may still be
+     * made as an inference call (GSR_FORWARD_INFERENCE: depth slabs with occlusion culling between them, SH colours only for
+     * listed splats) -- gsr_backward / gsr_backward_raw accept such a call's scratch and walk the slabs' list segments back to
+     * front (a pair a later slab dropped belongs to a tile whose pixels had all stopped: no gradient flows through it).  Same
+     * images, same gradients up to the order of the atomic sums; the training forward pays for the pairs and colours it uses
+     * instead of all of them.  This repository's Python binding follows the hint unless GSR_OPT_BACKWARD_DETERMINISTIC is set
+     * (that mode sorts ONE list per tile).  0: grad-mode forward calls are full calls, as before round 5. */
+    GSR_OPT_GRAD_SLABS = 11,
     GSR_OPT_NUM
 } gsr_option;
 GSR_API int gsr_set_option(int option, int value);

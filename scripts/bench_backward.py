@@ -17,7 +17,8 @@ ap.add_argument("--reference", action="store_true",
                 help="time the REFERENCE's own forward+backward kernels compiled for gfx950 (oracle/_ref/libgsr_ref_hip.so)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
-cfg = {"c2": (scenes.config_c2, 960, 540, 200), "c3": (scenes.config_c3, 1920, 1080, 800)}[args.workload]
+cfg = {"c2": (scenes.config_c2, 960, 540, 200), "c3": (scenes.config_c3, 1920, 1080, 800),
+       "heavy": (scenes.config_heavy, 960, 540, 200), "heavy1080": (scenes.config_heavy, 1920, 1080, 200)}[args.workload]
 cloud = cfg[0]().to(dev)
 cams = [c.to(dev) for c in orbit_cameras(cfg[3], cfg[1], cfg[2])[:args.steps + 5]]
 bg = torch.zeros(3, device=dev)

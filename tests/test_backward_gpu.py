@@ -28,7 +28,11 @@ from test_parity_gpu import report
 pytestmark = pytest.mark.gpu
 
 
-MODES = ("atomic", "deterministic")
+# atomic / deterministic: the forward is a FULL call (one list per tile; its scratch is decoded and compared with the oracle's lists);
+# slabs: the forward is an inference call cut into as many depth slabs as the scene gives (GSR_OPT_GRAD_SLABS, what the binding
+# does by default in grad mode -- here with slabs small enough that even these scenes are cut up) and the backward walks the
+# slabs' segments; float atomics.
+MODES = ("atomic", "deterministic", "slabs")
 
 
 def hip_backward(cloud, cam, pg, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, sh_degree=None, cov3D_precomp=None,
@@ -53,6 +57,11 @@ def hip_backward(cloud, cam, pg, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, sh_degr
         kw["scales"], kw["rotations"] = scales, rots
     _lib.set_option(_lib.OPT_TILE_CULL, 1 if cull else 0)
     _lib.set_option(_lib.OPT_BACKWARD_DETERMINISTIC, 1 if mode == "deterministic" else 0)
+    _lib.set_option(_lib.OPT_GRAD_SLABS, 1 if mode == "slabs" else 0)
+    if mode == "slabs":
+        _lib.set_option(_lib.OPT_SLABS, 0)
+        _lib.set_option(_lib.OPT_SLAB_FIRST, 6)
+        _lib.set_option(_lib.OPT_SLAB_MIN_REST, 0)
     try:
         color, depth, alpha, radii = GaussianRasterizer(st)(means3D=means3D, means2D=means2D, opacities=opac, shs=shs,
                                                             colors_precomp=colors, **kw)
@@ -61,7 +70,10 @@ def hip_backward(cloud, cam, pg, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, sh_degr
         from diff_gaussian_rasterization import _C
         torch.cuda.synchronize()
         saved = color.grad_fn.saved_tensors   # (.., radii, sh, geom, binning, image, alpha): __init__.py save_for_backward
-        fwd = decode_scratch(_C.last_layout(), saved[7], saved[8], saved[9], cloud.P, cam.image_width, cam.image_height) if cloud.P else {}
+        if mode == "slabs":
+            fwd = {"slab_pairs": _C.last_layout()["slab_pairs"]} if cloud.P else {}
+        else:
+            fwd = decode_scratch(_C.last_layout(), saved[7], saved[8], saved[9], cloud.P, cam.image_width, cam.image_height) if cloud.P else {}
         t = lambda a: torch.from_numpy(a).to(device)
         loss = (color * t(pg["dL_dcolor"])).sum() + (depth * t(pg["dL_ddepth"])).sum() + (alpha * t(pg["dL_dalpha"])).sum()
         loss.backward()
@@ -69,11 +81,15 @@ def hip_backward(cloud, cam, pg, bg=(0.0, 0.0, 0.0), scale_modifier=1.0, sh_degr
     finally:
         _lib.set_option(_lib.OPT_TILE_CULL, 1)
         _lib.set_option(_lib.OPT_BACKWARD_DETERMINISTIC, 0)
+        _lib.set_option(_lib.OPT_GRAD_SLABS, 1)
+        _lib.set_option(_lib.OPT_SLABS, 2)
+        _lib.set_option(_lib.OPT_SLAB_FIRST, 400)
+        _lib.set_option(_lib.OPT_SLAB_MIN_REST, 3000000)
     g = lambda x: None if x is None or x.grad is None else x.grad.cpu().numpy()
     return {"color": color.detach().cpu().numpy(), "depth": depth.detach().cpu().numpy(), "alpha": alpha.detach().cpu().numpy(),
             "dL_dmeans3D": g(means3D), "dL_dmeans2D": g(means2D),
             "dL_dopacity": g(opac), "dL_dsh": g(shs), "dL_dcolors": g(colors), "dL_dscales": g(scales),
-            "dL_drotations": g(rots), "dL_dcov3D": g(cov), "radii": radii.cpu().numpy(), "fwd": fwd, "cull": cull}
+            "dL_drotations": g(rots), "dL_dcov3D": g(cov), "radii": radii.cpu().numpy(), "fwd": fwd, "cull": cull, "mode": mode}
 
 
 def assert_forward_state(name, hip, fref):
@@ -88,7 +104,9 @@ def assert_forward_state(name, hip, fref):
     V = int(vis.sum())
     ids = np.nonzero(vis)[0]
     expect = ids[np.lexsort((ids, fref["depths"][ids].view(np.uint32)))]
-    if not hip["cull"]:
+    if hip.get("mode") == "slabs":
+        pass   # (an inference call's scratch: its lists are compared with the full call's at every parity case of test_parity_gpu.py)
+    elif not hip["cull"]:
         np.testing.assert_array_equal(f["depth_order"][:V], expect.astype(np.uint32), err_msg=f"{name}: depth order")
         np.testing.assert_array_equal(f["point_list"], fref["point_list"], err_msg=f"{name}: point_list")
         np.testing.assert_array_equal(f["ranges"], fref["ranges"], err_msg=f"{name}: ranges")
@@ -363,10 +381,13 @@ def test_backward_sh_degree_four_with_25_coefficients_leaves_higher_bands_zero()
     np.testing.assert_array_equal(a["color"], b["color"])
 
 
-def test_backward_rejects_the_scratch_of_an_inference_call():
-    """An inference call (GSR_FORWARD_INFERENCE) may cut its lists into depth slabs and drop finished tiles' pairs: its
-    scratch cannot be differentiated, and gsr_backward says so instead of reading lists that are not there.  (The
-    autograd Function only makes inference calls when no input requires a gradient, so this needs the raw binding.)"""
+def test_backward_accepts_the_scratch_of_an_inference_call_and_the_deterministic_mode_says_what_it_needs():
+    """Round 5 (GSR_OPT_GRAD_SLABS): an inference call (GSR_FORWARD_INFERENCE) cuts its lists into depth slabs and drops finished
+    tiles' pairs -- pairs behind every pixel's last contributor, which the backward never visits -- and gsr_backward walks the slabs'
+    segments back to front: the gradients equal those of a full call's scratch up to the order of the atomic sums (a
+    well-conditioned scene: 1e-5 of each array's scale).  The deterministic backward sorts ONE list per tile: handed a
+    multi-slab scratch it says so instead of reading lists that are laid out differently."""
+    from autovfx_amd import _lib
     from diff_gaussian_rasterization import _C
     dev = "cuda:0"
     cloud, cam = scenes.config_c1(P=3000, seed=4), scenes.c1_camera(96, 64)
@@ -376,19 +397,34 @@ def test_backward_rejects_the_scratch_of_an_inference_call():
     fwd_args = (st.bg, c.means3D, e, c.opacities, c.scales, c.rotations, 1.0, e, st.viewmatrix, st.projmatrix, st.tanfovx,
                 st.tanfovy, st.image_height, st.image_width, c.shs, st.sh_degree, st.campos, False, False)
     _C.set_geometry_cache(False)
+    _lib.set_option(_lib.OPT_SLABS, 0)
+    _lib.set_option(_lib.OPT_SLAB_FIRST, 6)
+    _lib.set_option(_lib.OPT_SLAB_MIN_REST, 0)
+    grads = {}
     try:
         for inference in (True, False):
             n, color, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians(*fwd_args, inference=inference)
+            slabs = len(_C.last_layout()["slab_pairs"])
+            assert slabs > 1 if inference else slabs == 1
             bw = lambda: _C.rasterize_gaussians_backward(
                 st.bg, c.means3D, radii, e, c.scales, c.rotations, 1.0, e, st.viewmatrix, st.projmatrix, st.tanfovx, st.tanfovy,
                 torch.ones_like(color), torch.zeros_like(depth), torch.zeros_like(alpha), c.shs, st.sh_degree, st.campos, geom, n,
                 binning, img, alpha, False)
+            grads[inference] = [g.clone() for g in bw()]
+            torch.cuda.synchronize()
             if inference:
-                with pytest.raises(RuntimeError, match="inference call"):
-                    bw()
-            else:
-                grads = bw()
-                torch.cuda.synchronize()
-                assert torch.isfinite(grads[3]).all() and float(grads[3].abs().sum()) > 0   # dL_dmeans3D
+                _lib.set_option(_lib.OPT_BACKWARD_DETERMINISTIC, 1)
+                try:
+                    with pytest.raises(RuntimeError, match="ONE list per tile"):
+                        bw()
+                finally:
+                    _lib.set_option(_lib.OPT_BACKWARD_DETERMINISTIC, 0)
+        for a, b in zip(grads[True], grads[False]):
+            if a.numel():
+                assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9
+        assert float(grads[True][3].abs().sum()) > 0   # dL_dmeans3D
     finally:
         _C.set_geometry_cache(None)
+        _lib.set_option(_lib.OPT_SLABS, 2)
+        _lib.set_option(_lib.OPT_SLAB_FIRST, 400)
+        _lib.set_option(_lib.OPT_SLAB_MIN_REST, 3000000)

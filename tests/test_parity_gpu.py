@@ -322,10 +322,13 @@ def test_one_and_a_half_billion_pairs_full_and_inference_calls_agree():
     big = GaussianCloud(means, torch.full((P, 1), 0.5), torch.full((P, 3), 40.0), rot, None, torch.rand(P, 3, generator=g), 0).to(dev)
     st = settings_for(cam, dev, (0.0, 0.0, 0.0), 1.0, 0)
     kw = dict(opacities=big.opacities, colors_precomp=big.colors_precomp, scales=big.scales, rotations=big.rotations)
+    from autovfx_amd import _lib
     try:
-        m = big.means3D.clone().requires_grad_(True)          # a full call: everything is kept for a backward
+        _lib.set_option(_lib.OPT_GRAD_SLABS, 0)               # (by default a grad-mode forward is an inference call too, since round 5)
+        m = big.means3D.clone().requires_grad_(True)          # a full call: every live pair expanded and sorted
         full = [t.detach() for t in GaussianRasterizer(st)(means3D=m, means2D=torch.zeros_like(m), **kw)]
         counts_full = dict(_C.last_layout()["counts"])
+        _lib.set_option(_lib.OPT_GRAD_SLABS, 1)
         with torch.no_grad():
             inf = list(GaussianRasterizer(st)(means3D=big.means3D, means2D=torch.zeros_like(big.means3D), **kw))
         counts_inf = dict(_C.last_layout()["counts"])
@@ -336,6 +339,7 @@ def test_one_and_a_half_billion_pairs_full_and_inference_calls_agree():
             assert torch.equal(a, b), name
         assert float(full[2].min()) > 0.999 and bool((full[3] > 0).all())
     finally:
+        _lib.set_option(_lib.OPT_GRAD_SLABS, 1)
         del big
         torch.cuda.empty_cache()
 

@@ -212,3 +212,12 @@ def test_c3_full_size_iteration_gradients():
     _, again = run(m, cam, bg, wts, True, ("render",))
     for k, v in fused.items():   # GSR_OPT_BACKWARD_DETERMINISTIC at BASELINE configs[2]: the same bits twice
         assert v is None or torch.equal(v, again[k]), f"{k}: two deterministic runs differ"
+    # the default mode: float atomics, and (GSR_OPT_GRAD_SLABS) the forward an inference call in two depth slabs whose segments the
+    # backward walks -- same images bit for bit, gradients against the same truth
+    slab_out, slab_fused = run(m, cam, bg, wts, True, ("render",), mode="atomic")
+    from diff_gaussian_rasterization import _C
+    assert len(_C.last_layout()["slab_pairs"]) == 2, "C3 in grad mode should be cut into two depth slabs"
+    for k in ("render", "depth", "radii"):
+        assert torch.equal(slab_out[k], ref_out[k]), k
+    _, slab_ref = run(m, cam, bg, wts, False, ("render",), mode="atomic")
+    compare_with_truth("c3_full", m, cam, bg, wts, ("render",), slab_fused, slab_ref, "atomic+slabs")
