@@ -1169,13 +1169,18 @@ def backward_iteration(key, device, steps=12, parity=True):
         it(i)
     live = _C.last_layout()["counts"]["live_pairs"]
     torch.cuda.synchronize()
-    _lib.set_stage_timing(True)
     timers = []
     t0 = time.perf_counter()
     for i in range(steps):
         it(5 + i, timers)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    # the two backward kernels by the library's own events, in a pass of their own: the per-stage events of a timed call (five per depth
+    # slab) are not part of the iteration that is reported above
+    _lib.set_stage_timing(True)
+    for i in range(steps):
+        it(5 + i, [])
+    torch.cuda.synchronize()
     bw_k = _lib.backward_times_ms()
     _lib.set_stage_timing(False)
     fw = sum(a.elapsed_time(b_) for a, b_, _ in timers) / len(timers)
