@@ -79,6 +79,9 @@ def _getters_are_one_class_s(cls) -> bool:
 # Same values forward (bit-identical images), gradients within the tolerance of sums formed with atomics
 # (tests/test_raw_autograd_gpu.py).  False: the reference's structure (PyTorch activations, two rasterizer calls).
 RAW_AUTOGRAD = True
+# True: in grad mode the normal and pseudo-normal maps take their values from the fused kernel and build their autograd graph only
+# when a gradient actually arrives for them (_NormalMaps).  False: the PyTorch expressions run in every forward.
+LAZY_NORMAL_GRADIENTS = True
 
 
 class _RasterizeRaw(torch.autograd.Function):
@@ -94,23 +97,73 @@ class _RasterizeRaw(torch.autograd.Function):
             s.tanfovx, s.tanfovy, s.image_height, s.image_width, s.sh_degree, s.campos, s.prefiltered, s.debug, want_normal=True,
             inference=inference)
         ctx.settings, ctx.num_rendered = s, n
-        ctx.save_for_backward(xyz, log_scales, rotations, opacity_logits, features_dc, features_rest, radii, geom, binning, image, alpha)
+        # colour and alpha are planes of ONE output buffer: the node hands out that buffer as the [4,H,W] RGBA image render() returns
+        # (the reference's torch.cat((rendered, alpha)), :186, without the copy and without the concat's graph node)
+        rgba = _C.rgba_planes(color, alpha)
+        ctx.save_for_backward(xyz, log_scales, rotations, opacity_logits, features_dc, features_rest, radii, geom, binning, image, rgba)
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)   # an image the loss never read arrives as None: its pass / terms are skipped
-        return color, depth, alpha, radii, normal
+        return rgba, depth, radii, normal
 
     @staticmethod
-    def backward(ctx, g_color, g_depth, g_alpha, _g_radii, g_normal):
+    def backward(ctx, g_rgba, g_depth, _g_radii, g_normal):
         from diff_gaussian_rasterization import _C
-        if g_color is None and g_depth is None and g_alpha is None and g_normal is None:
+        if g_rgba is None and g_depth is None and g_normal is None:
             return (None,) * 8
         s = ctx.settings
-        xyz, log_scales, rotations, opacity_logits, features_dc, features_rest, radii, geom, binning, image, alpha = ctx.saved_tensors
+        xyz, log_scales, rotations, opacity_logits, features_dc, features_rest, radii, geom, binning, image, rgba = ctx.saved_tensors
+        alpha = rgba[3:4]
+        g_color = g_alpha = None
+        if g_rgba is not None:
+            g_rgba = g_rgba.contiguous()
+            g_color, g_alpha = g_rgba[:3], g_rgba[3:4]
         g2d, gxyz, gls, grot, gop, gdc, grest = _C.rasterize_gaussians_raw_backward(
             s.bg, xyz, log_scales, rotations, opacity_logits, features_dc, features_rest, radii, s.scale_modifier, s.viewmatrix,
             s.projmatrix, s.tanfovx, s.tanfovy, g_color, g_depth, g_alpha, g_normal, s.sh_degree, s.campos, geom, ctx.num_rendered,
             binning, image, alpha, s.debug)
         return gxyz, gls, grot, gop, gdc, grest, g2d, None
+
+
+def _normal_maps_torch(normal_image, depth_image, c2w, h, w, fx, fy):
+    """The reference's per-pixel post-processing (gaussian_renderer/__init__.py:186-208) as PyTorch expressions."""
+    normal = (normal_image - 0.5) * 2.0
+    normal = torch.nn.functional.normalize(normal.permute(1, 2, 0), p=2, dim=-1)
+    directions = get_ray_directions(h, w, fx, fy, w / 2, h / 2, depth_image.device)
+    rays_d = directions @ c2w[:3, :3].T
+    rays_o = c2w[:3, 3].expand_as(rays_d)
+    return normal, depth_pcd2normal(rays_o + rays_d * depth_image.unsqueeze(-1))
+
+
+class _NormalMaps(torch.autograd.Function):
+    """The normal map and the pseudo-normal map of a grad-mode ``render()``: VALUES from the fused kernel the inference path uses
+    (``gsr_normal_maps``: the same formulas in the same order, ``torch.equal`` to the PyTorch expressions -- tests/test_raw_gpu.py),
+    GRADIENTS, if the loss ever asks for them, by re-running the PyTorch expressions under autograd in ``backward``.  The
+    reference's training losses read ``render`` only (scene_representation.py:507-510, train.py:84-134): they used to pay ~15
+    PyTorch launches and their graph per iteration for two maps nobody differentiated."""
+
+    @staticmethod
+    def forward(ctx, normal_image, depth_image, c2w, h, w, fx, fy):
+        ctx.save_for_backward(normal_image, depth_image, c2w)
+        ctx.dims = (h, w, fx, fy)
+        ctx.set_materialize_grads(False)   # a map the loss never read arrives as None
+        normal, pseudo = _fused_normal_maps(normal_image.detach(), depth_image.detach(), c2w, fx, fy, w / 2, h / 2)
+        return normal, pseudo
+
+    @staticmethod
+    def backward(ctx, g_normal, g_pseudo):
+        normal_image, depth_image, c2w = ctx.saved_tensors
+        h, w, fx, fy = ctx.dims
+        with torch.enable_grad():
+            n = normal_image.detach().requires_grad_(True)
+            d = depth_image.detach().requires_grad_(True)
+            normal, pseudo = _normal_maps_torch(n, d, c2w, h, w, fx, fy)
+            outs, grads = [], []
+            if g_normal is not None:
+                outs.append(normal); grads.append(g_normal)
+            if g_pseudo is not None:
+                outs.append(pseudo); grads.append(g_pseudo)
+            gn, gd = torch.autograd.grad(outs, [n, d], grads, allow_unused=True) if outs else (None, None)
+        return gn, gd, None, None, None, None, None
 
 
 def raw_parameters(pc):
@@ -271,7 +324,9 @@ def _render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_col
 
     xyz = pc.get_xyz
     if torch.is_grad_enabled():
-        screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True) + 0
+        # (the reference writes ``torch.zeros_like(..., requires_grad=True) + 0`` and retain_grad(): a zero fill, an add and a graph
+        # node per frame for a tensor that is only ever read through ``.grad``; a zero leaf carries the same values and the same .grad)
+        screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True)
     else:   # only ever read through its gradient (densification statistics): without autograd it is P x 3 zeros that
         # nobody reads, returned as a broadcast view instead of a fresh 12-byte-per-Gaussian fill per frame
         screenspace_points = torch.zeros((1, 1), dtype=xyz.dtype, device=xyz.device).expand(xyz.shape)
@@ -302,15 +357,12 @@ def _render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_col
     if raw is not None and torch.is_grad_enabled():
         # one differentiable rasterizer call from the raw tensors; the per-pixel post-processing stays in PyTorch (:186-208),
         # so whatever the loss reads -- RGBA, depth, normal map, pseudo normals -- carries its gradient back
-        rendered, depth_image, alpha_image, radii, normal_image = _RasterizeRaw.apply(*raw, screenspace_points, settings)
-        rendered_image = torch.cat((rendered, alpha_image), dim=0)
+        rendered_image, depth_image, radii, normal_image = _RasterizeRaw.apply(*raw, screenspace_points, settings)
         depth_image = depth_image.squeeze(0)
-        normal_image = (normal_image - 0.5) * 2.0
-        normal_image = torch.nn.functional.normalize(normal_image.permute(1, 2, 0), p=2, dim=-1)
-        directions = get_ray_directions(h, w, fx, fy, w / 2, h / 2, depth_image.device)
-        rays_d = directions @ c2w[:3, :3].T
-        rays_o = c2w[:3, 3].expand_as(rays_d)
-        pseudo_normal = depth_pcd2normal(rays_o + rays_d * depth_image.unsqueeze(-1))
+        if LAZY_NORMAL_GRADIENTS:
+            normal_image, pseudo_normal = _NormalMaps.apply(normal_image, depth_image, c2w, h, w, fx, fy)
+        else:
+            normal_image, pseudo_normal = _normal_maps_torch(normal_image, depth_image, c2w, h, w, fx, fy)
         return {"render": rendered_image, "depth": depth_image, "normal": normal_image, "pseudo_normal": pseudo_normal,
                 "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
     if raw is not None:
