@@ -194,17 +194,18 @@ class DynamicScene:
             # An index >= n (or a negative one, a huge offset once cast to uint32) would be an out-of-bounds device read in
             # gsr_place_object_subset.  Host lists are checked here every time; a list that already lives on the GPU -- the fast path
             # of a caller that matched meshes once and keeps the per-frame lists resident -- is checked ONCE (one host read of its
-            # min and max) and remembered by (storage address, length, version counter): the frames after the first pay nothing,
+            # min and max) and remembered by (tensor object, version counter, length): the frames after the first pay nothing,
             # and an in-place edit or a new tensor is checked again.
-            key = (t.data_ptr(), t.numel(), t._version, int(n)) if t.is_cuda else None
+            # The memory is the TENSOR OBJECT's (a weak reference: an address alone could be a recycled allocation).
+            import weakref
             seen = self.__dict__.setdefault("_checked_subsets", {})
-            if key is None or key not in seen:
+            entry = seen.get(id(t)) if t.is_cuda else None
+            if entry is None or entry[0]() is not t or entry[1] != (t._version, t.numel(), int(n)):
                 if int(t.min()) < 0 or int(t.max()) >= n:
                     raise ValueError("subset indices out of range")
-                if key is not None:
-                    if len(seen) >= 4096:
-                        seen.clear()
-                    seen[key] = True
+                if t.is_cuda:
+                    key = id(t)
+                    seen[key] = (weakref.ref(t, lambda _r, key=key, seen=seen: seen.pop(key, None)), (t._version, t.numel(), int(n)))
         return t.to(device=self.device, dtype=torch.int32).contiguous()
 
     def compose_model(self, placements, slot: int = 0) -> FrameModel:

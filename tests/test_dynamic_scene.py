@@ -323,3 +323,30 @@ def test_masked_subsets_are_merged_bit_for_bit_and_render_like_subset_then_merge
         scene.compose([("ball", None, None, None, np.ones(5, bool))])
     with pytest.raises(ValueError, match="untransformed"):
         scene.compose([("ball", None, np.eye(3), 1.0, None)])
+
+
+@pytest.mark.gpu
+def test_resident_subset_index_lists_are_validated_once():
+    """an index list that already lives on the GPU used to reach gsr_place_object_subset unchecked -- an index >= n
+    or a negative one is an out-of-bounds device read.  It is checked now the first time a given list is seen (one host read of
+    its min / max) and remembered by (address, length, version): a bad list raises, a good one is not read back again, and an
+    in-place edit is checked anew."""
+    from autovfx_amd.dynamic_scene import DynamicScene
+    base, objs = models()
+    scene = DynamicScene(base, objs)
+    name = next(iter(objs))
+    n = int(objs[name][0]._xyz.shape[0])
+    good = torch.arange(0, n, 3, dtype=torch.int32, device="cuda")
+    scene.compose([(name, None, None, None, good)])
+    seen = dict(scene._checked_subsets)
+    assert len(seen) == 1                                      # (keyed by the caller's tensor: address, length, version, object size)
+    scene.compose([(name, None, None, None, good)])
+    assert scene._checked_subsets == seen                      # the second frame did not look again
+    for bad_value in (n, -1):
+        bad = good.clone()
+        bad[5] = bad_value
+        with pytest.raises(ValueError, match="out of range"):
+            scene.compose([(name, None, None, None, bad)])
+    good[7] = n + 3                                            # an in-place edit bumps the version: checked again
+    with pytest.raises(ValueError, match="out of range"):
+        scene.compose([(name, None, None, None, good)])
