@@ -1,6 +1,6 @@
 // gsr_frameio.hip -- the frame loop's outputs and the compositor's inputs on the GPU.
 //
-//   png_encode_kernel / png_finish_kernel : an 8-bit RGB / RGBA image that lives on the GPU -> the bytes of its PNG FILE, also on
+//   png_encode_kernel / png_crc_kernel / png_finish_kernel : an 8-bit RGB / RGBA image that lives on the GPU -> the bytes of its PNG FILE, also on
 //       the GPU, so that one device-to-host copy and one write() put a frame on disk.  Replaces, for the reference's per-frame
 //       files (scene_representation.py:425-438: torchvision.utils.save_image, cv2.imwrite x 2), the host-side zlib pass that made
 //       the unchanged trajectory job I/O-bound 28x (round 4: 6.8 ms per 960x540 frame through a 32-thread pool, 0.24 ms to
@@ -68,93 +68,150 @@ struct PngLayout {
     unsigned long long data_at;  // file offset of the IDAT payload (= 41)
     unsigned long long data_len; // 2 + 5 * blocks + N + 4
     unsigned long long file_len;
+    uint32_t crc_init_term;      // 0xFFFFFFFF x^(8 * (4 + data_len)) mod P: the CRC's pre-conditioning as one more linear term (host-computed)
     uint8_t head[48];            // the first data_at bytes of the file: signature, IHDR chunk, IDAT length + type
     uint8_t tail[16];            // the 12 bytes after the IDAT CRC: IEND chunk
 };
 
-// One lane = 16 consecutive, 16-byte aligned bytes of the FILE.
-__global__ void __launch_bounds__(256) png_encode_kernel(PngLayout L, PngTables T, const uint8_t* __restrict__ pixels, uint8_t* __restrict__ out,
+// One lane = 16 consecutive, 16-byte aligned bytes of the FILE: where each byte comes from is worked out once per lane (two 64-bit
+// divisions) and stepped from byte to byte; the CRC is a kernel of its own (below).  Adler-32's two sums are taken here, where the
+// scanline bytes pass through registers anyway.
+__global__ void __launch_bounds__(256) png_encode_kernel(PngLayout L, const uint8_t* __restrict__ pixels, uint8_t* __restrict__ out,
                                                         unsigned long long* __restrict__ sums /*[0] s1, [1] s2, [2] crc (low word); zero on entry*/) {
-    __shared__ uint32_t s_byte[256];
-    __shared__ uint32_t s_x2n[32];
-    for (int i = threadIdx.x; i < 256; i += 256) s_byte[i] = T.byte[i];
-    if (threadIdx.x < 32) s_x2n[threadIdx.x] = T.x2n[threadIdx.x];
-    __syncthreads();
     const unsigned long long first = ((unsigned long long)blockIdx.x * 256ull + threadIdx.x) * 16ull;
     unsigned long long a1 = 0ull, a2 = 0ull;
-    uint32_t crc = 0u;
-    unsigned long long crc_last = 0ull;   // file offset just behind the last byte that entered `crc`
-    bool crc_any = false;
     if (first < L.file_len) {
         const unsigned long long adler_at = L.data_at + L.data_len - 4ull;   // Adler-32, then the chunk's CRC, then IEND
-        const unsigned long long crc_from = L.data_at - 4ull;                // the chunk type "IDAT" is part of the CRC
-        uint32_t words[4] = {0u, 0u, 0u, 0u};
-#pragma unroll 1
+        const unsigned long long stream_at = L.data_at + 2ull;                // first stored block's header
+        // position of this lane's first byte inside the deflate stream, if it is there: (block, offset in the block incl. its 5-byte header),
+        // and for a scanline byte (row, column in the row incl. its filter byte, pixel x, channel)
+        unsigned long long block = 0ull, r = 0ull, row = 0ull;
+        uint32_t off = 0u, col = 0u, x = 0u, ch = 0u;
+        bool placed = false;
+        // Phase 1: where each of the 16 bytes comes from -- a constant, or an address in the image -- without touching the image;
+        // phase 2: the (up to 16) image bytes, all loads in flight together; phase 3: assemble, and the Adler sums.
+        uint32_t konst[16];
+        long long src[16];           // >= 0: index into pixels; -1: konst[k]
+        unsigned long long weight[16];   // N - r for a scanline byte (Adler's second sum), 0 otherwise
+#pragma unroll
         for (int k = 0; k < 16; ++k) {
             const unsigned long long f = first + (unsigned long long)k;
-            if (f >= L.file_len) break;
             uint32_t b = 0u;
-            if (f < L.data_at) {
+            long long from = -1;
+            unsigned long long wgt = 0ull;
+            if (f >= L.file_len) {
+            } else if (f < L.data_at) {
                 b = L.head[f];
             } else if (f >= adler_at) {
                 const unsigned long long t = f - adler_at;
                 b = t < 8ull ? 0u : L.tail[t - 8ull];       // the two checksums are filled in by png_finish_kernel
+            } else if (f < stream_at) {
+                b = f == L.data_at ? 0x78u : 0x01u;         // zlib header: deflate, 32 K window, no dictionary, fastest (FCHECK makes it % 31 == 0)
             } else {
-                const unsigned long long d = f - L.data_at;
-                if (d < 2ull) {
-                    b = d == 0ull ? 0x78u : 0x01u;          // zlib header: deflate, 32 K window, no dictionary, fastest (FCHECK makes it % 31 == 0)
-                } else {
-                    const unsigned long long e = d - 2ull;
-                    const unsigned long long block = e / (kStored + 5ull);
-                    const uint32_t off = (uint32_t)(e - block * (kStored + 5ull));
-                    if (off < 5u) {
-                        const unsigned long long left = L.N - block * kStored;
-                        const uint32_t len = left < kStored ? (uint32_t)left : kStored;
-                        b = off == 0u ? (block + 1ull == L.blocks ? 1u : 0u)
-                          : off == 1u ? (len & 0xFFu) : off == 2u ? (len >> 8) : off == 3u ? (~len & 0xFFu) : ((~len >> 8) & 0xFFu);
-                    } else {
-                        const unsigned long long r = block * kStored + (off - 5u);   // index in the scanline stream
-                        const unsigned long long row = r / L.row_len;
-                        const uint32_t col = (uint32_t)(r - row * L.row_len);
-                        if (col != 0u) {                                            // (col 0: the row's filter type, 0)
-                            const uint32_t x = (col - 1u) / (uint32_t)L.C, ch = (col - 1u) - x * (uint32_t)L.C;
-                            b = L.planar ? pixels[((size_t)ch * L.H + row) * L.W + x] : pixels[(row * L.W + x) * L.C + ch];
-                        }
-                        a1 += b;
-                        a2 += (L.N - r) * b;
-                    }
+                if (!placed) {
+                    const unsigned long long e = f - stream_at;
+                    block = e / (kStored + 5ull);
+                    off = (uint32_t)(e - block * (kStored + 5ull));
+                    placed = true;
+                    r = block * kStored + (off >= 5u ? off - 5u : 0u);   // this scanline byte, or the one that follows the header
+                    row = r / L.row_len;
+                    col = (uint32_t)(r - row * L.row_len);
+                    if (col != 0u) { x = (col - 1u) / (uint32_t)L.C; ch = (col - 1u) - x * (uint32_t)L.C; }
                 }
+                if (off < 5u) {
+                    const unsigned long long left = L.N - block * kStored;
+                    const uint32_t len = left < kStored ? (uint32_t)left : kStored;
+                    b = off == 0u ? (block + 1ull == L.blocks ? 1u : 0u)
+                      : off == 1u ? (len & 0xFFu) : off == 2u ? (len >> 8) : off == 3u ? (~len & 0xFFu) : ((~len >> 8) & 0xFFu);
+                } else {
+                    wgt = L.N - r;
+                    if (col != 0u) {                        // (col 0: the row's filter type, 0)
+                        from = L.planar ? (long long)(((size_t)ch * L.H + row) * L.W + x) : (long long)((row * L.W + x) * L.C + ch);
+                        if (++ch == (uint32_t)L.C) { ch = 0u; ++x; }
+                    }
+                    ++r;
+                    if (++col == L.row_len) { col = 0u; x = 0u; ch = 0u; ++row; }
+                }
+                if (++off == kStored + 5u) { off = 0u; ++block; }
             }
-            words[k >> 2] |= b << (8 * (k & 3));
-            if (f >= crc_from && f < adler_at + 4ull) {   // (the Adler bytes count as zeros here; png_finish_kernel adds their term)
-                crc = s_byte[(crc ^ b) & 0xFFu] ^ (crc >> 8);
-                crc_last = f + 1ull;
-                crc_any = true;
-            }
+            konst[k] = b; src[k] = from; weight[k] = wgt;
+        }
+        uint32_t bytes[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) bytes[k] = src[k] >= 0 ? (uint32_t)pixels[src[k]] : konst[k];
+        uint32_t words[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            words[k >> 2] |= bytes[k] << (8 * (k & 3));
+            if (weight[k] != 0ull) { a1 += bytes[k]; a2 += weight[k] * bytes[k]; }
         }
         if (first + 16ull <= L.file_len) {
             *reinterpret_cast<uint4*>(out + first) = make_uint4(words[0], words[1], words[2], words[3]);
         } else {
             for (unsigned long long f = first; f < L.file_len; ++f) out[f] = (uint8_t)(words[(f - first) >> 2] >> (8 * ((f - first) & 3)));
         }
-        if (crc_any && crc != 0u) crc = crc_multmodp(crc_x2nmodp(s_x2n, (adler_at + 4ull) - crc_last, 3u), crc);   // shift to its place
-        else crc = 0u;
     }
-    // wave sums, one atomic per wave and value (integer adds and XOR: any order, same result)
+    // wave sums, one atomic per wave and value (integer adds: any order, same result)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         a1 += __shfl_xor(a1, d);
         a2 += __shfl_xor(a2, d);
-        crc ^= (uint32_t)__shfl_xor((int)crc, d);
     }
     if ((threadIdx.x & 63) == 0) {
         if (a1 != 0ull) atomicAdd(sums + 0, a1);
         if (a2 != 0ull) atomicAdd(sums + 1, a2 % 65521ull);   // (a wave's s2 can reach 1e13; the running total stays far below 2^64)
-        if (crc != 0u) atomicXor(reinterpret_cast<unsigned int*>(sums + 2), crc);
     }
 }
 
-__global__ void png_finish_kernel(PngLayout L, PngTables T, uint8_t* __restrict__ out, const unsigned long long* __restrict__ sums) {
+// CRC-32 of the IDAT chunk's type + payload, read back from the file image png_encode_kernel just wrote (L2-resident).  One lane =
+// kCrcChunk consecutive file bytes, loaded up front: their raw CRC four bytes at a time (slicing-by-4: four table lookups per word
+// instead of a chain of four), then ONE shift to the lane's place in the message -- x^(8 * bytes behind it) mod P -- and an XOR into
+// the total.
+constexpr uint32_t kCrcChunk = 64u;
+__global__ void __launch_bounds__(256) png_crc_kernel(PngLayout L, PngTables T, const uint8_t* __restrict__ file, unsigned long long* __restrict__ sums) {
+    __shared__ uint32_t s_t[4][256];
+    __shared__ uint32_t s_x2n[32];
+    {
+        const int i = threadIdx.x;
+        const uint32_t t0 = T.byte[i];
+        const uint32_t t1 = (t0 >> 8) ^ T.byte[t0 & 0xFFu];
+        const uint32_t t2 = (t1 >> 8) ^ T.byte[t1 & 0xFFu];
+        s_t[0][i] = t0; s_t[1][i] = t1; s_t[2][i] = t2; s_t[3][i] = (t2 >> 8) ^ T.byte[t2 & 0xFFu];
+        if (i < 32) s_x2n[i] = T.x2n[i];
+    }
+    __syncthreads();
+    const unsigned long long crc_from = L.data_at - 4ull, crc_end = L.data_at + L.data_len;   // "IDAT" ... Adler-32 (still zeros) inclusive
+    const unsigned long long lo0 = ((unsigned long long)blockIdx.x * 256ull + threadIdx.x) * kCrcChunk;
+    uint32_t crc = 0u;
+    if (lo0 < crc_end && lo0 + kCrcChunk > crc_from) {
+        // the lane's 64 bytes in four 16-byte loads, all issued before the first is used (the file image ends with 32 bytes of
+        // scratch behind a 16-byte boundary: reading the whole chunk is always inside the buffer)
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)   // (a 16-byte piece that starts inside the message ends inside the file)
+            v[k] = lo0 + 16u * k < crc_end ? *reinterpret_cast<const uint4*>(file + lo0 + 16u * k) : make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t w[16] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w, v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
+        const unsigned long long lo = lo0 < crc_from ? crc_from : lo0, hi = lo0 + kCrcChunk < crc_end ? lo0 + kCrcChunk : crc_end;
+        if (lo == lo0 && hi == lo0 + kCrcChunk) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t x = crc ^ w[k];
+                crc = s_t[3][x & 0xFFu] ^ s_t[2][(x >> 8) & 0xFFu] ^ s_t[1][(x >> 16) & 0xFFu] ^ s_t[0][x >> 24];
+            }
+        } else {   // the first and the last chunk of the message: byte by byte
+            for (unsigned long long f = lo; f < hi; ++f) {
+                const uint32_t b = (w[(f - lo0) >> 2] >> (8 * ((f - lo0) & 3ull))) & 0xFFu;
+                crc = s_t[0][(crc ^ b) & 0xFFu] ^ (crc >> 8);
+            }
+        }
+        if (crc != 0u && hi < crc_end) crc = crc_multmodp(crc_x2nmodp(s_x2n, crc_end - hi, 3u), crc);   // shift to its place
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) crc ^= (uint32_t)__shfl_xor((int)crc, d);
+    if ((threadIdx.x & 63) == 0 && crc != 0u) atomicXor(reinterpret_cast<unsigned int*>(sums + 2), crc);   // (XOR: any order, same result)
+}
+
+__global__ void png_finish_kernel(PngLayout L, uint8_t* __restrict__ out, const unsigned long long* __restrict__ sums) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const uint32_t s1 = (uint32_t)((1ull + sums[0]) % 65521ull);
     const uint32_t s2 = (uint32_t)((L.N % 65521ull + sums[1]) % 65521ull);
@@ -164,10 +221,10 @@ __global__ void png_finish_kernel(PngLayout L, PngTables T, uint8_t* __restrict_
     for (int k = 0; k < 4; ++k) {
         const uint32_t b = (adler >> (24 - 8 * k)) & 0xFFu;   // big-endian
         out[adler_at + k] = (uint8_t)b;
-        crc_a = T.byte[(crc_a ^ b) & 0xFFu] ^ (crc_a >> 8);
+        crc_a ^= b;
+        for (int i = 0; i < 8; ++i) crc_a = (crc_a & 1u) ? (crc_a >> 1) ^ kCrcPoly : crc_a >> 1;
     }
-    const unsigned long long message = 4ull + L.data_len;     // "IDAT" + payload
-    const uint32_t crc = ((uint32_t)sums[2] ^ crc_a ^ crc_multmodp(crc_x2nmodp(T.x2n, message, 3u), 0xFFFFFFFFu)) ^ 0xFFFFFFFFu;
+    const uint32_t crc = ((uint32_t)sums[2] ^ crc_a ^ L.crc_init_term) ^ 0xFFFFFFFFu;
     for (int k = 0; k < 4; ++k) out[adler_at + 4 + k] = (uint8_t)(crc >> (24 - 8 * k));
 }
 
@@ -205,6 +262,7 @@ bool png_layout(int W, int H, int C, int planar, PngLayout* L) {
     L->data_len = 2ull + 5ull * L->blocks + L->N + 4ull;
     if (L->data_len > 0x7FFFFFFFull) return false;   // one IDAT chunk: a 31-bit length (an image of 2 GB)
     L->file_len = L->data_at + L->data_len + 4ull + 12ull;
+    L->crc_init_term = crc_multmodp(crc_x2nmodp(png_tables().x2n, 4ull + L->data_len, 3u), 0xFFFFFFFFu);
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
     uint8_t* h = L->head;
     for (int i = 0; i < 48; ++i) h[i] = 0;
@@ -466,8 +524,10 @@ hipError_t launch_png_encode(const uint8_t* pixels, int W, int H, int C, int pla
     hipError_t e = hipMemsetAsync(scratch, 0, 32, stream);
     if (e != hipSuccess) return e;
     const unsigned long long lanes = (L.file_len + 15ull) / 16ull;
-    hipLaunchKernelGGL(png_encode_kernel, dim3((unsigned)((lanes + 255ull) / 256ull)), dim3(256), 0, stream, L, png_tables(), pixels, out, scratch);
-    hipLaunchKernelGGL(png_finish_kernel, dim3(1), dim3(64), 0, stream, L, png_tables(), out, scratch);
+    hipLaunchKernelGGL(png_encode_kernel, dim3((unsigned)((lanes + 255ull) / 256ull)), dim3(256), 0, stream, L, pixels, out, scratch);
+    const unsigned long long crc_lanes = (L.file_len + kCrcChunk - 1ull) / kCrcChunk;
+    hipLaunchKernelGGL(png_crc_kernel, dim3((unsigned)((crc_lanes + 255ull) / 256ull)), dim3(256), 0, stream, L, png_tables(), out, scratch);
+    hipLaunchKernelGGL(png_finish_kernel, dim3(1), dim3(64), 0, stream, L, out, scratch);
     return hipGetLastError();
 }
 
