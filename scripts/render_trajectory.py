@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--deflate", action="store_true",
                     help="compress the PNGs on a pool of host threads (zlib level 3) instead of building stored-deflate file images on the GPU")
     ap.add_argument("--writer-threads", type=int, default=4, help="host threads that write() the GPU-built file images")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="frames in flight on as many HIP streams, fed by this one host thread through render_begin / finish (1: one blocking render() per frame)")
     args = ap.parse_args()
 
     rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
@@ -97,15 +99,15 @@ def main():
         if args.rigid_body_json:
             with open(args.rigid_body_json) as f:
                 transforms = json.load(f)
-        scene = DynamicScene(model, objects, device=dev, sh_degree=model.active_sh_degree,
+        scene = DynamicScene(model, objects, device=dev, sh_degree=model.active_sh_degree, slots=max(1, args.streams),
                              placed_sh_degree=None if args.full_sh_on_placed_frames else 0)
 
-    def frame_model(i):
+    def frame_model(i, slot=0):
         if scene is None:
             return model
         key = "{0:03d}".format(i + 1)   # frame index starts from 001 (scene_representation.py:362)
         placed = [(oid, t[key]["pos"], t[key]["rot"], float(t[key]["scale"])) for oid, t in transforms.items() if key in t]
-        return scene.compose_model(placed)
+        return scene.compose_model(placed, slot=slot)   # (a frame in flight keeps its own copy of the scene buffers)
 
     mine = shard_frames(len(cams), rank, world)
     cams_dev = dict(zip(mine, cameras.Camera.batch_to([cams[i] for i in mine], dev)))   # this rank's cameras, uploaded in five copies
@@ -113,16 +115,42 @@ def main():
     # file images built on the GPU (stored-deflate PNGs, checksums in the kernel), host threads only write(); --deflate: the frame
     # crosses as pixels and a pool of host threads compresses it (zlib level 3: files a third of the size, ~30x the host time)
     make_writer = (lambda: frame_io.FrameWriter(args.out)) if args.deflate else (lambda: frame_io.GpuFrameWriter(args.out, workers=args.writer_threads))
+    S = max(1, args.streams)
     with torch.no_grad(), make_writer() as writer:
-        for i in mine:
-            out = renderer.render(cams_dev[i], frame_model(i), renderer.PipelineParams, bg)
-            # (the maps are per-call buffers: the next frame's placement rewrites the scene buffers, not them)
-            writer.submit(cams[i].image_name or f"{i:05d}", out)
+        if S == 1:
+            for i in mine:
+                out = renderer.render(cams_dev[i], frame_model(i), renderer.PipelineParams, bg)
+                # (the maps are per-call buffers: the next frame's placement rewrites the scene buffers, not them)
+                writer.submit(cams[i].image_name or f"{i:05d}", out)
+        else:
+            # S frames in flight from this one thread: a frame's first half (projection, depth sort) is queued on its stream before
+            # the host waits for an older frame's pair count; its second half, the file images and their copy follow on that stream
+            from collections import deque
+            from autovfx_amd.frame_parallel import side_streams
+            side, q = side_streams(dev, S), deque()
+
+            def finish_oldest():
+                st, name, pending = q.popleft()
+                with torch.cuda.stream(st):
+                    writer.submit(name, pending.finish())
+
+            for k, i in enumerate(mine):
+                while len(q) == S:
+                    finish_oldest()
+                st = side[k % S]
+                with torch.cuda.stream(st):
+                    q.append((st, cams[i].image_name or f"{i:05d}",
+                              renderer.render_begin(cams_dev[i], frame_model(i, k % S), renderer.PipelineParams, bg)))
+            while q:
+                finish_oldest()
+            for st in side:
+                torch.cuda.current_stream(dev).wait_stream(st)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(json.dumps({"rank": rank, "frames": len(mine), "seconds": round(dt, 3),
                       "frames_per_s_including_png_encode": round(len(mine) / max(dt, 1e-9), 2),
-                      "writer": "host zlib pool" if args.deflate else f"GPU file images, {args.writer_threads} writer threads"}), flush=True)
+                      "writer": "host zlib pool" if args.deflate else f"GPU file images, {args.writer_threads} writer threads",
+                      "streams": S}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
