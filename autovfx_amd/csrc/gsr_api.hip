@@ -761,14 +761,14 @@ int gsr_frame_files(const float* color, const float* alpha, const float* depth, 
 }
 
 size_t gsr_png_size(int width, int height, int channels) { return gsr::png_file_bytes(width, height, channels); }
+size_t gsr_png_room(int width, int height, int channels) { return gsr::png_room_bytes(width, height, channels); }
 
 int gsr_png_encode(const uint8_t* pixels, int width, int height, int channels, int planar, uint8_t* out, void* stream_) {
     const size_t n = gsr::png_file_bytes(width, height, channels);
     if (n == 0) return fail(GSR_ERR_INVALID_ARG, "gsr_png_encode: %dx%d with %d channels cannot be encoded (3 or 4 channels, < 2 GB)", width, height, channels);
     if (!pixels || !out) return fail(GSR_ERR_INVALID_ARG, "null pointer");
     if ((reinterpret_cast<uintptr_t>(out) & 15u) != 0) return fail(GSR_ERR_INVALID_ARG, "gsr_png_encode: out must be 16-byte aligned");
-    unsigned long long* scratch = reinterpret_cast<unsigned long long*>(out + ((n + 15) & ~size_t(15)));
-    GSR_HIP(gsr::launch_png_encode(pixels, width, height, channels, planar, out, scratch, (hipStream_t)stream_));
+    GSR_HIP(gsr::launch_png_encode(pixels, width, height, channels, planar, out, (hipStream_t)stream_));
     return GSR_OK;
 }
 

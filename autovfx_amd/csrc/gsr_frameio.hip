@@ -69,6 +69,7 @@ struct PngLayout {
     unsigned long long data_len; // 2 + 5 * blocks + N + 4
     unsigned long long file_len;
     uint32_t crc_init_term;      // 0xFFFFFFFF x^(8 * (4 + data_len)) mod P: the CRC's pre-conditioning as one more linear term (host-computed)
+    uint32_t crc_tail_shift;     // x^(8 * ((data_at + data_len) mod 64)) mod P
     uint8_t head[48];            // the first data_at bytes of the file: signature, IHDR chunk, IDAT length + type
     uint8_t tail[16];            // the 12 bytes after the IDAT CRC: IEND chunk
 };
@@ -77,7 +78,8 @@ struct PngLayout {
 // divisions) and stepped from byte to byte; the CRC is a kernel of its own (below).  Adler-32's two sums are taken here, where the
 // scanline bytes pass through registers anyway.
 __global__ void __launch_bounds__(256) png_encode_kernel(PngLayout L, const uint8_t* __restrict__ pixels, uint8_t* __restrict__ out,
-                                                        unsigned long long* __restrict__ sums /*[0] s1, [1] s2, [2] crc (low word); zero on entry*/) {
+                                                        unsigned long long* __restrict__ adler_partials /*[workgroups][2], every entry written*/) {
+    __shared__ unsigned long long s_sum[4][2];
     const unsigned long long first = ((unsigned long long)blockIdx.x * 256ull + threadIdx.x) * 16ull;
     unsigned long long a1 = 0ull, a2 = 0ull;
     if (first < L.file_len) {
@@ -151,33 +153,41 @@ __global__ void __launch_bounds__(256) png_encode_kernel(PngLayout L, const uint
             for (unsigned long long f = first; f < L.file_len; ++f) out[f] = (uint8_t)(words[(f - first) >> 2] >> (8 * ((f - first) & 3)));
         }
     }
-    // wave sums, one atomic per wave and value (integer adds: any order, same result)
+    // wave sums -> workgroup sums -> ONE plain store per workgroup; png_finish_kernel adds the workgroups up.  (Same-address atomics
+    // are served one per ~12 ns on this GPU: two per wave made this kernel 50 us for a 2 MB image, a memset in front of it included.)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         a1 += __shfl_xor(a1, d);
         a2 += __shfl_xor(a2, d);
     }
-    if ((threadIdx.x & 63) == 0) {
-        if (a1 != 0ull) atomicAdd(sums + 0, a1);
-        if (a2 != 0ull) atomicAdd(sums + 1, a2 % 65521ull);   // (a wave's s2 can reach 1e13; the running total stays far below 2^64)
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6][0] = a1; s_sum[threadIdx.x >> 6][1] = a2 % 65521ull; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        adler_partials[2 * (size_t)blockIdx.x + 0] = s_sum[0][0] + s_sum[1][0] + s_sum[2][0] + s_sum[3][0];
+        adler_partials[2 * (size_t)blockIdx.x + 1] = (s_sum[0][1] + s_sum[1][1] + s_sum[2][1] + s_sum[3][1]) % 65521ull;
     }
 }
+
+// x^(8 * 64 * m) mod P for m = i, 256 i, 65536 i (i = 0 .. 255): a CRC piece's shift by 64 m bytes is a product of three table entries.
+__device__ uint32_t g_crc_shift64[3][256];
 
 // CRC-32 of the IDAT chunk's type + payload, read back from the file image png_encode_kernel just wrote (L2-resident).  One lane =
 // kCrcChunk consecutive file bytes, loaded up front: their raw CRC four bytes at a time (slicing-by-4: four table lookups per word
 // instead of a chain of four), then ONE shift to the lane's place in the message -- x^(8 * bytes behind it) mod P -- and an XOR into
 // the total.
 constexpr uint32_t kCrcChunk = 64u;
-__global__ void __launch_bounds__(256) png_crc_kernel(PngLayout L, PngTables T, const uint8_t* __restrict__ file, unsigned long long* __restrict__ sums) {
+__global__ void __launch_bounds__(256) png_crc_kernel(PngLayout L, PngTables T, const uint8_t* __restrict__ file,
+                                                     uint32_t* __restrict__ crc_partials /*[workgroups], every entry written*/) {
     __shared__ uint32_t s_t[4][256];
-    __shared__ uint32_t s_x2n[32];
+    __shared__ uint32_t s_shift[3][256];
+    __shared__ uint32_t s_crc[4];
     {
         const int i = threadIdx.x;
         const uint32_t t0 = T.byte[i];
         const uint32_t t1 = (t0 >> 8) ^ T.byte[t0 & 0xFFu];
         const uint32_t t2 = (t1 >> 8) ^ T.byte[t1 & 0xFFu];
         s_t[0][i] = t0; s_t[1][i] = t1; s_t[2][i] = t2; s_t[3][i] = (t2 >> 8) ^ T.byte[t2 & 0xFFu];
-        if (i < 32) s_x2n[i] = T.x2n[i];
+        s_shift[0][i] = g_crc_shift64[0][i]; s_shift[1][i] = g_crc_shift64[1][i]; s_shift[2][i] = g_crc_shift64[2][i];
     }
     __syncthreads();
     const unsigned long long crc_from = L.data_at - 4ull, crc_end = L.data_at + L.data_len;   // "IDAT" ... Adler-32 (still zeros) inclusive
@@ -204,17 +214,40 @@ __global__ void __launch_bounds__(256) png_crc_kernel(PngLayout L, PngTables T, 
                 crc = s_t[0][(crc ^ b) & 0xFFu] ^ (crc >> 8);
             }
         }
-        if (crc != 0u && hi < crc_end) crc = crc_multmodp(crc_x2nmodp(s_x2n, crc_end - hi, 3u), crc);   // shift to its place
+        if (crc != 0u && hi < crc_end) {
+            // shift to its place: crc_end - hi = 64 m + (crc_end mod 64) bytes lie behind this piece (hi is a multiple of 64 here);
+            // x^(8 * 64 m) from the three tables, x^(8 * (crc_end mod 64)) host-computed -- four modular products instead of the
+            // twenty of an exponentiation (38 -> 12 us for a 2 MB image)
+            const unsigned long long m = (crc_end - hi) >> 6;
+            crc = crc_multmodp(L.crc_tail_shift, crc);
+            if (m & 0xFFull) crc = crc_multmodp(s_shift[0][m & 0xFFull], crc);
+            if ((m >> 8) & 0xFFull) crc = crc_multmodp(s_shift[1][(m >> 8) & 0xFFull], crc);
+            if (m >> 16) crc = crc_multmodp(s_shift[2][(m >> 16) & 0xFFull], crc);
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) crc ^= (uint32_t)__shfl_xor((int)crc, d);
-    if ((threadIdx.x & 63) == 0 && crc != 0u) atomicXor(reinterpret_cast<unsigned int*>(sums + 2), crc);   // (XOR: any order, same result)
+    if ((threadIdx.x & 63) == 0) s_crc[threadIdx.x >> 6] = crc;
+    __syncthreads();
+    if (threadIdx.x == 0) crc_partials[blockIdx.x] = s_crc[0] ^ s_crc[1] ^ s_crc[2] ^ s_crc[3];   // (XOR: any order, same result)
 }
 
-__global__ void png_finish_kernel(PngLayout L, uint8_t* __restrict__ out, const unsigned long long* __restrict__ sums) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const uint32_t s1 = (uint32_t)((1ull + sums[0]) % 65521ull);
-    const uint32_t s2 = (uint32_t)((L.N % 65521ull + sums[1]) % 65521ull);
+// One wave: adds up the workgroups' Adler sums and XORs their CRC terms, writes the two checksums into the file image.
+__global__ void __launch_bounds__(64) png_finish_kernel(PngLayout L, uint8_t* __restrict__ out, const unsigned long long* __restrict__ adler_partials,
+                                                       uint32_t adler_groups, const uint32_t* __restrict__ crc_partials, uint32_t crc_groups) {
+    unsigned long long a1 = 0ull, a2 = 0ull;
+    uint32_t crc_sum = 0u;
+    for (uint32_t i = threadIdx.x; i < adler_groups; i += 64u) { a1 += adler_partials[2 * (size_t)i]; a2 += adler_partials[2 * (size_t)i + 1]; }
+    for (uint32_t i = threadIdx.x; i < crc_groups; i += 64u) crc_sum ^= crc_partials[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        a1 += __shfl_xor(a1, d);
+        a2 += __shfl_xor(a2, d);
+        crc_sum ^= (uint32_t)__shfl_xor((int)crc_sum, d);
+    }
+    if (threadIdx.x != 0) return;
+    const uint32_t s1 = (uint32_t)((1ull + a1) % 65521ull);
+    const uint32_t s2 = (uint32_t)((L.N % 65521ull + a2) % 65521ull);
     const uint32_t adler = (s2 << 16) | s1;
     const unsigned long long adler_at = L.data_at + L.data_len - 4ull;
     uint32_t crc_a = 0u;   // raw CRC of the four Adler bytes: the last bytes of the message, nothing behind them
@@ -224,7 +257,7 @@ __global__ void png_finish_kernel(PngLayout L, uint8_t* __restrict__ out, const 
         crc_a ^= b;
         for (int i = 0; i < 8; ++i) crc_a = (crc_a & 1u) ? (crc_a >> 1) ^ kCrcPoly : crc_a >> 1;
     }
-    const uint32_t crc = ((uint32_t)sums[2] ^ crc_a ^ L.crc_init_term) ^ 0xFFFFFFFFu;
+    const uint32_t crc = (crc_sum ^ crc_a ^ L.crc_init_term) ^ 0xFFFFFFFFu;
     for (int k = 0; k < 4; ++k) out[adler_at + 4 + k] = (uint8_t)(crc >> (24 - 8 * k));
 }
 
@@ -263,6 +296,7 @@ bool png_layout(int W, int H, int C, int planar, PngLayout* L) {
     if (L->data_len > 0x7FFFFFFFull) return false;   // one IDAT chunk: a 31-bit length (an image of 2 GB)
     L->file_len = L->data_at + L->data_len + 4ull + 12ull;
     L->crc_init_term = crc_multmodp(crc_x2nmodp(png_tables().x2n, 4ull + L->data_len, 3u), 0xFFFFFFFFu);
+    L->crc_tail_shift = crc_x2nmodp(png_tables().x2n, (L->data_at + L->data_len) & 63ull, 3u);
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
     uint8_t* h = L->head;
     for (int i = 0; i < 48; ++i) h[i] = 0;
@@ -506,8 +540,7 @@ hipError_t launch_frame_files(const float* color, const float* alpha, const floa
     const uint8_t* srcs[3] = {rgba8, depth_rgb, normal_rgb};
     for (int k = 0; k < 3; ++k) {
         if (sizes[k] == 0) return hipErrorInvalidValue;
-        unsigned long long* scratch = reinterpret_cast<unsigned long long*>(outs[k] + ((sizes[k] + 15) & ~size_t(15)));
-        if ((e = launch_png_encode(srcs[k], W, H, k == 0 ? 4 : 3, k == 0 ? 1 : 0, outs[k], scratch, stream)) != hipSuccess) return e;
+        if ((e = launch_png_encode(srcs[k], W, H, k == 0 ? 4 : 3, k == 0 ? 1 : 0, outs[k], stream)) != hipSuccess) return e;
     }
     return hipMemcpyAsync(npy_plane, depth, n * sizeof(float), hipMemcpyDeviceToDevice, stream);
 }
@@ -517,17 +550,60 @@ size_t png_file_bytes(int W, int H, int C) {
     return png_layout(W, H, C, 0, &L) ? (size_t)L.file_len : 0;
 }
 
-// out: png_file_bytes(...) bytes, 16-byte aligned; scratch: 32 bytes (any content).
-hipError_t launch_png_encode(const uint8_t* pixels, int W, int H, int C, int planar, uint8_t* out, unsigned long long* scratch, hipStream_t stream) {
+namespace {
+struct PngScratch { size_t adler_at, crc_at, total; uint32_t enc_groups, crc_groups; };   // offsets from the start of `out`
+PngScratch png_scratch(const PngLayout& L) {
+    PngScratch p;
+    p.enc_groups = (uint32_t)((((L.file_len + 15ull) / 16ull) + 255ull) / 256ull);
+    p.crc_groups = (uint32_t)((((L.file_len + kCrcChunk - 1ull) / kCrcChunk) + 255ull) / 256ull);
+    p.adler_at = ((size_t)L.file_len + 15) & ~size_t(15);
+    p.crc_at = p.adler_at + (size_t)p.enc_groups * 16;
+    p.total = p.crc_at + (((size_t)p.crc_groups * 4 + 15) & ~size_t(15));
+    return p;
+}
+} // namespace
+
+// Bytes `out` of launch_png_encode must hold: the file, then (from the next 16-byte boundary) the workgroups' partial checksums.
+size_t png_room_bytes(int W, int H, int C) {
+    PngLayout L;
+    return png_layout(W, H, C, 0, &L) ? png_scratch(L).total : 0;
+}
+
+namespace {
+std::mutex g_shift_mutex;
+bool g_shift_ready[64] = {};
+hipError_t ensure_shift_tables() {   // once per device: 3 KB of constants for png_crc_kernel
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_shift_mutex);
+    if (g_shift_ready[dev]) return hipSuccess;
+    static uint32_t host[3][256];
+    const uint32_t* x2n = png_tables().x2n;
+    for (int t = 0; t < 3; ++t) {
+        const uint32_t step = crc_x2nmodp(x2n, 64ull << (8 * t), 3u);   // x^(8 * 64 * 256^t)
+        uint32_t p = 1u << 31;                                           // x^0
+        for (int i = 0; i < 256; ++i) { host[t][i] = p; p = crc_multmodp(step, p); }
+    }
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_crc_shift64), host, sizeof host);
+    if (e == hipSuccess) g_shift_ready[dev] = true;
+    return e;
+}
+} // namespace
+
+// out: png_room_bytes(...) bytes, 16-byte aligned (the file image, then the kernels' partial checksums).  Three launches, no memset.
+hipError_t launch_png_encode(const uint8_t* pixels, int W, int H, int C, int planar, uint8_t* out, hipStream_t stream) {
     PngLayout L;
     if (!png_layout(W, H, C, planar, &L)) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(scratch, 0, 32, stream);
-    if (e != hipSuccess) return e;
-    const unsigned long long lanes = (L.file_len + 15ull) / 16ull;
-    hipLaunchKernelGGL(png_encode_kernel, dim3((unsigned)((lanes + 255ull) / 256ull)), dim3(256), 0, stream, L, pixels, out, scratch);
-    const unsigned long long crc_lanes = (L.file_len + kCrcChunk - 1ull) / kCrcChunk;
-    hipLaunchKernelGGL(png_crc_kernel, dim3((unsigned)((crc_lanes + 255ull) / 256ull)), dim3(256), 0, stream, L, png_tables(), out, scratch);
-    hipLaunchKernelGGL(png_finish_kernel, dim3(1), dim3(64), 0, stream, L, out, scratch);
+    const hipError_t ready = ensure_shift_tables();
+    if (ready != hipSuccess) return ready;
+    const PngScratch p = png_scratch(L);
+    unsigned long long* adler_partials = reinterpret_cast<unsigned long long*>(out + p.adler_at);
+    uint32_t* crc_partials = reinterpret_cast<uint32_t*>(out + p.crc_at);
+    hipLaunchKernelGGL(png_encode_kernel, dim3(p.enc_groups), dim3(256), 0, stream, L, pixels, out, adler_partials);
+    hipLaunchKernelGGL(png_crc_kernel, dim3(p.crc_groups), dim3(256), 0, stream, L, png_tables(), out, crc_partials);
+    hipLaunchKernelGGL(png_finish_kernel, dim3(1), dim3(64), 0, stream, L, out, adler_partials, p.enc_groups, crc_partials, p.crc_groups);
     return hipGetLastError();
 }
 

@@ -325,9 +325,9 @@ hipError_t launch_pack_rgba8(const float* color, const float* alpha, uint8_t* ou
 // ---- frame outputs / compositor inputs (gsr_frameio.hip) ----
 // Bytes of the PNG file launch_png_encode writes for a W x H image with C (3 or 4) 8-bit channels; 0 if the size is not encodable.
 size_t png_file_bytes(int W, int H, int C);
-// pixels: u8, interleaved [H,W,C] or (planar != 0) [C,H,W]; out: png_file_bytes bytes, 16-byte aligned; scratch: 32 bytes.
-hipError_t launch_png_encode(const uint8_t* pixels, int W, int H, int C, int planar, uint8_t* out, unsigned long long* scratch,
-                             hipStream_t stream);
+size_t png_room_bytes(int W, int H, int C);   // what `out` must hold: the file, then the kernels' partial checksums
+// pixels: u8, interleaved [H,W,C] or (planar != 0) [C,H,W]; out: png_room_bytes bytes, 16-byte aligned.
+hipError_t launch_png_encode(const uint8_t* pixels, int W, int H, int C, int planar, uint8_t* out, hipStream_t stream);
 
 // The reference's four per-frame files from a render() result, queued by one host call (gsr.h: gsr_frame_files).  work: 10 * W * H bytes.
 hipError_t launch_frame_files(const float* color, const float* alpha, const float* depth, const float* normal, float depth_scale,

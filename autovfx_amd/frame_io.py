@@ -142,25 +142,27 @@ def png_size(width: int, height: int, channels: int) -> int:
     return n
 
 
-def _png_room(n: int) -> int:
-    return ((n + 15) & ~15) + 32     # the file, then the encoder's 32 bytes of scratch from the next 16-byte boundary on
+def png_room(width: int, height: int, channels: int) -> int:
+    """Bytes the encoder's output buffer must hold: the file, then the kernels' partial checksums (``gsr_png_room``)."""
+    from . import _lib
+    return int(_lib.lib.gsr_png_room(int(width), int(height), int(channels)))
 
 
 def encode_png_gpu(image: torch.Tensor, planar: bool = False, out: "torch.Tensor | None" = None) -> torch.Tensor:
     """uint8 GPU image -- interleaved ``[H,W,C]`` or, ``planar``, ``[C,H,W]`` (what ``pack_rgba8`` leaves); C = 3 or 4 -- to the
     bytes of its PNG file, a uint8 GPU tensor (``gsr_png_encode``).  ``out``: a 16-byte aligned uint8 buffer of at least
-    ``png_size + 47`` bytes to encode into (a slice of a staging buffer); the returned tensor is its first ``png_size`` bytes."""
+    ``png_room(W, H, C)`` bytes to encode into (a slice of a staging buffer); the returned tensor is its first ``png_size`` bytes."""
     import ctypes
     from . import _lib
     if not (image.is_cuda and image.dtype == torch.uint8 and image.dim() == 3):
         raise ValueError("encode_png_gpu expects a uint8 GPU tensor [H,W,C] or [C,H,W]")
     img = image.contiguous()
     C, H, W = (int(v) for v in (img.shape if planar else (img.shape[2], img.shape[0], img.shape[1])))
-    n = png_size(W, H, C)
+    n, room = png_size(W, H, C), png_room(W, H, C)
     if out is None:
-        out = torch.empty(_png_room(n), dtype=torch.uint8, device=img.device)
-    if not (out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous() and out.numel() >= _png_room(n) and out.data_ptr() % 16 == 0):
-        raise ValueError("encode_png_gpu: out must be a contiguous, 16-byte aligned uint8 GPU buffer of png_size + 47 bytes")
+        out = torch.empty(room, dtype=torch.uint8, device=img.device)
+    if not (out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous() and out.numel() >= room and out.data_ptr() % 16 == 0):
+        raise ValueError("encode_png_gpu: out must be a contiguous, 16-byte aligned uint8 GPU buffer of png_room(W, H, C) bytes")
     with torch.cuda.device(img.device):
         rc = _lib.lib.gsr_png_encode(img.data_ptr(), W, H, C, 1 if planar else 0, out.data_ptr(),
                                      ctypes.c_void_p(torch.cuda.current_stream(img.device).cuda_stream))
@@ -193,11 +195,12 @@ class GpuFrameWriter:
     def _prepare(self, H: int, W: int, device):
         """Byte ranges of the four files inside a slot, the staging buffers, the constant .npy header."""
         sizes = {"images": png_size(W, H, 4), "depth_preview": png_size(W, H, 3), "normal": png_size(W, H, 3)}
+        rooms = {"images": png_room(W, H, 4), "depth_preview": png_room(W, H, 3), "normal": png_room(W, H, 3)}
         header = npy_header((H, W))
         at, off = 0, {}
         for k in ("images", "depth_preview", "normal"):
             off[k] = (at, sizes[k])
-            at += _png_room(sizes[k])
+            at += (rooms[k] + 15) & ~15
         off["depth"] = (at, len(header) + 4 * H * W)      # (header lengths are multiples of 64: the plane is 4-byte aligned)
         at += (len(header) + 4 * H * W + 15) & ~15
         self._off, self._bytes, self._shape = off, at, (H, W)

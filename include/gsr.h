@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 11
+#define GSR_ABI_VERSION 12
 
 #if defined(__GNUC__)
 #define GSR_API __attribute__((visibility("default")))
@@ -249,14 +249,16 @@ GSR_API int gsr_pack_rgba8(const float* color, const float* alpha, uint8_t* rgba
  * bytes of its PNG FILE, on the GPU: 8-bit truecolour (with alpha), one IDAT chunk holding a zlib stream of stored deflate
  * blocks (filter-0 scanlines, no compression), Adler-32 and CRC-32 computed in the kernel.  Any PNG reader decodes it to the
  * same pixels as the reference's compressed file; the caller copies gsr_png_size(...) bytes to the host and writes them out.
- * `out` must hold gsr_png_size(width, height, channels) + 32 bytes (the last 32, from the next 16-byte boundary on, are the
- * kernel's scratch) and be 16-byte aligned.  gsr_png_size returns 0 for sizes that cannot be encoded. */
+ * `out` must hold gsr_png_room(width, height, channels) bytes -- the file, then from the next 16-byte boundary on the kernels'
+ * per-workgroup partial checksums (16 bytes per 4 KB of file, 4 per 16 KB) -- and be 16-byte aligned.  Both return 0 for sizes
+ * that cannot be encoded.  Three launches, no memset, no atomics. */
 GSR_API size_t gsr_png_size(int width, int height, int channels);
+GSR_API size_t gsr_png_room(int width, int height, int channels);
 /* ... and one frame's four files in one call (ten launches on `stream`): color [3,H,W] + alpha [H,W] -> the RGBA PNG (save_image's
  * rounding, gsr_pack_rgba8); depth [H,W] -> the turbo-coloured preview PNG (depth2img(depth, depth_scale): uint8(clip(d / scale,
  * 0, 1) * 255) through turbo_lut, 256 RGB triples on the device) and, copied behind the caller's .npy header, the fp32 plane;
- * normal [H,W,3] -> uint8((n + 1) / 2 * 255), truncated.  png_* as `out` of gsr_png_encode (sizes gsr_png_size(w, h, 4 / 3 / 3)
- * + 32, 16-byte aligned); npy_plane: W * H floats; work: 10 * W * H bytes of device scratch. */
+ * normal [H,W,3] -> uint8((n + 1) / 2 * 255), truncated.  png_* as `out` of gsr_png_encode (gsr_png_room(w, h, 4 / 3 / 3) bytes,
+ * 16-byte aligned); npy_plane: W * H floats; work: 10 * W * H bytes of device scratch. */
 GSR_API int gsr_frame_files(const float* color, const float* alpha, const float* depth, const float* normal, float depth_scale,
                             const uint8_t* turbo_lut, int width, int height, uint8_t* png_rgba, uint8_t* png_depth_preview,
                             uint8_t* png_normal, float* npy_plane, uint8_t* work, void* stream);

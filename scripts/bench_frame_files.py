@@ -38,7 +38,7 @@ def row(name, ms, nbytes, what):
 
 rgba = torch.rand(4, H, W, device=dev, generator=g)
 u8 = pack_rgba8(rgba[:3], rgba[3:4])
-out = torch.empty(frame_io._png_room(frame_io.png_size(W, H, 4)), dtype=torch.uint8, device=dev)
+out = torch.empty(frame_io.png_room(W, H, 4), dtype=torch.uint8, device=dev)
 row("gsr_png_encode RGBA (memset + png_encode_kernel + png_finish_kernel)", timed(lambda: frame_io.encode_png_gpu(u8, planar=True, out=out)),
     4 * W * H + frame_io.png_size(W, H, 4), "4 B/pixel in, the file (4 B/pixel + 1 B/row + 5 B/65535) out")
 result = {"render": rgba, "depth": torch.rand(H, W, device=dev, generator=g) * 5, "normal": torch.nn.functional.normalize(torch.randn(H, W, 3, device=dev, generator=g), dim=-1)}

@@ -6,7 +6,7 @@ python scripts/bench_frame_files.py 960x540 > $out/frameio.jsonl 2> $out/frameio
 python scripts/bench_frame_files.py 1920x1080 >> $out/frameio.jsonl 2>> $out/frameio.err
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof -o f -- python $GRAFT_REPO_ROOT/scripts/bench_frame_files.py 960x540 > /dev/null 2> $GRAFT_REPO_ROOT/$out/prof.err )
 F=$(find $out/prof -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp "$F" $out/frameio_kernel_stats.csv; rm -rf $out/prof
-for n in 2000; do
+for n in 2000 2000; do
 timeout 300 python scripts/render_trajectory.py --synthetic 1000000 --orbit $n 960x540 --out /dev/shm/r5n_traj >> $out/traj.json 2>> $out/traj.err
 rm -rf /dev/shm/r5n_traj
 done
