@@ -789,7 +789,7 @@ namespace {
 // keep several frames in flight on several streams without blocking on the newest one.
 struct ForwardCall {
     hipStream_t stream = nullptr;
-    int debug = 0, prefiltered = 0, P = 0, T = 0, width = 0, height = 0, slot = 0;
+    int debug = 0, prefiltered = 0, P = 0, T = 0, width = 0, height = 0, slot = 0, tally_groups = 1;
     bool queued = false, device_work = false, timed = false, inference = false, defer_colour = false;
     gsr::Camera cam;
     gsr::GaussianInputs in;
@@ -978,6 +978,7 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     fc.off_order = gc.take<uint32_t>((size_t)gsr::kMaxSlabs * 8 * gsr::kOrderClasses);  // tiles per (slab, XCD band, list-length class)
     const size_t zero_end = gc.off;
     const size_t off_tallies = gc.take<gsr::BlockTally>((n + 255) / 256);
+    const size_t off_pool_first = gc.take<uint32_t>((n + 255) / 256);
     fc.off_listed = gc.take<uint8_t>(fc.defer_colour ? n : 0);  // one byte per Gaussian: which slab listed it (cleared by the
                                                                 // projection kernel among its other per-Gaussian stores)
     const size_t off_tile_totals = gc.take<uint32_t>(2 * dup_blocks);  // tile totals, then global offsets at tile ends
@@ -1022,6 +1023,7 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     ga.listed = fc.defer_colour ? (uint8_t*)(gbase + fc.off_listed) : nullptr;
     ga.counters = (gsr::FrameCounters*)(gbase + off_flag);
     ga.tallies = (gsr::BlockTally*)(gbase + off_tallies);
+    ga.pool_first = (uint32_t*)(gbase + off_pool_first);
     fc.point_offsets = (uint32_t*)(gbase + geom_off[GSR_GEOM_POINT_OFFSETS]);
     fc.slab_offsets = (uint32_t*)(gbase + off_slab_offsets);
     fc.slab_cpos = (uint32_t*)(gbase + off_slab_cpos);
@@ -1041,8 +1043,10 @@ int forward_begin(ForwardCall& fc, gsr_alloc_fn geom_alloc, void* geom_user, gsr
     // event while the GPU is already running the depth sort.
     void* const host_dev = fc.pinned.dev;
     memset(fc.pinned.host, 0, kCounterBytes);
+    fc.tally_groups = host_dev != nullptr ? gsr::kTallyGroups : 1;
     const gsr::TallyDuty tally = {ga.tallies, (P + 255) / 256, ga.counters, (int)((zero_end - off_flag) / 4),
-                                  reinterpret_cast<gsr::FrameCounters*>(host_dev), host_dev != nullptr ? 16 : 1};
+                                  reinterpret_cast<gsr::FrameCounters*>(host_dev), fc.tally_groups,
+                                  gsr::tally_chunk_shift((P + 255) / 256, fc.tally_groups), ga.pool_first};
     // (a runtime that does not map pinned memory: the totals go into the zero block's first slots and are copied behind the sort)
     uint32_t* keys_sorted = nullptr;
     fc.queued = true;   // from the first launch below on a kernel may store into the pinned slot (what ~ForwardCall looks at)
@@ -1081,13 +1085,16 @@ int forward_finish(ForwardCall& fc) {
     const gsr::FrameCounters* hc = reinterpret_cast<const gsr::FrameCounters*>(fc.pinned.host);  // first kCounterBytes only
     uint32_t flag = 0u;
     unsigned long long rect_total = 0, live_total = 0, emitting = 0, pool_rows = 0;
-    for (int i = 0; i < gsr::kRectPartials; ++i) {
+    uint32_t pool_group_first[gsr::kTallyGroups];   // run pool: where the rows of each tally group's large splats start
+    for (int i = 0; i < gsr::kTallyGroups; ++i) {   // (the slots behind the groups' are zero)
         rect_total += hc->pair_totals[i] >> 32;
         live_total += hc->pair_totals[i] & 0xFFFFFFFFull;
         emitting += hc->visible[i];
+        pool_group_first[i] = (uint32_t)pool_rows;
         pool_rows += hc->big_rows[i] & 0x7FFFFFFFu;
         flag |= hc->big_rows[i] >> 31;
     }
+    if (pool_rows > 0xFFFFFFFFull) return fail(GSR_ERR_INVALID_ARG, "%llu tile rows of large splats overflow 32 bits", pool_rows);
     if (debug && fc.prefiltered && (flag & 1u))
         return fail(GSR_ERR_PREFILTERED, "a Gaussian was culled although prefiltered is set (auxiliary.h:156-160)");
     if (rect_total > 0x7FFFFFFFull) return fail(GSR_ERR_INVALID_ARG, "num_rendered %llu overflows int", rect_total);
@@ -1140,6 +1147,9 @@ int forward_finish(ForwardCall& fc) {
     ba.slab_cpos = fc.slab_cpos; ba.slab_coffs = fc.slab_coffs; ba.tiles_p = (P + gsr::kDupTile - 1) / gsr::kDupTile;
     ba.run_pool = (uint32_t*)(bbase + off_pool); ba.pool_rows = (uint32_t)pool_rows;
     ba.run_incl = (uint32_t*)(bbase + off_pool_incl);
+    ba.pool_first = ga.pool_first;
+    ba.pool_group_shift = 8 + gsr::tally_chunk_shift((P + 255) / 256, fc.tally_groups);
+    for (int i = 0; i < gsr::kTallyGroups; ++i) ba.pool_group_first[i] = pool_group_first[i];
     ba.counters = ga.counters;
     ba.slabs = (gsr::SlabInfo*)(gbase + fc.off_slabs);
     // the slabs' pair counts are stored into the pinned slot by the kernels that settle them (pinned memory is device-visible

@@ -221,7 +221,7 @@ struct TileWalker {
 // ------------------------------------------------------------------------------------------------
 // bin_gather: positions [0, V) of the depth order.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) bin_gather_kernel(BinningArrays a) {
+__global__ void __launch_bounds__(256, 7) bin_gather_kernel(BinningArrays a) {
     __shared__ uint32_t s_wave[4];
     // per wave: the large splats of one round, flattened to (splat, tile row) items (see below)
     __shared__ float4 s_reg0[4][64];     // conic A, B, C, beta
@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(256) bin_gather_kernel(BinningArrays a) {
     }
     uint4 rec[4];
     uint32_t count[4];
-    uint32_t rows_needed = 0;
+    bool any_rows = false;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         rec[j] = make_uint4(0u, 0u, 0u, 0u);
@@ -252,25 +252,21 @@ __global__ void __launch_bounds__(256) bin_gather_kernel(BinningArrays a) {
         if (k0 + j < V) {
             rec[j] = *reinterpret_cast<const uint4*>(a.bins + gid[j]);  // the one random gather per splat
             if (rec_is_masked(rec[j].y)) count[j] = (uint32_t)__popc(rec[j].z) + (uint32_t)__popc(rec[j].w);
-            else if (a.tile_cull) rows_needed += rec[j].y >> 16;
+            else if (a.tile_cull) {
+                any_rows = true;   // z: rows of the large splats before it in its projection workgroup -> its first row in the pool
+                rec[j].z += a.pool_first[gid[j] >> 8] + a.pool_group_first[gid[j] >> a.pool_group_shift];
+            }
         }
     }
-    // Large splats: one run of live columns per tile row, parked in the pool.  Rows are handed out with one atomic per
-    // wave; a splat that does not get its rows (cannot happen: the pool is sized from the projection kernel's count)
-    // keeps its full rectangle, which is only less culled, never wrong.
-    const unsigned long long any_big = __ballot(rows_needed != 0u);
+    // Large splats: one run of live columns per tile row, parked in the pool.  Where a splat's rows start is a prefix sum
+    // over the Gaussians in THEIR order -- inside the projection workgroup (the record's z), over the workgroups of a tally
+    // group (pool_first), over the groups (the host, which has read their totals back to size the pool) -- so nothing is
+    // handed out here.  (Rounds 3 - 4: one atomic per wave on one word; at about 12 ns per same-address atomic that was a
+    // third of this kernel on a cloud of large splats.)  A splat whose rows would not fit (cannot happen: the pool is sized
+    // from the same sums) keeps its full rectangle, which is only less culled, never wrong.
+    const unsigned long long any_big = __ballot(any_rows);
     GSR_BTRACE(blockIdx.x, 1);
     if (any_big != 0ull) {   // wave-uniform
-        uint32_t incl = rows_needed;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
-            if (lane >= d) incl += o;
-        }
-        uint32_t base = 0u;
-        if (lane == 63) base = atomicAdd(&a.counters->pool_used, incl);
-        base = (uint32_t)__shfl((int)base, 63);
-        uint32_t pool_at = base + incl - rows_needed;
         // A lane walking the tile rows of its own splats makes the wave run as long as its tallest splat (up to the
         // whole image height) while the other lanes wait.  Instead the (splat, tile row) items of the wave are
         // flattened, one of the lane's four positions at a time: item t belongs to the splat whose inclusive row count
@@ -281,9 +277,10 @@ __global__ void __launch_bounds__(256) bin_gather_kernel(BinningArrays a) {
         for (int j = 0; j < 4; ++j) {
             const bool large = k0 + j < V && !rec_is_masked(rec[j].y);
             const uint32_t h = large ? rec[j].y >> 16 : 0u;
+            const uint32_t pool_at = rec[j].z;
             bool walk = false;
             if (large) {
-                if (pool_at + h > a.pool_rows) {
+                if (pool_at > a.pool_rows || h > a.pool_rows - pool_at) {
                     rec[j].z = 0xFFFFFFFFu;  // every row is the full width
                     count[j] = (rec[j].y & 0xFFFFu) * h;
                     rec[j].w = count[j];
@@ -364,7 +361,6 @@ __global__ void __launch_bounds__(256) bin_gather_kernel(BinningArrays a) {
                 }
                 __builtin_amdgcn_wave_barrier();     // (the next round overwrites the tables)
             }
-            if (walk) pool_at += h;
         }
     }
     if (!a.tile_cull) {

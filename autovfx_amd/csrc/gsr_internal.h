@@ -25,7 +25,7 @@ struct FrameCounters {
     uint32_t visible[kRectPartials];                // Gaussians that emit at least the chance of a pair (key != kCulledKey)
     uint32_t big_rows[kRectPartials];               // tile rows of the splats too large for a mask (sizes the run pool)
     uint32_t error_flag;                            // (unused: a prefiltered violation travels as bit 31 of a big_rows slot)
-    uint32_t pool_used;                             // run pool: rows handed out so far (bin_gather_kernel)
+    uint32_t pool_used;                             // (unused since round 5: the run pool's rows are placed by prefix sums)
     uint32_t order_violations;                      // debug calls: list entries out of (tile, depth bits, id) order
     uint32_t pad;
 };
@@ -110,6 +110,8 @@ struct GeometryArrays {
     SplatBin* bins;
     FrameCounters* counters;
     BlockTally* tallies;  // [div_up(P, 256)] one entry per workgroup of the projection kernel
+    uint32_t* pool_first; // [div_up(P, 256)] run pool: rows of the large splats of the workgroups before this one, counted
+                          // from the first workgroup of the same tally group (TallyDuty)
     int* radii;           // caller's radii or the internal array
     uint32_t* depth_keys; // sort keys (float bits of depth, kCulledKey if culled)
     uint32_t* ids;        // 0..P-1, the sort payload; nullptr when the sort generates it itself
@@ -178,8 +180,19 @@ struct TallyDuty {
     FrameCounters* zero_block;
     int zero_words;
     FrameCounters* host_totals;
-    int groups;   // workgroups that share the duty (<= kRectPartials; 1 if host_totals is null): group j fills slot j of the totals
+    int groups;   // workgroups that share the duty (<= kTallyGroups; 1 if host_totals is null): group j fills slot j of the totals
+                  // from the tallies [j << chunk_shift, (j + 1) << chunk_shift) -- a contiguous share, so that ...
+    int chunk_shift;
+    uint32_t* pool_first;  // ... [blocks] it can leave the exclusive sum of big_rows inside its share: with the groups' totals
+                           // (which the host has read back by then) that places every large splat's rows in the run pool
 };
+constexpr int kTallyGroups = 16;
+// (a power of two, so that the kernel that looks a Gaussian's group up shifts instead of dividing)
+inline int tally_chunk_shift(int blocks, int groups) {
+    int s = 0;
+    while (((long long)groups << s) < blocks) ++s;
+    return s;
+}
 // SH colours of the Gaussians the pair expansion of one slab marked (`listed[gid] == tag`, tag = slab + 1;
 // GaussianInputs::defer_colour), evaluated in Gaussian order; rgb[gid] is written.
 // `duty` (nullable): the slab's tile ranges are computed by the first workgroups of the same launch.
@@ -211,6 +224,11 @@ struct BinningArrays {
     uint32_t* run_pool;           // [pool_rows] column runs of the large splats
     uint32_t* run_incl;           // [pool_rows] live tiles of the splat's rows up to and including this one
     uint32_t pool_rows;
+    // where a large splat's rows start: pool_group_first[gid >> pool_group_shift] + pool_first[gid >> 8] + the offset among
+    // its own workgroup's large splats that the projection kernel left in the record (SplatBin::lo) -- no atomics
+    const uint32_t* pool_first;
+    int pool_group_shift;         // 8 + TallyDuty::chunk_shift
+    uint32_t pool_group_first[kTallyGroups];
     FrameCounters* counters;
     SlabInfo* slabs;              // [kMaxSlabs] device
     SlabInfo* slabs_host;         // nullable: the same table in pinned host memory (device-visible address); the kernels that

@@ -275,17 +275,16 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
     }
 
     GSR_KTRACE(blockIdx.x, 2);
-    if (in_range) {
-        out.radii[i] = radius_out;
-        *reinterpret_cast<uint4*>(out.bins + i) = make_uint4(bin.xy0, bin.wh, bin.lo, bin.hi);
-        out.depth_keys[i] = key;
-        if (out.listed != nullptr) out.listed[i] = 0u;   // (a 3 MB memset queued beside other frames' blends took ~100 us)
-    }
     // Pair totals, needed on the host before the binning arena can be sized: an upper bound of the live pairs (what
     // gets expanded and sorted; exact but for the splats too large for a mask) in the low word and the reference's
     // num_rendered (sum of rectangle areas, part of its return value) in the high word of one 64-bit sum.  Summed over
     // the wave, then over the workgroup's four waves through LDS, and stored as this workgroup's BlockTally: no atomics and
     // no zero-filled accumulator (the tally duty of the depth sort's first count kernel adds the workgroups up).
+    //
+    // The tile rows of the large splats are summed as a prefix: the rows before a splat's own, among the large splats of
+    // its workgroup, travel in its record (SplatBin::lo), and with the prefix over the workgroups (tally duty) that is the
+    // splat's place in the run pool -- bin_gather_kernel used to hand the rows out with one atomic per wave on ONE word
+    // (about 12 ns each on this part: a third of that kernel on a cloud of large splats).
     __shared__ unsigned long long s_tot[4];
     __shared__ uint32_t s_vis[4], s_big[4];
     unsigned long long wave_tot = ((unsigned long long)rect_area << 32) | (unsigned long long)live_bound;
@@ -293,18 +292,33 @@ __global__ void __launch_bounds__(256) preprocess_kernel(GaussianInputs in, Came
     for (int d = 32; d >= 1; d >>= 1) wave_tot += __shfl_xor(wave_tot, d);
     const unsigned long long emitting = __ballot(key != kCulledKey);
     const unsigned long long any_big = __ballot(big_rows != 0u);
-    if (any_big != 0ull) {
+    uint32_t big_incl = big_rows;
+    if (any_big != 0ull) {   // wave-uniform
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) big_rows += (uint32_t)__shfl_xor((int)big_rows, d);
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)big_incl, d);
+            if ((int)(threadIdx.x & 63) >= d) big_incl += o;
+        }
     }
     const unsigned long long any_violation = __ballot(violation);
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 63) {
         const int w = threadIdx.x >> 6;
         s_tot[w] = wave_tot;
         s_vis[w] = (uint32_t)__popcll(emitting);
-        s_big[w] = (any_big != 0ull ? big_rows : 0u) | (any_violation != 0ull ? 0x80000000u : 0u);
+        s_big[w] = big_incl | (any_violation != 0ull ? 0x80000000u : 0u);
     }
     __syncthreads();
+    if (big_rows != 0u) {
+        uint32_t before = big_incl - big_rows;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += s_big[w] & 0x7FFFFFFFu;
+        bin.lo = before;   // (hi stays all ones)
+    }
+    if (in_range) {
+        out.radii[i] = radius_out;
+        *reinterpret_cast<uint4*>(out.bins + i) = make_uint4(bin.xy0, bin.wh, bin.lo, bin.hi);
+        out.depth_keys[i] = key;
+        if (out.listed != nullptr) out.listed[i] = 0u;   // (a 3 MB memset queued beside other frames' blends took ~100 us)
+    }
     if (threadIdx.x == 0) {
         BlockTally t;
         t.pair_total = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];

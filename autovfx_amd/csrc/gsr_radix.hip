@@ -92,28 +92,41 @@ __device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t* sc
 // own (7 us between the projection and the depth sort); now it rides on the depth sort's first count kernel: `groups` extra
 // workgroups (one when the totals land in the zero block itself), each filling its own slot of the totals, which the host adds.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void counter_tally_duty(const TallyDuty& d, int group, uint32_t* lds /* >= 6 * kWaves words */) {
+__device__ __forceinline__ void counter_tally_duty(const TallyDuty& d, int group, uint32_t* lds /* >= 7 * kWaves words */) {
     unsigned long long* s_tot = reinterpret_cast<unsigned long long*>(lds);
-    uint32_t *s_vis = lds + 2 * kWaves, *s_big = s_vis + kWaves, *s_flag = s_big + kWaves;
+    uint32_t *s_vis = lds + 2 * kWaves, *s_big = s_vis + kWaves, *s_flag = s_big + kWaves, *s_scan = s_flag + kWaves;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int first = group * kThreads + tid, stride = d.groups * kThreads;
+    // this group's share of the tallies is contiguous and a lane takes four consecutive entries of it: the rows of the large
+    // splats are summed as a prefix (pool_first), everything else as a total
+    const int chunk = 1 << d.chunk_shift;
+    const int share_first = min(group * chunk, d.blocks), share_end = min(share_first + chunk, d.blocks);
     unsigned long long tot = 0ull;
     uint32_t vis = 0u, big = 0u, flag = 0u;
     // four independent loads in flight per lane: at 3 M Gaussians and 16 groups that is the whole share of a lane, one memory
     // round trip (one group walking all 11 719 tallies a load at a time outlasted the count kernel it rides on)
-    for (int b0 = first; b0 < d.blocks; b0 += 4 * stride) {
+    for (int base = share_first; base < share_end; base += 4 * kThreads) {   // (workgroup-uniform bounds)
+        const int b0 = base + 4 * tid;
         uint4 t[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int b = b0 + j * stride;
-            t[j] = b < d.blocks ? *reinterpret_cast<const uint4*>(d.tallies + b) : make_uint4(0u, 0u, 0u, 0u);
-        }
+        for (int j = 0; j < 4; ++j)
+            t[j] = b0 + j < share_end ? *reinterpret_cast<const uint4*>(d.tallies + b0 + j) : make_uint4(0u, 0u, 0u, 0u);
+        uint32_t rows[4], mine = 0u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             tot += (unsigned long long)t[j].x | ((unsigned long long)t[j].y << 32);
             vis += t[j].z;
-            big += t[j].w & 0x7FFFFFFFu;
+            rows[j] = t[j].w & 0x7FFFFFFFu;
+            mine += rows[j];
             flag |= t[j].w >> 31;
+        }
+        uint32_t round_total;
+        uint32_t before = big + block_exclusive_sum(mine, s_scan, tid, &round_total);   // (big: the same in every lane)
+        big += round_total;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (b0 + j < share_end) d.pool_first[b0 + j] = before;
+            before += rows[j];
         }
     }
     uint32_t* z = reinterpret_cast<uint32_t*>(d.zero_block);
@@ -122,14 +135,13 @@ __device__ __forceinline__ void counter_tally_duty(const TallyDuty& d, int group
     for (int s = 32; s >= 1; s >>= 1) {
         tot += __shfl_xor(tot, s);
         vis += (uint32_t)__shfl_xor((int)vis, s);
-        big += (uint32_t)__shfl_xor((int)big, s);
         flag |= (uint32_t)__shfl_xor((int)flag, s);
     }
-    if (lane == 0) { s_tot[wave] = tot; s_vis[wave] = vis; s_big[wave] = big; s_flag[wave] = flag; }
+    if (lane == 0) { s_tot[wave] = tot; s_vis[wave] = vis; s_flag[wave] = flag; }
     __syncthreads();   // (one group, totals into the zero block itself: it is cleared before they land in it)
     if (tid == 0) {
-        tot = 0ull; vis = 0u; big = 0u; flag = 0u;
-        for (int w = 0; w < kWaves; ++w) { tot += s_tot[w]; vis += s_vis[w]; big += s_big[w]; flag |= s_flag[w]; }
+        tot = 0ull; vis = 0u; flag = 0u;   // (big: already the group's total)
+        for (int w = 0; w < kWaves; ++w) { tot += s_tot[w]; vis += s_vis[w]; flag |= s_flag[w]; }
         FrameCounters* dst = d.host_totals != nullptr ? d.host_totals : d.zero_block;
         dst->pair_totals[group] = tot;                     // the host adds the slots up
         dst->visible[group] = vis;

@@ -421,8 +421,9 @@ typedef enum gsr_geom_slot {
                                    opacity, view-space z, -ln(255 opacity) - 1e-4 -- valid where radii > 0             */
     GSR_GEOM_RGB,               /* f32[3P]  SH-evaluated colour (unused with colors_precomp)       */
     GSR_GEOM_SPLAT_BINS,        /* u32[4P]  per splat: first tile x | y << 16 and size w | h << 16 of its tight rectangle
-                                   (0 = emits nothing), then the 64-bit mask of its live tiles when w * h <= 64 (all ones
-                                   for a larger splat, whose live tiles are found later); GSR_OPT_TILE_CULL */
+                                   (0 = emits nothing), then the 64-bit mask of its live tiles when w * h <= 64 (for a
+                                   larger splat, whose live tiles are found later: the tile rows of the larger splats before
+                                   it among the 256 Gaussians it shares id >> 8 with, then all ones); GSR_OPT_TILE_CULL */
     GSR_GEOM_INTERNAL_RADII,    /* i32[P]   used when the caller passes radii == NULL              */
     GSR_GEOM_DEPTH_ORDER,       /* u32[P]   Gaussian ids, ascending (depth bits, id): the visible ones; GSR_OPT_DEPTH_DROP */
     GSR_GEOM_POINT_OFFSETS,     /* u32[P]   inclusive scan of the pair counts in DEPTH_ORDER order     */

@@ -344,6 +344,51 @@ def test_one_and_a_half_billion_pairs_full_and_inference_calls_agree():
         torch.cuda.empty_cache()
 
 
+def test_run_pool_placement_over_several_tally_rounds():
+    """The rows of the splats too large for a mask are placed in the run pool by prefix sums over the Gaussians in their own
+    order: inside a projection workgroup, over the workgroups of a tally group (four entries per lane and round), over the
+    groups.  4.4 M Gaussians = 17 188 projection workgroups = shares of 2048 per group, two rounds each; large splats every
+    997 ids, in runs across wave, workgroup, round and group boundaries, and at both ends.  A misplaced splat overwrites
+    another one's runs: with culling on the image would differ from the one without."""
+    P = 4_400_000
+    g = torch.Generator().manual_seed(11)
+    means = torch.zeros(P, 3)
+    means[:, :2] = (torch.rand(P, 2, generator=g) - 0.5) * 3.0
+    means[:, 2] = torch.rand(P, generator=g) * 0.5
+    means[::2, 2] -= 20.0                                   # every other one behind the camera: culled, but part of the tallies
+    scales = torch.full((P, 3), 0.003)
+    opac = torch.full((P, 1), 0.6)
+    large = torch.zeros(P, dtype=torch.bool)
+    large[::997] = True
+    for first in (0, 60, 250, 1024 * 256 - 30, 2048 * 256 - 40, 3 * 2048 * 256 - 130, P - 70):   # wave / workgroup / round / group edges
+        large[first:first + 70] = True
+    means[large, 2] = torch.rand(int(large.sum()), generator=g) * 0.5
+    scales[large] = 0.3 + 0.4 * torch.rand(int(large.sum()), 1, generator=g)
+    scales[large, 1] *= 0.4                                  # elongated: the runs are shorter than the rectangle is wide
+    opac[large] = 0.02
+    rot = torch.randn(P, 4, generator=g)
+    cloud = GaussianCloud(means, opac, scales, rot, None, torch.rand(P, 3, generator=g), 0)
+    cam = scenes.c1_camera(640, 368)
+    off = hip_forward_raw(cloud, cam, cull=False, debug=False)
+    on = hip_forward_raw(cloud, cam, cull=True, debug=False)
+    w, h = on["tight_rect"][:, 2].astype(np.int64), on["tight_rect"][:, 3].astype(np.int64)
+    pooled = (w * h > 64)
+    assert int(pooled.sum()) > 3000 and pooled[:70].any() and pooled[-70:].any() and pooled[2048 * 256 - 40:2048 * 256 + 30].sum() > 40
+    # the record of a pooled splat: the rows of the pooled splats before it among the 256 Gaussians of its projection workgroup
+    rows = np.where(pooled, h, 0)
+    before = np.cumsum(rows) - rows
+    block_first = np.repeat(before[::256], 256)[:P]
+    np.testing.assert_array_equal((on["live_mask"] & np.uint64(0xFFFFFFFF))[pooled], (before - block_first)[pooled].astype(np.uint64))
+    for k in ("color", "depth", "alpha", "radii"):
+        np.testing.assert_array_equal(on[k], off[k], err_msg=f"{k} changed by tile culling")
+    assert on["num_rendered"] == off["num_rendered"] and on["live_pairs"] < 0.8 * off["live_pairs"]
+    assert float(on["alpha"].max()) > 0.5
+    report("run_pool_rounds", pooled=int(pooled.sum()), pool_rows=int(rows.sum()), pairs_culled=int(on["live_pairs"]), pairs_full=int(off["live_pairs"]))
+    again = hip_forward_raw(cloud, cam, cull=True, debug=False)
+    for k in ("point_list", "tile_keys", "ranges", "live_mask", "color"):
+        np.testing.assert_array_equal(again[k], on[k], err_msg=f"{k} differs between two runs")
+
+
 def test_near_plane_threshold():
     """view z == 0.2 is culled, the next float above is kept (auxiliary.h:154)."""
     import math
