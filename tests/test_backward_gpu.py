@@ -255,7 +255,7 @@ def test_training_step_reduces_loss():
         opt.zero_grad()
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     report("bw:train", first=losses[0], last=losses[-1])
     assert losses[-1] < 0.7 * losses[0], losses
 
