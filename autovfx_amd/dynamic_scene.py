@@ -100,14 +100,16 @@ class DynamicScene:
     that renders it, so a frame's objects are never overwritten while an earlier frame on another stream still reads them."""
 
     def __init__(self, base, objects: Dict[str, Tuple[object, Sequence[float]]], device="cuda:0", sh_degree: Optional[int] = None,
-                 slots: int = 1, placed_sh_degree: Optional[int] = 0):
+                 slots: int = 1, placed_sh_degree: Optional[int] = 0, copies: int = 1):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("DynamicScene places objects with a HIP kernel: it needs a GPU (there is no CPU fallback)")
         t = lambda a: a.detach().to(device=self.device, dtype=torch.float32).contiguous()
         self.objects = {k: _ObjectCloud(m, c0, self.device) for k, (m, c0) in objects.items()}
         self.P_base = int(base._xyz.shape[0])
-        cap = self.P_base + sum(o.P for o in self.objects.values())
+        # ``copies``: how often one object may be placed in ONE frame (the melting branch merges an object's mesh and the mesh's
+        # duplicate: two subsets of the same object, scene_representation.py:395-398)
+        cap = self.P_base + max(1, int(copies)) * sum(o.P for o in self.objects.values())
         M = int(base._features_dc.shape[1] + base._features_rest.shape[1])
         for k, o in self.objects.items():
             if int(o.shs.shape[1]) != M:

@@ -85,18 +85,28 @@ def decode_png(data: bytes) -> np.ndarray:
     return rows[:, 1:].reshape(h, w, c).copy()
 
 
-_made_dirs: set = set()
-
-
-def _frame_paths(out_dir: str, name: str) -> dict:
+def _frame_paths(out_dir: str, name: str, made: "set | None" = None) -> dict:
+    """The four paths of a frame; their directories are created.  ``made``: a writer's own memory of the directories it has
+    created (once per directory and writer, not four system calls per frame).  It is per writer, not per process: a directory
+    that is removed and re-rendered into later in the same process is created again by the next writer."""
     paths = {k: os.path.join(out_dir, k, name + ext) for k, ext in (("images", ".png"), ("depth", ".npy"), ("normal", ".png"))}
     paths["depth_preview"] = os.path.join(out_dir, "depth", name + ".png")
     for p in paths.values():
         d = os.path.dirname(p)
-        if d not in _made_dirs:      # (once per directory, not four system calls per frame)
+        if made is None or d not in made:
             os.makedirs(d, exist_ok=True)
-            _made_dirs.add(d)
+            if made is not None:
+                made.add(d)
     return paths
+
+
+def _open_for_write(path: str):
+    """``open(path, 'wb')``; a directory that vanished since the writer created it (results cleaned while a loop runs) is made again."""
+    try:
+        return open(path, "wb")
+    except FileNotFoundError:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        return open(path, "wb")
 
 
 def _frame_to_host(result: dict):
@@ -110,12 +120,13 @@ def _frame_to_host(result: dict):
 
 
 def _write_host_frame(paths: dict, rgba8: np.ndarray, depth: np.ndarray, normal: np.ndarray, compress_level: int = 3) -> dict:
-    with open(paths["images"], "wb") as f:
+    with _open_for_write(paths["images"]) as f:
         f.write(encode_png(rgba8, compress_level))
-    np.save(paths["depth"], depth)
-    with open(paths["depth_preview"], "wb") as f:   # (scene_representation.py:432-433)
+    with _open_for_write(paths["depth"]) as f:
+        np.save(f, depth)
+    with _open_for_write(paths["depth_preview"]) as f:   # (scene_representation.py:432-433)
         f.write(encode_png(depth2img(depth.squeeze(), 3.0), compress_level))
-    with open(paths["normal"], "wb") as f:
+    with _open_for_write(paths["normal"]) as f:
         f.write(encode_png(normal, compress_level))
     return paths
 
@@ -132,6 +143,10 @@ def npy_header(shape, dtype=np.float32) -> bytes:
     np.lib.format.write_array_header_1_0(f, {"descr": np.lib.format.dtype_to_descr(np.dtype(dtype)), "fortran_order": False,
                                             "shape": tuple(int(v) for v in shape)})
     return f.getvalue()
+
+
+def png_mode() -> str:
+    return "stored"
 
 
 def png_size(width: int, height: int, channels: int) -> int:
@@ -190,7 +205,7 @@ class GpuFrameWriter:
         self._slots, self._n_slots, self._next = [], max(2, slots), 0
         self._shape = None
         self._lut = None
-        self._made_dirs = False
+        self._made_dirs: set = set()
 
     def _prepare(self, H: int, W: int, device):
         """Byte ranges of the four files inside a slot, the staging buffers, the constant .npy header."""
@@ -214,6 +229,9 @@ class GpuFrameWriter:
             self._slots.append({"dev": dev, "host": host, "np": host.numpy(), "event": torch.cuda.Event(), "pending": None,
                                 "work": torch.empty(10 * H * W, dtype=torch.uint8, device=device)})
         self._header_len = len(header)
+        # the slots are handed out round-robin to whatever stream a frame arrives on: their header fills (queued above on THIS
+        # stream) must have landed before another stream copies a slot out.  Once per image size.
+        torch.cuda.current_stream(device).synchronize()
 
     def submit(self, name: str, result: dict) -> None:
         rgba, depth, normal = result["render"], result["depth"].detach(), result["normal"].detach()
@@ -239,11 +257,15 @@ class GpuFrameWriter:
                                           base + off["images"][0], base + off["depth_preview"][0], base + off["normal"][0],
                                           base + off["depth"][0] + self._header_len, slot["work"].data_ptr(),
                                           ctypes.c_void_p(torch.cuda.current_stream(dev.device).cuda_stream))
-        if rc != 0:
-            raise RuntimeError(f"gsr_frame_files failed ({rc}): {_lib.last_error()}")
-        slot["host"].copy_(dev, non_blocking=True)
-        slot["event"].record()
-        paths = _frame_paths(self.out_dir, name)
+            if rc != 0:
+                raise RuntimeError(f"gsr_frame_files failed ({rc}): {_lib.last_error()}")
+            # the copy and the event go to the SAME device and stream as the kernels above (the frame's device need not be the
+            # process's current one, and Event.record() without an argument records on the current device's current stream)
+            stream = torch.cuda.current_stream(dev.device)
+            with torch.cuda.stream(stream):
+                slot["host"].copy_(dev, non_blocking=True)
+            slot["event"].record(stream)
+        paths = _frame_paths(self.out_dir, name, self._made_dirs)
         slot["pending"] = self._pool.submit(self._write, slot, paths, dict(off))
 
     @staticmethod
@@ -251,7 +273,7 @@ class GpuFrameWriter:
         slot["event"].synchronize()
         buf = slot["np"]
         for k, (at, n) in off.items():
-            with open(paths[k], "wb") as f:
+            with _open_for_write(paths[k]) as f:
                 f.write(memoryview(buf[at:at + n]))
         return paths
 
@@ -294,11 +316,12 @@ class FrameWriter:
         self.out_dir, self.compress_level = out_dir, compress_level
         self._pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="frame-writer")
         self._pending = []
+        self._made_dirs: set = set()
         self._max_pending = max_pending if max_pending > 0 else 4 * workers   # bounds the host memory held by queued frames
 
     def submit(self, name: str, result: dict) -> None:
         arrays = _frame_to_host(result)
-        paths = _frame_paths(self.out_dir, name)
+        paths = _frame_paths(self.out_dir, name, self._made_dirs)
         while len(self._pending) >= self._max_pending:
             self._pending.pop(0).result()
         self._pending.append(self._pool.submit(_write_host_frame, paths, *arrays, self.compress_level))

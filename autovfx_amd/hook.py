@@ -16,7 +16,10 @@ AutoVFX reaches the rasterizer through two imports (paths under the reference tr
 2. a module named ``...blend_all`` (``blender/blend_all.py``, imported at ``scene_representation.py:13``) gets its ``blend_frames``
    replaced by ``autovfx_amd.compositor.blend_frames`` (same arguments, same files in and out; PIL's resizes and the per-pixel
    composite run on the GPU);
-3. every module named ``...gaussian_renderer`` -- already imported or imported later (a ``sys.meta_path`` hook) -- gets its
+3. a module named ``...scene_representation`` gets ``SceneRepresentation.render_from_3DGS`` (the frame loop, ``:337-447``) replaced
+   by ``autovfx_amd.frame_loop.render_from_3DGS``: same arguments and files; inserted objects are loaded once instead of once per
+   frame, several frames are in flight, the four files of a frame are built on the GPU;
+4. every module named ``...gaussian_renderer`` -- already imported or imported later (a ``sys.meta_path`` hook) -- gets its
    ``render`` replaced by ``autovfx_amd.renderer.render`` (same signature, same result dictionary; the original stays
    reachable as ``<module>.reference_render``), and every already-imported module that holds the original function under
    any name (``from ... import render [as gs_render]``) is rebound too.
@@ -41,6 +44,7 @@ from typing import Callable, List, Optional
 _REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _TARGET_LEAF = "gaussian_renderer"
 _BLEND_LEAF = "blend_all"                # blender/blend_all.py: its blend_frames() is called at scene_representation.py:232
+_SCENE_LEAF = "scene_representation"     # scene_representation.py: SceneRepresentation.render_from_3DGS is the frame loop (:337-447)
 _installed: Optional["_RendererHook"] = None
 patched_modules: List[str] = []          # names of the modules whose ``render`` was replaced (introspection / tests)
 _strict = True                           # install(strict=...): may a failure to load the render path break the importing process?
@@ -48,11 +52,44 @@ _gave_up = False                         # lenient mode: the render path could n
 
 
 def _is_target(fullname: str) -> bool:
-    return any(fullname == leaf or fullname.endswith("." + leaf) for leaf in (_TARGET_LEAF, _BLEND_LEAF))
+    return any(fullname == leaf or fullname.endswith("." + leaf) for leaf in (_TARGET_LEAF, _BLEND_LEAF, _SCENE_LEAF))
 
 
 def _is_blend_module(name: str) -> bool:
     return name == _BLEND_LEAF or name.endswith("." + _BLEND_LEAF)
+
+
+def _is_scene_module(name: str) -> bool:
+    return name == _SCENE_LEAF or name.endswith("." + _SCENE_LEAF)
+
+
+def _our_frame_loop() -> Callable:
+    from .frame_loop import render_from_3DGS
+    return render_from_3DGS
+
+
+def _patch_scene_module(module: types.ModuleType) -> None:
+    """``SceneRepresentation.render_from_3DGS`` (scene_representation.py:337-447) becomes autovfx_amd.frame_loop.render_from_3DGS:
+    same arguments, same directories, names and file contents; objects loaded once instead of per frame, frames in flight, file
+    images built on the GPU.  The reference's method stays reachable as ``SceneRepresentation.reference_render_from_3DGS``."""
+    global _gave_up
+    cls = module.__dict__.get("SceneRepresentation")
+    original = getattr(cls, "__dict__", {}).get("render_from_3DGS") if isinstance(cls, type) else None
+    if original is None or (getattr(original, "__module__", None) or "").startswith("autovfx_amd") or _gave_up:
+        return
+    try:
+        ours = _our_frame_loop()
+    except Exception as e:
+        if _strict:
+            raise
+        _gave_up = True
+        sys.stderr.write(f"[autovfx_amd] {module.__name__}.SceneRepresentation.render_from_3DGS left as the reference's: the frame loop "
+                         f"could not be loaded ({e!r})\n")
+        return
+    cls.reference_render_from_3DGS = original
+    cls.render_from_3DGS = ours
+    if module.__name__ not in patched_modules:
+        patched_modules.append(module.__name__)
 
 
 def _our_render() -> Callable:
@@ -67,6 +104,9 @@ def _our_blend_frames() -> Callable:
 
 def _patch_renderer_module(module: types.ModuleType) -> None:
     global _gave_up
+    if _is_scene_module(module.__name__):
+        _patch_scene_module(module)
+        return
     if _is_blend_module(module.__name__):
         # the compositing step of the edit loop: ``blend_all.blend_frames(results_dir, cfg_path)`` (scene_representation.py:232) becomes
         # autovfx_amd.compositor.blend_frames -- same arguments, same files in and out, the resizes and the per-pixel composite on the GPU
@@ -190,4 +230,8 @@ def uninstall() -> None:
             module.render = module.reference_render
         if module is not None and hasattr(module, "reference_blend_frames"):
             module.blend_frames = module.reference_blend_frames
+        cls = getattr(module, "SceneRepresentation", None) if module is not None else None
+        if isinstance(cls, type) and "reference_render_from_3DGS" in cls.__dict__:
+            cls.render_from_3DGS = cls.reference_render_from_3DGS
+            del cls.reference_render_from_3DGS
     patched_modules.clear()

@@ -875,6 +875,7 @@ def run_also(device, side, S, parity=True):
 
     guarded("c5_render_and_composite", c5)
     guarded("c5_dynamic", lambda: dynamic_scene_bench(device, side, S))
+    guarded("c5_loop", lambda: frame_loop_bench(device))
     guarded("c3_reference_shaped_render", lambda: reference_shaped_render(device))
     guarded("backward_c3", lambda: backward_iteration("c3", device, parity=parity))
     guarded("training_render_c3", lambda: training_render_iteration(device))
@@ -979,6 +980,161 @@ def dynamic_scene_bench(device, side, S, frames=120):
         b = rasterize(reference_shaped_compose(base, objs, place(37), device), cams[37], bg)[0]
     out["rgb_maxabs_vs_reference_shaped_frame37"] = float((a - b).abs().max())
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# also.c5_loop: SceneRepresentation.render_from_3DGS as a whole (scene_representation.py:337-447) -- rebuild of the frame's
+# Gaussian set, render(), the four files of every frame on a tmpfs -- through the drop-in and in the reference's shape
+# ---------------------------------------------------------------------------------------------------------------------
+_LOOP_CENTRES = {}
+
+
+def load_gaussians(path, max_sh_degree=4):            # what frame_loop takes from "the module of the scene class": here, this file
+    from autovfx_amd.gaussian_model import GaussianModel
+    return GaussianModel(max_sh_degree).load_ply(path, device="cuda:%d" % torch.cuda.current_device())
+
+
+def get_center_of_mesh_2(mesh_path):
+    return np.asarray(_LOOP_CENTRES[mesh_path], np.float64)
+
+
+class _LoopScene:
+    """The attributes render_from_3DGS reads from the reference's SceneRepresentation (scene_representation.py:47-113,192-221)."""
+
+    def __init__(self, root, results, ply, views, objects, rb_info, device):
+        import types
+        from autovfx_amd import renderer
+        self.hparams = types.SimpleNamespace(max_sh_degree=4, render_type="MULTI_VIEW", blender_output_dir_name="blend")
+        self.traj_results_dir = os.path.join(root, results)
+        self.blender_cache_dir = os.path.join(root, "no_cache")
+        self.cameras = {"cameras": views}
+        self.anchor_frame_idx, self.total_frames = 0, len(views)
+        self.rb_transform_info, self.blender_cfg = rb_info, {"insert_object_info": objects}
+        self.background = torch.zeros(3, device=device)
+        self.pipe, self._ply, self._device, self.load_seconds = renderer.PipelineParams, ply, device, 0.0
+
+    def load_scene(self):
+        from autovfx_amd.gaussian_model import GaussianModel
+        t0 = time.perf_counter()
+        self.gaussians = GaussianModel(3).load_ply(self._ply, device=str(self._device))
+        torch.cuda.synchronize()
+        self.load_seconds = time.perf_counter() - t0
+
+
+def _reference_shaped_loop(scene, frame_ids):
+    """scene_representation.py:355-438 in the reference's shape on this GPU: per frame a deep copy of the scene, every placed object's PLY
+    from disk, transform_gaussians + merge_two_gaussians as PyTorch operations (oracle/dynamic_torch.py), ONE blocking render() -- this
+    package's, the unchanged caller's 1 ms -- then the host writers: ``save_image`` (PIL, its default compression), ``.cpu().numpy()``,
+    ``np.save``, two ``cv2.imwrite``-equivalents (PNG compression 1, OpenCV's default)."""
+    import copy
+    from PIL import Image
+    from autovfx_amd import renderer
+    from autovfx_amd.dynamic_scene import FrameModel
+    from autovfx_amd.frame_io import depth2img
+    from autovfx_amd.gaussian_model import get_minimum_axis
+    from oracle.dynamic_torch import reference_shaped_compose
+    out = scene.traj_results_dir
+    for sub in ("images", "depth", "normal"):
+        os.makedirs(os.path.join(out, sub), exist_ok=True)
+    info = {o["object_id"]: o for o in scene.blender_cfg["insert_object_info"]}
+    with torch.no_grad():
+        for idx in frame_ids:
+            view = scene.cameras["cameras"][idx]
+            base = copy.deepcopy(scene.gaussians)
+            key, placed, objs = "{0:03d}".format(idx + 1), [], {}
+            for oid, t in scene.rb_transform_info.items():
+                if key in t:
+                    path = os.path.join("/".join(info[oid]["object_path"].split("/")[:-2]), "object_gaussians.ply")
+                    objs[oid] = (load_gaussians(path, 3), get_center_of_mesh_2(info[oid]["object_path"]))
+                    placed.append((oid, t[key]["pos"], t[key]["rot"], t[key]["scale"]))
+            cloud = reference_shaped_compose(base, objs, placed, scene._device)
+            model = FrameModel(cloud, get_minimum_axis(cloud.scales, cloud.rotations).contiguous())
+            res = renderer.render(view, model, scene.pipe, scene.background)
+            rgba = res["render"].mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to("cpu", torch.uint8).numpy()
+            Image.fromarray(rgba).save(os.path.join(out, "images", view.image_name + ".png"))
+            depth = res["depth"].cpu().numpy().squeeze()
+            np.save(os.path.join(out, "depth", view.image_name + ".npy"), depth.astype(np.float32))
+            Image.fromarray(depth2img(depth, 3.0)).save(os.path.join(out, "depth", view.image_name + ".png"), compress_level=1)
+            normal = ((res["normal"].cpu().numpy() + 1) / 2 * 255).astype(np.uint8)
+            Image.fromarray(normal).save(os.path.join(out, "normal", view.image_name + ".png"), compress_level=1)
+
+
+def frame_loop_bench(device, frames=400, reference_frames=10):
+    """C2 (1 M Gaussians, 960x540) + two inserted objects of 60 k Gaussians that move rigidly every frame, 400 frames (configs[4]):
+    ``autovfx_amd.frame_loop.render_from_3DGS`` -- what ``install()`` puts behind ``SceneRepresentation.render_from_3DGS`` -- end
+    to end on a tmpfs, and the reference-shaped loop beside it on a bounded number of frames."""
+    import math
+    import shutil
+    import tempfile
+    from autovfx_amd import frame_loop, scenes
+    from autovfx_amd.cameras import orbit_cameras
+    from autovfx_amd.gaussian_model import GaussianModel
+    W, H = 960, 540
+    root = tempfile.mkdtemp(prefix="gsr_loop_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        c = scenes.config_c2()
+        ply = os.path.join(root, "scene", "point_cloud.ply")
+        GaussianModel.from_activated(c.means3D, c.opacities, c.scales, c.rotations, c.shs, 3).save_ply(ply)
+        objects = []
+        for k, name in enumerate(("a", "b")):
+            o = scenes.config_c1(P=60_000, seed=70 + k)
+            d = os.path.join(root, "assets", name)
+            GaussianModel.from_activated(o.means3D * 0.25, o.opacities, o.scales * 0.25, o.rotations, o.shs, 3).save_ply(
+                os.path.join(d, "object_gaussians.ply"))
+            mesh = os.path.join(d, "mesh", name + ".obj")
+            _LOOP_CENTRES[mesh] = (0.0, 0.0, 0.0)
+            objects.append({"object_id": name, "object_path": mesh})
+        rz = lambda deg: [[math.cos(math.radians(deg)), -math.sin(math.radians(deg)), 0.0],
+                          [math.sin(math.radians(deg)), math.cos(math.radians(deg)), 0.0], [0.0, 0.0, 1.0]]
+        rb = {"a": {}, "b": {}}
+        for f in range(frames):
+            key = "{0:03d}".format(f + 1)
+            rb["a"][key] = {"pos": [0.8 * math.cos(0.05 * f), 0.8 * math.sin(0.05 * f), 0.2], "rot": rz(3.0 * f), "scale": 1.0}
+            rb["b"][key] = {"pos": [-0.5, 0.3 + 0.004 * f, 0.1 * math.sin(0.1 * f)], "rot": rz(-2.0 * f), "scale": 1.0 + 0.002 * f}
+        cams = orbit_cameras(200, W, H)
+        views = [cams[f % 200].to(device) for f in range(frames)]
+        for f, v in enumerate(views):
+            v.image_name = "{0:05d}".format(f)
+        ours = _LoopScene(root, "ours", ply, views, objects, rb, device)
+        frame_loop.render_from_3DGS(ours)                         # warm: allocator pools, pinned slots, page cache of the PLYs
+        shutil.rmtree(ours.traj_results_dir)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        frame_loop.render_from_3DGS(ours)
+        torch.cuda.synchronize()
+        t_call = time.perf_counter() - t0
+        t_loop = t_call - ours.load_seconds
+        files = [os.path.join(ours.traj_results_dir, sub, "00007" + ext) for sub, ext in
+                 (("images", ".png"), ("depth", ".npy"), ("depth", ".png"), ("normal", ".png"))]
+        nbytes = sum(os.path.getsize(p) for p in files)
+        n_written = sum(len(os.listdir(os.path.join(ours.traj_results_dir, sub))) for sub in ("images", "depth", "normal"))
+        shutil.rmtree(ours.traj_results_dir)
+        theirs = _LoopScene(root, "theirs", ply, views, objects, rb, device)
+        theirs.load_scene()
+        ids = list(range(0, frames, max(1, frames // reference_frames)))[:reference_frames]
+        _reference_shaped_loop(theirs, ids[:2])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _reference_shaped_loop(theirs, ids)
+        torch.cuda.synchronize()
+        t_ref = time.perf_counter() - t0
+        ref_bytes = sum(os.path.getsize(os.path.join(theirs.traj_results_dir, sub, views[ids[0]].image_name + ext)) for sub, ext in
+                        (("images", ".png"), ("depth", ".npy"), ("depth", ".png"), ("normal", ".png")))
+        return {"workload": "C2 scene (1 M Gaussians, 960x540) + 2 inserted objects of 60 k Gaussians moved rigidly every frame; "
+                            "4 files per frame to a tmpfs", "frames": frames, "files_written": n_written,
+                "value": round(frames / t_loop, 1), "unit": "frames/s", "ms_per_frame": round(t_loop / frames * 1e3, 4),
+                "call_seconds": round(t_call, 3), "load_scene_seconds": round(ours.load_seconds, 3),
+                "frames_per_s_including_load_scene": round(frames / t_call, 1),
+                "streams": frame_loop.DEFAULT_STREAMS, "writer_threads": frame_loop.DEFAULT_WRITER_THREADS,
+                "bytes_per_frame": int(nbytes), "png": frame_loop.png_mode(),
+                "reference_shaped_loop": {"frames": len(ids), "ms_per_frame": round(t_ref / len(ids) * 1e3, 2),
+                                          "frames_per_s": round(len(ids) / t_ref, 2), "bytes_per_frame": int(ref_bytes),
+                                          "what": "per frame: deepcopy of the scene, the objects' PLYs from disk, transform + merge in PyTorch, one "
+                                                  "blocking render() of this package, PIL / numpy host writers (one thread)"},
+                "vs_reference_shaped_loop": round((frames / t_loop) / (len(ids) / t_ref), 1)}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
 
 
 class ReferenceGetters:

@@ -1,0 +1,31 @@
+#!/usr/bin/env python
+"""One leg of bench.py's `also` object on its own: `also.c5_loop` (the whole frame loop of an edited scene to a tmpfs, the
+reference-shaped loop beside it) and, with --blend, `also.c5_blend_frames`.  Prints one JSON line per leg."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=400)
+    ap.add_argument("--reference-frames", type=int, default=10)
+    ap.add_argument("--legs", default="c5_loop")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    sys.modules.setdefault("bench", bench)
+    for leg in args.legs.split(","):
+        if leg == "c5_loop":
+            out = bench.frame_loop_bench(dev, frames=args.frames, reference_frames=args.reference_frames)
+        elif leg == "c5_blend_frames":
+            out = bench.blend_frames_bench(dev, frames=args.frames)
+        else:
+            raise SystemExit("unknown leg " + leg)
+        print(json.dumps({leg: out}), flush=True)

@@ -112,39 +112,18 @@ def main():
     mine = shard_frames(len(cams), rank, world)
     cams_dev = dict(zip(mine, cameras.Camera.batch_to([cams[i] for i in mine], dev)))   # this rank's cameras, uploaded in five copies
     t0 = time.perf_counter()
-    # file images built on the GPU (stored-deflate PNGs, checksums in the kernel), host threads only write(); --deflate: the frame
-    # crosses as pixels and a pool of host threads compresses it (zlib level 3: files a third of the size, ~30x the host time)
-    make_writer = (lambda: frame_io.FrameWriter(args.out)) if args.deflate else (lambda: frame_io.GpuFrameWriter(args.out, workers=args.writer_threads))
+    # file images built on the GPU, host threads only write(); --deflate: the frame crosses as pixels and a pool of host threads
+    # compresses it (zlib level 3)
     S = max(1, args.streams)
-    with torch.no_grad(), make_writer() as writer:
-        if S == 1:
-            for i in mine:
-                out = renderer.render(cams_dev[i], frame_model(i), renderer.PipelineParams, bg)
-                # (the maps are per-call buffers: the next frame's placement rewrites the scene buffers, not them)
-                writer.submit(cams[i].image_name or f"{i:05d}", out)
-        else:
-            # S frames in flight from this one thread: a frame's first half (projection, depth sort) is queued on its stream before
-            # the host waits for an older frame's pair count; its second half, the file images and their copy follow on that stream
-            from collections import deque
-            from autovfx_amd.frame_parallel import side_streams
-            side, q = side_streams(dev, S), deque()
-
-            def finish_oldest():
-                st, name, pending = q.popleft()
-                with torch.cuda.stream(st):
-                    writer.submit(name, pending.finish())
-
-            for k, i in enumerate(mine):
-                while len(q) == S:
-                    finish_oldest()
-                st = side[k % S]
-                with torch.cuda.stream(st):
-                    q.append((st, cams[i].image_name or f"{i:05d}",
-                              renderer.render_begin(cams_dev[i], frame_model(i, k % S), renderer.PipelineParams, bg)))
-            while q:
-                finish_oldest()
-            for st in side:
-                torch.cuda.current_stream(dev).wait_stream(st)
+    from autovfx_amd import frame_loop
+    if args.deflate:   # host zlib pool instead of GPU-built file images
+        frame_loop._make_writer = lambda out_dir, threads, slots: frame_io.FrameWriter(out_dir)
+    names = [c.image_name or f"{i:05d}" for i, c in enumerate(cams)]
+    views = [cams_dev.get(i) for i in range(len(cams))]
+    with torch.no_grad():
+        # S frames in flight from this one thread (autovfx_amd/frame_loop.py: the loop behind SceneRepresentation.render_from_3DGS)
+        frame_loop.render_frames(views, names, frame_model, args.out, renderer.PipelineParams, bg, frame_ids=mine, streams=S,
+                                 writer_threads=args.writer_threads)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(json.dumps({"rank": rank, "frames": len(mine), "seconds": round(dt, 3),
