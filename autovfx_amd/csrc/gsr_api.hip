@@ -756,7 +756,39 @@ int gsr_frame_files(const float* color, const float* alpha, const float* depth, 
         return fail(GSR_ERR_INVALID_ARG, "gsr_frame_files: the PNG buffers must be 16-byte aligned");
     if (!(depth_scale > 0.0f)) return fail(GSR_ERR_INVALID_ARG, "gsr_frame_files: depth_scale must be positive");
     GSR_HIP(gsr::launch_frame_files(color, alpha, depth, normal, depth_scale, turbo_lut, width, height, png_rgba, png_depth_preview, png_normal,
-                                    npy_plane, work, (hipStream_t)stream_));
+                                    npy_plane, work, nullptr, nullptr, (hipStream_t)stream_));
+    return GSR_OK;
+}
+
+int gsr_frame_files_deflate(const float* color, const float* alpha, const float* depth, const float* normal, float depth_scale, const uint8_t* turbo_lut,
+                            int width, int height, uint8_t* png_rgba, uint8_t* png_depth_preview, uint8_t* png_normal, float* npy_plane, uint8_t* work,
+                            uint8_t* png_scratch, uint64_t* png_lengths, void* stream_) {
+    if (width <= 0 || height <= 0 || gsr::png_deflate_max_bytes(width, height, 4) == 0) return fail(GSR_ERR_INVALID_ARG, "bad image size %dx%d", width, height);
+    if (!color || !alpha || !depth || !normal || !turbo_lut || !png_rgba || !png_depth_preview || !png_normal || !npy_plane || !work || !png_scratch || !png_lengths)
+        return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    if (((reinterpret_cast<uintptr_t>(png_rgba) | reinterpret_cast<uintptr_t>(png_depth_preview) | reinterpret_cast<uintptr_t>(png_normal) |
+          reinterpret_cast<uintptr_t>(png_scratch)) & 15u) != 0 ||
+        (reinterpret_cast<uintptr_t>(png_lengths) & 7u) != 0)
+        return fail(GSR_ERR_INVALID_ARG, "gsr_frame_files_deflate: the PNG buffers must be 16-byte aligned, the lengths 8-byte aligned");
+    if (!(depth_scale > 0.0f)) return fail(GSR_ERR_INVALID_ARG, "gsr_frame_files_deflate: depth_scale must be positive");
+    GSR_HIP(gsr::launch_frame_files(color, alpha, depth, normal, depth_scale, turbo_lut, width, height, png_rgba, png_depth_preview, png_normal,
+                                    npy_plane, work, png_scratch, reinterpret_cast<unsigned long long*>(png_lengths), (hipStream_t)stream_));
+    return GSR_OK;
+}
+
+size_t gsr_png_deflate_max_size(int width, int height, int channels) { return gsr::png_deflate_max_bytes(width, height, channels); }
+size_t gsr_png_deflate_room(int width, int height, int channels) { return gsr::png_deflate_room_bytes(width, height, channels); }
+size_t gsr_png_deflate_scratch(int width, int height, int channels) { return gsr::png_deflate_scratch_bytes(width, height, channels); }
+
+int gsr_png_encode_deflate(const uint8_t* pixels, int width, int height, int channels, int planar, uint8_t* out, uint8_t* scratch, uint64_t* out_len,
+                           void* stream_) {
+    if (gsr::png_deflate_max_bytes(width, height, channels) == 0)
+        return fail(GSR_ERR_INVALID_ARG, "gsr_png_encode_deflate: %dx%d with %d channels cannot be encoded (3 or 4 channels, < 2 GB)", width, height, channels);
+    if (!pixels || !out || !scratch || !out_len) return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    if (((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(scratch)) & 15u) != 0 || (reinterpret_cast<uintptr_t>(out_len) & 7u) != 0)
+        return fail(GSR_ERR_INVALID_ARG, "gsr_png_encode_deflate: out and scratch must be 16-byte aligned, out_len 8-byte aligned");
+    GSR_HIP(gsr::launch_png_encode_deflate(pixels, width, height, channels, planar, out, scratch, reinterpret_cast<unsigned long long*>(out_len),
+                                           (hipStream_t)stream_));
     return GSR_OK;
 }
 

@@ -20,6 +20,7 @@
 //     conditioning is one more term, 0xFFFFFFFF x^(8 N) ^ 0xFFFFFFFF.
 #include "gsr_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <mutex>
 #include <vector>
@@ -318,6 +319,625 @@ bool png_layout(int W, int H, int C, int planar, PngLayout* L) {
 }
 
 // ================================================================================================
+// Compressed PNGs (round 6): the same file with an IDAT of DYNAMIC-HUFFMAN deflate blocks instead of stored ones.
+//
+// What the reference writes are compressed files (scene_representation.py:427-438: save_image -> PIL -> zlib level 6; cv2.imwrite ->
+// libpng).  What compresses a rendered frame is (a) a predictive scanline filter and (b) an entropy code fitted to the residuals;
+// LZ77 string matching buys almost nothing on such data (zlib's own Z_RLE strategy exists for that reason).  So:
+//   * every scanline is Paeth-filtered (PNG filter type 4: a pure function of the raw pixel and its left / upper / upper-left
+//     neighbours -- embarrassingly parallel);
+//   * tokens are literals and run-length matches only (distance 1, length 3 .. 64: "the byte before, n more times" -- flat
+//     backgrounds), found independently in every 64-byte piece of the filtered stream, one lane per piece;
+//   * ONE Huffman code per image, built on the GPU from the image's token histogram (length-limited to 15 bits, canonical), and
+//     sent in every block's header with a fixed 4-bit code for the code lengths (RFC 1951 3.2.7; 153 bytes per block);
+//   * the stream is cut into blocks of 16 KB of filtered bytes, one workgroup each.  A non-final block ends with an empty stored
+//     block (zlib's Z_SYNC_FLUSH marker, 00 00 FF FF after padding to a byte): every block's bits start on a byte boundary, so a
+//     block's place in the file is a prefix sum of BYTE counts -- known from the per-block histograms and the code lengths before
+//     a single bit is written; a block that would not shrink is sent stored.
+// Kernels, each launched ONCE for all images of a batch (a frame's three PNGs: blockIdx.y = image):
+//   png_filter_kernel   the filtered stream to scratch, 16 bytes per lane, Adler-32 partial sums            (HBM-bound, a few us)
+//   png_hist_kernel     one workgroup per block: tokens, histogram
+//   png_table_kernel    one workgroup per image: sort by count, Huffman's two-queue merge (the one serial step: 285 merges by one lane
+//                       with the queue heads in registers), depths / lengths / canonical codes in parallel, block sizes and places
+//   png_deflate_kernel  one workgroup per block: tokens -> bits in LDS (phase-aligned with the file), one coalesced copy out
+//   png_crc_dynamic_kernel / png_finish_dynamic_kernel   as for stored files, the lengths read from the device
+// First version (same round) re-filtered inside the histogram and deflate kernels and built the code on one lane out of LDS: 58 + 182 + 61 us
+// per image, three images one after the other (profiles/r06_png_deflate.md).
+// ================================================================================================
+constexpr uint32_t kDefBlock = 16384u;        // filtered-stream bytes per deflate block (= per workgroup)
+constexpr uint32_t kDefPiece = 64u;           // ... per lane
+constexpr uint32_t kDefPitch = 68u;           // LDS pitch of a piece: 17 words, conflict-free word accesses across lanes
+constexpr uint32_t kDefSyms = 288u;           // literal / length alphabet (286 used) padded
+constexpr uint32_t kDefHeaderBits = 3u + 14u + 19u * 3u + 287u * 4u;   // BFINAL + BTYPE, HLIT / HDIST / HCLEN, code-length code, 286 + 1 lengths = 1222
+constexpr uint32_t kDefHeaderBytes = (kDefHeaderBits + 7u) / 8u;        // 153
+constexpr uint32_t kFilterBytes = 4096u;      // stream bytes per workgroup of the filter kernel (16 per lane)
+constexpr int kMaxBatch = 3;
+
+struct PngDynamic {                // what the table kernel leaves for the kernels behind it (device memory)
+    unsigned long long data_len;   // IDAT payload: 2 + deflate bytes + 4
+    unsigned long long file_len;
+    uint32_t crc_init_term, crc_tail_shift;
+    uint32_t table[kDefSyms];      // bit-reversed code | length << 16
+    uint32_t header_words[(kDefHeaderBytes + 3u) / 4u + 1u];   // a dynamic block's first 1222 bits (BFINAL = 0)
+};
+
+struct DeflateScratch {            // offsets from the start of the image's scratch; `out` holds the file alone
+    size_t dyn_at, hist_at, adler_at, off_at, crc_at, stream_at, total, out_room;
+    uint32_t blocks, crc_groups, filter_groups;
+    unsigned long long file_max;
+};
+
+DeflateScratch deflate_scratch(const PngLayout& L) {
+    DeflateScratch d;
+    d.blocks = (uint32_t)((L.N + kDefBlock - 1ull) / kDefBlock);
+    d.filter_groups = (uint32_t)((L.N + kFilterBytes - 1ull) / kFilterBytes);
+    d.file_max = L.data_at + 2ull + 5ull * d.blocks + L.N + 4ull + 4ull + 12ull;
+    d.crc_groups = (uint32_t)((((d.file_max + kCrcChunk - 1ull) / kCrcChunk) + 255ull) / 256ull);
+    d.out_room = ((size_t)d.file_max + 64 + 15) & ~size_t(15);    // (the CRC kernel reads whole 64-byte chunks)
+    size_t at = 0;
+    d.dyn_at = at;    at += (sizeof(PngDynamic) + 15) & ~size_t(15);
+    d.hist_at = at;   at += (size_t)d.blocks * kDefSyms * 4;
+    d.adler_at = at;  at += (size_t)d.filter_groups * 16;
+    d.off_at = at;    at += (((size_t)d.blocks + 1) * 4 + 15) & ~size_t(15);
+    d.crc_at = at;    at += ((size_t)d.crc_groups * 4 + 15) & ~size_t(15);
+    d.stream_at = at; at += (size_t)d.blocks * kDefBlock + 16;   // the filtered scanline stream, whole blocks (the tail is never interpreted)
+    d.total = at;
+    return d;
+}
+
+struct PngJob {
+    PngLayout L;
+    const uint8_t* pixels;
+    uint8_t* out;                       // the file image
+    uint8_t* stream;                    // filtered scanline stream (scratch)
+    PngDynamic* dyn;
+    uint32_t* hist;                     // [blocks][288]
+    unsigned long long* adler;          // [filter_groups][2]
+    uint32_t* block_off;                // [blocks + 1]; bit 31: stored
+    uint32_t* crc_partials;             // [crc_groups]
+    unsigned long long* out_len;        // nullable
+    uint32_t blocks, filter_groups, crc_groups;
+};
+struct PngBatch { int n; PngJob job[kMaxBatch]; };
+
+// The filtered scanline stream's byte r: the row's filter type (4) in column 0, else raw - paeth(left, up, upper left) mod 256.
+__device__ __forceinline__ uint32_t paeth_stream_byte(const PngLayout& L, const uint8_t* __restrict__ pixels, uint32_t row, uint32_t col) {
+    if (col == 0u) return 4u;
+    const uint32_t c = col - 1u;
+    const uint32_t x = L.C == 4 ? c >> 2 : c / 3u, ch = c - x * (uint32_t)L.C;
+    const size_t at = L.planar ? ((size_t)ch * L.H + row) * L.W + x : ((size_t)row * L.W + x) * L.C + ch;
+    const size_t dx = L.planar ? 1 : (size_t)L.C, dy = L.planar ? (size_t)L.W : (size_t)L.W * L.C;
+    const int raw = pixels[at];
+    const int a = x > 0u ? pixels[at - dx] : 0, b = row > 0u ? pixels[at - dy] : 0, cc = (x > 0u && row > 0u) ? pixels[at - dy - dx] : 0;
+    const int pr = a + b - cc;
+    const int pa = abs(pr - a), pb = abs(pr - b), pc = abs(pr - cc);
+    const int pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : cc);
+    return (uint32_t)(raw - pred) & 255u;
+}
+
+// One lane = 16 consecutive bytes of the filtered stream (one 16-byte store); Adler-32's two sums per workgroup.
+__global__ void __launch_bounds__(256) png_filter_kernel(PngBatch B) {
+    if ((int)blockIdx.y >= B.n) return;
+    const PngJob& J = B.job[blockIdx.y];
+    if (blockIdx.x >= J.filter_groups) return;
+    const PngLayout& L = J.L;
+    __shared__ unsigned long long s_sum[4][2];
+    const unsigned long long r0 = ((unsigned long long)blockIdx.x * 256ull + threadIdx.x) * 16ull;
+    unsigned long long a1 = 0ull, a2 = 0ull;
+    if (r0 < L.N) {
+        uint32_t row = (uint32_t)(r0 / L.row_len), col = (uint32_t)(r0 - (unsigned long long)row * L.row_len);
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (r0 + (unsigned long long)k < L.N) {
+                const uint32_t v = paeth_stream_byte(L, J.pixels, row, col);
+                w[k >> 2] |= v << (8 * (k & 3));
+                a1 += v;
+                a2 += (L.N - (r0 + (unsigned long long)k)) * v;
+                if (++col == L.row_len) { col = 0u; ++row; }
+            }
+        }
+        *reinterpret_cast<uint4*>(J.stream + r0) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a1 += __shfl_xor(a1, d); a2 += __shfl_xor(a2, d); }
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6][0] = a1; s_sum[threadIdx.x >> 6][1] = a2 % 65521ull; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        J.adler[2 * (size_t)blockIdx.x + 0] = s_sum[0][0] + s_sum[1][0] + s_sum[2][0] + s_sum[3][0];
+        J.adler[2 * (size_t)blockIdx.x + 1] = (s_sum[0][1] + s_sum[1][1] + s_sum[2][1] + s_sum[3][1]) % 65521ull;
+    }
+}
+
+// A lane's 64-byte piece of the block from the filtered stream into LDS (for byte-wise reads while walking it); returns the byte in
+// front of the piece (256: there is none -- the first byte of the image).
+__device__ __forceinline__ uint32_t load_piece(const uint8_t* __restrict__ stream, uint32_t block, uint32_t t, uint8_t* s_piece) {
+    const size_t at = (size_t)block * kDefBlock + (size_t)t * kDefPiece;
+    const uint4* src = reinterpret_cast<const uint4*>(stream + at);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(s_piece);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint4 v = src[q];
+        dst[4 * q + 0] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+    }
+    return at == 0 ? 256u : (uint32_t)stream[at - 1];
+}
+
+// length 3 .. 64 -> (symbol - 257, extra bits, extra value)  (RFC 1951 3.2.5)
+__device__ __forceinline__ void length_code(uint32_t n, uint32_t* k, uint32_t* ebits, uint32_t* evalue) {
+    if (n < 11u) { *k = n - 3u; *ebits = 0u; *evalue = 0u; }
+    else if (n < 19u) { *k = 8u + ((n - 11u) >> 1); *ebits = 1u; *evalue = (n - 11u) & 1u; }
+    else if (n < 35u) { *k = 12u + ((n - 19u) >> 2); *ebits = 2u; *evalue = (n - 19u) & 3u; }
+    else { *k = 16u + ((n - 35u) >> 3); *ebits = 3u; *evalue = (n - 35u) & 7u; }
+}
+__host__ __device__ inline uint32_t length_symbol_extra_bits(uint32_t sym) {   // extra bits + the 1-bit distance code of a match symbol
+    if (sym < 257u) return 0u;
+    const uint32_t k = sym - 257u;
+    return (k < 8u ? 0u : k < 12u ? 1u : k < 16u ? 2u : k < 20u ? 3u : k < 24u ? 4u : k < 28u ? 5u : 0u) + 1u;
+}
+
+// One lane's piece of the block as tokens: f.literal(byte) / f.match(length).  `same` bit i: byte i equals the byte before it.
+template <class F>
+__device__ __forceinline__ void walk_piece(const uint8_t* piece, uint32_t prev, uint32_t count, F& f) {
+    unsigned long long same = 0ull;
+    uint32_t p = prev;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(piece);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const uint32_t v = w[q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t b = (v >> (8 * j)) & 255u;
+            if (b == p) same |= 1ull << (4 * q + j);
+            p = b;
+        }
+    }
+    if (count < 64u) same &= (1ull << count) - 1ull;
+    uint32_t i = 0u;
+    while (i < count) {
+        if ((same >> i) & 1ull) {
+            const unsigned long long rest = ~(same >> i);
+            uint32_t n = rest ? (uint32_t)__builtin_ctzll(rest) : 64u;
+            if (n > count - i) n = count - i;
+            if (n >= 3u) { f.match(n); i += n; continue; }
+        }
+        f.literal(piece[i]);
+        ++i;
+    }
+}
+
+struct HistTokens {
+    uint32_t* hist;
+    __device__ __forceinline__ void literal(uint32_t b) { atomicAdd(&hist[b], 1u); }
+    __device__ __forceinline__ void match(uint32_t n) { uint32_t k, e, v; length_code(n, &k, &e, &v); atomicAdd(&hist[257u + k], 1u); }
+};
+
+__device__ __forceinline__ uint32_t block_length(const PngLayout& L, uint32_t block) {
+    const unsigned long long left = L.N - (unsigned long long)block * kDefBlock;
+    return left < kDefBlock ? (uint32_t)left : kDefBlock;
+}
+
+__global__ void __launch_bounds__(256) png_hist_kernel(PngBatch B) {
+    if ((int)blockIdx.y >= B.n) return;
+    const PngJob& J = B.job[blockIdx.y];
+    if (blockIdx.x >= J.blocks) return;
+    __shared__ __attribute__((aligned(16))) uint8_t s_stream[256 * kDefPitch];
+    __shared__ uint32_t s_hist[4][kDefSyms];
+    const uint32_t block = blockIdx.x, t = threadIdx.x;
+    const uint32_t blen = block_length(J.L, block);
+    for (uint32_t i = t; i < 4u * kDefSyms; i += 256u) (&s_hist[0][0])[i] = 0u;
+    const uint32_t prev = load_piece(J.stream, block, t, s_stream + t * kDefPitch);
+    __syncthreads();
+    const uint32_t first = t * kDefPiece;
+    if (first < blen) {
+        HistTokens f = {s_hist[t >> 6]};
+        walk_piece(s_stream + t * kDefPitch, prev, blen - first < kDefPiece ? blen - first : kDefPiece, f);
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < kDefSyms; i += 256u)
+        J.hist[(size_t)block * kDefSyms + i] = s_hist[0][i] + s_hist[1][i] + s_hist[2][i] + s_hist[3][i] + (i == 256u ? 1u : 0u);   // + the block's end-of-block
+}
+
+__device__ __forceinline__ uint32_t bit_reverse(uint32_t v, uint32_t n) { return __brev(v) >> (32u - n); }
+
+// ONE workgroup per image: the Huffman code of the image's tokens, every block's size and place, the head of the file.
+__global__ void __launch_bounds__(256) png_table_kernel(PngBatch B, PngTables T) {
+    if ((int)blockIdx.x >= B.n) return;
+    const PngJob& J = B.job[blockIdx.x];
+    const PngLayout& L = J.L;
+    const uint32_t blocks = J.blocks;
+    __shared__ unsigned long long s_key[512];     // count << 16 | symbol, ascending; unused symbols sort to the end
+    __shared__ uint32_t s_weight[kDefSyms];       // internal nodes of the Huffman tree, in creation order
+    __shared__ uint16_t s_parent_leaf[kDefSyms], s_parent_node[kDefSyms];
+    __shared__ uint8_t s_len[kDefSyms];           // by symbol
+    __shared__ uint8_t s_depth[kDefSyms];         // by sorted position
+    __shared__ uint32_t s_code[kDefSyms];
+    __shared__ uint32_t s_count_of[17], s_next_code[17];
+    __shared__ uint32_t s_n, s_carry;
+    __shared__ uint32_t s_header[(kDefHeaderBytes + 3u) / 4u + 1u];
+    __shared__ uint32_t s_scan[256];
+    const uint32_t t = threadIdx.x;
+    for (uint32_t s = t; s < 512u; s += 256u) {
+        unsigned long long key = ~0ull;
+        if (s < 286u) {
+            uint32_t c = 0u;
+            for (uint32_t b = 0; b < blocks; ++b) c += J.hist[(size_t)b * kDefSyms + s];
+            if (c) key = ((unsigned long long)c << 16) | s;
+        }
+        s_key[s] = key;
+    }
+    for (uint32_t s = t; s < kDefSyms; s += 256u) { s_len[s] = 0; s_code[s] = 0u; s_depth[s] = 0; }
+    for (uint32_t s = t; s < sizeof(s_header) / 4u; s += 256u) s_header[s] = 0u;
+    if (t < 17u) s_count_of[t] = 0u;
+    __syncthreads();
+    // bitonic sort of the 512 keys, one compare-exchange per lane and step
+    for (uint32_t k = 2u; k <= 512u; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
+            const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), p = i | j;      // the t-th pair of this step
+            const bool up = (i & k) == 0u;
+            const unsigned long long a = s_key[i], b = s_key[p];
+            if ((a > b) == up) { s_key[i] = b; s_key[p] = a; }
+            __syncthreads();
+        }
+    }
+    if (t == 0) {
+        uint32_t n = 0u;
+        { uint32_t lo = 0u, hi = 286u; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_key[mid] != ~0ull) lo = mid + 1u; else hi = mid; } n = lo; }
+        s_n = n;
+        // Huffman's algorithm on sorted leaves with two queues (leaves by count, internal nodes in creation order).  The heads of both
+        // queues live in registers and the next head is fetched while the current one is used: the merge never waits on LDS twice in a row.
+        if (n >= 2u) {
+            const uint32_t kInf = 0xFFFFFFFFu;
+            uint32_t li = 0u, ni = 0u;
+            uint32_t leaf_w = (uint32_t)(s_key[0] >> 16), leaf_next = n > 1u ? (uint32_t)(s_key[1] >> 16) : kInf;
+            uint32_t node_w = kInf, node_next = kInf;          // weights of nodes ni, ni + 1 (kInf: not made yet)
+            for (uint32_t k = 0; k + 1u < n; ++k) {
+                uint32_t w = 0u;
+#pragma unroll
+                for (int pick = 0; pick < 2; ++pick) {
+                    if (leaf_w <= node_w) {                     // (a tie takes the leaf: shallower trees)
+                        w += leaf_w;
+                        s_parent_leaf[li] = (uint16_t)k;
+                        ++li;
+                        leaf_w = leaf_next;
+                        leaf_next = li + 1u < n ? (uint32_t)(s_key[li + 1u] >> 16) : kInf;
+                    } else {
+                        w += node_w;
+                        s_parent_node[ni] = (uint16_t)k;
+                        ++ni;
+                        node_w = node_next;
+                        node_next = ni + 1u < k ? s_weight[ni + 1u] : kInf;     // nodes < k exist; k itself is forwarded below
+                    }
+                }
+                s_weight[k] = w;
+                if (ni == k) node_w = w;                        // the queue was empty: the new node is its head
+                else if (ni + 1u == k) node_next = w;           // ... or the one behind the head
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n = s_n;
+    // every leaf walks up to the root (node n - 2): its depth, clamped to 15
+    for (uint32_t j = t; j < n; j += 256u) {
+        uint32_t d = 1u;
+        if (n >= 2u) {
+            uint32_t p = s_parent_leaf[j];
+            while (p != n - 2u) { p = s_parent_node[p]; ++d; }
+        }
+        if (d > 15u) d = 15u;
+        s_depth[j] = (uint8_t)d;
+        atomicAdd(&s_count_of[d], 1u);
+    }
+    __syncthreads();
+    if (t == 0) {
+        // length limit (zlib trees.c gen_bitlen): while the code is over-subscribed, split a shorter code and drop one 15-bit code
+        for (;;) {
+            unsigned long long kraft = 0ull;
+            for (uint32_t d = 1; d <= 15u; ++d) kraft += (unsigned long long)s_count_of[d] << (15u - d);
+            if (kraft <= (1ull << 15) || n < 2u) break;
+            uint32_t bits = 14u;
+            while (s_count_of[bits] == 0u) --bits;
+            --s_count_of[bits]; s_count_of[bits + 1u] += 2u; --s_count_of[15];
+        }
+        uint32_t code = 0u;
+        s_count_of[0] = 0u;
+        for (uint32_t d = 1; d <= 15u; ++d) { code = (code + s_count_of[d - 1u]) << 1; s_next_code[d] = code; }
+        // the fixed part of a dynamic block's header: BFINAL 0, BTYPE 10, HLIT 29, HDIST 0, HCLEN 15, the code-length code: lengths 0 .. 15 as 4-bit codes
+        uint32_t bit = 0u;
+        auto put = [&](uint32_t v, uint32_t nb) { s_header[bit >> 5] |= v << (bit & 31u); if ((bit & 31u) + nb > 32u) s_header[(bit >> 5) + 1u] |= v >> (32u - (bit & 31u)); bit += nb; };
+        put(0u, 1u); put(2u, 2u); put(29u, 5u); put(0u, 5u); put(15u, 4u);
+        const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        for (int q = 0; q < 19; ++q) put(order[q] >= 16 ? 0u : 4u, 3u);
+    }
+    __syncthreads();
+    // the rarest symbols get the longest codes: sorted position j (ascending count) has the length d with
+    // sum_{e > d} count_of[e] <= j < sum_{e >= d} count_of[e]
+    for (uint32_t j = t; j < n; j += 256u) {
+        uint32_t before = 0u, d = 15u;
+        for (; d >= 1u; --d) { if (j < before + s_count_of[d]) break; before += s_count_of[d]; }
+        s_len[(uint32_t)(s_key[j] & 0xFFFFull)] = (uint8_t)d;
+    }
+    __syncthreads();
+    // canonical codes (RFC 1951 3.2.2): a symbol's code is its length's first code plus the number of smaller symbols of that length
+    for (uint32_t s = t; s < 286u; s += 256u) {
+        const uint32_t len = s_len[s];
+        if (len) {
+            uint32_t rank = 0u;
+            for (uint32_t q = 0; q < s; ++q) rank += s_len[q] == len ? 1u : 0u;
+            s_code[s] = bit_reverse(s_next_code[len] + rank, len);
+        }
+    }
+    // the 286 literal / length code lengths and the one distance code length (1), each as its 4-bit code, most significant bit first
+    for (uint32_t s = t; s < 287u; s += 256u) {
+        const uint32_t v = bit_reverse(s < 286u ? s_len[s] : 1u, 4u), bit = 74u + 4u * s;
+        atomicOr(&s_header[bit >> 5], v << (bit & 31u));
+        if ((bit & 31u) > 28u) atomicOr(&s_header[(bit >> 5) + 1u], v >> (32u - (bit & 31u)));
+    }
+    __syncthreads();
+    for (uint32_t s = t; s < kDefSyms; s += 256u) J.dyn->table[s] = s_code[s] | ((uint32_t)s_len[s] << 16);
+    for (uint32_t s = t; s < sizeof(s_header) / 4u; s += 256u) J.dyn->header_words[s] = s_header[s];
+    // every block's size in bytes -- the cheaper of dynamic and stored -- and its place: an exclusive prefix sum.  A wave per block:
+    // the 286 counts times their code lengths, 64 at a time.
+    if (t == 0) s_carry = 0u;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < blocks; b0 += 256u) {
+        for (uint32_t q = 0; q < 64u; ++q) {                       // wave w takes blocks b0 + 64 w + q
+            const uint32_t b = b0 + (t >> 6) * 64u + q;
+            if (b >= blocks) break;                                // (wave-uniform)
+            uint32_t bits = 0u;
+            for (uint32_t s = t & 63u; s < 286u; s += 64u) {
+                const uint32_t c = J.hist[(size_t)b * kDefSyms + s];
+                bits += c * ((uint32_t)s_len[s] + length_symbol_extra_bits(s));
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) bits += __shfl_xor(bits, d);
+            if ((t & 63u) == 0u) s_scan[(t >> 6) * 64u + q] = bits;
+        }
+        __syncthreads();
+        const uint32_t b = b0 + t;
+        uint32_t bytes = 0u, stored_flag = 0u;
+        if (b < blocks) {
+            const uint32_t blen = block_length(L, b);
+            const unsigned long long bits = (unsigned long long)kDefHeaderBits + s_scan[t];
+            const bool last = b + 1u == blocks;
+            const unsigned long long dyn_bytes = last ? (bits + 7ull) >> 3 : ((bits + 3ull + 7ull) >> 3) + 4ull;
+            bytes = 5u + blen;
+            if (dyn_bytes <= bytes) bytes = (uint32_t)dyn_bytes; else stored_flag = 1u << 31;
+        }
+        __syncthreads();
+        s_scan[t] = bytes;
+        __syncthreads();
+        for (uint32_t d = 1; d < 256u; d <<= 1) {
+            const uint32_t v = t >= d ? s_scan[t - d] : 0u;
+            __syncthreads();
+            s_scan[t] += v;
+            __syncthreads();
+        }
+        if (b < blocks) J.block_off[b] = (s_carry + s_scan[t] - bytes) | stored_flag;
+        __syncthreads();
+        if (t == 255u) s_carry += s_scan[255];
+        __syncthreads();
+    }
+    if (t == 0) {
+        const uint32_t total = s_carry;
+        J.block_off[blocks] = total;
+        const unsigned long long data_len = 2ull + total + 4ull, file_len = L.data_at + data_len + 4ull + 12ull;
+        J.dyn->data_len = data_len;
+        J.dyn->file_len = file_len;
+        J.dyn->crc_init_term = crc_multmodp(crc_x2nmodp(T.x2n, 4ull + data_len, 3u), 0xFFFFFFFFu);
+        J.dyn->crc_tail_shift = crc_x2nmodp(T.x2n, (L.data_at + data_len) & 63ull, 3u);
+        if (J.out_len) *J.out_len = file_len;
+        uint8_t* out = J.out;
+        for (uint32_t i = 0; i < (uint32_t)L.data_at; ++i) out[i] = L.head[i];
+        out[33] = (uint8_t)(data_len >> 24); out[34] = (uint8_t)(data_len >> 16); out[35] = (uint8_t)(data_len >> 8); out[36] = (uint8_t)data_len;
+        out[L.data_at] = 0x78u; out[L.data_at + 1ull] = 0x01u;
+    }
+}
+
+struct SizeTokens {
+    const uint32_t* table;
+    uint32_t bits;
+    __device__ __forceinline__ void literal(uint32_t b) { bits += table[b] >> 16; }
+    __device__ __forceinline__ void match(uint32_t n) { uint32_t k, e, v; length_code(n, &k, &e, &v); bits += (table[257u + k] >> 16) + e + 1u; }
+};
+struct EmitTokens {
+    const uint32_t* table;
+    uint32_t* out;                 // LDS words, zeroed
+    unsigned long long acc;
+    uint32_t nacc, word;
+    __device__ __forceinline__ void put(uint32_t v, uint32_t nb) {
+        acc |= (unsigned long long)v << nacc;
+        nacc += nb;
+        if (nacc >= 32u) { atomicOr(&out[word++], (uint32_t)acc); acc >>= 32; nacc -= 32u; }
+    }
+    __device__ __forceinline__ void literal(uint32_t b) { const uint32_t e = table[b]; put(e & 0xFFFFu, e >> 16); }
+    __device__ __forceinline__ void match(uint32_t n) {
+        uint32_t k, eb, ev;
+        length_code(n, &k, &eb, &ev);
+        const uint32_t e = table[257u + k];
+        put(e & 0xFFFFu, e >> 16);
+        put(ev, eb + 1u);          // the extra bits, then the one distance code: a single 0 bit
+    }
+    __device__ __forceinline__ void flush() { if (nacc) atomicOr(&out[word], (uint32_t)acc); }
+};
+
+__global__ void __launch_bounds__(256) png_deflate_kernel(PngBatch B) {
+    if ((int)blockIdx.y >= B.n) return;
+    const PngJob& J = B.job[blockIdx.y];
+    if (blockIdx.x >= J.blocks) return;
+    const PngLayout& L = J.L;
+    uint8_t* __restrict__ out = J.out;
+    __shared__ __attribute__((aligned(16))) uint8_t s_stream[256 * kDefPitch];
+    __shared__ uint32_t s_out[(kDefBlock + 5u + 3u) / 4u + 3u];
+    __shared__ uint32_t s_table[kDefSyms];
+    __shared__ uint32_t s_wave[4];
+    const uint32_t block = blockIdx.x, t = threadIdx.x, blocks = J.blocks;
+    const uint32_t blen = block_length(L, block);
+    const bool last = block + 1u == blocks;
+    const uint32_t off = J.block_off[block];
+    const bool stored = (off >> 31) != 0u;
+    const unsigned long long g0 = L.data_at + 2ull + (off & 0x7FFFFFFFu);           // the block's first byte in the file
+    const uint32_t bytes = (J.block_off[block + 1u] & 0x7FFFFFFFu) - (off & 0x7FFFFFFFu);
+    if (stored) {
+        const uint8_t* src = J.stream + (size_t)block * kDefBlock;
+        if (t < 5u) out[g0 + t] = (uint8_t)(t == 0u ? (last ? 1u : 0u) : t == 1u ? (blen & 255u) : t == 2u ? (blen >> 8) : t == 3u ? (~blen & 255u) : ((~blen >> 8) & 255u));
+        for (uint32_t i = t; i < blen; i += 256u) out[g0 + 5ull + i] = src[i];
+        return;
+    }
+    for (uint32_t i = t; i < kDefSyms; i += 256u) s_table[i] = J.dyn->table[i];
+    for (uint32_t i = t; i < sizeof(s_out) / 4u; i += 256u) s_out[i] = 0u;
+    const uint32_t prev = load_piece(J.stream, block, t, s_stream + t * kDefPitch);
+    __syncthreads();
+    // LDS image of the block, phased like the file: LDS byte (g0 & 3) is file byte g0, so whole LDS words are whole file words
+    const uint32_t phase = (uint32_t)(g0 & 3ull);
+    const uint32_t first = t * kDefPiece;
+    const uint32_t count = first < blen ? (blen - first < kDefPiece ? blen - first : kDefPiece) : 0u;
+    SizeTokens sz = {s_table, 0u};
+    if (count) walk_piece(s_stream + t * kDefPitch, prev, count, sz);
+    // exclusive prefix sum of the lanes' bit counts
+    uint32_t incl = sz.bits;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); if ((t & 63u) >= (uint32_t)d) incl += v; }
+    if ((t & 63u) == 63u) s_wave[t >> 6] = incl;
+    // the block header's bytes, meanwhile (byte granular: the block starts on a byte)
+    if (t < kDefHeaderBytes) {
+        uint32_t v = reinterpret_cast<const uint8_t*>(J.dyn->header_words)[t];
+        if (t == 0u && last) v |= 1u;     // BFINAL
+        atomicOr(&s_out[(phase + t) >> 2], v << (8u * ((phase + t) & 3u)));
+    }
+    __syncthreads();
+    uint32_t before = 0u;
+    for (uint32_t w = 0; w < (t >> 6); ++w) before += s_wave[w];
+    const uint32_t total_bits = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    const uint32_t my_bit = phase * 8u + kDefHeaderBits + before + incl - sz.bits;
+    if (count) {
+        EmitTokens em = {s_table, s_out, 0ull, my_bit & 31u, my_bit >> 5};
+        walk_piece(s_stream + t * kDefPitch, prev, count, em);
+        em.flush();
+    }
+    if (t == 0) {   // end of block; for a non-final block an empty stored block: 3 zero bits, padding to a byte, 00 00 FF FF
+        const uint32_t e = s_table[256];
+        const uint32_t at = phase * 8u + kDefHeaderBits + total_bits;
+        EmitTokens em = {s_table, s_out, 0ull, at & 31u, at >> 5};
+        em.put(e & 0xFFFFu, e >> 16);
+        em.flush();
+        if (!last) {
+            const uint32_t nlen = ((at + (e >> 16) + 3u + 7u) & ~7u) + 16u;     // LEN (16 zero bits) starts on the next byte boundary behind the 3 header bits; NLEN = FFFF
+            atomicOr(&s_out[nlen >> 5], 0xFFFFu << (nlen & 31u));
+            if ((nlen & 31u) > 16u) atomicOr(&s_out[(nlen >> 5) + 1u], 0xFFFFu >> (32u - (nlen & 31u)));
+        }
+    }
+    __syncthreads();
+    // copy out: file bytes [g0, g0 + bytes) are LDS bytes [phase, phase + bytes); whole words where the file word is wholly this block's
+    const uint8_t* ob = reinterpret_cast<const uint8_t*>(s_out);
+    const uint32_t lo = phase, hi = phase + bytes;                       // LDS byte range
+    const uint32_t wlo = (lo + 3u) >> 2, whi = hi >> 2;                  // whole words [wlo, whi)
+    uint8_t* fbase = out + (g0 - phase);                                 // file address of LDS byte 0 (4-byte aligned)
+    for (uint32_t w = wlo + t; w < whi; w += 256u) reinterpret_cast<uint32_t*>(fbase)[w] = s_out[w];
+    if (t < 4u) {
+        const uint32_t i = lo + t;
+        if (i < (wlo << 2) && i < hi) fbase[i] = ob[i];
+        const uint32_t j = (whi << 2) + t;
+        if (j >= lo && j < hi && whi >= wlo) fbase[j] = ob[j];
+    }
+}
+
+// CRC-32 and the last bytes of a deflate-compressed file: as png_crc_kernel / png_finish_kernel, with the lengths read from the device
+__global__ void __launch_bounds__(256) png_crc_dynamic_kernel(PngBatch B, PngTables T) {
+    if ((int)blockIdx.y >= B.n) return;
+    const PngJob& J = B.job[blockIdx.y];
+    if (blockIdx.x >= J.crc_groups) return;
+    const PngLayout& L = J.L;
+    const uint8_t* __restrict__ file = J.out;
+    __shared__ uint32_t s_t[4][256];
+    __shared__ uint32_t s_shift[3][256];
+    __shared__ uint32_t s_crc[4];
+    {
+        const int i = threadIdx.x;
+        const uint32_t t0 = T.byte[i];
+        const uint32_t t1 = (t0 >> 8) ^ T.byte[t0 & 0xFFu];
+        const uint32_t t2 = (t1 >> 8) ^ T.byte[t1 & 0xFFu];
+        s_t[0][i] = t0; s_t[1][i] = t1; s_t[2][i] = t2; s_t[3][i] = (t2 >> 8) ^ T.byte[t2 & 0xFFu];
+        s_shift[0][i] = g_crc_shift64[0][i]; s_shift[1][i] = g_crc_shift64[1][i]; s_shift[2][i] = g_crc_shift64[2][i];
+    }
+    __syncthreads();
+    const unsigned long long data_len = J.dyn->data_len;
+    const uint32_t tail_shift = J.dyn->crc_tail_shift;
+    // "IDAT" ... the last deflate byte; the four Adler bytes that end the message are folded in by the finish kernel, which writes them
+    const unsigned long long crc_from = L.data_at - 4ull, crc_end = L.data_at + data_len, body_end = crc_end - 4ull;
+    const unsigned long long lo0 = ((unsigned long long)blockIdx.x * 256ull + threadIdx.x) * kCrcChunk;
+    uint32_t crc = 0u;
+    if (lo0 < body_end && lo0 + kCrcChunk > crc_from) {
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = lo0 + 16u * k < body_end ? *reinterpret_cast<const uint4*>(file + lo0 + 16u * k) : make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t w[16] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w, v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
+        const unsigned long long lo = lo0 < crc_from ? crc_from : lo0, hi = lo0 + kCrcChunk < body_end ? lo0 + kCrcChunk : body_end;
+        if (lo == lo0 && hi == lo0 + kCrcChunk) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t x = crc ^ w[k];
+                crc = s_t[3][x & 0xFFu] ^ s_t[2][(x >> 8) & 0xFFu] ^ s_t[1][(x >> 16) & 0xFFu] ^ s_t[0][x >> 24];
+            }
+        } else {
+            for (unsigned long long f = lo; f < hi; ++f) {
+                const uint32_t b = (w[(f - lo0) >> 2] >> (8 * ((f - lo0) & 3ull))) & 0xFFu;
+                crc = s_t[0][(crc ^ b) & 0xFFu] ^ (crc >> 8);
+            }
+        }
+        if (crc != 0u) {   // crc_end - hi bytes lie behind this piece: a multiple of 64 plus (crc_end mod 64) when hi is a chunk end, anything for the last piece
+            const unsigned long long behind = crc_end - hi;
+            if ((hi & 63ull) == 0ull) {
+                const unsigned long long m = behind >> 6;
+                crc = crc_multmodp(tail_shift, crc);
+                if (m & 0xFFull) crc = crc_multmodp(s_shift[0][m & 0xFFull], crc);
+                if ((m >> 8) & 0xFFull) crc = crc_multmodp(s_shift[1][(m >> 8) & 0xFFull], crc);
+                if (m >> 16) crc = crc_multmodp(s_shift[2][(m >> 16) & 0xFFull], crc);
+            } else {
+                crc = crc_multmodp(crc_x2nmodp(T.x2n, behind, 3u), crc);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) crc ^= (uint32_t)__shfl_xor((int)crc, d);
+    if ((threadIdx.x & 63) == 0) s_crc[threadIdx.x >> 6] = crc;
+    __syncthreads();
+    if (threadIdx.x == 0) J.crc_partials[blockIdx.x] = s_crc[0] ^ s_crc[1] ^ s_crc[2] ^ s_crc[3];
+}
+
+__global__ void __launch_bounds__(64) png_finish_dynamic_kernel(PngBatch B) {
+    if ((int)blockIdx.x >= B.n) return;
+    const PngJob& J = B.job[blockIdx.x];
+    const PngLayout& L = J.L;
+    uint8_t* __restrict__ out = J.out;
+    unsigned long long a1 = 0ull, a2 = 0ull;
+    uint32_t crc_sum = 0u;
+    for (uint32_t i = threadIdx.x; i < J.filter_groups; i += 64u) { a1 += J.adler[2 * (size_t)i]; a2 += J.adler[2 * (size_t)i + 1]; }
+    for (uint32_t i = threadIdx.x; i < J.crc_groups; i += 64u) crc_sum ^= J.crc_partials[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        a1 += __shfl_xor(a1, d);
+        a2 += __shfl_xor(a2, d);
+        crc_sum ^= (uint32_t)__shfl_xor((int)crc_sum, d);
+    }
+    if (threadIdx.x != 0) return;
+    const uint32_t s1 = (uint32_t)((1ull + a1) % 65521ull);
+    const uint32_t s2 = (uint32_t)((L.N % 65521ull + a2) % 65521ull);
+    const uint32_t adler = (s2 << 16) | s1;
+    const unsigned long long adler_at = L.data_at + J.dyn->data_len - 4ull;
+    uint32_t crc_a = 0u;
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t b = (adler >> (24 - 8 * k)) & 0xFFu;
+        out[adler_at + k] = (uint8_t)b;
+        crc_a ^= b;
+        for (int i = 0; i < 8; ++i) crc_a = (crc_a & 1u) ? (crc_a >> 1) ^ kCrcPoly : crc_a >> 1;
+    }
+    const uint32_t crc = (crc_sum ^ crc_a ^ J.dyn->crc_init_term) ^ 0xFFFFFFFFu;
+    for (int k = 0; k < 4; ++k) out[adler_at + 4 + k] = (uint8_t)(crc >> (24 - 8 * k));
+    for (int k = 0; k < 12; ++k) out[adler_at + 8 + k] = L.tail[k];
+}
+
+// ================================================================================================
 // PIL's Image.resize, bit for bit (blender/blend_all.py:21-28: downsample_image = Image.fromarray(a).resize(new_size, BILINEAR) for
 // the RGBA8 layers, resize(new_size, NEAREST) for the float depth maps; called on every Blender layer of every frame, :217-234).
 //
@@ -507,10 +1127,13 @@ namespace {
 // table -- and the normal map, uint8((n + 1) / 2 * 255): the same fp32 operations in the same order, truncation.
 __global__ void __launch_bounds__(256) frame_previews_kernel(const float* __restrict__ depth, const float* __restrict__ normal /*[H,W,3]*/,
                                                             float depth_scale, const uint8_t* __restrict__ lut /*[256,3]*/, size_t n_pixels,
-                                                            uint8_t* __restrict__ depth_rgb, uint8_t* __restrict__ normal_rgb) {
+                                                            uint8_t* __restrict__ depth_rgb, uint8_t* __restrict__ normal_rgb,
+                                                            float* __restrict__ depth_copy /*the .npy plane: the depth map as it is*/) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_pixels) return;
-    const float d = fminf(fmaxf(depth[i] / depth_scale, 0.0f), 1.0f) * 255.0f;
+    const float depth_i = depth[i];
+    depth_copy[i] = depth_i;
+    const float d = fminf(fmaxf(depth_i / depth_scale, 0.0f), 1.0f) * 255.0f;
     const uint32_t idx = (uint32_t)(int)d & 255u;
     depth_rgb[3 * i + 0] = lut[3 * idx + 0];
     depth_rgb[3 * i + 1] = lut[3 * idx + 1];
@@ -523,10 +1146,14 @@ __global__ void __launch_bounds__(256) frame_previews_kernel(const float* __rest
 }
 } // namespace
 
+hipError_t launch_png_encode_deflate_batch(int n, const uint8_t* const* pixels, const int* Ws, const int* Hs, const int* Cs, const int* planars,
+                                           uint8_t* const* outs, uint8_t* const* scratches, unsigned long long* const* out_lens, hipStream_t stream);
+
 // One frame's four files (gsr.h: gsr_frame_files): quantise, colour, encode, copy -- ten launches queued by ONE host call.
 hipError_t launch_frame_files(const float* color, const float* alpha, const float* depth, const float* normal, float depth_scale,
                               const uint8_t* turbo_lut, int W, int H, uint8_t* png_rgba, uint8_t* png_depth, uint8_t* png_normal,
-                              float* npy_plane, uint8_t* work, hipStream_t stream) {
+                              float* npy_plane, uint8_t* work, uint8_t* png_scratch, unsigned long long* png_lengths /*both null: stored PNGs; else
+                              scratch for the three compressed files and [3] lengths, device*/, hipStream_t stream) {
     const size_t n = (size_t)W * H;
     uint8_t* rgba8 = work;                 // planar [4,H,W]
     uint8_t* depth_rgb = work + 4 * n;     // [H,W,3]
@@ -534,15 +1161,36 @@ hipError_t launch_frame_files(const float* color, const float* alpha, const floa
     hipError_t e = launch_pack_rgba8(color, alpha, rgba8, n, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(frame_previews_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, depth, normal, depth_scale, turbo_lut, n,
-                       depth_rgb, normal_rgb);
+                       depth_rgb, normal_rgb, npy_plane);
     const size_t sizes[3] = {png_file_bytes(W, H, 4), png_file_bytes(W, H, 3), png_file_bytes(W, H, 3)};
     uint8_t* outs[3] = {png_rgba, png_depth, png_normal};
     const uint8_t* srcs[3] = {rgba8, depth_rgb, normal_rgb};
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 3; ++k)
         if (sizes[k] == 0) return hipErrorInvalidValue;
-        if ((e = launch_png_encode(srcs[k], W, H, k == 0 ? 4 : 3, k == 0 ? 1 : 0, outs[k], stream)) != hipSuccess) return e;
+    if (png_lengths) {
+        const int Ws[3] = {W, W, W}, Hs[3] = {H, H, H}, Cs[3] = {4, 3, 3}, planars[3] = {1, 0, 0};
+        unsigned long long* lens[3] = {png_lengths, png_lengths + 1, png_lengths + 2};
+        const size_t s4 = png_deflate_scratch_bytes(W, H, 4), s3 = png_deflate_scratch_bytes(W, H, 3);
+        uint8_t* scratches[3] = {png_scratch, png_scratch + s4, png_scratch + s4 + s3};
+        return launch_png_encode_deflate_batch(3, srcs, Ws, Hs, Cs, planars, outs, scratches, lens, stream);
     }
-    return hipMemcpyAsync(npy_plane, depth, n * sizeof(float), hipMemcpyDeviceToDevice, stream);
+    for (int k = 0; k < 3; ++k)
+        if ((e = launch_png_encode(srcs[k], W, H, k == 0 ? 4 : 3, k == 0 ? 1 : 0, outs[k], stream)) != hipSuccess) return e;
+    return hipSuccess;
+}
+
+// ---- deflate-compressed files: sizes and the launch sequence ----
+size_t png_deflate_max_bytes(int W, int H, int C) {
+    PngLayout L;
+    return png_layout(W, H, C, 0, &L) ? (size_t)deflate_scratch(L).file_max : 0;
+}
+size_t png_deflate_room_bytes(int W, int H, int C) {
+    PngLayout L;
+    return png_layout(W, H, C, 0, &L) ? deflate_scratch(L).out_room : 0;
+}
+size_t png_deflate_scratch_bytes(int W, int H, int C) {
+    PngLayout L;
+    return png_layout(W, H, C, 0, &L) ? deflate_scratch(L).total : 0;
 }
 
 size_t png_file_bytes(int W, int H, int C) {
@@ -605,6 +1253,48 @@ hipError_t launch_png_encode(const uint8_t* pixels, int W, int H, int C, int pla
     hipLaunchKernelGGL(png_crc_kernel, dim3(p.crc_groups), dim3(256), 0, stream, L, png_tables(), out, crc_partials);
     hipLaunchKernelGGL(png_finish_kernel, dim3(1), dim3(64), 0, stream, L, out, adler_partials, p.enc_groups, crc_partials, p.crc_groups);
     return hipGetLastError();
+}
+
+// A batch of up to three images (a frame's three PNGs), every kernel launched once for all of them.  outs[i]: png_deflate_room_bytes(...)
+// bytes (the file), scratches[i]: png_deflate_scratch_bytes(...) bytes, both 16-byte aligned; the files' lengths go to out_lens[i] (device
+// memory; entries may be null).  Six launches per batch, no memset, no global atomics.
+hipError_t launch_png_encode_deflate_batch(int n, const uint8_t* const* pixels, const int* Ws, const int* Hs, const int* Cs, const int* planars,
+                                           uint8_t* const* outs, uint8_t* const* scratches, unsigned long long* const* out_lens, hipStream_t stream) {
+    if (n < 1 || n > kMaxBatch) return hipErrorInvalidValue;
+    const hipError_t ready = ensure_shift_tables();
+    if (ready != hipSuccess) return ready;
+    PngBatch B;
+    B.n = n;
+    uint32_t max_filter = 0u, max_blocks = 0u, max_crc = 0u;
+    for (int i = 0; i < n; ++i) {
+        PngJob& J = B.job[i];
+        if (!png_layout(Ws[i], Hs[i], Cs[i], planars[i], &J.L)) return hipErrorInvalidValue;
+        const DeflateScratch d = deflate_scratch(J.L);
+        uint8_t* sc = scratches[i];
+        J.pixels = pixels[i];
+        J.out = outs[i];
+        J.stream = sc + d.stream_at;
+        J.dyn = reinterpret_cast<PngDynamic*>(sc + d.dyn_at);
+        J.hist = reinterpret_cast<uint32_t*>(sc + d.hist_at);
+        J.adler = reinterpret_cast<unsigned long long*>(sc + d.adler_at);
+        J.block_off = reinterpret_cast<uint32_t*>(sc + d.off_at);
+        J.crc_partials = reinterpret_cast<uint32_t*>(sc + d.crc_at);
+        J.out_len = out_lens ? out_lens[i] : nullptr;
+        J.blocks = d.blocks; J.filter_groups = d.filter_groups; J.crc_groups = d.crc_groups;
+        max_filter = std::max(max_filter, d.filter_groups); max_blocks = std::max(max_blocks, d.blocks); max_crc = std::max(max_crc, d.crc_groups);
+    }
+    hipLaunchKernelGGL(png_filter_kernel, dim3(max_filter, n), dim3(256), 0, stream, B);
+    hipLaunchKernelGGL(png_hist_kernel, dim3(max_blocks, n), dim3(256), 0, stream, B);
+    hipLaunchKernelGGL(png_table_kernel, dim3(n), dim3(256), 0, stream, B, png_tables());
+    hipLaunchKernelGGL(png_deflate_kernel, dim3(max_blocks, n), dim3(256), 0, stream, B);
+    hipLaunchKernelGGL(png_crc_dynamic_kernel, dim3(max_crc, n), dim3(256), 0, stream, B, png_tables());
+    hipLaunchKernelGGL(png_finish_dynamic_kernel, dim3(n), dim3(64), 0, stream, B);
+    return hipGetLastError();
+}
+
+hipError_t launch_png_encode_deflate(const uint8_t* pixels, int W, int H, int C, int planar, uint8_t* out, uint8_t* scratch, unsigned long long* out_len,
+                                     hipStream_t stream) {
+    return launch_png_encode_deflate_batch(1, &pixels, &W, &H, &C, &planar, &out, &scratch, &out_len, stream);
 }
 
 } // namespace gsr

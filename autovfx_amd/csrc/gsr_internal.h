@@ -346,11 +346,18 @@ size_t png_file_bytes(int W, int H, int C);
 size_t png_room_bytes(int W, int H, int C);   // what `out` must hold: the file, then the kernels' partial checksums
 // pixels: u8, interleaved [H,W,C] or (planar != 0) [C,H,W]; out: png_room_bytes bytes, 16-byte aligned.
 hipError_t launch_png_encode(const uint8_t* pixels, int W, int H, int C, int planar, uint8_t* out, hipStream_t stream);
+// The same file with a deflate-compressed IDAT (Paeth filter, run-length matches, one Huffman code per image built on the GPU).
+size_t png_deflate_max_bytes(int W, int H, int C);    // upper bound of the file's length
+size_t png_deflate_room_bytes(int W, int H, int C);   // what `out` must hold (the file's bound + what the CRC kernel may read behind it)
+size_t png_deflate_scratch_bytes(int W, int H, int C);   // device scratch per image: filtered stream, per-block histograms / offsets, checksums
+hipError_t launch_png_encode_deflate(const uint8_t* pixels, int W, int H, int C, int planar, uint8_t* out, uint8_t* scratch, unsigned long long* out_len,
+                                     hipStream_t stream);
 
 // The reference's four per-frame files from a render() result, queued by one host call (gsr.h: gsr_frame_files).  work: 10 * W * H bytes.
 hipError_t launch_frame_files(const float* color, const float* alpha, const float* depth, const float* normal, float depth_scale,
                               const uint8_t* turbo_lut, int W, int H, uint8_t* png_rgba, uint8_t* png_depth, uint8_t* png_normal,
-                              float* npy_plane, uint8_t* work, hipStream_t stream);
+                              float* npy_plane, uint8_t* work, uint8_t* png_scratch, unsigned long long* png_lengths /*both null: stored PNGs*/,
+                              hipStream_t stream);
 // PIL's Image.resize(BILINEAR) on an RGBA8 image [H,W,4] and Image.resize(NEAREST) on an fp32 image, bit for bit
 // (blend_all.py:21-28).  tmp: src_h * dst_w * 4 bytes (needed when both sizes change).
 hipError_t launch_resize_rgba8_bilinear(const uint8_t* src, int src_w, int src_h, uint8_t* dst, int dst_w, int dst_h, uint8_t* tmp,

@@ -68,7 +68,8 @@ def encode_png(image: np.ndarray, compress_level: int = 3) -> bytes:
 
 
 def decode_png(data: bytes) -> np.ndarray:
-    """Inverse of ``encode_png`` for the PNGs it writes (filter type 0 only)."""
+    """A small PNG reader for 8-bit truecolour (+ alpha), non-interlaced files: what ``encode_png`` and the GPU encoders write (filter
+    type 0 everywhere, or Paeth-filtered rows), any of the five filter types in general."""
     assert data[:8] == b"\x89PNG\r\n\x1a\n"
     pos, idat, w = 8, b"", 0
     while pos < len(data):
@@ -81,8 +82,35 @@ def decode_png(data: bytes) -> np.ndarray:
             idat += body
         pos += 12 + n
     rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + w * c)
-    assert not rows[:, 0].any(), "only filter type 0 is supported"
-    return rows[:, 1:].reshape(h, w, c).copy()
+    if not rows[:, 0].any():
+        return rows[:, 1:].reshape(h, w, c).copy()
+    out = np.zeros((h, w, c), np.int32)
+    zero_row = np.zeros((w, c), np.int32)
+    for y in range(h):
+        ft, line = int(rows[y, 0]), rows[y, 1:].reshape(w, c).astype(np.int32)
+        up = out[y - 1] if y else zero_row
+        if ft == 0:
+            out[y] = line
+        elif ft == 1:
+            out[y] = np.cumsum(line, axis=0) & 255
+        elif ft == 2:
+            out[y] = (line + up) & 255
+        elif ft in (3, 4):
+            left, ul = np.zeros(c, np.int32), np.zeros(c, np.int32)
+            for x in range(w):
+                b = up[x]
+                if ft == 3:
+                    pred = (left + b) >> 1
+                else:
+                    p = left + b - ul
+                    pa, pb, pc = np.abs(p - left), np.abs(p - b), np.abs(p - ul)
+                    pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, b, ul))
+                left = (line[x] + pred) & 255
+                out[y, x] = left
+                ul = b
+        else:
+            raise ValueError(f"PNG filter type {ft}")
+    return out.astype(np.uint8)
 
 
 def _frame_paths(out_dir: str, name: str, made: "set | None" = None) -> dict:
@@ -145,8 +173,13 @@ def npy_header(shape, dtype=np.float32) -> bytes:
     return f.getvalue()
 
 
+def deflate_default() -> bool:
+    """Compressed PNGs unless ``GSR_PNG_DEFLATE=0`` (then: stored deflate blocks, files as large as the raw image)."""
+    return os.environ.get("GSR_PNG_DEFLATE", "1") not in ("0", "", "false", "False", "off")
+
+
 def png_mode() -> str:
-    return "stored"
+    return "deflate" if deflate_default() else "stored"
 
 
 def png_size(width: int, height: int, channels: int) -> int:
@@ -161,6 +194,50 @@ def png_room(width: int, height: int, channels: int) -> int:
     """Bytes the encoder's output buffer must hold: the file, then the kernels' partial checksums (``gsr_png_room``)."""
     from . import _lib
     return int(_lib.lib.gsr_png_room(int(width), int(height), int(channels)))
+
+
+def png_deflate_max_size(width: int, height: int, channels: int) -> int:
+    from . import _lib
+    n = int(_lib.lib.gsr_png_deflate_max_size(int(width), int(height), int(channels)))
+    if n == 0:
+        raise ValueError(f"a {width}x{height} image with {channels} channels cannot be encoded")
+    return n
+
+
+def png_deflate_room(width: int, height: int, channels: int) -> int:
+    from . import _lib
+    return int(_lib.lib.gsr_png_deflate_room(int(width), int(height), int(channels)))
+
+
+def png_deflate_scratch(width: int, height: int, channels: int) -> int:
+    from . import _lib
+    return int(_lib.lib.gsr_png_deflate_scratch(int(width), int(height), int(channels)))
+
+
+def encode_png_gpu_deflate(image: torch.Tensor, planar: bool = False) -> torch.Tensor:
+    """``encode_png_gpu`` with a compressed IDAT (``gsr_png_encode_deflate``: Paeth filter, run-length matches, one Huffman code per
+    image built on the GPU).  The file's length depends on the image, so this convenience form reads it back (one host
+    synchronisation); the frame writer keeps it on the device and copies it out with the file."""
+    import ctypes
+    from . import _lib
+    if not (image.is_cuda and image.dtype == torch.uint8 and image.dim() == 3):
+        raise ValueError("encode_png_gpu_deflate expects a uint8 GPU tensor [H,W,C] or [C,H,W]")
+    img = image.contiguous()
+    C, H, W = (int(v) for v in (img.shape if planar else (img.shape[2], img.shape[0], img.shape[1])))
+    room = png_deflate_room(W, H, C)
+    if room == 0:
+        raise ValueError(f"a {W}x{H} image with {C} channels cannot be encoded")
+    out = torch.empty(room, dtype=torch.uint8, device=img.device)
+    scratch = torch.empty(png_deflate_scratch(W, H, C), dtype=torch.uint8, device=img.device)
+    length = torch.zeros(1, dtype=torch.int64, device=img.device)
+    with torch.cuda.device(img.device):
+        rc = _lib.lib.gsr_png_encode_deflate(img.data_ptr(), W, H, C, 1 if planar else 0, out.data_ptr(), scratch.data_ptr(), length.data_ptr(),
+                                             ctypes.c_void_p(torch.cuda.current_stream(img.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"gsr_png_encode_deflate failed ({rc}): {_lib.last_error()}")
+    n = int(length.item())
+    assert 0 < n <= png_deflate_max_size(W, H, C), (n, png_deflate_max_size(W, H, C))
+    return out[:n]
 
 
 def encode_png_gpu(image: torch.Tensor, planar: bool = False, out: "torch.Tensor | None" = None) -> torch.Tensor:
@@ -198,9 +275,11 @@ class GpuFrameWriter:
     The pixels any PNG reader gets, and ``np.load`` of the depth file, are bit-identical to ``FrameWriter``'s and the
     reference's (tests/test_frame_io.py)."""
 
-    def __init__(self, out_dir: str, workers: int = 4, slots: int = 8):
+    def __init__(self, out_dir: str, workers: int = 4, slots: int = 8, deflate: "bool | None" = None):
         from concurrent.futures import ThreadPoolExecutor
         self.out_dir = out_dir
+        # compressed PNGs (gsr_frame_files_deflate: what the reference writes, 1.0 - 1.2 x PIL's size) or stored ones (as large as the raw image)
+        self.deflate = deflate_default() if deflate is None else bool(deflate)
         self._pool = ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="gpu-frame-writer")
         self._slots, self._n_slots, self._next = [], max(2, slots), 0
         self._shape = None
@@ -209,8 +288,9 @@ class GpuFrameWriter:
 
     def _prepare(self, H: int, W: int, device):
         """Byte ranges of the four files inside a slot, the staging buffers, the constant .npy header."""
-        sizes = {"images": png_size(W, H, 4), "depth_preview": png_size(W, H, 3), "normal": png_size(W, H, 3)}
-        rooms = {"images": png_room(W, H, 4), "depth_preview": png_room(W, H, 3), "normal": png_room(W, H, 3)}
+        size_of, room_of = (png_deflate_max_size, png_deflate_room) if self.deflate else (png_size, png_room)
+        sizes = {"images": size_of(W, H, 4), "depth_preview": size_of(W, H, 3), "normal": size_of(W, H, 3)}   # (deflate: upper bounds)
+        rooms = {"images": room_of(W, H, 4), "depth_preview": room_of(W, H, 3), "normal": room_of(W, H, 3)}
         header = npy_header((H, W))
         at, off = 0, {}
         for k in ("images", "depth_preview", "normal"):
@@ -218,6 +298,8 @@ class GpuFrameWriter:
             at += (rooms[k] + 15) & ~15
         off["depth"] = (at, len(header) + 4 * H * W)      # (header lengths are multiples of 64: the plane is 4-byte aligned)
         at += (len(header) + 4 * H * W + 15) & ~15
+        self._lengths_at = at          # deflate: the three files' lengths (uint64), written by the kernels, copied out with the files
+        at += 32
         self._off, self._bytes, self._shape = off, at, (H, W)
         self._lut = torch.from_numpy(TURBO_LUT.copy()).to(device)
         hdr = torch.frombuffer(bytearray(header), dtype=torch.uint8).to(device)
@@ -227,7 +309,9 @@ class GpuFrameWriter:
             dev[off["depth"][0]:off["depth"][0] + len(header)] = hdr
             host = torch.empty(at, dtype=torch.uint8, pin_memory=True)
             self._slots.append({"dev": dev, "host": host, "np": host.numpy(), "event": torch.cuda.Event(), "pending": None,
-                                "work": torch.empty(10 * H * W, dtype=torch.uint8, device=device)})
+                                "work": torch.empty(10 * H * W, dtype=torch.uint8, device=device),
+                                "scratch": (torch.empty(png_deflate_scratch(W, H, 4) + 2 * png_deflate_scratch(W, H, 3), dtype=torch.uint8, device=device)
+                                            if self.deflate else None)})
         self._header_len = len(header)
         # the slots are handed out round-robin to whatever stream a frame arrives on: their header fills (queued above on THIS
         # stream) must have landed before another stream copies a slot out.  Once per image size.
@@ -253,10 +337,14 @@ class GpuFrameWriter:
         from . import _lib
         base = dev.data_ptr()
         with torch.cuda.device(dev.device):
-            rc = _lib.lib.gsr_frame_files(color.data_ptr(), alpha.data_ptr(), d.data_ptr(), nrm.data_ptr(), 3.0, self._lut.data_ptr(), W, H,
-                                          base + off["images"][0], base + off["depth_preview"][0], base + off["normal"][0],
-                                          base + off["depth"][0] + self._header_len, slot["work"].data_ptr(),
-                                          ctypes.c_void_p(torch.cuda.current_stream(dev.device).cuda_stream))
+            args = (color.data_ptr(), alpha.data_ptr(), d.data_ptr(), nrm.data_ptr(), 3.0, self._lut.data_ptr(), W, H,
+                    base + off["images"][0], base + off["depth_preview"][0], base + off["normal"][0],
+                    base + off["depth"][0] + self._header_len, slot["work"].data_ptr())
+            stream_ptr = ctypes.c_void_p(torch.cuda.current_stream(dev.device).cuda_stream)
+            if self.deflate:
+                rc = _lib.lib.gsr_frame_files_deflate(*args, slot["scratch"].data_ptr(), base + self._lengths_at, stream_ptr)
+            else:
+                rc = _lib.lib.gsr_frame_files(*args, stream_ptr)
             if rc != 0:
                 raise RuntimeError(f"gsr_frame_files failed ({rc}): {_lib.last_error()}")
             # the copy and the event go to the SAME device and stream as the kernels above (the frame's device need not be the
@@ -266,12 +354,18 @@ class GpuFrameWriter:
                 slot["host"].copy_(dev, non_blocking=True)
             slot["event"].record(stream)
         paths = _frame_paths(self.out_dir, name, self._made_dirs)
-        slot["pending"] = self._pool.submit(self._write, slot, paths, dict(off))
+        slot["pending"] = self._pool.submit(self._write, slot, paths, dict(off), self._lengths_at if self.deflate else None)
 
     @staticmethod
-    def _write(slot, paths, off):
+    def _write(slot, paths, off, lengths_at=None):
         slot["event"].synchronize()
         buf = slot["np"]
+        if lengths_at is not None:     # the compressed files' lengths arrived with them
+            got = np.frombuffer(buf[lengths_at:lengths_at + 24], dtype=np.uint64)
+            for k, n in zip(("images", "depth_preview", "normal"), got):
+                if not 0 < int(n) <= off[k][1]:
+                    raise RuntimeError(f"compressed PNG {k!r}: length {int(n)} outside (0, {off[k][1]}]")
+                off[k] = (off[k][0], int(n))
         for k, (at, n) in off.items():
             with _open_for_write(paths[k]) as f:
                 f.write(memoryview(buf[at:at + n]))

@@ -1109,6 +1109,19 @@ def frame_loop_bench(device, frames=400, reference_frames=10):
         nbytes = sum(os.path.getsize(p) for p in files)
         n_written = sum(len(os.listdir(os.path.join(ours.traj_results_dir, sub))) for sub in ("images", "depth", "normal"))
         shutil.rmtree(ours.traj_results_dir)
+        host_profile = None
+        if os.environ.get("GSR_LOOP_PROFILE"):       # where the host thread's time goes (cProfile slows the loop: not the timed call)
+            import cProfile
+            import io
+            import pstats
+            pr = cProfile.Profile()
+            pr.enable()
+            frame_loop.render_from_3DGS(ours)
+            pr.disable()
+            shutil.rmtree(ours.traj_results_dir)
+            buf = io.StringIO()
+            pstats.Stats(pr, stream=buf).sort_stats("tottime").print_stats(28)
+            host_profile = [ln.rstrip() for ln in buf.getvalue().splitlines() if ln.strip()][:45]
         theirs = _LoopScene(root, "theirs", ply, views, objects, rb, device)
         theirs.load_scene()
         ids = list(range(0, frames, max(1, frames // reference_frames)))[:reference_frames]
@@ -1131,7 +1144,8 @@ def frame_loop_bench(device, frames=400, reference_frames=10):
                                           "frames_per_s": round(len(ids) / t_ref, 2), "bytes_per_frame": int(ref_bytes),
                                           "what": "per frame: deepcopy of the scene, the objects' PLYs from disk, transform + merge in PyTorch, one "
                                                   "blocking render() of this package, PIL / numpy host writers (one thread)"},
-                "vs_reference_shaped_loop": round((frames / t_loop) / (len(ids) / t_ref), 1)}
+                "vs_reference_shaped_loop": round((frames / t_loop) / (len(ids) / t_ref), 1),
+                **({"host_profile": host_profile} if host_profile else {})}
     finally:
         shutil.rmtree(root, ignore_errors=True)
 

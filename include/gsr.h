@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 12
+#define GSR_ABI_VERSION 13
 
 #if defined(__GNUC__)
 #define GSR_API __attribute__((visibility("default")))
@@ -263,6 +263,27 @@ GSR_API int gsr_frame_files(const float* color, const float* alpha, const float*
                             const uint8_t* turbo_lut, int width, int height, uint8_t* png_rgba, uint8_t* png_depth_preview,
                             uint8_t* png_normal, float* npy_plane, uint8_t* work, void* stream);
 GSR_API int gsr_png_encode(const uint8_t* pixels, int width, int height, int channels, int planar, uint8_t* out, void* stream);
+/* The same files COMPRESSED, as the reference's are (torchvision.utils.save_image -> PIL -> zlib; cv2.imwrite -> libpng:
+ * scene_representation.py:427,433,438) -- ABI 13.  The IDAT holds dynamic-Huffman deflate blocks of Paeth-filtered scanlines
+ * (PNG filter type 4) with run-length matches (distance 1): one Huffman code per image, built on the GPU from the image's token
+ * histogram; blocks of 16 KB of filtered bytes, each ending on a byte boundary (an empty stored block, zlib's sync-flush marker),
+ * a block that would not shrink is sent stored.  Any PNG reader decodes the reference's pixels; the file is 1.0 - 1.2 x the size
+ * PIL writes at its default level for rendered frames.  The file's length depends on the image: it is written to *out_len
+ * (DEVICE memory, 8-byte aligned; at most gsr_png_deflate_max_size) by the kernels -- copy it back with the file.  `out` must hold
+ * gsr_png_deflate_room(...) bytes (the file's bound and 64 bytes the checksum kernel may read behind it), `scratch`
+ * gsr_png_deflate_scratch(...) bytes (filtered scanlines, per-block histograms / offsets, checksum partials); both 16-byte aligned.
+ * Six launches, no memset, no global atomics.  gsr_frame_files_deflate is gsr_frame_files with the three PNGs compressed -- each
+ * kernel launched once for all three --, png_scratch of gsr_png_deflate_scratch(w, h, 4) + 2 * gsr_png_deflate_scratch(w, h, 3)
+ * bytes and the files' lengths in png_lengths[3] (device; order: RGBA, depth preview, normal). */
+GSR_API size_t gsr_png_deflate_max_size(int width, int height, int channels);
+GSR_API size_t gsr_png_deflate_room(int width, int height, int channels);
+GSR_API size_t gsr_png_deflate_scratch(int width, int height, int channels);
+GSR_API int gsr_png_encode_deflate(const uint8_t* pixels, int width, int height, int channels, int planar, uint8_t* out,
+                                   uint8_t* scratch, uint64_t* out_len, void* stream);
+GSR_API int gsr_frame_files_deflate(const float* color, const float* alpha, const float* depth, const float* normal, float depth_scale,
+                                    const uint8_t* turbo_lut, int width, int height, uint8_t* png_rgba, uint8_t* png_depth_preview,
+                                    uint8_t* png_normal, float* npy_plane, uint8_t* work, uint8_t* png_scratch, uint64_t* png_lengths,
+                                    void* stream);
 
 /* The compositor's input side (blender/blend_all.py:21-28,217-234: every Blender layer of every frame is brought to the size of
  * the rendered frame with PIL -- Image.resize(new_size, BILINEAR) for the RGBA8 layers, Image.resize(new_size, NEAREST) for the
