@@ -127,18 +127,39 @@ def load_rgb(path):
 
 
 def load_depth_exr(path):
-    """``blend_all.load_depth_exr`` (:70-75): the first channel of Blender's OpenEXR depth pass, through OpenCV as in the reference
-    (``OPENCV_IO_ENABLE_OPENEXR=1``).  OpenCV is an optional dependency of this function only."""
+    """``blend_all.load_depth_exr`` (:70-75): Blender's OpenEXR depth pass as ``cv2.imread(path, ANYCOLOR | ANYDEPTH)[:, :, 0]`` gives
+    it -- float32 ``[H,W]`` of the file's B channel.  With OpenCV installed (``OPENCV_IO_ENABLE_OPENEXR=1``) that very call is made,
+    as in the reference; without it ``autovfx_amd.exr`` reads the file (scanline files, half / float, NONE / RLE / ZIPS / ZIP: what
+    Blender's File Output node writes by default)."""
     import os
     if not os.path.exists(path):
         return None
     os.environ.setdefault("OPENCV_IO_ENABLE_OPENEXR", "1")
     try:
         import cv2
-    except ImportError as e:
-        raise RuntimeError(f"{path}: reading Blender's EXR depth passes needs OpenCV (cv2), as blender/blend_all.py does") from e
-    d = cv2.imread(path, cv2.IMREAD_ANYCOLOR | cv2.IMREAD_ANYDEPTH)
-    return d[:, :, 0]
+    except ImportError:
+        cv2 = None
+    if cv2 is not None and hasattr(cv2, "imread"):
+        d = cv2.imread(path, cv2.IMREAD_ANYCOLOR | cv2.IMREAD_ANYDEPTH)
+        return d[:, :, 0]
+    from .exr import load_depth_exr as read
+    return read(path)
+
+
+_LAYERS_RGB = ("rgb_obj", "rgb_shadow", "rgb_all", "rgb_obj_3dgs", "rgb_smoke_fire", "rgb_smoke_fire_pre")
+_LAYERS_DEPTH = ("depth_obj", "depth_shadow", "depth_obj_3dgs", "depth_smoke_fire")
+
+
+def _load_frame_layers(cache, bg_path, i):
+    """Everything ``blend_frames`` reads for frame ``i`` (blend_all.py:185-205), decoded on the host: a dict of numpy arrays / None.
+    Runs on a pool thread: PIL's and zlib's decoders release the interpreter lock."""
+    import os
+    out = {"bg": load_rgb(bg_path)}
+    for kind in _LAYERS_RGB:
+        out[kind] = load_rgb(os.path.join(cache, kind, "{:0>3d}.png".format(i + 1)))
+    for kind in _LAYERS_DEPTH:
+        out[kind] = load_depth_exr(os.path.join(cache, kind, "{:0>3d}".format(i + 1), "Image{:0>4d}.exr".format(i + 1)))
+    return out
 
 
 def blend_frames(blend_results_dir, input_config_path=None, device=None, write_video=True):
@@ -148,8 +169,9 @@ def blend_frames(blend_results_dir, input_config_path=None, device=None, write_v
     (``<blend_results_dir>/frames/%04d.png`` and, when ``imageio`` / ``skimage`` are importable, ``blended.mp4``).  What happens
     between loading and saving runs on the GPU: the smoke-depth fill, PIL's resizes of every Blender layer to the frame's size
     (``resize_rgba8`` / ``resize_depth``), the per-pixel composite (``gsr_composite``) and the PNG encoding of the result
-    (``gsr_png_encode``: stored-deflate files holding the same pixels as ``Image.fromarray(frame).save``).  Decoding PNG / EXR
-    stays on the host, in the libraries the reference uses.  Returns the list of frame paths."""
+    (``gsr_png_encode_deflate``: compressed files holding the same pixels as ``Image.fromarray(frame).save``).  Decoding PNG / EXR
+    stays on the host -- Pillow; OpenCV for EXR when it is installed, ``autovfx_amd.exr`` otherwise -- on a pool of threads that
+    works ahead of the GPU.  Returns the list of frame paths."""
     import glob
     import json
     import os
@@ -166,40 +188,60 @@ def blend_frames(blend_results_dir, input_config_path=None, device=None, write_v
     os.makedirs(out_img_dir, exist_ok=True)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     up = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    rgb = lambda kind, i: load_rgb(os.path.join(cache, kind, "{:0>3d}.png".format(i + 1)))
-    exr = lambda kind, i: load_depth_exr(os.path.join(cache, kind, "{:0>3d}".format(i + 1), "Image{:0>4d}.exr".format(i + 1)))
-    paths, host_frames = [], []
-    for i in range(n_frame):
-        bg_c = up(load_rgb(bg_rgb[i]))
-        o_c, o_d = up(rgb("rgb_obj", i)), up(exr("depth_obj", i))
-        s_c, s_d = up(rgb("rgb_shadow", i)), up(exr("depth_shadow", i))
-        o_s_c = up(rgb("rgb_all", i))
-        o_gs_c, o_gs_d = up(rgb("rgb_obj_3dgs", i)), up(exr("depth_obj_3dgs", i))
-        s_f_c, s_f_d = up(rgb("rgb_smoke_fire", i)), up(exr("depth_smoke_fire", i))
-        s_f_c_pre = up(rgb("rgb_smoke_fire_pre", i))
-        if o_gs_c is None:
-            o_gs_d = None
-        if s_f_c is not None:
-            s_f_d = smoke_depth_fill(s_f_c, s_f_d.to(torch.float32))       # on the full-size layers, before the resizes (:207-215)
-        else:
-            s_f_d = s_f_c_pre = None
-        f32 = lambda t: None if t is None else t.to(torch.float32)
-        frame = composite_frame(bg_c, o_c, f32(o_d), s_c, f32(s_d), o_s_c, o_gs_c, f32(o_gs_d), s_f_c, f32(s_f_d), s_f_c_pre)
-        data = frame_io.encode_png_gpu(frame)
-        path = os.path.join(out_img_dir, "{:0>4d}.png".format(i))
-        with open(path, "wb") as f:
-            f.write(data.cpu().numpy().tobytes())
-        paths.append(path)
-        if write_video:
-            host_frames.append(frame.cpu().numpy())
-    if write_video and host_frames:
-        try:   # generate_video_from_frames (:31-54): the reference's own host libraries, when they are there
+    video = None
+    if write_video:       # the frames are kept on the host only if the video can be written at all (400 frames of 960x540 are 0.8 GB)
+        try:
             import imageio.v2 as imageio
             import skimage.transform
-            h, w = host_frames[0].shape[:2]
-            new_h, new_w = h - h % 2, w - w % 2
-            series = [(skimage.transform.resize(fr, (new_h, new_w)) * 255.0).astype(np.uint8) for fr in host_frames]
-            imageio.mimsave(os.path.join(blend_results_dir, "blended.mp4"), series, fps=15, macro_block_size=1)
+            video = (imageio, skimage.transform)
         except ImportError:
-            print("[autovfx_amd] blended.mp4 not written: imageio / skimage are not installed (the frames are under " + out_img_dir + ")")
+            print("[autovfx_amd] blended.mp4 will not be written: imageio / skimage are not installed (the frames go to " + out_img_dir + ")")
+    # Decoding ~11 PNG / EXR layers per frame at Blender's resolution is host work that dwarfs the GPU's 0.13 ms per frame: a pool of
+    # threads decodes frames i + 1 ... i + k while the GPU resizes, composites and encodes frame i; another writes the finished files.
+    from concurrent.futures import ThreadPoolExecutor
+    workers = int(os.environ.get("AUTOVFX_AMD_BLEND_DECODERS", "0")) or (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)
+    workers = max(1, min(16, workers))
+    ahead = 2 * workers
+
+    def write_file(path, data):
+        with open(path, "wb") as f:
+            f.write(data)
+
+    paths, host_frames, pending, writes = [], [], {}, []
+    with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="blend-decode") as pool, \
+            ThreadPoolExecutor(max_workers=2, thread_name_prefix="blend-write") as wpool:
+        for i in range(n_frame):
+            for j in range(i, min(n_frame, i + ahead + 1)):
+                if j not in pending:
+                    pending[j] = pool.submit(_load_frame_layers, cache, bg_rgb[j], j)
+            L = pending.pop(i).result()
+            bg_c = up(L["bg"])
+            o_c, o_d = up(L["rgb_obj"]), up(L["depth_obj"])
+            s_c, s_d = up(L["rgb_shadow"]), up(L["depth_shadow"])
+            o_s_c = up(L["rgb_all"])
+            o_gs_c, o_gs_d = up(L["rgb_obj_3dgs"]), up(L["depth_obj_3dgs"])
+            s_f_c, s_f_d = up(L["rgb_smoke_fire"]), up(L["depth_smoke_fire"])
+            s_f_c_pre = up(L["rgb_smoke_fire_pre"])
+            if o_gs_c is None:
+                o_gs_d = None
+            if s_f_c is not None:
+                s_f_d = smoke_depth_fill(s_f_c, s_f_d.to(torch.float32))       # on the full-size layers, before the resizes (:207-215)
+            else:
+                s_f_d = s_f_c_pre = None
+            f32 = lambda t: None if t is None else t.to(torch.float32)
+            frame = composite_frame(bg_c, o_c, f32(o_d), s_c, f32(s_d), o_s_c, o_gs_c, f32(o_gs_d), s_f_c, f32(s_f_d), s_f_c_pre)
+            data = (frame_io.encode_png_gpu_deflate(frame) if frame_io.deflate_default() else frame_io.encode_png_gpu(frame)).cpu().numpy()
+            path = os.path.join(out_img_dir, "{:0>4d}.png".format(i))
+            writes.append(wpool.submit(write_file, path, data))
+            paths.append(path)
+            if video is not None:
+                host_frames.append(frame.cpu().numpy())
+        for w in writes:
+            w.result()
+    if video is not None and host_frames:   # generate_video_from_frames (:31-54), with the reference's own host libraries
+        imageio, transform = video
+        h, w = host_frames[0].shape[:2]
+        new_h, new_w = h - h % 2, w - w % 2
+        series = [(transform.resize(fr, (new_h, new_w)) * 255.0).astype(np.uint8) for fr in host_frames]
+        imageio.mimsave(os.path.join(blend_results_dir, "blended.mp4"), series, fps=15, macro_block_size=1)
     return paths

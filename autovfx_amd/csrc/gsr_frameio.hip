@@ -393,7 +393,7 @@ struct PngJob {
     PngDynamic* dyn;
     uint32_t* hist;                     // [blocks][288]
     unsigned long long* adler;          // [filter_groups][2]
-    uint32_t* block_off;                // [blocks + 1]; bit 31: stored
+    uint32_t* block_off;                // [blocks]: every block's size in the file; bit 31: stored
     uint32_t* crc_partials;             // [crc_groups]
     unsigned long long* out_len;        // nullable
     uint32_t blocks, filter_groups, crc_groups;
@@ -415,29 +415,27 @@ __device__ __forceinline__ uint32_t paeth_stream_byte(const PngLayout& L, const 
     return (uint32_t)(raw - pred) & 255u;
 }
 
-// One lane = 16 consecutive bytes of the filtered stream (one 16-byte store); Adler-32's two sums per workgroup.
+// The filtered stream to scratch, 4 KB per workgroup: in every step the lanes of a wave take CONSECUTIVE bytes, so a wave's loads of the
+// raw pixels and their three neighbours are a few whole cache lines and its stores one (a lane that walked 16 consecutive bytes of its
+// own made every load a 64-line gather: 24 us for a frame's three images instead of 4); Adler-32's two sums per workgroup.
 __global__ void __launch_bounds__(256) png_filter_kernel(PngBatch B) {
     if ((int)blockIdx.y >= B.n) return;
     const PngJob& J = B.job[blockIdx.y];
     if (blockIdx.x >= J.filter_groups) return;
     const PngLayout& L = J.L;
     __shared__ unsigned long long s_sum[4][2];
-    const unsigned long long r0 = ((unsigned long long)blockIdx.x * 256ull + threadIdx.x) * 16ull;
+    const unsigned long long base = (unsigned long long)blockIdx.x * kFilterBytes;
     unsigned long long a1 = 0ull, a2 = 0ull;
-    if (r0 < L.N) {
-        uint32_t row = (uint32_t)(r0 / L.row_len), col = (uint32_t)(r0 - (unsigned long long)row * L.row_len);
-        uint32_t w[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            if (r0 + (unsigned long long)k < L.N) {
-                const uint32_t v = paeth_stream_byte(L, J.pixels, row, col);
-                w[k >> 2] |= v << (8 * (k & 3));
-                a1 += v;
-                a2 += (L.N - (r0 + (unsigned long long)k)) * v;
-                if (++col == L.row_len) { col = 0u; ++row; }
-            }
+#pragma unroll 4
+    for (uint32_t k = 0; k < kFilterBytes / 256u; ++k) {
+        const unsigned long long r = base + k * 256u + threadIdx.x;
+        if (r < L.N) {
+            const uint32_t row = (uint32_t)r / L.row_len, col = (uint32_t)r - row * L.row_len;     // (N < 2^31)
+            const uint32_t v = paeth_stream_byte(L, J.pixels, row, col);
+            J.stream[r] = (uint8_t)v;
+            a1 += v;
+            a2 += (L.N - r) * v;
         }
-        *reinterpret_cast<uint4*>(J.stream + r0) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { a1 += __shfl_xor(a1, d); a2 += __shfl_xor(a2, d); }
@@ -449,18 +447,22 @@ __global__ void __launch_bounds__(256) png_filter_kernel(PngBatch B) {
     }
 }
 
-// A lane's 64-byte piece of the block from the filtered stream into LDS (for byte-wise reads while walking it); returns the byte in
-// front of the piece (256: there is none -- the first byte of the image).
-__device__ __forceinline__ uint32_t load_piece(const uint8_t* __restrict__ stream, uint32_t block, uint32_t t, uint8_t* s_piece) {
-    const size_t at = (size_t)block * kDefBlock + (size_t)t * kDefPiece;
-    const uint4* src = reinterpret_cast<const uint4*>(stream + at);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(s_piece);
+// A workgroup's 16 KB block of the filtered stream into LDS, consecutive lanes loading consecutive 16-byte pieces (piece p of the block
+// lands at p / 4 * kDefPitch + p % 4 * 16: a lane's 64-byte piece has the pitch that keeps the later per-lane word reads conflict-free).
+// Call __syncthreads() behind it.  piece_prev(): the byte in front of lane t's piece (256: none -- the first byte of the image).
+__device__ __forceinline__ void load_block(const uint8_t* __restrict__ stream, uint32_t block, uint8_t* s_stream) {
+    const uint4* src = reinterpret_cast<const uint4*>(stream + (size_t)block * kDefBlock);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint4 v = src[q];
-        dst[4 * q + 0] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+    for (uint32_t k = 0; k < 4u; ++k) {
+        const uint32_t p = k * 256u + threadIdx.x;
+        const uint4 v = src[p];
+        uint32_t* dst = reinterpret_cast<uint32_t*>(s_stream + (p >> 2) * kDefPitch + (p & 3u) * 16u);
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
     }
-    return at == 0 ? 256u : (uint32_t)stream[at - 1];
+}
+__device__ __forceinline__ uint32_t piece_prev(const uint8_t* __restrict__ stream, uint32_t block, uint32_t t, const uint8_t* s_stream) {
+    if (t) return s_stream[(t - 1u) * kDefPitch + 63u];
+    return block == 0u ? 256u : (uint32_t)stream[(size_t)block * kDefBlock - 1u];
 }
 
 // length 3 .. 64 -> (symbol - 257, extra bits, extra value)  (RFC 1951 3.2.5)
@@ -526,8 +528,9 @@ __global__ void __launch_bounds__(256) png_hist_kernel(PngBatch B) {
     const uint32_t block = blockIdx.x, t = threadIdx.x;
     const uint32_t blen = block_length(J.L, block);
     for (uint32_t i = t; i < 4u * kDefSyms; i += 256u) (&s_hist[0][0])[i] = 0u;
-    const uint32_t prev = load_piece(J.stream, block, t, s_stream + t * kDefPitch);
+    load_block(J.stream, block, s_stream);
     __syncthreads();
+    const uint32_t prev = piece_prev(J.stream, block, t, s_stream);
     const uint32_t first = t * kDefPiece;
     if (first < blen) {
         HistTokens f = {s_hist[t >> 6]};
@@ -540,11 +543,10 @@ __global__ void __launch_bounds__(256) png_hist_kernel(PngBatch B) {
 
 __device__ __forceinline__ uint32_t bit_reverse(uint32_t v, uint32_t n) { return __brev(v) >> (32u - n); }
 
-// ONE workgroup per image: the Huffman code of the image's tokens, every block's size and place, the head of the file.
-__global__ void __launch_bounds__(256) png_table_kernel(PngBatch B, PngTables T) {
+// ONE workgroup per image: the Huffman code of the image's tokens and the dynamic blocks' common header.
+__global__ void __launch_bounds__(256) png_table_kernel(PngBatch B) {
     if ((int)blockIdx.x >= B.n) return;
     const PngJob& J = B.job[blockIdx.x];
-    const PngLayout& L = J.L;
     const uint32_t blocks = J.blocks;
     __shared__ unsigned long long s_key[512];     // count << 16 | symbol, ascending; unused symbols sort to the end
     __shared__ uint32_t s_weight[kDefSyms];       // internal nodes of the Huffman tree, in creation order
@@ -553,14 +555,14 @@ __global__ void __launch_bounds__(256) png_table_kernel(PngBatch B, PngTables T)
     __shared__ uint8_t s_depth[kDefSyms];         // by sorted position
     __shared__ uint32_t s_code[kDefSyms];
     __shared__ uint32_t s_count_of[17], s_next_code[17];
-    __shared__ uint32_t s_n, s_carry;
+    __shared__ uint32_t s_n;
     __shared__ uint32_t s_header[(kDefHeaderBytes + 3u) / 4u + 1u];
-    __shared__ uint32_t s_scan[256];
     const uint32_t t = threadIdx.x;
     for (uint32_t s = t; s < 512u; s += 256u) {
         unsigned long long key = ~0ull;
         if (s < 286u) {
             uint32_t c = 0u;
+#pragma unroll 16
             for (uint32_t b = 0; b < blocks; ++b) c += J.hist[(size_t)b * kDefSyms + s];
             if (c) key = ((unsigned long long)c << 16) | s;
         }
@@ -676,61 +678,27 @@ __global__ void __launch_bounds__(256) png_table_kernel(PngBatch B, PngTables T)
     __syncthreads();
     for (uint32_t s = t; s < kDefSyms; s += 256u) J.dyn->table[s] = s_code[s] | ((uint32_t)s_len[s] << 16);
     for (uint32_t s = t; s < sizeof(s_header) / 4u; s += 256u) J.dyn->header_words[s] = s_header[s];
-    // every block's size in bytes -- the cheaper of dynamic and stored -- and its place: an exclusive prefix sum.  A wave per block:
-    // the 286 counts times their code lengths, 64 at a time.
-    if (t == 0) s_carry = 0u;
-    __syncthreads();
-    for (uint32_t b0 = 0; b0 < blocks; b0 += 256u) {
-        for (uint32_t q = 0; q < 64u; ++q) {                       // wave w takes blocks b0 + 64 w + q
-            const uint32_t b = b0 + (t >> 6) * 64u + q;
-            if (b >= blocks) break;                                // (wave-uniform)
-            uint32_t bits = 0u;
-            for (uint32_t s = t & 63u; s < 286u; s += 64u) {
-                const uint32_t c = J.hist[(size_t)b * kDefSyms + s];
-                bits += c * ((uint32_t)s_len[s] + length_symbol_extra_bits(s));
-            }
+}
+
+// A wave per block: the block's size in bytes -- its 286 token counts times their code lengths; the cheaper of dynamic and stored (bit 31).
+__global__ void __launch_bounds__(256) png_size_kernel(PngBatch B) {
+    if ((int)blockIdx.y >= B.n) return;
+    const PngJob& J = B.job[blockIdx.y];
+    const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (b >= J.blocks) return;
+    uint32_t bits = 0u;
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) bits += __shfl_xor(bits, d);
-            if ((t & 63u) == 0u) s_scan[(t >> 6) * 64u + q] = bits;
-        }
-        __syncthreads();
-        const uint32_t b = b0 + t;
-        uint32_t bytes = 0u, stored_flag = 0u;
-        if (b < blocks) {
-            const uint32_t blen = block_length(L, b);
-            const unsigned long long bits = (unsigned long long)kDefHeaderBits + s_scan[t];
-            const bool last = b + 1u == blocks;
-            const unsigned long long dyn_bytes = last ? (bits + 7ull) >> 3 : ((bits + 3ull + 7ull) >> 3) + 4ull;
-            bytes = 5u + blen;
-            if (dyn_bytes <= bytes) bytes = (uint32_t)dyn_bytes; else stored_flag = 1u << 31;
-        }
-        __syncthreads();
-        s_scan[t] = bytes;
-        __syncthreads();
-        for (uint32_t d = 1; d < 256u; d <<= 1) {
-            const uint32_t v = t >= d ? s_scan[t - d] : 0u;
-            __syncthreads();
-            s_scan[t] += v;
-            __syncthreads();
-        }
-        if (b < blocks) J.block_off[b] = (s_carry + s_scan[t] - bytes) | stored_flag;
-        __syncthreads();
-        if (t == 255u) s_carry += s_scan[255];
-        __syncthreads();
+    for (uint32_t q = 0; q < 5u; ++q) {
+        const uint32_t sym = q * 64u + lane;
+        if (sym < 286u) bits += J.hist[(size_t)b * kDefSyms + sym] * ((J.dyn->table[sym] >> 16) + length_symbol_extra_bits(sym));
     }
-    if (t == 0) {
-        const uint32_t total = s_carry;
-        J.block_off[blocks] = total;
-        const unsigned long long data_len = 2ull + total + 4ull, file_len = L.data_at + data_len + 4ull + 12ull;
-        J.dyn->data_len = data_len;
-        J.dyn->file_len = file_len;
-        J.dyn->crc_init_term = crc_multmodp(crc_x2nmodp(T.x2n, 4ull + data_len, 3u), 0xFFFFFFFFu);
-        J.dyn->crc_tail_shift = crc_x2nmodp(T.x2n, (L.data_at + data_len) & 63ull, 3u);
-        if (J.out_len) *J.out_len = file_len;
-        uint8_t* out = J.out;
-        for (uint32_t i = 0; i < (uint32_t)L.data_at; ++i) out[i] = L.head[i];
-        out[33] = (uint8_t)(data_len >> 24); out[34] = (uint8_t)(data_len >> 16); out[35] = (uint8_t)(data_len >> 8); out[36] = (uint8_t)data_len;
-        out[L.data_at] = 0x78u; out[L.data_at + 1ull] = 0x01u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) bits += __shfl_xor(bits, d);
+    if (lane == 0u) {
+        const uint32_t blen = block_length(J.L, b);
+        const unsigned long long all = (unsigned long long)kDefHeaderBits + bits;
+        const unsigned long long dyn_bytes = b + 1u == J.blocks ? (all + 7ull) >> 3 : ((all + 3ull + 7ull) >> 3) + 4ull;
+        J.block_off[b] = dyn_bytes <= 5ull + blen ? (uint32_t)dyn_bytes : ((5u + blen) | (1u << 31));
     }
 }
 
@@ -761,7 +729,7 @@ struct EmitTokens {
     __device__ __forceinline__ void flush() { if (nacc) atomicOr(&out[word], (uint32_t)acc); }
 };
 
-__global__ void __launch_bounds__(256) png_deflate_kernel(PngBatch B) {
+__global__ void __launch_bounds__(256) png_deflate_kernel(PngBatch B, PngTables T) {
     if ((int)blockIdx.y >= B.n) return;
     const PngJob& J = B.job[blockIdx.y];
     if (blockIdx.x >= J.blocks) return;
@@ -774,10 +742,36 @@ __global__ void __launch_bounds__(256) png_deflate_kernel(PngBatch B) {
     const uint32_t block = blockIdx.x, t = threadIdx.x, blocks = J.blocks;
     const uint32_t blen = block_length(L, block);
     const bool last = block + 1u == blocks;
-    const uint32_t off = J.block_off[block];
-    const bool stored = (off >> 31) != 0u;
-    const unsigned long long g0 = L.data_at + 2ull + (off & 0x7FFFFFFFu);           // the block's first byte in the file
-    const uint32_t bytes = (J.block_off[block + 1u] & 0x7FFFFFFFu) - (off & 0x7FFFFFFFu);
+    // the block's place: the sizes of the blocks in front of it (png_size_kernel), added up here.  The FIRST block's workgroup (nothing in
+    // front of it, and the first to start) adds up all of them instead: the file's length, for the head of the file and the checksum kernels.
+    uint32_t before_bytes = 0u;
+    const uint32_t upto = block == 0u ? blocks : block;
+    for (uint32_t b = t; b < upto; b += 256u) before_bytes += J.block_off[b] & 0x7FFFFFFFu;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) before_bytes += __shfl_xor(before_bytes, d);
+    if ((t & 63u) == 0u) s_wave[t >> 6] = before_bytes;
+    __syncthreads();
+    const uint32_t summed = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+    const uint32_t off = block == 0u ? 0u : summed;
+    const uint32_t mine = J.block_off[block];
+    const bool stored = (mine >> 31) != 0u;
+    const uint32_t bytes = mine & 0x7FFFFFFFu;
+    const unsigned long long g0 = L.data_at + 2ull + off;                            // the block's first byte in the file
+    if (block == 0u && t == 64u) {   // (a lane of the second wave: the first has the end-of-block duty below)
+        const uint32_t total = summed;
+        const unsigned long long data_len = 2ull + total + 4ull, file_len = L.data_at + data_len + 4ull + 12ull;
+        J.dyn->data_len = data_len;
+        J.dyn->file_len = file_len;
+        // (x^(8 n) for n < 64: six modular products at most.  The pre-conditioning term, x^(8 (4 + data_len)), is twenty of them in a row on one
+        // lane -- 35 us that every other wave of this workgroup waited for at the next barrier -- and is formed by the finishing kernel
+        // instead, as a product tree over a wave.)
+        J.dyn->crc_tail_shift = crc_x2nmodp(T.x2n, (L.data_at + data_len) & 63ull, 3u);
+        if (J.out_len) *J.out_len = file_len;
+        for (uint32_t i = 0; i < (uint32_t)L.data_at; ++i) out[i] = L.head[i];
+        out[33] = (uint8_t)(data_len >> 24); out[34] = (uint8_t)(data_len >> 16); out[35] = (uint8_t)(data_len >> 8); out[36] = (uint8_t)data_len;
+        out[L.data_at] = 0x78u; out[L.data_at + 1ull] = 0x01u;
+    }
     if (stored) {
         const uint8_t* src = J.stream + (size_t)block * kDefBlock;
         if (t < 5u) out[g0 + t] = (uint8_t)(t == 0u ? (last ? 1u : 0u) : t == 1u ? (blen & 255u) : t == 2u ? (blen >> 8) : t == 3u ? (~blen & 255u) : ((~blen >> 8) & 255u));
@@ -786,8 +780,9 @@ __global__ void __launch_bounds__(256) png_deflate_kernel(PngBatch B) {
     }
     for (uint32_t i = t; i < kDefSyms; i += 256u) s_table[i] = J.dyn->table[i];
     for (uint32_t i = t; i < sizeof(s_out) / 4u; i += 256u) s_out[i] = 0u;
-    const uint32_t prev = load_piece(J.stream, block, t, s_stream + t * kDefPitch);
+    load_block(J.stream, block, s_stream);
     __syncthreads();
+    const uint32_t prev = piece_prev(J.stream, block, t, s_stream);
     // LDS image of the block, phased like the file: LDS byte (g0 & 3) is file byte g0, so whole LDS words are whole file words
     const uint32_t phase = (uint32_t)(g0 & 3ull);
     const uint32_t first = t * kDefPiece;
@@ -905,11 +900,21 @@ __global__ void __launch_bounds__(256) png_crc_dynamic_kernel(PngBatch B, PngTab
     if (threadIdx.x == 0) J.crc_partials[blockIdx.x] = s_crc[0] ^ s_crc[1] ^ s_crc[2] ^ s_crc[3];
 }
 
-__global__ void __launch_bounds__(64) png_finish_dynamic_kernel(PngBatch B) {
+__global__ void __launch_bounds__(64) png_finish_dynamic_kernel(PngBatch B, PngTables T) {
     if ((int)blockIdx.x >= B.n) return;
     const PngJob& J = B.job[blockIdx.x];
     const PngLayout& L = J.L;
     uint8_t* __restrict__ out = J.out;
+    // the CRC's pre-conditioning as one more linear term: 0xFFFFFFFF x^(8 (4 + data_len)) mod P.  x^(8 n) is the product of x^(8 2^i) over
+    // the set bits i of n (crc_x2nmodp): one factor per lane, multiplied together in five rounds
+    uint32_t init_term;
+    {
+        const unsigned long long n = 4ull + J.dyn->data_len;
+        uint32_t f = (threadIdx.x < 40u && ((n >> threadIdx.x) & 1ull)) ? T.x2n[(threadIdx.x + 3u) & 31u] : (1u << 31);   // (1 << 31 is x^0)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) f = crc_multmodp(f, (uint32_t)__shfl_xor((int)f, d));
+        init_term = crc_multmodp(f, 0xFFFFFFFFu);
+    }
     unsigned long long a1 = 0ull, a2 = 0ull;
     uint32_t crc_sum = 0u;
     for (uint32_t i = threadIdx.x; i < J.filter_groups; i += 64u) { a1 += J.adler[2 * (size_t)i]; a2 += J.adler[2 * (size_t)i + 1]; }
@@ -932,7 +937,7 @@ __global__ void __launch_bounds__(64) png_finish_dynamic_kernel(PngBatch B) {
         crc_a ^= b;
         for (int i = 0; i < 8; ++i) crc_a = (crc_a & 1u) ? (crc_a >> 1) ^ kCrcPoly : crc_a >> 1;
     }
-    const uint32_t crc = (crc_sum ^ crc_a ^ J.dyn->crc_init_term) ^ 0xFFFFFFFFu;
+    const uint32_t crc = (crc_sum ^ crc_a ^ init_term) ^ 0xFFFFFFFFu;
     for (int k = 0; k < 4; ++k) out[adler_at + 4 + k] = (uint8_t)(crc >> (24 - 8 * k));
     for (int k = 0; k < 12; ++k) out[adler_at + 8 + k] = L.tail[k];
 }
@@ -1285,10 +1290,11 @@ hipError_t launch_png_encode_deflate_batch(int n, const uint8_t* const* pixels, 
     }
     hipLaunchKernelGGL(png_filter_kernel, dim3(max_filter, n), dim3(256), 0, stream, B);
     hipLaunchKernelGGL(png_hist_kernel, dim3(max_blocks, n), dim3(256), 0, stream, B);
-    hipLaunchKernelGGL(png_table_kernel, dim3(n), dim3(256), 0, stream, B, png_tables());
-    hipLaunchKernelGGL(png_deflate_kernel, dim3(max_blocks, n), dim3(256), 0, stream, B);
+    hipLaunchKernelGGL(png_table_kernel, dim3(n), dim3(256), 0, stream, B);
+    hipLaunchKernelGGL(png_size_kernel, dim3((max_blocks + 3u) / 4u, n), dim3(256), 0, stream, B);
+    hipLaunchKernelGGL(png_deflate_kernel, dim3(max_blocks, n), dim3(256), 0, stream, B, png_tables());
     hipLaunchKernelGGL(png_crc_dynamic_kernel, dim3(max_crc, n), dim3(256), 0, stream, B, png_tables());
-    hipLaunchKernelGGL(png_finish_dynamic_kernel, dim3(n), dim3(64), 0, stream, B);
+    hipLaunchKernelGGL(png_finish_dynamic_kernel, dim3(n), dim3(64), 0, stream, B, png_tables());
     return hipGetLastError();
 }
 

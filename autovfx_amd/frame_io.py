@@ -347,12 +347,10 @@ class GpuFrameWriter:
                 rc = _lib.lib.gsr_frame_files(*args, stream_ptr)
             if rc != 0:
                 raise RuntimeError(f"gsr_frame_files failed ({rc}): {_lib.last_error()}")
-            # the copy and the event go to the SAME device and stream as the kernels above (the frame's device need not be the
-            # process's current one, and Event.record() without an argument records on the current device's current stream)
-            stream = torch.cuda.current_stream(dev.device)
-            with torch.cuda.stream(stream):
-                slot["host"].copy_(dev, non_blocking=True)
-            slot["event"].record(stream)
+            # (inside the device guard: the copy goes to the current stream of the FRAME's device, and the event is recorded on that
+            # stream explicitly -- Event.record() without an argument would take the process's current device)
+            slot["host"].copy_(dev, non_blocking=True)
+            slot["event"].record(torch.cuda.current_stream(dev.device))
         paths = _frame_paths(self.out_dir, name, self._made_dirs)
         slot["pending"] = self._pool.submit(self._write, slot, paths, dict(off), self._lengths_at if self.deflate else None)
 

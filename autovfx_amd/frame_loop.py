@@ -42,6 +42,7 @@ import torch
 
 DEFAULT_STREAMS = int(os.environ.get("AUTOVFX_AMD_LOOP_STREAMS", "3"))
 DEFAULT_WRITER_THREADS = int(os.environ.get("AUTOVFX_AMD_LOOP_WRITERS", "4"))
+LAST_LOOP_STATS: dict = {}     # AUTOVFX_AMD_LOOP_STATS=1: host seconds of the last render_frames call spent in begin / finish (waiting) / submit
 
 # The three things the loop is made of.  They are module attributes so that the CPU test of the drop-in (no GPU there) can put
 # doubles in their place EXPLICITLY; the product never rebinds them and there is no automatic choice between them.
@@ -107,17 +108,37 @@ def render_frames(views: Sequence, names: Sequence[str], model_for_frame: Callab
         for st in side:                # what the caller queued on its stream (the model's upload, the scene buffers) comes first
             st.wait_stream(torch.cuda.current_stream(device))
 
+        stats = LAST_LOOP_STATS if os.environ.get("AUTOVFX_AMD_LOOP_STATS") else None
+        if stats is not None:          # where the host thread's time goes: begin (compose + first half), finish (wait + second half), submit (files)
+            import time
+            clock = time.perf_counter
+            stats.clear()
+            stats.update(frames=len(ids), streams=S, begin_s=0.0, finish_s=0.0, submit_s=0.0)
+
         def finish_oldest():
             st, name, pending = q.popleft()
             with torch.cuda.stream(st):
-                writer.submit(name, pending.finish())
+                if stats is None:
+                    writer.submit(name, pending.finish())
+                else:
+                    t0 = clock()
+                    result = pending.finish()
+                    t1 = clock()
+                    writer.submit(name, result)
+                    stats["finish_s"] += t1 - t0
+                    stats["submit_s"] += clock() - t1
 
+        # (One host thread on purpose.  Handing the file kernels of a frame to a second thread was tried: its Python parts take the
+        # interpreter lock from this one for milliseconds at a time -- profiles/r06_loop_filer_thread_ab.txt.)
         for k, i in enumerate(it):
             while len(q) == S:
                 finish_oldest()
             st = side[k % S]
             with torch.cuda.stream(st):
+                t0 = clock() if stats is not None else 0.0
                 q.append((st, names[i], _render_begin(views[i], model_for_frame(i, k % S), pipe, bg)))
+                if stats is not None:
+                    stats["begin_s"] += clock() - t0
         while q:
             finish_oldest()
         for st in side:

@@ -341,7 +341,8 @@ def _render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_col
         bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
         projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
         campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
-    rasterizer = GaussianRasterizer(raster_settings=settings)
+    # (the module object is only needed on the path that makes two separate rasterizer calls: constructing an nn.Module per frame
+    # costs 20 us of host time that the fused paths, which call the binding directly, need not pay)
 
     h, w = int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)
     fx, fy = fov2focal(viewpoint_camera.FoVx, w), fov2focal(viewpoint_camera.FoVy, h)
@@ -438,6 +439,7 @@ def _render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_col
             return PendingRender(lambda: assemble(pending.finish()), pending.ready)
         return assemble(_C.rasterize_gaussians_extra(*call_args, inference=True))
     else:
+        rasterizer = GaussianRasterizer(raster_settings=settings)
         rendered_image, depth_image, alpha_image, radii = rasterizer(
             means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity, scales=scales,
             rotations=rotations, cov3D_precomp=cov3D_precomp)

@@ -876,6 +876,7 @@ def run_also(device, side, S, parity=True):
     guarded("c5_render_and_composite", c5)
     guarded("c5_dynamic", lambda: dynamic_scene_bench(device, side, S))
     guarded("c5_loop", lambda: frame_loop_bench(device))
+    guarded("c5_blend_frames", lambda: blend_frames_bench(device))
     guarded("c3_reference_shaped_render", lambda: reference_shaped_render(device))
     guarded("backward_c3", lambda: backward_iteration("c3", device, parity=parity))
     guarded("training_render_c3", lambda: training_render_iteration(device))
@@ -1145,7 +1146,149 @@ def frame_loop_bench(device, frames=400, reference_frames=10):
                                           "what": "per frame: deepcopy of the scene, the objects' PLYs from disk, transform + merge in PyTorch, one "
                                                   "blocking render() of this package, PIL / numpy host writers (one thread)"},
                 "vs_reference_shaped_loop": round((frames / t_loop) / (len(ids) / t_ref), 1),
+                **({"host_seconds": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in frame_loop.LAST_LOOP_STATS.items()}}
+                   if frame_loop.LAST_LOOP_STATS else {}),
                 **({"host_profile": host_profile} if host_profile else {})}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# also.c5_blend_frames: blender/blend_all.py::blend_frames as a whole -- file discovery, PNG / EXR decoding of every Blender layer
+# at 2x the frame, resizes, smoke fill, composite, the frame's PNG -- through the drop-in and in the reference's shape
+# ---------------------------------------------------------------------------------------------------------------------
+def _synthetic_blender_tree(root, W, H, frames, distinct=4, seed=3):
+    """<root>/scene/custom_camera_path/{images, traj/exp} + <root>/cache/out/{rgb,depth}_*: `distinct` different frames of layers at 2x
+    (object, shadow catcher, object + shadow, 3DGS object, smoke, fire; EXR depth passes as Blender writes them: R = G = B = Z, half,
+    ZIP), hard-linked under the names of `frames` frames."""
+    from PIL import Image
+    from autovfx_amd import exr
+    g = np.random.default_rng(seed)
+    results = os.path.join(root, "scene", "custom_camera_path", "traj", "exp")
+    images = os.path.join(root, "scene", "custom_camera_path", "images")
+    cache = os.path.join(root, "cache", "out")
+    for d in (results, images):
+        os.makedirs(d)
+    cfg = os.path.join(root, "cfg.json")
+    with open(cfg, "w") as f:
+        json.dump({"blender_cache_dir": os.path.join(root, "cache"), "output_dir_name": "out"}, f)
+    W2, H2 = 2 * W, 2 * H
+    yy, xx = np.mgrid[0:H2, 0:W2].astype(np.float32)
+
+    def blob(cx, cy, r):
+        return np.clip(1.5 - np.hypot(xx - cx * W2, yy - cy * H2) / (r * H2), 0.0, 1.0)
+
+    def rgba(alpha, tint):
+        img = np.empty((H2, W2, 4), np.uint8)
+        for c in range(3):
+            img[..., c] = np.clip(tint[c] * (0.6 + 0.4 * np.sin(xx * 0.01 + c)) * 255, 0, 255).astype(np.uint8)
+        img[..., 3] = (alpha * 255).astype(np.uint8)
+        return img
+
+    kinds_rgb = ("rgb_obj", "rgb_shadow", "rgb_all", "rgb_obj_3dgs", "rgb_smoke_fire", "rgb_smoke_fire_pre")
+    kinds_d = ("depth_obj", "depth_shadow", "depth_obj_3dgs", "depth_smoke_fire")
+    for k in range(distinct):
+        sh = 0.03 * k
+        a = {"rgb_obj": blob(0.45 + sh, 0.5, 0.2), "rgb_shadow": blob(0.5 + sh, 0.62, 0.3) * 0.6, "rgb_all": blob(0.47 + sh, 0.55, 0.3),
+             "rgb_obj_3dgs": blob(0.7 - sh, 0.45, 0.12), "rgb_smoke_fire": blob(0.3 + sh, 0.35, 0.18) * 0.7, "rgb_smoke_fire_pre": blob(0.3 + sh, 0.4, 0.1)}
+        bgimg = (g.integers(0, 255, (H, W, 4))).astype(np.uint8)
+        bgimg[..., 3] = 255
+        Image.fromarray(bgimg).save(os.path.join(images, f"src{k}.png"), compress_level=1)
+        for j, kind in enumerate(kinds_rgb):
+            os.makedirs(os.path.join(cache, kind), exist_ok=True)
+            Image.fromarray(rgba(a[kind], (0.9 - 0.1 * j, 0.4 + 0.1 * j, 0.3 + 0.05 * j))).save(os.path.join(cache, kind, f"src{k}.png"), compress_level=1)
+        for j, kind in enumerate(kinds_d):
+            z = (3.0 + j + 2.0 * blob(0.5, 0.5, 0.5) + 0.2 * np.sin(yy * 0.02)).astype(np.float32)
+            z[blob(0.5 + sh, 0.5, 0.45) <= 0] = 65504.0            # "nothing here"
+            os.makedirs(os.path.join(cache, kind, f"src{k}"), exist_ok=True)
+            exr.write_exr(os.path.join(cache, kind, f"src{k}", "Image.exr"), {"R": z, "G": z, "B": z, "A": np.ones_like(z)}, half=True, level=1)
+    for i in range(frames):
+        k = i % distinct
+        os.link(os.path.join(images, f"src{k}.png"), os.path.join(images, f"{i:05d}.png"))
+        for kind in kinds_rgb:
+            os.link(os.path.join(cache, kind, f"src{k}.png"), os.path.join(cache, kind, "{:0>3d}.png".format(i + 1)))
+        for kind in kinds_d:
+            d = os.path.join(cache, kind, "{:0>3d}".format(i + 1))
+            os.makedirs(d)
+            os.link(os.path.join(cache, kind, f"src{k}", "Image.exr"), os.path.join(d, "Image{:0>4d}.exr".format(i + 1)))
+    for k in range(distinct):      # the sources themselves are not frames: rgb_all/*.png is what blend_frames counts
+        os.remove(os.path.join(images, f"src{k}.png"))
+        for kind in kinds_rgb:
+            os.remove(os.path.join(cache, kind, f"src{k}.png"))
+    return results, cfg
+
+
+def _reference_shaped_blend_frames(results, cfg_path, frame_ids):
+    """blend_all.blend_frames (:95-346) in the reference's shape, one host thread: PIL loads, the EXR reader (the reference's is
+    cv2.imread, absent here), PIL resizes of every layer (:21-28,217-234), the numpy composite (oracle/compositor_oracle.py: pinned to
+    the reference's function), Image.save of the frame."""
+    from PIL import Image
+    from autovfx_amd import compositor
+    from oracle import compositor_oracle as co
+    with open(cfg_path) as f:
+        cfg = json.load(f)
+    cache = os.path.join(cfg["blender_cache_dir"], cfg["output_dir_name"])
+    root_dir = os.path.dirname(os.path.normpath(os.path.dirname(os.path.normpath(results))))
+    out_dir = os.path.join(results, "frames_reference_shaped")
+    os.makedirs(out_dir, exist_ok=True)
+    names = {"o_c": "rgb_obj", "s_c": "rgb_shadow", "o_s_c": "rgb_all", "o_gs_c": "rgb_obj_3dgs", "s_f_c": "rgb_smoke_fire", "s_f_c_pre": "rgb_smoke_fire_pre",
+             "o_d": "depth_obj", "s_d": "depth_shadow", "o_gs_d": "depth_obj_3dgs", "s_f_d": "depth_smoke_fire"}
+
+    def down(a, size):
+        if a.dtype == np.uint8:
+            return np.array(Image.fromarray(a).resize(size, Image.BILINEAR))
+        return np.array(Image.fromarray(a).resize(size, Image.NEAREST))
+
+    for i in frame_ids:
+        L = compositor._load_frame_layers(cache, os.path.join(root_dir, "images", f"{i:05d}.png"), i)
+        args = {k: L[v] for k, v in names.items() if L[v] is not None}
+        args["bg_c"] = L["bg"]
+        if "s_f_c" in args:
+            args["s_f_d"], _ = co.smoke_depth_fill(args["s_f_c"], args["s_f_d"].astype(np.float32), None)
+        size = (args["bg_c"].shape[1], args["bg_c"].shape[0])
+        for k in list(args):
+            if k != "bg_c":
+                args[k] = down(args[k] if args[k].dtype == np.uint8 else args[k].astype(np.float32), size)
+        frame = co.composite_frame(**args)
+        Image.fromarray(frame).save(os.path.join(out_dir, f"{i:04d}.png"))
+    return out_dir
+
+
+def blend_frames_bench(device, frames=400, reference_frames=3):
+    """``autovfx_amd.compositor.blend_frames`` -- what ``install()`` puts behind ``blend_all.blend_frames`` -- on a 400-frame synthetic
+    Blender tree (960x540 frames, every Blender layer at 1920x1080: 6 RGBA PNGs and 4 half-float ZIP EXR depth passes per frame), to a
+    tmpfs; the reference-shaped function beside it on a bounded number of frames."""
+    import shutil
+    import tempfile
+    from PIL import Image
+    from autovfx_amd import compositor
+    W, H = 960, 540
+    root = tempfile.mkdtemp(prefix="gsr_blend_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        results, cfg = _synthetic_blender_tree(root, W, H, frames)
+        compositor.blend_frames(results, cfg, device=device, write_video=False)          # warm: resize tables, allocator, page cache
+        shutil.rmtree(os.path.join(results, "frames"))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        paths = compositor.blend_frames(results, cfg, device=device, write_video=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ids = list(range(0, frames, max(1, frames // reference_frames)))[:reference_frames]
+        t0 = time.perf_counter()
+        ref_dir = _reference_shaped_blend_frames(results, cfg, ids)
+        t_ref = time.perf_counter() - t0
+        same = all(np.array_equal(np.asarray(Image.open(paths[i])), np.asarray(Image.open(os.path.join(ref_dir, f"{i:04d}.png")))) for i in ids)
+        layer_bytes = sum(os.path.getsize(os.path.join(root, "cache", "out", k, "001.png")) for k in compositor._LAYERS_RGB) + \
+            sum(os.path.getsize(os.path.join(root, "cache", "out", k, "001", "Image0001.exr")) for k in compositor._LAYERS_DEPTH)
+        return {"workload": "400 frames at 960x540; per frame 6 RGBA PNG layers + 4 half-float ZIP EXR depth passes at 1920x1080 (Blender at 2x), "
+                            "the 3DGS frame's PNG; frames written as compressed PNGs to a tmpfs", "frames": len(paths),
+                "value": round(len(paths) / dt, 1), "unit": "frames/s", "ms_per_frame": round(dt / len(paths) * 1e3, 3),
+                "decode_threads": int(os.environ.get("AUTOVFX_AMD_BLEND_DECODERS", "0")) or min(16, len(os.sched_getaffinity(0))),
+                "input_bytes_per_frame": int(layer_bytes), "output_bytes_per_frame": int(os.path.getsize(paths[0])),
+                "reference_shaped": {"frames": len(ids), "ms_per_frame": round(t_ref / len(ids) * 1e3, 1), "frames_per_s": round(len(ids) / t_ref, 3),
+                                     "what": "one host thread: PIL loads, EXR reads, PIL resizes of ten layers, numpy composite, PIL save"},
+                "same_pixels_as_reference_shaped": bool(same), "vs_reference_shaped": round((len(paths) / dt) / (len(ids) / t_ref), 1)}
     finally:
         shutil.rmtree(root, ignore_errors=True)
 

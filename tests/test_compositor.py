@@ -233,11 +233,13 @@ def test_hip_compositor_takes_blender_resolution_layers(variant, hw, scale):
     np.testing.assert_array_equal(got.cpu().numpy(), want)
 
 
-def write_blender_tree(root, L, hw, frames=2):
+def write_blender_tree(root, L, hw, frames=2, half=False, compression="ZIP"):
     """The directory layout blend_frames expects (blend_all.py:118-182), filled with synthetic layers: the 3DGS frames under
-    <scene>/custom_camera_path/images, Blender's passes under <cache>/out/{rgb,depth}_*; EXR depth passes are stood in for by .npy
-    files of the same name stem (the test patches the EXR loader: OpenCV is not part of this image)."""
+    <scene>/custom_camera_path/images, Blender's passes under <cache>/out/{rgb,depth}_*; the depth passes are real OpenEXR files as
+    Blender's File Output node writes them -- R, G, B, A channels all holding the Z pass, ZIP compression (autovfx_amd.exr.write_exr);
+    ``half``: 16-bit floats, Blender's default colour depth (the layers handed back are then the values such a file holds)."""
     from PIL import Image
+    from autovfx_amd import exr
     results = root / "scene" / "custom_camera_path" / "traj" / "exp"
     results.mkdir(parents=True)
     images = root / "scene" / "custom_camera_path" / "images"
@@ -250,6 +252,8 @@ def write_blender_tree(root, L, hw, frames=2):
     per_frame = []
     for i in range(frames):
         Li = {k: (np.roll(v, 3 * i, axis=1) if isinstance(v, np.ndarray) else v) for k, v in L.items()}
+        if half:
+            Li = {k: (v.astype(np.float16).astype(np.float32) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v) for k, v in Li.items()}
         Image.fromarray(Li["bg_c"]).save(images / f"{i:05d}.png")
         for kind, key in kinds.items():
             if key in Li:
@@ -259,25 +263,27 @@ def write_blender_tree(root, L, hw, frames=2):
             if key in Li:
                 d = cache / kind / f"{i + 1:03d}"
                 d.mkdir(parents=True, exist_ok=True)
-                np.save(d / f"Image{i + 1:04d}.npy", Li[key])
+                z = Li[key]
+                exr.write_exr(str(d / f"Image{i + 1:04d}.exr"), {"R": z, "G": z, "B": z, "A": np.ones_like(z)}, compression=compression, half=half)
         per_frame.append(Li)
     return results, cfg, per_frame
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["plain", "all"])
-def test_blend_frames_drop_in_on_a_directory_tree(tmp_path, monkeypatch, variant):
+@pytest.mark.parametrize("variant", ["plain", "all", "all-half-zips"])
+def test_blend_frames_drop_in_on_a_directory_tree(tmp_path, variant):
     """autovfx_amd.compositor.blend_frames -- what ``blend_all.blend_frames`` becomes after ``autovfx_amd.install()`` -- on a
     directory tree shaped like the reference's (blend_all.py:118-182), Blender layers at 2x the frame: the frames it writes decode
     (PIL) to the oracle's composite of the same layers, byte for byte; the frame count follows rgb_all/*.png."""
     from PIL import Image
     from autovfx_amd import compositor
     hw = (54, 96)
-    L = blender_layers(hw, (2, 2), seed=5, with_3dgs=variant == "all", with_smoke=variant == "all", with_fire=variant == "all")
-    results, cfg, per_frame = write_blender_tree(tmp_path, L, hw)
-    monkeypatch.setattr(compositor, "load_depth_exr", lambda p: np.load(p[:-4] + ".npy") if os.path.exists(p[:-4] + ".npy") else None)
-    paths = compositor.blend_frames(str(results), str(cfg), write_video=False)
-    assert [os.path.basename(p) for p in paths] == ["0000.png", "0001.png"]
+    full = variant != "plain"
+    L = blender_layers(hw, (2, 2), seed=5, with_3dgs=full, with_smoke=full, with_fire=full)
+    results, cfg, per_frame = write_blender_tree(tmp_path, L, hw, frames=5, half=variant.endswith("zips"),
+                                                 compression="ZIPS" if variant.endswith("zips") else "ZIP")
+    paths = compositor.blend_frames(str(results), str(cfg), write_video=False)     # (EXR depth passes read by autovfx_amd.exr: no OpenCV here)
+    assert [os.path.basename(p) for p in paths] == [f"{i:04d}.png" for i in range(5)]
     for path, Li in zip(paths, per_frame):
         got = np.array(Image.open(path))
         np.testing.assert_array_equal(got, oracle_from_blender_layers(Li, hw), err_msg=path)
@@ -302,7 +308,8 @@ def test_reference_blend_frames_on_the_same_directory_tree(tmp_path):
     (tmp_path / "scene" / "custom_camera_path" / "depth").mkdir()
     for i in range(len(per_frame)):
         np.save(tmp_path / "scene" / "custom_camera_path" / "depth" / f"{i:05d}.npy", np.zeros(hw, np.float32))
-    ba.load_depth_exr = lambda p: np.load(p[:-4] + ".npy") if os.path.exists(p[:-4] + ".npy") else None
+    from autovfx_amd import exr
+    ba.load_depth_exr = lambda p: exr.load_depth_exr(p) if os.path.exists(p) else None    # (the reference's is two lines around cv2.imread, which this image lacks)
     ba.generate_video_from_frames = lambda *a, **k: None
     ba.blend_frames(str(results), str(cfg))
     for i, Li in enumerate(per_frame):

@@ -1,0 +1,111 @@
+"""autovfx_amd.exr: the OpenEXR scanline reader behind ``blend_frames`` where OpenCV is absent (blender/blend_all.py:70-75).
+CPU only.  Pinned three ways: a file assembled byte by byte from the OpenEXR file-layout document (independent of the writer), round
+trips through the package's writer in every supported mode, and -- where they are importable -- OpenCV / the OpenEXR module."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from autovfx_amd import exr
+
+
+def _hand_made(W=3, H=2, compressed=False):
+    """A scanline file with channels G (half) and Z (float), written out from the specification: magic, version, attributes (name \\0 type
+    \\0 size data), empty name, offset table, then per block: y, size, [for each line: for each channel in name order: W values]."""
+    g = (np.arange(W * H, dtype=np.float32).reshape(H, W) * 0.25 - 0.5).astype("<f2")
+    z = (np.arange(W * H, dtype=np.float32).reshape(H, W) * 1.5 + 1000.0).astype("<f4")
+    attr = lambda n, t, d: n + b"\0" + t + b"\0" + struct.pack("<i", len(d)) + d
+    chl = b"G\0" + struct.pack("<iB3xii", 1, 0, 1, 1) + b"Z\0" + struct.pack("<iB3xii", 2, 0, 1, 1) + b"\0"
+    head = struct.pack("<ii", 20000630, 2) + attr(b"channels", b"chlist", chl) + attr(b"compression", b"compression", bytes([2 if compressed else 0])) \
+        + attr(b"dataWindow", b"box2i", struct.pack("<4i", 10, 20, 10 + W - 1, 20 + H - 1)) \
+        + attr(b"displayWindow", b"box2i", struct.pack("<4i", 0, 0, 63, 63)) + attr(b"lineOrder", b"lineOrder", b"\0") \
+        + attr(b"pixelAspectRatio", b"float", struct.pack("<f", 1.0)) + attr(b"screenWindowCenter", b"v2f", struct.pack("<2f", 0, 0)) \
+        + attr(b"screenWindowWidth", b"float", struct.pack("<f", 1.0)) + b"\0"
+    blocks = []
+    for y in range(H):
+        raw = g[y].tobytes() + z[y].tobytes()
+        if compressed:      # ZIPS: even bytes, then odd bytes; delta predictor with bias 128; zlib
+            t = raw[0::2] + raw[1::2]
+            d = bytes([t[0]] + [(t[i] - t[i - 1] + 128) & 255 for i in range(1, len(t))])
+            packed = zlib.compress(d)
+            raw = packed if len(packed) < len(raw) else raw
+        blocks.append(struct.pack("<ii", 20 + y, len(raw)) + raw)
+    at, table = len(head) + 8 * H, b""
+    for b in blocks:
+        table += struct.pack("<Q", at)
+        at += len(b)
+    return head + table + b"".join(blocks), g, z
+
+
+@pytest.mark.parametrize("compressed", [False, True])
+def test_reads_a_file_assembled_from_the_specification(compressed):
+    data, g, z = _hand_made(compressed=compressed)
+    ch = exr.read_exr(data)
+    assert set(ch) == {"G", "Z"} and ch["G"].dtype == np.float16 and ch["Z"].dtype == np.float32
+    np.testing.assert_array_equal(ch["G"], g)
+    np.testing.assert_array_equal(ch["Z"], z)
+    wide, g, z = _hand_made(W=300, H=5, compressed=compressed)      # (long enough for the zlib stream to be shorter than the raw block)
+    ch = exr.read_exr(wide)
+    np.testing.assert_array_equal(ch["G"], g)
+    np.testing.assert_array_equal(ch["Z"], z)
+
+
+@pytest.mark.parametrize("compression", ["NONE", "ZIPS", "ZIP"])
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("shape", [(1, 1), (16, 7), (17, 33), (54, 96), (100, 3)])
+@pytest.mark.parametrize("decreasing", [False, True])
+def test_round_trip_in_every_mode(tmp_path, compression, half, shape, decreasing):
+    g = np.random.default_rng(shape[0] * 7 + shape[1])
+    depth = (g.random(shape) * 9 + 0.5).astype(np.float32)
+    depth[: shape[0] // 2] = 1e10 if not half else 65504.0        # Blender's "nothing here" depth; flat areas compress, noisy ones do not
+    channels = {"R": depth, "G": depth, "B": depth + 1, "A": np.ones(shape, np.float32)}
+    p = str(tmp_path / "Image0001.exr")
+    exr.write_exr(p, channels, compression=compression, half=half, line_order_decreasing=decreasing)
+    got = exr.read_exr(p)
+    assert list(got) == ["A", "B", "G", "R"]
+    for k, v in channels.items():
+        want = v.astype(np.float16) if half else v
+        np.testing.assert_array_equal(got[k], want, err_msg=k)
+    d = exr.load_depth_exr(p)                                       # cv2.imread(...)[:, :, 0] is the B channel
+    assert d.dtype == np.float32 and d.shape == shape
+    np.testing.assert_array_equal(d, (depth + 1).astype(np.float16).astype(np.float32) if half else depth + 1)
+
+
+def test_what_is_not_supported_says_so(tmp_path):
+    data, _g, _z = _hand_made()
+    piz = data.replace(b"compression\0compression\0" + struct.pack("<i", 1) + b"\0", b"compression\0compression\0" + struct.pack("<i", 1) + b"\x04")
+    with pytest.raises(ValueError, match="PIZ"):
+        exr.read_exr(piz)
+    tiled = data[:4] + struct.pack("<i", 2 | 0x200) + data[8:]
+    with pytest.raises(ValueError, match="tiled"):
+        exr.read_exr(tiled)
+    with pytest.raises(ValueError, match="magic"):
+        exr.read_exr(b"\x89PNG" + data[4:])
+    single = str(tmp_path / "z.exr")
+    exr.write_exr(single, {"Z": np.full((4, 4), 2.5, np.float32)})
+    np.testing.assert_array_equal(exr.load_depth_exr(single), np.full((4, 4), 2.5, np.float32))   # no colour channels: the one there is
+
+
+def test_against_opencv_or_the_openexr_module_where_installed(tmp_path):
+    depth = (np.random.default_rng(3).random((37, 53)) * 20).astype(np.float32)
+    p = str(tmp_path / "Image0001.exr")
+    exr.write_exr(p, {"R": depth, "G": depth * 2, "B": depth * 3}, compression="ZIP")
+    checked = False
+    os.environ.setdefault("OPENCV_IO_ENABLE_OPENEXR", "1")
+    try:
+        import cv2
+        if hasattr(cv2, "imread"):
+            d = cv2.imread(p, cv2.IMREAD_ANYCOLOR | cv2.IMREAD_ANYDEPTH)
+            np.testing.assert_array_equal(d[:, :, 0], exr.load_depth_exr(p))
+            checked = True
+    except ImportError:
+        pass
+    try:
+        import OpenEXR  # noqa: F401
+        checked = True
+    except ImportError:
+        pass
+    if not checked:
+        pytest.skip("neither OpenCV nor the OpenEXR module is installed in this image")
