@@ -905,14 +905,16 @@ __global__ void __launch_bounds__(64) png_finish_dynamic_kernel(PngBatch B, PngT
     const PngJob& J = B.job[blockIdx.x];
     const PngLayout& L = J.L;
     uint8_t* __restrict__ out = J.out;
-    // the CRC's pre-conditioning as one more linear term: 0xFFFFFFFF x^(8 (4 + data_len)) mod P.  x^(8 n) is the product of x^(8 2^i) over
-    // the set bits i of n (crc_x2nmodp): one factor per lane, multiplied together in five rounds
-    uint32_t init_term;
-    {
-        const unsigned long long n = 4ull + J.dyn->data_len;
-        uint32_t f = (threadIdx.x < 40u && ((n >> threadIdx.x) & 1ull)) ? T.x2n[(threadIdx.x + 3u) & 31u] : (1u << 31);   // (1 << 31 is x^0)
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) f = crc_multmodp(f, (uint32_t)__shfl_xor((int)f, d));
+    // the CRC's pre-conditioning as one more linear term: 0xFFFFFFFF x^(8 n) mod P, n = 4 + data_len = 64 m + r.  x^(8 64 m) is a product of
+    // three entries of the shift tables the CRC kernel uses, x^(8 r) six squarings' worth at most: nine modular products on one lane
+    // (twenty in a row cost 35 us where this first lived; a product tree over the wave was no faster: every lane runs the worst case)
+    uint32_t init_term = 0u;
+    if (threadIdx.x == 0) {
+        const unsigned long long n = 4ull + J.dyn->data_len, m = n >> 6;
+        uint32_t f = crc_x2nmodp(T.x2n, n & 63ull, 3u);
+        if (m & 0xFFull) f = crc_multmodp(g_crc_shift64[0][m & 0xFFull], f);
+        if ((m >> 8) & 0xFFull) f = crc_multmodp(g_crc_shift64[1][(m >> 8) & 0xFFull], f);
+        if ((m >> 16) & 0xFFull) f = crc_multmodp(g_crc_shift64[2][(m >> 16) & 0xFFull], f);
         init_term = crc_multmodp(f, 0xFFFFFFFFu);
     }
     unsigned long long a1 = 0ull, a2 = 0ull;

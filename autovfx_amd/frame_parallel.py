@@ -31,6 +31,19 @@ def shard_frames(num_frames: int, rank: int, world_size: int) -> List[int]:
     return list(range(rank, num_frames, world_size))
 
 
+def local_device() -> torch.device:
+    """The GPU this process drives: one process per GPU, ``cuda:LOCAL_RANK`` as ``torch.distributed.run`` hands it out
+    (``LOCAL_RANK``, not ``RANK``: on a second node rank 11 is device 3)."""
+    import os
+    return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def rank_world() -> tuple:
+    """``(RANK, WORLD_SIZE)`` from the launcher's environment (``(0, 1)`` without one)."""
+    import os
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
 def pack_rgba8(color: torch.Tensor, alpha: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[3,H,W] + [1,H,W] float -> [4,H,W] uint8 with save_image's rounding.  GPU tensors go through
     the library's fused kernel (one launch, 20 B per pixel); anything else through plain torch ops."""

@@ -39,6 +39,23 @@ def build_rotation(r: torch.Tensor) -> torch.Tensor:
     return R
 
 
+def build_covariance_from_scaling_rotation(scaling: torch.Tensor, scaling_modifier: float, rotation: torch.Tensor) -> torch.Tensor:
+    """The six upper-triangle entries of R S S^T R^T, [P,6] (``scene/gaussian_model.py:26-30`` with ``build_scaling_rotation`` /
+    ``strip_symmetric``, ``general_utils.py:64-76,101-110``): what ``render()`` hands over as ``cov3D_precomp`` when
+    ``pipe.compute_cov3D_python`` is set (``gaussian_renderer/__init__.py:127-128``).  Note that the reference passes the RAW rotation
+    (``self._rotation``, ``gaussian_model.py:114``): ``build_rotation`` normalises it itself."""
+    s = scaling_modifier * scaling
+    L = torch.zeros((s.shape[0], 3, 3), dtype=torch.float, device=s.device)
+    R = build_rotation(rotation)
+    L[:, 0, 0], L[:, 1, 1], L[:, 2, 2] = s[:, 0], s[:, 1], s[:, 2]
+    L = R @ L
+    cov = L @ L.transpose(1, 2)
+    out = torch.zeros((cov.shape[0], 6), dtype=torch.float, device=s.device)
+    out[:, 0], out[:, 1], out[:, 2] = cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2]
+    out[:, 3], out[:, 4], out[:, 5] = cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]
+    return out
+
+
 def get_minimum_axis(scales: torch.Tensor, rotations: torch.Tensor) -> torch.Tensor:
     """The rotation column belonging to the smallest scale (``general_utils.py:135-141``; the reference
     flags its own implementation as questionable but it is what ships, so it is mirrored as is)."""
@@ -151,6 +168,10 @@ class GaussianModel:
     def get_normal(self, dir_pp_normalized=None):
         normal_axis, _ = flip_align_view(self.get_minimum_axis, dir_pp_normalized)
         return normal_axis / normal_axis.norm(dim=1, keepdim=True)
+
+    def get_covariance(self, scaling_modifier: float = 1):
+        """``GaussianModel.get_covariance`` (``scene/gaussian_model.py:113-114``)."""
+        return build_covariance_from_scaling_rotation(self.get_scaling, scaling_modifier, self._rotation)
 
     # ---- PLY (gaussian_model.py:187-266) ----
     def _attribute_names(self):

@@ -486,8 +486,10 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    from autovfx_amd.frame_parallel import local_device
+    device = local_device()                     # cuda:LOCAL_RANK: one process per GPU
+    assert device.index == local_rank
+    torch.cuda.set_device(device)
 
     import torch.distributed as dist
     distributed = world > 1 or args.force_distributed
@@ -600,6 +602,17 @@ def main():
         per_rank_fps = [round(float(v), 2) for v in t.tolist()]
     else:
         per_rank_fps = [round(my_fps, 2)]
+    # N x single-GPU, measured in THIS run: rank 0 renders the same frames alone -- no gather, the other ranks waiting at a
+    # barrier -- so that the line carries its own yardstick (the driver computes efficiency from separate N = 1 runs as well)
+    alone_fps = None
+    if distributed and not strong and not args.profile_run:
+        with torch.no_grad():
+            dist.barrier()
+            if rank == 0:
+                b.run(timed_frames[:min(K, 2 * S + 2)], rgba, S, side, composed)
+                asecs = timed_regions(lambda: b.run(timed_frames, rgba, S, side, composed), min(R, 3), False, device)
+                alone_fps = K / sorted(asecs)[len(asecs) // 2]
+            dist.barrier()
 
     if args.profile_run:
         if rank == 0:
@@ -779,6 +792,14 @@ def main():
         rf["reference_on_gpu_ms"] = reference_on_gpu.get("ms_per_frame") if isinstance(reference_on_gpu, dict) else None
         line["config"]["serial_frames_per_s"] = None if serial is None else serial["value"]
         line["config"]["n_ranks_seen"] = n_ranks_seen
+        # the multi-GPU scalars where the driver's record keeps scalars: every rank's own rate (min / max; the list is `per_rank_frames_per_s`),
+        # the gather's tail behind the last rendered frame, and the whole job against N times rank 0 alone in this same run
+        line["config"]["per_rank_frames_per_s_min"] = min(per_rank_fps) if per_rank_fps else None
+        line["config"]["per_rank_frames_per_s_max"] = max(per_rank_fps) if per_rank_fps else None
+        line["config"]["gather_tail_ms"] = round(gather_stats.get("gather_tail_s", 0.0) * 1e3, 3) if gather_stats else None
+        line["config"]["gather_render_s"] = round(gather_stats.get("render_s", 0.0), 5) if gather_stats else None
+        line["config"]["single_gpu_frames_per_s_same_run"] = None if alone_fps is None else round(alone_fps, 2)
+        line["config"]["frac_of_n_x_single_gpu"] = None if alone_fps is None else round(fps(med) / (world * alone_fps), 4)
         if isinstance(also, dict):
             ur = also.get("c3_reference_shaped_render") or {}
             bw = also.get("backward_c3") or {}

@@ -59,8 +59,9 @@ def main():
     rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
     if not torch.cuda.is_available():
         raise SystemExit("needs a HIP device: the render path has no CPU fallback")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    from autovfx_amd.frame_parallel import local_device
+    dev = local_device()                        # cuda:LOCAL_RANK
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

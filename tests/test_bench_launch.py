@@ -40,7 +40,7 @@ def test_dry_run_shows_the_child_and_runs_nothing():
     assert d["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
-@pytest.mark.parametrize("n", [2, 3])
+@pytest.mark.parametrize("n", [2, 3, 8])
 def test_gpus_n_as_typed_reaches_n_ranks_and_prints_one_line(n):
     r = _run({"BENCH_LAUNCH_PROBE": "1", "BENCH_LAUNCH_ALLOW_NO_GPU": "1"}, "--gpus", str(n), "--steps", "2", "--warmup", "1")
     assert r.returncode == 0, r.stderr[-3000:]

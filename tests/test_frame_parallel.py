@@ -191,3 +191,77 @@ def test_two_rank_gloo_matches_single_process(tmp_path, num_frames):
     assert got["rgba8"].shape == (num_frames, 4, 24, 40) and got["rgba8"].dtype == torch.uint8
     assert torch.equal(got["rgba8"], ref["rgba8"]) and torch.equal(got["depth"], ref["depth"])
     assert len({bytes(f.numpy().tobytes()) for f in got["rgba8"]}) == num_frames   # frames differ: order is checked
+
+
+# ---- eight ranks: BASELINE configs[2]'s shape (800 frames over 8 GPUs) on CPU with gloo ---------------------------------------------------
+def _synthetic_frame(cloud, cam, bg):
+    """A renderer that costs nothing and makes every frame different: the camera's position painted into a 32x18 image (the test is
+    about which rank renders which frame and where it lands at rank 0)."""
+    H, W = cam.image_height, cam.image_width
+    c = cam.camera_center.to(torch.float32)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    color = torch.stack([torch.frac(xx * 0.03 + yy * 0.05 + c[k].abs() * 0.37 + 0.1 * k) for k in range(3)])
+    alpha = torch.frac(c.sum().abs() + xx * 0.01)[None]
+    return color, torch.ones(1, H, W), alpha, torch.zeros(cloud.means3D.shape[0], dtype=torch.int32)
+
+
+class _SyntheticPending:
+    def __init__(self, *a):
+        self.a = a
+
+    def finish(self):
+        return _synthetic_frame(*self.a)
+
+
+def _synthetic_begin(cloud, cam, bg):
+    return _SyntheticPending(cloud, cam, bg)
+
+
+def _worker_eight(rank, world, port, num_frames, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cloud = scenes.config_c1(P=50, seed=2)
+        cams = orbit_cameras(num_frames, 32, 18)
+        mine = fp.shard_frames(num_frames, rank, world)
+        assert mine == list(range(rank, num_frames, world)) and abs(len(mine) - num_frames / world) < 1
+        stats = {}
+        res = fp.render_and_gather(cloud, cams, mine, torch.zeros(3), chunks=16, stats=stats, begin_fn=_synthetic_begin,
+                                   driver="pipelined", streams=3)
+        if rank == 0:
+            torch.save(fp.frames_in_order(res, num_frames), out_path)
+        else:
+            assert res is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_frames", [800, 803])
+def test_eight_ranks_800_frames_round_robin_and_gather(tmp_path, num_frames):
+    """configs[2]'s job shape: 800 frames (and 803: shards of 101 and 100 frames, a zero-padded last piece) sharded round-robin over
+    EIGHT ranks, each rank's stack gathered to rank 0 in 16 pipelined pieces; the result is what one process renders, frame for frame."""
+    out = str(tmp_path / "gathered.pt")
+    mp.spawn(_worker_eight, args=(8, _free_port(), num_frames, out), nprocs=8, join=True)
+    got = torch.load(out)
+    cloud = scenes.config_c1(P=50, seed=2)
+    cams = orbit_cameras(num_frames, 32, 18)
+    assert got.shape == (num_frames, 4, 18, 32) and got.dtype == torch.uint8
+    for i in range(num_frames):                      # every frame is the one its own camera renders: nothing swapped, dropped or padded in
+        c, _d, a, _r = _synthetic_frame(cloud, cams[i], None)
+        assert torch.equal(got[i], fp.pack_rgba8(c, a)), i
+    assert len({bytes(f.numpy().tobytes()) for f in got}) > num_frames // 2    # (and the frames do differ)
+
+
+def test_rank_to_device_mapping_follows_local_rank(monkeypatch):
+    """One process per GPU: rank r of a node drives cuda:LOCAL_RANK -- bench.py, scripts/render_trajectory.py and the frame loop all
+    go through ``frame_parallel.local_device()``; LOCAL_RANK wins over RANK (multi-node ranks are not device indices)."""
+    for env, want in (({"RANK": "5", "LOCAL_RANK": "5", "WORLD_SIZE": "8"}, 5), ({"RANK": "11", "LOCAL_RANK": "3", "WORLD_SIZE": "16"}, 3),
+                      ({}, 0), ({"RANK": "2"}, 0)):
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        d = fp.local_device()
+        assert d.type == "cuda" and d.index == want, (env, d)
+        assert fp.rank_world() == (int(env.get("RANK", 0)), int(env.get("WORLD_SIZE", 1)))

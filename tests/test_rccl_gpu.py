@@ -42,6 +42,13 @@ def test_one_rank_rccl_group_gathers_the_bytes_of_the_single_process_path():
     assert dist["config"]["gather"]["gathered_shape"] == [1, 8, 4, 540, 960]
     assert "RCCL gather" in dist["config"]["boundary"]
     assert dist["frames_digest"] == plain["frames_digest"]
+    # the multi-GPU scalars ride in `config` (where the driver's record keeps scalars): every rank's rate, the gather's tail, and
+    # the job against N x rank 0 alone in the same run
+    c = dist["config"]
+    assert c["n_ranks_seen"] == 1 and c["per_rank_frames_per_s_min"] == c["per_rank_frames_per_s_max"] == dist["per_rank_frames_per_s"][0] > 0
+    assert c["gather_tail_ms"] >= 0.0 and c["single_gpu_frames_per_s_same_run"] > 0
+    assert 0.3 < c["frac_of_n_x_single_gpu"] < 1.5      # one rank: the gather's cost against the same frames without it
+    assert plain["config"]["frac_of_n_x_single_gpu"] is None and plain["config"]["gather_tail_ms"] is None
 
 
 def test_one_rank_rccl_job_with_cloud_broadcast_and_uneven_pieces():
