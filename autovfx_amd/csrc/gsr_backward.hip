@@ -522,15 +522,24 @@ __device__ __forceinline__ F4 view_normal_backward(F3 p, F3 cam, F3 s, F4 q, F3 
     return F4{(gq.x - w * qd) / n2, (gq.y - x * qd) / n2, (gq.z - y * qd) / n2, (gq.w - z * qd) / n2};    // through q / ||q||
 }
 
-constexpr int kShStagePitch = 65;  // words between consecutive floats of one lane's record in the LDS stage
+// The LDS stage of dL_dsh: one slot of 48 floats per Gaussian THAT HAS A GRADIENT, handed out in lane order (a ballot and a population
+// count), kShStageSlots per wave.  Pitch 49: the lanes of a wave write float f of 64 different slots to 64 different banks.  A wave with
+// more contributing Gaussians than slots (dense training views) stores the records of the surplus lanes straight to HBM.
+constexpr int kShStagePitch = 49;
+constexpr int kShStageSlots = 32;
 
-// One lane = one Gaussian.  `stage` (nullable) is this lane's column of the wave's LDS stage for dL_dsh: float f of
-// the record goes to stage[f * kShStagePitch]; with stage == nullptr the record is stored straight to HBM.
+// One lane = one Gaussian.  `stage` (nullable) is the wave's LDS stage for dL_dsh: a lane with a gradient takes slot number
+// (contributing lanes below it) and puts float f of its record at stage[slot * kShStagePitch + f]; with stage == nullptr, or no slot
+// left, the record is stored straight to HBM.
+// Returns where the lane's dL_dsh record is: 0 nowhere -- an idle lane (not rendered, or rendered without a contribution) leaves the stage
+// alone, its record is all zeros and the workgroup's copy-out writes them without reading anything from LDS; 1 in the lane's slot of
+// the stage; 2 in HBM already (no stage, or no slot left).
 template <bool kRaw>
-__device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, const Camera& cam, int idx, float* stage) {
+__device__ __forceinline__ int preprocess_backward_lane(const BackwardArgs& g, const Camera& cam, int idx, float* stage) {
     // the sums of this Gaussian, one 64-byte line (ten slots; 10 - 12: a second feature set's colour sums; the rest stay zero)
     const float4* line = reinterpret_cast<const float4*>(g.accum + (size_t)kAccumStride * idx);
     bool idle = !(g.radii[idx] > 0);
+    const bool staged = stage != nullptr;      // the wave's dL_dsh records leave through the LDS stage (this lane's own may still go direct)
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2q = s0, s3q = s0;
     if (!idle) {
         s0 = line[0]; s1 = line[1]; s2q = line[2]; s3q = line[3];
@@ -541,6 +550,11 @@ __device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, 
         // overflowed, which would have stored NaN.)
         idle = s0.x == 0.f && s0.y == 0.f && s0.z == 0.f && s0.w == 0.f && s1.x == 0.f && s1.y == 0.f && s1.z == 0.f && s1.w == 0.f &&
                s2q.x == 0.f && s2q.y == 0.f && s2q.z == 0.f && s2q.w == 0.f && s3q.x == 0.f && s3q.y == 0.f && s3q.z == 0.f && s3q.w == 0.f;
+    }
+    if (stage != nullptr) {   // (every lane of the wave that has a Gaussian is here: the ballot sees them all)
+        const unsigned long long live = __ballot(!idle);
+        const int slot = __popcll(live & ((1ull << (threadIdx.x & 63)) - 1ull));
+        stage = slot < kShStageSlots ? stage + slot * kShStagePitch : nullptr;
     }
     if (idle) {
         // Not rendered, or rendered without a contribution: every gradient of this Gaussian is zero.  The kernel defines ALL
@@ -557,8 +571,9 @@ __device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, 
             *reinterpret_cast<F3*>(g.dL_dcov3D + 6 * (size_t)idx) = z3;
             *reinterpret_cast<F3*>(g.dL_dcov3D + 6 * (size_t)idx + 3) = z3;
         }
-        if (stage != nullptr) {
-            for (int f = 0; f < 3 * g.M; ++f) stage[f * kShStagePitch] = 0.f;
+        if (staged) {
+            // (nothing: see the return value.  Four Gaussians in five take this path at C3; their 48 LDS writes each and the 48 reads that
+            // fetched the zeros back were most of this kernel's LDS traffic)
         } else if (g.dL_dsh != nullptr) {
             if (kRaw) {
                 *reinterpret_cast<F3*>(g.dL_dsh + 3 * (size_t)idx) = z3;
@@ -569,7 +584,7 @@ __device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, 
         }
         *reinterpret_cast<F3*>(g.dL_dscale + 3 * (size_t)idx) = z3;
         *reinterpret_cast<F4*>(g.dL_drot + 4 * (size_t)idx) = F4{0.f, 0.f, 0.f, 0.f};
-        return;
+        return 0;
     }
     const float* __restrict__ view = cam.viewmatrix;
     const float* __restrict__ proj = cam.projmatrix;
@@ -738,9 +753,9 @@ __device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, 
 #pragma unroll
             for (int k = 0; k < 16; ++k) {  // staged records are M = 16 wide; bands above the degree are zero
                 const float m = k < ncoef ? kk[k] : 0.f;
-                stage[(3 * k + 0) * kShStagePitch] = m * dL0;
-                stage[(3 * k + 1) * kShStagePitch] = m * dL1;
-                stage[(3 * k + 2) * kShStagePitch] = m * dL2;
+                stage[3 * k + 0] = m * dL0;
+                stage[3 * k + 1] = m * dL1;
+                stage[3 * k + 2] = m * dL2;
             }
         } else {
 #pragma unroll
@@ -808,6 +823,7 @@ __device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, 
         *reinterpret_cast<F3*>(g.dL_dscale + 3 * (size_t)idx) = F3{0.f, 0.f, 0.f};
         *reinterpret_cast<F4*>(g.dL_drot + 4 * (size_t)idx) = F4{0.f, 0.f, 0.f, 0.f};
     }
+    return g.shs == nullptr ? 0 : stage != nullptr ? 1 : 2;
 }
 
 // dL_dsh is 192 bytes per Gaussian: written lane by lane it goes out as 12-byte pieces 192 bytes apart (measured
@@ -815,20 +831,27 @@ __device__ __forceinline__ void preprocess_backward_lane(const BackwardArgs& g, 
 // wave writes its 12 KB as contiguous 16-byte stores (5.9 TB/s).  Taken when M == 16 and the tensor is 16-byte aligned.
 template <bool kRaw>
 __global__ void __launch_bounds__(256) preprocess_backward_kernel(BackwardArgs g, Camera cam) {
-    __shared__ float s_stage[4][48 * kShStagePitch];
+    __shared__ float s_stage[4][kShStageSlots * kShStagePitch];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // (raw: the record leaves as _features_dc's 12 bytes and _features_rest's 180: both dense arrays, 16-byte aligned starts)
-    const bool staged = g.dL_dsh != nullptr && g.M == 16 &&
+    const bool staged = g.dL_dsh != nullptr && g.shs != nullptr && g.M == 16 &&
                         (reinterpret_cast<uintptr_t>(kRaw ? g.dL_dsh_rest : g.dL_dsh) & 15u) == 0;  // uniform
-    if (idx < g.P) preprocess_backward_lane<kRaw>(g, cam, idx, staged ? s_stage[wave] + lane : nullptr);
+    const int where = idx < g.P ? preprocess_backward_lane<kRaw>(g, cam, idx, staged ? s_stage[wave] : nullptr) : 0;
+    const bool in_slot = where == 1;
     if (!staged) return;
     const int g0 = blockIdx.x * 256 + wave * 64;  // first Gaussian of this wave
     if (g0 >= g.P) return;
+    // Which of the wave's Gaussians have a record in the stage -- wave-uniform, in scalar registers.  The others' records are zeros,
+    // written from here without a trip through LDS -- except the surplus lanes of a wave with more than kShStageSlots contributing
+    // Gaussians, which stored their own records (`direct`).  A Gaussian's slot is the number of staged ones below it.
+    const unsigned long long in_stage = __ballot(in_slot);
+    const unsigned long long direct = __ballot(where == 2);
     __builtin_amdgcn_s_waitcnt(0);       // this wave's own LDS writes have landed
     __builtin_amdgcn_wave_barrier();
     const float* mine = s_stage[wave];
     const int count = min(64, g.P - g0);
+    auto slot_of = [&](int gi) { return __popcll(in_stage & ((1ull << gi) - 1ull)) * kShStagePitch; };
     if (!kRaw) {
         float4* dst = reinterpret_cast<float4*>(g.dL_dsh + 48 * (size_t)g0);
         const int chunks = count * 12;
@@ -837,15 +860,21 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(BackwardArgs g
             const int c = k * 64 + lane;  // 16-byte chunk of the wave's 12 KB
             if (c < chunks) {
                 const int gi = c / 12, f = (c - gi * 12) * 4;
-                dst[c] = make_float4(mine[(f + 0) * kShStagePitch + gi], mine[(f + 1) * kShStagePitch + gi],
-                                     mine[(f + 2) * kShStagePitch + gi], mine[(f + 3) * kShStagePitch + gi]);
+                if ((direct >> gi) & 1ull) continue;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((in_stage >> gi) & 1ull) {
+                    const float* rec = mine + slot_of(gi) + f;
+                    v = make_float4(rec[0], rec[1], rec[2], rec[3]);
+                }
+                dst[c] = v;
             }
         }
     } else {
         // coefficient 0 -> _features_dc's gradient: 12 bytes per Gaussian, neighbouring lanes neighbouring addresses
-        if (lane < count)
-            *reinterpret_cast<F3*>(g.dL_dsh + 3 * (size_t)(g0 + lane)) =
-                F3{mine[0 * kShStagePitch + lane], mine[1 * kShStagePitch + lane], mine[2 * kShStagePitch + lane]};
+        if (lane < count && !((direct >> lane) & 1ull)) {
+            const float* rec = mine + slot_of(lane);
+            *reinterpret_cast<F3*>(g.dL_dsh + 3 * (size_t)(g0 + lane)) = in_slot ? F3{rec[0], rec[1], rec[2]} : F3{0.f, 0.f, 0.f};
+        }
         // coefficients 1..15 -> _features_rest's: the wave's 64 x 45 floats are one contiguous run (64 x 180 bytes, a multiple
         // of 16), written as 16-byte chunks; float F of the run belongs to Gaussian F / 45, record float 3 + F % 45
         float4* dst = reinterpret_cast<float4*>(g.dL_dsh_rest + 45 * (size_t)g0);
@@ -854,19 +883,20 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(BackwardArgs g
         for (int k = 0; k < 12; ++k) {
             const int c = k * 64 + lane;
             const int F = 4 * c;
-            if (F + 3 < floats) {
-                float v[4];
+            if (F >= floats) continue;
+            float v[4];
+            bool whole = F + 3 < floats;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int gi = (F + t) / 45, r = (F + t) - 45 * gi;
-                    v[t] = mine[(3 + r) * kShStagePitch + gi];
-                }
+            for (int t = 0; t < 4; ++t) {
+                const int gi = min((F + t) / 45, 63), r = (F + t) - 45 * ((F + t) / 45);
+                v[t] = ((in_stage >> gi) & 1ull) ? mine[slot_of(gi) + 3 + r] : 0.f;
+                if ((direct >> gi) & 1ull) whole = false;
+            }
+            if (whole) {
                 dst[c] = make_float4(v[0], v[1], v[2], v[3]);
-            } else if (F < floats) {   // (the last chunk of a ragged last wave)
-                for (int t = 0; F + t < floats; ++t) {
-                    const int gi = (F + t) / 45, r = (F + t) - 45 * gi;
-                    g.dL_dsh_rest[45 * (size_t)g0 + F + t] = mine[(3 + r) * kShStagePitch + gi];
-                }
+            } else {   // the last chunk of a ragged last wave, or a chunk that touches a Gaussian that stored its own record
+                for (int t = 0; t < 4 && F + t < floats; ++t)
+                    if (!((direct >> ((F + t) / 45)) & 1ull)) g.dL_dsh_rest[45 * (size_t)g0 + F + t] = v[t];
             }
         }
     }
