@@ -113,7 +113,8 @@ def render_frames(views: Sequence, names: Sequence[str], model_for_frame: Callab
             import time
             clock = time.perf_counter
             stats.clear()
-            stats.update(frames=len(ids), streams=S, begin_s=0.0, finish_s=0.0, submit_s=0.0)
+            stats.update(frames=len(ids), streams=S, begin_s=0.0, finish_s=0.0, submit_s=0.0, loop_s=0.0)
+            t_loop = clock()
 
         def finish_oldest():
             st, name, pending = q.popleft()
@@ -141,6 +142,8 @@ def render_frames(views: Sequence, names: Sequence[str], model_for_frame: Callab
                     stats["begin_s"] += clock() - t0
         while q:
             finish_oldest()
+        if stats is not None:
+            stats["loop_s"] = clock() - t_loop
         for st in side:
             torch.cuda.current_stream(device).wait_stream(st)
     return len(ids)
@@ -271,13 +274,18 @@ def render_from_3DGS(self, render_video=False, post_rendering=False):
     rank, world, dist = _rank_world()
     streams = DEFAULT_STREAMS
     names = [view.image_name for view in camera_views]
+    import time
     with torch.no_grad():
+        t0 = time.perf_counter()
         plan = _plan(self, mod, len(camera_views), streams)
+        t1 = time.perf_counter()
         mine = list(range(rank, len(camera_views), world))
         tqdm = getattr(mod, "tqdm", None)
         progress = (lambda ids: tqdm(ids, desc="Rendering progress")) if tqdm is not None else None
         render_frames(camera_views, names, plan.model_for_frame, self.traj_results_dir, self.pipe, self.background,
                       frame_ids=mine, streams=streams, progress=progress)
+        if os.environ.get("AUTOVFX_AMD_LOOP_STATS"):
+            LAST_LOOP_STATS.update(plan_s=t1 - t0, render_frames_s=time.perf_counter() - t1)
     if dist is not None and world > 1:
         dist.barrier()                 # every rank's files are on disk before anyone reads the directory
 

@@ -18,6 +18,31 @@ if __name__ == "__main__":
     ap.add_argument("--reference-frames", type=int, default=10)
     ap.add_argument("--legs", default="c5_loop")
     args = ap.parse_args()
+    # diagnosis knobs (not product paths): GSR_LOOP_DIAG=nowrite -- the files are built and copied to the host, nothing is written;
+    # GSR_LOOP_DIAG=nofiles -- frames are rendered and dropped
+    diag = os.environ.get("GSR_LOOP_DIAG", "")
+    if diag:
+        from autovfx_amd import frame_io, frame_loop
+
+        class _Drop:
+            def __enter__(self):
+                return self
+
+            def __exit__(self, *a):
+                return False
+
+            def submit(self, name, result):
+                pass
+
+        if diag == "nofiles":
+            frame_loop._make_writer = lambda out_dir, threads, slots: _Drop()
+        elif diag == "nowrite":
+            def _no_write(slot, paths, off, lengths_at=None):
+                slot["event"].synchronize()
+                for p_ in paths.values():
+                    open(p_, "wb").close()
+                return paths
+            frame_io.GpuFrameWriter._write = staticmethod(_no_write)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     sys.modules.setdefault("bench", bench)
