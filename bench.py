@@ -1282,8 +1282,8 @@ def _reference_shaped_blend_frames(results, cfg_path, frame_ids):
     return out_dir
 
 
-def blend_frames_bench(device, frames=400, reference_frames=3):
-    """``autovfx_amd.compositor.blend_frames`` -- what ``install()`` puts behind ``blend_all.blend_frames`` -- on a 400-frame synthetic
+def blend_frames_bench(device, frames=200, reference_frames=3):
+    """``autovfx_amd.compositor.blend_frames`` -- what ``install()`` puts behind ``blend_all.blend_frames`` -- on a synthetic
     Blender tree (960x540 frames, every Blender layer at 1920x1080: 6 RGBA PNGs and 4 half-float ZIP EXR depth passes per frame), to a
     tmpfs; the reference-shaped function beside it on a bounded number of frames."""
     import shutil
@@ -1308,7 +1308,7 @@ def blend_frames_bench(device, frames=400, reference_frames=3):
         same = all(np.array_equal(np.asarray(Image.open(paths[i])), np.asarray(Image.open(os.path.join(ref_dir, f"{i:04d}.png")))) for i in ids)
         layer_bytes = sum(os.path.getsize(os.path.join(root, "cache", "out", k, "001.png")) for k in compositor._LAYERS_RGB) + \
             sum(os.path.getsize(os.path.join(root, "cache", "out", k, "001", "Image0001.exr")) for k in compositor._LAYERS_DEPTH)
-        return {"workload": "400 frames at 960x540; per frame 6 RGBA PNG layers + 4 half-float ZIP EXR depth passes at 1920x1080 (Blender at 2x), "
+        return {"workload": f"{frames} frames at 960x540; per frame 6 RGBA PNG layers + 4 half-float ZIP EXR depth passes at 1920x1080 (Blender at 2x), "
                             "the 3DGS frame's PNG; frames written as compressed PNGs to a tmpfs", "frames": len(paths),
                 "value": round(len(paths) / dt, 1), "unit": "frames/s", "ms_per_frame": round(dt / len(paths) * 1e3, 3),
                 "decode_threads": int(os.environ.get("AUTOVFX_AMD_BLEND_DECODERS", "0")) or min(16, len(os.sched_getaffinity(0))),
