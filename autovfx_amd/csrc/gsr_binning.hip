@@ -157,6 +157,10 @@ struct TileWalker {
         runs = (!masked && rec.z != 0xFFFFFFFFu) ? pool + rec.z : nullptr;
         incl = runs != nullptr ? pool_incl + rec.z : nullptr;
         mask = (unsigned long long)rec.z | ((unsigned long long)rec.w << 32);
+        // later slabs: the tiles finished by the slabs in front leave the mask HERE (round 6).  slab_recount_kernel used to write the
+        // reduced mask back into the record -- 75 MB of read-modify-write per C3 frame for a few bit operations on a table that
+        // is resident in LDS anyway; the records now stay as bin_gather_kernel wrote them.
+        if (masked && done != nullptr) mask &= ~done_rect(done, row_words, rec.x, rec.y);
     }
     // position on the r-th (0-based) live tile
     __device__ __forceinline__ void start(const uint4 rec, uint32_t r, const uint32_t* pool, const uint32_t* pool_incl,
@@ -504,11 +508,7 @@ __global__ void __launch_bounds__(256, 7) slab_recount_kernel(BinningArrays a, i
         if (rec[j].y == 0u || !rec_is_masked(rec[j].y)) continue;
         const unsigned long long m = (unsigned long long)rec[j].z | ((unsigned long long)rec[j].w << 32);
         const unsigned long long left = m & ~done_rect(s_done, a.row_words, rec[j].x, rec[j].y);
-        if (left != m) {
-            rec[j].z = (uint32_t)left; rec[j].w = (uint32_t)(left >> 32);
-            a.sorted_bins[k] = rec[j];
-        }
-        count[j] = (uint32_t)__popcll(left);
+        count[j] = (uint32_t)__popcll(left);        // (counted, not written back: the expansion's walker subtracts the finished tiles itself)
     }
     GSR_BTRACE(8192 + blockIdx.x, 3);
     // Large splats: the live, unfinished tiles of every tile row, the rows of the wave's splats flattened over its lanes

@@ -1726,25 +1726,43 @@ def time_frame_files(b, n):
             # .npy header in front of the depth plane), one D2H copy per frame, four host threads that only write()
             from autovfx_amd.frame_io import GpuFrameWriter
             mg = 16 * n
-            with GpuFrameWriter(d, workers=4) as w:
-                for j in range(8):
-                    w.submit(f"w{j:05d}", frames[j % 4])     # slots, pinned buffers, the first writes
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            with GpuFrameWriter(d, workers=4) as w:
-                for j in range(mg):
-                    w.submit(f"g{j:05d}", frames[j % 4])
-            t_gpu = time.perf_counter() - t0
-            file_bytes = sum(os.path.getsize(os.path.join(d, sub, "g00000" + ext)) for sub, ext in
-                             (("images", ".png"), ("depth", ".npy"), ("depth", ".png"), ("normal", ".png")))
+            gpu = {}
+            for mode, deflate in (("compressed", True), ("stored", False)):
+                with GpuFrameWriter(d, workers=4, deflate=deflate) as w:
+                    for j in range(8):
+                        w.submit(f"w{j:05d}", frames[j % 4])     # slots, pinned buffers, the first writes
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                with GpuFrameWriter(d, workers=4, deflate=deflate) as w:
+                    for j in range(mg):
+                        w.submit(f"g{j:05d}", frames[j % 4])
+                t_gpu = time.perf_counter() - t0
+                file_bytes = sum(os.path.getsize(os.path.join(d, sub, "g00000" + ext)) for sub, ext in
+                                 (("images", ".png"), ("depth", ".npy"), ("depth", ".png"), ("normal", ".png")))
+                png_bytes = file_bytes - os.path.getsize(os.path.join(d, "depth", "g00000.npy"))
+                gpu[mode] = {"frames": mg, "threads": 4, "ms_per_frame": round(t_gpu / mg * 1e3, 3), "frames_per_s": round(mg / t_gpu, 1),
+                             "bytes_per_frame": int(file_bytes), "png_bytes_per_frame": int(png_bytes),
+                             "GBps_to_files": round(file_bytes * mg / t_gpu / 1e9, 2)}
+            # what PIL (torchvision.utils.save_image's writer) makes of the same three images at its default level: the size yardstick
+            import io as _io
+            from PIL import Image as _Image
+            from autovfx_amd.frame_io import _frame_to_host, depth2img
+            rgba8, depth_h, normal_h = _frame_to_host(frames[0])
+            pil_bytes = 0
+            for img in (rgba8, depth2img(depth_h.squeeze(), 3.0), normal_h):
+                buf = _io.BytesIO()
+                _Image.fromarray(np.ascontiguousarray(img)).save(buf, format="PNG")
+                pil_bytes += buf.getbuffer().nbytes
+            gpu["compressed"]["png_bytes_vs_pil_default"] = round(gpu["compressed"]["png_bytes_per_frame"] / pil_bytes, 3)
+            gpu["pil_default_png_bytes_per_frame"] = int(pil_bytes)
+            gpu["what"] = ("the same four files, their bytes built on the GPU -- compressed: Paeth-filtered scanlines, run-length matches, one Huffman "
+                           "code per image built in the kernel (gsr_frame_files_deflate); stored: deflate stored blocks (gsr_frame_files); "
+                           "Adler-32 / CRC-32 in the kernels, .npy header + fp32 plane -- one D2H copy per frame into pinned memory, four host "
+                           "threads write() to a temporary directory")
         return {"frames": n, "ms_per_frame": round(t_total / n * 1e3, 2),
                 "what": "RGBA PNG + depth .npy + depth preview PNG + normal PNG per frame (D2H copies, zlib level 3, file writes), one host thread",
                 "writer_pool": {"frames": m, "threads": workers, "ms_per_frame": round(t_pool / m * 1e3, 2)},
-                "gpu_file_images": {"frames": mg, "threads": 4, "ms_per_frame": round(t_gpu / mg * 1e3, 3),
-                                    "bytes_per_frame": int(file_bytes), "GBps_to_files": round(file_bytes * mg / t_gpu / 1e9, 2),
-                                    "what": "the same four files, their bytes built on the GPU (stored-deflate PNGs with Adler-32 / CRC-32 "
-                                            "computed in the kernel; .npy header + fp32 plane), one D2H copy per frame into pinned memory, "
-                                            "four host threads write() to a temporary directory"}}
+                "gpu_file_images": gpu}
     except Exception as e:
         return {"error": repr(e)[:200]}
 
