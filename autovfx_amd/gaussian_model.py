@@ -203,18 +203,23 @@ class GaussianModel:
         names, table = read_ply_vertex_table(path)
         col = {n: i for i, n in enumerate(names)}
         pick = lambda prefix: sorted((n for n in names if n.startswith(prefix)), key=lambda s: int(s.split("_")[-1]))
-        xyz = table[:, [col["x"], col["y"], col["z"]]]
-        opac = table[:, [col["opacity"]]]
-        dc = table[:, [col["f_dc_0"], col["f_dc_1"], col["f_dc_2"]]].reshape(-1, 3, 1)
         rest_names = pick("f_rest_")
         assert len(rest_names) == 3 * (self.max_sh_degree + 1) ** 2 - 3, "PLY SH count does not match max_sh_degree"
-        rest = table[:, [col[n] for n in rest_names]].reshape(-1, 3, (self.max_sh_degree + 1) ** 2 - 1)
-        scales = table[:, [col[n] for n in pick("scale_")]]
-        rots = table[:, [col[n] for n in pick("rot")]]
-        t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=device)
-        self._xyz, self._opacity, self._scaling, self._rotation = t(xyz), t(opac), t(scales), t(rots)
-        self._features_dc = t(dc).transpose(1, 2).contiguous()
-        self._features_rest = t(rest).transpose(1, 2).contiguous()
+        # the whole table goes to the device in ONE copy; the columns are picked (and f_rest transposed) there
+        tbl = torch.from_numpy(np.ascontiguousarray(table)).to(device=device, dtype=torch.float32)
+
+        def cols(keys):
+            idx = [col[k] for k in keys]
+            if idx == list(range(idx[0], idx[0] + len(idx))):          # the usual layout: a contiguous block of columns
+                return tbl[:, idx[0]:idx[0] + len(idx)]
+            return tbl[:, torch.as_tensor(idx, device=tbl.device)]
+
+        self._xyz = cols(["x", "y", "z"]).contiguous()
+        self._opacity = cols(["opacity"]).contiguous()
+        self._scaling = cols(pick("scale_")).contiguous()
+        self._rotation = cols(pick("rot")).contiguous()
+        self._features_dc = cols(["f_dc_0", "f_dc_1", "f_dc_2"]).reshape(-1, 3, 1).transpose(1, 2).contiguous()
+        self._features_rest = cols(rest_names).reshape(-1, 3, (self.max_sh_degree + 1) ** 2 - 1).transpose(1, 2).contiguous()
         self.active_sh_degree = self.max_sh_degree
         self.invalidate_cache()
         return self
@@ -262,8 +267,8 @@ _PLY_TYPES = {"float": "<f4", "float32": "<f4", "double": "<f8", "float64": "<f8
 
 
 def read_ply_vertex_table(path: str):
-    """Minimal PLY reader: the ``vertex`` element of a binary-little-endian or ASCII file as a float64
-    table plus its property names (what ``plyfile`` gives ``load_ply``)."""
+    """Minimal PLY reader: the ``vertex`` element of a binary-little-endian or ASCII file as a table (float32 when every
+    property is a 4-byte float, float64 otherwise) plus its property names (what ``plyfile`` gives ``load_ply``)."""
     with open(path, "rb") as f:
         if f.readline().strip() != b"ply":
             raise ValueError(f"{path}: not a PLY file")
@@ -292,8 +297,17 @@ def read_ply_vertex_table(path: str):
         names = [n for n, _ in props]
         if fmt == "binary_little_endian":
             rec = np.dtype([(n, t) for n, t in props])
-            data = np.frombuffer(f.read(rec.itemsize * count), dtype=rec, count=count)
-            table = np.stack([data[n].astype(np.float64) for n in names], axis=1) if count else np.zeros((0, len(names)))
+            raw = bytearray(rec.itemsize * count)      # (writable: torch.from_numpy wants to own what it wraps)
+            got = f.readinto(raw)
+            if got != len(raw):
+                raise ValueError(f"{path}: the vertex element is truncated ({got} of {len(raw)} bytes)")
+            if count and all(np.dtype(t) == np.dtype("<f4") for _n, t in props):
+                # every property a 4-byte float (what 3DGS writes): the records ARE a float32 table -- no per-column conversion
+                # (62 strided column copies to float64 made a 1 M-Gaussian scene take 0.9 s to read, a 60 k object 40 - 120 ms)
+                table = np.frombuffer(raw, dtype="<f4", count=count * len(props)).reshape(count, len(props))
+            else:
+                data = np.frombuffer(raw, dtype=rec, count=count)
+                table = np.stack([data[n].astype(np.float64) for n in names], axis=1) if count else np.zeros((0, len(names)))
         elif fmt == "ascii":
             table = np.loadtxt(f, dtype=np.float64, max_rows=count, ndmin=2) if count else np.zeros((0, len(names)))
         else:
