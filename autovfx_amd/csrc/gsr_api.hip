@@ -172,6 +172,7 @@ const char* gsr_last_error(void) { return g_error; }
 int gsr_abi_version(void) { return GSR_ABI_VERSION; }
 const char* gsr_target_arch(void) { return "gfx950"; }
 
+static void trim_det_pools();
 int gsr_set_option(int option, int value) {
     if (option < 0 || option >= GSR_OPT_NUM) return fail(GSR_ERR_INVALID_ARG, "unknown option %d", option);
     if (option == GSR_OPT_RADIX_RANK_ACTIVE) return fail(GSR_ERR_INVALID_ARG, "GSR_OPT_RADIX_RANK_ACTIVE is read-only");
@@ -180,7 +181,9 @@ int gsr_set_option(int option, int value) {
         if (value < 0 || value > 3) return fail(GSR_ERR_INVALID_ARG, "GSR_OPT_RADIX_RANK must be 0, 1, 2 or 3");
         gsr::radix_set_rank_request(value);
     }
+    const int before = g_options[option];
     g_options[option] = value;
+    if (option == GSR_OPT_BACKWARD_DETERMINISTIC && before != 0 && value == 0) trim_det_pools();   // give the records' memory back
     return GSR_OK;
 }
 int gsr_get_option(int option) {
@@ -355,6 +358,18 @@ constexpr int kMaxPoolDevices = 64;
 std::mutex g_det_pool_mutex;
 hipMemPool_t g_det_pool[kMaxPoolDevices] = {};
 bool g_det_pool_tried[kMaxPoolDevices] = {};
+
+} // namespace
+// Switching GSR_OPT_BACKWARD_DETERMINISTIC off releases what its pools hold (after one call at C3 the library kept
+// 1.4 GB per device outside the host framework's allocator for the life of the process).  While the option is on the pools keep
+// their memory between calls -- that is what they are for.
+static void trim_det_pools() {
+    std::lock_guard<std::mutex> lock(g_det_pool_mutex);
+    for (int d = 0; d < kMaxPoolDevices; ++d)
+        if (g_det_pool[d] != nullptr) (void)hipMemPoolTrimTo(g_det_pool[d], 0);
+    (void)hipGetLastError();
+}
+namespace {
 
 hipError_t det_alloc(void** ptr, size_t bytes, hipStream_t stream) {
     int dev = 0;

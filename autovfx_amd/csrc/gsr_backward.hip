@@ -522,26 +522,30 @@ __device__ __forceinline__ F4 view_normal_backward(F3 p, F3 cam, F3 s, F4 q, F3 
     return F4{(gq.x - w * qd) / n2, (gq.y - x * qd) / n2, (gq.z - y * qd) / n2, (gq.w - z * qd) / n2};    // through q / ||q||
 }
 
-// The LDS stage of dL_dsh: one slot of 48 floats per Gaussian THAT HAS A GRADIENT, handed out in lane order (a ballot and a population
-// count), kShStageSlots per wave.  Pitch 49: the lanes of a wave write float f of 64 different slots to 64 different banks.  A wave with
-// more contributing Gaussians than slots (dense training views) stores the records of the surplus lanes straight to HBM.
+// The LDS stage of dL_dsh: one slot of 48 floats per Gaussian of the workgroup THAT HAS A GRADIENT, handed out in Gaussian order,
+// kShStageSlots per workgroup of 256 Gaussians (51 contribute on average at C3).  Pitch 49: the lanes of a wave write float f of 64
+// different slots to 64 different banks.  A workgroup with more contributing Gaussians than slots (dense training views) stores the
+// records of the surplus ones straight to HBM.
 constexpr int kShStagePitch = 49;
-constexpr int kShStageSlots = 32;
+constexpr int kShStageSlots = 96;
 
-// One lane = one Gaussian.  `stage` (nullable) is the wave's LDS stage for dL_dsh: a lane with a gradient takes slot number
-// (contributing lanes below it) and puts float f of its record at stage[slot * kShStagePitch + f]; with stage == nullptr, or no slot
-// left, the record is stored straight to HBM.
-// Returns where the lane's dL_dsh record is: 0 nowhere -- an idle lane (not rendered, or rendered without a contribution) leaves the stage
-// alone, its record is all zeros and the workgroup's copy-out writes them without reading anything from LDS; 1 in the lane's slot of
-// the stage; 2 in HBM already (no stage, or no slot left).
-template <bool kRaw>
+// One lane = one Gaussian, in two phases (round 6).  Phase 1, every Gaussian on its own lane: is it idle -- not rendered, or rendered
+// without a contribution?  Then all its gradients are zeros, written here (dL_dsh excepted when the workgroup stages it: `stage` non-null
+// says so, and the copy-out writes those zeros without reading anything from LDS) and 0 is returned; otherwise 3: "has a gradient",
+// nothing computed yet.  Phase 2, the Gaussians WITH a gradient packed onto the first lanes of the workgroup (four of five have none
+// at C3, scattered over the waves: run in place, nearly every wave went through the whole per-Gaussian chain at 20 % lane
+// efficiency): the chain itself; `stage` is this Gaussian's slot of the LDS stage for dL_dsh, or null (store it straight to HBM).
+// Returns where the dL_dsh record went: 1 its slot, 2 HBM (0: there is none -- colours were given, not SH).
+template <bool kRaw, int kPhase>
 __device__ __forceinline__ int preprocess_backward_lane(const BackwardArgs& g, const Camera& cam, int idx, float* stage) {
     // the sums of this Gaussian, one 64-byte line (ten slots; 10 - 12: a second feature set's colour sums; the rest stay zero)
     const float4* line = reinterpret_cast<const float4*>(g.accum + (size_t)kAccumStride * idx);
-    bool idle = !(g.radii[idx] > 0);
-    const bool staged = stage != nullptr;      // the wave's dL_dsh records leave through the LDS stage (this lane's own may still go direct)
+    bool idle = kPhase == 2 ? false : !(g.radii[idx] > 0);
+    const bool staged = stage != nullptr;      // phase 1: the workgroup's dL_dsh records leave through the LDS stage
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2q = s0, s3q = s0;
-    if (!idle) {
+    if (kPhase == 2) {
+        s0 = line[0]; s1 = line[1]; s2q = line[2]; s3q = line[3];     // (read by phase 1 a moment ago: an L1 / L2 hit)
+    } else if (!idle) {
         s0 = line[0]; s1 = line[1]; s2q = line[2]; s3q = line[3];
         // Rendered, but no pixel composited it (behind an opaque front, or alpha < 1/255 everywhere: 80 % of C3's rendered
         // Gaussians, 99 % of the trained-scene stand-in's): every sum is an exact zero and every gradient below is a product
@@ -550,11 +554,6 @@ __device__ __forceinline__ int preprocess_backward_lane(const BackwardArgs& g, c
         // overflowed, which would have stored NaN.)
         idle = s0.x == 0.f && s0.y == 0.f && s0.z == 0.f && s0.w == 0.f && s1.x == 0.f && s1.y == 0.f && s1.z == 0.f && s1.w == 0.f &&
                s2q.x == 0.f && s2q.y == 0.f && s2q.z == 0.f && s2q.w == 0.f && s3q.x == 0.f && s3q.y == 0.f && s3q.z == 0.f && s3q.w == 0.f;
-    }
-    if (stage != nullptr) {   // (every lane of the wave that has a Gaussian is here: the ballot sees them all)
-        const unsigned long long live = __ballot(!idle);
-        const int slot = __popcll(live & ((1ull << (threadIdx.x & 63)) - 1ull));
-        stage = slot < kShStageSlots ? stage + slot * kShStagePitch : nullptr;
     }
     if (idle) {
         // Not rendered, or rendered without a contribution: every gradient of this Gaussian is zero.  The kernel defines ALL
@@ -586,6 +585,7 @@ __device__ __forceinline__ int preprocess_backward_lane(const BackwardArgs& g, c
         *reinterpret_cast<F4*>(g.dL_drot + 4 * (size_t)idx) = F4{0.f, 0.f, 0.f, 0.f};
         return 0;
     }
+    if (kPhase == 1) return 3;
     const float* __restrict__ view = cam.viewmatrix;
     const float* __restrict__ proj = cam.projmatrix;
     const F3 mean = ld3(g.means3D + 3 * (size_t)idx);
@@ -831,39 +831,51 @@ __device__ __forceinline__ int preprocess_backward_lane(const BackwardArgs& g, c
 // wave writes its 12 KB as contiguous 16-byte stores (5.9 TB/s).  Taken when M == 16 and the tensor is 16-byte aligned.
 template <bool kRaw>
 __global__ void __launch_bounds__(256) preprocess_backward_kernel(BackwardArgs g, Camera cam) {
-    __shared__ float s_stage[4][kShStageSlots * kShStagePitch];
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ float s_stage[kShStageSlots * kShStagePitch];
+    __shared__ uint16_t s_list[256];     // the workgroup's Gaussians with a gradient, in order
+    __shared__ uint16_t s_rank[256];     // per Gaussian: its place in that list, 0xFFFF: no gradient
+    __shared__ uint32_t s_count[4];
+    const int base = blockIdx.x * 256, tid = threadIdx.x;
+    const int idx = base + tid;
+    const int wave = tid >> 6, lane = tid & 63;
     // (raw: the record leaves as _features_dc's 12 bytes and _features_rest's 180: both dense arrays, 16-byte aligned starts)
     const bool staged = g.dL_dsh != nullptr && g.shs != nullptr && g.M == 16 &&
                         (reinterpret_cast<uintptr_t>(kRaw ? g.dL_dsh_rest : g.dL_dsh) & 15u) == 0;  // uniform
-    const int where = idx < g.P ? preprocess_backward_lane<kRaw>(g, cam, idx, staged ? s_stage[wave] : nullptr) : 0;
-    const bool in_slot = where == 1;
+    // phase 1: who has a gradient?  (the others' zeros are written here)
+    const bool has = idx < g.P && preprocess_backward_lane<kRaw, 1>(g, cam, idx, staged ? s_stage : nullptr) == 3;
+    const unsigned long long mask = __ballot(has);
+    if (lane == 0) s_count[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t before = 0u;
+    for (int w = 0; w < wave; ++w) before += s_count[w];
+    const uint32_t n_live = s_count[0] + s_count[1] + s_count[2] + s_count[3];
+    const uint32_t rank = before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    s_rank[tid] = has ? (uint16_t)rank : (uint16_t)0xFFFFu;
+    if (has) s_list[rank] = (uint16_t)tid;
+    __syncthreads();
+    // phase 2: the per-Gaussian chain, on the first n_live lanes (usually the first wave alone)
+    if ((uint32_t)tid < n_live) {
+        float* slot = (staged && tid < kShStageSlots) ? s_stage + tid * kShStagePitch : nullptr;
+        (void)preprocess_backward_lane<kRaw, 2>(g, cam, base + (int)s_list[tid], slot);
+    }
     if (!staged) return;
-    const int g0 = blockIdx.x * 256 + wave * 64;  // first Gaussian of this wave
-    if (g0 >= g.P) return;
-    // Which of the wave's Gaussians have a record in the stage -- wave-uniform, in scalar registers.  The others' records are zeros,
-    // written from here without a trip through LDS -- except the surplus lanes of a wave with more than kShStageSlots contributing
-    // Gaussians, which stored their own records (`direct`).  A Gaussian's slot is the number of staged ones below it.
-    const unsigned long long in_stage = __ballot(in_slot);
-    const unsigned long long direct = __ballot(where == 2);
-    __builtin_amdgcn_s_waitcnt(0);       // this wave's own LDS writes have landed
-    __builtin_amdgcn_wave_barrier();
-    const float* mine = s_stage[wave];
-    const int count = min(64, g.P - g0);
-    auto slot_of = [&](int gi) { return __popcll(in_stage & ((1ull << gi) - 1ull)) * kShStagePitch; };
+    __syncthreads();
+    // phase 3: dL_dsh of the workgroup's 256 Gaussians as whole 16-byte chunks: a staged record from its slot, zeros for a Gaussian
+    // without a gradient (no trip through LDS), nothing where the record was stored directly (no slot left)
+    const int count = min(256, g.P - base);
     if (!kRaw) {
-        float4* dst = reinterpret_cast<float4*>(g.dL_dsh + 48 * (size_t)g0);
+        float4* dst = reinterpret_cast<float4*>(g.dL_dsh + 48 * (size_t)base);
         const int chunks = count * 12;
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
-            const int c = k * 64 + lane;  // 16-byte chunk of the wave's 12 KB
+            const int c = k * 256 + tid;  // 16-byte chunk of the workgroup's 48 KB
             if (c < chunks) {
                 const int gi = c / 12, f = (c - gi * 12) * 4;
-                if ((direct >> gi) & 1ull) continue;
+                const uint32_t r = s_rank[gi];
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((in_stage >> gi) & 1ull) {
-                    const float* rec = mine + slot_of(gi) + f;
+                if (r != 0xFFFFu) {
+                    if (r >= (uint32_t)kShStageSlots) continue;
+                    const float* rec = s_stage + r * kShStagePitch + f;
                     v = make_float4(rec[0], rec[1], rec[2], rec[3]);
                 }
                 dst[c] = v;
@@ -871,32 +883,39 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(BackwardArgs g
         }
     } else {
         // coefficient 0 -> _features_dc's gradient: 12 bytes per Gaussian, neighbouring lanes neighbouring addresses
-        if (lane < count && !((direct >> lane) & 1ull)) {
-            const float* rec = mine + slot_of(lane);
-            *reinterpret_cast<F3*>(g.dL_dsh + 3 * (size_t)(g0 + lane)) = in_slot ? F3{rec[0], rec[1], rec[2]} : F3{0.f, 0.f, 0.f};
+        if (tid < count) {
+            const uint32_t r = s_rank[tid];
+            if (r == 0xFFFFu) *reinterpret_cast<F3*>(g.dL_dsh + 3 * (size_t)(base + tid)) = F3{0.f, 0.f, 0.f};
+            else if (r < (uint32_t)kShStageSlots) {
+                const float* rec = s_stage + r * kShStagePitch;
+                *reinterpret_cast<F3*>(g.dL_dsh + 3 * (size_t)(base + tid)) = F3{rec[0], rec[1], rec[2]};
+            }
         }
-        // coefficients 1..15 -> _features_rest's: the wave's 64 x 45 floats are one contiguous run (64 x 180 bytes, a multiple
-        // of 16), written as 16-byte chunks; float F of the run belongs to Gaussian F / 45, record float 3 + F % 45
-        float4* dst = reinterpret_cast<float4*>(g.dL_dsh_rest + 45 * (size_t)g0);
+        // coefficients 1..15 -> _features_rest's: the workgroup's 256 x 45 floats are one contiguous run (a multiple of 16 bytes),
+        // written as 16-byte chunks; float F of the run belongs to Gaussian F / 45, record float 3 + F % 45
+        float4* dst = reinterpret_cast<float4*>(g.dL_dsh_rest + 45 * (size_t)base);
         const int floats = count * 45;
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
-            const int c = k * 64 + lane;
+            const int c = k * 256 + tid;
             const int F = 4 * c;
             if (F >= floats) continue;
             float v[4];
             bool whole = F + 3 < floats;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int gi = min((F + t) / 45, 63), r = (F + t) - 45 * ((F + t) / 45);
-                v[t] = ((in_stage >> gi) & 1ull) ? mine[slot_of(gi) + 3 + r] : 0.f;
-                if ((direct >> gi) & 1ull) whole = false;
+                const int gi = min((F + t) / 45, 255), rr = (F + t) - 45 * ((F + t) / 45);
+                const uint32_t r = s_rank[gi];
+                v[t] = (r != 0xFFFFu && r < (uint32_t)kShStageSlots) ? s_stage[r * kShStagePitch + 3 + rr] : 0.f;
+                if (r != 0xFFFFu && r >= (uint32_t)kShStageSlots) whole = false;
             }
             if (whole) {
                 dst[c] = make_float4(v[0], v[1], v[2], v[3]);
-            } else {   // the last chunk of a ragged last wave, or a chunk that touches a Gaussian that stored its own record
-                for (int t = 0; t < 4 && F + t < floats; ++t)
-                    if (!((direct >> ((F + t) / 45)) & 1ull)) g.dL_dsh_rest[45 * (size_t)g0 + F + t] = v[t];
+            } else {   // the last chunk of a ragged last workgroup, or a chunk that touches a Gaussian that stored its own record
+                for (int t = 0; t < 4 && F + t < floats; ++t) {
+                    const uint32_t r = s_rank[(F + t) / 45];
+                    if (r == 0xFFFFu || r < (uint32_t)kShStageSlots) g.dL_dsh_rest[45 * (size_t)base + F + t] = v[t];
+                }
             }
         }
     }

@@ -97,6 +97,7 @@ class _RasterizeRaw(torch.autograd.Function):
             s.tanfovx, s.tanfovy, s.image_height, s.image_width, s.sh_degree, s.campos, s.prefiltered, s.debug, want_normal=True,
             inference=inference)
         ctx.settings, ctx.num_rendered = s, n
+        ctx.gsr_slab_forward = bool(inference)     # (diff_gaussian_rasterization._C.deterministic_backward_guard)
         # colour and alpha are planes of ONE output buffer: the node hands out that buffer as the [4,H,W] RGBA image render() returns
         # (the reference's torch.cat((rendered, alpha)), :186, without the copy and without the concat's graph node)
         rgba = _C.rgba_planes(color, alpha)
@@ -117,10 +118,11 @@ class _RasterizeRaw(torch.autograd.Function):
         if g_rgba is not None:
             g_rgba = g_rgba.contiguous()
             g_color, g_alpha = g_rgba[:3], g_rgba[3:4]
-        g2d, gxyz, gls, grot, gop, gdc, grest = _C.rasterize_gaussians_raw_backward(
-            s.bg, xyz, log_scales, rotations, opacity_logits, features_dc, features_rest, radii, s.scale_modifier, s.viewmatrix,
-            s.projmatrix, s.tanfovx, s.tanfovy, g_color, g_depth, g_alpha, g_normal, s.sh_degree, s.campos, geom, ctx.num_rendered,
-            binning, image, alpha, s.debug)
+        with _C.deterministic_backward_guard(ctx.gsr_slab_forward):
+            g2d, gxyz, gls, grot, gop, gdc, grest = _C.rasterize_gaussians_raw_backward(
+                s.bg, xyz, log_scales, rotations, opacity_logits, features_dc, features_rest, radii, s.scale_modifier, s.viewmatrix,
+                s.projmatrix, s.tanfovx, s.tanfovy, g_color, g_depth, g_alpha, g_normal, s.sh_degree, s.campos, geom, ctx.num_rendered,
+                binning, image, alpha, s.debug)
         return gxyz, gls, grot, gop, gdc, grest, g2d, None
 
 

@@ -172,6 +172,29 @@ def grad_slabs() -> bool:
     return _lib.get_option(_lib.OPT_GRAD_SLABS) != 0 and _lib.get_option(_lib.OPT_BACKWARD_DETERMINISTIC) == 0
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def deterministic_backward_guard(slab_forward: bool):
+    """``GSR_OPT_BACKWARD_DETERMINISTIC`` must be set BEFORE the forward call it is meant for: the deterministic backward sorts one list
+    per tile, and a grad-mode forward made while the option was off may have built its lists per depth slab (``GSR_OPT_GRAD_SLABS``).
+    If the option was switched on between such a forward and its backward -- another thread, a test fixture -- the library would refuse
+    (``GSR_ERR_INVALID_ARG``); the graph is still differentiable, so this call is made with float atomics instead, with a warning
+    (ADVICE round 5).  The choice the forward made rides in the autograd context (``ctx.gsr_slab_forward``)."""
+    flip = bool(slab_forward) and _lib.get_option(_lib.OPT_BACKWARD_DETERMINISTIC) != 0
+    if flip:
+        import warnings
+        warnings.warn("GSR_OPT_BACKWARD_DETERMINISTIC was switched on after this graph's forward call, which built its lists per depth slab: "
+                      "this backward uses float atomics (set the option before the forward call)", RuntimeWarning, stacklevel=3)
+        _lib.set_option(_lib.OPT_BACKWARD_DETERMINISTIC, 0)
+    try:
+        yield
+    finally:
+        if flip:
+            _lib.set_option(_lib.OPT_BACKWARD_DETERMINISTIC, 1)
+
+
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
                         prefiltered, debug, *, inference: bool = False

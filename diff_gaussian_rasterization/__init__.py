@@ -83,6 +83,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             forward_fn, native_args, s.debug, _SNAPSHOT_FW, "forward")
         ctx.raster_settings = s
         ctx.num_rendered = num_rendered
+        ctx.gsr_slab_forward = bool(inference)      # the lists of this call may be per depth slab: see backward
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_buffer,
                               binning_buffer, img_buffer, alpha)
         ctx.mark_non_differentiable(radii)
@@ -105,9 +106,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                        s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, grad_out_color, grad_out_depth,
                        grad_out_alpha, sh, s.sh_degree, s.campos, geom_buffer, ctx.num_rendered, binning_buffer,
                        img_buffer, alpha, s.debug)
-        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
-         grad_rotations) = _call_with_snapshot(functools.partial(_C.rasterize_gaussians_backward, skip_unused=True), native_args,
-                                               s.debug, _SNAPSHOT_BW, "backward")
+        with _C.deterministic_backward_guard(ctx.gsr_slab_forward):
+            (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+             grad_rotations) = _call_with_snapshot(functools.partial(_C.rasterize_gaussians_backward, skip_unused=True), native_args,
+                                                   s.debug, _SNAPSHOT_BW, "backward")
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales,
                 grad_rotations, grad_cov3Ds_precomp, None)
 

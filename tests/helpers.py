@@ -210,6 +210,9 @@ class dump_on_failure:
 
 # ---- gradient parity against the fp64 truth (oracle/gsr_oracle.c: gsro_backward_f64) ----
 GRAD_REL, GRAD_ABS, GRAD_REF_FACTOR = 2e-4, 1e-6, 4.0
+GRAD_PER_ELEMENT = True      # the bar also holds element by element (assert_gradients_vs_truth)
+GRAD_ELEMENT_FACTOR = 6.0    # ... with 6 instead of 4 times the reference's own error AT THAT ELEMENT: an element's yardstick is one
+                             # sample (eight draws of the noise model, one fp32 run of the reference), the array's maximum many
 
 
 def report_row(name, **kv):
@@ -249,7 +252,12 @@ def assert_gradients_vs_truth(name, got, ref32, truth, keys, rel=GRAD_REL, abs_t
     second says an ill-conditioned one (a needle's 1 / (denom^2 + 1e-7)) may be as far from the truth as the reference
     itself is, times ``ref_factor`` -- two fp32 samples of such a gradient differ from each other by more than 2e-4 of the
     scale even with exact per-Gaussian sums (profiles/r05_gradient_truth.md).  No stragglers, no noise multipliers.
-    Writes one report row with, per array: err (|got - truth| / scale), ref_err, vs_ref and frac = err / bar."""
+    Writes one report row with, per array: err (|got - truth| / scale), ref_err, vs_ref and frac = err / bar.
+
+    Round 6: the max-norm bar lets ONE ill-conditioned element set the allowance of a whole array.  The same
+    inequality is therefore also held ELEMENT BY ELEMENT -- element i may be as far from the truth as the fixed bar, or as
+    ``ref_factor`` times the reference's own error (or the noise yardstick) AT THAT ELEMENT: a well-conditioned Gaussian inside an
+    ill-conditioned array is pinned at ``rel * scale`` again.  ``frac_elem`` in the report row is the worst element's fraction."""
     row, failures = {}, []
     for k in keys:
         if got.get(k) is None:
@@ -263,6 +271,20 @@ def assert_gradients_vs_truth(name, got, ref32, truth, keys, rel=GRAD_REL, abs_t
             row[k]["noise"] = e_noise / s
         if not e_got <= bar:
             failures.append(f"{k}: |got - truth| {e_got:.3e} > bar {bar:.3e} (scale {scale:.3e}, |ref32 - truth| {e_ref:.3e})")
+        # ... and per element
+        g_, r_, t_ = (np.asarray(a, np.float64).reshape(-1) for a in (got[k], ref32[k], truth[k]))
+        ok = np.isfinite(t_) & np.isfinite(r_)
+        if ok.any():
+            allow = np.abs(r_ - t_)
+            if noise is not None and k in noise and np.size(noise[k]) == g_.size:
+                allow = np.maximum(allow, np.asarray(noise[k], np.float64).reshape(-1))
+            bar_i = np.maximum(rel * scale + abs_tol, max(ref_factor, GRAD_ELEMENT_FACTOR) * allow)[ok]
+            frac_i = np.abs(g_ - t_)[ok] / bar_i
+            worst = int(np.argmax(frac_i))
+            row[k]["frac_elem"] = float(frac_i[worst])
+            if GRAD_PER_ELEMENT and not frac_i[worst] <= 1.0:
+                failures.append(f"{k}: element {worst}: |got - truth| {np.abs(g_ - t_)[ok][worst]:.3e} > its own bar {bar_i[worst]:.3e} "
+                                f"(scale {scale:.3e}, |ref32 - truth| there {np.abs(r_ - t_)[ok][worst]:.3e})")
     report_row("grad:" + name, **{f"{k}.{m}": v for k, d in row.items() for m, v in d.items()})
     assert not failures, f"{name}: " + "; ".join(failures)
     return row

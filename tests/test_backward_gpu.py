@@ -428,3 +428,49 @@ def test_backward_accepts_the_scratch_of_an_inference_call_and_the_deterministic
         _lib.set_option(_lib.OPT_SLABS, 2)
         _lib.set_option(_lib.OPT_SLAB_FIRST, 400)
         _lib.set_option(_lib.OPT_SLAB_MIN_REST, 3000000)
+
+
+def test_the_deterministic_option_switched_on_between_forward_and_backward_does_not_break_the_graph():
+    """every grad-mode forward is a slab call (GSR_OPT_GRAD_SLABS); if GSR_OPT_BACKWARD_DETERMINISTIC is switched on between
+    such a forward and its backward the library refuses the scratch.  The autograd node remembers what its forward built
+    (``ctx.gsr_slab_forward``): the backward then runs with float atomics, WARNS, and leaves the option as it found it; set before the
+    forward the option gives the deterministic backward as always."""
+    import warnings
+    from autovfx_amd import _lib
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = "cuda:0"
+    cloud, cam = scenes.config_c1(P=3000, seed=4), scenes.c1_camera(96, 64)
+    c = cloud.to(dev)
+    st = settings_for(cam, dev, (0.0, 0.0, 0.0), 1.0, cloud.sh_degree)
+    _lib.set_option(_lib.OPT_SLABS, 0)
+    _lib.set_option(_lib.OPT_SLAB_FIRST, 6)
+    _lib.set_option(_lib.OPT_SLAB_MIN_REST, 0)
+    try:
+        def run(flip):
+            leaves = [t.clone().requires_grad_(True) for t in (c.means3D, c.opacities, c.shs, c.scales, c.rotations)]
+            m3, op, sh, sc, rot = leaves
+            img, _d, _a, _r = GaussianRasterizer(st)(m3, torch.zeros_like(m3, requires_grad=True), op, shs=sh, scales=sc, rotations=rot)
+            if flip:
+                _lib.set_option(_lib.OPT_BACKWARD_DETERMINISTIC, 1)
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                img.sum().backward()
+            torch.cuda.synchronize()
+            return [t.grad.clone() for t in leaves], [str(x.message) for x in w]
+        want, quiet = run(False)
+        assert not any("DETERMINISTIC" in m for m in quiet)
+        got, said = run(True)
+        assert any("GSR_OPT_BACKWARD_DETERMINISTIC was switched on after" in m for m in said), said
+        assert _lib.get_option(_lib.OPT_BACKWARD_DETERMINISTIC) == 1          # left as the caller set it
+        for a, b in zip(got, want):
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9
+        det1, said = run(False)                                               # the option is on BEFORE this forward: a full call, no warning
+        det2, _ = run(False)
+        assert not any("switched on after" in m for m in said)
+        for a, b in zip(det1, det2):
+            assert torch.equal(a, b)                                          # deterministic: the same bits twice
+    finally:
+        _lib.set_option(_lib.OPT_BACKWARD_DETERMINISTIC, 0)
+        _lib.set_option(_lib.OPT_SLABS, 2)
+        _lib.set_option(_lib.OPT_SLAB_FIRST, 400)
+        _lib.set_option(_lib.OPT_SLAB_MIN_REST, 3000000)
