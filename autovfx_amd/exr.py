@@ -34,11 +34,13 @@ def _cstr(buf: bytes, at: int):
 def _undo_predictor_and_interleave(raw: bytes) -> bytes:
     """The inverse of what ZIP / ZIPS / RLE blocks are pre-processed with: a running byte sum (delta predictor, bias 128), then the
     two halves -- bytes at even offsets, bytes at odd offsets -- woven back together."""
-    t = np.frombuffer(raw, np.uint8).astype(np.int64)
+    t = np.frombuffer(raw, np.uint8).copy()
     if t.size == 0:
         return raw
-    t[1:] -= 128
-    t = (np.cumsum(t) & 255).astype(np.uint8)
+    # t[i] = t[i-1] + d[i] - 128 (mod 256): a running sum in uint8 arithmetic, which wraps the way the format means it (-128 = +128 mod 256).
+    # (An int64 running sum of the same bytes was most of a frame's decoding time.)
+    t[1:] += np.uint8(128)
+    t = np.add.accumulate(t, dtype=np.uint8)
     half = (t.size + 1) // 2
     out = np.empty_like(t)
     out[0::2] = t[:half]
