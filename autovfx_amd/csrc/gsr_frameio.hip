@@ -548,7 +548,8 @@ __global__ void __launch_bounds__(256) png_table_kernel(PngBatch B) {
     if ((int)blockIdx.x >= B.n) return;
     const PngJob& J = B.job[blockIdx.x];
     const uint32_t blocks = J.blocks;
-    __shared__ unsigned long long s_key[512];     // count << 16 | symbol, ascending; unused symbols sort to the end
+    __shared__ unsigned long long s_key[288];     // count << 16 | symbol per symbol (~0: unused)
+    __shared__ unsigned long long s_sorted[288];  // ... of the used symbols, ascending
     __shared__ uint32_t s_weight[kDefSyms];       // internal nodes of the Huffman tree, in creation order
     __shared__ uint16_t s_parent_leaf[kDefSyms], s_parent_node[kDefSyms];
     __shared__ uint8_t s_len[kDefSyms];           // by symbol
@@ -558,7 +559,8 @@ __global__ void __launch_bounds__(256) png_table_kernel(PngBatch B) {
     __shared__ uint32_t s_n;
     __shared__ uint32_t s_header[(kDefHeaderBytes + 3u) / 4u + 1u];
     const uint32_t t = threadIdx.x;
-    for (uint32_t s = t; s < 512u; s += 256u) {
+    if (t == 0) s_n = 0u;
+    for (uint32_t s = t; s < 288u; s += 256u) {
         unsigned long long key = ~0ull;
         if (s < 286u) {
             uint32_t c = 0u;
@@ -572,26 +574,26 @@ __global__ void __launch_bounds__(256) png_table_kernel(PngBatch B) {
     for (uint32_t s = t; s < sizeof(s_header) / 4u; s += 256u) s_header[s] = 0u;
     if (t < 17u) s_count_of[t] = 0u;
     __syncthreads();
-    // bitonic sort of the 512 keys, one compare-exchange per lane and step
-    for (uint32_t k = 2u; k <= 512u; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0u; j >>= 1) {
-            const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), p = i | j;      // the t-th pair of this step
-            const bool up = (i & k) == 0u;
-            const unsigned long long a = s_key[i], b = s_key[p];
-            if ((a > b) == up) { s_key[i] = b; s_key[p] = a; }
-            __syncthreads();
+    // sort by rank: a used symbol's place is the number of smaller keys (the keys are distinct: the symbol is their low half); 286 reads of
+    // LDS per lane and two barriers instead of the 45 compare-exchange steps of a bitonic network
+    for (uint32_t q = t; q < 286u; q += 256u) {
+        const unsigned long long key = s_key[q];
+        if (key != ~0ull) {
+            uint32_t r = 0u;
+            for (uint32_t o = 0; o < 286u; ++o) r += s_key[o] < key ? 1u : 0u;
+            s_sorted[r] = key;
+            atomicAdd(&s_n, 1u);
         }
     }
+    __syncthreads();
     if (t == 0) {
-        uint32_t n = 0u;
-        { uint32_t lo = 0u, hi = 286u; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_key[mid] != ~0ull) lo = mid + 1u; else hi = mid; } n = lo; }
-        s_n = n;
+        const uint32_t n = s_n;
         // Huffman's algorithm on sorted leaves with two queues (leaves by count, internal nodes in creation order).  The heads of both
         // queues live in registers and the next head is fetched while the current one is used: the merge never waits on LDS twice in a row.
         if (n >= 2u) {
             const uint32_t kInf = 0xFFFFFFFFu;
             uint32_t li = 0u, ni = 0u;
-            uint32_t leaf_w = (uint32_t)(s_key[0] >> 16), leaf_next = n > 1u ? (uint32_t)(s_key[1] >> 16) : kInf;
+            uint32_t leaf_w = (uint32_t)(s_sorted[0] >> 16), leaf_next = n > 1u ? (uint32_t)(s_sorted[1] >> 16) : kInf;
             uint32_t node_w = kInf, node_next = kInf;          // weights of nodes ni, ni + 1 (kInf: not made yet)
             for (uint32_t k = 0; k + 1u < n; ++k) {
                 uint32_t w = 0u;
@@ -602,7 +604,7 @@ __global__ void __launch_bounds__(256) png_table_kernel(PngBatch B) {
                         s_parent_leaf[li] = (uint16_t)k;
                         ++li;
                         leaf_w = leaf_next;
-                        leaf_next = li + 1u < n ? (uint32_t)(s_key[li + 1u] >> 16) : kInf;
+                        leaf_next = li + 1u < n ? (uint32_t)(s_sorted[li + 1u] >> 16) : kInf;
                     } else {
                         w += node_w;
                         s_parent_node[ni] = (uint16_t)k;
@@ -657,7 +659,7 @@ __global__ void __launch_bounds__(256) png_table_kernel(PngBatch B) {
     for (uint32_t j = t; j < n; j += 256u) {
         uint32_t before = 0u, d = 15u;
         for (; d >= 1u; --d) { if (j < before + s_count_of[d]) break; before += s_count_of[d]; }
-        s_len[(uint32_t)(s_key[j] & 0xFFFFull)] = (uint8_t)d;
+        s_len[(uint32_t)(s_sorted[j] & 0xFFFFull)] = (uint8_t)d;
     }
     __syncthreads();
     // canonical codes (RFC 1951 3.2.2): a symbol's code is its length's first code plus the number of smaller symbols of that length
