@@ -812,6 +812,13 @@ def main():
             rf["training_render_iteration_ms"] = tr.get("ms_per_iter")
             rf["training_render_iteration_reference_structure_ms"] = tr.get("reference_structure_ms_per_iter")
             line["config"]["unchanged_render_frames_per_s"] = ur.get("value")
+            # ... and the two whole functions of the unchanged process beside the op-level headline (C2-sized, to a tmpfs): the frame
+            # loop with its four files per frame, and blend_frames with its ~11 layers per frame
+            lp, bl = also.get("c5_loop") or {}, also.get("c5_blend_frames") or {}
+            line["config"]["frame_loop_c2_frames_per_s"] = lp.get("value")
+            line["config"]["frame_loop_c2_reference_shaped_frames_per_s"] = (lp.get("reference_shaped_loop") or {}).get("frames_per_s")
+            line["config"]["blend_frames_frames_per_s"] = bl.get("value")
+            line["config"]["blend_frames_reference_shaped_frames_per_s"] = (bl.get("reference_shaped") or {}).get("frames_per_s")
         if args.frames_digest and last_frames[0] is not None:
             import hashlib
             torch.cuda.synchronize()

@@ -502,11 +502,25 @@ def test_gpu_melting_loop_files_equal_the_reference_shaped_loop(installed_on_the
 
 @pytest.mark.gpu
 def test_gpu_loop_with_one_stream_and_with_many_gives_the_same_files(tmp_path, monkeypatch):
-    ours, theirs, _ = _gpu_scenes(str(tmp_path), n_frames=9)
+    """A soak of the frames-in-flight machinery: 96 frames, objects moving in most of them, rendered one blocking frame at a time and
+    with seven frames in flight through eight writer slots -- every file of every frame identical (a frame's scene slot, result tensors,
+    staging slot and pinned buffer are all reused many times over)."""
+    n = 96
+    ours, theirs, _ = _gpu_scenes(str(tmp_path), n_frames=n, wh=(128, 72), P_base=8000, P_obj=1500)
+    info = {"chair": {}, "ball": {}}
+    for i in range(n):
+        key = "{0:03d}".format(i + 1)
+        if i % 5 != 3:
+            info["chair"][key] = {"pos": [0.3 + 0.01 * i, 0.2, -0.1], "rot": rot((0, 0, 1), 7 * i).tolist(), "scale": 1.0 + 0.01 * i}
+        if i % 3 == 1:
+            info["ball"][key] = {"pos": [-0.4, 0.005 * i, 0.2], "rot": rot((1, 2, 3), 11 * i).tolist(), "scale": 0.7}
     for s in (ours, theirs):
-        s.rb_transform_info = rigid_body_info()
+        s.rb_transform_info = info
     monkeypatch.setattr(frame_loop, "DEFAULT_STREAMS", 1)
     frame_loop.render_from_3DGS(ours)
-    monkeypatch.setattr(frame_loop, "DEFAULT_STREAMS", 5)
+    monkeypatch.setattr(frame_loop, "DEFAULT_STREAMS", 7)
     frame_loop.render_from_3DGS(theirs)
-    assert_same_frame_files(ours.traj_results_dir, theirs.traj_results_dir, 9)
+    assert_same_frame_files(ours.traj_results_dir, theirs.traj_results_dir, n)
+    # ... and the raw bytes of the files, not only what they decode to: the encoder is a pure function of the frame
+    for rel in ("images/00041.png", "depth/00041.png", "normal/00041.png", "depth/00041.npy"):
+        assert open(os.path.join(ours.traj_results_dir, rel), "rb").read() == open(os.path.join(theirs.traj_results_dir, rel), "rb").read(), rel
