@@ -131,13 +131,26 @@ def render_frames(views: Sequence, names: Sequence[str], model_for_frame: Callab
 
         # (One host thread on purpose.  Handing the file kernels of a frame to a second thread was tried: its Python parts take the
         # interpreter lock from this one for milliseconds at a time -- profiles/r06_loop_filer_thread_ab.txt.)
+        split = True       # render() in two halves; a model / pipeline it cannot split gets one blocking render() per frame instead
         for k, i in enumerate(it):
             while len(q) == S:
                 finish_oldest()
             st = side[k % S]
             with torch.cuda.stream(st):
                 t0 = clock() if stats is not None else 0.0
-                q.append((st, names[i], _render_begin(views[i], model_for_frame(i, k % S), pipe, bg)))
+                model = model_for_frame(i, k % S)
+                pending = None
+                if split:
+                    try:
+                        pending = _render_begin(views[i], model, pipe, bg)
+                    except RuntimeError as e:
+                        if "render_begin needs" not in str(e):
+                            raise
+                        split = False          # (same kernels, the same library: only the frames no longer overlap)
+                if pending is not None:
+                    q.append((st, names[i], pending))
+                else:
+                    writer.submit(names[i], _render(views[i], model, pipe, bg))
                 if stats is not None:
                     stats["begin_s"] += clock() - t0
         while q:
