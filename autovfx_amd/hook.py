@@ -19,7 +19,9 @@ AutoVFX reaches the rasterizer through two imports (paths under the reference tr
 3. a module named ``...scene_representation`` gets ``SceneRepresentation.render_from_3DGS`` (the frame loop, ``:337-447``) replaced
    by ``autovfx_amd.frame_loop.render_from_3DGS``: same arguments and files; inserted objects are loaded once instead of once per
    frame, several frames are in flight, the four files of a frame are built on the GPU;
-4. every module named ``...gaussian_renderer`` -- already imported or imported later (a ``sys.meta_path`` hook) -- gets its
+4. a module named ``...sugar_model`` gets ``SuGaR.render_image_gaussian_rasterizer`` (two rasterizer calls over the same geometry) run with
+   the binding's geometry reuse switched on for its duration: the second call costs one blend launch, same bits;
+5. every module named ``...gaussian_renderer`` -- already imported or imported later (a ``sys.meta_path`` hook) -- gets its
    ``render`` replaced by ``autovfx_amd.renderer.render`` (same signature, same result dictionary; the original stays
    reachable as ``<module>.reference_render``), and every already-imported module that holds the original function under
    any name (``from ... import render [as gs_render]``) is rebound too.
@@ -45,6 +47,7 @@ _REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _TARGET_LEAF = "gaussian_renderer"
 _BLEND_LEAF = "blend_all"                # blender/blend_all.py: its blend_frames() is called at scene_representation.py:232
 _SCENE_LEAF = "scene_representation"     # scene_representation.py: SceneRepresentation.render_from_3DGS is the frame loop (:337-447)
+_SUGAR_LEAF = "sugar_model"              # sugar/sugar_scene/sugar_model.py: SuGaR.render_image_gaussian_rasterizer calls the rasterizer twice (:2141,2174)
 _installed: Optional["_RendererHook"] = None
 patched_modules: List[str] = []          # names of the modules whose ``render`` was replaced (introspection / tests)
 _strict = True                           # install(strict=...): may a failure to load the render path break the importing process?
@@ -52,7 +55,7 @@ _gave_up = False                         # lenient mode: the render path could n
 
 
 def _is_target(fullname: str) -> bool:
-    return any(fullname == leaf or fullname.endswith("." + leaf) for leaf in (_TARGET_LEAF, _BLEND_LEAF, _SCENE_LEAF))
+    return any(fullname == leaf or fullname.endswith("." + leaf) for leaf in (_TARGET_LEAF, _BLEND_LEAF, _SCENE_LEAF, _SUGAR_LEAF))
 
 
 def _is_blend_module(name: str) -> bool:
@@ -92,6 +95,42 @@ def _patch_scene_module(module: types.ModuleType) -> None:
         patched_modules.append(module.__name__)
 
 
+def _is_sugar_module(name: str) -> bool:
+    return name == _SUGAR_LEAF or name.endswith("." + _SUGAR_LEAF)
+
+
+def _patch_sugar_module(module: types.ModuleType) -> None:
+    """``SuGaR.render_image_gaussian_rasterizer`` (sugar/sugar_scene/sugar_model.py:1960-2230, BASELINE configs[3]) rasterizes the same
+    geometry twice -- colours at :2141, the per-Gaussian normals as colours at :2174 -- with nothing in between that writes to the
+    positions, scales, rotations or the camera.  The method itself stays the reference's; it is merely run with the binding's
+    geometry reuse switched ON for its duration (``diff_gaussian_rasterization._C.set_geometry_cache``: off by default because a
+    write that bypasses PyTorch's version counters between two calls would be invisible to it -- here the code between the two calls
+    is known): the second call then blends its colours over the first call's lists, one launch instead of a whole pipeline, same
+    bits.  The original stays reachable as ``SuGaR.reference_render_image_gaussian_rasterizer``."""
+    cls = module.__dict__.get("SuGaR")
+    original = getattr(cls, "__dict__", {}).get("render_image_gaussian_rasterizer") if isinstance(cls, type) else None
+    if original is None or getattr(original, "_autovfx_amd_wrapped", False):
+        return
+
+    import functools
+
+    @functools.wraps(original)
+    def render_image_gaussian_rasterizer(self, *args, **kwargs):
+        from diff_gaussian_rasterization import _C
+        before = _C.geometry_cache_enabled()
+        _C.set_geometry_cache(True)
+        try:
+            return original(self, *args, **kwargs)
+        finally:
+            _C.set_geometry_cache(before)
+
+    render_image_gaussian_rasterizer._autovfx_amd_wrapped = True
+    cls.reference_render_image_gaussian_rasterizer = original
+    cls.render_image_gaussian_rasterizer = render_image_gaussian_rasterizer
+    if module.__name__ not in patched_modules:
+        patched_modules.append(module.__name__)
+
+
 def _our_render() -> Callable:
     from .renderer import render   # imports torch and loads libgsr_hip.so: only when a renderer module really appears
     return render
@@ -106,6 +145,9 @@ def _patch_renderer_module(module: types.ModuleType) -> None:
     global _gave_up
     if _is_scene_module(module.__name__):
         _patch_scene_module(module)
+        return
+    if _is_sugar_module(module.__name__):
+        _patch_sugar_module(module)
         return
     if _is_blend_module(module.__name__):
         # the compositing step of the edit loop: ``blend_all.blend_frames(results_dir, cfg_path)`` (scene_representation.py:232) becomes
@@ -234,4 +276,8 @@ def uninstall() -> None:
         if isinstance(cls, type) and "reference_render_from_3DGS" in cls.__dict__:
             cls.render_from_3DGS = cls.reference_render_from_3DGS
             del cls.reference_render_from_3DGS
+        cls = getattr(module, "SuGaR", None) if module is not None else None
+        if isinstance(cls, type) and "reference_render_image_gaussian_rasterizer" in cls.__dict__:
+            cls.render_image_gaussian_rasterizer = cls.reference_render_image_gaussian_rasterizer
+            del cls.reference_render_image_gaussian_rasterizer
     patched_modules.clear()

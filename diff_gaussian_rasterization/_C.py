@@ -131,6 +131,10 @@ _GEOMETRY_CACHE = _GEOMETRY_CACHE_DEFAULT
 cache_stats = {"hits": 0, "misses": 0}
 
 
+def geometry_cache_enabled() -> bool:
+    return bool(_GEOMETRY_CACHE)
+
+
 def set_geometry_cache(enabled) -> None:
     """True / False; None restores the process default (``GSR_GEOMETRY_CACHE``, off when unset)."""
     global _GEOMETRY_CACHE

@@ -524,3 +524,43 @@ def test_gpu_loop_with_one_stream_and_with_many_gives_the_same_files(tmp_path, m
     # ... and the raw bytes of the files, not only what they decode to: the encoder is a pure function of the frame
     for rel in ("images/00041.png", "depth/00041.png", "normal/00041.png", "depth/00041.npy"):
         assert open(os.path.join(ours.traj_results_dir, rel), "rb").read() == open(os.path.join(theirs.traj_results_dir, rel), "rb").read(), rel
+
+
+@needs_reference
+def test_install_runs_sugars_two_pass_render_with_geometry_reuse(monkeypatch):
+    """BASELINE configs[3]: the REFERENCE's ``SuGaR.render_image_gaussian_rasterizer`` (sugar_model.py:1960-2230), imported unchanged, is
+    run by ``install()`` with the binding's geometry reuse on for its duration (the second rasterizer call of the method blends over the
+    first call's lists) and the switch goes back to what it was, also when the method raises; ``uninstall()`` restores the method."""
+    import autovfx_amd
+    from diff_gaussian_rasterization import _C
+    with reference_env.reference_tree(cpu=True):
+        autovfx_amd.install()
+        try:
+            import sugar.sugar_scene.sugar_model as sm
+            cls = sm.SuGaR
+            assert getattr(cls.render_image_gaussian_rasterizer, "_autovfx_amd_wrapped", False)
+            assert cls.reference_render_image_gaussian_rasterizer.__module__.endswith("sugar_model")
+            seen = []
+            monkeypatch.setattr(cls, "reference_render_image_gaussian_rasterizer", None, raising=False)   # (only the wrapper is exercised here)
+            import functools
+            wrapped = cls.render_image_gaussian_rasterizer
+            inner = wrapped.__wrapped__
+            assert inner.__name__ == "render_image_gaussian_rasterizer" and inner.__module__.endswith("sugar_model")
+            # drive the wrapper with a stand-in for the reference's body: the switch is on inside, restored outside
+            cell = [c for c in wrapped.__closure__ if callable(c.cell_contents) and getattr(c.cell_contents, "__name__", "") == inner.__name__][0]
+            def body(self, *a, **k):
+                seen.append(_C.geometry_cache_enabled())
+                if k.get("boom"):
+                    raise ValueError("boom")
+                return "image"
+            cell.cell_contents = body
+            _C.set_geometry_cache(False)
+            assert wrapped(object()) == "image" and seen == [True] and _C.geometry_cache_enabled() is False
+            with pytest.raises(ValueError):
+                wrapped(object(), boom=True)
+            assert seen == [True, True] and _C.geometry_cache_enabled() is False
+            cell.cell_contents = inner
+        finally:
+            _C.set_geometry_cache(None)
+            autovfx_amd.uninstall()
+        assert not hasattr(sm.SuGaR.render_image_gaussian_rasterizer, "_autovfx_amd_wrapped")
