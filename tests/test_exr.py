@@ -18,7 +18,7 @@ def _hand_made(W=3, H=2, compressed=False):
     z = (np.arange(W * H, dtype=np.float32).reshape(H, W) * 1.5 + 1000.0).astype("<f4")
     attr = lambda n, t, d: n + b"\0" + t + b"\0" + struct.pack("<i", len(d)) + d
     chl = b"G\0" + struct.pack("<iB3xii", 1, 0, 1, 1) + b"Z\0" + struct.pack("<iB3xii", 2, 0, 1, 1) + b"\0"
-    head = struct.pack("<ii", 20000630, 2) + attr(b"channels", b"chlist", chl) + attr(b"compression", b"compression", bytes([2 if compressed else 0])) \
+    head = struct.pack("<ii", 20000630, 2) + attr(b"channels", b"chlist", chl) + attr(b"compression", b"compression", bytes([1 if compressed == "rle" else 2 if compressed else 0])) \
         + attr(b"dataWindow", b"box2i", struct.pack("<4i", 10, 20, 10 + W - 1, 20 + H - 1)) \
         + attr(b"displayWindow", b"box2i", struct.pack("<4i", 0, 0, 63, 63)) + attr(b"lineOrder", b"lineOrder", b"\0") \
         + attr(b"pixelAspectRatio", b"float", struct.pack("<f", 1.0)) + attr(b"screenWindowCenter", b"v2f", struct.pack("<2f", 0, 0)) \
@@ -26,10 +26,27 @@ def _hand_made(W=3, H=2, compressed=False):
     blocks = []
     for y in range(H):
         raw = g[y].tobytes() + z[y].tobytes()
-        if compressed:      # ZIPS: even bytes, then odd bytes; delta predictor with bias 128; zlib
+        if compressed:      # ZIPS / RLE: even bytes, then odd bytes; delta predictor with bias 128; then zlib, or run lengths
             t = raw[0::2] + raw[1::2]
             d = bytes([t[0]] + [(t[i] - t[i - 1] + 128) & 255 for i in range(1, len(t))])
-            packed = zlib.compress(d)
+            if compressed == "rle":     # a run of n + 1 equal bytes: (n, byte); n literal bytes: (-n as a signed byte, the bytes); runs <= 128
+                packed, i = bytearray(), 0
+                while i < len(d):
+                    run = 1
+                    while i + run < len(d) and d[i + run] == d[i] and run < 128:
+                        run += 1
+                    if run >= 3:
+                        packed += bytes([run - 1, d[i]])
+                        i += run
+                    else:
+                        j = i
+                        while j < len(d) and j - i < 127 and not (j + 2 < len(d) and d[j] == d[j + 1] == d[j + 2]):
+                            j += 1
+                        packed += bytes([(256 - (j - i)) & 255]) + d[i:j]
+                        i = j
+                packed = bytes(packed)
+            else:
+                packed = zlib.compress(d)
             raw = packed if len(packed) < len(raw) else raw
         blocks.append(struct.pack("<ii", 20 + y, len(raw)) + raw)
     at, table = len(head) + 8 * H, b""
@@ -39,7 +56,7 @@ def _hand_made(W=3, H=2, compressed=False):
     return head + table + b"".join(blocks), g, z
 
 
-@pytest.mark.parametrize("compressed", [False, True])
+@pytest.mark.parametrize("compressed", [False, True, "rle"])
 def test_reads_a_file_assembled_from_the_specification(compressed):
     data, g, z = _hand_made(compressed=compressed)
     ch = exr.read_exr(data)

@@ -363,3 +363,34 @@ def test_gpu_frame_writer_in_both_png_modes(tmp_path, deflate):
         assert (b / "depth" / f"{i:05d}.npy").read_bytes() == (a / "depth" / f"{i:05d}.npy").read_bytes()
     raw = 10 * 320 * 180 * 10
     assert (total < raw) if deflate else (total > raw)
+
+
+@pytest.mark.gpu
+def test_gpu_deflate_png_length_limits_a_skewed_code():
+    """Token counts in powers of two make Huffman's tree a chain (also with the filter-type and end-of-block symbols mixed in): 18 literals
+    -> code lengths up to 18 bits, which deflate does not allow.  The table kernel must limit the lengths to 15 and still hand zlib a COMPLETE code (an over- or under-subscribed one is rejected
+    at the block header).  The image is built backwards from the residuals it should have (Paeth un-filtering, as a reader does)."""
+    counts = [1 << k for k in range(18)]                                           # 1, 2, 4 ... 131 072: each symbol as frequent as all rarer ones together
+    h, w, c = 63, 1387, 3                                                          # 63 x 1387 x 3 = 262 143 = their sum, exactly
+    assert sum(counts) == h * w * c
+    resid = np.concatenate([np.full(n, 3 + 7 * k, np.uint8) for k, n in enumerate(counts)])   # 18 distinct residual values
+    np.random.default_rng(5).shuffle(resid)
+    resid = resid.reshape(h, w * c)
+    img = np.zeros((h, w, c), np.int32)
+    for y in range(h):
+        line = resid[y].reshape(w, c).astype(np.int32)
+        up = img[y - 1] if y else np.zeros((w, c), np.int32)
+        left, ul = np.zeros(c, np.int32), np.zeros(c, np.int32)
+        for x in range(w):
+            b = up[x]
+            p = left + b - ul
+            pa, pb, pc = np.abs(p - left), np.abs(p - b), np.abs(p - ul)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, b, ul))
+            left = (line[x] + pred) & 255
+            img[y, x] = left
+            ul = b
+    img = img.astype(np.uint8)
+    np.testing.assert_array_equal(_paeth_stream(img)[:, 1:], resid)                 # the residuals are what was asked for
+    data = frame_io.encode_png_gpu_deflate(torch.from_numpy(img).cuda()).cpu().numpy().tobytes()
+    _check_png_file(data, img, paeth=True)
+    assert len(data) < img.size                                                     # (about two bits per byte)
