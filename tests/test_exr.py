@@ -63,6 +63,12 @@ def test_reads_a_file_assembled_from_the_specification(compressed):
     assert set(ch) == {"G", "Z"} and ch["G"].dtype == np.float16 and ch["Z"].dtype == np.float32
     np.testing.assert_array_equal(ch["G"], g)
     np.testing.assert_array_equal(ch["Z"], z)
+    for name, want in (("G", g), ("Z", z)):                           # one channel alone (mixed pixel types: the stretches differ in width)
+        one = exr.read_exr(data, only=name)
+        assert list(one) == [name]
+        np.testing.assert_array_equal(one[name], want)
+    with pytest.raises(KeyError, match="no channel"):
+        exr.read_exr(data, only="B")
     wide, g, z = _hand_made(W=300, H=5, compressed=compressed)      # (long enough for the zlib stream to be shorter than the raw block)
     ch = exr.read_exr(wide)
     np.testing.assert_array_equal(ch["G"], g)
@@ -85,6 +91,7 @@ def test_round_trip_in_every_mode(tmp_path, compression, half, shape, decreasing
     for k, v in channels.items():
         want = v.astype(np.float16) if half else v
         np.testing.assert_array_equal(got[k], want, err_msg=k)
+        np.testing.assert_array_equal(exr.read_exr(p, only=k)[k], want, err_msg=f"{k} alone")    # (the partial undo of a block)
     d = exr.load_depth_exr(p)                                       # cv2.imread(...)[:, :, 0] is the B channel
     assert d.dtype == np.float32 and d.shape == shape
     np.testing.assert_array_equal(d, (depth + 1).astype(np.float16).astype(np.float32) if half else depth + 1)
