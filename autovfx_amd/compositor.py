@@ -38,9 +38,7 @@ def _percentile_linear(values: torch.Tensor, q: float) -> torch.Tensor:
 
 def smoke_depth_fill(s_f_c: torch.Tensor, s_f_d: torch.Tensor) -> torch.Tensor:
     mask = (s_f_c[..., 3].to(torch.float32) / 255.0) > 0.0
-    out = s_f_d.clone()
-    out[mask] = _percentile_linear(s_f_d, 0.001)
-    return out
+    return torch.where(mask, _percentile_linear(s_f_d, 0.001), s_f_d)    # (no boolean-mask assignment: that one waits for the GPU)
 
 
 def resize_rgba8(image: torch.Tensor, size_wh, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -151,8 +149,8 @@ _LAYERS_DEPTH = ("depth_obj", "depth_shadow", "depth_obj_3dgs", "depth_smoke_fir
 
 
 def _load_frame_layers(cache, bg_path, i):
-    """Everything ``blend_frames`` reads for frame ``i`` (blend_all.py:185-205), decoded on the host: a dict of numpy arrays / None.
-    Runs on a pool thread: PIL's and zlib's decoders release the interpreter lock."""
+    """Everything ``blend_frames`` reads for frame ``i`` (blend_all.py:185-205), decoded on the host with the reference's libraries: a
+    dict of numpy arrays / None (the reference-shaped loader: tests and bench.py compare against it)."""
     import os
     out = {"bg": load_rgb(bg_path)}
     for kind in _LAYERS_RGB:
@@ -160,6 +158,92 @@ def _load_frame_layers(cache, bg_path, i):
     for kind in _LAYERS_DEPTH:
         out[kind] = load_depth_exr(os.path.join(cache, kind, "{:0>3d}".format(i + 1), "Image{:0>4d}.exr".format(i + 1)))
     return out
+
+
+_worker_local = None
+
+
+def _thread_stream(dev):
+    """One side stream per pool thread and device: whatever the thread queues for its frame is ordered among itself and runs beside
+    the other threads' frames."""
+    import threading
+    global _worker_local
+    if _worker_local is None:
+        _worker_local = threading.local()
+    streams = _worker_local.__dict__.setdefault("streams", {})
+    stream = streams.get(dev)
+    if stream is None:
+        stream = streams[dev] = torch.cuda.Stream(device=dev)
+    return stream
+
+
+def _load_frame_layers_to_gpu(cache, bg_path, i, dev, staging):
+    """The same layers as GPU tensors (``uint8[H, W, 4]``; depth in the file's precision), queued on the CURRENT stream: the host
+    inflates the files' zlib streams into ``staging`` (page-locked) and copies from there, kernels undo the PNG filters / the EXR
+    predictor (``autovfx_amd.layer_io``).  ``staging`` may be reset once the stream has been synchronised."""
+    import os
+    from . import layer_io
+    out = {"bg": layer_io.load_rgba(bg_path, dev, staging)}
+    for kind in _LAYERS_RGB:
+        out[kind] = layer_io.load_rgba(os.path.join(cache, kind, "{:0>3d}.png".format(i + 1)), dev, staging)
+    for kind in _LAYERS_DEPTH:
+        out[kind] = layer_io.load_depth(os.path.join(cache, kind, "{:0>3d}".format(i + 1), "Image{:0>4d}.exr".format(i + 1)), dev, staging)
+    return out
+
+
+def _blend_one_frame(cache, bg_path, i, dev, out_path, want_frame, stats=None):
+    """Frame ``i`` of ``blend_frames`` from its files to its file (blend_all.py:185-337), on the calling pool thread and its stream."""
+    import time
+    from . import frame_io
+    t0 = time.perf_counter()
+    staging = _worker_local.__dict__.get("staging") if _worker_local is not None else None
+    if staging is None:
+        from . import layer_io
+        _thread_stream(dev)
+        staging = _worker_local.__dict__["staging"] = layer_io.Staging()
+    staging.reset()                                 # (the previous frame of this thread ended with a wait for its stream)
+    with torch.cuda.stream(_thread_stream(dev)):
+        L = _load_frame_layers_to_gpu(cache, bg_path, i, dev, staging)
+        t1 = time.perf_counter()
+        bg_c = L["bg"]
+        o_c, o_d = L["rgb_obj"], L["depth_obj"]
+        s_c, s_d = L["rgb_shadow"], L["depth_shadow"]
+        o_s_c = L["rgb_all"]
+        o_gs_c, o_gs_d = L["rgb_obj_3dgs"], L["depth_obj_3dgs"]
+        s_f_c, s_f_d = L["rgb_smoke_fire"], L["depth_smoke_fire"]
+        s_f_c_pre = L["rgb_smoke_fire_pre"]
+        if o_gs_c is None:
+            o_gs_d = None
+        if s_f_c is not None:
+            s_f_d = smoke_depth_fill(s_f_c, s_f_d.to(torch.float32))       # on the full-size layers, before the resizes (:207-215)
+        else:
+            s_f_d = s_f_c_pre = None
+        f32 = lambda t: None if t is None else t.to(torch.float32)
+        frame = composite_frame(bg_c, o_c, f32(o_d), s_c, f32(s_d), o_s_c, o_gs_c, f32(o_gs_d), s_f_c, f32(s_f_d), s_f_c_pre)
+        png = frame_io.encode_png_gpu_deflate(frame) if frame_io.deflate_default() else frame_io.encode_png_gpu(frame)
+        t2 = time.perf_counter()
+        data = png.cpu().numpy()                   # (waits for this thread's stream: the frame is finished, the staging memory free)
+        host_frame = frame.cpu().numpy() if want_frame else None
+    t3 = time.perf_counter()
+    with open(out_path, "wb") as f:
+        f.write(data)
+    if stats is not None:
+        t4 = time.perf_counter()
+        stats.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3))
+    return host_frame
+
+
+LAST_BLEND_STATS: dict = {}     # with AUTOVFX_AMD_BLEND_STATS=1: thread-seconds of the last blend_frames call by stage, summed over the pool
+
+
+def decode_threads() -> int:
+    """Threads of ``blend_frames``' pool: ``AUTOVFX_AMD_BLEND_DECODERS``, or the cores this process may run on, at most 16 (past that
+    the interpreter lock around the threads' Python stretches eats the gain)."""
+    import os
+    n = int(os.environ.get("AUTOVFX_AMD_BLEND_DECODERS", "0"))
+    if n <= 0:
+        n = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)
+    return max(1, n)
 
 
 def blend_frames(blend_results_dir, input_config_path=None, device=None, write_video=True):
@@ -187,7 +271,6 @@ def blend_frames(blend_results_dir, input_config_path=None, device=None, write_v
     out_img_dir = os.path.join(blend_results_dir, "frames")
     os.makedirs(out_img_dir, exist_ok=True)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    up = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     video = None
     if write_video:       # the frames are kept on the host only if the video can be written at all (400 frames of 960x540 are 0.8 GB)
         try:
@@ -196,48 +279,29 @@ def blend_frames(blend_results_dir, input_config_path=None, device=None, write_v
             video = (imageio, skimage.transform)
         except ImportError:
             print("[autovfx_amd] blended.mp4 will not be written: imageio / skimage are not installed (the frames go to " + out_img_dir + ")")
-    # Decoding ~11 PNG / EXR layers per frame at Blender's resolution is host work that dwarfs the GPU's 0.13 ms per frame: a pool of
-    # threads decodes frames i + 1 ... i + k while the GPU resizes, composites and encodes frame i; another writes the finished files.
+    # Reading ~11 PNG / EXR layers per frame at Blender's resolution dwarfs the 0.13 ms of resizing, compositing and encoding a frame,
+    # and frames do not depend on each other: each thread of a pool takes whole frames -- inflates and uploads the files, queues the
+    # kernels that undo the image predictors (layer_io), resize, composite and encode on ITS stream, copies the file out and writes
+    # it.  This thread only keeps the order (and the frames for the video, where one is written).
     from concurrent.futures import ThreadPoolExecutor
-    workers = int(os.environ.get("AUTOVFX_AMD_BLEND_DECODERS", "0")) or (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)
-    workers = max(1, min(16, workers))
+    workers = decode_threads()
     ahead = 2 * workers
-
-    def write_file(path, data):
-        with open(path, "wb") as f:
-            f.write(data)
-
-    paths, host_frames, pending, writes = [], [], {}, []
-    with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="blend-decode") as pool, \
-            ThreadPoolExecutor(max_workers=2, thread_name_prefix="blend-write") as wpool:
+    paths = [os.path.join(out_img_dir, "{:0>4d}.png".format(i)) for i in range(n_frame)]
+    host_frames, pending = [], {}
+    stats = [] if os.environ.get("AUTOVFX_AMD_BLEND_STATS") == "1" else None
+    with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="blend-frame") as pool:
         for i in range(n_frame):
             for j in range(i, min(n_frame, i + ahead + 1)):
                 if j not in pending:
-                    pending[j] = pool.submit(_load_frame_layers, cache, bg_rgb[j], j)
-            L = pending.pop(i).result()
-            bg_c = up(L["bg"])
-            o_c, o_d = up(L["rgb_obj"]), up(L["depth_obj"])
-            s_c, s_d = up(L["rgb_shadow"]), up(L["depth_shadow"])
-            o_s_c = up(L["rgb_all"])
-            o_gs_c, o_gs_d = up(L["rgb_obj_3dgs"]), up(L["depth_obj_3dgs"])
-            s_f_c, s_f_d = up(L["rgb_smoke_fire"]), up(L["depth_smoke_fire"])
-            s_f_c_pre = up(L["rgb_smoke_fire_pre"])
-            if o_gs_c is None:
-                o_gs_d = None
-            if s_f_c is not None:
-                s_f_d = smoke_depth_fill(s_f_c, s_f_d.to(torch.float32))       # on the full-size layers, before the resizes (:207-215)
-            else:
-                s_f_d = s_f_c_pre = None
-            f32 = lambda t: None if t is None else t.to(torch.float32)
-            frame = composite_frame(bg_c, o_c, f32(o_d), s_c, f32(s_d), o_s_c, o_gs_c, f32(o_gs_d), s_f_c, f32(s_f_d), s_f_c_pre)
-            data = (frame_io.encode_png_gpu_deflate(frame) if frame_io.deflate_default() else frame_io.encode_png_gpu(frame)).cpu().numpy()
-            path = os.path.join(out_img_dir, "{:0>4d}.png".format(i))
-            writes.append(wpool.submit(write_file, path, data))
-            paths.append(path)
+                    pending[j] = pool.submit(_blend_one_frame, cache, bg_rgb[j], j, dev, paths[j], video is not None, stats)
+            host_frame = pending.pop(i).result()
             if video is not None:
-                host_frames.append(frame.cpu().numpy())
-        for w in writes:
-            w.result()
+                host_frames.append(host_frame)
+    if stats is not None:
+        LAST_BLEND_STATS.clear()
+        LAST_BLEND_STATS.update({"frames": n_frame, "threads": workers, "read_and_upload_s": sum(x[0] for x in stats),
+                                 "queue_kernels_s": sum(x[1] for x in stats), "wait_and_copy_out_s": sum(x[2] for x in stats),
+                                 "write_file_s": sum(x[3] for x in stats)})
     if video is not None and host_frames:   # generate_video_from_frames (:31-54), with the reference's own host libraries
         imageio, transform = video
         h, w = host_frames[0].shape[:2]

@@ -807,6 +807,37 @@ int gsr_png_encode_deflate(const uint8_t* pixels, int width, int height, int cha
     return GSR_OK;
 }
 
+size_t gsr_png_unfilter_scratch(int width, int height) { return gsr::png_unfilter_scratch_bytes(width, height); }
+
+int gsr_png_unfilter(const uint8_t* scanlines, int width, int height, int channels, uint8_t* out_rgba, uint8_t* scratch, void* stream_) {
+    if (gsr::png_unfilter_scratch_bytes(width, height) == 0 || (channels != 3 && channels != 4))
+        return fail(GSR_ERR_INVALID_ARG, "gsr_png_unfilter: %dx%d with %d channels is not supported (8-bit RGB / RGBA, at most 4096 pixels wide)", width, height,
+                    channels);
+    if (!scanlines || !out_rgba || !scratch) return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    if (((reinterpret_cast<uintptr_t>(out_rgba) | reinterpret_cast<uintptr_t>(scratch)) & 15u) != 0)
+        return fail(GSR_ERR_INVALID_ARG, "gsr_png_unfilter: out_rgba and scratch must be 16-byte aligned");
+    GSR_HIP(gsr::launch_png_unfilter(scanlines, width, height, channels, out_rgba, scratch, (hipStream_t)stream_));
+    return GSR_OK;
+}
+
+int gsr_exr_unpack_channel(const uint8_t* blocks, int height, int bytes_per_line, int lines_per_block, int channel_at, int channel_bytes, uint8_t* plane,
+                           void* stream_) {
+    if (height <= 0 || bytes_per_line <= 0 || (bytes_per_line & 1) || lines_per_block <= 0 || channel_at < 0 || channel_bytes <= 0 ||
+        channel_at + channel_bytes > bytes_per_line || (long long)bytes_per_line * lines_per_block > (1ll << 30))
+        return fail(GSR_ERR_INVALID_ARG, "gsr_exr_unpack_channel: bad layout (height %d, %d bytes per line, %d lines per block, channel at %d + %d)", height,
+                    bytes_per_line, lines_per_block, channel_at, channel_bytes);
+    if (!blocks || !plane) return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    GSR_HIP(gsr::launch_exr_unpack_channel(blocks, height, bytes_per_line, lines_per_block, channel_at, channel_bytes, plane, (hipStream_t)stream_));
+    return GSR_OK;
+}
+
+int gsr_upload(void* device_dst, const void* host_src, size_t bytes, void* stream_) {
+    if (bytes == 0) return GSR_OK;
+    if (!device_dst || !host_src) return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    GSR_HIP(hipMemcpyAsync(device_dst, host_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream_));
+    return GSR_OK;
+}
+
 size_t gsr_png_size(int width, int height, int channels) { return gsr::png_file_bytes(width, height, channels); }
 size_t gsr_png_room(int width, int height, int channels) { return gsr::png_room_bytes(width, height, channels); }
 

@@ -364,6 +364,16 @@ hipError_t launch_resize_rgba8_bilinear(const uint8_t* src, int src_w, int src_h
                                         hipStream_t stream);
 hipError_t launch_resize_f32_nearest(const float* src, int src_w, int src_h, float* dst, int dst_w, int dst_h, hipStream_t stream);
 
+// ---- the compositor's input files (gsr_layerio.hip) ----
+// The inflated IDAT stream of an 8-bit RGB / RGBA, non-interlaced PNG (device memory) -> RGBA8 [H,W,4] (alpha 255 for RGB).
+// scratch: png_unfilter_scratch_bytes(W, H) bytes, 16-byte aligned (0: the width is not supported).
+size_t png_unfilter_scratch_bytes(int W, int H);
+hipError_t launch_png_unfilter(const uint8_t* stream_bytes, int W, int H, int C, uint8_t* out_rgba, uint8_t* scratch, hipStream_t stream);
+// The inflated, still predictor-coded scanline blocks of an OpenEXR file one after another (device memory) -> the bytes of the channel
+// that occupies [c_at, c_at + c_bytes) of every line: plane[H][c_bytes].
+hipError_t launch_exr_unpack_channel(const uint8_t* blocks, int H, int bytes_per_line, int lines_per_block, int c_at, int c_bytes, uint8_t* plane,
+                                     hipStream_t stream);
+
 // ---- hand-written radix sort (gsr_radix.hip) ----
 // Stable ascending LSD sort on the low `bits` key bits, 8 per pass (count / scan / scatter kernels, no spinning,
 // nothing to zero-fill).  scratch: radix_scratch_words(n) u32 words of any content.  iota_payload: the payload

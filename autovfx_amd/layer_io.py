@@ -1,0 +1,290 @@
+"""Blender's layers from file to GPU memory: the host side of ``csrc/gsr_layerio.hip``.
+
+``blend_all.blend_frames`` (blender/blend_all.py:185-205) reads, per frame, six RGBA PNGs (``load_rgb``: ``Image.open(path).convert
+("RGBA")``, :56-60) and four OpenEXR depth passes (``load_depth_exr``: ``cv2.imread(...)[:, :, 0]``, :70-75), all at Blender's
+resolution.  Decoding them with Pillow / numpy cost 0.34 s of host time per frame and bound the whole function.  Here the host does
+what only a host can do well -- parse the container, run zlib's inflate over each stream (byte-serial; it releases the interpreter
+lock) -- and uploads the inflated bytes as they are; the image predictors (PNG's five scanline filters, OpenEXR's byte-wise running
+sum and interleave) are undone by kernels (``gsr_png_unfilter``, ``gsr_exr_unpack_channel``).  The results are the arrays the
+reference's loaders return, bit for bit; a file the kernels do not cover (16-bit, palette, grey, interlaced or very wide PNGs; PIZ /
+tiled / stored-block EXRs) is decoded by Pillow / ``autovfx_amd.exr`` as before.
+
+Everything here runs on the CALLER's current stream.  The host side of a file is: parse, ``inflate`` straight into page-locked memory
+(zlib's ``uncompress`` through ctypes: no intermediate ``bytes``, no interpreter lock), one asynchronous copy from there.  Inflating
+into ordinary memory and copying from it was the serial resource of ``blend_frames`` at 8 GB/s: pageable copies go through the
+runtime's single staging path.  A ``Staging`` arena belongs to one thread and one stream; ``reset()`` it once that stream has been
+synchronised.
+"""
+import ctypes
+import ctypes.util
+import os
+import struct
+import zlib
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib, exr
+
+_PNG_SIGNATURE = b"\x89PNG\r\n\x1a\n"
+
+try:
+    _libz = ctypes.CDLL(ctypes.util.find_library("z") or "libz.so.1")
+    _libz.uncompress.restype = ctypes.c_int
+    _libz.uncompress.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulong), ctypes.c_char_p, ctypes.c_ulong]
+except OSError:          # no shared zlib to bind: Python's module inflates, one more copy
+    _libz = None
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {_lib.last_error()}")
+
+
+class Staging:
+    """Page-locked host memory handed out front to back; ``reset()`` starts over (after the stream that copies from it has drained).
+    Grows by allocating a new block: earlier hand-outs stay valid until ``reset``."""
+
+    def __init__(self, nbytes: int = 0):
+        self._blocks, self._at, self._room = [], 0, 0
+        if nbytes:
+            self._grow(nbytes)
+
+    def _grow(self, nbytes):
+        self._blocks.append(torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, pin_memory=torch.cuda.is_available()))
+        self._at, self._room = 0, self._blocks[-1].numel()
+
+    def take(self, nbytes: int) -> torch.Tensor:
+        nbytes = int(nbytes)
+        if self._at + nbytes > self._room:
+            self._grow(max(nbytes, 2 * self._room))
+        out = self._blocks[-1][self._at:self._at + nbytes]
+        self._at += (nbytes + 63) & ~63
+        return out
+
+    def reset(self):
+        if len(self._blocks) > 1:          # one block of the total size from now on
+            total = sum(b.numel() for b in self._blocks)
+            self._blocks = []
+            self._grow(total)
+        self._at = 0
+
+
+def inflate_into(dst: torch.Tensor, data: bytes) -> bool:
+    """The zlib stream ``data`` inflated into the host tensor ``dst`` (uint8); False unless it fills it exactly."""
+    n = dst.numel()
+    if _libz is not None:
+        got = ctypes.c_ulong(n)
+        rc = _libz.uncompress(ctypes.c_void_p(dst.data_ptr()), ctypes.byref(got), data, len(data))
+        return rc == 0 and got.value == n
+    try:
+        raw = zlib.decompress(data)
+    except zlib.error:
+        return False
+    if len(raw) != n:
+        return False
+    ctypes.memmove(ctypes.c_void_p(dst.data_ptr()), raw, n)
+    return True
+
+
+def _upload(host: torch.Tensor, device) -> torch.Tensor:
+    dst = torch.empty(host.numel(), dtype=torch.uint8, device=device)
+    _check(_lib.lib.gsr_upload(ctypes.c_void_p(dst.data_ptr()), ctypes.cast(ctypes.c_void_p(host.data_ptr()), ctypes.c_char_p), host.numel(),
+                               _stream_ptr(device)), "gsr_upload")
+    return dst
+
+
+def png_chunks(buf: bytes):
+    """``(width, height, channels, the IDAT chunks' zlib stream)`` of a PNG file the unfilter kernel covers -- 8-bit RGB or RGBA, not
+    interlaced, no ``tRNS`` chunk, at most 4096 pixels wide -- or None (another flavour, or a file a real decoder should complain about)."""
+    if buf[:8] != _PNG_SIGNATURE:
+        return None
+    at, ihdr, idat = 8, None, []
+    while at + 12 <= len(buf):
+        n, = struct.unpack_from(">I", buf, at)
+        kind = buf[at + 4:at + 8]
+        if at + 12 + n > len(buf):
+            return None
+        data = buf[at + 8:at + 8 + n]
+        if kind in (b"IHDR", b"IDAT"):
+            crc, = struct.unpack_from(">I", buf, at + 8 + n)
+            if zlib.crc32(data, zlib.crc32(kind)) != crc:
+                return None
+        if kind == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", data)
+        elif kind == b"IDAT":
+            idat.append(data)
+        elif kind in (b"tRNS", b"PLTE"):
+            return None
+        elif kind == b"IEND":
+            break
+        at += 12 + n
+    if ihdr is None or not idat:
+        return None
+    w, h, depth, colour, compression, filtering, interlace = ihdr
+    if depth != 8 or colour not in (2, 6) or compression or filtering or interlace or w < 1 or h < 1:
+        return None
+    if _lib.lib.gsr_png_unfilter_scratch(w, h) == 0:
+        return None
+    return w, h, (3 if colour == 2 else 4), (idat[0] if len(idat) == 1 else b"".join(idat))
+
+
+def png_scanlines(buf: bytes):
+    """``(width, height, channels, inflated scanline stream)`` of a covered PNG file, or None: ``png_chunks`` plus what ``load_rgba`` checks
+    after inflating (the stream's length, the filter-type bytes)."""
+    parsed = png_chunks(buf)
+    if parsed is None:
+        return None
+    w, h, c, stream = parsed
+    try:
+        raw = zlib.decompress(stream)
+    except zlib.error:
+        return None
+    stride = 1 + w * c
+    if len(raw) != h * stride or max(raw[0::stride]) > 4:
+        return None
+    return w, h, c, raw
+
+
+def _unfilter(host: torch.Tensor, w: int, h: int, c: int, device) -> torch.Tensor:
+    lib = _lib.lib
+    staged = _upload(host, device)
+    out = torch.empty((h, w, 4), dtype=torch.uint8, device=device)
+    scratch = torch.empty(lib.gsr_png_unfilter_scratch(w, h), dtype=torch.uint8, device=device)
+    with torch.cuda.device(device):
+        _check(lib.gsr_png_unfilter(staged.data_ptr(), w, h, c, out.data_ptr(), scratch.data_ptr(), _stream_ptr(device)), "gsr_png_unfilter")
+    return out
+
+
+def unfilter_png(raw: bytes, w: int, h: int, c: int, device) -> torch.Tensor:
+    """The inflated scanline stream of an 8-bit RGB / RGBA PNG -> ``uint8[h, w, 4]`` on ``device`` (alpha 255 for RGB).  Blocking."""
+    host = Staging(len(raw)).take(len(raw))
+    ctypes.memmove(ctypes.c_void_p(host.data_ptr()), raw, len(raw))
+    out = _unfilter(host, w, h, c, device)
+    torch.cuda.current_stream(device).synchronize()
+    return out
+
+
+def load_rgba(path: str, device, staging: Optional[Staging] = None) -> Optional[torch.Tensor]:
+    """``blend_all.load_rgb`` (:56-60) with the result on the GPU: ``uint8[H, W, 4]`` = ``np.array(Image.open(path).convert("RGBA"))``,
+    None when the file does not exist.  With a ``staging`` arena the call only queues work on the current stream."""
+    if not os.path.exists(path):
+        return None
+    with open(path, "rb") as f:
+        buf = f.read()
+    parsed = png_chunks(buf)
+    if parsed is not None:
+        w, h, c, stream = parsed
+        stride = 1 + w * c
+        own = staging is None
+        host = (Staging(h * stride) if own else staging).take(h * stride)
+        if inflate_into(host, stream) and int(host.numpy()[0::stride].max()) <= 4:
+            out = _unfilter(host, w, h, c, device)
+            if own:
+                torch.cuda.current_stream(device).synchronize()
+            return out
+    from PIL import Image       # any other flavour (or a damaged file: Pillow says what is wrong with it), as in the reference
+    import io
+    return torch.from_numpy(np.array(Image.open(io.BytesIO(buf)).convert("RGBA"))).to(device)
+
+
+def _exr_plan(buf: bytes, want: Optional[str] = None):
+    """``(header + layout, channel name, codec, [(compressed block, inflated size)] in increasing y)`` of a scanline OpenEXR file the
+    unpack kernel covers -- ZIP / ZIPS / RLE, the wanted channel half or float, every block actually compressed -- or None."""
+    try:
+        h = exr.read_header(buf)
+    except (ValueError, KeyError, IndexError, struct.error):
+        return None
+    name, lines_per_block = exr._COMPRESSION.get(h["compression"], (None, 0))
+    if name not in ("ZIP", "ZIPS", "RLE"):
+        return None
+    names = [n for n, _p in h["channels"]]
+    pick = want if want is not None else next((n for n in ("B", "G", "R", "Y", "Z", "V") if n in names), names[0])
+    if pick not in names or dict(h["channels"])[pick] not in (1, 2):
+        return None
+    xmin, ymin, xmax, ymax = h["data_window"]
+    W, H = xmax - xmin + 1, ymax - ymin + 1
+    bytes_per_line = sum(exr._PIXEL[p].itemsize for _n, p in h["channels"]) * W
+    n_blocks = (H + lines_per_block - 1) // lines_per_block
+    try:
+        offsets = struct.unpack_from(f"<{n_blocks}Q", buf, h["offsets_at"])
+        pieces = []
+        for k, off in enumerate(offsets):
+            y, size = struct.unpack_from("<ii", buf, off)
+            expected = min(lines_per_block, H - k * lines_per_block) * bytes_per_line
+            if y != ymin + k * lines_per_block or size >= expected or off + 8 + size > len(buf):   # (a block that did not shrink is stored without the predictor)
+                return None
+            pieces.append((buf[off + 8:off + 8 + size], expected))
+    except struct.error:
+        return None
+    c_at = 0
+    for n, p in h["channels"]:
+        if n == pick:
+            dt = exr._PIXEL[p]
+            break
+        c_at += exr._PIXEL[p].itemsize * W
+    layout = dict(h, width=W, height=H, bytes_per_line=bytes_per_line, lines_per_block=lines_per_block, channel_at=c_at, channel_bytes=dt.itemsize * W,
+                  channel_dtype=torch.float16 if dt.itemsize == 2 else torch.float32)
+    return layout, pick, name, pieces
+
+
+def exr_blocks(buf: bytes, want: Optional[str] = None):
+    """``(header + layout, channel name, inflated blocks in increasing y)`` of a covered OpenEXR file, or None."""
+    plan = _exr_plan(buf, want)
+    if plan is None:
+        return None
+    layout, pick, name, pieces = plan
+    out = []
+    for data, expected in pieces:
+        try:
+            raw = zlib.decompress(data) if name != "RLE" else exr._rle_decode(data, expected)
+        except (zlib.error, ValueError):
+            return None
+        if len(raw) != expected:
+            return None
+        out.append(raw)
+    return layout, pick, out
+
+
+def load_depth(path: str, device, staging: Optional[Staging] = None) -> Optional[torch.Tensor]:
+    """``blend_all.load_depth_exr`` (:70-75) with the result on the GPU: the plane ``cv2.imread(path, ANYCOLOR | ANYDEPTH)[:, :, 0]``
+    returns (the file's B channel), in the file's precision (float16 for Blender's half-float passes: widening it to float32 is exact
+    and the caller's); None when the file does not exist.  With a ``staging`` arena the call only queues work on the current stream."""
+    if not os.path.exists(path):
+        return None
+    with open(path, "rb") as f:
+        buf = f.read()
+    plan = _exr_plan(buf)
+    if plan is not None:
+        L, _pick, name, pieces = plan
+        own = staging is None
+        total = L["height"] * L["bytes_per_line"]
+        host = (Staging(total) if own else staging).take(total)
+        at, ok = 0, True
+        for data, expected in pieces:
+            if name == "RLE":
+                try:
+                    ctypes.memmove(ctypes.c_void_p(host.data_ptr() + at), exr._rle_decode(data, expected), expected)
+                except ValueError:
+                    ok = False
+            else:
+                ok = inflate_into(host[at:at + expected], data)
+            if not ok:
+                break
+            at += expected
+        if ok:
+            staged = _upload(host, device)
+            plane = torch.empty((L["height"], L["channel_bytes"]), dtype=torch.uint8, device=device)
+            with torch.cuda.device(device):
+                _check(_lib.lib.gsr_exr_unpack_channel(staged.data_ptr(), L["height"], L["bytes_per_line"], L["lines_per_block"], L["channel_at"],
+                                                       L["channel_bytes"], plane.data_ptr(), _stream_ptr(device)), "gsr_exr_unpack_channel")
+            if own:
+                torch.cuda.current_stream(device).synchronize()
+            return plane.view(L["channel_dtype"])
+    from . import compositor       # OpenCV where installed, autovfx_amd.exr otherwise: what the kernels do not cover
+    return torch.from_numpy(np.ascontiguousarray(compositor.load_depth_exr(path))).to(device)

@@ -1318,7 +1318,9 @@ def blend_frames_bench(device, frames=200, reference_frames=3):
         return {"workload": f"{frames} frames at 960x540; per frame 6 RGBA PNG layers + 4 half-float ZIP EXR depth passes at 1920x1080 (Blender at 2x), "
                             "the 3DGS frame's PNG; frames written as compressed PNGs to a tmpfs", "frames": len(paths),
                 "value": round(len(paths) / dt, 1), "unit": "frames/s", "ms_per_frame": round(dt / len(paths) * 1e3, 3),
-                "decode_threads": int(os.environ.get("AUTOVFX_AMD_BLEND_DECODERS", "0")) or min(16, len(os.sched_getaffinity(0))),
+                "decode_threads": compositor.decode_threads(),
+                **({"thread_seconds_by_stage": {k: round(v, 3) for k, v in compositor.LAST_BLEND_STATS.items() if k.endswith("_s")}}
+                   if compositor.LAST_BLEND_STATS else {}),
                 "input_bytes_per_frame": int(layer_bytes), "output_bytes_per_frame": int(os.path.getsize(paths[0])),
                 "reference_shaped": {"frames": len(ids), "ms_per_frame": round(t_ref / len(ids) * 1e3, 1), "frames_per_s": round(len(ids) / t_ref, 3),
                                      "what": "one host thread: PIL loads, EXR reads, PIL resizes of ten layers, numpy composite, PIL save"},

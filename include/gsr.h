@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 13
+#define GSR_ABI_VERSION 14
 
 #if defined(__GNUC__)
 #define GSR_API __attribute__((visibility("default")))
@@ -295,6 +295,25 @@ GSR_API int gsr_resize_rgba8_bilinear(const uint8_t* src, int src_width, int src
                                       uint8_t* tmp, void* stream);
 GSR_API int gsr_resize_f32_nearest(const float* src, int src_width, int src_height, float* dst, int dst_width, int dst_height,
                                    void* stream);
+
+/* The compositor's input FILES (blender/blend_all.py:56-75,185-205: load_rgb -- Image.open(path).convert("RGBA") -- for six PNG layers
+ * and load_depth_exr -- cv2.imread(path, ANYCOLOR | ANYDEPTH)[:, :, 0] -- for four OpenEXR depth passes per frame, at Blender's
+ * resolution).  Inflating a file's zlib stream(s) stays with the caller (zlib: byte-serial, one stream per PNG / per EXR block);
+ * what is left -- undoing the image predictor -- runs here, on what the caller uploads (gsr_upload: hipMemcpyAsync from any host
+ * memory, so that a binding needs no second runtime handle):
+ *  gsr_png_unfilter: `scanlines` = the inflated IDAT data of an 8-bit RGB (channels 3) or RGBA (4), non-interlaced PNG: height rows of
+ *   1 filter-type byte (0 ... 4; the caller checks them) + width * channels bytes, device memory.  out_rgba: [height, width, 4] u8,
+ *   alpha 255 for RGB -- the pixels Image.open(...).convert("RGBA") returns.  scratch: gsr_png_unfilter_scratch(w, h) bytes (0: the
+ *   width is over 4096 -- use a host decoder); both 16-byte aligned.  Two launches; one workgroup walks the image as a wavefront.
+ *  gsr_exr_unpack_channel: `blocks` = the inflated, still predictor-coded scanline blocks (ZIP / ZIPS / RLE) of one part, one after
+ *   another in increasing y, each lines * bytes_per_line bytes; plane: [height][channel_bytes] = the bytes of the channel stored at
+ *   [channel_at, channel_at + channel_bytes) of every line (half / float / uint samples in the file's byte order). */
+GSR_API size_t gsr_png_unfilter_scratch(int width, int height);
+GSR_API int gsr_png_unfilter(const uint8_t* scanlines, int width, int height, int channels, uint8_t* out_rgba, uint8_t* scratch,
+                             void* stream);
+GSR_API int gsr_exr_unpack_channel(const uint8_t* blocks, int height, int bytes_per_line, int lines_per_block, int channel_at,
+                                   int channel_bytes, uint8_t* plane, void* stream);
+GSR_API int gsr_upload(void* device_dst, const void* host_src, size_t bytes, void* stream);
 
 /* The sort stage on its own (what gsr_forward runs twice per call; replaces the reference's
  * cub::DeviceRadixSort::SortPairs, rasterizer_impl.cu:304-309): stable ascending sort of n (u32 key, u32

@@ -1,0 +1,240 @@
+"""autovfx_amd.layer_io + csrc/gsr_layerio.hip: Blender's layers from file to GPU memory (blender/blend_all.py:56-75,185-205 -- load_rgb /
+load_depth_exr on six PNGs and four EXRs per frame).  The host inflates, the GPU undoes the image predictors; the result must be the
+array the reference's loader returns, bit for bit.
+
+CPU: the container parsing -- which files the kernels are given, which go to Pillow / autovfx_amd.exr -- and the parsed stream against a
+numpy restatement of the PNG filters.  GPU: the kernels against Pillow / the numpy readers on files with every filter type, image sizes
+on both sides of the 64-row band and 4-pixel group boundaries, RGB and RGBA, and the EXR modes."""
+import io
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from autovfx_amd import exr, frame_io, layer_io
+
+
+# ---- a PNG written from the specification, with chosen filter types per row ----------------------------------------------------
+
+def _filter_rows(pixels: np.ndarray, types) -> bytes:
+    """PNG specification section 9: the FORWARD filters (each byte minus its prediction from the unfiltered neighbours)."""
+    h, w, c = pixels.shape
+    p = pixels.astype(np.int32)
+    left = np.zeros_like(p); left[:, 1:] = p[:, :-1]
+    up = np.zeros_like(p); up[1:] = p[:-1]
+    corner = np.zeros_like(p); corner[1:, 1:] = p[:-1, :-1]
+    est = left + up - corner
+    pa, pb, pc = np.abs(est - left), np.abs(est - up), np.abs(est - corner)
+    paeth = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, up, corner))
+    pred = {0: np.zeros_like(p), 1: left, 2: up, 3: (left + up) >> 1, 4: paeth}
+    rows = []
+    for y in range(h):
+        t = int(types[y])
+        rows.append(bytes([t]) + ((p[y] - pred.get(t, pred[0])[y]) & 255).astype(np.uint8).tobytes())
+    return b"".join(rows)
+
+
+def _png_file(pixels: np.ndarray, types, level=6, idat_pieces=1, extra=b"", interlace=0, depth=8, colour=None) -> bytes:
+    h, w, c = pixels.shape
+    chunk = lambda kind, data: struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data))
+    z = zlib.compress(_filter_rows(pixels, types), level)
+    cuts = [len(z) * k // idat_pieces for k in range(idat_pieces + 1)]
+    colour = (2 if c == 3 else 6) if colour is None else colour
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, colour, 0, 0, interlace)) + extra
+            + b"".join(chunk(b"IDAT", z[a:b]) for a, b in zip(cuts, cuts[1:])) + chunk(b"IEND", b""))
+
+
+def _noise(h, w, c, seed):
+    g = np.random.default_rng(seed)
+    img = g.integers(0, 256, (h, w, c)).astype(np.uint8)
+    img[: h // 3] = (img[: h // 3] // 64) * 64                   # flat stretches and ties between the Paeth candidates
+    return img
+
+
+def test_written_png_is_what_pillow_reads():
+    """The test's own PNG writer (every filter type) against Pillow and against the package's numpy reader: the fixture is sound."""
+    img = _noise(23, 17, 4, 0)
+    data = _png_file(img, [y % 5 for y in range(23)], idat_pieces=3)
+    np.testing.assert_array_equal(np.array(Image.open(io.BytesIO(data))), img)
+    np.testing.assert_array_equal(frame_io.decode_png(data), img)
+
+
+@pytest.mark.parametrize("c", [3, 4])
+def test_png_scanlines_parses_what_the_kernel_covers(c):
+    img = _noise(19, 31, c, c)
+    types = [(3 * y + 1) % 5 for y in range(19)]
+    w, h, cc, raw = layer_io.png_scanlines(_png_file(img, types, idat_pieces=4, extra=struct.pack(">I", 4) + b"gAMA" + struct.pack(">I", 45455)
+                                                     + struct.pack(">I", zlib.crc32(b"gAMA" + struct.pack(">I", 45455)))))
+    assert (w, h, cc) == (31, 19, c) and raw == _filter_rows(img, types)
+    buf = io.BytesIO()
+    Image.fromarray(img).save(buf, format="PNG")
+    w, h, cc, raw = layer_io.png_scanlines(buf.getvalue())              # Pillow's adaptive filters
+    assert (w, h, cc) == (31, 19, c) and len(raw) == 19 * (1 + 31 * c)
+
+
+def test_png_flavours_left_to_pillow():
+    img = _noise(8, 8, 3, 1)
+    ok = _png_file(img, [0] * 8)
+    assert layer_io.png_scanlines(ok) is not None
+    assert layer_io.png_scanlines(_png_file(img, [0] * 8, interlace=1)) is None
+    assert layer_io.png_scanlines(_png_file(img, [0] * 8, depth=16)) is None
+    assert layer_io.png_scanlines(_png_file(img, [0] * 8, colour=0)) is None          # grey
+    trns = struct.pack(">I", 6) + b"tRNS" + bytes(6) + struct.pack(">I", zlib.crc32(b"tRNS" + bytes(6)))
+    assert layer_io.png_scanlines(_png_file(img, [0] * 8, extra=trns)) is None        # a transparent colour: convert("RGBA") applies it
+    assert layer_io.png_scanlines(_png_file(img, [0, 1, 2, 3, 4, 5, 0, 0])) is None   # filter type 5 does not exist
+    assert layer_io.png_scanlines(ok[:40] + bytes([ok[40] ^ 1]) + ok[41:]) is None    # a flipped bit: the chunk's CRC
+    assert layer_io.png_scanlines(ok[:-30]) is None                                    # truncated
+    assert layer_io.png_scanlines(b"GIF89a" + ok) is None
+    for mode in ("P", "L", "LA", "I;16"):
+        buf = io.BytesIO()
+        Image.fromarray(img).convert(mode).save(buf, format="PNG")
+        assert layer_io.png_scanlines(buf.getvalue()) is None, mode
+
+
+def test_exr_blocks_parses_what_the_kernel_covers(tmp_path):
+    g = np.random.default_rng(5)
+    z = np.linspace(0.5, 9.0, 40 * 24, dtype=np.float32).reshape(40, 24)
+    p = str(tmp_path / "a.exr")
+    exr.write_exr(p, {"R": z, "G": z, "B": z + 1, "A": np.ones_like(z)}, compression="ZIP", half=True)
+    h, pick, pieces = layer_io.exr_blocks(open(p, "rb").read())
+    assert pick == "B" and [len(x) for x in pieces] == [16 * 24 * 8, 16 * 24 * 8, 8 * 24 * 8] and h["bytes_per_line"] == 24 * 8
+    exr.write_exr(p, {"Z": np.repeat(z, 8, axis=1)}, compression="ZIPS", half=True)     # (a line per block: long enough to shrink)
+    assert layer_io.exr_blocks(open(p, "rb").read())[1] == "Z"
+    exr.write_exr(p, {"B": z}, compression="NONE")
+    assert layer_io.exr_blocks(open(p, "rb").read()) is None                         # nothing to undo: the host reader
+    noise = g.random((16, 24)).astype(np.float32)
+    exr.write_exr(p, {"B": noise}, compression="ZIP")                                  # noise does not shrink: the block is stored as it is
+    assert layer_io.exr_blocks(open(p, "rb").read()) is None
+    np.testing.assert_array_equal(exr.load_depth_exr(p), noise)
+    assert layer_io.exr_blocks(b"not an exr file at all") is None
+
+
+def test_staging_arena_and_inflate_into():
+    """The host-side hand-over: zlib streams inflate straight into the arena (libz through ctypes, or Python's zlib and one copy); an
+    arena grows without moving what it has handed out and starts over on reset."""
+    st = layer_io.Staging()
+    payload = bytes(np.random.default_rng(0).integers(0, 7, 300000).astype(np.uint8))
+    a = st.take(len(payload))
+    assert layer_io.inflate_into(a, zlib.compress(payload, 1)) and bytes(a.numpy()) == payload
+    b = st.take(3 << 20)                                     # larger than what is left: a new block; `a` is untouched
+    b.zero_()
+    assert bytes(a.numpy()) == payload and a.data_ptr() % 64 == 0 and b.data_ptr() % 64 == 0
+    assert not layer_io.inflate_into(st.take(len(payload) - 1), zlib.compress(payload))     # does not fit
+    assert not layer_io.inflate_into(st.take(len(payload) + 1), zlib.compress(payload))     # does not fill
+    assert not layer_io.inflate_into(st.take(len(payload)), zlib.compress(payload)[:-9])    # truncated stream
+    assert not layer_io.inflate_into(st.take(16), b"not a zlib stream")
+    st.reset()
+    c = st.take(len(payload))
+    assert layer_io.inflate_into(c, zlib.compress(payload, 9)) and bytes(c.numpy()) == payload
+    saved, layer_io._libz = layer_io._libz, None             # the fall-back without a shared zlib
+    try:
+        d = st.take(len(payload))
+        assert layer_io.inflate_into(d, zlib.compress(payload)) and bytes(d.numpy()) == payload
+        assert not layer_io.inflate_into(st.take(5), zlib.compress(payload))
+    finally:
+        layer_io._libz = saved
+
+
+# ---- the kernels -----------------------------------------------------------------------------------------------------------------
+
+def _unfilter_on_gpu(data: bytes) -> np.ndarray:
+    parsed = layer_io.png_scanlines(data)
+    assert parsed is not None
+    w, h, c, raw = parsed
+    return layer_io.unfilter_png(raw, w, h, c, torch.device("cuda", 0)).cpu().numpy()
+
+
+def _rgba(img):
+    return img if img.shape[2] == 4 else np.concatenate([img, np.full(img.shape[:2] + (1,), 255, np.uint8)], axis=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", [3, 4])
+@pytest.mark.parametrize("hw", [(1, 1), (1, 9), (9, 1), (3, 5), (64, 64), (65, 130), (63, 3), (130, 61), (257, 300), (300, 7), (7, 1100)])
+def test_unfilter_every_filter_type(hw, c):
+    """Rows of all five types in a fixed rotation and in random order, on images that cross the 64-row bands (1, 2, 3 and 5 of them:
+    one and two rounds of the four waves) and the 4-pixel groups."""
+    h, w = hw
+    img = _noise(h, w, c, h * 1000 + w + c)
+    for types in ([y % 5 for y in range(h)], np.random.default_rng(w).integers(0, 5, h), [4] * h, [3] * h):
+        got = _unfilter_on_gpu(_png_file(img, types, level=1))
+        np.testing.assert_array_equal(got, _rgba(img), err_msg=f"{hw} x {c}, types {list(types)[:8]}...")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(1920, 1080), (960, 540), (4096, 70)])
+def test_unfilter_layer_sized_images_as_pillow_writes_them(size):
+    """Blender-sized layers with Pillow's adaptive filter choice: a smooth picture (Sub / Up / Paeth rows), noise, and transparency."""
+    w, h = size
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    smooth = np.stack([(127 + 120 * np.sin(xx * 0.01 + k) * np.cos(yy * 0.013 - k)) for k in range(4)], axis=2).astype(np.uint8)
+    smooth[..., 3] = np.clip(400 - np.hypot(xx - w / 2, yy - h / 2), 0, 255).astype(np.uint8)
+    for img in (smooth, _noise(h, w, 4, 9), smooth[..., :3].copy()):
+        buf = io.BytesIO()
+        Image.fromarray(img).save(buf, format="PNG", compress_level=1)
+        got = _unfilter_on_gpu(buf.getvalue())
+        np.testing.assert_array_equal(got, np.array(Image.open(io.BytesIO(buf.getvalue())).convert("RGBA")))
+
+
+@pytest.mark.gpu
+def test_load_rgba_is_load_rgb(tmp_path):
+    """``load_rgba`` against ``blend_all.load_rgb``'s expression for a covered file, for flavours left to Pillow, and for a missing file."""
+    dev = torch.device("cuda", 0)
+    img = _noise(70, 90, 4, 3)
+    cases = {"rgba.png": Image.fromarray(img), "rgb.png": Image.fromarray(img[..., :3].copy()), "grey.png": Image.fromarray(img[..., 0].copy()),
+             "palette.png": Image.fromarray(img[..., :3].copy()).convert("P")}
+    for name, im in cases.items():
+        p = str(tmp_path / name)
+        im.save(p)
+        got = layer_io.load_rgba(p, dev)
+        np.testing.assert_array_equal(got.cpu().numpy(), np.array(Image.open(p).convert("RGBA")), err_msg=name)
+    assert layer_io.load_rgba(str(tmp_path / "missing.png"), dev) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compression", ["ZIPS", "ZIP"])
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("shape", [(1, 2), (16, 7), (17, 33), (54, 96), (100, 3), (540, 960)])
+def test_load_depth_is_load_depth_exr(tmp_path, compression, half, shape):
+    dev = torch.device("cuda", 0)
+    g = np.random.default_rng(shape[0] + shape[1])
+    yy, xx = np.mgrid[0:shape[0], 0:shape[1]].astype(np.float32)
+    depth = (3.0 + np.sin(xx * 0.05) + 0.01 * g.random(shape)).astype(np.float32)
+    depth[: shape[0] // 2] = 65504.0 if half else 1e10
+    p = str(tmp_path / "Image0001.exr")
+    exr.write_exr(p, {"R": depth, "G": depth, "B": depth + 1, "A": np.ones(shape, np.float32)}, compression=compression, half=half, level=1)
+    want = exr.load_depth_exr(p)
+    got = layer_io.load_depth(p, dev)
+    if layer_io.exr_blocks(open(p, "rb").read()) is not None:
+        assert got.dtype == (torch.float16 if half else torch.float32)
+    np.testing.assert_array_equal(got.to(torch.float32).cpu().numpy(), want)
+    exr.write_exr(p, {"Z": depth}, compression=compression, half=half)                 # a single channel; a line is one stretch
+    got = layer_io.load_depth(p, dev)
+    np.testing.assert_array_equal(got.to(torch.float32).cpu().numpy(), exr.load_depth_exr(p))
+
+
+@pytest.mark.gpu
+def test_load_depth_falls_back_for_what_the_kernel_does_not_cover(tmp_path):
+    dev = torch.device("cuda", 0)
+    g = np.random.default_rng(1)
+    noise = g.random((40, 30)).astype(np.float32)             # float noise does not shrink under zlib: blocks stored as they are
+    p = str(tmp_path / "Image0001.exr")
+    for compression in ("NONE", "ZIP"):
+        exr.write_exr(p, {"B": noise, "G": noise}, compression=compression)
+        got = layer_io.load_depth(p, dev)
+        np.testing.assert_array_equal(got.cpu().numpy(), noise)
+    assert layer_io.load_depth(str(tmp_path / "missing.exr"), dev) is None
+
+
+@pytest.mark.gpu
+def test_rle_file_from_the_specification(tmp_path):
+    from test_exr import _hand_made
+    data, g_plane, z_plane = _hand_made(W=300, H=5, compressed="rle")
+    p = str(tmp_path / "rle.exr")
+    open(p, "wb").write(data)
+    got = layer_io.load_depth(p, torch.device("cuda", 0))
+    np.testing.assert_array_equal(got.to(torch.float32).cpu().numpy(), exr.load_depth_exr(p))
