@@ -183,9 +183,8 @@ def _load_frame_layers_to_gpu(cache, bg_path, i, dev, staging):
     predictor (``autovfx_amd.layer_io``).  ``staging`` may be reset once the stream has been synchronised."""
     import os
     from . import layer_io
-    out = {"bg": layer_io.load_rgba(bg_path, dev, staging)}
-    for kind in _LAYERS_RGB:
-        out[kind] = layer_io.load_rgba(os.path.join(cache, kind, "{:0>3d}.png".format(i + 1)), dev, staging)
+    pngs = [bg_path] + [os.path.join(cache, kind, "{:0>3d}.png".format(i + 1)) for kind in _LAYERS_RGB]
+    out = dict(zip(("bg",) + _LAYERS_RGB, layer_io.load_rgba_many(pngs, dev, staging)))       # (one launch for the frame's PNGs)
     for kind in _LAYERS_DEPTH:
         out[kind] = layer_io.load_depth(os.path.join(cache, kind, "{:0>3d}".format(i + 1), "Image{:0>4d}.exr".format(i + 1)), dev, staging)
     return out

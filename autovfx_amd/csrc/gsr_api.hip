@@ -809,15 +809,27 @@ int gsr_png_encode_deflate(const uint8_t* pixels, int width, int height, int cha
 
 size_t gsr_png_unfilter_scratch(int width, int height) { return gsr::png_unfilter_scratch_bytes(width, height); }
 
-int gsr_png_unfilter(const uint8_t* scanlines, int width, int height, int channels, uint8_t* out_rgba, uint8_t* scratch, void* stream_) {
-    if (gsr::png_unfilter_scratch_bytes(width, height) == 0 || (channels != 3 && channels != 4))
-        return fail(GSR_ERR_INVALID_ARG, "gsr_png_unfilter: %dx%d with %d channels is not supported (8-bit RGB / RGBA, at most 4096 pixels wide)", width, height,
-                    channels);
-    if (!scanlines || !out_rgba || !scratch) return fail(GSR_ERR_INVALID_ARG, "null pointer");
-    if (((reinterpret_cast<uintptr_t>(out_rgba) | reinterpret_cast<uintptr_t>(scratch)) & 15u) != 0)
-        return fail(GSR_ERR_INVALID_ARG, "gsr_png_unfilter: out_rgba and scratch must be 16-byte aligned");
-    GSR_HIP(gsr::launch_png_unfilter(scanlines, width, height, channels, out_rgba, scratch, (hipStream_t)stream_));
+static_assert(sizeof(GsrPngUnfilterJob) == sizeof(gsr::PngUnfilterJob), "GsrPngUnfilterJob is passed through as it is");
+
+int gsr_png_unfilter_batch(int count, const GsrPngUnfilterJob* jobs, void* stream_) {
+    if (count < 0 || (count > 0 && !jobs)) return fail(GSR_ERR_INVALID_ARG, "gsr_png_unfilter_batch: bad job list");
+    for (int i = 0; i < count; ++i) {
+        const GsrPngUnfilterJob& j = jobs[i];
+        if (gsr::png_unfilter_scratch_bytes(j.width, j.height) == 0 || (j.channels != 3 && j.channels != 4))
+            return fail(GSR_ERR_INVALID_ARG, "gsr_png_unfilter: job %d: %dx%d with %d channels is not supported (8-bit RGB / RGBA, at most 4096 pixels wide)", i,
+                        j.width, j.height, j.channels);
+        if (!j.scanlines || !j.out_rgba || !j.scratch) return fail(GSR_ERR_INVALID_ARG, "gsr_png_unfilter: job %d: null pointer", i);
+        if (((reinterpret_cast<uintptr_t>(j.out_rgba) | reinterpret_cast<uintptr_t>(j.scratch)) & 15u) != 0)
+            return fail(GSR_ERR_INVALID_ARG, "gsr_png_unfilter: job %d: out_rgba and scratch must be 16-byte aligned", i);
+    }
+    if (count == 0) return GSR_OK;
+    GSR_HIP(gsr::launch_png_unfilter_batch(count, reinterpret_cast<const gsr::PngUnfilterJob*>(jobs), (hipStream_t)stream_));
     return GSR_OK;
+}
+
+int gsr_png_unfilter(const uint8_t* scanlines, int width, int height, int channels, uint8_t* out_rgba, uint8_t* scratch, void* stream_) {
+    const GsrPngUnfilterJob job = {scanlines, width, height, channels, out_rgba, scratch};
+    return gsr_png_unfilter_batch(1, &job, stream_);
 }
 
 int gsr_exr_unpack_channel(const uint8_t* blocks, int height, int bytes_per_line, int lines_per_block, int channel_at, int channel_bytes, uint8_t* plane,

@@ -368,7 +368,13 @@ hipError_t launch_resize_f32_nearest(const float* src, int src_w, int src_h, flo
 // The inflated IDAT stream of an 8-bit RGB / RGBA, non-interlaced PNG (device memory) -> RGBA8 [H,W,4] (alpha 255 for RGB).
 // scratch: png_unfilter_scratch_bytes(W, H) bytes, 16-byte aligned (0: the width is not supported).
 size_t png_unfilter_scratch_bytes(int W, int H);
-hipError_t launch_png_unfilter(const uint8_t* stream_bytes, int W, int H, int C, uint8_t* out_rgba, uint8_t* scratch, hipStream_t stream);
+struct PngUnfilterJob {      // (= GsrPngUnfilterJob, gsr.h)
+    const uint8_t* scanlines;
+    int width, height, channels;
+    uint8_t* out_rgba;
+    uint8_t* scratch;
+};
+hipError_t launch_png_unfilter_batch(int n, const PngUnfilterJob* jobs, hipStream_t stream);   // one workgroup per image, eight images per launch
 // The inflated, still predictor-coded scanline blocks of an OpenEXR file one after another (device memory) -> the bytes of the channel
 // that occupies [c_at, c_at + c_bytes) of every line: plane[H][c_bytes].
 hipError_t launch_exr_unpack_channel(const uint8_t* blocks, int H, int bytes_per_line, int lines_per_block, int c_at, int c_bytes, uint8_t* plane,

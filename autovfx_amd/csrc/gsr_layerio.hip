@@ -7,8 +7,8 @@
 //       filter types None / Sub / Up / Average / Paeth) -> RGBA8 pixels.  Every byte depends on its left, upper and upper-left
 //       neighbours, so the image is a wavefront: lane l of a wave owns row l of a band of 64 rows and runs l pixels behind the lane
 //       above it, whose output of the previous step -- the pixel right above -- arrives through one DPP move (wave_shr:1); the
-//       four waves of a workgroup (one per SIMD) work on four consecutive bands, each 17 four-pixel groups behind the one above,
-//       whose last row it reads from LDS.  All four bytes of a pixel go through the five predictors at once, two bytes per
+//       four waves of a workgroup (one per SIMD) work on four consecutive bands, each 20 four-pixel groups behind the one above,
+//       whose last row it reads from LDS (a workgroup barrier every four groups).  All four bytes of a pixel go through the five predictors at once, two bytes per
 //       32-bit register (16-bit fields, packed min / max / shifts); a row's filter type selects by masks, so rows of different
 //       types share the instruction stream.  ~60 VALU instructions per pixel step: a 1920x1080 layer in ~1.3 ms on ONE compute
 //       unit -- the layers of a frame, and the frames of the decode threads, run beside each other.
@@ -20,6 +20,7 @@
 // kernels do not cover).
 #include "gsr_internal.h"
 
+#include <algorithm>
 #include <mutex>
 
 namespace gsr {
@@ -29,10 +30,22 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kUnfWaves = 4;        // one per SIMD: the kernel is bound by VALU issue
-constexpr int kUnfLag = 17;         // groups a band runs behind the band above: after g + 16 groups lane 63 of that band has finished pixel 4 g + 4
+constexpr int kUnfSpan = 4;         // four-pixel groups between two workgroup barriers
+constexpr int kUnfLag = 5;          // spans a band runs behind the band above: after 4 spans + 3 groups more, lane 63 up there has finished pixel 16 s + 16
 constexpr int kUnfPad = 64;         // pixels in front of a scratch row (lane l starts l pixels to the left of the image)
-constexpr int kUnfTail = 72;        // and behind it (lane 0 runs 63 pixels past the end while lane 63 finishes)
-constexpr int kUnfMaxWidth = 4096;  // four LDS edge rows of 2 (W + kUnfTail) words: 133 KB
+constexpr int kUnfTail = 96;        // and behind it (lane 0 runs 63 pixels past the end while lane 63 finishes; whole spans)
+constexpr int kUnfMaxWidth = 4096;  // four LDS edge rows of 2 (W + kUnfTail) words: 134 KB
+constexpr int kUnfMaxJobs = 8;      // images per launch
+
+struct UnfJob {
+    const uint8_t* stream;          // inflated IDAT data
+    uint32_t* words;                // scratch: H rows of W + kUnfPad + kUnfTail words
+    uint32_t* out;                  // [H][W] RGBA8
+    int W, H, C;
+};
+struct UnfBatch {
+    UnfJob job[kUnfMaxJobs];
+};
 
 __device__ __forceinline__ u16x2 as_u16(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
 
@@ -69,23 +82,28 @@ __device__ __forceinline__ uint32_t dpp_keep(uint32_t old, uint32_t src) {
 
 // Row bytes -> one aligned 32-bit word per pixel (alpha byte 0 for RGB), in a scratch image whose rows have kUnfPad pixels in front
 // and kUnfTail behind: the wavefront kernel's 16-byte loads are then in bounds for every lane at every step.
-__global__ void __launch_bounds__(256) png_rows_to_words_kernel(const uint8_t* __restrict__ stream, int W, int C, uint32_t* __restrict__ words, int pitch) {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= W) return;
-    const uint8_t* p = stream + (size_t)blockIdx.y * ((size_t)W * C + 1) + 1 + (size_t)x * C;
+__global__ void __launch_bounds__(256) png_rows_to_words_kernel(UnfBatch batch) {
+    const UnfJob& j = batch.job[blockIdx.z];
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= j.W || y >= j.H) return;
+    const uint8_t* p = j.stream + (size_t)y * ((size_t)j.W * j.C + 1) + 1 + (size_t)x * j.C;
     uint32_t v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
-    if (C == 4) v |= (uint32_t)p[3] << 24;
-    words[(size_t)blockIdx.y * pitch + kUnfPad + x] = v;
+    if (j.C == 4) v |= (uint32_t)p[3] << 24;
+    j.words[(size_t)y * (j.W + kUnfPad + kUnfTail) + kUnfPad + x] = v;
 }
 
-__global__ void __launch_bounds__(kUnfWaves * 64) png_unfilter_kernel(const uint8_t* __restrict__ stream, int W, int H, int C,
-                                                                      const uint32_t* __restrict__ words, int pitch, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(kUnfWaves * 64) png_unfilter_kernel(UnfBatch batch) {
     // [kUnfWaves][2][edge_pitch]: the last row of each wave's band as it is produced, even bytes / odd bytes in the form the step uses
     extern __shared__ uint32_t s_edge[];
+    const UnfJob& job = batch.job[blockIdx.x];
+    const int W = job.W, H = job.H, C = job.C;
+    const uint8_t* __restrict__ stream = job.stream;
+    const int pitch = W + kUnfPad + kUnfTail;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int edge_pitch = ((W + kUnfTail + 3) & ~3);
     const int groups = (W + 62) / 4 + 1;                 // lane 63 reaches pixel W - 1 in group (W + 62) / 4
-    const int round_groups = groups + kUnfLag * (kUnfWaves - 1);
+    const int spans = (groups + kUnfSpan - 1) / kUnfSpan;
+    const int round_spans = spans + kUnfLag * (kUnfWaves - 1);
     const int bands = (H + 63) >> 6;
     const int rounds = (bands + kUnfWaves - 1) / kUnfWaves;
     const size_t stride = (size_t)W * C + 1;
@@ -103,58 +121,68 @@ __global__ void __launch_bounds__(kUnfWaves * 64) png_unfilter_kernel(const uint
         const uint32_t m_sub = opaque(type == 1 ? ~0u : 0u), m_up = opaque(type == 2 ? ~0u : 0u), m_avg = opaque(type == 3 ? ~0u : 0u),
                        m_paeth = opaque(type == 4 ? ~0u : 0u);
         const bool edge_on = band > 0;                   // band 0 has zeros above it
-        const uint32_t* row_words = words + (size_t)(row_on ? row : 0) * pitch + kUnfPad - lane;   // group g: pixels 4 g - lane ... + 3
-        uint32_t* row_out = out + (size_t)(row_on ? row : 0) * W;
+        const uint32_t* row_words = job.words + (size_t)(row_on ? row : 0) * pitch + kUnfPad - lane;   // group g: pixels 4 g - lane ... + 3
+        uint32_t* row_out = job.out + (size_t)(row_on ? row : 0) * W;
         uint32_t left_e = 0u, left_o = 0u;               // this row's previous pixel: even bytes (R, B) / odd bytes (G, A) in 16-bit fields
         uint32_t corner_e = 0u, corner_o = 0u;           // the row above at the previous step: this step's upper-left
-        uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
-        if (band_on) {
-            __builtin_memcpy(&q0, row_words, 16);
-            __builtin_memcpy(&q1, row_words + 4, 16);
+        uint4 cur[kUnfSpan];
+#pragma unroll
+        for (int k = 0; k < kUnfSpan; ++k) {
+            cur[k] = make_uint4(0, 0, 0, 0);
+            if (band_on) __builtin_memcpy(&cur[k], row_words + 4 * k, 16);
         }
-        for (int t = 0; t < round_groups; ++t) {
-            const int g = t - kUnfLag * wave;
-            if (band_on && g >= 0 && g < groups) {
-                uint4 q2 = make_uint4(0, 0, 0, 0);
-                if (g + 2 < groups) __builtin_memcpy(&q2, row_words + 4 * (g + 2), 16);      // (at most W + 62 + 3 words behind the row's first: inside kUnfTail)
-                uint4 ee = make_uint4(0, 0, 0, 0), eo = ee;
-                if (edge_on) {                           // the same address in every lane: a broadcast; only lane 0 uses it
-                    ee = *reinterpret_cast<const uint4*>(edge_in + 4 * g);
-                    eo = *reinterpret_cast<const uint4*>(edge_in + edge_pitch + 4 * g);
-                }
-                const uint32_t f[4] = {q0.x, q0.y, q0.z, q0.w};
-                const uint32_t above_e[4] = {ee.x, ee.y, ee.z, ee.w}, above_o[4] = {eo.x, eo.y, eo.z, eo.w};
-                uint32_t px[4];
-                const int x0 = 4 * g - lane;
+        for (int t = 0; t < round_spans; ++t) {
+            const int s = t - kUnfLag * wave;
+            if (band_on && s >= 0 && s < spans) {
+                // the next span's pixels (in flight for a whole span) and, from LDS, the row above this band for the whole span
+                uint4 nxt[kUnfSpan], ee[kUnfSpan], eo[kUnfSpan];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int x = x0 + i;
-                    // the pixel above: what the lane above produced in the previous step; lane 0 keeps the band above's last row
-                    const uint32_t b_e = dpp_keep<0x138>(above_e[i], left_e);
-                    const uint32_t b_o = dpp_keep<0x138>(above_o[i], left_o);
-                    const uint32_t keep = opaque((unsigned)x < (unsigned)W ? kLow : 0u);     // outside the image everything is zero
-                    const uint32_t pred_e = (left_e & m_sub) | (b_e & m_up) | (average2(left_e, b_e) & m_avg) | (paeth2(left_e, b_e, corner_e) & m_paeth);
-                    const uint32_t pred_o = (left_o & m_sub) | (b_o & m_up) | (average2(left_o, b_o) & m_avg) | (paeth2(left_o, b_o, corner_o) & m_paeth);
-                    corner_e = b_e; corner_o = b_o;
-                    left_e = ((f[i] & kLow) + pred_e) & keep;
-                    left_o = (((f[i] >> 8) & kLow) + pred_o) & keep;
-                    px[i] = left_e | (left_o << 8);
-                    if (lane == 63 && (unsigned)x < (unsigned)W) {
-                        edge_out[x] = left_e;
-                        edge_out[edge_pitch + x] = left_o;
+                for (int k = 0; k < kUnfSpan; ++k) {
+                    nxt[k] = make_uint4(0, 0, 0, 0);
+                    if (s + 1 < spans) __builtin_memcpy(&nxt[k], row_words + 4 * (kUnfSpan * (s + 1) + k), 16);   // (at most W + 62 + 16 + 3 words in: inside kUnfTail)
+                    ee[k] = eo[k] = make_uint4(0, 0, 0, 0);
+                    if (edge_on) {                       // the same address in every lane: a broadcast; only lane 0 uses it
+                        ee[k] = *reinterpret_cast<const uint4*>(edge_in + 4 * (kUnfSpan * s + k));
+                        eo[k] = *reinterpret_cast<const uint4*>(edge_in + edge_pitch + 4 * (kUnfSpan * s + k));
                     }
                 }
-                if (row_on) {
-                    if (x0 >= 0 && x0 + 3 < W) {
-                        const uint4 v = make_uint4(px[0] | alpha, px[1] | alpha, px[2] | alpha, px[3] | alpha);
-                        __builtin_memcpy(row_out + x0, &v, 16);
-                    } else {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if ((unsigned)(x0 + i) < (unsigned)W) row_out[x0 + i] = px[i] | alpha;
+                for (int k = 0; k < kUnfSpan; ++k) {
+                    const uint32_t f[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
+                    const uint32_t above_e[4] = {ee[k].x, ee[k].y, ee[k].z, ee[k].w}, above_o[4] = {eo[k].x, eo[k].y, eo[k].z, eo[k].w};
+                    uint32_t px[4];
+                    const int x0 = 4 * (kUnfSpan * s + k) - lane;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int x = x0 + i;
+                        // the pixel above: what the lane above produced in the previous step; lane 0 keeps the band above's last row
+                        const uint32_t b_e = dpp_keep<0x138>(above_e[i], left_e);
+                        const uint32_t b_o = dpp_keep<0x138>(above_o[i], left_o);
+                        const uint32_t keep = opaque((unsigned)x < (unsigned)W ? kLow : 0u);     // outside the image everything is zero
+                        const uint32_t pred_e = (left_e & m_sub) | (b_e & m_up) | (average2(left_e, b_e) & m_avg) | (paeth2(left_e, b_e, corner_e) & m_paeth);
+                        const uint32_t pred_o = (left_o & m_sub) | (b_o & m_up) | (average2(left_o, b_o) & m_avg) | (paeth2(left_o, b_o, corner_o) & m_paeth);
+                        corner_e = b_e; corner_o = b_o;
+                        left_e = ((f[i] & kLow) + pred_e) & keep;
+                        left_o = (((f[i] >> 8) & kLow) + pred_o) & keep;
+                        px[i] = left_e | (left_o << 8);
+                        if (lane == 63 && (unsigned)x < (unsigned)W) {
+                            edge_out[x] = left_e;
+                            edge_out[edge_pitch + x] = left_o;
+                        }
+                    }
+                    if (row_on) {
+                        if (x0 >= 0 && x0 + 3 < W) {
+                            const uint4 v = make_uint4(px[0] | alpha, px[1] | alpha, px[2] | alpha, px[3] | alpha);
+                            __builtin_memcpy(row_out + x0, &v, 16);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if ((unsigned)(x0 + i) < (unsigned)W) row_out[x0 + i] = px[i] | alpha;
+                        }
                     }
                 }
-                q0 = q1; q1 = q2;
+#pragma unroll
+                for (int k = 0; k < kUnfSpan; ++k) cur[k] = nxt[k];
             }
             // hand the edge pixels over: LDS operations only (the image loads and stores stay in flight across the barrier)
             asm volatile("" ::: "memory");
@@ -232,11 +260,7 @@ size_t png_unfilter_scratch_bytes(int W, int H) {
     return (size_t)H * (size_t)(W + kUnfPad + kUnfTail) * 4;
 }
 
-hipError_t launch_png_unfilter(const uint8_t* stream_bytes, int W, int H, int C, uint8_t* out_rgba, uint8_t* scratch, hipStream_t stream) {
-    const int pitch = W + kUnfPad + kUnfTail;
-    uint32_t* words = reinterpret_cast<uint32_t*>(scratch);
-    hipLaunchKernelGGL(png_rows_to_words_kernel, dim3((W + 255) / 256, H), dim3(256), 0, stream, stream_bytes, W, C, words, pitch);
-    const size_t lds = (size_t)kUnfWaves * 2 * ((W + kUnfTail + 3) & ~3) * 4;
+hipError_t launch_png_unfilter_batch(int n, const PngUnfilterJob* jobs, hipStream_t stream) {
     static std::once_flag once[16];
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -246,8 +270,20 @@ hipError_t launch_png_unfilter(const uint8_t* stream_bytes, int W, int H, int C,
         attr = hipFuncSetAttribute(reinterpret_cast<const void*>(png_unfilter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     });
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL(png_unfilter_kernel, dim3(1), dim3(kUnfWaves * 64), lds, stream, stream_bytes, W, H, C, words, pitch,
-                       reinterpret_cast<uint32_t*>(out_rgba));
+    for (int at = 0; at < n; at += kUnfMaxJobs) {
+        UnfBatch batch = {};
+        const int m = std::min(kUnfMaxJobs, n - at);
+        int max_w = 0, max_h = 0;
+        for (int i = 0; i < m; ++i) {
+            const PngUnfilterJob& j = jobs[at + i];
+            batch.job[i] = {j.scanlines, reinterpret_cast<uint32_t*>(j.scratch), reinterpret_cast<uint32_t*>(j.out_rgba), j.width, j.height, j.channels};
+            max_w = std::max(max_w, j.width);
+            max_h = std::max(max_h, j.height);
+        }
+        hipLaunchKernelGGL(png_rows_to_words_kernel, dim3((max_w + 255) / 256, max_h, m), dim3(256), 0, stream, batch);
+        const size_t lds = (size_t)kUnfWaves * 2 * ((max_w + kUnfTail + 3) & ~3) * 4;
+        hipLaunchKernelGGL(png_unfilter_kernel, dim3(m), dim3(kUnfWaves * 64), lds, stream, batch);
+    }
     return hipGetLastError();
 }
 

@@ -151,46 +151,70 @@ def png_scanlines(buf: bytes):
     return w, h, c, raw
 
 
-def _unfilter(host: torch.Tensor, w: int, h: int, c: int, device) -> torch.Tensor:
+def _unfilter_many(jobs, device):
+    """``jobs``: ``[(page-locked scanline stream, w, h, c)]`` -> the RGBA8 images, by one ``gsr_png_unfilter_batch`` call (a workgroup per
+    image, side by side) on the current stream."""
     lib = _lib.lib
-    staged = _upload(host, device)
-    out = torch.empty((h, w, 4), dtype=torch.uint8, device=device)
-    scratch = torch.empty(lib.gsr_png_unfilter_scratch(w, h), dtype=torch.uint8, device=device)
+    if not jobs:
+        return []
+    table = (_lib.PngUnfilterJob * len(jobs))()
+    held, outs = [], []
+    for k, (host, w, h, c) in enumerate(jobs):
+        staged = _upload(host, device)
+        out = torch.empty((h, w, 4), dtype=torch.uint8, device=device)
+        scratch = torch.empty(lib.gsr_png_unfilter_scratch(w, h), dtype=torch.uint8, device=device)
+        table[k] = _lib.PngUnfilterJob(staged.data_ptr(), w, h, c, out.data_ptr(), scratch.data_ptr())
+        held += [staged, scratch]         # (freed to the stream's pool after the launch below: ordered behind it)
+        outs.append(out)
     with torch.cuda.device(device):
-        _check(lib.gsr_png_unfilter(staged.data_ptr(), w, h, c, out.data_ptr(), scratch.data_ptr(), _stream_ptr(device)), "gsr_png_unfilter")
-    return out
+        _check(lib.gsr_png_unfilter_batch(len(jobs), ctypes.byref(table), _stream_ptr(device)), "gsr_png_unfilter_batch")
+    return outs
 
 
 def unfilter_png(raw: bytes, w: int, h: int, c: int, device) -> torch.Tensor:
     """The inflated scanline stream of an 8-bit RGB / RGBA PNG -> ``uint8[h, w, 4]`` on ``device`` (alpha 255 for RGB).  Blocking."""
     host = Staging(len(raw)).take(len(raw))
     ctypes.memmove(ctypes.c_void_p(host.data_ptr()), raw, len(raw))
-    out = _unfilter(host, w, h, c, device)
+    out, = _unfilter_many([(host, w, h, c)], device)
     torch.cuda.current_stream(device).synchronize()
     return out
 
 
+def load_rgba_many(paths, device, staging: Optional[Staging] = None):
+    """``blend_all.load_rgb`` (:56-60) for several files with the results on the GPU: per path ``uint8[H, W, 4]`` =
+    ``np.array(Image.open(path).convert("RGBA"))``, or None where the file does not exist.  The files the kernel covers are inflated
+    into ``staging`` and unfiltered by ONE batch launch; with a ``staging`` arena the call only queues work on the current stream."""
+    own = staging is None
+    if own:
+        staging = Staging()
+    results, jobs, slots = [None] * len(paths), [], []
+    for k, path in enumerate(paths):
+        if not os.path.exists(path):
+            continue
+        with open(path, "rb") as f:
+            buf = f.read()
+        parsed = png_chunks(buf)
+        if parsed is not None:
+            w, h, c, stream = parsed
+            stride = 1 + w * c
+            host = staging.take(h * stride)
+            if inflate_into(host, stream) and int(host.numpy()[0::stride].max()) <= 4:
+                jobs.append((host, w, h, c))
+                slots.append(k)
+                continue
+        from PIL import Image       # any other flavour (or a damaged file: Pillow says what is wrong with it), as in the reference
+        import io
+        results[k] = torch.from_numpy(np.array(Image.open(io.BytesIO(buf)).convert("RGBA"))).to(device)
+    for k, out in zip(slots, _unfilter_many(jobs, device)):
+        results[k] = out
+    if own:
+        torch.cuda.current_stream(device).synchronize()
+    return results
+
+
 def load_rgba(path: str, device, staging: Optional[Staging] = None) -> Optional[torch.Tensor]:
-    """``blend_all.load_rgb`` (:56-60) with the result on the GPU: ``uint8[H, W, 4]`` = ``np.array(Image.open(path).convert("RGBA"))``,
-    None when the file does not exist.  With a ``staging`` arena the call only queues work on the current stream."""
-    if not os.path.exists(path):
-        return None
-    with open(path, "rb") as f:
-        buf = f.read()
-    parsed = png_chunks(buf)
-    if parsed is not None:
-        w, h, c, stream = parsed
-        stride = 1 + w * c
-        own = staging is None
-        host = (Staging(h * stride) if own else staging).take(h * stride)
-        if inflate_into(host, stream) and int(host.numpy()[0::stride].max()) <= 4:
-            out = _unfilter(host, w, h, c, device)
-            if own:
-                torch.cuda.current_stream(device).synchronize()
-            return out
-    from PIL import Image       # any other flavour (or a damaged file: Pillow says what is wrong with it), as in the reference
-    import io
-    return torch.from_numpy(np.array(Image.open(io.BytesIO(buf)).convert("RGBA"))).to(device)
+    """``load_rgba_many`` for one file."""
+    return load_rgba_many([path], device, staging)[0]
 
 
 def _exr_plan(buf: bytes, want: Optional[str] = None):

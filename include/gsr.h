@@ -311,6 +311,14 @@ GSR_API int gsr_resize_f32_nearest(const float* src, int src_width, int src_heig
 GSR_API size_t gsr_png_unfilter_scratch(int width, int height);
 GSR_API int gsr_png_unfilter(const uint8_t* scanlines, int width, int height, int channels, uint8_t* out_rgba, uint8_t* scratch,
                              void* stream);
+/* Several images in one pair of launches (the layers of a frame: a workgroup each, side by side). */
+typedef struct GsrPngUnfilterJob {
+    const uint8_t* scanlines;
+    int width, height, channels;
+    uint8_t* out_rgba;
+    uint8_t* scratch;
+} GsrPngUnfilterJob;
+GSR_API int gsr_png_unfilter_batch(int count, const GsrPngUnfilterJob* jobs, void* stream);
 GSR_API int gsr_exr_unpack_channel(const uint8_t* blocks, int height, int bytes_per_line, int lines_per_block, int channel_at,
                                    int channel_bytes, uint8_t* plane, void* stream);
 GSR_API int gsr_upload(void* device_dst, const void* host_src, size_t bytes, void* stream);

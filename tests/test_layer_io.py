@@ -196,6 +196,34 @@ def test_load_rgba_is_load_rgb(tmp_path):
 
 
 @pytest.mark.gpu
+def test_load_rgba_many_is_one_batch_of_mixed_images(tmp_path):
+    """Eleven files of different sizes and channel counts (more than one launch holds), a palette image and a missing file among
+    them, on a side stream with a shared staging arena -- the way a ``blend_frames`` pool thread calls it."""
+    dev = torch.device("cuda", 0)
+    sizes = [(70, 90, 4), (1, 1, 3), (200, 33, 3), (64, 64, 4), (129, 257, 4), (5, 700, 3), (300, 300, 4), (66, 2, 4), (17, 17, 3), (90, 70, 4)]
+    paths = []
+    for k, (h, w, c) in enumerate(sizes):
+        p = str(tmp_path / f"{k}.png")
+        Image.fromarray(_noise(h, w, c, k)).save(p, compress_level=1 + k % 3)
+        paths.append(p)
+    pal = str(tmp_path / "pal.png")
+    Image.fromarray(_noise(40, 40, 3, 99)).convert("P").save(pal)
+    paths = paths[:4] + [pal, str(tmp_path / "missing.png")] + paths[4:]
+    staging = layer_io.Staging()
+    stream = torch.cuda.Stream(device=dev)
+    for _ in range(2):                                    # the second pass reuses the arena
+        staging.reset()
+        with torch.cuda.stream(stream):
+            got = layer_io.load_rgba_many(paths, dev, staging)
+        stream.synchronize()
+        for p, g in zip(paths, got):
+            if not os.path.exists(p):
+                assert g is None
+            else:
+                np.testing.assert_array_equal(g.cpu().numpy(), np.array(Image.open(p).convert("RGBA")), err_msg=p)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("compression", ["ZIPS", "ZIP"])
 @pytest.mark.parametrize("half", [False, True])
 @pytest.mark.parametrize("shape", [(1, 2), (16, 7), (17, 33), (54, 96), (100, 3), (540, 960)])
