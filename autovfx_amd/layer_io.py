@@ -129,7 +129,7 @@ def png_chunks(buf: bytes):
     w, h, depth, colour, compression, filtering, interlace = ihdr
     if depth != 8 or colour not in (2, 6) or compression or filtering or interlace or w < 1 or h < 1:
         return None
-    if _lib.lib.gsr_png_unfilter_scratch(w, h) == 0:
+    if _lib.lib.gsr_png_unfilter_scratch(w, h) == 0 or h * (1 + 4 * w) > (1 << 30):      # (too wide for the kernel / a header not to be trusted with staging memory)
         return None
     return w, h, (3 if colour == 2 else 4), (idat[0] if len(idat) == 1 else b"".join(idat))
 
