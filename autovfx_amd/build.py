@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(OUT_DIR, "libgsr_hip.so")
-SOURCES = ["gsr_kernels.hip", "gsr_binning.hip", "gsr_blend.hip", "gsr_backward.hip", "gsr_radix.hip", "gsr_frameio.hip", "gsr_layerio.hip", "gsr_api.hip"]
+SOURCES = ["gsr_kernels.hip", "gsr_binning.hip", "gsr_blend.hip", "gsr_backward.hip", "gsr_radix.hip", "gsr_frameio.hip", "gsr_layerio.hip", "gsr_layerfiles.hip", "gsr_api.hip"]
 HEADERS = [os.path.join(CSRC, "gsr_internal.h"), os.path.join(CSRC, "gsr_device.h"),
            os.path.join(HERE, "..", "include", "gsr.h")]
 # -ffp-contract=off: the parity contract is fp32 in the reference's operation order;
@@ -95,7 +95,7 @@ def build(force: bool = False, verbose: bool = False, trace: bool = False, unfus
             list(ex.map(run, jobs))
     if jobs or force or _stale(lib, objs):
         run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs,
-             "-Wl,--exclude-libs,ALL"])
+             "-Wl,--exclude-libs,ALL", "-lz"])      # zlib: gsr_layerfiles.hip (inflate, crc32 for the compositor's input files)
     return lib
 
 

@@ -843,6 +843,28 @@ int gsr_exr_unpack_channel(const uint8_t* blocks, int height, int bytes_per_line
     return GSR_OK;
 }
 
+static_assert(sizeof(GsrPngFileInfo) == sizeof(gsr::PngFileLayout) && sizeof(GsrExrFileInfo) == sizeof(gsr::ExrFileLayout), "file infos are passed through");
+
+int gsr_png_file_probe(const uint8_t* file, size_t file_bytes, GsrPngFileInfo* info) {
+    if (!file || !info) return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    return gsr::png_file_probe(file, file_bytes, reinterpret_cast<gsr::PngFileLayout*>(info));
+}
+
+int gsr_png_file_inflate(const uint8_t* file, size_t file_bytes, uint8_t* scanlines, size_t scanline_bytes) {
+    if (!file || !scanlines) return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    return gsr::png_file_inflate(file, file_bytes, scanlines, scanline_bytes);
+}
+
+int gsr_exr_file_probe(const uint8_t* file, size_t file_bytes, const char* channel, GsrExrFileInfo* info) {
+    if (!file || !info) return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    return gsr::exr_file_probe(file, file_bytes, channel, reinterpret_cast<gsr::ExrFileLayout*>(info));
+}
+
+int gsr_exr_file_inflate(const uint8_t* file, size_t file_bytes, const char* channel, uint8_t* blocks, size_t blocks_bytes) {
+    if (!file || !blocks) return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    return gsr::exr_file_inflate(file, file_bytes, channel, blocks, blocks_bytes);
+}
+
 int gsr_upload(void* device_dst, const void* host_src, size_t bytes, void* stream_) {
     if (bytes == 0) return GSR_OK;
     if (!device_dst || !host_src) return fail(GSR_ERR_INVALID_ARG, "null pointer");

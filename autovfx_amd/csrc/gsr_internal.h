@@ -380,6 +380,22 @@ hipError_t launch_png_unfilter_batch(int n, const PngUnfilterJob* jobs, hipStrea
 hipError_t launch_exr_unpack_channel(const uint8_t* blocks, int H, int bytes_per_line, int lines_per_block, int c_at, int c_bytes, uint8_t* plane,
                                      hipStream_t stream);
 
+// ---- the host side of the same files (gsr_layerfiles.hip: container parsing + zlib inflate, one call per file) ----
+struct PngFileLayout {       // (= GsrPngFileInfo, gsr.h)
+    int width, height, channels;
+    size_t scanline_bytes;   // height * (1 + width * channels)
+};
+struct ExrFileLayout {       // (= GsrExrFileInfo, gsr.h)
+    int width, height, bytes_per_line, lines_per_block, channel_at, channel_bytes, channel_is_half;
+    size_t blocks_bytes;     // height * bytes_per_line
+    char channel[32];
+};
+// 0: a file the kernels take; 1: not covered (another flavour, or damaged) -- a host decoder's.
+int png_file_probe(const uint8_t* file, size_t n, PngFileLayout* out);
+int png_file_inflate(const uint8_t* file, size_t n, uint8_t* scanlines, size_t scanline_bytes);
+int exr_file_probe(const uint8_t* file, size_t n, const char* want_channel, ExrFileLayout* out);
+int exr_file_inflate(const uint8_t* file, size_t n, const char* want_channel, uint8_t* blocks, size_t blocks_bytes);
+
 // ---- hand-written radix sort (gsr_radix.hip) ----
 // Stable ascending LSD sort on the low `bits` key bits, 8 per pass (count / scan / scatter kernels, no spinning,
 // nothing to zero-fill).  scratch: radix_scratch_words(n) u32 words of any content.  iota_payload: the payload

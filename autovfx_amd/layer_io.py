@@ -3,14 +3,15 @@
 ``blend_all.blend_frames`` (blender/blend_all.py:185-205) reads, per frame, six RGBA PNGs (``load_rgb``: ``Image.open(path).convert
 ("RGBA")``, :56-60) and four OpenEXR depth passes (``load_depth_exr``: ``cv2.imread(...)[:, :, 0]``, :70-75), all at Blender's
 resolution.  Decoding them with Pillow / numpy cost 0.34 s of host time per frame and bound the whole function.  Here the host does
-what only a host can do well -- parse the container, run zlib's inflate over each stream (byte-serial; it releases the interpreter
-lock) -- and uploads the inflated bytes as they are; the image predictors (PNG's five scanline filters, OpenEXR's byte-wise running
+what only a host can do well -- parse the container, run zlib's inflate over each stream (byte-serial; natively, one call per file,
+outside the interpreter lock: ``csrc/gsr_layerfiles.hip``) -- and uploads the inflated bytes as they are; the image predictors (PNG's five scanline filters, OpenEXR's byte-wise running
 sum and interleave) are undone by kernels (``gsr_png_unfilter``, ``gsr_exr_unpack_channel``).  The results are the arrays the
 reference's loaders return, bit for bit; a file the kernels do not cover (16-bit, palette, grey, interlaced or very wide PNGs; PIZ /
 tiled / stored-block EXRs) is decoded by Pillow / ``autovfx_amd.exr`` as before.
 
-Everything here runs on the CALLER's current stream.  The host side of a file is: parse, ``inflate`` straight into page-locked memory
-(zlib's ``uncompress`` through ctypes: no intermediate ``bytes``, no interpreter lock), one asynchronous copy from there.  Inflating
+Everything here runs on the CALLER's current stream.  The host side of a file is: read it, two native calls that parse it and
+``inflate`` it straight into page-locked memory (no intermediate ``bytes``, no interpreter lock), one asynchronous copy from there.
+The Python parsers in this module (``png_chunks``, ``_exr_plan`` ...) state the same rules readably; the tests hold the two together.  Inflating
 into ordinary memory and copying from it was the serial resource of ``blend_frames`` at 8 GB/s: pageable copies go through the
 runtime's single staging path.  A ``Staging`` arena belongs to one thread and one stream; ``reset()`` it once that stream has been
 synchronised.
@@ -97,6 +98,34 @@ def _upload(host: torch.Tensor, device) -> torch.Tensor:
     _check(_lib.lib.gsr_upload(ctypes.c_void_p(dst.data_ptr()), ctypes.cast(ctypes.c_void_p(host.data_ptr()), ctypes.c_char_p), host.numel(),
                                _stream_ptr(device)), "gsr_upload")
     return dst
+
+
+def read_png_scanlines(buf: bytes, staging: "Staging"):
+    """``(page-locked scanline stream, w, h, c)`` of a PNG file the unfilter kernel covers, or None: two native calls
+    (``gsr_png_file_probe`` / ``gsr_png_file_inflate``: chunk walk, CRCs, zlib's inflate straight into ``staging``, the filter-type
+    check), no interpreter lock held meanwhile.  ``png_chunks`` / ``png_scanlines`` below are the same logic in Python."""
+    lib = _lib.lib
+    info = _lib.PngFileInfo()
+    if lib.gsr_png_file_probe(buf, len(buf), ctypes.byref(info)) != 0:
+        return None
+    host = staging.take(info.scanline_bytes)
+    if lib.gsr_png_file_inflate(buf, len(buf), ctypes.c_void_p(host.data_ptr()), info.scanline_bytes) != 0:
+        return None
+    return host, info.width, info.height, info.channels
+
+
+def read_exr_blocks(buf: bytes, staging: "Staging", want: Optional[str] = None):
+    """``(page-locked inflated blocks, GsrExrFileInfo)`` of an OpenEXR file the unpack kernel covers, or None: two native calls
+    (``gsr_exr_file_probe`` / ``gsr_exr_file_inflate``).  ``_exr_plan`` / ``exr_blocks`` below are the same logic in Python."""
+    lib = _lib.lib
+    info = _lib.ExrFileInfo()
+    channel = None if want is None else want.encode()
+    if lib.gsr_exr_file_probe(buf, len(buf), channel, ctypes.byref(info)) != 0:
+        return None
+    host = staging.take(info.blocks_bytes)
+    if lib.gsr_exr_file_inflate(buf, len(buf), channel, ctypes.c_void_p(host.data_ptr()), info.blocks_bytes) != 0:
+        return None
+    return host, info
 
 
 def png_chunks(buf: bytes):
@@ -193,15 +222,11 @@ def load_rgba_many(paths, device, staging: Optional[Staging] = None):
             continue
         with open(path, "rb") as f:
             buf = f.read()
-        parsed = png_chunks(buf)
-        if parsed is not None:
-            w, h, c, stream = parsed
-            stride = 1 + w * c
-            host = staging.take(h * stride)
-            if inflate_into(host, stream) and int(host.numpy()[0::stride].max()) <= 4:
-                jobs.append((host, w, h, c))
-                slots.append(k)
-                continue
+        job = read_png_scanlines(buf, staging)
+        if job is not None:
+            jobs.append(job)
+            slots.append(k)
+            continue
         from PIL import Image       # any other flavour (or a damaged file: Pillow says what is wrong with it), as in the reference
         import io
         results[k] = torch.from_numpy(np.array(Image.open(io.BytesIO(buf)).convert("RGBA"))).to(device)
@@ -221,38 +246,48 @@ def _exr_plan(buf: bytes, want: Optional[str] = None):
     """``(header + layout, channel name, codec, [(compressed block, inflated size)] in increasing y)`` of a scanline OpenEXR file the
     unpack kernel covers -- ZIP / ZIPS / RLE, the wanted channel half or float, every block actually compressed -- or None."""
     try:
-        h = exr.read_header(buf)
-    except (ValueError, KeyError, IndexError, struct.error):
+        return _exr_plan_unchecked(buf, want)
+    except (ValueError, KeyError, IndexError, struct.error, OverflowError, UnicodeDecodeError):      # a damaged header
         return None
+
+
+def _exr_plan_unchecked(buf, want):
+    h = exr.read_header(buf)
     name, lines_per_block = exr._COMPRESSION.get(h["compression"], (None, 0))
-    if name not in ("ZIP", "ZIPS", "RLE"):
+    if name not in ("ZIP", "ZIPS", "RLE") or len(h["attributes"]["compression"][1]) != 1:
         return None
     names = [n for n, _p in h["channels"]]
-    pick = want if want is not None else next((n for n in ("B", "G", "R", "Y", "Z", "V") if n in names), names[0])
-    if pick not in names or dict(h["channels"])[pick] not in (1, 2):
+    if not names or any(p not in exr._PIXEL for _n, p in h["channels"]):
+        return None
+    pick = want if want else next((n for n in ("B", "G", "R", "Y", "Z", "V") if n in names), names[0])
+    if pick not in names:
         return None
     xmin, ymin, xmax, ymax = h["data_window"]
     W, H = xmax - xmin + 1, ymax - ymin + 1
-    bytes_per_line = sum(exr._PIXEL[p].itemsize for _n, p in h["channels"]) * W
-    n_blocks = (H + lines_per_block - 1) // lines_per_block
-    try:
-        offsets = struct.unpack_from(f"<{n_blocks}Q", buf, h["offsets_at"])
-        pieces = []
-        for k, off in enumerate(offsets):
-            y, size = struct.unpack_from("<ii", buf, off)
-            expected = min(lines_per_block, H - k * lines_per_block) * bytes_per_line
-            if y != ymin + k * lines_per_block or size >= expected or off + 8 + size > len(buf):   # (a block that did not shrink is stored without the predictor)
-                return None
-            pieces.append((buf[off + 8:off + 8 + size], expected))
-    except struct.error:
+    if W < 1 or H < 1 or W > (1 << 20) or H > (1 << 24):
         return None
-    c_at = 0
-    for n, p in h["channels"]:
-        if n == pick:
-            dt = exr._PIXEL[p]
-            break
+    bytes_per_line = sum(exr._PIXEL[p].itemsize for _n, p in h["channels"]) * W
+    if bytes_per_line * lines_per_block > (1 << 30) or bytes_per_line * H > (1 << 32):
+        return None
+    c_at, dt = 0, None
+    for n, p in h["channels"]:        # (a name listed twice: the first entry, as the native reader takes it)
+        if n == pick and dt is None:
+            dt, at_pick = exr._PIXEL[p], c_at
         c_at += exr._PIXEL[p].itemsize * W
-    layout = dict(h, width=W, height=H, bytes_per_line=bytes_per_line, lines_per_block=lines_per_block, channel_at=c_at, channel_bytes=dt.itemsize * W,
+    if dt.kind != "f":
+        return None
+    n_blocks = (H + lines_per_block - 1) // lines_per_block
+    offsets = struct.unpack_from(f"<{n_blocks}Q", buf, h["offsets_at"])
+    pieces = []
+    for k, off in enumerate(offsets):
+        if off + 8 > len(buf):
+            return None
+        y, size = struct.unpack_from("<ii", buf, off)
+        expected = min(lines_per_block, H - k * lines_per_block) * bytes_per_line
+        if y != ymin + k * lines_per_block or size < 0 or size >= expected or off + 8 + size > len(buf):   # (a block that did not shrink is stored without the predictor)
+            return None
+        pieces.append((buf[off + 8:off + 8 + size], expected))
+    layout = dict(h, width=W, height=H, bytes_per_line=bytes_per_line, lines_per_block=lines_per_block, channel_at=at_pick, channel_bytes=dt.itemsize * W,
                   channel_dtype=torch.float16 if dt.itemsize == 2 else torch.float32)
     return layout, pick, name, pieces
 
@@ -283,32 +318,17 @@ def load_depth(path: str, device, staging: Optional[Staging] = None) -> Optional
         return None
     with open(path, "rb") as f:
         buf = f.read()
-    plan = _exr_plan(buf)
-    if plan is not None:
-        L, _pick, name, pieces = plan
-        own = staging is None
-        total = L["height"] * L["bytes_per_line"]
-        host = (Staging(total) if own else staging).take(total)
-        at, ok = 0, True
-        for data, expected in pieces:
-            if name == "RLE":
-                try:
-                    ctypes.memmove(ctypes.c_void_p(host.data_ptr() + at), exr._rle_decode(data, expected), expected)
-                except ValueError:
-                    ok = False
-            else:
-                ok = inflate_into(host[at:at + expected], data)
-            if not ok:
-                break
-            at += expected
-        if ok:
-            staged = _upload(host, device)
-            plane = torch.empty((L["height"], L["channel_bytes"]), dtype=torch.uint8, device=device)
-            with torch.cuda.device(device):
-                _check(_lib.lib.gsr_exr_unpack_channel(staged.data_ptr(), L["height"], L["bytes_per_line"], L["lines_per_block"], L["channel_at"],
-                                                       L["channel_bytes"], plane.data_ptr(), _stream_ptr(device)), "gsr_exr_unpack_channel")
-            if own:
-                torch.cuda.current_stream(device).synchronize()
-            return plane.view(L["channel_dtype"])
+    own = staging is None
+    got = read_exr_blocks(buf, Staging() if own else staging)
+    if got is not None:
+        host, L = got
+        staged = _upload(host, device)
+        plane = torch.empty((L.height, L.channel_bytes), dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            _check(_lib.lib.gsr_exr_unpack_channel(staged.data_ptr(), L.height, L.bytes_per_line, L.lines_per_block, L.channel_at, L.channel_bytes,
+                                                   plane.data_ptr(), _stream_ptr(device)), "gsr_exr_unpack_channel")
+        if own:
+            torch.cuda.current_stream(device).synchronize()
+        return plane.view(torch.float16 if L.channel_is_half else torch.float32)
     from . import compositor       # OpenCV where installed, autovfx_amd.exr otherwise: what the kernels do not cover
     return torch.from_numpy(np.ascontiguousarray(compositor.load_depth_exr(path))).to(device)

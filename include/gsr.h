@@ -323,6 +323,30 @@ GSR_API int gsr_exr_unpack_channel(const uint8_t* blocks, int height, int bytes_
                                    int channel_bytes, uint8_t* plane, void* stream);
 GSR_API int gsr_upload(void* device_dst, const void* host_src, size_t bytes, void* stream);
 
+/* The HOST side of the same files, one native call per file (no GPU involved): container parsing and zlib's inflate, writing what the
+ * two kernels above take straight into the caller's buffer (page-locked, if gsr_upload is to be asynchronous).  `file`: the whole
+ * file in memory.  Return GSR_OK for a file the kernels cover, GSR_NOT_COVERED (1) for any other flavour or a damaged file -- decode
+ * those with the host library the reference uses (Pillow, OpenCV) --, a negative gsr_status for bad arguments.
+ *  PNG: 8-bit truecolour with / without alpha, not interlaced, no tRNS, at most 4096 wide; IHDR / IDAT CRCs verified, the stream must
+ *   inflate to exactly height * (1 + width * channels) bytes with filter types 0 ... 4.
+ *  OpenEXR: version 2 single-part scanline files, RLE / ZIPS / ZIP, no sub-sampling, every block actually compressed; `channel`:
+ *   the wanted channel, NULL for what cv2.imread(path, ANYCOLOR | ANYDEPTH)[:, :, 0] is (B, else G, R, Y, Z, V, else the first);
+ *   it must hold HALF or FLOAT samples.  blocks: info.blocks_bytes = height * bytes_per_line bytes, the blocks in increasing y. */
+#define GSR_NOT_COVERED 1
+typedef struct GsrPngFileInfo {
+    int width, height, channels;
+    size_t scanline_bytes;
+} GsrPngFileInfo;
+typedef struct GsrExrFileInfo {
+    int width, height, bytes_per_line, lines_per_block, channel_at, channel_bytes, channel_is_half;
+    size_t blocks_bytes;
+    char channel[32];
+} GsrExrFileInfo;
+GSR_API int gsr_png_file_probe(const uint8_t* file, size_t file_bytes, GsrPngFileInfo* info);
+GSR_API int gsr_png_file_inflate(const uint8_t* file, size_t file_bytes, uint8_t* scanlines, size_t scanline_bytes);
+GSR_API int gsr_exr_file_probe(const uint8_t* file, size_t file_bytes, const char* channel, GsrExrFileInfo* info);
+GSR_API int gsr_exr_file_inflate(const uint8_t* file, size_t file_bytes, const char* channel, uint8_t* blocks, size_t blocks_bytes);
+
 /* The sort stage on its own (what gsr_forward runs twice per call; replaces the reference's
  * cub::DeviceRadixSort::SortPairs, rasterizer_impl.cu:304-309): stable ascending sort of n (u32 key, u32
  * payload) pairs on the low `bits` key bits.  *_alt are ping-pong partners of the same length; on return

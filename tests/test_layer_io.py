@@ -89,6 +89,7 @@ def test_png_flavours_left_to_pillow():
     assert layer_io.png_scanlines(ok[:40] + bytes([ok[40] ^ 1]) + ok[41:]) is None    # a flipped bit: the chunk's CRC
     assert layer_io.png_scanlines(ok[:-30]) is None                                    # truncated
     assert layer_io.png_scanlines(b"GIF89a" + ok) is None
+    assert layer_io.png_scanlines(_png_file(_noise(2, 4097, 3, 2), [1, 4])) is None   # wider than the kernel's LDS rows: 4096
     for mode in ("P", "L", "LA", "I;16"):
         buf = io.BytesIO()
         Image.fromarray(img).convert(mode).save(buf, format="PNG")
@@ -139,6 +140,112 @@ def test_staging_arena_and_inflate_into():
         layer_io._libz = saved
 
 
+# ---- the native file readers (csrc/gsr_layerfiles.hip) against the Python restatement: host code, no GPU ----------------------------
+
+def _native_png(buf):
+    got = layer_io.read_png_scanlines(buf, layer_io.Staging())
+    return None if got is None else (got[1], got[2], got[3], bytes(got[0].numpy()))
+
+
+def _native_exr(buf, want=None):
+    got = layer_io.read_exr_blocks(buf, layer_io.Staging(), want)
+    if got is None:
+        return None
+    host, L = got
+    return ({k: getattr(L, k) for k in ("width", "height", "bytes_per_line", "lines_per_block", "channel_at", "channel_bytes")},
+            L.channel.decode("latin-1"), bool(L.channel_is_half), bytes(host.numpy()))
+
+
+def _python_exr(buf, want=None):
+    got = layer_io.exr_blocks(buf, want)
+    if got is None:
+        return None
+    L, pick, pieces = got
+    return ({k: L[k] for k in ("width", "height", "bytes_per_line", "lines_per_block", "channel_at", "channel_bytes")}, pick,
+            L["channel_dtype"] == torch.float16, b"".join(pieces))
+
+
+def _png_corpus():
+    img3, img4 = _noise(8, 8, 3, 1), _noise(19, 31, 4, 2)
+    ok = _png_file(img3, [0] * 8)
+    trns = struct.pack(">I", 6) + b"tRNS" + bytes(6) + struct.pack(">I", zlib.crc32(b"tRNS" + bytes(6)))
+    files = [ok, _png_file(img4, [(3 * y + 1) % 5 for y in range(19)], idat_pieces=5), _png_file(img4, [4] * 19, level=0),
+             _png_file(img3, [0] * 8, interlace=1), _png_file(img3, [0] * 8, depth=16), _png_file(img3, [0] * 8, colour=0),
+             _png_file(img3, [0] * 8, extra=trns), _png_file(img3, [0, 1, 2, 3, 4, 5, 0, 0]), ok[:40] + bytes([ok[40] ^ 1]) + ok[41:], ok[:-30],
+             b"GIF89a" + ok, _png_file(_noise(2, 4097, 3, 2), [1, 4]), _png_file(_noise(2, 4096, 3, 2), [1, 4]), b"", b"\x89PNG\r\n\x1a\n",
+             ok + b"trailing bytes after IEND"]
+    for mode in ("RGB", "RGBA", "P", "L", "LA", "I;16"):
+        buf = io.BytesIO()
+        Image.fromarray(img4).convert(mode).save(buf, format="PNG")
+        files.append(buf.getvalue())
+    # the stream holds more, or less, than the header's image
+    chunk = lambda kind, data: struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data))
+    for rows in (7, 9):
+        z = zlib.compress(_filter_rows(_noise(rows, 8, 3, 3), [1] * rows))
+        files.append(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 8, 8, 8, 2, 0, 0, 0)) + chunk(b"IDAT", z) + chunk(b"IEND", b""))
+    return files
+
+
+def test_native_png_reader_is_the_python_one():
+    """Same decision (covered / left to Pillow) and the same scanline bytes for every file of a corpus of good, odd and damaged PNGs, and
+    for every truncation and a sweep of single-byte corruptions of a good one."""
+    for k, buf in enumerate(_png_corpus()):
+        assert _native_png(buf) == layer_io.png_scanlines(buf), f"corpus file {k}"
+    good = _png_file(_noise(19, 31, 4, 2), [(3 * y + 1) % 5 for y in range(19)], idat_pieces=3)
+    assert _native_png(good) is not None
+    for cut in range(0, len(good), 7):
+        assert _native_png(good[:cut]) == layer_io.png_scanlines(good[:cut]), f"cut at {cut}"
+    g = np.random.default_rng(0)
+    for _ in range(300):
+        at = int(g.integers(0, len(good)))
+        bad = good[:at] + bytes([good[at] ^ (1 << int(g.integers(0, 8)))]) + good[at + 1:]
+        assert _native_png(bad) == layer_io.png_scanlines(bad), f"bit flipped in byte {at}"
+
+
+def _exr_corpus(tmp_path):
+    from test_exr import _hand_made
+    g = np.random.default_rng(5)
+    z = np.linspace(0.5, 9.0, 40 * 24, dtype=np.float32).reshape(40, 24)
+    files = []
+
+    def written(channels, **kw):
+        p = str(tmp_path / "f.exr")
+        exr.write_exr(p, channels, **kw)
+        return open(p, "rb").read()
+    files.append(written({"R": z, "G": z, "B": z + 1, "A": np.ones_like(z)}, compression="ZIP", half=True))
+    files.append(written({"R": z, "G": z, "B": z + 1, "A": np.ones_like(z)}, compression="ZIP", half=False, line_order_decreasing=True))
+    files.append(written({"Z": np.repeat(z, 8, axis=1)}, compression="ZIPS", half=True))
+    files.append(written({"V": np.repeat(z, 8, axis=1), "W": np.repeat(z, 8, axis=1)}, compression="ZIPS"))
+    files.append(written({"Q": np.repeat(z, 8, axis=1), "S": np.repeat(z, 8, axis=1)}, compression="ZIP"))       # none of B G R Y Z V: the first
+    files.append(written({"B": z}, compression="NONE"))
+    files.append(written({"B": g.random((16, 24)).astype(np.float32)}, compression="ZIP"))                          # stored block
+    files += [_hand_made(W=300, H=5, compressed="rle")[0], _hand_made(W=300, H=5, compressed=True)[0], _hand_made()[0]]
+    files += [b"not an exr file at all", b"", struct.pack("<ii", 20000630, 2), struct.pack("<ii", 20000630, 2 | 0x200) + files[0][8:]]
+    return files
+
+
+def test_native_exr_reader_is_the_python_one(tmp_path):
+    files = _exr_corpus(tmp_path)
+    for k, buf in enumerate(files):
+        assert _native_exr(buf) == _python_exr(buf), f"corpus file {k}"
+        for want in ("A", "G", "Z", "nope"):
+            assert _native_exr(buf, want) == _python_exr(buf, want), f"corpus file {k}, channel {want}"
+    good = files[0]
+    assert _native_exr(good) is not None and _native_exr(good)[1] == "B"
+    for cut in list(range(0, 700, 5)) + list(range(700, len(good), 97)):
+        assert _native_exr(good[:cut]) == _python_exr(good[:cut]), f"cut at {cut}"
+    g = np.random.default_rng(1)
+    for _ in range(300):
+        at = int(g.integers(0, len(good)))
+        bad = good[:at] + bytes([good[at] ^ (1 << int(g.integers(0, 8)))]) + good[at + 1:]
+        assert _native_exr(bad) == _python_exr(bad), f"bit flipped in byte {at}"
+    for k in (0, 7):                                       # every bit of the header, the offset table and the first block's head
+        for at in range(min(len(files[k]), 480)):
+            for bit in range(8):
+                bad = files[k][:at] + bytes([files[k][at] ^ (1 << bit)]) + files[k][at + 1:]
+                assert _native_exr(bad) == _python_exr(bad), f"file {k}: bit {bit} of byte {at} flipped"
+
+
 # ---- the kernels -----------------------------------------------------------------------------------------------------------------
 
 def _unfilter_on_gpu(data: bytes) -> np.ndarray:
@@ -186,7 +293,7 @@ def test_load_rgba_is_load_rgb(tmp_path):
     dev = torch.device("cuda", 0)
     img = _noise(70, 90, 4, 3)
     cases = {"rgba.png": Image.fromarray(img), "rgb.png": Image.fromarray(img[..., :3].copy()), "grey.png": Image.fromarray(img[..., 0].copy()),
-             "palette.png": Image.fromarray(img[..., :3].copy()).convert("P")}
+             "palette.png": Image.fromarray(img[..., :3].copy()).convert("P"), "wide.png": Image.fromarray(_noise(3, 4100, 4, 8))}   # (wider than the kernel takes)
     for name, im in cases.items():
         p = str(tmp_path / name)
         im.save(p)
