@@ -55,7 +55,13 @@ def main():
     buf = open(png, "rb").read()
     w, h, c, stream = layer_io.png_chunks(buf)
     host = staging.take(h * (1 + w * c))
-    out["png"]["host_parse_inflate_ms"] = round(_timed(lambda: (layer_io.png_chunks(buf), layer_io.inflate_into(host, stream)), 20), 3)
+    out["png"]["host_parse_inflate_python_ms"] = round(_timed(lambda: (layer_io.png_chunks(buf), layer_io.inflate_into(host, stream)), 20), 3)
+
+    def native_png():
+        staging.reset()
+        return layer_io.read_png_scanlines(buf, staging)
+    out["png"]["host_parse_inflate_ms"] = round(_timed(native_png, 20), 3)           # the product path: two native calls
+    host = native_png()[0]
     staged = layer_io._upload(host, dev)
     rgba = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
     scratch = torch.empty(layer_io._lib.lib.gsr_png_unfilter_scratch(w, h), dtype=torch.uint8, device=dev)
@@ -83,7 +89,13 @@ def main():
         for data, expected in pieces:
             layer_io.inflate_into(ehost[at:at + expected], data)
             at += expected
-    out["exr"]["host_parse_inflate_ms"] = round(_timed(lambda: (layer_io._exr_plan(ebuf), inflate_all()), 10), 3)
+    out["exr"]["host_parse_inflate_python_ms"] = round(_timed(lambda: (layer_io._exr_plan(ebuf), inflate_all()), 10), 3)
+
+    def native_exr():
+        staging.reset()
+        return layer_io.read_exr_blocks(ebuf, staging)
+    out["exr"]["host_parse_inflate_ms"] = round(_timed(native_exr, 10), 3)           # the product path: two native calls
+    ehost = native_exr()[0]
     estaged = layer_io._upload(ehost, dev)
     plane = torch.empty((L["height"], L["channel_bytes"]), dtype=torch.uint8, device=dev)
     out["exr"]["upload_ms"] = round(gpu_ms(lambda: layer_io._upload(ehost, dev)), 4)
