@@ -36,7 +36,8 @@ class PngFileInfo(ctypes.Structure):
 class ExrFileInfo(ctypes.Structure):
     """``GsrExrFileInfo`` (gsr.h)."""
     _fields_ = [("width", ctypes.c_int), ("height", ctypes.c_int), ("bytes_per_line", ctypes.c_int), ("lines_per_block", ctypes.c_int),
-                ("channel_at", ctypes.c_int), ("channel_bytes", ctypes.c_int), ("channel_is_half", ctypes.c_int), ("blocks_bytes", ctypes.c_size_t),
+                ("channel_at", ctypes.c_int), ("channel_bytes", ctypes.c_int), ("channel_is_half", ctypes.c_int), ("compression", ctypes.c_int),
+                ("n_blocks", ctypes.c_int), ("blocks_bytes", ctypes.c_size_t),
                 ("channel", ctypes.c_char * 32)]
 
 
@@ -50,7 +51,7 @@ FORWARD_INFERENCE = 1
 # every symbol include/gsr.h declares
 SYMBOLS = ("gsr_forward", "gsr_mark_visible", "gsr_backward", "gsr_last_geom_offsets", "gsr_last_binning_offsets",
            "gsr_last_image_offsets", "gsr_set_stage_timing", "gsr_get_stage_times", "gsr_last_error",
-           "gsr_abi_version", "gsr_target_arch", "gsr_set_option", "gsr_get_option", "gsr_pack_rgba8", "gsr_png_size", "gsr_png_room", "gsr_png_encode", "gsr_frame_files", "gsr_png_deflate_max_size", "gsr_png_deflate_room", "gsr_png_deflate_scratch", "gsr_png_encode_deflate", "gsr_frame_files_deflate", "gsr_resize_rgba8_bilinear", "gsr_resize_f32_nearest", "gsr_png_unfilter_scratch", "gsr_png_unfilter", "gsr_png_unfilter_batch", "gsr_exr_unpack_channel", "gsr_upload", "gsr_png_file_probe", "gsr_png_file_inflate", "gsr_exr_file_probe", "gsr_exr_file_inflate", "gsr_last_pair_counts", "gsr_blend", "gsr_composite",
+           "gsr_abi_version", "gsr_target_arch", "gsr_set_option", "gsr_get_option", "gsr_pack_rgba8", "gsr_png_size", "gsr_png_room", "gsr_png_encode", "gsr_frame_files", "gsr_png_deflate_max_size", "gsr_png_deflate_room", "gsr_png_deflate_scratch", "gsr_png_encode_deflate", "gsr_frame_files_deflate", "gsr_resize_rgba8_bilinear", "gsr_resize_f32_nearest", "gsr_png_unfilter_scratch", "gsr_png_unfilter", "gsr_png_unfilter_batch", "gsr_exr_unpack_channel", "gsr_upload", "gsr_png_file_probe", "gsr_png_file_inflate", "gsr_exr_file_probe", "gsr_exr_file_inflate", "gsr_selftest_inflate_host", "gsr_exr_file_pack", "gsr_inflate_zlib_blocks", "gsr_last_pair_counts", "gsr_blend", "gsr_composite",
            "gsr_radix_scratch_bytes", "gsr_radix_sort_pairs", "gsr_selftest_exp", "gsr_view_normals", "gsr_normal_maps", "gsr_forward_extra", "gsr_get_call_times",
            "gsr_forward_begin", "gsr_forward_finish", "gsr_forward_ready", "gsr_forward_cancel", "gsr_last_slab_pairs", "gsr_plan_slabs", "gsr_selftest_lds_atomic_order", "gsr_get_backward_times", "gsr_place_object",
            "gsr_forward_raw", "gsr_forward_raw_begin", "gsr_backward_raw", "gsr_place_object_subset")
@@ -186,6 +187,12 @@ def _load() -> ctypes.CDLL:
     lib.gsr_exr_file_probe.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_void_p]
     lib.gsr_exr_file_inflate.restype = ctypes.c_int
     lib.gsr_exr_file_inflate.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t]
+    lib.gsr_exr_file_pack.restype = ctypes.c_int
+    lib.gsr_exr_file_pack.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    lib.gsr_inflate_zlib_blocks.restype = ctypes.c_int
+    lib.gsr_inflate_zlib_blocks.argtypes = [c_f, c_f, c_f, ctypes.c_int, c_f, c_f, ctypes.c_void_p]
+    lib.gsr_selftest_inflate_host.restype = ctypes.c_int
+    lib.gsr_selftest_inflate_host.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
     lib.gsr_upload.restype = ctypes.c_int
     lib.gsr_upload.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
     lib.gsr_resize_rgba8_bilinear.restype = ctypes.c_int

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(OUT_DIR, "libgsr_hip.so")
 SOURCES = ["gsr_kernels.hip", "gsr_binning.hip", "gsr_blend.hip", "gsr_backward.hip", "gsr_radix.hip", "gsr_frameio.hip", "gsr_layerio.hip", "gsr_layerfiles.hip", "gsr_api.hip"]
-HEADERS = [os.path.join(CSRC, "gsr_internal.h"), os.path.join(CSRC, "gsr_device.h"),
+HEADERS = [os.path.join(CSRC, "gsr_internal.h"), os.path.join(CSRC, "gsr_device.h"), os.path.join(CSRC, "gsr_inflate_core.h"),
            os.path.join(HERE, "..", "include", "gsr.h")]
 # -ffp-contract=off: the parity contract is fp32 in the reference's operation order;
 # no -ffast-math: IEEE divide / sqrt, accurate expf.

@@ -177,23 +177,26 @@ def _thread_stream(dev):
     return stream
 
 
-def _load_frame_layers_to_gpu(cache, bg_path, i, dev, staging):
+def _load_frame_layers_to_gpu(cache, bg_path, i, dev, staging, error_flag=None):
     """The same layers as GPU tensors (``uint8[H, W, 4]``; depth in the file's precision), queued on the CURRENT stream: the host
     inflates the files' zlib streams into ``staging`` (page-locked) and copies from there, kernels undo the PNG filters / the EXR
-    predictor (``autovfx_amd.layer_io``).  ``staging`` may be reset once the stream has been synchronised."""
+    predictor (``autovfx_amd.layer_io``).  ``staging`` may be reset once the stream has been synchronised.  With ``error_flag`` the
+    EXR passes' zlib streams are inflated on the GPU as well (a refused stream sets the flag)."""
     import os
     from . import layer_io
     pngs = [bg_path] + [os.path.join(cache, kind, "{:0>3d}.png".format(i + 1)) for kind in _LAYERS_RGB]
     out = dict(zip(("bg",) + _LAYERS_RGB, layer_io.load_rgba_many(pngs, dev, staging)))       # (one launch for the frame's PNGs)
-    for kind in _LAYERS_DEPTH:
-        out[kind] = layer_io.load_depth(os.path.join(cache, kind, "{:0>3d}".format(i + 1), "Image{:0>4d}.exr".format(i + 1)), dev, staging)
+    exrs = [os.path.join(cache, kind, "{:0>3d}".format(i + 1), "Image{:0>4d}.exr".format(i + 1)) for kind in _LAYERS_DEPTH]
+    out.update(zip(_LAYERS_DEPTH, layer_io.load_depth_many(exrs, dev, staging, error_flag)))    # (one inflate launch for the four passes)
     return out
 
 
-def _blend_one_frame(cache, bg_path, i, dev, out_path, want_frame, stats=None):
+def _blend_one_frame(cache, bg_path, i, dev, out_path, want_frame, stats=None, exr_on_gpu=None):
     """Frame ``i`` of ``blend_frames`` from its files to its file (blend_all.py:185-337), on the calling pool thread and its stream."""
     import time
-    from . import frame_io
+    from . import frame_io, layer_io
+    if exr_on_gpu is None:
+        exr_on_gpu = layer_io.exr_inflate_on_gpu()
     t0 = time.perf_counter()
     staging = _worker_local.__dict__.get("staging") if _worker_local is not None else None
     if staging is None:
@@ -202,7 +205,8 @@ def _blend_one_frame(cache, bg_path, i, dev, out_path, want_frame, stats=None):
         staging = _worker_local.__dict__["staging"] = layer_io.Staging()
     staging.reset()                                 # (the previous frame of this thread ended with a wait for its stream)
     with torch.cuda.stream(_thread_stream(dev)):
-        L = _load_frame_layers_to_gpu(cache, bg_path, i, dev, staging)
+        error_flag = torch.zeros(1, dtype=torch.int32, device=dev) if exr_on_gpu else None
+        L = _load_frame_layers_to_gpu(cache, bg_path, i, dev, staging, error_flag)
         t1 = time.perf_counter()
         bg_c = L["bg"]
         o_c, o_d = L["rgb_obj"], L["depth_obj"]
@@ -222,6 +226,9 @@ def _blend_one_frame(cache, bg_path, i, dev, out_path, want_frame, stats=None):
         png = frame_io.encode_png_gpu_deflate(frame) if frame_io.deflate_default() else frame_io.encode_png_gpu(frame)
         t2 = time.perf_counter()
         data = png.cpu().numpy()                   # (waits for this thread's stream: the frame is finished, the staging memory free)
+        if error_flag is not None and int(error_flag.cpu()) != 0:
+            # the GPU's decoder refused a depth pass's zlib stream: once more with zlib on the host, which reads it or says why not
+            return _blend_one_frame(cache, bg_path, i, dev, out_path, want_frame, stats, exr_on_gpu=False)
         host_frame = frame.cpu().numpy() if want_frame else None
     t3 = time.perf_counter()
     with open(out_path, "wb") as f:

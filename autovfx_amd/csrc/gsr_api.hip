@@ -865,6 +865,25 @@ int gsr_exr_file_inflate(const uint8_t* file, size_t file_bytes, const char* cha
     return gsr::exr_file_inflate(file, file_bytes, channel, blocks, blocks_bytes);
 }
 
+static_assert(sizeof(GsrInflateJob) == sizeof(gsr::InflateJob), "GsrInflateJob is passed through as it is");
+
+int gsr_exr_file_pack(const uint8_t* file, size_t file_bytes, const char* channel, uint8_t* packed, size_t packed_room, GsrInflateJob* jobs, size_t* packed_bytes) {
+    if (!file || !packed || !jobs || !packed_bytes) return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    return gsr::exr_file_pack(file, file_bytes, channel, packed, packed_room, reinterpret_cast<gsr::InflateJob*>(jobs), packed_bytes);
+}
+
+int gsr_inflate_zlib_blocks(const uint8_t* streams, uint8_t* out, const GsrInflateJob* jobs, int count, int* status, int* any_error, void* stream_) {
+    if (count < 0 || (count > 0 && (!streams || !out || !jobs || !status))) return fail(GSR_ERR_INVALID_ARG, "gsr_inflate_zlib_blocks: bad arguments");
+    if ((reinterpret_cast<uintptr_t>(streams) & 3u) != 0) return fail(GSR_ERR_INVALID_ARG, "gsr_inflate_zlib_blocks: streams must be 4-byte aligned");
+    GSR_HIP(gsr::launch_inflate_zlib_blocks(streams, out, reinterpret_cast<const gsr::InflateJob*>(jobs), count, status, any_error, (hipStream_t)stream_));
+    return GSR_OK;
+}
+
+int gsr_selftest_inflate_host(const uint8_t* zlib_stream, size_t stream_bytes, uint8_t* out, size_t out_bytes) {
+    if (!zlib_stream || (!out && out_bytes)) return fail(GSR_ERR_INVALID_ARG, "null pointer");
+    return gsr::inflate_zlib_host(zlib_stream, stream_bytes, out, out_bytes);
+}
+
 int gsr_upload(void* device_dst, const void* host_src, size_t bytes, void* stream_) {
     if (bytes == 0) return GSR_OK;
     if (!device_dst || !host_src) return fail(GSR_ERR_INVALID_ARG, "null pointer");

@@ -380,6 +380,13 @@ hipError_t launch_png_unfilter_batch(int n, const PngUnfilterJob* jobs, hipStrea
 hipError_t launch_exr_unpack_channel(const uint8_t* blocks, int H, int bytes_per_line, int lines_per_block, int c_at, int c_bytes, uint8_t* plane,
                                      hipStream_t stream);
 
+// zlib streams inflated on the GPU, a single-wave workgroup each.  jobs / status / any_error: DEVICE memory; src_at multiples of 4,
+// `streams` readable up to the next multiple of 4 behind every stream.  status[i]: 0 or an inflate::Status; *any_error is OR-ed with 1.
+struct InflateJob {          // (= GsrInflateJob, gsr.h)
+    uint32_t src_at, src_bytes, dst_at, dst_bytes;
+};
+hipError_t launch_inflate_zlib_blocks(const uint8_t* streams, uint8_t* out, const InflateJob* jobs, int count, int* status, int* any_error, hipStream_t stream);
+
 // ---- the host side of the same files (gsr_layerfiles.hip: container parsing + zlib inflate, one call per file) ----
 struct PngFileLayout {       // (= GsrPngFileInfo, gsr.h)
     int width, height, channels;
@@ -387,6 +394,7 @@ struct PngFileLayout {       // (= GsrPngFileInfo, gsr.h)
 };
 struct ExrFileLayout {       // (= GsrExrFileInfo, gsr.h)
     int width, height, bytes_per_line, lines_per_block, channel_at, channel_bytes, channel_is_half;
+    int compression, n_blocks;   // the file's compression attribute (1 RLE, 2 ZIPS, 3 ZIP); scanline blocks in the part
     size_t blocks_bytes;     // height * bytes_per_line
     char channel[32];
 };
@@ -395,6 +403,12 @@ int png_file_probe(const uint8_t* file, size_t n, PngFileLayout* out);
 int png_file_inflate(const uint8_t* file, size_t n, uint8_t* scanlines, size_t scanline_bytes);
 int exr_file_probe(const uint8_t* file, size_t n, const char* want_channel, ExrFileLayout* out);
 int exr_file_inflate(const uint8_t* file, size_t n, const char* want_channel, uint8_t* blocks, size_t blocks_bytes);
+// ZIP / ZIPS files: the blocks' zlib streams copied one behind the other at 4-byte aligned offsets into `packed` (room: n + 4 * n_blocks
+// + 4 bytes), jobs[n_blocks] filled for launch_inflate_zlib_blocks; *packed_bytes: what to upload.
+int exr_file_pack(const uint8_t* file, size_t n, const char* want_channel, uint8_t* packed, size_t packed_room, InflateJob* jobs, size_t* packed_bytes);
+
+// gsr_inflate_core.h's decoder run by one host lane (tests); 0 or an inflate::Status
+int inflate_zlib_host(const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_len);
 
 // ---- hand-written radix sort (gsr_radix.hip) ----
 // Stable ascending LSD sort on the low `bits` key bits, 8 per pass (count / scan / scatter kernels, no spinning,

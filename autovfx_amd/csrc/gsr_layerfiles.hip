@@ -11,6 +11,7 @@
 // scanline files ("OpenEXR File Layout"), compression RLE / ZIPS / ZIP, the wanted channel HALF or FLOAT, no sub-sampling.  Anything
 // else is reported as "not covered" (the caller's host decoder reads it), never guessed at.
 #include "gsr_internal.h"
+#include "gsr_inflate_core.h"
 
 #include <zlib.h>
 
@@ -184,6 +185,8 @@ bool walk_exr(const uint8_t* f, size_t n, const char* want, ExrWalk* out) {
     L.channel_bytes = (int)((chans[pick].type == 1 ? 2 : 4) * W);
     L.channel_is_half = chans[pick].type == 1;
     L.blocks_bytes = (size_t)(bytes_per_line * H);
+    L.compression = out->compression;
+    L.n_blocks = (int)((H + lines_per_block - 1) / lines_per_block);
     std::memset(L.channel, 0, sizeof L.channel);
     std::strncpy(L.channel, chans[pick].name, sizeof L.channel - 1);
     out->n_blocks = (int)((H + lines_per_block - 1) / lines_per_block);
@@ -224,6 +227,15 @@ bool exr_rle_decode(const uint8_t* in, size_t n_in, uint8_t* out, size_t n_out) 
 
 } // namespace
 
+// The wave decoder's host instantiation (one lane): what the CPU tests compare with zlib.  src need not be aligned here.
+int inflate_zlib_host(const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_len) {
+    std::vector<uint32_t> aligned((src_len + 3) / 4 + 2, 0u);
+    std::memcpy(aligned.data(), src, src_len);
+    std::vector<uint8_t> shared(sizeof(inflate::Shared));
+    return inflate::inflate_zlib<1>(reinterpret_cast<const uint8_t*>(aligned.data()), src_len, dst, dst_len,
+                                    *reinterpret_cast<inflate::Shared*>(shared.data()));
+}
+
 int png_file_probe(const uint8_t* file, size_t n, PngFileLayout* out) {
     PngWalk w;
     if (!walk_png(file, n, &w)) return 1;
@@ -254,7 +266,7 @@ int png_file_inflate(const uint8_t* file, size_t n, uint8_t* scanlines, size_t s
                 z.next_out = spill;
                 z.avail_out = sizeof spill;
             }
-            rc = inflate(&z, Z_NO_FLUSH);
+            rc = ::inflate(&z, Z_NO_FLUSH);
             if (z.total_out > scanline_bytes) rc = Z_DATA_ERROR;
         }
     }
@@ -292,6 +304,27 @@ int exr_file_inflate(const uint8_t* file, size_t n, const char* want_channel, ui
         }
         at += expected;
     }
+    return 0;
+}
+
+int exr_file_pack(const uint8_t* file, size_t n, const char* want_channel, uint8_t* packed, size_t packed_room, InflateJob* jobs, size_t* packed_bytes) {
+    ExrWalk w;
+    if (!walk_exr(file, n, want_channel, &w) || w.compression == 1) return 1;      // (RLE is not a zlib stream: exr_file_inflate)
+    const ExrFileLayout& L = w.layout;
+    size_t at = 0, out_at = 0;
+    for (int k = 0; k < w.n_blocks; ++k) {
+        const uint64_t off = le64(file + w.offsets_at + 8 * (size_t)k);
+        const size_t size = (size_t)le32(file + off + 4);
+        const size_t lines = (size_t)std::min<long long>(L.lines_per_block, (long long)L.height - (long long)k * L.lines_per_block);
+        const size_t padded = (size + 3) & ~(size_t)3;
+        if (at + padded > packed_room) return 1;
+        std::memcpy(packed + at, file + off + 8, size);
+        std::memset(packed + at + size, 0, padded - size);
+        jobs[k] = {(uint32_t)at, (uint32_t)size, (uint32_t)out_at, (uint32_t)(lines * (size_t)L.bytes_per_line)};
+        at += padded;
+        out_at += lines * (size_t)L.bytes_per_line;
+    }
+    *packed_bytes = at;
     return 0;
 }
 

@@ -16,9 +16,14 @@
 //       sum and the even / odd byte interleave, OpenEXR "ImfZip.cpp" as the file format documents it) -> the bytes of ONE channel's
 //       plane.  One workgroup per block: per-thread run totals, a workgroup scan, a second walk that stores the wanted bytes.
 //
+//   inflate_zlib_kernel : the zlib streams of an OpenEXR ZIP / ZIPS part themselves (one per scanline block: 68 for a 1080p pass) ->
+//       the predictor-coded blocks exr_unpack_channel_kernel takes.  One single-wave workgroup per stream, the window in LDS:
+//       gsr_inflate_core.h (the same source runs on one host lane under the CPU tests).
+//
 // Host-side mirror: autovfx_amd/layer_io.py (chunk / header parsing, zlib, the fall-back to Pillow / autovfx_amd.exr for files these
 // kernels do not cover).
 #include "gsr_internal.h"
+#include "gsr_inflate_core.h"
 
 #include <algorithm>
 #include <mutex>
@@ -253,7 +258,24 @@ __global__ void __launch_bounds__(kExrThreads) exr_unpack_channel_kernel(ExrPlan
     }
 }
 
+// ---- zlib streams: one single-wave workgroup per stream (gsr_inflate_core.h) ----------------------------------------------------
+__global__ void __launch_bounds__(64) inflate_zlib_kernel(const uint8_t* __restrict__ streams, uint8_t* __restrict__ out, const InflateJob* __restrict__ jobs,
+                                                          int* __restrict__ status, int* __restrict__ any_error) {
+    __shared__ inflate::Shared sh;
+    const InflateJob j = jobs[blockIdx.x];
+    const int rc = inflate::inflate_zlib<64>(streams + j.src_at, j.src_bytes, out + j.dst_at, j.dst_bytes, sh);
+    if (threadIdx.x == 0) {
+        status[blockIdx.x] = rc;
+        if (rc != 0 && any_error) atomicOr(any_error, 1);
+    }
+}
+
 } // namespace
+
+hipError_t launch_inflate_zlib_blocks(const uint8_t* streams, uint8_t* out, const InflateJob* jobs, int count, int* status, int* any_error, hipStream_t stream) {
+    if (count > 0) hipLaunchKernelGGL(inflate_zlib_kernel, dim3(count), dim3(64), 0, stream, streams, out, jobs, status, any_error);
+    return hipGetLastError();
+}
 
 size_t png_unfilter_scratch_bytes(int W, int H) {
     if (W <= 0 || H <= 0 || W > kUnfMaxWidth) return 0;

@@ -310,25 +310,121 @@ def exr_blocks(buf: bytes, want: Optional[str] = None):
     return layout, pick, out
 
 
-def load_depth(path: str, device, staging: Optional[Staging] = None) -> Optional[torch.Tensor]:
-    """``blend_all.load_depth_exr`` (:70-75) with the result on the GPU: the plane ``cv2.imread(path, ANYCOLOR | ANYDEPTH)[:, :, 0]``
-    returns (the file's B channel), in the file's precision (float16 for Blender's half-float passes: widening it to float32 is exact
-    and the caller's); None when the file does not exist.  With a ``staging`` arena the call only queues work on the current stream."""
-    if not os.path.exists(path):
-        return None
-    with open(path, "rb") as f:
-        buf = f.read()
+def exr_inflate_on_gpu() -> bool:
+    """Whether ZIP / ZIPS OpenEXR blocks are inflated by the GPU (``AUTOVFX_AMD_EXR_INFLATE=gpu``, the default) or by zlib on the host."""
+    return os.environ.get("AUTOVFX_AMD_EXR_INFLATE", "gpu").lower() != "host"
+
+
+def inflate_zlib_streams(streams, sizes, device):
+    """Independent zlib streams inflated on the GPU (``gsr_inflate_zlib_blocks``: a single-wave workgroup each): ``(out uint8[sum(sizes)],
+    status int32[n])`` device tensors; stream i must inflate to exactly ``sizes[i]`` bytes, ``status[i]`` says whether it did.  Blocking."""
+    n = len(streams)
+    jobs = np.zeros((n, 4), np.uint32)
+    at = out_at = 0
+    for k, (data, size) in enumerate(zip(streams, sizes)):
+        jobs[k] = (at, len(data), out_at, size)
+        at += (len(data) + 3) & ~3
+        out_at += size
+    packed = np.zeros(at + 4, np.uint8)
+    for k, data in enumerate(streams):
+        packed[jobs[k, 0]:jobs[k, 0] + len(data)] = np.frombuffer(data, np.uint8)
+    d_packed, d_jobs = torch.from_numpy(packed).to(device), torch.from_numpy(jobs.view(np.int32)).to(device)
+    out = torch.empty(max(out_at, 1), dtype=torch.uint8, device=device)
+    status = torch.full((max(n, 1),), -1, dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        _check(_lib.lib.gsr_inflate_zlib_blocks(d_packed.data_ptr(), out.data_ptr(), d_jobs.data_ptr(), n, status.data_ptr(), None, _stream_ptr(device)),
+               "gsr_inflate_zlib_blocks")
+    torch.cuda.current_stream(device).synchronize()
+    return out[:out_at], status[:n]
+
+
+def _depth_blocks_on_gpu(bufs, device, staging: Staging, error_flag):
+    """The inflated blocks of several ZIP / ZIPS OpenEXR files as device tensors, inflated ON the GPU by ONE launch (a single-wave
+    workgroup per scanline block of every file): the host only copies the compressed streams together (``gsr_exr_file_pack``).  Per
+    file ``(blocks, info)`` or None (not covered: RLE, another codec, a damaged header).  A stream the decoder refuses sets
+    ``error_flag`` (device int32[1]) -- the caller looks at it once its stream has drained and reads the files on the host instead."""
+    lib = _lib.lib
+    infos = []
+    for buf in bufs:
+        info = _lib.ExrFileInfo()
+        ok = buf is not None and lib.gsr_exr_file_probe(buf, len(buf), None, ctypes.byref(info)) == 0 and info.compression != 1
+        infos.append(info if ok else None)
+    n_jobs = sum(i.n_blocks for i in infos if i is not None)
+    if n_jobs == 0:
+        return [None] * len(bufs)
+    room = sum(len(b) + 4 * i.n_blocks + 4 for b, i in zip(bufs, infos) if i is not None)
+    host = staging.take(16 * n_jobs + room)                       # [jobs of every file | their packed streams]: one upload
+    jobs = host[:16 * n_jobs].numpy().view(np.uint32).reshape(n_jobs, 4)
+    job_at, packed_at, out_at, spans = 0, 0, 0, []
+    for k, (buf, info) in enumerate(zip(bufs, infos)):
+        if info is None:
+            spans.append(None)
+            continue
+        packed_bytes = ctypes.c_size_t(0)
+        if lib.gsr_exr_file_pack(buf, len(buf), None, ctypes.c_void_p(host.data_ptr() + 16 * n_jobs + packed_at), room - packed_at,
+                                 ctypes.c_void_p(host.data_ptr() + 16 * job_at), ctypes.byref(packed_bytes)) != 0:
+            raise RuntimeError("gsr_exr_file_pack refused a file gsr_exr_file_probe covers")
+        mine = jobs[job_at:job_at + info.n_blocks]
+        mine[:, 0] += packed_at                                   # the file's offsets -> offsets into the common buffers
+        mine[:, 2] += out_at
+        spans.append((out_at, info.blocks_bytes))
+        job_at += info.n_blocks
+        packed_at += (packed_bytes.value + 15) & ~15
+        out_at += (info.blocks_bytes + 15) & ~15
+    staged = _upload(host[:16 * n_jobs + packed_at + 4], device)
+    blocks = torch.empty(out_at, dtype=torch.uint8, device=device)
+    status = torch.empty(n_jobs, dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        _check(lib.gsr_inflate_zlib_blocks(staged.data_ptr() + 16 * n_jobs, blocks.data_ptr(), staged.data_ptr(), n_jobs, status.data_ptr(),
+                                           error_flag.data_ptr(), _stream_ptr(device)), "gsr_inflate_zlib_blocks")
+    return [None if sp is None else (blocks[sp[0]:sp[0] + sp[1]], info) for sp, info in zip(spans, infos)]
+
+
+def _unpack_plane(staged: torch.Tensor, L, device) -> torch.Tensor:
+    plane = torch.empty((L.height, L.channel_bytes), dtype=torch.uint8, device=device)
+    with torch.cuda.device(device):
+        _check(_lib.lib.gsr_exr_unpack_channel(staged.data_ptr(), L.height, L.bytes_per_line, L.lines_per_block, L.channel_at, L.channel_bytes,
+                                               plane.data_ptr(), _stream_ptr(device)), "gsr_exr_unpack_channel")
+    return plane.view(torch.float16 if L.channel_is_half else torch.float32)
+
+
+def load_depth_many(paths, device, staging: Optional[Staging] = None, error_flag: Optional[torch.Tensor] = None):
+    """``blend_all.load_depth_exr`` (:70-75) for several files with the results on the GPU: per path the plane
+    ``cv2.imread(path, ANYCOLOR | ANYDEPTH)[:, :, 0]`` returns (the file's B channel) in the file's precision (float16 for Blender's
+    half-float passes: widening it to float32 is exact and the caller's), None where the file does not exist.  With a ``staging`` arena
+    the call only queues work on the current stream.  With ``error_flag`` (device int32[1], zero) the zlib streams of ZIP / ZIPS files
+    are inflated by the GPU, all files' blocks in one launch; the caller checks the flag after synchronising and, if it is set, calls
+    again without it (zlib on the host then says what is wrong with the file)."""
     own = staging is None
-    got = read_exr_blocks(buf, Staging() if own else staging)
-    if got is not None:
-        host, L = got
-        staged = _upload(host, device)
-        plane = torch.empty((L.height, L.channel_bytes), dtype=torch.uint8, device=device)
-        with torch.cuda.device(device):
-            _check(_lib.lib.gsr_exr_unpack_channel(staged.data_ptr(), L.height, L.bytes_per_line, L.lines_per_block, L.channel_at, L.channel_bytes,
-                                                   plane.data_ptr(), _stream_ptr(device)), "gsr_exr_unpack_channel")
-        if own:
-            torch.cuda.current_stream(device).synchronize()
-        return plane.view(torch.float16 if L.channel_is_half else torch.float32)
-    from . import compositor       # OpenCV where installed, autovfx_amd.exr otherwise: what the kernels do not cover
-    return torch.from_numpy(np.ascontiguousarray(compositor.load_depth_exr(path))).to(device)
+    if own:
+        staging = Staging()
+    bufs = []
+    for path in paths:
+        if os.path.exists(path):
+            with open(path, "rb") as f:
+                bufs.append(f.read())
+        else:
+            bufs.append(None)
+    on_gpu = _depth_blocks_on_gpu(bufs, device, staging, error_flag) if error_flag is not None else [None] * len(bufs)
+    results = []
+    for path, buf, got in zip(paths, bufs, on_gpu):
+        if buf is None:
+            results.append(None)
+            continue
+        if got is None:
+            host_got = read_exr_blocks(buf, staging)
+            if host_got is not None:
+                got = (_upload(host_got[0], device), host_got[1])
+        if got is not None:
+            results.append(_unpack_plane(got[0], got[1], device))
+        else:
+            from . import compositor       # OpenCV where installed, autovfx_amd.exr otherwise: what the kernels do not cover
+            results.append(torch.from_numpy(np.ascontiguousarray(compositor.load_depth_exr(path))).to(device))
+    if own:
+        torch.cuda.current_stream(device).synchronize()
+    return results
+
+
+def load_depth(path: str, device, staging: Optional[Staging] = None, error_flag: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """``load_depth_many`` for one file."""
+    return load_depth_many([path], device, staging, error_flag)[0]

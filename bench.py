@@ -1236,7 +1236,8 @@ def _synthetic_blender_tree(root, W, H, frames, distinct=4, seed=3):
             z = (3.0 + j + 2.0 * blob(0.5, 0.5, 0.5) + 0.2 * np.sin(yy * 0.02)).astype(np.float32)
             z[blob(0.5 + sh, 0.5, 0.45) <= 0] = 65504.0            # "nothing here"
             os.makedirs(os.path.join(cache, kind, f"src{k}"), exist_ok=True)
-            exr.write_exr(os.path.join(cache, kind, f"src{k}", "Image.exr"), {"R": z, "G": z, "B": z, "A": np.ones_like(z)}, half=True, level=1)
+            # (zlib level 4: what OpenEXR 3.1.3+ -- Blender 3.x / 4.x -- compresses ZIP blocks with; earlier versions used 6)
+            exr.write_exr(os.path.join(cache, kind, f"src{k}", "Image.exr"), {"R": z, "G": z, "B": z, "A": np.ones_like(z)}, half=True, level=4)
     for i in range(frames):
         k = i % distinct
         os.link(os.path.join(images, f"src{k}.png"), os.path.join(images, f"{i:05d}.png"))

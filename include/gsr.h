@@ -339,6 +339,7 @@ typedef struct GsrPngFileInfo {
 } GsrPngFileInfo;
 typedef struct GsrExrFileInfo {
     int width, height, bytes_per_line, lines_per_block, channel_at, channel_bytes, channel_is_half;
+    int compression, n_blocks; /* the compression attribute (1 RLE, 2 ZIPS, 3 ZIP); scanline blocks in the part */
     size_t blocks_bytes;
     char channel[32];
 } GsrExrFileInfo;
@@ -346,6 +347,26 @@ GSR_API int gsr_png_file_probe(const uint8_t* file, size_t file_bytes, GsrPngFil
 GSR_API int gsr_png_file_inflate(const uint8_t* file, size_t file_bytes, uint8_t* scanlines, size_t scanline_bytes);
 GSR_API int gsr_exr_file_probe(const uint8_t* file, size_t file_bytes, const char* channel, GsrExrFileInfo* info);
 GSR_API int gsr_exr_file_inflate(const uint8_t* file, size_t file_bytes, const char* channel, uint8_t* blocks, size_t blocks_bytes);
+/* ZIP / ZIPS OpenEXR parts are one zlib stream per scanline block (68 for a 1080p ZIP pass): independent streams, so the GPU can
+ * inflate them -- one single-wave workgroup per stream, the 32 KB window in LDS, matches copied and tables filled by the 64 lanes --
+ * instead of the host (gsr_exr_file_inflate).
+ *  gsr_exr_file_pack (host): the blocks' compressed streams copied one behind the other, each at a 4-byte aligned offset, into
+ *   `packed` (room: file_bytes + 4 * info.n_blocks + 4), and jobs[info.n_blocks] = where each stream is and where its output goes.
+ *   GSR_NOT_COVERED for RLE files and whatever gsr_exr_file_probe does not cover.
+ *  gsr_inflate_zlib_blocks (GPU): `streams`, `out`, `jobs`, `status[count]` and `any_error` (may be NULL) are DEVICE pointers;
+ *   stream i = streams[src_at, src_at + src_bytes) -> out[dst_at, dst_at + dst_bytes), which it must fill exactly; status[i] = 0 or
+ *   why not (gsr_inflate_core.h: bad header / code / distance / checksum / sizes ...), *any_error |= 1 on any failure.  A stream that
+ *   zlib's uncompress() accepts for that output size decodes to the same bytes; anything else is refused (Adler-32 verified). */
+typedef struct GsrInflateJob {
+    uint32_t src_at, src_bytes, dst_at, dst_bytes;
+} GsrInflateJob;
+GSR_API int gsr_exr_file_pack(const uint8_t* file, size_t file_bytes, const char* channel, uint8_t* packed, size_t packed_room,
+                              GsrInflateJob* jobs, size_t* packed_bytes);
+GSR_API int gsr_inflate_zlib_blocks(const uint8_t* streams, uint8_t* out, const GsrInflateJob* jobs, int count, int* status,
+                                    int* any_error, void* stream);
+/* The GPU's zlib decoder (gsr_inflate_zlib_blocks above) run by ONE host lane: the same source, for tests against zlib.  Returns 0 or
+ * the decoder's status (1 bad header ... 10 short output: gsr_inflate_core.h).  out_bytes: the exact size the stream inflates to. */
+GSR_API int gsr_selftest_inflate_host(const uint8_t* zlib_stream, size_t stream_bytes, uint8_t* out, size_t out_bytes);
 
 /* The sort stage on its own (what gsr_forward runs twice per call; replaces the reference's
  * cub::DeviceRadixSort::SortPairs, rasterizer_impl.cu:304-309): stable ascending sort of n (u32 key, u32

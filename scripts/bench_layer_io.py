@@ -37,7 +37,7 @@ def main():
     d = tempfile.mkdtemp(prefix="gsr_layer_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     png, exrp = os.path.join(d, "layer.png"), os.path.join(d, "Image0001.exr")
     Image.fromarray(img).save(png, compress_level=1)
-    exr.write_exr(exrp, {"R": z, "G": z, "B": z, "A": np.ones_like(z)}, half=True, level=1)
+    exr.write_exr(exrp, {"R": z, "G": z, "B": z, "A": np.ones_like(z)}, half=True, level=4)      # (zlib level 4: OpenEXR 3.1.3+)
     staging = layer_io.Staging(64 << 20)
     out = {"png": {"file_bytes": os.path.getsize(png)}, "exr": {"file_bytes": os.path.getsize(exrp)}}
 
@@ -102,6 +102,29 @@ def main():
     out["exr"]["unpack_kernel_ms"] = round(gpu_ms(lambda: layer_io._lib.lib.gsr_exr_unpack_channel(
         estaged.data_ptr(), L["height"], L["bytes_per_line"], L["lines_per_block"], L["channel_at"], L["channel_bytes"], plane.data_ptr(), stream_ptr)), 4)
     out["exr"]["load_depth_blocking_ms"] = round(_timed(lambda: layer_io.load_depth(exrp, dev), 10), 3)
+    # the same file with its 68 zlib streams inflated on the GPU (a single-wave workgroup each): host side = copying the streams together
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def pack_only():
+        staging.reset()
+        info = layer_io._lib.ExrFileInfo()
+        layer_io._lib.lib.gsr_exr_file_probe(ebuf, len(ebuf), None, ctypes.byref(info))
+        room = len(ebuf) + 4 * info.n_blocks + 4
+        h = staging.take(16 * info.n_blocks + room)
+        n = ctypes.c_size_t(0)
+        layer_io._lib.lib.gsr_exr_file_pack(ebuf, len(ebuf), None, ctypes.c_void_p(h.data_ptr() + 16 * info.n_blocks), room, ctypes.c_void_p(h.data_ptr()), ctypes.byref(n))
+        return h, info, n.value
+    out["exr"]["gpu_inflate_host_pack_ms"] = round(_timed(pack_only, 20), 3)
+    h, info, n_packed = pack_only()
+    d_in = layer_io._upload(h[:16 * info.n_blocks + n_packed + 4], dev)
+    d_blocks = torch.empty(info.blocks_bytes, dtype=torch.uint8, device=dev)
+    d_status = torch.empty(info.n_blocks, dtype=torch.int32, device=dev)
+    out["exr"]["gpu_inflate_kernel_ms"] = round(gpu_ms(lambda: layer_io._lib.lib.gsr_inflate_zlib_blocks(
+        d_in.data_ptr() + 16 * info.n_blocks, d_blocks.data_ptr(), d_in.data_ptr(), info.n_blocks, d_status.data_ptr(), flag.data_ptr(), stream_ptr)), 4)
+    out["exr"]["gpu_inflate_streams"] = int(info.n_blocks)
+    out["exr"]["load_depth_gpu_inflate_blocking_ms"] = round(_timed(lambda: layer_io.load_depth(exrp, dev, None, flag), 10), 3)
+    out["exr"]["gpu_inflate_same_as_host_reader"] = bool(int(flag.cpu()) == 0 and np.array_equal(
+        layer_io.load_depth(exrp, dev, None, flag).to(torch.float32).cpu().numpy(), exr.load_depth_exr(exrp)))
     out["exr"]["host_reader_ms"] = round(_timed(lambda: exr.load_depth_exr(exrp), 5), 3)
     out["exr"]["same_as_host_reader"] = bool(np.array_equal(layer_io.load_depth(exrp, dev).to(torch.float32).cpu().numpy(), exr.load_depth_exr(exrp)))
     print(json.dumps(out))

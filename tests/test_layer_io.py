@@ -246,6 +246,71 @@ def test_native_exr_reader_is_the_python_one(tmp_path):
                 assert _native_exr(bad) == _python_exr(bad), f"file {k}: bit {bit} of byte {at} flipped"
 
 
+# ---- the wave's zlib decoder (csrc/gsr_inflate_core.h): its one-lane host instantiation against zlib ------------------------------------
+
+def _zlib_corpus(sizes=(0, 1, 2, 5, 100, 4095, 4096, 4097, 70000), levels=(0, 1, 6, 9), windows=(15, 9)):
+    """(stream, its data): stored / fixed / dynamic blocks, long and overlapping matches, literals only, small windows."""
+    g = np.random.default_rng(0)
+    out = []
+    for size in sizes:
+        sparse = np.zeros(size, np.uint8)
+        if size:
+            sparse[g.integers(0, size, size // 50)] = g.integers(0, 256, size // 50)
+        for data in (bytes(size), bytes(g.integers(0, 256, size, dtype=np.uint8)), (b"the quick brown fox jumps over the lazy dog. " * (size // 40 + 1))[:size],
+                     bytes((np.arange(size) % 251).astype(np.uint8)), bytes(sparse)):
+            for level in levels:
+                for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_RLE, zlib.Z_HUFFMAN_ONLY):
+                    for wbits in windows:
+                        c = zlib.compressobj(level, zlib.DEFLATED, wbits, 8, strategy)
+                        out.append((c.compress(data) + c.flush(), data))
+    data = bytes((np.arange(50000) % 97).astype(np.uint8)) + bytes(g.integers(0, 256, 20000, dtype=np.uint8))
+    for mode in (zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH):           # empty stored blocks between the others
+        c, stream = zlib.compressobj(6), b""
+        for k in range(0, len(data), 7001):
+            stream += c.compress(data[k:k + 7001]) + c.flush(mode)
+        out.append((stream + c.flush(), data))
+    return out
+
+
+def _host_lane_inflate(stream, n):
+    import ctypes
+    out = ctypes.create_string_buffer(max(n, 1))
+    rc = layer_io._lib.lib.gsr_selftest_inflate_host(stream, len(stream), out, n)
+    return rc, out.raw[:n]
+
+
+def _zlib_says(stream, n):
+    d = zlib.decompressobj()
+    try:
+        out = d.decompress(stream)
+    except zlib.error:
+        return None
+    return out if d.eof and len(out) == n else None
+
+
+def test_wave_inflate_on_one_host_lane_is_zlib():
+    """The decoder the GPU runs, instantiated for one host lane: every stream of the corpus inflates to its data; wrong sizes, truncated
+    streams are refused; a flipped bit is either refused or zlib accepts the same bytes -- and nothing zlib accepts is refused."""
+    for k, (stream, data) in enumerate(_zlib_corpus()):
+        assert _host_lane_inflate(stream, len(data)) == (0, data), f"stream {k}: {len(data)} bytes"
+    stream, data = _zlib_corpus(sizes=(70000,), levels=(6,), windows=(15,))[8]
+    assert _host_lane_inflate(stream, len(data) - 1)[0] == 7 and _host_lane_inflate(stream, len(data) + 1)[0] == 10      # overflow / short output
+    assert _host_lane_inflate(stream + b"trailing", len(data)) == (0, data)
+    for cut in list(range(0, 40)) + list(range(40, len(stream), max(1, len(stream) // 150))):
+        assert _host_lane_inflate(stream[:cut], len(data))[0] != 0, f"truncated at {cut}"
+    g = np.random.default_rng(1)
+    small = bytes((np.arange(3000) % 13).astype(np.uint8)) + bytes(g.integers(0, 256, 1500, dtype=np.uint8)) + b"abcabcabc" * 100
+    for level, strategy in ((6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_FIXED), (0, zlib.Z_DEFAULT_STRATEGY)):
+        c = zlib.compressobj(level, zlib.DEFLATED, 15, 8, strategy)
+        stream = c.compress(small) + c.flush()
+        for at in range(0, len(stream), 1 if level else 7):
+            for bit in range(8):
+                bad = stream[:at] + bytes([stream[at] ^ (1 << bit)]) + stream[at + 1:]
+                rc, out = _host_lane_inflate(bad, len(small))
+                want = _zlib_says(bad, len(small))
+                assert (rc == 0) == (want is not None) and (rc != 0 or out == want), f"level {level}: bit {bit} of byte {at}"
+
+
 # ---- the kernels -----------------------------------------------------------------------------------------------------------------
 
 def _unfilter_on_gpu(data: bytes) -> np.ndarray:
@@ -350,6 +415,58 @@ def test_load_depth_is_load_depth_exr(tmp_path, compression, half, shape):
     exr.write_exr(p, {"Z": depth}, compression=compression, half=half)                 # a single channel; a line is one stretch
     got = layer_io.load_depth(p, dev)
     np.testing.assert_array_equal(got.to(torch.float32).cpu().numpy(), exr.load_depth_exr(p))
+
+
+@pytest.mark.gpu
+def test_zlib_streams_inflated_on_the_gpu():
+    """``gsr_inflate_zlib_blocks``: the whole corpus in one launch, good streams beside damaged ones -- each good one inflates to its
+    data, each damaged one is refused with the host lane's verdict, and no stream disturbs its neighbours."""
+    dev = torch.device("cuda", 0)
+    corpus = _zlib_corpus(sizes=(0, 1, 5, 100, 4096, 4097, 70000, 300000), levels=(0, 1, 9), windows=(15,))
+    streams, sizes, want = [], [], []
+    for k, (stream, data) in enumerate(corpus):
+        if k % 5 == 3 and len(stream) > 12:                      # damage some: a flipped bit in the middle, or a lost tail
+            stream = stream[:len(stream) // 2] + bytes([stream[len(stream) // 2] ^ 16]) + stream[len(stream) // 2 + 1:] if k % 2 else stream[:-5]
+        streams.append(stream)
+        sizes.append(len(data))
+        want.append(_host_lane_inflate(stream, len(data)))
+    out, status = layer_io.inflate_zlib_streams(streams, sizes, dev)
+    out, status = out.cpu().numpy(), status.cpu().numpy()
+    at = refused = 0
+    for k, (rc, data) in enumerate(want):
+        assert status[k] == rc, f"stream {k}: status {status[k]}, the host lane says {rc}"
+        if rc == 0:
+            assert bytes(out[at:at + sizes[k]]) == data == corpus[k][1], f"stream {k}"
+        else:
+            refused += 1
+        at += sizes[k]
+    assert refused > 10 and refused < len(want) // 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("half", [False, True])
+def test_load_depth_with_the_blocks_inflated_on_the_gpu(tmp_path, half):
+    dev = torch.device("cuda", 0)
+    g = np.random.default_rng(2)
+    yy, xx = np.mgrid[0:270, 0:480].astype(np.float32)
+    depth = (3.0 + np.sin(xx * 0.05) + np.cos(yy * 0.03) + 0.001 * g.random((270, 480))).astype(np.float32)
+    depth[:100] = 65504.0 if half else 1e10
+    p = str(tmp_path / "Image0001.exr")
+    for compression in ("ZIP", "ZIPS"):
+        exr.write_exr(p, {"R": depth, "G": depth, "B": depth + 1, "A": np.ones_like(depth)}, compression=compression, half=half, level=6)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        got = layer_io.load_depth(p, dev, None, flag)
+        assert int(flag.cpu()) == 0 and got.dtype == (torch.float16 if half else torch.float32)
+        np.testing.assert_array_equal(got.to(torch.float32).cpu().numpy(), exr.load_depth_exr(p))
+    # a damaged block sets the flag (the caller then reads the file on the host, which raises or falls back as before)
+    buf = bytearray(open(p, "rb").read())
+    first = struct.unpack_from("<Q", buf, exr.read_header(bytes(buf))["offsets_at"])[0]
+    buf[first + 8 + 20] ^= 0x40
+    open(p, "wb").write(bytes(buf))
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    layer_io.load_depth(p, dev, None, flag)
+    torch.cuda.synchronize()
+    assert int(flag.cpu()) == 1
 
 
 @pytest.mark.gpu
