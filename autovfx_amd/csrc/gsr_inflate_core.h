@@ -72,6 +72,9 @@ struct Exec<1> {                                   // host: one lane does every 
     static GSR_HD void sync() {}
     static GSR_HD uint32_t uni(uint32_t v) { return v; }
     static GSR_HD uint64_t sum(uint64_t v) { return v; }
+    struct Input {};                               // the stream's words: read where they lie
+    static GSR_HD void input_open(Input&, const uint32_t*, uint32_t) {}
+    static GSR_HD uint32_t input_word(Input&, const uint32_t* words, uint32_t n_words, uint32_t i) { return i < n_words ? words[i] : 0u; }
 };
 
 #if defined(__HIPCC__)
@@ -91,48 +94,97 @@ struct Exec<64> {                                  // device: a single-wave work
         for (int d = 32; d >= 1; d >>= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, d, 64);
         return v;
     }
+    // The stream's words, 64 at a time: lane k holds word base + k of the current piece and of the next (one coalesced 256-byte load
+    // each, the second in flight while the first is being used); the reader takes a word with v_readlane -- no memory access, and so
+    // no memory latency, on the decoder's critical path.  (A plain load where the word is needed cost ~1 us every 32 bits.)
+    struct Input {
+        uint32_t cur, nxt, base;
+    };
+    static __device__ uint32_t piece(const uint32_t* words, uint32_t n_words, uint32_t base) {
+        const uint32_t i = base + threadIdx.x;
+        return i < n_words ? words[i] : 0u;
+    }
+    static __device__ void input_open(Input& in, const uint32_t* words, uint32_t n_words) {
+        in.base = 0;
+        in.cur = piece(words, n_words, 0);
+        in.nxt = piece(words, n_words, 64);
+    }
+    static __device__ uint32_t input_word(Input& in, const uint32_t* words, uint32_t n_words, uint32_t i) {      // i: uniform, never behind in.base
+        if (i >= in.base + 128u) {                 // a jump (behind a long stored block)
+            in.base = i & ~63u;
+            in.cur = piece(words, n_words, in.base);
+            in.nxt = piece(words, n_words, in.base + 64u);
+        } else if (i >= in.base + 64u) {
+            in.base += 64u;
+            in.cur = in.nxt;
+            in.nxt = piece(words, n_words, in.base + 64u);
+        }
+        return (uint32_t)__builtin_amdgcn_readlane((int)in.cur, (int)(i - in.base));
+    }
 };
 #endif
 
 // ---- the bit reader: 32-bit words of a 4-byte aligned stream, least significant bit first -----------------------------------------
+// (kept lean: one wave alone on its SIMD issues an instruction every five to ten cycles, so the ~100 scalar instructions a symbol cost
+// at first were the decoder's time: the bits taken so far are derived, not counted; peeks are 32-bit)
+template <int kLanes>
 struct Bits {
     const uint32_t* words;
-    uint32_t n_words, next;
+    uint32_t n_words, next;  // word next - 1 is in `ahead`, everything before it has entered `buf`
     uint64_t buf;
     int cnt;                 // valid bits in buf
-    uint64_t consumed;       // bits taken so far
-    uint32_t ahead;          // the next word, loaded one refill early
+    uint32_t ahead;          // the next word
+    typename Exec<kLanes>::Input in;
 };
 
-GSR_HD inline void bits_open(Bits& b, const uint8_t* src, size_t src_len) {
+template <int kLanes>
+GSR_HD inline void bits_open(Bits<kLanes>& b, const uint8_t* src, size_t src_len) {
     b.words = reinterpret_cast<const uint32_t*>(src);
     b.n_words = (uint32_t)((src_len + 3) / 4);
     b.buf = 0;
     b.cnt = 0;
-    b.consumed = 0;
     b.next = 1;
-    b.ahead = b.n_words > 0 ? b.words[0] : 0u;
+    Exec<kLanes>::input_open(b.in, b.words, b.n_words);
+    b.ahead = Exec<kLanes>::input_word(b.in, b.words, b.n_words, 0u);
 }
 // at least 32 valid bits afterwards -- the longest run of takes between two refills is a distance code and its extra bits, 28 --
-// (zeros behind the end of the stream: `consumed` tells)
-GSR_HD inline void bits_refill(Bits& b) {
+// (zeros behind the end of the stream: bits_consumed tells)
+template <int kLanes>
+GSR_HD inline void bits_refill(Bits<kLanes>& b) {
     if (b.cnt <= 32) {
         b.buf |= (uint64_t)b.ahead << b.cnt;
         b.cnt += 32;
-        b.ahead = b.next < b.n_words ? b.words[b.next] : 0u;
+        b.ahead = Exec<kLanes>::input_word(b.in, b.words, b.n_words, b.next);
         ++b.next;
     }
 }
-GSR_HD inline uint32_t bits_peek(const Bits& b, int n) { return (uint32_t)(b.buf & ((1ull << n) - 1ull)); }
-GSR_HD inline void bits_drop(Bits& b, int n) {
+template <int kLanes>
+GSR_HD inline uint64_t bits_consumed(const Bits<kLanes>& b) { return (uint64_t)(b.next - 1u) * 32u - (uint64_t)b.cnt; }
+template <int kLanes>
+GSR_HD inline uint32_t bits_peek(const Bits<kLanes>& b, int n) { return (uint32_t)b.buf & ((1u << n) - 1u); }      // n <= 28, within the 32 refilled bits
+template <int kLanes>
+GSR_HD inline void bits_drop(Bits<kLanes>& b, int n) {
     b.buf >>= n;
     b.cnt -= n;
-    b.consumed += (uint64_t)n;
 }
-GSR_HD inline uint32_t bits_take(Bits& b, int n) {
+template <int kLanes>
+GSR_HD inline uint32_t bits_take(Bits<kLanes>& b, int n) {
     const uint32_t v = bits_peek(b, n);
     bits_drop(b, n);
     return v;
+}
+// the reader repositioned to byte `at` of the stream (behind a stored block)
+template <int kLanes>
+GSR_HD inline void bits_seek(Bits<kLanes>& b, uint32_t at) {
+    b.next = at / 4u;
+    b.buf = 0;
+    b.cnt = 0;
+    b.ahead = Exec<kLanes>::input_word(b.in, b.words, b.n_words, b.next);
+    ++b.next;
+    bits_refill(b);
+    const int skip = (int)(at & 3u) * 8;
+    b.buf >>= skip;
+    b.cnt -= skip;
 }
 
 GSR_HD inline uint32_t reverse_bits(uint32_t v, int n) {
@@ -192,7 +244,7 @@ GSR_HD inline int build_code(Shared& sh, int at, int n, Code& code, uint16_t* lu
 
 // One symbol.  < 0: no code word matches.
 template <int kLanes>
-GSR_HD inline int decode_symbol(const Code& code, const uint16_t* lut, int lut_bits, Bits& b) {
+GSR_HD inline int decode_symbol(const Code& code, const uint16_t* lut, int lut_bits, Bits<kLanes>& b) {
     typedef Exec<kLanes> X;
     const uint32_t e = X::uni(lut[bits_peek(b, lut_bits)]);
     if (e) {
@@ -261,15 +313,11 @@ template <int kLanes>
 GSR_HD inline int inflate_zlib(const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_len, Shared& sh) {
     typedef Exec<kLanes> X;
     const int lane = X::lane();
-    const uint16_t len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-    const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-    const uint16_t dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-    const uint8_t dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
     const uint8_t cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
     if ((reinterpret_cast<uintptr_t>(src) & 3u) != 0 || src_len < 6 || dst_len > 0xFFFFFFFFull - 512ull) return kBadHeader;
     const uint64_t total_bits = (uint64_t)src_len * 8u;
-    Bits b;
+    Bits<kLanes> b;
     bits_open(b, src, src_len);
     bits_refill(b);
     const uint32_t cmf = bits_take(b, 8), flg = bits_take(b, 8);
@@ -284,15 +332,15 @@ GSR_HD inline int inflate_zlib(const uint8_t* src, size_t src_len, uint8_t* dst,
         if (type == 3u) return kBadBlockType;
         if (type == 0u) {
             // ---- stored: to the next byte boundary, LEN, ~LEN, LEN bytes
-            bits_drop(b, (int)((8u - (uint32_t)(b.consumed & 7u)) & 7u));
+            bits_drop(b, (int)((8u - (uint32_t)(bits_consumed(b) & 7u)) & 7u));
             bits_refill(b);
             const uint32_t len = bits_take(b, 16);
             bits_refill(b);
             const uint32_t nlen = bits_take(b, 16);
             if ((len ^ nlen) != 0xFFFFu) return kBadStored;
-            if (b.consumed + (uint64_t)len * 8u > total_bits) return kInputOverrun;
+            if (bits_consumed(b) + (uint64_t)len * 8u > total_bits) return kInputOverrun;
             if (len > out_len - pos) return kOutputOverflow;
-            const uint32_t from = (uint32_t)(b.consumed >> 3);        // byte offset in the stream
+            const uint32_t from = (uint32_t)(bits_consumed(b) >> 3);  // byte offset in the stream
             uint32_t done = 0;
             while (done < len) {                                       // (in pieces, so that the ring's unflushed part stays small)
                 const uint32_t piece = len - done < (uint32_t)kFlush ? len - done : (uint32_t)kFlush;
@@ -305,18 +353,7 @@ GSR_HD inline int inflate_zlib(const uint8_t* src, size_t src_len, uint8_t* dst,
                     flushed += (uint32_t)kFlush;
                 }
             }
-            // the reader starts over behind the copied bytes
-            const uint32_t at = from + len;
-            b.consumed = (uint64_t)at * 8u;
-            b.next = at / 4u;
-            b.buf = 0;
-            b.cnt = 0;
-            b.ahead = b.next < b.n_words ? b.words[b.next] : 0u;
-            ++b.next;
-            bits_refill(b);
-            const int skip = (int)(at & 3u) * 8;
-            b.buf >>= skip;
-            b.cnt -= skip;
+            bits_seek(b, from + len);      // the reader starts over behind the copied bytes
         } else {
             int n_lit = 288, n_dist = 30;
             if (type == 1u) {
@@ -347,7 +384,7 @@ GSR_HD inline int inflate_zlib(const uint8_t* src, size_t src_len, uint8_t* dst,
                 // (lens[] is being read by nobody now: the code length code lives in sh.dist / dist_lut)
                 while (have < n_lit + n_dist) {
                     bits_refill(b);
-                    if (b.consumed > total_bits) return kInputOverrun;
+                    if (bits_consumed(b) > total_bits) return kInputOverrun;
                     const int sym = decode_symbol<kLanes>(sh.dist, sh.dist_lut, 7, b);
                     if (sym < 0) return kBadCode;
                     if (sym < 16) {
@@ -400,10 +437,11 @@ GSR_HD inline int inflate_zlib(const uint8_t* src, size_t src_len, uint8_t* dst,
                 }
                 if (!((nonzero == 1 && ones == 1) || nonzero == 0)) return kBadLengths;
             }
-            // ---- the symbols of the block
+            // ---- the symbols of the block.  (No end-of-input test per symbol: behind the stream's end the reader delivers zeros, and a
+            // stream of zeros ends -- in an output overflow, or in an end-of-block symbol and then a stored block whose LEN / NLEN do
+            // not match; the test behind the block catches the overrun.)
             for (;;) {
                 bits_refill(b);
-                if (b.consumed > total_bits) return kInputOverrun;
                 int sym = decode_symbol<kLanes>(sh.lit, sh.lit_lut, kLitBits, b);
                 if (sym < 0) return kBadCode;
                 if (sym < 256) {
@@ -415,21 +453,31 @@ GSR_HD inline int inflate_zlib(const uint8_t* src, size_t src_len, uint8_t* dst,
                 } else {
                     sym -= 257;
                     if (sym >= 29) return kBadCode;
-                    const uint32_t len = len_base[sym] + bits_take(b, len_extra[sym]);
+                    // RFC 1951 3.2.5 as arithmetic (a table in memory costs a load on the critical path): lengths 3 ... 10 one by one,
+                    // then four codes per extra bit; 258 has its own code
+                    const int l_extra = sym < 8 || sym == 28 ? 0 : (sym - 4) >> 2;
+                    const uint32_t l_base = sym < 8 ? 3u + (uint32_t)sym : sym == 28 ? 258u : 3u + ((4u + ((uint32_t)sym & 3u)) << l_extra);
+                    const uint32_t len = l_base + bits_take(b, l_extra);
                     bits_refill(b);
                     const int dsym = decode_symbol<kLanes>(sh.dist, sh.dist_lut, kDistBits, b);
                     if (dsym < 0 || dsym >= 30) return kBadCode;
-                    const uint32_t dist = dist_base[dsym] + bits_take(b, dist_extra[dsym]);
+                    const int d_extra = dsym < 4 ? 0 : (dsym - 2) >> 1;        // distances 1 ... 4 one by one, then two codes per extra bit
+                    const uint32_t d_base = dsym < 4 ? 1u + (uint32_t)dsym : 1u + ((2u + ((uint32_t)dsym & 1u)) << d_extra);
+                    const uint32_t dist = d_base + bits_take(b, d_extra);
                     if (dist > pos) return kBadDistance;
                     if (len > out_len - pos) return kOutputOverflow;
                     // byte i of the match is byte (i mod dist) of the dist bytes in front of it: nothing to wait for
                     X::sync();
                     const uint32_t start = pos - dist;
-                    for (uint32_t i0 = 0; i0 < len; i0 += (uint32_t)kLanes) {
-                        const uint32_t i = i0 + (uint32_t)lane;
-                        uint32_t byte = 0;
-                        if (i < len) byte = sh.ring[(start + (dist >= len ? i : i % dist)) & (uint32_t)(kWindow - 1)];
-                        if (i < len) sh.ring[(pos + i) & (uint32_t)(kWindow - 1)] = (uint8_t)byte;
+                    uint32_t from = (uint32_t)lane, step = (uint32_t)kLanes;       // i mod dist, without a division per piece
+                    if (dist < len) {
+                        from %= dist;
+                        step %= dist;
+                    }
+                    for (uint32_t i = (uint32_t)lane; i < len; i += (uint32_t)kLanes) {
+                        sh.ring[(pos + i) & (uint32_t)(kWindow - 1)] = sh.ring[(start + from) & (uint32_t)(kWindow - 1)];
+                        from += step;
+                        if (dist < len && from >= dist) from -= dist;
                     }
                     pos += len;
                 }
@@ -439,19 +487,19 @@ GSR_HD inline int inflate_zlib(const uint8_t* src, size_t src_len, uint8_t* dst,
                 }
             }
         }
-        if (b.consumed > total_bits) return kInputOverrun;
+        if (bits_consumed(b) > total_bits) return kInputOverrun;
         if (last) break;
     }
     if (pos > flushed) flush<kLanes>(sh, dst, flushed, pos - flushed, ad);
     if (pos != out_len) return kShortOutput;
     // the Adler-32 of the output, big-endian, on the next byte boundary
-    bits_drop(b, (int)((8u - (uint32_t)(b.consumed & 7u)) & 7u));
+    bits_drop(b, (int)((8u - (uint32_t)(bits_consumed(b) & 7u)) & 7u));
     uint32_t stored = 0;
     for (int k = 0; k < 4; ++k) {
         bits_refill(b);
         stored = (stored << 8) | bits_take(b, 8);
     }
-    if (b.consumed > total_bits) return kInputOverrun;
+    if (bits_consumed(b) > total_bits) return kInputOverrun;
     if (stored != ((ad.s2 << 16) | ad.s1)) return kBadChecksum;
     return kOk;
 }
