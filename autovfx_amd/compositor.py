@@ -191,52 +191,132 @@ def _load_frame_layers_to_gpu(cache, bg_path, i, dev, staging, error_flag=None):
     return out
 
 
+def _composite_layers(L):
+    """The loaded layers of a frame -> the blended RGBA8 frame on the GPU (blend_all.py:207-337), queued on the current stream."""
+    bg_c = L["bg"]
+    o_c, o_d = L["rgb_obj"], L["depth_obj"]
+    s_c, s_d = L["rgb_shadow"], L["depth_shadow"]
+    o_s_c = L["rgb_all"]
+    o_gs_c, o_gs_d = L["rgb_obj_3dgs"], L["depth_obj_3dgs"]
+    s_f_c, s_f_d = L["rgb_smoke_fire"], L["depth_smoke_fire"]
+    s_f_c_pre = L["rgb_smoke_fire_pre"]
+    if o_gs_c is None:
+        o_gs_d = None
+    if s_f_c is not None:
+        s_f_d = smoke_depth_fill(s_f_c, s_f_d.to(torch.float32))       # on the full-size layers, before the resizes (:207-215)
+    else:
+        s_f_d = s_f_c_pre = None
+    f32 = lambda t: None if t is None else t.to(torch.float32)
+    return composite_frame(bg_c, o_c, f32(o_d), s_c, f32(s_d), o_s_c, o_gs_c, f32(o_gs_d), s_f_c, f32(s_f_d), s_f_c_pre)
+
+
 def _blend_one_frame(cache, bg_path, i, dev, out_path, want_frame, stats=None, exr_on_gpu=None):
-    """Frame ``i`` of ``blend_frames`` from its files to its file (blend_all.py:185-337), on the calling pool thread and its stream."""
-    import time
+    """Frame ``i`` of ``blend_frames`` from its files to its file (blend_all.py:185-337), start to finish on the calling thread and its
+    stream (the pool's workers split this in two -- ``_FrameWorker`` -- and come back here, with zlib on the host, for a frame whose
+    depth passes the GPU's decoder refused)."""
     from . import frame_io, layer_io
     if exr_on_gpu is None:
         exr_on_gpu = layer_io.exr_inflate_on_gpu()
-    t0 = time.perf_counter()
-    staging = _worker_local.__dict__.get("staging") if _worker_local is not None else None
-    if staging is None:
-        from . import layer_io
-        _thread_stream(dev)
-        staging = _worker_local.__dict__["staging"] = layer_io.Staging()
-    staging.reset()                                 # (the previous frame of this thread ended with a wait for its stream)
+    staging = layer_io.Staging()
     with torch.cuda.stream(_thread_stream(dev)):
         error_flag = torch.zeros(1, dtype=torch.int32, device=dev) if exr_on_gpu else None
-        L = _load_frame_layers_to_gpu(cache, bg_path, i, dev, staging, error_flag)
-        t1 = time.perf_counter()
-        bg_c = L["bg"]
-        o_c, o_d = L["rgb_obj"], L["depth_obj"]
-        s_c, s_d = L["rgb_shadow"], L["depth_shadow"]
-        o_s_c = L["rgb_all"]
-        o_gs_c, o_gs_d = L["rgb_obj_3dgs"], L["depth_obj_3dgs"]
-        s_f_c, s_f_d = L["rgb_smoke_fire"], L["depth_smoke_fire"]
-        s_f_c_pre = L["rgb_smoke_fire_pre"]
-        if o_gs_c is None:
-            o_gs_d = None
-        if s_f_c is not None:
-            s_f_d = smoke_depth_fill(s_f_c, s_f_d.to(torch.float32))       # on the full-size layers, before the resizes (:207-215)
-        else:
-            s_f_d = s_f_c_pre = None
-        f32 = lambda t: None if t is None else t.to(torch.float32)
-        frame = composite_frame(bg_c, o_c, f32(o_d), s_c, f32(s_d), o_s_c, o_gs_c, f32(o_gs_d), s_f_c, f32(s_f_d), s_f_c_pre)
+        frame = _composite_layers(_load_frame_layers_to_gpu(cache, bg_path, i, dev, staging, error_flag))
         png = frame_io.encode_png_gpu_deflate(frame) if frame_io.deflate_default() else frame_io.encode_png_gpu(frame)
-        t2 = time.perf_counter()
-        data = png.cpu().numpy()                   # (waits for this thread's stream: the frame is finished, the staging memory free)
+        data = png.cpu().numpy()                   # (waits for this thread's stream)
         if error_flag is not None and int(error_flag.cpu()) != 0:
-            # the GPU's decoder refused a depth pass's zlib stream: once more with zlib on the host, which reads it or says why not
             return _blend_one_frame(cache, bg_path, i, dev, out_path, want_frame, stats, exr_on_gpu=False)
         host_frame = frame.cpu().numpy() if want_frame else None
-    t3 = time.perf_counter()
     with open(out_path, "wb") as f:
         f.write(data)
-    if stats is not None:
-        t4 = time.perf_counter()
-        stats.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3))
     return host_frame
+
+
+class _FrameWorker:
+    """One pool thread of ``blend_frames``: takes whole frames off a shared counter and keeps TWO in flight -- while the GPU undoes the
+    predictors of frame i, composites and encodes it (5 - 15 ms behind the other threads' kernels), the thread already reads and
+    inflates the files of its next frame; only then does it wait for frame i, and writes its file.  Two staging arenas and two sets
+    of page-locked result buffers alternate."""
+
+    def __init__(self, job):
+        self.job = job
+        self.slots = [{"staging": None, "png": None, "len": None, "flag": None, "frame": None} for _ in range(2)]
+
+    def _pinned(self, slot, key, numel, dtype):
+        t = slot[key]
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            t = slot[key] = torch.empty(numel, dtype=dtype, pin_memory=True)
+        return t
+
+    def begin(self, i, slot):
+        import time
+        from . import frame_io, layer_io
+        job, dev = self.job, self.job["dev"]
+        t0 = time.perf_counter()
+        if slot["staging"] is None:
+            slot["staging"] = layer_io.Staging()
+        slot["staging"].reset()                     # (this slot's previous frame has been waited for)
+        stream = _thread_stream(dev)
+        with torch.cuda.stream(stream):
+            flag = torch.zeros(1, dtype=torch.int32, device=dev) if job["exr_on_gpu"] else None
+            L = _load_frame_layers_to_gpu(job["cache"], job["bg_rgb"][i], i, dev, slot["staging"], flag)
+            t1 = time.perf_counter()
+            frame = _composite_layers(L)
+            if frame_io.deflate_default():
+                out, length = frame_io.encode_png_gpu_deflate_queued(frame)
+                self._pinned(slot, "len", 1, torch.int64).copy_(length, non_blocking=True)
+                n = None
+            else:
+                out = frame_io.encode_png_gpu(frame)
+                n = out.numel()
+            self._pinned(slot, "png", out.numel(), torch.uint8)[:out.numel()].copy_(out, non_blocking=True)
+            if flag is not None:
+                self._pinned(slot, "flag", 1, torch.int32).copy_(flag, non_blocking=True)
+            if job["want_frames"]:
+                self._pinned(slot, "frame", frame.numel(), torch.uint8)[:frame.numel()].copy_(frame.reshape(-1), non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(stream)
+        t2 = time.perf_counter()
+        return {"i": i, "slot": slot, "done": done, "n": n, "checked": flag is not None, "shape": tuple(frame.shape), "t": (t1 - t0, t2 - t1)}
+
+    def finish(self, fr):
+        import time
+        job, slot, i = self.job, fr["slot"], fr["i"]
+        t0 = time.perf_counter()
+        fr["done"].synchronize()
+        t1 = time.perf_counter()
+        if fr["checked"] and int(slot["flag"][0]) != 0:
+            # the GPU's decoder refused a depth pass's zlib stream: once more with zlib on the host, which reads it or says why not
+            host_frame = _blend_one_frame(job["cache"], job["bg_rgb"][i], i, job["dev"], job["paths"][i], job["want_frames"], None, exr_on_gpu=False)
+        else:
+            n = fr["n"] if fr["n"] is not None else int(slot["len"][0])
+            with open(job["paths"][i], "wb") as f:
+                f.write(memoryview(slot["png"].numpy())[:n])
+            host_frame = slot["frame"][:int(torch.Size(fr["shape"]).numel())].numpy().reshape(fr["shape"]).copy() if job["want_frames"] else None
+        if job["want_frames"]:
+            job["host_frames"][i] = host_frame
+        if job["stats"] is not None:
+            job["stats"].append(fr["t"] + (t1 - t0, time.perf_counter() - t1))
+
+    def run(self):
+        job, prev, k = self.job, None, 0
+        try:
+            while job["error"] is None:
+                with job["lock"]:
+                    i = job["next"]
+                    job["next"] += 1
+                if i >= job["n_frame"]:
+                    break
+                cur = self.begin(i, self.slots[k & 1])
+                k += 1
+                if prev is not None:
+                    self.finish(prev)
+                prev = cur
+            if prev is not None and job["error"] is None:
+                self.finish(prev)
+        except BaseException as e:                  # the first failure stops the pool and is raised by blend_frames
+            with job["lock"]:
+                if job["error"] is None:
+                    job["error"] = e
 
 
 LAST_BLEND_STATS: dict = {}     # with AUTOVFX_AMD_BLEND_STATS=1: thread-seconds of the last blend_frames call by stage, summed over the pool
@@ -259,9 +339,10 @@ def blend_frames(blend_results_dir, input_config_path=None, device=None, write_v
     (``<blend_results_dir>/frames/%04d.png`` and, when ``imageio`` / ``skimage`` are importable, ``blended.mp4``).  What happens
     between loading and saving runs on the GPU: the smoke-depth fill, PIL's resizes of every Blender layer to the frame's size
     (``resize_rgba8`` / ``resize_depth``), the per-pixel composite (``gsr_composite``) and the PNG encoding of the result
-    (``gsr_png_encode_deflate``: compressed files holding the same pixels as ``Image.fromarray(frame).save``).  Decoding PNG / EXR
-    stays on the host -- Pillow; OpenCV for EXR when it is installed, ``autovfx_amd.exr`` otherwise -- on a pool of threads that
-    works ahead of the GPU.  Returns the list of frame paths."""
+    (``gsr_png_encode_deflate``: compressed files holding the same pixels as ``Image.fromarray(frame).save``).  Of reading the layers
+    the host keeps the container parsing and the PNGs' ``inflate``; the EXR blocks' zlib streams, the PNG filters and the EXR predictor
+    are undone on the GPU (``autovfx_amd.layer_io``); files those kernels do not cover go to Pillow / OpenCV / ``autovfx_amd.exr``.
+    Returns the list of frame paths."""
     import glob
     import json
     import os
@@ -287,26 +368,28 @@ def blend_frames(blend_results_dir, input_config_path=None, device=None, write_v
             print("[autovfx_amd] blended.mp4 will not be written: imageio / skimage are not installed (the frames go to " + out_img_dir + ")")
     # Reading ~11 PNG / EXR layers per frame at Blender's resolution dwarfs the 0.13 ms of resizing, compositing and encoding a frame,
     # and frames do not depend on each other: each thread of a pool takes whole frames -- inflates and uploads the files, queues the
-    # kernels that undo the image predictors (layer_io), resize, composite and encode on ITS stream, copies the file out and writes
-    # it.  This thread only keeps the order (and the frames for the video, where one is written).
-    from concurrent.futures import ThreadPoolExecutor
-    workers = decode_threads()
-    ahead = 2 * workers
+    # kernels that inflate the EXR blocks, undo the image predictors (layer_io), resize, composite and encode on ITS stream, copies
+    # the file out and writes it -- two frames in flight per thread (_FrameWorker).  This thread only waits.
+    import threading
+    from . import layer_io
+    workers = max(1, min(decode_threads(), n_frame))
     paths = [os.path.join(out_img_dir, "{:0>4d}.png".format(i)) for i in range(n_frame)]
-    host_frames, pending = [], {}
-    stats = [] if os.environ.get("AUTOVFX_AMD_BLEND_STATS") == "1" else None
-    with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="blend-frame") as pool:
-        for i in range(n_frame):
-            for j in range(i, min(n_frame, i + ahead + 1)):
-                if j not in pending:
-                    pending[j] = pool.submit(_blend_one_frame, cache, bg_rgb[j], j, dev, paths[j], video is not None, stats)
-            host_frame = pending.pop(i).result()
-            if video is not None:
-                host_frames.append(host_frame)
+    job = {"cache": cache, "bg_rgb": bg_rgb, "dev": dev, "paths": paths, "n_frame": n_frame, "next": 0, "lock": threading.Lock(), "error": None,
+           "want_frames": video is not None, "host_frames": {}, "exr_on_gpu": layer_io.exr_inflate_on_gpu(),
+           "stats": [] if os.environ.get("AUTOVFX_AMD_BLEND_STATS") == "1" else None}
+    threads = [threading.Thread(target=_FrameWorker(job).run, name=f"blend-frame-{k}") for k in range(workers)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if job["error"] is not None:
+        raise job["error"]
+    host_frames = [job["host_frames"][i] for i in range(n_frame)] if video is not None else []
+    stats = job["stats"]
     if stats is not None:
         LAST_BLEND_STATS.clear()
         LAST_BLEND_STATS.update({"frames": n_frame, "threads": workers, "read_and_upload_s": sum(x[0] for x in stats),
-                                 "queue_kernels_s": sum(x[1] for x in stats), "wait_and_copy_out_s": sum(x[2] for x in stats),
+                                 "queue_kernels_s": sum(x[1] for x in stats), "wait_for_gpu_s": sum(x[2] for x in stats),
                                  "write_file_s": sum(x[3] for x in stats)})
     if video is not None and host_frames:   # generate_video_from_frames (:31-54), with the reference's own host libraries
         imageio, transform = video

@@ -268,6 +268,53 @@ GSR_HD inline int decode_symbol(const Code& code, const uint16_t* lut, int lut_b
     return -1;
 }
 
+// A match: bytes [pos, pos + len) of the output = the bytes dist in front of them, len <= 258.  Byte i of the match is byte
+// (i mod dist) of the dist bytes in front of it -- a match that overlaps itself repeats its first dist bytes -- so no byte waits for
+// another: every lane reads ALL its bytes (at most five: one LDS round trip, not five), then writes them.
+template <int kLanes>
+GSR_HD inline void copy_match(Shared& sh, uint32_t pos, uint32_t dist, uint32_t len) {
+    typedef Exec<kLanes> X;
+    constexpr uint32_t kMask = (uint32_t)(kWindow - 1);
+    const uint32_t start = pos - dist;
+    X::sync();
+    if (kLanes == 1) {
+        uint32_t from = 0;
+        for (uint32_t i = 0; i < len; ++i) {
+            sh.ring[(pos + i) & kMask] = sh.ring[(start + from) & kMask];
+            if (++from == dist) from = 0;
+        }
+    } else {
+        const uint32_t lane = (uint32_t)X::lane();
+        // lane mod dist and kLanes mod dist without an integer division (two of them cost more than the rest of a short match):
+        // a float quotient, corrected by one where it rounds the wrong way (the operands are below 2^16: exact enough)
+        uint32_t from = lane, step = (uint32_t)kLanes;
+        if (dist < len && dist <= (uint32_t)kLanes) {
+            const float inv = 1.0f / (float)dist;
+            from = lane - (uint32_t)((float)lane * inv) * dist;
+            from = (int32_t)from < 0 ? from + dist : from >= dist ? from - dist : from;      // (a quotient one too many / one too few)
+            step = (uint32_t)kLanes - (uint32_t)((float)kLanes * inv) * dist;
+            step = (int32_t)step < 0 ? step + dist : step >= dist ? step - dist : step;
+        }
+        if (len <= (uint32_t)kLanes) {               // the common case: one piece
+            if (lane < len) sh.ring[(pos + lane) & kMask] = sh.ring[(start + from) & kMask];
+        } else {
+            constexpr int kPieces = (258 + kLanes - 1) / kLanes;
+            uint8_t bytes[kPieces];
+#pragma unroll
+            for (int k = 0; k < kPieces; ++k) {
+                bytes[k] = lane + (uint32_t)(k * kLanes) < len ? sh.ring[(start + from) & kMask] : (uint8_t)0;
+                from += step;
+                if (dist < len && from >= dist) from -= dist;
+            }
+#pragma unroll
+            for (int k = 0; k < kPieces; ++k) {
+                const uint32_t i = lane + (uint32_t)(k * kLanes);
+                if (i < len) sh.ring[(pos + i) & kMask] = bytes[k];
+            }
+        }
+    }
+}
+
 struct Adler {
     uint32_t s1, s2;
 };
@@ -308,6 +355,67 @@ GSR_HD inline void flush(Shared& sh, uint8_t* dst, uint32_t from, uint32_t m, Ad
     X::sync();
 }
 
+// RFC 1951 3.2.5 as arithmetic (a table in memory costs a load on the critical path): lengths 3 ... 10 one by one, then four codes per
+// extra bit, 258 with its own code; distances 1 ... 4 one by one, then two codes per extra bit.
+GSR_HD inline int length_extra_bits(int ls) { return ls < 8 || ls == 28 ? 0 : (ls - 4) >> 2; }
+GSR_HD inline uint32_t length_base(int ls) { return ls < 8 ? 3u + (uint32_t)ls : ls == 28 ? 258u : 3u + ((4u + ((uint32_t)ls & 3u)) << length_extra_bits(ls)); }
+GSR_HD inline int distance_extra_bits(int ds) { return ds < 4 ? 0 : (ds - 2) >> 1; }
+GSR_HD inline uint32_t distance_base(int ds) { return ds < 4 ? 1u + (uint32_t)ds : 1u + ((2u + ((uint32_t)ds & 1u)) << distance_extra_bits(ds)); }
+
+struct Output {              // where the decoder stands in its output
+    uint8_t* dst;
+    uint32_t out_len, pos, flushed;
+    Adler ad;
+};
+
+template <int kLanes>
+GSR_HD inline void flush_full_segments(Shared& sh, Output& o) {
+    while (o.pos - o.flushed >= (uint32_t)kFlush) {
+        flush<kLanes>(sh, o.dst, o.flushed, (uint32_t)kFlush, o.ad);
+        o.flushed += (uint32_t)kFlush;
+    }
+}
+
+// One symbol of a block, every step in turn: 0 go on, 1 end of block, < 0 minus a Status.
+template <int kLanes>
+GSR_HD inline int symbol_step(Shared& sh, Bits<kLanes>& b, Output& o) {
+    bits_refill(b);
+    int sym = decode_symbol<kLanes>(sh.lit, sh.lit_lut, kLitBits, b);
+    if (sym < 0) return -kBadCode;
+    if (sym < 256) {
+        if (o.pos >= o.out_len) return -kOutputOverflow;
+        if (Exec<kLanes>::lane() == 0) sh.ring[o.pos & (uint32_t)(kWindow - 1)] = (uint8_t)sym;
+        ++o.pos;
+    } else if (sym == 256) {
+        return 1;
+    } else {
+        sym -= 257;
+        if (sym >= 29) return -kBadCode;
+        const int l_extra = length_extra_bits(sym);
+        const uint32_t len = length_base(sym) + bits_take(b, l_extra);
+        bits_refill(b);
+        const int dsym = decode_symbol<kLanes>(sh.dist, sh.dist_lut, kDistBits, b);
+        if (dsym < 0 || dsym >= 30) return -kBadCode;
+        const int d_extra = distance_extra_bits(dsym);
+        const uint32_t dist = distance_base(dsym) + bits_take(b, d_extra);
+        if (dist > o.pos) return -kBadDistance;
+        if (len > o.out_len - o.pos) return -kOutputOverflow;
+        copy_match<kLanes>(sh, o.pos, dist, len);
+        o.pos += len;
+    }
+    flush_full_segments<kLanes>(sh, o);
+    return 0;
+}
+
+// The symbols of a block up to its end-of-block code.  0, or minus a Status.
+template <int kLanes>
+GSR_HD inline int decode_block(Shared& sh, Bits<kLanes>& b, Output& o) {
+    for (;;) {
+        const int r = symbol_step<kLanes>(sh, b, o);
+        if (r != 0) return r < 0 ? r : 0;
+    }
+}
+
 // The zlib stream [src, src + src_len) -> dst[0 ... dst_len).  src: 4-byte aligned, readable up to the next multiple of 4.
 template <int kLanes>
 GSR_HD inline int inflate_zlib(const uint8_t* src, size_t src_len, uint8_t* dst, size_t dst_len, Shared& sh) {
@@ -323,9 +431,11 @@ GSR_HD inline int inflate_zlib(const uint8_t* src, size_t src_len, uint8_t* dst,
     const uint32_t cmf = bits_take(b, 8), flg = bits_take(b, 8);
     if ((cmf & 15u) != 8u || (cmf >> 4) > 7u || (flg & 32u) != 0u || ((cmf << 8) | flg) % 31u != 0u) return kBadHeader;
 
-    uint32_t pos = 0, flushed = 0;
-    Adler ad = {1u, 0u};
-    const uint32_t out_len = (uint32_t)dst_len;
+    Output o = {dst, (uint32_t)dst_len, 0u, 0u, {1u, 0u}};
+    uint32_t& pos = o.pos;
+    uint32_t& flushed = o.flushed;
+    Adler& ad = o.ad;
+    const uint32_t out_len = o.out_len;
     for (;;) {
         bits_refill(b);
         const uint32_t last = bits_take(b, 1), type = bits_take(b, 2);
@@ -440,52 +550,8 @@ GSR_HD inline int inflate_zlib(const uint8_t* src, size_t src_len, uint8_t* dst,
             // ---- the symbols of the block.  (No end-of-input test per symbol: behind the stream's end the reader delivers zeros, and a
             // stream of zeros ends -- in an output overflow, or in an end-of-block symbol and then a stored block whose LEN / NLEN do
             // not match; the test behind the block catches the overrun.)
-            for (;;) {
-                bits_refill(b);
-                int sym = decode_symbol<kLanes>(sh.lit, sh.lit_lut, kLitBits, b);
-                if (sym < 0) return kBadCode;
-                if (sym < 256) {
-                    if (pos >= out_len) return kOutputOverflow;
-                    if (lane == 0) sh.ring[pos & (uint32_t)(kWindow - 1)] = (uint8_t)sym;
-                    ++pos;
-                } else if (sym == 256) {
-                    break;
-                } else {
-                    sym -= 257;
-                    if (sym >= 29) return kBadCode;
-                    // RFC 1951 3.2.5 as arithmetic (a table in memory costs a load on the critical path): lengths 3 ... 10 one by one,
-                    // then four codes per extra bit; 258 has its own code
-                    const int l_extra = sym < 8 || sym == 28 ? 0 : (sym - 4) >> 2;
-                    const uint32_t l_base = sym < 8 ? 3u + (uint32_t)sym : sym == 28 ? 258u : 3u + ((4u + ((uint32_t)sym & 3u)) << l_extra);
-                    const uint32_t len = l_base + bits_take(b, l_extra);
-                    bits_refill(b);
-                    const int dsym = decode_symbol<kLanes>(sh.dist, sh.dist_lut, kDistBits, b);
-                    if (dsym < 0 || dsym >= 30) return kBadCode;
-                    const int d_extra = dsym < 4 ? 0 : (dsym - 2) >> 1;        // distances 1 ... 4 one by one, then two codes per extra bit
-                    const uint32_t d_base = dsym < 4 ? 1u + (uint32_t)dsym : 1u + ((2u + ((uint32_t)dsym & 1u)) << d_extra);
-                    const uint32_t dist = d_base + bits_take(b, d_extra);
-                    if (dist > pos) return kBadDistance;
-                    if (len > out_len - pos) return kOutputOverflow;
-                    // byte i of the match is byte (i mod dist) of the dist bytes in front of it: nothing to wait for
-                    X::sync();
-                    const uint32_t start = pos - dist;
-                    uint32_t from = (uint32_t)lane, step = (uint32_t)kLanes;       // i mod dist, without a division per piece
-                    if (dist < len) {
-                        from %= dist;
-                        step %= dist;
-                    }
-                    for (uint32_t i = (uint32_t)lane; i < len; i += (uint32_t)kLanes) {
-                        sh.ring[(pos + i) & (uint32_t)(kWindow - 1)] = sh.ring[(start + from) & (uint32_t)(kWindow - 1)];
-                        from += step;
-                        if (dist < len && from >= dist) from -= dist;
-                    }
-                    pos += len;
-                }
-                while (pos - flushed >= (uint32_t)kFlush) {
-                    flush<kLanes>(sh, dst, flushed, (uint32_t)kFlush, ad);
-                    flushed += (uint32_t)kFlush;
-                }
-            }
+            const int r = decode_block<kLanes>(sh, b, o);
+            if (r != 0) return -r;
         }
         if (bits_consumed(b) > total_bits) return kInputOverrun;
         if (last) break;

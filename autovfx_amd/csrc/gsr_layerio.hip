@@ -199,7 +199,8 @@ __global__ void __launch_bounds__(kUnfWaves * 64) png_unfilter_kernel(UnfBatch b
 }
 
 // ---- OpenEXR blocks ------------------------------------------------------------------------------------------------------------
-constexpr int kExrThreads = 1024;
+constexpr int kExrThreads = 256;
+constexpr int kExrTile = kExrThreads * 16;     // bytes per step of a workgroup: a 16-byte piece per thread
 
 struct ExrPlan {
     const uint8_t* blocks;   // the inflated blocks one after another, in increasing y
@@ -207,53 +208,72 @@ struct ExrPlan {
     int H, bytes_per_line, lines_per_block, c_at, c_bytes;
 };
 
+// One workgroup per scanline block.  The block is [even bytes of all its lines | odd bytes], each byte the running sum (mod 256) of
+// the stored bytes up to it, + 128 per odd position (the format's bias).  The workgroup walks the block in 4 KB tiles, 16 consecutive
+// bytes per thread (coalesced 16-byte loads): per-thread byte totals, a workgroup scan, the tile's carry; then every thread runs
+// the sum through its 16 bytes and stores those that belong to the wanted channel -- byte k of the first half is byte 2 k of the
+// block's lines, byte k of the second half byte 2 k + 1.
 __global__ void __launch_bounds__(kExrThreads) exr_unpack_channel_kernel(ExrPlan p) {
     __shared__ uint32_t s_wave[kExrThreads / 64];
     const int y0 = blockIdx.x * p.lines_per_block;
     const int lines = min(p.lines_per_block, p.H - y0);
-    const int n = lines * p.bytes_per_line;                            // (even: every pixel type has an even size)
-    const int half = n >> 1;
+    const uint32_t n = (uint32_t)lines * (uint32_t)p.bytes_per_line;       // (even: every pixel type has an even size)
+    const uint32_t half = n >> 1, bpl = (uint32_t)p.bytes_per_line;
     const uint8_t* t = p.blocks + (size_t)y0 * p.bytes_per_line;
-    const int run = ((n + kExrThreads - 1) / kExrThreads + 3) & ~3;    // bytes per thread, whole words
-    const int at = min((int)threadIdx.x * run, n), end = min(at + run, n);
-    // 1: the thread's total.  t'[i] = t[i] + 128 for i > 0 (the format's "- 128" of the predictor, mod 256): added analytically below.
-    uint32_t sum = 0;
-    {
-        int i = at;
-        if ((reinterpret_cast<uintptr_t>(t + i) & 3u) == 0)
-            for (; i + 4 <= end; i += 4) sum = __builtin_amdgcn_sad_u8(*reinterpret_cast<const uint32_t*>(t + i), 0u, sum);
-        for (; i < end; ++i) sum += t[i];
-    }
-    // 2: exclusive scan of the totals over the workgroup
-    uint32_t incl = sum;
+    const bool aligned = (reinterpret_cast<uintptr_t>(t) & 15u) == 0;
+    const uint32_t c_at = (uint32_t)p.c_at, c_end = (uint32_t)(p.c_at + p.c_bytes);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;                                                     // the running sum in front of the tile (mod 256 at use)
+    for (uint32_t tile = 0; tile < n; tile += kExrTile) {
+        const uint32_t at = tile + threadIdx.x * 16u;
+        uint32_t q[4] = {0u, 0u, 0u, 0u};
+        if (at + 16u <= n && aligned) {
+            const uint4 v = *reinterpret_cast<const uint4*>(t + at);
+            q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+        } else if (at < n) {
+            for (uint32_t j = 0; j < 16u && at + j < n; ++j) q[j >> 2] |= (uint32_t)t[at + j] << (8u * (j & 3u));
+        }
+        uint32_t sum = 0;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d, 64);
-        if ((int)(threadIdx.x & 63) >= d) incl += o;
-    }
-    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    uint32_t before = incl - sum;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += s_wave[w];
-    // 3: walk the run again; byte i of the running sum is byte 2 k (+ 1 for the second half) of the block, k = i (- half)
-    if (at >= end) return;
-    const int c_end = p.c_at + p.c_bytes;
-    uint32_t running = before;
-    int i = at;
-    while (i < end) {
-        const int h = i >= half ? 1 : 0;
-        const int stop = h ? end : min(end, half);
-        int off = 2 * (i - h * half) + h;                  // offset of this byte in the de-interleaved block
-        int line = off / p.bytes_per_line;
-        int within = off - line * p.bytes_per_line;
-        for (; i < stop; ++i) {
-            running += t[i];
-            if (within >= p.c_at && within < c_end) {
-                const uint32_t v = running + ((i & 1) ? 128u : 0u);       // + 128 * i mod 256
-                p.plane[(size_t)(y0 + line) * p.c_bytes + (within - p.c_at)] = (uint8_t)v;
+        for (int k = 0; k < 4; ++k) sum = __builtin_amdgcn_sad_u8(q[k], 0u, sum);
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        __syncthreads();                                                    // (s_wave of the previous tile has been read)
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = carry + incl - sum, total = 0;
+#pragma unroll
+        for (int w = 0; w < kExrThreads / 64; ++w) {
+            if (w < wave) before += s_wave[w];
+            total += s_wave[w];
+        }
+        carry += total;
+        if (at >= n) continue;
+        // the thread's bytes: where byte `at` of the block lands in the block's lines
+        uint32_t running = before;
+        uint32_t h = at >= half ? 1u : 0u;
+        uint32_t off = 2u * (at - h * half) + h;
+        uint32_t line = off / bpl, within = off - line * bpl;
+#pragma unroll
+        for (uint32_t j = 0; j < 16u; ++j) {
+            const uint32_t i = at + j;
+            if (i == half && j != 0u) {                                     // the second half starts inside this piece (a short last block)
+                h = 1u;
+                line = 0u;
+                within = 1u;
             }
-            within += 2;
-            if (within >= p.bytes_per_line) { within -= p.bytes_per_line; ++line; }
+            running += (q[j >> 2] >> (8u * (j & 3u))) & 255u;
+            if (i < n && within >= c_at && within < c_end)
+                p.plane[(size_t)(y0 + (int)line) * p.c_bytes + (within - c_at)] = (uint8_t)(running + ((i & 1u) ? 128u : 0u));
+            within += 2u;
+            if (within >= bpl) {
+                within -= bpl;
+                ++line;
+            }
         }
     }
 }

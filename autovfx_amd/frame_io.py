@@ -214,6 +214,30 @@ def png_deflate_scratch(width: int, height: int, channels: int) -> int:
     return int(_lib.lib.gsr_png_deflate_scratch(int(width), int(height), int(channels)))
 
 
+def encode_png_gpu_deflate_queued(image: torch.Tensor, planar: bool = False):
+    """``encode_png_gpu_deflate`` without the host synchronisation: ``(out, length)`` -- the buffer the file is being written into
+    (``png_deflate_room`` bytes) and a device ``int64[1]`` that will hold the file's length -- for callers that copy both out behind
+    the kernels and look at them once their stream has drained."""
+    import ctypes
+    from . import _lib
+    if not (image.is_cuda and image.dtype == torch.uint8 and image.dim() == 3):
+        raise ValueError("encode_png_gpu_deflate expects a uint8 GPU tensor [H,W,C] or [C,H,W]")
+    img = image.contiguous()
+    C, H, W = (int(v) for v in (img.shape if planar else (img.shape[2], img.shape[0], img.shape[1])))
+    room = png_deflate_room(W, H, C)
+    if room == 0:
+        raise ValueError(f"a {W}x{H} image with {C} channels cannot be encoded")
+    out = torch.empty(room, dtype=torch.uint8, device=img.device)
+    scratch = torch.empty(png_deflate_scratch(W, H, C), dtype=torch.uint8, device=img.device)
+    length = torch.zeros(1, dtype=torch.int64, device=img.device)
+    with torch.cuda.device(img.device):
+        rc = _lib.lib.gsr_png_encode_deflate(img.data_ptr(), W, H, C, 1 if planar else 0, out.data_ptr(), scratch.data_ptr(), length.data_ptr(),
+                                             ctypes.c_void_p(torch.cuda.current_stream(img.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"gsr_png_encode_deflate failed ({rc}): {_lib.last_error()}")
+    return out[:png_deflate_max_size(W, H, C)], length
+
+
 def encode_png_gpu_deflate(image: torch.Tensor, planar: bool = False) -> torch.Tensor:
     """``encode_png_gpu`` with a compressed IDAT (``gsr_png_encode_deflate``: Paeth filter, run-length matches, one Huffman code per
     image built on the GPU).  The file's length depends on the image, so this convenience form reads it back (one host
