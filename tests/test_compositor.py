@@ -1,7 +1,9 @@
 """Compositor: the numpy oracle against the reference's own blend_frames (run on synthetic layers with its
 file loaders monkey-patched), then the HIP kernel against the oracle."""
 import importlib
+import json
 import os
+import struct
 import sys
 import types
 
@@ -287,6 +289,49 @@ def test_blend_frames_drop_in_on_a_directory_tree(tmp_path, variant):
     for path, Li in zip(paths, per_frame):
         got = np.array(Image.open(path))
         np.testing.assert_array_equal(got, oracle_from_blender_layers(Li, hw), err_msg=path)
+
+
+@pytest.mark.gpu
+def test_blend_frames_hands_the_frames_to_the_video_writer_and_survives_its_fallbacks(tmp_path, monkeypatch):
+    """The branches a plain run does not take: with ``imageio`` / ``skimage`` importable (doubles here) every frame also comes back to
+    the host, in order, for ``blended.mp4`` (blend_all.py:31-54); more pool threads than frames; the EXR streams inflated by zlib on
+    the host (``AUTOVFX_AMD_EXR_INFLATE=host``) and a depth pass the GPU's decoder refuses (the frame is read again on the host) give
+    the same frames."""
+    from PIL import Image
+    from autovfx_amd import compositor
+    hw = (54, 96)
+    L = blender_layers(hw, (2, 2), seed=7, with_3dgs=True, with_smoke=True, with_fire=True)
+    results, cfg, per_frame = write_blender_tree(tmp_path, L, hw, frames=7, half=True, compression="ZIP")
+    want = [oracle_from_blender_layers(Li, hw) for Li in per_frame]
+    seen = {}
+    imageio, v2, skimage, transform = (types.ModuleType(n) for n in ("imageio", "imageio.v2", "skimage", "skimage.transform"))
+    v2.mimsave = lambda path, series, fps, macro_block_size: seen.update(path=path, series=[np.array(f) for f in series], fps=fps)
+    transform.resize = lambda frame, shape: frame.astype(np.float64) / 255.0 if tuple(frame.shape[:2]) == tuple(shape) else None
+    imageio.v2, skimage.transform = v2, transform
+    for name, mod in (("imageio", imageio), ("imageio.v2", v2), ("skimage", skimage), ("skimage.transform", transform)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    monkeypatch.setenv("AUTOVFX_AMD_BLEND_DECODERS", "12")                      # more threads than frames
+    paths = compositor.blend_frames(str(results), str(cfg))
+    assert seen["path"].endswith("blended.mp4") and seen["fps"] == 15 and len(seen["series"]) == 7
+    for k, (path, frame) in enumerate(zip(paths, seen["series"])):
+        np.testing.assert_array_equal(np.array(Image.open(path)), want[k], err_msg=path)
+        np.testing.assert_array_equal(frame, want[k], err_msg=f"video frame {k}")
+    monkeypatch.setenv("AUTOVFX_AMD_BLEND_DECODERS", "2")
+    monkeypatch.setenv("AUTOVFX_AMD_EXR_INFLATE", "host")
+    for path, w in zip(compositor.blend_frames(str(results), str(cfg), write_video=False), want):
+        np.testing.assert_array_equal(np.array(Image.open(path)), w, err_msg=path + " (host inflate)")
+    # a flipped bit inside the first zlib stream of frame 3's object depth pass: the GPU's decoder refuses it; zlib on the host does too,
+    # and the file then goes the way of every file the kernels do not cover -- the host reader, which raises
+    monkeypatch.setenv("AUTOVFX_AMD_EXR_INFLATE", "gpu")
+    cache = os.path.join(json.load(open(cfg))["blender_cache_dir"], json.load(open(cfg))["output_dir_name"])
+    victim = os.path.join(cache, "depth_obj", "004", "Image0004.exr")
+    from autovfx_amd import exr
+    buf = bytearray(open(victim, "rb").read())
+    first = struct.unpack_from("<Q", buf, exr.read_header(bytes(buf))["offsets_at"])[0]
+    buf[first + 8 + 12] ^= 0x20
+    open(victim, "wb").write(bytes(buf))
+    with pytest.raises(Exception):
+        compositor.blend_frames(str(results), str(cfg), write_video=False)
 
 
 @needs_reference
