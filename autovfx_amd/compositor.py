@@ -382,6 +382,7 @@ def blend_frames(blend_results_dir, input_config_path=None, device=None, write_v
         t.start()
     for t in threads:
         t.join()
+    torch.cuda.empty_cache()       # (the workers' streams are gone: what the allocator cached for them would never be handed out again)
     if job["error"] is not None:
         raise job["error"]
     host_frames = [job["host_frames"][i] for i in range(n_frame)] if video is not None else []
