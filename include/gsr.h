@@ -42,6 +42,9 @@
 extern "C" {
 #endif
 
+/* 14 (round 6): + the compositor's input files -- gsr_png_unfilter(_batch), gsr_exr_unpack_channel, gsr_inflate_zlib_blocks, the host-side
+ * gsr_png_file_* / gsr_exr_file_* readers, gsr_upload.  13: + compressed frame files (gsr_png_encode_deflate, gsr_frame_files_deflate).
+ * Additions only: a binding written against 12 works unchanged apart from the version it checks. */
 #define GSR_ABI_VERSION 14
 
 #if defined(__GNUC__)
@@ -296,7 +299,7 @@ GSR_API int gsr_resize_rgba8_bilinear(const uint8_t* src, int src_width, int src
 GSR_API int gsr_resize_f32_nearest(const float* src, int src_width, int src_height, float* dst, int dst_width, int dst_height,
                                    void* stream);
 
-/* The compositor's input FILES (blender/blend_all.py:56-75,185-205: load_rgb -- Image.open(path).convert("RGBA") -- for six PNG layers
+/* ABI 14.  The compositor's input FILES (blender/blend_all.py:56-75,185-205: load_rgb -- Image.open(path).convert("RGBA") -- for six PNG layers
  * and load_depth_exr -- cv2.imread(path, ANYCOLOR | ANYDEPTH)[:, :, 0] -- for four OpenEXR depth passes per frame, at Blender's
  * resolution).  Inflating a file's zlib stream(s) stays with the caller (zlib: byte-serial, one stream per PNG / per EXR block);
  * what is left -- undoing the image predictor -- runs here, on what the caller uploads (gsr_upload: hipMemcpyAsync from any host
