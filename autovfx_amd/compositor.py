@@ -383,6 +383,8 @@ def blend_frames(blend_results_dir, input_config_path=None, device=None, write_v
     for t in threads:
         t.join()
     torch.cuda.empty_cache()       # (the workers' streams are gone: what the allocator cached for them would never be handed out again)
+    if hasattr(torch._C, "_host_emptyCache"):
+        torch._C._host_emptyCache()                 # ... and their page-locked staging (~100 MB per worker)
     if job["error"] is not None:
         raise job["error"]
     host_frames = [job["host_frames"][i] for i in range(n_frame)] if video is not None else []

@@ -57,7 +57,10 @@ class Staging:
             self._grow(nbytes)
 
     def _grow(self, nbytes):
-        self._blocks.append(torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, pin_memory=torch.cuda.is_available()))
+        # page-locking memory is slow (and every block is locked again when reset() joins them): the first block of a pinned arena
+        # holds a frame's worth of 1080p layers, so that a frame usually means ONE allocation
+        pinned = torch.cuda.is_available()
+        self._blocks.append(torch.empty(max(int(nbytes), (64 << 20) if pinned else (1 << 20)), dtype=torch.uint8, pin_memory=pinned))
         self._at, self._room = 0, self._blocks[-1].numel()
 
     def take(self, nbytes: int) -> torch.Tensor:
